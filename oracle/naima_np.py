@@ -1,0 +1,694 @@
+"""CPU oracle for the naima radiative-likelihood hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a unit-free NumPy restatement of the reference algorithm
+(zblz/naima, /root/reference).  It exists to *check* the HIP kernels; nothing in
+``naima_amd/`` may import it.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` use it.
+
+Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the
+reference's own ``radiative.py / models.py / utils.py / core.py`` (script:
+``tests/golden/gen_golden.py``) and ``tests/test_oracle.py`` checks this file
+against (i) those per-energy vectors and (ii) the known-answer luminosities of
+the reference's ``tests/test_models.py``.  The ensemble move (emcee, third
+party, not in the reference tree, not installed) is restated from its published
+algorithm and is "parity unpinned" -- see ``stretch_move_reference``.
+
+Conventions (all float64, no unit objects):
+  photon energies      eV
+  electron grid        Lorentz factor  gamma (dimensionless)
+  proton grid          total energy, GeV
+  particle spectra     dN/dE in 1/eV, evaluated at energies in eV
+  spectra returned     1/(s eV)   (intrinsic; divide by 4 pi d^2 for flux)
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/src/naima/).
+"""
+import warnings
+
+import numpy as np
+
+# ---------------------------------------------------------------------------
+# constants: astropy CODATA-2018 values as used by the reference
+# (radiative.py:11,34-40; measured by importing the reference)
+# ---------------------------------------------------------------------------
+E_GAUSS = 4.803204712570263e-10  # electron charge, esu
+C_CGS = 29979245800.0
+HBAR_CGS = 1.0545718176461565e-27
+M_E_G = 9.1093837015e-28
+ALPHA_FS = 0.0072973525693
+MEC2_ERG = 8.187105776823886e-07
+MEC2_EV = 510998.9499961643
+AR_CGS = 7.565733250280007e-15  # radiation constant erg cm-3 K-4
+R0_CM = 2.817940324670788e-13
+ERG_PER_EV = 1.602176634e-12
+M_P_GEV = 0.9382720881604903
+KPC_CM = 3.0856775814913673e21
+PC_CM = 3.085677581491367e18
+
+M_PI_GEV = 0.1349766  # radiative.py:1212
+T_TH_GEV = 0.27966184  # radiative.py:1213
+
+
+# ---------------------------------------------------------------------------
+# row 1: the quadrature  (utils.py:285-355)
+# ---------------------------------------------------------------------------
+def trapz_loglog(y, x, axis=-1, intervals=False):
+    """Power-law-exact trapezoid in log-log space, utils.py:285-355.
+
+    Per segment: b = log10(y2/y1)/log10(x2/x1) (utils.py:336); the term is
+    y1*(x2*(x2/x1)**b - x1)/(b+1) when |b+1| > 1e-10, else x1*y1*ln(x2/x1)
+    (utils.py:340-345).  A NaN ``b`` (sign change / negative y) fails the ``>``
+    test and therefore takes the log branch.  Segments with a zero node or a
+    repeated abscissa contribute 0 (utils.py:347-348).
+    """
+    y = np.asanyarray(y, dtype=float)
+    x = np.asanyarray(x, dtype=float)
+    y = np.moveaxis(y, axis, -1)
+    if x.ndim != 1:
+        x = np.moveaxis(x, axis, -1)
+    y1, y2 = y[..., :-1], y[..., 1:]
+    x1, x2 = x[..., :-1], x[..., 1:]
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        b = np.log10(y2 / y1) / np.log10(x2 / x1)
+        plaw = (y1 * (x2 * (x2 / x1) ** b - x1)) / (b + 1)
+        logb = x1 * y1 * np.log(x2 / x1)
+        seg = np.where(np.abs(b + 1.0) > 1e-10, plaw, logb)
+    kill = (y1 == 0.0) | (y2 == 0.0) | (x1 == x2)
+    seg = np.where(kill, 0.0, seg)
+    if intervals:
+        return np.moveaxis(seg, -1, axis)
+    # the reference reduces with np.add.reduce along `axis` (utils.py:353);
+    # summation order differs only at the 1e-16 level
+    return seg.sum(axis=-1)
+
+
+# ---------------------------------------------------------------------------
+# row 2: particle distributions (models.py eval statics)
+# ---------------------------------------------------------------------------
+PD_KINDS = ("PowerLaw", "ExponentialCutoffPowerLaw", "BrokenPowerLaw",
+            "ExponentialCutoffBrokenPowerLaw", "LogParabola")
+
+
+def pdist_eval(kind, e, **p):
+    """dN/dE at energies ``e`` (eV); all energy parameters in eV.
+
+    PowerLaw models.py:88-92; ECPL 157-161; BPL 234-238; ECBPL 330-335;
+    LogParabola 402-407.
+    """
+    e = np.asarray(e, dtype=float)
+    A = p["amplitude"]
+    with np.errstate(all="ignore"):
+        if kind == "PowerLaw":
+            return A * (e / p["e_0"]) ** (-p["alpha"])
+        if kind == "ExponentialCutoffPowerLaw":
+            return (A * (e / p["e_0"]) ** (-p["alpha"])
+                    * np.exp(-((e / p["e_cutoff"]) ** p.get("beta", 1.0))))
+        if kind in ("BrokenPowerLaw", "ExponentialCutoffBrokenPowerLaw"):
+            below = e < p["e_break"]
+            K = np.where(below, 1.0, (p["e_break"] / p["e_0"]) ** (p["alpha_2"] - p["alpha_1"]))
+            idx = np.where(below, p["alpha_1"], p["alpha_2"])
+            out = A * K * (e / p["e_0"]) ** -idx
+            if kind == "ExponentialCutoffBrokenPowerLaw":
+                out = out * np.exp(-((e / p["e_cutoff"]) ** p.get("beta", 1.0)))
+            return out
+        if kind == "LogParabola":
+            ee = e / p["e_0"]
+            return A * ee ** (-p["alpha"] - p["beta"] * np.log(ee))
+    raise ValueError("unknown particle distribution kind: %r" % (kind,))
+
+
+class ParticleDist:
+    """(kind, params) bundle; amplitude in 1/eV, energies in eV."""
+
+    def __init__(self, kind, **params):
+        self.kind = kind
+        self.params = params
+
+    def __call__(self, e_eV):
+        return pdist_eval(self.kind, e_eV, **self.params)
+
+
+# ---------------------------------------------------------------------------
+# row 3: grids, nelec/J, We/Wp
+# ---------------------------------------------------------------------------
+def log_grid(lo, hi, per_decade):
+    """np.logspace(log10 lo, log10 hi, max(10, int(per_decade*dlog10)))
+    radiative.py:147-154 (electrons, lo/hi = E/mec2) and 1002-1009 (protons,
+    lo/hi in GeV)."""
+    l0, l1 = np.log10(lo), np.log10(hi)
+    return np.logspace(l0, l1, max(10, int(per_decade * (l1 - l0))))
+
+
+def electron_grid(Eemin_eV, Eemax_eV, nEed):
+    return log_grid(Eemin_eV / MEC2_EV, Eemax_eV / MEC2_EV, nEed)
+
+
+def proton_grid(Epmin_GeV, Epmax_GeV, nEpd):
+    """radiative.py:1002-1009; note the count uses log10(Epmax/Epmin)."""
+    return np.logspace(np.log10(Epmin_GeV), np.log10(Epmax_GeV),
+                       max(10, int(nEpd * np.log10(Epmax_GeV / Epmin_GeV))))
+
+
+def nelec_on(pd, gam):
+    """electrons per unit Lorentz factor, radiative.py:156-160."""
+    return pd(gam * MEC2_EV) * MEC2_EV
+
+
+def J_on(pd, Ep_GeV):
+    """protons per GeV, radiative.py:1011-1015."""
+    return pd(Ep_GeV * 1e9) * 1e9
+
+
+def electron_energy_content(pd, gam):
+    """We in erg = trapz_loglog(gam*nelec, gam*mec2), radiative.py:162-195."""
+    return trapz_loglog(gam * nelec_on(pd, gam), gam * MEC2_ERG)
+
+
+def proton_energy_content(pd, Ep_GeV):
+    """Wp in erg, radiative.py:1017-1055."""
+    return trapz_loglog(Ep_GeV * J_on(pd, Ep_GeV), Ep_GeV) * (1e9 * ERG_PER_EV)
+
+
+# ---------------------------------------------------------------------------
+# row 5: synchrotron (radiative.py:282-342)
+# ---------------------------------------------------------------------------
+def gtilde(x):
+    """AKP10 Eq. D7 with a single cube root, radiative.py:300-311."""
+    cb = np.cbrt(x)
+    cb2 = cb * cb
+    cb4 = cb2 * cb2
+    g1 = 1.808 * cb / np.sqrt(1 + 3.4 * cb2)
+    g2 = 1 + 2.210 * cb2 + 0.347 * cb4
+    g3 = 1 + 1.353 * cb2 + 0.217 * cb4
+    return g1 * (g2 / g3) * np.exp(-x)
+
+
+def synchrotron_spectrum(E_eV, gam, nelec, B_G):
+    """Intrinsic synchrotron spectrum 1/(s eV); radiative.py:319-340."""
+    E_erg = np.asarray(E_eV, dtype=float) * ERG_PER_EV
+    cs1 = (np.sqrt(3) * E_GAUSS ** 3 * B_G) / (
+        2 * np.pi * M_E_G * C_CGS ** 2 * HBAR_CGS * E_erg)
+    Ec = 3 * E_GAUSS * HBAR_CGS * B_G * gam ** 2
+    Ec = Ec / (2 * (M_E_G * C_CGS))
+    with np.errstate(all="ignore"):
+        dNdE = cs1[None, :] * gtilde(E_erg[None, :] / Ec[:, None])
+        spec = trapz_loglog(nelec[:, None] * dNdE, gam, axis=0)  # 1/(s erg)
+    return spec * ERG_PER_EV
+
+
+# ---------------------------------------------------------------------------
+# rows 6-8: inverse Compton
+# ---------------------------------------------------------------------------
+_PI26 = np.pi ** 2 / 6.0
+K_TO_MEC2 = 1.6863699549e-10  # literal, radiative.py:557
+IC_PLANCK_NORM = 2.6318735743809104e16  # literal, radiative.py:571
+SIGT_LIT = 6.652458734983284e-25  # literal, radiative.py:650
+C_LIT = 29979245800.0  # literal, radiative.py:651
+
+
+def G12(x, a):
+    """Khangulyan+14 Eqs 20,24,25; radiative.py:345-354."""
+    al, aa, be, bb = a
+    G = (_PI26 + x) * np.exp(-x)
+    g = 1.0 / (aa * x ** al / (1 + bb * x ** be) + 1.0)
+    return G * g
+
+
+def G34(x, a):
+    """radiative.py:357-367."""
+    al, aa, be, bb, cc = a
+    G = _PI26 * ((1 + cc * x) / (1 + _PI26 * cc * x)) * np.exp(-x)
+    g = 1.0 / (aa * x ** al / (1 + bb * x ** be) + 1.0)
+    return G * g
+
+
+A3 = (0.606, 0.443, 1.481, 0.540, 0.319)
+A4 = (0.461, 0.726, 1.457, 0.382, 6.620)
+A1 = (0.857, 0.153, 1.840, 0.254)
+A2 = (0.691, 1.330, 1.668, 0.534)
+
+
+def ic_planck_kernel(gam, T_K, Eph_mec2, theta=None):
+    """(n_E, n_gam) matrix of Khangulyan+14 Eq. 14 (isotropic, theta None) or
+    Eq. 11 (anisotropic); radiative.py:547-607."""
+    Tp = T_K * K_TO_MEC2
+    eg = np.asarray(Eph_mec2, dtype=float)[:, None]
+    g = np.asarray(gam, dtype=float)[None, :]
+    with np.errstate(all="ignore"):
+        z = eg / g
+        if theta is None:
+            x = z / (1 - z) / (4.0 * g * Tp)
+            cs = z ** 2 / (2 * (1 - z)) * G34(x, A3) + G34(x, A4)
+        else:
+            tt = 2.0 * g * Tp * (1.0 - np.cos(theta))
+            x = z / (1 - z) / tt
+            cs = z ** 2 / (2 * (1 - z)) * G12(x, A1) + G12(x, A2)
+        pref = (Tp / g) ** 2
+        pref = pref * IC_PLANCK_NORM
+        cs = pref * cs
+    ok = (eg < g) & (g > 1)
+    return np.where(ok, cs, 0.0)
+
+
+def heaviside(x):
+    """radiative.py:1539-1540 (value 1/2 at 0)."""
+    return (np.sign(x) + 1) / 2.0
+
+
+def ic_seed_array_kernel(gam, seedE_eV, seed_density, Eph_mec2):
+    """Aharonian&Atoyan81 Eq.22 kernel, radiative.py:609-655.
+
+    seedE_eV: array of seed photon energies (eV).  seed_density: for size>1
+    the differential photon density 1/(eV cm3); for size 1 the energy density
+    eV/cm3.  Returns the (n_E, n_gam) matrix in 1/s.
+    """
+    e0 = (np.atleast_1d(np.asarray(seedE_eV, dtype=float)) / MEC2_EV)[:, None, None]
+    phn = np.atleast_1d(np.asarray(seed_density, dtype=float))[:, None, None]
+    g = np.asarray(gam, dtype=float)[None, None, :]
+    eg = np.asarray(Eph_mec2, dtype=float)[None, :, None]
+    with np.errstate(all="ignore"):
+        b = 4 * e0 * g
+        w = eg / g
+        q = w / (b * (1 - w))
+        fic = (2 * q * np.log(q) + (1 + 2 * q) * (1 - q)
+               + 0.5 * (b * q) ** 2 * (1 - q) / (1 + b * q))
+        gi = fic * heaviside(1 - q) * heaviside(q - 1.0 / (4 * g ** 2))
+        gi = np.where(np.isnan(gi), 0.0, gi)
+        if phn.size > 1:
+            dens = phn * MEC2_EV  # 1/(eV cm3) -> 1/(mec2 cm3), radiative.py:639
+            gi = trapz_loglog(gi * dens / e0, e0[:, 0, 0], axis=0)
+        else:
+            dens = phn / MEC2_EV  # eV/cm3 -> mec2/cm3, radiative.py:642
+            gi = (gi * (dens / e0 ** 2))[0]
+        gi = gi * ((3.0 / 4.0) * SIGT_LIT * C_LIT / g[0] ** 2)
+    return gi
+
+
+def ic_seed_spectrum(E_eV, gam, nelec, seed):
+    """One seed's spectrum 1/(s eV), radiative.py:657-687.
+
+    seed: dict(type='thermal', T=K, u=erg/cm3, theta=None|rad) or
+          dict(type='array', energy=eV array, density=array (see above)).
+    """
+    E_eV = np.asarray(E_eV, dtype=float)
+    Eph = E_eV / MEC2_EV
+    if seed["type"] == "thermal":
+        T = seed["T"]
+        uf = seed["u"] / (AR_CGS * T ** 4)
+        K = ic_planck_kernel(gam, T, Eph, seed.get("theta"))
+    else:
+        uf = 1.0
+        K = ic_seed_array_kernel(gam, seed["energy"], seed["density"], Eph)
+    lum = uf * Eph * trapz_loglog(nelec[None, :] * K, gam)
+    return lum / E_eV
+
+
+def ic_spectrum(E_eV, gam, nelec, seeds):
+    """Sum over seeds after integrating each, radiative.py:689-710."""
+    per = [ic_seed_spectrum(E_eV, gam, nelec, s) for s in seeds]
+    return np.sum(per, axis=0), per
+
+
+def thermal_seed(name):
+    """Default GALPROP-like fields, radiative.py:438-467 (u in erg/cm3)."""
+    if name == "CMB":
+        T = 2.72548
+        return dict(type="thermal", T=T, u=AR_CGS * T ** 4, theta=None)
+    if name == "FIR":
+        return dict(type="thermal", T=30.0, u=0.5 * ERG_PER_EV, theta=None)
+    if name == "NIR":
+        return dict(type="thermal", T=3000.0, u=1.0 * ERG_PER_EV, theta=None)
+    raise TypeError(name)
+
+
+# ---------------------------------------------------------------------------
+# row 10: bremsstrahlung (radiative.py:838-989), cross sections in cm2/mec2
+# ---------------------------------------------------------------------------
+GAM_TRANS = 2e6 / MEC2_EV  # 2 MeV, radiative.py:914
+
+
+def brems_sigma_1(g, eps):
+    """Baring+99 A2, radiative.py:838-849."""
+    s1 = 4 * R0_CM ** 2 * ALPHA_FS / eps
+    s2 = 1 + (1.0 / 3.0 - eps / g) * (1 - eps / g)
+    s3 = np.log(2 * g * (g - eps) / eps) - 0.5
+    s3 = np.where(g < eps, 0.0, s3)
+    return s1 * s2 * s3
+
+
+def brems_sigma_2(g, eps):
+    """Baring+99 A3, radiative.py:851-871."""
+    s0 = R0_CM ** 2 * ALPHA_FS / (3 * eps)
+    a = (16 * (1 - eps + eps ** 2) * np.log(g / eps)
+         + (-1 / eps ** 2 + 3 / eps - 4 - 4 * eps - 8 * eps ** 2)
+         + (-2 * (1 - 2 * eps) * np.log(1 - 2 * eps))
+         * (1 / (4 * eps ** 3) - 1 / (2 * eps ** 2) + 3 / eps - 2 + 4 * eps))
+    b = (2 / eps) * ((4 - 1 / eps + 1 / (4 * eps ** 2)) * np.log(2 * g)
+                     + (-2 + 2 / eps - 5 / (8 * eps ** 2)))
+    return s0 * np.where(eps <= 0.5, a, b) * heaviside(g - eps)
+
+
+def brems_sigma_ee_rel(g, eps):
+    """Baring+99 A1,A4, radiative.py:873-880."""
+    A = 1 - 8 / 3 * (g - 1) ** 0.2 / (g + 1) * (eps / g) ** (1.0 / 3.0)
+    return (brems_sigma_1(g, eps) + brems_sigma_2(g, eps)) * A
+
+
+def brems_F(x, g):
+    """Baring+99 A6,A7, radiative.py:882-896."""
+    beta = np.sqrt(1 - g ** -2.0)
+    B = 1 + 0.5 * (g ** 2 - 1)
+    C = 10 * x * g * beta * (2 + g * beta)
+    C = C / (1 + x ** 2 * (g ** 2 - 1))
+    F1 = (17 - 3 * x ** 2 / (2 - x) ** 2 - C) * np.sqrt(1 - x)
+    F2 = 12 * (2 - x) - 7 * x ** 2 / (2 - x) - 3 * x ** 4 / (2 - x) ** 3
+    F3 = np.log((1 + np.sqrt(1 - x)) / np.sqrt(x))
+    return B * F1 + F2 * F3
+
+
+def brems_sigma_ee_nonrel(g, eps):
+    """Baring+99 A5, radiative.py:898-908."""
+    s0 = 4 * R0_CM ** 2 * ALPHA_FS / (15 * eps)
+    x = 4 * eps / (g ** 2 - 1)
+    s = s0 * brems_F(x, g)
+    s = np.where(eps >= 0.25 * (g ** 2 - 1.0), 0.0, s)
+    s = np.where(g * np.ones_like(eps) < 1.0, 0.0, s)
+    return s
+
+
+def brems_sigma_ee(g, eps):
+    """radiative.py:910-928 (g: (n_gam,1), eps: (n_E,)) -> cm2/mec2."""
+    with np.errstate(all="ignore"):
+        nonrel = brems_sigma_ee_nonrel(g, eps)
+        rel = brems_sigma_ee_rel(g, eps)
+    return np.where(g * np.ones_like(eps) <= GAM_TRANS, nonrel, rel)
+
+
+def brems_spectrum(E_eV, gam, nelec, n0=1.0, weight_ee=None, weight_ep=None):
+    """radiative.py:940-989; result 1/(s eV)."""
+    if weight_ee is None or weight_ep is None:
+        Y = np.array([1.0, 9.59e-2])
+        Z = np.array([1, 2])
+        X = Y / np.sum(Y)
+        weight_ee = np.sum(Z * X) if weight_ee is None else weight_ee
+        weight_ep = np.sum(Z ** 2 * X) if weight_ep is None else weight_ep
+    E_eV = np.asarray(E_eV, dtype=float)
+    eps = E_eV / MEC2_EV
+    g = gam[:, None]
+    with np.errstate(all="ignore"):
+        if weight_ee == 0.0:
+            ee = np.zeros_like(E_eV)
+        else:
+            see = brems_sigma_ee(g, eps) / MEC2_EV  # cm2/eV
+            ee = C_CGS * trapz_loglog(nelec[:, None] * see, gam, axis=0)
+        if weight_ep == 0.0:
+            ep = np.zeros_like(E_eV)
+        else:
+            sep = brems_sigma_1(g, eps) / MEC2_EV
+            ep = C_CGS * trapz_loglog(nelec[:, None] * sep, gam, axis=0)
+    return n0 * (weight_ee * ee + weight_ep * ep)
+
+
+# ---------------------------------------------------------------------------
+# row 9: pi0 decay, Kafexhiu+14 (radiative.py:1099-1536)
+# ---------------------------------------------------------------------------
+PP_A = {"Geant4": (0.728, 0.596, 0.491, 0.2503, 0.117),
+        "Pythia8": (0.652, 0.0016, 0.488, 0.1928, 0.483),
+        "SIBYLL": (5.436, 0.254, 0.072, 0.075, 0.166),
+        "QGSJET": (0.908, 0.0009, 6.089, 0.176, 0.448)}  # radiative.py:1179-1183
+PP_FHI = {"Geant4": (3.0, 0.5, 4.9, 1.0), "Pythia8": (3.5, 0.5, 4.0, 1.0),
+          "SIBYLL": (3.55, 0.5, 3.6, 1.0), "QGSJET": (3.55, 0.5, 4.5, 1.0)}  # 1194-1197
+PP_B = {"Geant4_0": (9.53, 0.52, 0.054), "Geant4": (9.13, 0.35, 9.7e-3),
+        "Pythia8": (9.06, 0.3795, 0.01105), "SIBYLL": (10.77, 0.412, 0.01264),
+        "QGSJET": (13.16, 0.4419, 0.01439)}  # 1200-1205
+PP_ETRANS = {"Pythia8": 50.0, "SIBYLL": 100.0, "QGSJET": 100.0, "Geant4": 100.0}  # 1209
+
+
+def pp_sigma_inel(Tp):
+    """Kafexhiu+14 Eq.1, radiative.py:1215-1233 (cm2)."""
+    L = np.log(Tp / T_TH_GEV)
+    s = 30.7 - 0.96 * L + 0.18 * L ** 2
+    s = s * (1 - (T_TH_GEV / Tp) ** 1.9) ** 3
+    return s * 1e-27
+
+
+def _pp_sigma_pi_lo(Tp):
+    """radiative.py:1235-1266."""
+    mp, mpi = M_P_GEV, M_PI_GEV
+    Mres, Gres = 1.1883, 0.2264
+    s = 2 * mp * (Tp + 2 * mp)
+    gamma = np.sqrt(Mres ** 2 * (Mres ** 2 + Gres ** 2))
+    K = np.sqrt(8) * Mres * Gres * gamma
+    K = K / (np.pi * np.sqrt(Mres ** 2 + gamma))
+    fBW = mp * K
+    fBW = fBW / (((np.sqrt(s) - mp) ** 2 - Mres ** 2) ** 2 + Mres ** 2 * Gres ** 2)
+    mu = np.sqrt((s - mpi ** 2 - 4 * mp ** 2) ** 2 - 16 * mpi ** 2 * mp ** 2)
+    mu = mu / (2 * mpi * np.sqrt(s))
+    s1 = 7.66e-3 * mu ** 1.95 * (1 + mu + mu ** 5) * fBW ** 1.86
+    s2 = 5.7 / (1 + np.exp(-9.3 * (Tp - 1.4)))
+    s2 = np.where(Tp < 0.56, 0.0, s2)
+    return (s1 + s2) * 1e-27
+
+
+def _pp_sigma_pi_mid(Tp):
+    """radiative.py:1268-1275."""
+    Qp = (Tp - T_TH_GEV) / M_P_GEV
+    return pp_sigma_inel(Tp) * (-6e-3 + 0.237 * Qp - 0.023 * Qp ** 2)
+
+
+def _pp_sigma_pi_hi(Tp, a):
+    """radiative.py:1277-1286."""
+    csip = (Tp - 3.0) / M_P_GEV
+    m1 = a[0] * csip ** a[3] * (1 + np.exp(-a[1] * csip ** a[4]))
+    m2 = 1 - np.exp(-a[2] * csip ** 0.25)
+    return pp_sigma_inel(Tp) * (m1 * m2)
+
+
+def pp_sigma_pi(Tp, hiE):
+    """piecewise inclusive pi0 cross-section, radiative.py:1288-1304."""
+    Et = PP_ETRANS[hiE]
+    with np.errstate(all="ignore"):
+        return np.select(
+            [Tp < 2.0, Tp < 5.0, Tp < Et],
+            [_pp_sigma_pi_lo(Tp), _pp_sigma_pi_mid(Tp), _pp_sigma_pi_hi(Tp, PP_A["Geant4"])],
+            _pp_sigma_pi_hi(Tp, PP_A[hiE]))
+
+
+def pp_EpimaxLAB(Tp):
+    """radiative.py:1325-1336."""
+    mp, mpi = M_P_GEV, M_PI_GEV
+    s = 2 * mp * (Tp + 2 * mp)
+    EpiCM = (s - 4 * mp ** 2 + mpi ** 2) / (2 * np.sqrt(s))
+    PpiCM = np.sqrt(EpiCM ** 2 - mpi ** 2)
+    gCM = (Tp + 2 * mp) / np.sqrt(s)
+    betaCM = np.sqrt(1 - gCM ** -2.0)
+    return gCM * (EpiCM + PpiCM * betaCM)
+
+
+def pp_Egmax(Tp):
+    """radiative.py:1338-1345."""
+    gpi = pp_EpimaxLAB(Tp) / M_PI_GEV
+    bpi = np.sqrt(1 - gpi ** -2.0)
+    return (M_PI_GEV / 2) * gpi * (1 + bpi)
+
+
+def pp_Amax(Tp, hiE):
+    """radiative.py:1306-1367."""
+    Et = PP_ETRANS[hiE]
+    b1, b2, b3 = [np.select([Tp < 5.0, Tp < Et],
+                            [PP_B["Geant4_0"][j], PP_B["Geant4"][j]], PP_B[hiE][j])
+                  for j in range(3)]
+    with np.errstate(all="ignore"):
+        spi = pp_sigma_pi(Tp, hiE)
+        lo = 5.9 * spi / pp_EpimaxLAB(Tp)
+        th = Tp / M_P_GEV
+        hi = b1 * th ** -b2 * np.exp(b3 * np.log(th) ** 2) * spi / M_P_GEV
+    return np.where(Tp < 1.0, lo, hi)
+
+
+def pp_F(Tp, Eg, hiE):
+    """Spectral shape, radiative.py:1369-1438: the Tp ranges are applied in
+    order so that ``Tp > Etrans`` overrides the (20,100] Geant4 range."""
+    Tp = np.asarray(Tp, dtype=float)
+    Et = PP_ETRANS[hiE]
+    with np.errstate(all="ignore"):
+        th = Tp / M_P_GEV
+        kappa = 3.29 - th ** -1.5 / 5.0  # 1386-1388
+        q = (Tp - 1.0) / M_P_GEV
+        mu = 1.25 * q ** 1.25 * np.exp(-1.25 * q)  # 1390-1393
+        c_exp = (Tp >= T_TH_GEV) & (Tp <= 1.0)
+        c_g0 = (Tp > 1.0) & (Tp <= 4.0)
+        c_g1 = (Tp > 4.0) & (Tp <= 20.0)
+        c_g2 = (Tp > 20.0) & (Tp <= 100.0)
+        c_hi = Tp > Et
+        hiP = PP_FHI[hiE]
+        # later ranges override earlier ones -> test them last-to-first
+        conds = [c_hi, c_g2, c_g1, c_g0, c_exp]
+        lam = np.select(conds, [hiP[0], 3.0, 3.0, 3.0, 1.0], np.nan)
+        alp = np.select(conds, [hiP[1], 0.5, 1.0, 1.0, 1.0], np.nan)
+        bet = np.select(conds, [hiP[2], 4.2, 1.5 * mu + 4.95, mu + 2.45, kappa], np.nan)
+        gam = np.select(conds, [hiP[3], 1.0, mu + 1.50, mu + 1.45, 0.0], np.nan)
+        # Eq 9-11, radiative.py:1369-1384
+        Egmax = pp_Egmax(Tp)
+        Yg = Eg + M_PI_GEV ** 2 / (4 * Eg)
+        Ygmax = Egmax + M_PI_GEV ** 2 / (4 * Egmax)
+        Xg = (Yg - M_PI_GEV) / (Ygmax - M_PI_GEV)
+        Xg = np.where(Xg > 1, 1.0, Xg)
+        C = lam * M_PI_GEV / Ygmax
+        F = (1 - Xg ** alp) ** bet
+        F = F / (1 + Xg / C) ** gam
+    inrange = c_hi | c_g2 | c_g1 | c_g0 | c_exp
+    return np.where(inrange, F, 0.0)
+
+
+def pp_nuclear_factor(Tp):
+    """radiative.py:1455-1482."""
+    sRpp = 10 * np.pi * 1e-27
+    with np.errstate(all="ignore"):
+        sin = pp_sigma_inel(Tp)
+        f = sin / pp_sigma_inel(1e3)
+        G = 1.0 + np.log(np.where(f > 1, f, 1.0))
+        eps = np.where(Tp > T_TH_GEV, 1.37 + (0.29 + 0.1) * sRpp * G / sin, 0.0)
+    if np.any(Tp < 1.0):
+        eps = np.where((Tp > T_TH_GEV) & (Tp < 1.0), 1.9141, eps)
+    return eps
+
+
+def pp_diffsigma(Ep_GeV, Eg_GeV, hiE="Pythia8", nuclear_enhancement=True):
+    """dsigma/dEgamma = Amax*F [*eps], cm2/GeV; radiative.py:1440-1453.
+    Ep_GeV: (n_p,), Eg_GeV: scalar."""
+    Tp = np.asarray(Ep_GeV, dtype=float) - M_P_GEV
+    ds = pp_Amax(Tp, hiE) * pp_F(Tp, Eg_GeV, hiE)
+    if nuclear_enhancement:
+        ds = ds * pp_nuclear_factor(Tp)
+    return ds
+
+
+class PionLUT:
+    """radiative.py:1770-1797: bicubic FITPACK spline through 10**lut."""
+
+    def __init__(self, filename):
+        from scipy.interpolate import RectBivariateSpline
+        f = np.load(filename)
+        self.X, self.Y = f["X"], f["Y"]
+        with np.errstate(all="ignore"):
+            self.spl = RectBivariateSpline(self.X, self.Y, 10 ** f["lut"], kx=3, ky=3, s=0)
+
+    def __call__(self, Ep_GeV, Eg_GeV):
+        return self.spl(np.log10(Ep_GeV), np.log10(Eg_GeV)).flatten()
+
+
+def pion_spectrum(E_eV, Ep_GeV, J, nh=1.0, diffsigma=None, hiE="Pythia8",
+                  nuclear_enhancement=True):
+    """radiative.py:1523-1536: one trapz_loglog per photon energy; 1/(s eV)."""
+    Eg = np.asarray(E_eV, dtype=float) * 1e-9
+    if diffsigma is None:
+        def diffsigma(ep, eg):
+            return pp_diffsigma(ep, eg, hiE, nuclear_enhancement)
+    out = np.empty(Eg.shape)
+    for k, eg in enumerate(Eg):
+        out[k] = trapz_loglog(diffsigma(Ep_GeV, eg) * J, Ep_GeV)
+    return out * (nh * C_CGS) * 1e-9
+
+
+# ---------------------------------------------------------------------------
+# row 4: flux / sed
+# ---------------------------------------------------------------------------
+def to_flux(spec, distance_cm):
+    """radiative.py:102-111: 1/(s eV) -> 1/(s cm2 eV); distance 0 -> unchanged."""
+    if distance_cm == 0:
+        return spec
+    return spec / (4 * np.pi * distance_cm ** 2)
+
+
+def to_sed(flux, E_eV):
+    """radiative.py:132: flux*E^2 -> erg/(cm2 s)."""
+    return flux * np.asarray(E_eV) ** 2 * ERG_PER_EV
+
+
+# ---------------------------------------------------------------------------
+# rows 11-13: likelihood and priors (core.py:34-121)
+# ---------------------------------------------------------------------------
+def lnprobmodel(model, data):
+    """core.py:64-94.  ``model`` and data['flux'] must already be in the same
+    representation/unit (the SED<->differential factor of core.py:69-71 is a
+    per-energy multiplier applied by the caller).  data: dict with flux,
+    flux_error_lo, flux_error_hi, ul (bool), cl (array)."""
+    model = np.asarray(model, dtype=float)
+    ul = np.asarray(data["ul"], dtype=bool)
+    notul = ~ul
+    diff = model[notul] - data["flux"][notul]
+    hi = diff > 0
+    err = np.where(hi, data["flux_error_hi"][notul], data["flux_error_lo"][notul])
+    total = np.sum(-(diff ** 2) / (2.0 * err ** 2))
+    if np.sum(ul) > 0:
+        nviol = int(np.sum(model[ul] > data["flux"][ul]))
+        # quirk kept: cl is indexed by the violation count (core.py:91-92)
+        total += nviol * np.log(1.0 - data["cl"][nviol])
+    return total
+
+
+def uniform_prior(value, umin, umax):
+    """core.py:34-39."""
+    return 0.0 if umin <= value <= umax else -np.inf
+
+
+def normal_prior(value, mean, sigma):
+    """core.py:42-44 (as written: no log, sigma not squared)."""
+    return -0.5 * (2 * np.pi * sigma) - (value - mean) ** 2 / (2.0 * sigma)
+
+
+def log_uniform_prior(value, umin=0, umax=None):
+    """core.py:47-58 (returns 1/value, as written)."""
+    if value > 0 and value >= umin:
+        if umax is not None and value > umax:
+            return -np.inf
+        return 1 / value
+    return -np.inf
+
+
+def lnprob(pars, data, modelfunc, priorfunc):
+    """core.py:97-121; modelfunc returns model (same representation as data)
+    or (model, *blobs)."""
+    lp = 0.0 if priorfunc is None else priorfunc(pars)
+    out = modelfunc(pars, data)
+    if isinstance(out, (tuple, list)):
+        model, blob = out[0], tuple(out)
+    else:
+        model, blob = out, (out, np.nan)
+    if not np.isinf(lp):
+        total = lnprobmodel(model, data) + lp
+    else:
+        total = lp
+    return (total,) + blob
+
+
+# ---------------------------------------------------------------------------
+# ensemble move (emcee >= 3, third party, NOT in /root/reference; parity unpinned)
+# ---------------------------------------------------------------------------
+def stretch_move_reference(coords, logp, lnprob_fn, rng, a=2.0):
+    """One emcee-3 ``StretchMove`` step restated from its published algorithm
+    (Goodman & Weare 2010; emcee.moves.RedBlueMove.propose + StretchMove.
+    get_proposal).  Call sites in the reference: core.py:128, 450-457.
+    lnprob_fn maps (n, ndim) -> (n,).  Returns (coords, logp, accepted)."""
+    nwalkers, ndim = coords.shape
+    coords, logp = coords.copy(), logp.copy()
+    accepted = np.zeros(nwalkers, dtype=bool)
+    inds = np.arange(nwalkers) % 2
+    rng.shuffle(inds)
+    for split in range(2):
+        S = inds == split
+        s, c = coords[S], coords[~S]
+        Ns, Nc = len(s), len(c)
+        zz = ((a - 1.0) * rng.random(Ns) + 1) ** 2.0 / a
+        factors = (ndim - 1.0) * np.log(zz)
+        rint = rng.integers(Nc, size=Ns)
+        q = c[rint] - (c[rint] - s) * zz[:, None]
+        newlp = lnprob_fn(q)
+        lnpdiff = factors + newlp - logp[S]
+        acc = np.log(rng.random(Ns)) < lnpdiff
+        idx = np.nonzero(S)[0][acc]
+        coords[idx] = q[acc]
+        logp[idx] = newlp[acc]
+        accepted[idx] = True
+    return coords, logp, accepted

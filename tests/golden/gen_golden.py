@@ -1,0 +1,302 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden vectors under tests/golden/ by running THE REFERENCE.
+
+Run in the build container only (the reference never travels):
+
+    /opt/conda/bin/python3.9 tests/golden/gen_golden.py
+
+It imports /root/reference/src/naima/{utils,radiative,models,core}.py through the
+loader of SURVEY.md 8c (naima/__init__.py needs emcee and a generated
+version.py; the three numpy names are registry-only shims for astropy 4.3.1 on
+numpy 1.26) and writes inputs + expected outputs as plain arrays.  The
+fixtures are data; no reference source is copied.
+"""
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+for n, f in (("asscalar", lambda a: a.item()), ("alen", len), ("rank", np.ndim)):
+    if not hasattr(np, n):
+        setattr(np, n, f)
+SRC = "/root/reference/src/naima"
+pkg = types.ModuleType("naima")
+pkg.__path__ = [SRC]
+pkg.__file__ = SRC + "/__init__.py"
+pkg.__package__ = "naima"
+sys.modules["naima"] = pkg
+sys.modules.setdefault("emcee", types.ModuleType("emcee"))
+for m in ("extern", "extern.validator", "utils", "model_utils", "radiative", "models", "core"):
+    importlib.import_module("naima." + m)
+
+warnings.simplefilter("ignore")
+import astropy.units as u  # noqa: E402
+from astropy.constants import c, m_e  # noqa: E402
+
+import naima.core as ncore  # noqa: E402
+import naima.models as nmodels  # noqa: E402
+import naima.radiative as nrad  # noqa: E402
+from naima.utils import trapz_loglog  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+spec = importlib.util.spec_from_file_location(
+    "workloads", os.path.join(REPO, "naima_amd", "workloads.py"))
+W = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(W)
+
+
+class RefNS:
+    """the reference, seen through the namespace the workloads are written against"""
+    u = u
+    ExponentialCutoffPowerLaw = nmodels.ExponentialCutoffPowerLaw
+    ExponentialCutoffBrokenPowerLaw = nmodels.ExponentialCutoffBrokenPowerLaw
+    PowerLaw = nmodels.PowerLaw
+    BrokenPowerLaw = nmodels.BrokenPowerLaw
+    LogParabola = nmodels.LogParabola
+    Synchrotron = nrad.Synchrotron
+    InverseCompton = nrad.InverseCompton
+    Bremsstrahlung = nrad.Bremsstrahlung
+    PionDecay = nrad.PionDecay
+    uniform_prior = staticmethod(ncore.uniform_prior)
+
+
+def qdata(raw):
+    return dict(energy=raw["energy"] * u.Unit(raw["energy_unit"]),
+                flux=raw["flux"] * u.Unit(raw["flux_unit"]),
+                flux_error_lo=raw["flux_error_lo"] * u.Unit(raw["flux_unit"]),
+                flux_error_hi=raw["flux_error_hi"] * u.Unit(raw["flux_unit"]),
+                ul=raw["ul"], cl=raw["cl"])
+
+
+def val(x, unit):
+    return np.asarray(u.Quantity(x).to(unit).value, dtype=float)
+
+
+def gen_cfg(name, nvec, variant=None):
+    wl = W.WORKLOADS[name]
+    model = wl["model"](RefNS) if variant is None else wl["model"](RefNS, **variant)
+    p0 = np.asarray(wl["p0"], dtype=float)
+
+    def flux_at_p0(E_eV):
+        out = model(p0, {"energy": E_eV * u.eV})
+        out = out[0] if isinstance(out, tuple) else out
+        return val(out, "1/(s cm2 eV)")
+
+    raw = W.build_data(name, flux_at_p0)
+    data = qdata(raw)
+    pars = W.test_vectors(name, nvec)
+    flux, blob, lnp, lnprior = [], [], [], []
+    prior = W.prior_for(name, RefNS)
+    for p in pars:
+        res = ncore.lnprob(p, data, model, None)
+        lnp.append(float(res[0]))
+        flux.append(val(res[1], "1/(s cm2 eV)"))
+        b = res[2]
+        blob.append(float(b.to("erg").value) if hasattr(b, "unit") else np.nan)
+        lnprior.append(0.0 if prior is None else float(prior(p)))
+    out = dict(pars=pars, flux=np.array(flux), blob=np.array(blob), lnprob=np.array(lnp),
+               lnprior=np.array(lnprior))
+    for k, v in raw.items():
+        out["data_" + k] = np.asarray(v)
+    return out, model, data, pars
+
+
+def main():
+    os.chdir(HERE)
+    # ---------------- per-workload fixtures --------------------------------
+    for name, nvec in (("cfg1", 8), ("cfg2", 8), ("cfg3", 8), ("cfg4", 3), ("cfg5", 8)):
+        if name == "cfg5":
+            out, _, _, _ = gen_cfg(name, nvec, dict(useLUT=True))
+            out2, _, _, _ = gen_cfg(name, nvec, dict(useLUT=False))
+            for k in ("flux", "blob", "lnprob"):
+                out[k + "_analytic"] = out2[k]
+            # data of the analytic variant differ (built from its own p0 flux)
+            for k in out2:
+                if k.startswith("data_"):
+                    out["analytic_" + k] = out2[k]
+        else:
+            out, model, data, pars = gen_cfg(name, nvec)
+        if name == "cfg3":
+            # component-level vectors for the headline workload
+            p = pars[0]
+            ECPL = nmodels.ExponentialCutoffPowerLaw(
+                10 ** p[0] / u.eV, 10 * u.TeV, p[1], 10 ** p[2] * u.TeV, p[4])
+            IC = nrad.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"],
+                                     Eemin=100 * u.GeV)
+            SYN = nrad.Synchrotron(ECPL, B=p[3] * u.uG)
+            IC.flux(data, distance=1 * u.kpc)
+            out["c_ic_gam"] = IC._gam
+            out["c_ic_nelec"] = IC._nelec
+            out["c_syn_gam"] = SYN._gam
+            out["c_syn_nelec"] = SYN._nelec
+            out["c_specic"] = np.array([val(s, "1/(s eV)") for s in IC.specic])
+            out["c_syn_spec"] = val(SYN.flux(data, distance=0), "1/(s eV)")
+            out["c_We_gt1TeV"] = float(IC.compute_We(Eemin=1 * u.TeV).to("erg").value)
+            out["c_We"] = float(IC.We.to("erg").value)
+        np.savez_compressed(name + ".npz", **out)
+        print(name, "lnprob", out["lnprob"][:3])
+
+    # ---------------- unit-level vectors ------------------------------------
+    U = {}
+    rng = np.random.default_rng(W.SEED)
+    # trapz_loglog incl. the edge semantics of utils.py:336-348
+    x = np.logspace(0, 3, 40)
+    ys = [x ** -2.0 * np.exp(-x / 300.0), x ** -1.0, np.full(x.size, 3.0),
+          np.abs(rng.standard_normal(x.size)) + 0.1]
+    y4 = ys[0].copy(); y4[5] = 0.0; y4[20:23] = 0.0
+    y5 = ys[0].copy(); y5[7] *= -1; y5[30] *= -1e-3
+    y6 = ys[3].copy(); y6[-1] = 0.0; y6[0] = 0.0
+    y7 = np.exp(-np.logspace(0, 3, 40)) * 1e-300  # denormal tail
+    ys += [y4, y5, y6, y7]
+    U["tz_x"] = x
+    U["tz_y"] = np.array(ys)
+    U["tz_out"] = np.array([trapz_loglog(y, x) for y in ys])
+    y2d = np.abs(rng.standard_normal((40, 6))) * x[:, None] ** -1.5
+    U["tz_y2d"] = y2d
+    U["tz_out2d"] = trapz_loglog(y2d, x, axis=0)
+
+    # particle distributions, models.py eval statics through __call__
+    e = np.logspace(8, 15.5, 60) * u.eV
+    U["pd_e"] = e.value
+    pds = {
+        "PowerLaw": nmodels.PowerLaw(3e30 / u.eV, 2 * u.TeV, 2.3),
+        "ExponentialCutoffPowerLaw": nmodels.ExponentialCutoffPowerLaw(
+            3e30 / u.eV, 2 * u.TeV, 2.3, 30 * u.TeV, 1.7),
+        "BrokenPowerLaw": nmodels.BrokenPowerLaw(3e30 / u.eV, 2 * u.TeV, 0.5 * u.TeV, 1.6, 2.9),
+        "ExponentialCutoffBrokenPowerLaw": nmodels.ExponentialCutoffBrokenPowerLaw(
+            3e30 / u.eV, 2 * u.TeV, 0.5 * u.TeV, 1.6, 2.9, 80 * u.TeV, 0.8),
+        "LogParabola": nmodels.LogParabola(3e30 / u.eV, 2 * u.TeV, 2.1, 0.15),
+    }
+    for k, pd in pds.items():
+        U["pd_" + k] = val(pd(e), "1/eV")
+
+    # grids: (Emin eV, Emax eV, per decade) -> count and values (radiative.py:147-154)
+    gspecs = [(1e9, 1e9 * nrad.mec2.to("eV").value, 100), (1e9, 1e15, 50), (1e11, 1e15, 100),
+              (1e8, 5e16, 100), (1e12, 1e9 * nrad.mec2.to("eV").value, 100),
+              (nrad.mec2.to("eV").value, 1e9 * nrad.mec2.to("eV").value, 300), (1e10, 1e13, 1000),
+              (1e9, 1.5e9, 100)]
+    U["grid_specs"] = np.array(gspecs)
+    glens = []
+    for i, (lo, hi, nd) in enumerate(gspecs):
+        s = nrad.Synchrotron(pds["PowerLaw"], Eemin=lo * u.eV, Eemax=hi * u.eV, nEed=nd)
+        g = s._gam
+        glens.append(len(g))
+        U["grid_%d" % i] = g
+    U["grid_lens"] = np.array(glens)
+    pp = nrad.PionDecay(pds["PowerLaw"])
+    U["pgrid_default"] = pp._Ep
+    pp = nrad.PionDecay(pds["PowerLaw"], Epmax=1 * u.PeV)
+    U["pgrid_1PeV"] = pp._Ep
+
+    # radiative per-energy spectra (intrinsic, 1/(s eV)), energies as test_models.py:41
+    E = np.logspace(0, 15, 120) * u.eV
+    U["E"] = E.value
+    eprops = {"Eemin": 100 * u.GeV, "Eemax": 1 * u.PeV}
+    ECPL, BPL, LP = pds["ExponentialCutoffPowerLaw"], pds["BrokenPowerLaw"], pds["LogParabola"]
+    for tag, pd in (("ecpl", ECPL), ("bpl", BPL), ("lp", LP)):
+        sy = nrad.Synchrotron(pd, B=1 * u.mG, **eprops)
+        U["syn_" + tag] = val(sy.flux(E, 0), "1/(s eV)")
+        U["We_" + tag] = float(sy.We.to("erg").value)
+        U["We10_" + tag] = float(sy.compute_We(Eemin=10 * u.TeV).to("erg").value)
+    sy = nrad.Synchrotron(ECPL)  # defaults B=3.24 uG, 1 GeV..1e9 mec2
+    U["syn_default"] = val(sy.flux(E, 0), "1/(s eV)")
+    ic = nrad.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"], **eprops)
+    U["ic_3seeds"] = val(ic.flux(E, 0), "1/(s eV)")
+    U["ic_3seeds_per"] = np.array([val(s, "1/(s eV)") for s in ic.specic])
+    ic = nrad.InverseCompton(BPL, seed_photon_fields=[["bb", 5000 * u.K, 0],
+                                                      ["bb2", 40 * u.K, 2.0 * u.eV / u.cm ** 3]])
+    U["ic_custom"] = val(ic.flux(E, 0), "1/(s eV)")
+    for ang in (45, 90, 135):
+        ic = nrad.InverseCompton(ECPL, seed_photon_fields=[
+            ["Star", 20000 * u.K, 0.1 * u.erg / u.cm ** 3, ang * u.deg]], **eprops)
+        U["ic_ani_%d" % ang] = val(ic.flux(E, 0), "1/(s eV)")
+    ic = nrad.InverseCompton(ECPL, seed_photon_fields=[["UV", 50 * u.eV, 15 * u.eV / u.cm ** 3]],
+                             **eprops)
+    U["ic_mono"] = val(ic.flux(E, 0), "1/(s eV)")
+    Es = np.logspace(-3.5, 0.5, 30) * u.eV
+    ns_ = (1e3 * (Es.value / 1e-2) ** -1.5 * np.exp(-Es.value / 1.0)) * u.Unit("1/(eV cm3)")
+    U["ic_arr_E"] = Es.value
+    U["ic_arr_n"] = ns_.value
+    ic = nrad.InverseCompton(ECPL, seed_photon_fields=[["arr", Es, ns_]], **eprops)
+    U["ic_array"] = val(ic.flux(E, 0), "1/(s eV)")
+    ic = nrad.InverseCompton(ECPL, seed_photon_fields=[["arr", Es, Es ** 2 * ns_]], **eprops)
+    U["ic_array_edens"] = val(ic.flux(E, 0), "1/(s eV)")
+    E2 = np.logspace(4, 14, 80) * u.eV
+    U["E_brems"] = E2.value
+    br = nrad.Bremsstrahlung(ECPL, n0=2.5 / u.cm ** 3, Eemin=m_e * c ** 2)
+    U["brems_mec2"] = val(br.flux(E2, 0), "1/(s eV)")
+    br = nrad.Bremsstrahlung(BPL)
+    U["brems_default"] = val(br.flux(E2, 0), "1/(s eV)")
+    U["brems_weights"] = np.array([br.weight_ee, br.weight_ep])
+    Eg = np.logspace(-3, 3, 60) * u.TeV
+    U["E_pp"] = Eg.to("eV").value
+    pprops = {"Epmax": 1 * u.PeV}
+    for tag, pd in (("ecpl", ECPL), ("bpl", BPL)):
+        p = nrad.PionDecay(pd, useLUT=True, **pprops)
+        U["pp_lut_" + tag] = val(p.flux(Eg, 0), "1/(s eV)")
+        U["Wp_" + tag] = float(p.Wp.to("erg").value)
+        p.useLUT = False
+        U["pp_ana_" + tag] = val(p.flux(Eg, 0), "1/(s eV)")
+    p = nrad.PionDecay(ECPL, useLUT=False, nuclear_enhancement=False, nh=3.0 / u.cm ** 3)
+    U["pp_nonuc"] = val(p.flux(Eg, 0), "1/(s eV)")
+    for hiE in ("Geant4", "SIBYLL", "QGSJET"):
+        p = nrad.PionDecay(ECPL, useLUT=False, hiEmodel=hiE)
+        U["pp_ana_" + hiE] = val(p.flux(Eg, 0), "1/(s eV)")
+    # the differential cross-section itself on a coarse grid
+    p = nrad.PionDecay(ECPL, useLUT=False)
+    Epg = np.logspace(np.log10(1.2181), 6.9, 50)
+    U["ds_Ep"] = Epg
+    U["ds_Eg"] = np.array([1e-2, 0.0675, 0.3, 3.0, 1e3, 1e5])
+    U["ds_ana"] = np.array([p._diffsigma(Epg, eg) for eg in U["ds_Eg"]])
+    lut = nrad.LookupTable(SRC + "/data/PionDecayKafexhiu14_LUT_NucEnh_Pythia8.npz")
+    U["ds_lut"] = np.array([lut(Epg, eg) for eg in U["ds_Eg"]])
+
+    # lnprobmodel (core.py:64-94): asymmetric errors, upper limits, SED<->diff
+    n = 12
+    en = np.geomspace(1, 50, n) * u.TeV
+    flux = (1e-11 * en.value ** -2.2) * u.Unit("1/(cm2 s TeV)")
+    d = dict(energy=en, flux=flux, flux_error_lo=0.1 * flux, flux_error_hi=0.2 * flux,
+             ul=np.zeros(n, bool), cl=np.full(n, 0.9))
+    d["ul"][[3, 9, 11]] = True
+    mods = [flux * (1 + 0.15 * rng.standard_normal(n)) for _ in range(6)]
+    U["ll_energy_TeV"] = en.value
+    U["ll_flux"] = flux.value
+    U["ll_ul"] = d["ul"]
+    U["ll_cl"] = d["cl"]
+    U["ll_models"] = np.array([m.value for m in mods])
+    U["ll_out"] = np.array([float(ncore.lnprobmodel(m, d)) for m in mods])
+    # model in SED, data differential -> conversion branch
+    U["ll_out_sedmodel"] = np.array(
+        [float(ncore.lnprobmodel((m * en ** 2).to("erg/(cm2 s)"), d)) for m in mods])
+    U["prior_normal"] = np.array([ncore.normal_prior(1.3, 1.0, 0.5)])
+    U["prior_logu"] = np.array([ncore.log_uniform_prior(2.0, 1.0, 3.0)])
+    np.savez_compressed("units.npz", **U)
+
+    # ---------------- known answers of the reference's own tests -------------
+    KA = {
+        "_source": "tests/test_models.py of the reference (luminosities in erg/s, energies in erg)",
+        "syn_lum": [0.00025231296225663107, 0.03316715765695228, 0.00044597089198025806],  # :75-79
+        "We": [5064124672.902273, 11551172166.866821, 926633861.2898524],  # :80
+        "syn_lum_B1G": 31374131.90312505,  # :102
+        "brems_lum": 2.3064095039069847e-05,  # :194
+        "ic_lum": [0.0002782201669858555, 0.004821189222961136, 0.00012916582897424096],  # :206-210
+        "ic_lum_3seeds": 0.0005833030059049264,  # :226
+        "ic_ani_lum": [48901.363932, 111356.423781, 149800.235776],  # :239
+        "pp_lum_LUT": [9.94070311e-13, 2.30256683e-12, 1.57263936e-13],  # :402
+        "pp_lum_noLUT": [9.94144387e-13, 2.30264140e-12, 1.57272216e-13],  # :404
+        "Wp": [5406.36160963, 8727.55086557, 554.13864492],  # :406
+        "pp_lum_nonuc": 5.693100769654807e-13,  # :440
+    }
+    with open("known_answers.json", "w") as fh:
+        json.dump(KA, fh, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

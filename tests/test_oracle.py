@@ -1,0 +1,250 @@
+"""The oracle (oracle/naima_np.py) against the reference: golden vectors made by
+running the reference itself (tests/golden/gen_golden.py) and the known-answer
+luminosities of the reference's tests/test_models.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import naima_np as O
+from oracle import workloads_np as WN
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# the oracle repeats the reference's arithmetic on raw floats; only unit-conversion
+# rounding (1 ulp per astropy .to()) separates them
+RT = 2e-12
+
+
+def _pds():
+    return {
+        "PowerLaw": O.ParticleDist("PowerLaw", amplitude=3e30, e_0=2e12, alpha=2.3),
+        "ExponentialCutoffPowerLaw": O.ParticleDist(
+            "ExponentialCutoffPowerLaw", amplitude=3e30, e_0=2e12, alpha=2.3, e_cutoff=30e12,
+            beta=1.7),
+        "BrokenPowerLaw": O.ParticleDist("BrokenPowerLaw", amplitude=3e30, e_0=2e12,
+                                         e_break=0.5e12, alpha_1=1.6, alpha_2=2.9),
+        "ExponentialCutoffBrokenPowerLaw": O.ParticleDist(
+            "ExponentialCutoffBrokenPowerLaw", amplitude=3e30, e_0=2e12, e_break=0.5e12,
+            alpha_1=1.6, alpha_2=2.9, e_cutoff=80e12, beta=0.8),
+        "LogParabola": O.ParticleDist("LogParabola", amplitude=3e30, e_0=2e12, alpha=2.1,
+                                      beta=0.15),
+    }
+
+
+def test_trapz_loglog_edges(golden):
+    U = golden("units")
+    for y, ref in zip(U["tz_y"], U["tz_out"]):
+        assert_allclose(O.trapz_loglog(y, U["tz_x"]), ref, rtol=1e-14)
+    assert_allclose(O.trapz_loglog(U["tz_y2d"], U["tz_x"], axis=0), U["tz_out2d"], rtol=1e-14)
+    # exact power law with index -1 -> log branch
+    x = U["tz_x"]
+    assert_allclose(O.trapz_loglog(1 / x, x), np.log(x[-1] / x[0]), rtol=1e-13)
+
+
+def test_particle_distributions(golden):
+    U = golden("units")
+    for k, pd in _pds().items():
+        assert_allclose(pd(U["pd_e"]), U["pd_" + k], rtol=1e-13)
+
+
+def test_grids(golden):
+    U = golden("units")
+    for i, (lo, hi, nd) in enumerate(U["grid_specs"]):
+        g = O.electron_grid(lo, hi, nd)
+        assert len(g) == U["grid_lens"][i]
+        assert_allclose(g, U["grid_%d" % i], rtol=1e-14)
+    assert_allclose(O.proton_grid(O.M_P_GEV + O.T_TH_GEV + 1e-4, 1e7, 100), U["pgrid_default"],
+                    rtol=1e-14)
+    assert_allclose(O.proton_grid(O.M_P_GEV + O.T_TH_GEV + 1e-4, 1e6, 100), U["pgrid_1PeV"],
+                    rtol=1e-14)
+
+
+def test_synchrotron_and_We(golden):
+    U = golden("units")
+    pds = _pds()
+    gam = O.electron_grid(100e9, 1e15, 100)
+    for tag, k in (("ecpl", "ExponentialCutoffPowerLaw"), ("bpl", "BrokenPowerLaw"),
+                   ("lp", "LogParabola")):
+        ne = O.nelec_on(pds[k], gam)
+        assert_allclose(O.synchrotron_spectrum(U["E"], gam, ne, 1e-3), U["syn_" + tag], rtol=RT)
+        assert_allclose(O.electron_energy_content(pds[k], gam), U["We_" + tag], rtol=RT)
+        g10 = O.electron_grid(10e12, 1e15, 100)
+        assert_allclose(O.electron_energy_content(pds[k], g10), U["We10_" + tag], rtol=RT)
+    gam = O.electron_grid(1e9, 1e9 * O.MEC2_EV, 100)
+    ne = O.nelec_on(pds["ExponentialCutoffPowerLaw"], gam)
+    assert_allclose(O.synchrotron_spectrum(U["E"], gam, ne, 3.24e-6), U["syn_default"], rtol=RT)
+
+
+def test_inverse_compton(golden):
+    U = golden("units")
+    pds = _pds()
+    E = U["E"]
+    gam = O.electron_grid(100e9, 1e15, 100)
+    ne = O.nelec_on(pds["ExponentialCutoffPowerLaw"], gam)
+    tot, per = O.ic_spectrum(E, gam, ne, [O.thermal_seed(s) for s in ("CMB", "FIR", "NIR")])
+    assert_allclose(per, U["ic_3seeds_per"], rtol=RT)
+    assert_allclose(tot, U["ic_3seeds"], rtol=RT)
+    g2 = O.electron_grid(1e9, 1e9 * O.MEC2_EV, 100)
+    seeds = [dict(type="thermal", T=5000.0, u=O.AR_CGS * 5000.0 ** 4, theta=None),
+             dict(type="thermal", T=40.0, u=2.0 * O.ERG_PER_EV, theta=None)]
+    tot, _ = O.ic_spectrum(E, g2, O.nelec_on(pds["BrokenPowerLaw"], g2), seeds)
+    assert_allclose(tot, U["ic_custom"], rtol=RT)
+    for ang in (45, 90, 135):
+        seeds = [dict(type="thermal", T=20000.0, u=0.1, theta=np.deg2rad(ang))]
+        tot, _ = O.ic_spectrum(E, gam, ne, seeds)
+        assert_allclose(tot, U["ic_ani_%d" % ang], rtol=RT)
+    tot, _ = O.ic_spectrum(E, gam, ne, [dict(type="array", energy=[50.0], density=[15.0])])
+    assert_allclose(tot, U["ic_mono"], rtol=RT)
+    tot, _ = O.ic_spectrum(E, gam, ne, [dict(type="array", energy=U["ic_arr_E"],
+                                             density=U["ic_arr_n"])])
+    assert_allclose(tot, U["ic_array"], rtol=RT)
+    assert_allclose(tot, U["ic_array_edens"], rtol=1e-10)
+
+
+def test_bremsstrahlung(golden):
+    U = golden("units")
+    pds = _pds()
+    gam = O.electron_grid(O.MEC2_EV, 1e9 * O.MEC2_EV, 300)
+    spec = O.brems_spectrum(U["E_brems"], gam, O.nelec_on(pds["ExponentialCutoffPowerLaw"], gam),
+                            n0=2.5)
+    assert_allclose(spec, U["brems_mec2"], rtol=RT)
+    gam = O.electron_grid(100e6, 1e9 * O.MEC2_EV, 300)
+    spec = O.brems_spectrum(U["E_brems"], gam, O.nelec_on(pds["BrokenPowerLaw"], gam))
+    assert_allclose(spec, U["brems_default"], rtol=RT)
+
+
+def test_pion_decay(golden):
+    U = golden("units")
+    pds = _pds()
+    E = U["E_pp"]
+    Ep = O.proton_grid(O.M_P_GEV + O.T_TH_GEV + 1e-4, 1e6, 100)
+    lut = WN.get_lut()
+    for eg, ana, lu in zip(U["ds_Eg"], U["ds_ana"], U["ds_lut"]):
+        assert_allclose(O.pp_diffsigma(U["ds_Ep"], eg), ana, rtol=1e-12, atol=1e-300)
+        assert_allclose(lut(U["ds_Ep"], eg), lu, rtol=1e-9, atol=1e-40)
+    for tag, k in (("ecpl", "ExponentialCutoffPowerLaw"), ("bpl", "BrokenPowerLaw")):
+        J = O.J_on(pds[k], Ep)
+        assert_allclose(O.pion_spectrum(E, Ep, J), U["pp_ana_" + tag], rtol=1e-11)
+        assert_allclose(O.pion_spectrum(E, Ep, J, diffsigma=lut), U["pp_lut_" + tag], rtol=1e-8)
+        assert_allclose(O.proton_energy_content(pds[k], Ep), U["Wp_" + tag], rtol=RT)
+    Ep = O.proton_grid(O.M_P_GEV + O.T_TH_GEV + 1e-4, 1e7, 100)
+    J = O.J_on(pds["ExponentialCutoffPowerLaw"], Ep)
+    assert_allclose(O.pion_spectrum(E, Ep, J, nh=3.0, nuclear_enhancement=False), U["pp_nonuc"],
+                    rtol=1e-11)
+    for hiE in ("Geant4", "SIBYLL", "QGSJET"):
+        assert_allclose(O.pion_spectrum(E, Ep, J, hiE=hiE), U["pp_ana_" + hiE], rtol=1e-11)
+
+
+def test_lnprobmodel_and_priors(golden):
+    U = golden("units")
+    flux = U["ll_flux"]
+    d = dict(flux=flux, flux_error_lo=0.1 * flux, flux_error_hi=0.2 * flux, ul=U["ll_ul"],
+             cl=U["ll_cl"])
+    for m, ref in zip(U["ll_models"], U["ll_out"]):
+        assert_allclose(O.lnprobmodel(m, d), ref, rtol=1e-13)
+    assert_allclose(U["ll_out_sedmodel"], U["ll_out"], rtol=1e-12)
+    assert_allclose(O.normal_prior(1.3, 1.0, 0.5), U["prior_normal"][0], rtol=1e-15)
+    assert_allclose(O.log_uniform_prior(2.0, 1.0, 3.0), U["prior_logu"][0], rtol=1e-15)
+    assert O.uniform_prior(1.0, 0.0, 2.0) == 0.0 and O.uniform_prior(3.0, 0.0, 2.0) == -np.inf
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_workloads(golden, name):
+    z = golden(name)
+    raw = WN.raw_from_npz(z)
+    n = len(z["pars"]) if name != "cfg4" else 2
+    for i in range(n):
+        lp, flux, blob = WN.lnprob(name, z["pars"][i], raw)
+        tol = 1e-8 if name == "cfg5" else 1e-10
+        assert_allclose(flux, z["flux"][i], rtol=tol, atol=1e-300)
+        assert_allclose(lp, z["lnprob"][i], rtol=1e-8)
+        if not np.isnan(z["blob"][i]):
+            assert_allclose(blob, z["blob"][i], rtol=1e-11)
+    if name == "cfg5":
+        raw = WN.raw_from_npz(z, "analytic_data_")
+        for i in range(3):
+            lp, flux, blob = WN.lnprob(name, z["pars"][i], raw, useLUT=False)
+            assert_allclose(flux, z["flux_analytic"][i], rtol=1e-10)
+            assert_allclose(lp, z["lnprob_analytic"][i], rtol=1e-8)
+
+
+def test_cfg3_components(golden):
+    z = golden("cfg3")
+    p = z["pars"][0]
+    pd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=10 ** p[0], e_0=10e12, alpha=p[1],
+                        e_cutoff=10 ** p[2] * 1e12, beta=p[4])
+    g_ic = O.electron_grid(100e9, 1e9 * O.MEC2_EV, 100)
+    g_sy = O.electron_grid(1e9, 1e9 * O.MEC2_EV, 100)
+    assert_allclose(g_ic, z["c_ic_gam"], rtol=1e-14)
+    assert_allclose(g_sy, z["c_syn_gam"], rtol=1e-14)
+    assert_allclose(O.nelec_on(pd, g_ic), z["c_ic_nelec"], rtol=1e-13)
+    E = WN.data_energy_eV(WN.raw_from_npz(z))
+    _, per = O.ic_spectrum(E, g_ic, O.nelec_on(pd, g_ic),
+                           [O.thermal_seed(s) for s in ("CMB", "FIR", "NIR")])
+    assert_allclose(per, z["c_specic"], rtol=RT)
+    assert_allclose(O.synchrotron_spectrum(E, g_sy, O.nelec_on(pd, g_sy), p[3] * 1e-6),
+                    z["c_syn_spec"], rtol=RT)
+    assert_allclose(O.electron_energy_content(pd, g_ic), z["c_We"], rtol=RT)
+
+
+def test_known_answers():
+    """The reference's own pins (tests/test_models.py:69-450), rtol 1e-7 as there."""
+    KA = json.load(open(os.path.join(HERE, "golden", "known_answers.json")))
+    E = np.logspace(0, 15, 1000)
+    mec2 = O.MEC2_EV
+
+    def lum(spec, EE=E):
+        return O.trapz_loglog(spec * EE, EE) * O.ERG_PER_EV
+
+    amp = 1.0 / mec2  # 1/mec2 in 1/eV
+    dists = [O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp, e_0=20e12, alpha=2.0,
+                            e_cutoff=10e12, beta=1.0),
+             O.ParticleDist("PowerLaw", amplitude=amp, e_0=20e12, alpha=2.0),
+             O.ParticleDist("BrokenPowerLaw", amplitude=amp, e_0=20e12, e_break=1e12,
+                            alpha_1=1.5, alpha_2=2.5)]
+    gam = O.electron_grid(100e9, 1e15, 100)
+    lsy, We, lic = [], [], []
+    for pd in dists:
+        ne = O.nelec_on(pd, gam)
+        lsy.append(lum(O.synchrotron_spectrum(E, gam, ne, 3.24e-6)))
+        We.append(O.electron_energy_content(pd, gam))
+        lic.append(lum(O.ic_spectrum(E, gam, ne, [O.thermal_seed("CMB")])[0]))
+    assert_allclose(lsy, KA["syn_lum"], rtol=1e-7)
+    assert_allclose(We, KA["We"], rtol=1e-7)
+    assert_allclose(lic, KA["ic_lum"], rtol=1e-7)
+    ne = O.nelec_on(dists[0], gam)
+    assert_allclose(lum(O.synchrotron_spectrum(E, gam, ne, 1.0)), KA["syn_lum_B1G"], rtol=1e-7)
+    g2 = O.electron_grid(1e9, 1e9 * mec2, 100)
+    tot, _ = O.ic_spectrum(E, g2, O.nelec_on(dists[0], g2),
+                           [O.thermal_seed(s) for s in ("CMB", "FIR", "NIR")])
+    assert_allclose(lum(tot), KA["ic_lum_3seeds"], rtol=1e-7)
+    ani = []
+    for ang in (45, 90, 135):
+        seeds = [dict(type="thermal", T=20000.0, u=0.1, theta=np.deg2rad(ang))]
+        ani.append(lum(O.ic_spectrum(E, gam, O.nelec_on(dists[1], gam), seeds)[0]))
+    assert_allclose(ani, KA["ic_ani_lum"], rtol=1e-7)
+    E2 = np.logspace(8, 14, 100)
+    g3 = O.electron_grid(mec2, 1e9 * mec2, 300)
+    assert_allclose(lum(O.brems_spectrum(E2, g3, O.nelec_on(dists[0], g3)), E2), KA["brems_lum"],
+                    rtol=1e-7)
+    # pion decay: amplitudes reset to 1/TeV (tests/test_models.py:399-400)
+    for pd in dists:
+        pd.params["amplitude"] = 1e-12
+    Epp = np.logspace(-3, 3, 60) * 1e12
+    Ep = O.proton_grid(O.M_P_GEV + O.T_TH_GEV + 1e-4, 1e6, 100)
+    lut = WN.get_lut()
+    l_lut, l_ana, Wp = [], [], []
+    for pd in dists:
+        J = O.J_on(pd, Ep)
+        l_lut.append(lum(O.pion_spectrum(Epp, Ep, J, diffsigma=lut), Epp))
+        l_ana.append(lum(O.pion_spectrum(Epp, Ep, J), Epp))
+        Wp.append(O.proton_energy_content(pd, Ep))
+    assert_allclose(l_lut, KA["pp_lum_LUT"], rtol=1e-7)
+    assert_allclose(l_ana, KA["pp_lum_noLUT"], rtol=1e-7)
+    assert_allclose(Wp, KA["Wp"], rtol=1e-7)
+    E3 = np.logspace(9, 13, 20)
+    J = O.J_on(dists[0], Ep)
+    assert_allclose(lum(O.pion_spectrum(E3, Ep, J, nuclear_enhancement=False), E3),
+                    KA["pp_lum_nonuc"], rtol=1e-7)
