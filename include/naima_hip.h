@@ -1,0 +1,196 @@
+/* naima_hip.h -- C ABI of libnaima_hip.so: the MI355X (gfx950) implementation of
+ * naima's radiative-likelihood hot path.
+ *
+ * The reference (zblz/naima) has NO FFI: the path sits behind Python callables
+ * (SURVEY.md 8b).  This header is the boundary this build introduces; every
+ * entry point names the reference function(s) it replaces (paths relative to
+ * /root/reference/src/naima/).  INTEGRATION.md shows the ctypes stub a naima
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a
+ *     negative NH_E* code, and nh_last_error() returns a thread-local message;
+ *   - all numeric data are float64, C-contiguous;
+ *   - compute entry points take DEVICE pointers obtained from nh_alloc() and are
+ *     asynchronous on the context's HIP stream (stream-ordered, single host
+ *     thread per context, no callbacks).  nh_upload/nh_download/nh_sync move
+ *     data and synchronise;
+ *   - "N" is the number of walkers in the batch (emcee evaluates lnprob once
+ *     per walker, core.py:450-457; here a half-ensemble is ONE call);
+ *   - particle spectra travel between kernels as the per-walker weight arrays
+ *       w[N][nG]  = x_i * n_w(E_i)      dlw[N][nG]: dlw[i] = ln|w[i+1]/w[i]|
+ *     with x the integration variable (Lorentz factor for electrons, total
+ *     energy in GeV for protons) and n the particles per unit x; the log-ratios
+ *     of ADJACENT nodes (last entry unused) are what utils.py:336 needs and are
+ *     assembled from small, separately accurate pieces;
+ *   - emission kernels travel as TRANSPOSED tables Kt[nG][nK] with
+ *     dlnKt[i][k] = ln|Kt[i+1][k]/Kt[i][k]| (last row unused); the
+ *     table builders write an [nG][nE] block with row stride ld >= nE, so several
+ *     seeds can sit side by side in one [nG][S*nE] table (Kt + j*nE, ld = S*nE);
+ *   - spectra are returned in 1/(s eV) (intrinsic luminosity per unit energy),
+ *     exactly what <Class>._spectrum() returns in the reference.
+ */
+#ifndef NAIMA_HIP_H
+#define NAIMA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nh_ctx nh_ctx;
+
+enum {
+  NH_OK = 0,
+  NH_EINVAL = -1,  /* bad argument */
+  NH_EHIP = -2,    /* HIP runtime error (message has the hipError string) */
+  NH_ENOMEM = -3,
+  NH_ECOMM = -4    /* RCCL error */
+};
+
+/* particle distribution kinds, models.py:49-422 */
+enum {
+  NH_PD_POWERLAW = 0,            /* models.py:88-92   */
+  NH_PD_ECPL = 1,                /* models.py:157-161 */
+  NH_PD_BROKENPL = 2,            /* models.py:234-238 */
+  NH_PD_ECBPL = 3,               /* models.py:330-335 */
+  NH_PD_LOGPARABOLA = 4          /* models.py:402-407 */
+};
+/* parameter row of a particle distribution (energies in eV):
+ *   [0] amplitude (1/eV)   [1] e_0      [2] alpha | alpha_1
+ *   [3] e_cutoff           [4] beta     [5] e_break   [6] alpha_2   [7] unused
+ * LogParabola uses [2]=alpha, [4]=beta. */
+#define NH_PD_NPAR 8
+
+/* hadronic high-energy models, radiative.py:1179-1209 */
+enum { NH_PP_GEANT4 = 0, NH_PP_PYTHIA8 = 1, NH_PP_SIBYLL = 2, NH_PP_QGSJET = 3 };
+
+/* ---- context, memory, stream ------------------------------------------- */
+const char* nh_last_error(void);
+int nh_version(void);
+int nh_create(int device, nh_ctx** out);
+int nh_destroy(nh_ctx* ctx);
+int nh_device_info(nh_ctx* ctx, char* name, int name_len, int* compute_units,
+                   double* hbm_bytes, int* clock_khz);
+int nh_alloc(nh_ctx* ctx, long long bytes, void** dev_out);
+int nh_free(nh_ctx* ctx, void* dev);
+int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes);
+int nh_download(nh_ctx* ctx, void* host_dst, const void* dev_src, long long bytes);
+int nh_memset(nh_ctx* ctx, void* dev, int byte, long long bytes);
+int nh_sync(nh_ctx* ctx);
+/* HIP-event timing on the context's stream (used by bench.py for the roofline) */
+int nh_timer_start(nh_ctx* ctx);
+int nh_timer_stop(nh_ctx* ctx, double* elapsed_ms);
+/* per-kernel accumulated HIP-event time since the last reset; kernel ids NH_K_* */
+enum { NH_K_PDIST = 0, NH_K_INTEGRATE = 1, NH_K_SYNCHROTRON = 2, NH_K_TABLES = 3,
+       NH_K_LNPROB = 4, NH_K_SSC = 5, NH_K_SAMPLER = 6, NH_K_COUNT = 8 };
+int nh_profile_enable(nh_ctx* ctx, int on);
+int nh_profile_read(nh_ctx* ctx, double* ms_per_kernel /*[NH_K_COUNT]*/,
+                    long long* launches /*[NH_K_COUNT]*/, int reset);
+
+/* ---- row 1: utils.py:285-355 trapz_loglog ------------------------------ */
+/* out[r] = trapz_loglog(y[r][0:n], x[0:n]) for r < nrows (axis=-1 semantics:
+ * zero nodes, NaN/sign-change -> log branch, |b+1| <= 1e-10 -> log branch). */
+int nh_trapz_loglog(nh_ctx* ctx, const double* y, const double* x, int nrows, int n,
+                    double* out);
+
+/* ---- rows 2,3: models.py eval statics + radiative.py:147-160,1002-1015 -- */
+/* w[N][nG] = xg_i * unit_scale * f_kind(e_eV_i; params_w), dlw[i] = ln|w[i+1]/w[i]|.
+ * unit_scale = mec2[eV] for electrons (1/eV -> 1/mec2, radiative.py:160) or 1e9
+ * for protons (1/eV -> 1/GeV, radiative.py:1015).  n_out (optional, may be NULL)
+ * receives the bare n = w/xg (what _nelec/_J return). */
+int nh_particle_weights(nh_ctx* ctx, int kind, const double* params /*[N][NH_PD_NPAR]*/,
+                        int N, const double* e_eV /*[nG]*/, const double* xg /*[nG]*/,
+                        int nG, double unit_scale, double* w, double* dlw, double* n_out);
+
+/* lx[i] = ln(xg[i+1]/xg[i]), i < nG-1 (the abscissa ratios of utils.py:336) */
+int nh_grid_logratio(nh_ctx* ctx, const double* xg, int nG, double* lx);
+
+/* ---- the generic per-walker reduction (rows 1+6..10) --------------------- */
+/* out[w*ldo + k] = scale[k] * trapz_loglog(n_w * K_k, xg)  for k < nK,
+ * evaluated as sum_i  lx_i * (u2-u1)/ln(u2/u1),  u = w_i*Kt[i][k],
+ * ln(u2/u1) = dlw[i] + dlnKt[i][k].
+ * scale may be NULL (=1).  Replaces the trapz_loglog(nelec*gamint, gam) calls of
+ * radiative.py:684 (IC), 949-953/966-970 (bremsstrahlung), 1530 (pion decay),
+ * 165/193/1020/1053 (We, Wp). */
+int nh_integrate_tables(nh_ctx* ctx, const double* w, const double* dlw, int N, int nG,
+                        const double* lx, const double* Kt, const double* dlnKt, int nK,
+                        const double* scale, double* out, int ldo);
+
+/* ---- row 5: radiative.py:282-342 Synchrotron._spectrum ------------------- */
+/* out[w*ldo+k] = spectrum 1/(s eV) at photon energy E_eV[k] for field B_G[w]
+ * (Gauss); walker-dependent through both w/lw and B. */
+int nh_synchrotron(nh_ctx* ctx, const double* w, const double* dlw, const double* B_G /*[N]*/,
+                   int N, const double* gam, const double* lx, int nG,
+                   const double* E_eV, int nE, double* out, int ldo);
+
+/* ---- rows 6,7: radiative.py:547-607 + G12/G34 345-367 -------------------- */
+/* Kt[i][k] (1/s per unit ... as _iso/_ani_ic_on_planck return) for temperature
+ * T_K; theta_rad < 0 selects the isotropic Eq.14, otherwise Eq.11.
+ * scale[k] = uf*Eph_k/E_eV_k so that integrate_tables gives radiative.py:684-687 */
+int nh_table_ic_planck(nh_ctx* ctx, const double* gam, int nG, const double* E_eV, int nE,
+                       double T_K, double theta_rad, double* Kt, double* dlnKt, int ld);
+
+/* ---- row 8: radiative.py:609-655 _iso_ic_on_monochromatic ---------------- */
+/* seed_E_eV[ns]; ns == 1: seed_dens = energy density eV/cm3 (monochromatic);
+ * ns > 1: differential photon density 1/(eV cm3), integrated with trapz_loglog
+ * over the seed energies (radiative.py:638-640). */
+int nh_table_ic_seed(nh_ctx* ctx, const double* gam, int nG, const double* E_eV, int nE,
+                     const double* seed_E_eV, const double* seed_dens, int ns,
+                     double* Kt, double* dlnKt, int ld);
+/* walker-dependent seed density (SSC: examples/CrabNebula_SynSSC.py:29-31):
+ * seed_dens[N][ns]; fused outer+inner reduction, out as nh_integrate_tables. */
+int nh_ic_seed_walkers(nh_ctx* ctx, const double* w, const double* dlw, int N,
+                       const double* gam, const double* lx, int nG,
+                       const double* E_eV, int nE, const double* seed_E_eV,
+                       const double* seed_dens /*[N][ns]*/, int ns, double* out, int ldo);
+
+/* ---- row 10: radiative.py:838-989 Bremsstrahlung ------------------------- */
+/* two tables: sigma_ee (rel/non-rel, 873-928) and sigma_ep = sigma_1 (838-849),
+ * both in cm2/eV. */
+int nh_table_brems(nh_ctx* ctx, const double* gam, int nG, const double* E_eV, int nE,
+                   double* Kt_ee, double* dlnKt_ee, double* Kt_ep, double* dlnKt_ep, int ld);
+
+/* ---- row 9: radiative.py:1215-1482 Kafexhiu+14, 1770-1797 LookupTable ---- */
+/* Kt[i][k] = dsigma/dEgamma(Ep_i, Egamma_k) in cm2/GeV */
+int nh_table_pion_analytic(nh_ctx* ctx, const double* Ep_GeV, int nG, const double* E_eV,
+                           int nE, int hiE_model, int nuclear_enhancement,
+                           double* Kt, double* dlnKt, int ld);
+/* bicubic tensor-product B-spline (FITPACK bispev) with knots tx[ntx], ty[nty]
+ * and coefficients c[(ntx-4)*(nty-4)], evaluated at (log10 Ep, log10 Egamma) */
+int nh_table_pion_lut(nh_ctx* ctx, const double* Ep_GeV, int nG, const double* E_eV, int nE,
+                      const double* tx, int ntx, const double* ty, int nty, const double* c,
+                      double* Kt, double* dlnKt, int ld);
+
+/* ---- row 11: core.py:64-94 lnprobmodel ----------------------------------- */
+/* model[w][k] = sum_j cscale[j] * comp_j[w*ldc + k]        (1/(s cm2 eV))
+ * m' = model*conv[k] (SED<->differential factor, utils.py:219-282)
+ * lnl[w] = -sum_{!ul} (m'-flux)^2/(2 sigma^2), sigma = err_hi if m'>flux else err_lo,
+ *          + nviol*ln(1-cl[nviol]), nviol = #{ul : m' > flux}   (cl indexed by count).
+ * model_out may be NULL.  ncomp <= 4. */
+int nh_lnprobmodel(nh_ctx* ctx, const double* const* comps /*host array of dev ptrs*/,
+                   const double* cscale /*host [ncomp]*/, int ncomp, int ldc, int N, int nE,
+                   const double* conv, const double* flux, const double* err_lo,
+                   const double* err_hi, const int* ul, const double* cl,
+                   double* model_out, double* lnl);
+
+/* ---- ensemble move (emcee StretchMove; call sites core.py:128,450-457) --- */
+/* q[j] = c[r_j] - (c[r_j]-s[j])*z_j ; factors[j] = (ndim-1) ln z_j */
+int nh_stretch_propose(nh_ctx* ctx, const double* s, const double* c, const int* partner,
+                       const double* z, int ns, int ndim, double* q, double* factors);
+/* accept where ln u < factors + newlp - oldlp; updates s/oldlp in place, accepted[j] */
+int nh_stretch_accept(nh_ctx* ctx, double* s, double* oldlp, const double* q,
+                      const double* newlp, const double* factors, const double* lnu, int ns,
+                      int ndim, int* accepted);
+
+/* ---- multi-GPU: one all-gather per half-step -------------- */
+#define NH_UNIQUE_ID_BYTES 128
+int nh_comm_unique_id(char* id_out /*[NH_UNIQUE_ID_BYTES]*/);
+int nh_comm_init(nh_ctx* ctx, int rank, int nranks, const char* id);
+int nh_comm_destroy(nh_ctx* ctx);
+/* recv[r*count .. (r+1)*count) = send of rank r (device buffers, float64 count) */
+int nh_comm_allgather(nh_ctx* ctx, const double* send, double* recv, long long count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAIMA_HIP_H */

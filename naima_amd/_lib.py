@@ -1,0 +1,249 @@
+"""ctypes binding of libnaima_hip.so (include/naima_hip.h) + device-array plumbing.
+
+There is NO CPU fallback: if the shared library or a GPU is missing, the first
+compute call raises.  Importing this module does not load the library, so the
+host-side pieces (units, data ingest, sampler bookkeeping) import on any box.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnaima_hip.so")
+
+NH_PD_NPAR = 8
+NH_K_NAMES = ("particle_weights", "integrate_tables", "synchrotron", "tables", "lnprobmodel",
+              "ic_seed_walkers", "sampler", "reserved")
+PD_KIND = {"PowerLaw": 0, "ExponentialCutoffPowerLaw": 1, "BrokenPowerLaw": 2,
+           "ExponentialCutoffBrokenPowerLaw": 3, "LogParabola": 4}
+PP_MODEL = {"Geant4": 0, "Pythia8": 1, "SIBYLL": 2, "QGSJET": 3}
+
+_dp = C.c_void_p
+_i = C.c_int
+_d = C.c_double
+_ll = C.c_longlong
+
+# name -> argtypes (restype is always int unless noted); mirrors include/naima_hip.h
+_SIGS = {
+    "nh_create": [_i, C.POINTER(_dp)],
+    "nh_destroy": [_dp],
+    "nh_device_info": [_dp, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_i)],
+    "nh_alloc": [_dp, _ll, C.POINTER(_dp)],
+    "nh_free": [_dp, _dp],
+    "nh_upload": [_dp, _dp, _dp, _ll],
+    "nh_download": [_dp, _dp, _dp, _ll],
+    "nh_memset": [_dp, _dp, _i, _ll],
+    "nh_sync": [_dp],
+    "nh_timer_start": [_dp],
+    "nh_timer_stop": [_dp, C.POINTER(_d)],
+    "nh_profile_enable": [_dp, _i],
+    "nh_profile_read": [_dp, C.POINTER(_d), C.POINTER(_ll), _i],
+    "nh_trapz_loglog": [_dp, _dp, _dp, _i, _i, _dp],
+    "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
+    "nh_grid_logratio": [_dp, _dp, _i, _dp],
+    "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i],
+    "nh_synchrotron": [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _i, _dp, _i],
+    "nh_table_ic_planck": [_dp, _dp, _i, _dp, _i, _d, _d, _dp, _dp, _i],
+    "nh_table_ic_seed": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _i],
+    "nh_ic_seed_walkers": [_dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _i],
+    "nh_table_brems": [_dp, _dp, _i, _dp, _i, _dp, _dp, _dp, _dp, _i],
+    "nh_table_pion_analytic": [_dp, _dp, _i, _dp, _i, _i, _i, _dp, _dp, _i],
+    "nh_table_pion_lut": [_dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _dp, _dp, _i],
+    "nh_lnprobmodel": [_dp, C.POINTER(_dp), C.POINTER(_d), _i, _i, _i, _i, _dp, _dp, _dp, _dp,
+                       _dp, _dp, _dp, _dp],
+    "nh_stretch_propose": [_dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
+    "nh_stretch_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp],
+    "nh_comm_unique_id": [C.c_char_p],
+    "nh_comm_init": [_dp, _i, _i, C.c_char_p],
+    "nh_comm_destroy": [_dp],
+    "nh_comm_allgather": [_dp, _dp, _dp, _ll],
+}
+EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")
+
+_lib = None
+
+
+class NaimaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libnaima_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or naima_amd/csrc/build.sh.  naima_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    lib.nh_last_error.restype = C.c_char_p
+    lib.nh_last_error.argtypes = []
+    lib.nh_version.restype = _i
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise NaimaHipError("libnaima_hip error %d: %s" % (rc, _lib.nh_last_error().decode()))
+
+
+class DeviceArray:
+    """A float64 (or int32) array in HBM owned by a Context's pool."""
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "__weakref__")
+
+    def __init__(self, ctx, ptr, shape, dtype, cap):
+        self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
+        self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            _chk(_lib.nh_download(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        if host.nbytes:
+            _chk(_lib.nh_upload(self.ctx.h, self.ptr, host.ctypes.data, host.nbytes))
+        return self
+
+    def __del__(self):
+        try:
+            if self._cap > 0 and self.ctx is not None and self.ctx.h:
+                self.ctx._release(self.ptr, self._cap)
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP device + stream; owns a size-bucketed buffer pool (hipMalloc is far
+    too slow for per-step scratch) and a content-addressed cache of small
+    constant arrays (grids, photon energies, data columns) resident in HBM."""
+
+    def __init__(self, device=0):
+        load()
+        h = _dp()
+        _chk(_lib.nh_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self._pool = {}
+        self._const = {}
+        self._keep = {}
+        self._lx = {}
+
+    # -- memory -------------------------------------------------------------
+    @staticmethod
+    def _bucket(nbytes):
+        b = 256
+        while b < nbytes:
+            b <<= 1
+        return b
+
+    def empty(self, shape, dtype=np.float64):
+        shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        cap = self._bucket(nbytes)
+        free = self._pool.get(cap)
+        if free:
+            ptr = free.pop()
+        else:
+            p = _dp()
+            _chk(_lib.nh_alloc(self.h, cap, C.byref(p)))
+            ptr = p.value
+        return DeviceArray(self, ptr, shape, dtype, cap)
+
+    def _release(self, ptr, cap):
+        self._pool.setdefault(cap, []).append(ptr)
+
+    def array(self, host, dtype=np.float64):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return self.empty(host.shape, dtype).set(host)
+
+    def const(self, host, dtype=np.float64):
+        """device copy of a small read-only array, cached by content"""
+        host = np.ascontiguousarray(host, dtype=dtype)
+        key = (host.shape, host.dtype.str, hash(host.tobytes()))
+        hit = self._const.get(key)
+        if hit is None:
+            if len(self._const) > 256:
+                self._const.clear()
+                self._lx.clear()
+            hit = self.array(host, dtype)
+            self._const[key] = hit
+        return hit
+
+    def grid_logratio(self, grid_dev):
+        """lx[i] = ln(x[i+1]/x[i]) for a cached grid (computed once on device)"""
+        hit = self._lx.get(grid_dev.ptr)
+        if hit is None:
+            n = grid_dev.shape[0]
+            hit = self.empty((n - 1,))
+            _chk(_lib.nh_grid_logratio(self.h, grid_dev.ptr, n, hit.ptr))
+            self._lx[grid_dev.ptr] = hit
+        return hit
+
+    def sync(self):
+        _chk(_lib.nh_sync(self.h))
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cus, clk, hbm = _i(), _i(), _d()
+        _chk(_lib.nh_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm), C.byref(clk)))
+        return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=hbm.value,
+                    clock_khz=clk.value)
+
+    # -- timing ---------------------------------------------------------------
+    def timer_start(self):
+        _chk(_lib.nh_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = _d()
+        _chk(_lib.nh_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on):
+        _chk(_lib.nh_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        ms = (_d * 8)()
+        n = (_ll * 8)()
+        _chk(_lib.nh_profile_read(self.h, ms, n, int(reset)))
+        return {NH_K_NAMES[i]: dict(ms=ms[i], launches=int(n[i])) for i in range(8) if n[i]}
+
+    def call(self, name, *args):
+        """invoke an entry point; DeviceArray arguments are passed as their pointers"""
+        conv = [a.ptr if isinstance(a, DeviceArray) else a for a in args]
+        _chk(getattr(_lib, name)(self.h, *conv))
+
+    def close(self):
+        if self.h:
+            self._const.clear()
+            self._lx.clear()
+            _lib.nh_destroy(self.h)
+            self.h = None
+
+
+_default = {}
+
+
+def get_context(device=None):
+    """process-wide default context (device from NAIMA_AMD_DEVICE / LOCAL_RANK, else 0)"""
+    if device is None:
+        device = int(os.environ.get("NAIMA_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _default.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default[device] = ctx
+    return ctx

@@ -1,0 +1,163 @@
+"""Likelihood, priors and the sampler entry points with naima's signatures
+(core.py of the reference), batched over walkers and evaluated on the GPU.
+
+``lnprob(pars, data, modelfunc, priorfunc)`` accepts ``pars[ndim]`` (one walker,
+the reference's contract, core.py:97-121) or ``pars[ndim, N]`` -- every
+``pars[i]`` is then a vector over walkers, the model function runs ONCE and
+returns ``(N, n_E)`` fluxes, and the Gaussian/upper-limit log-likelihood of
+core.py:64-94 is computed for all walkers by the ``nh_lnprobmodel`` kernel.
+"""
+import numpy as np
+
+from . import units as u
+from ._lib import get_context
+
+__all__ = ["normal_prior", "uniform_prior", "log_uniform_prior", "lnprob", "lnprobmodel",
+           "get_sampler", "run_sampler"]
+
+
+# ---- priors (core.py:34-58), valid for scalars and for vectors over walkers ----
+def uniform_prior(value, umin, umax):
+    """Uniform prior distribution: 0 inside [umin, umax], -inf outside."""
+    value = np.asarray(value, dtype=float)
+    out = np.where((umin <= value) & (value <= umax), 0.0, -np.inf)
+    return float(out) if out.ndim == 0 else out
+
+
+def normal_prior(value, mean, sigma):
+    """Normal prior distribution (as the reference writes it, core.py:42-44)."""
+    return -0.5 * (2 * np.pi * sigma) - (value - mean) ** 2 / (2.0 * sigma)
+
+
+def log_uniform_prior(value, umin=0, umax=None):
+    """Log-uniform prior distribution (returns 1/value as the reference, core.py:47-58)."""
+    value = np.asarray(value, dtype=float)
+    ok = (value > 0) & (value >= umin)
+    if umax is not None:
+        ok &= value <= umax
+    with np.errstate(divide="ignore"):
+        out = np.where(ok, 1.0 / value, -np.inf)
+    return float(out) if out.ndim == 0 else out
+
+
+# ---- SED <-> differential conversion (utils.py:219-282) ------------------------
+_SED_TYPES = ("power", "flux", "energy")
+_DIFF_TYPES = ("differential flux", "differential power", "differential energy",
+               "differential number density")
+
+
+def sed_conversion(energy, model_unit, sed):
+    """(f_unit, sedf): the unit and per-energy factor that bring a model to SED
+    (``sed=True``) or differential (``sed=False``) form."""
+    pt = u.Unit(model_unit).physical_type
+    is_integral = pt in _SED_TYPES
+    is_differential = pt in _DIFF_TYPES
+    ones = np.ones(np.shape(energy.value))
+    if (sed and is_integral) or (not sed and is_differential):
+        sedf = ones
+    elif sed and is_differential:
+        sedf = energy ** 2
+    elif not sed and is_integral:
+        sedf = 1 / (energy ** 2)
+    else:
+        raise u.UnitsError("Model physical type ({0}) is not supported".format(pt),
+                           "Supported physical types are: power, flux, differential power, "
+                           "differential flux")
+    energy_like = pt in ("energy", "differential energy")
+    particle_like = pt in ("flux", "differential flux")
+    if sed:
+        f_unit = u.erg if energy_like else (u.Unit("erg/(s cm2)") if particle_like
+                                            else u.Unit("erg/s"))
+    else:
+        f_unit = u.Unit("1/TeV") if energy_like else (u.Unit("1/(s TeV cm2)") if particle_like
+                                                      else u.Unit("1/(s TeV)"))
+    return f_unit, sedf
+
+
+def _conversion_to_data(model_unit, data):
+    """per-energy factor taking model values (in model_unit) to data['flux'].unit"""
+    dunit = data["flux"].unit
+    model_is_sed = u.Unit(model_unit).physical_type in ["power", "flux"]
+    data_is_sed = dunit.physical_type in ["power", "flux"]
+    energy = data["energy"]
+    n = np.size(energy.value)
+    if model_is_sed != data_is_sed:
+        _, sedf = sed_conversion(energy, model_unit, data_is_sed)
+        f = (u.Quantity(np.ones(n), model_unit) * sedf).to(dunit).value
+    else:
+        f = np.full(n, u.Unit(model_unit)._factor_to(dunit))
+    return np.ascontiguousarray(f, dtype=float)
+
+
+class _DataOnDevice:
+    """the data columns the likelihood needs, resident in HBM (cached per table)"""
+
+    def __init__(self, ctx, data):
+        dunit = data["flux"].unit
+        self.flux = ctx.const(data["flux"].value)
+        self.elo = ctx.const(data["flux_error_lo"].to(dunit).value)
+        self.ehi = ctx.const(data["flux_error_hi"].to(dunit).value)
+        self.ul = ctx.const(np.asarray(data["ul"]).astype(np.int32), dtype=np.int32)
+        cl = np.broadcast_to(np.asarray(data["cl"], dtype=float), np.shape(data["flux"].value))
+        # cl is indexed by the violation count (core.py:92): pad so that index n_E is valid
+        self.cl = ctx.const(np.concatenate([cl, cl[-1:]]))
+        self.n = int(np.size(data["flux"].value))
+
+
+def lnprobmodel(model, data):
+    """Log-likelihood of ``model`` (Quantity, shape (n_E,) or (N, n_E)) given the data
+    table: asymmetric Gaussian errors plus the upper-limit penalty (core.py:64-94)."""
+    import ctypes as C
+    ctx = get_context()
+    conv = _conversion_to_data(model.unit, data)
+    dd = _DataOnDevice(ctx, data)
+    m = np.asarray(model.value, dtype=float)
+    batched = m.ndim == 2
+    m2 = np.ascontiguousarray(m if batched else m[None, :])
+    N, nE = m2.shape
+    if nE != dd.n:
+        raise ValueError("model has %d energies, data table has %d" % (nE, dd.n))
+    md = ctx.array(m2)
+    lnl = ctx.empty((N,))
+    comps = (C.c_void_p * 1)(md.ptr)
+    cscale = (C.c_double * 1)(1.0)
+    ctx.call("nh_lnprobmodel", comps, cscale, 1, nE, N, nE, ctx.const(conv), dd.flux, dd.elo,
+             dd.ehi, dd.ul, dd.cl, None, lnl)
+    out = lnl.get()
+    return out if batched else float(out[0])
+
+
+def lnprob(pars, data, modelfunc, priorfunc):
+    """(lnprob, *blobs) for one walker or for a batch (core.py:97-121)."""
+    pars = np.asarray(pars, dtype=float)
+    if priorfunc is None:
+        lnprob_priors = 0.0
+    else:
+        lnprob_priors = priorfunc(pars)
+    modelout = modelfunc(pars, data)
+    if isinstance(modelout, (tuple, list)):
+        model = modelout[0]
+        blob = tuple(modelout)
+    else:
+        model = modelout
+        blob = (modelout, np.nan)
+    lp = np.asarray(lnprob_priors, dtype=float)
+    if np.all(np.isinf(lp)):
+        total = lnprob_priors
+    else:
+        lnprob_model = lnprobmodel(model, data)
+        # walkers forbidden by the prior keep the prior value (core.py:115-119)
+        total = np.where(np.isinf(lp), lp, lnprob_model + lp)
+        if total.ndim == 0:
+            total = float(total)
+    return (total, *blob)
+
+
+def get_sampler(*args, **kwargs):
+    from .sampler import get_sampler as _gs
+    return _gs(*args, **kwargs)
+
+
+def run_sampler(*args, **kwargs):
+    from .sampler import run_sampler as _rs
+    return _rs(*args, **kwargs)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build libnaima_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles
+# without a GPU.  Usage: naima_amd/csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libnaima_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+  -Wall -Wno-unused-function "$@" \
+  "$here/nh_core.hip" "$here/nh_synchrotron.hip" "$here/nh_tables.hip" "$here/nh_comm.hip" \
+  -ldl -o "$out"
+echo "built $out"

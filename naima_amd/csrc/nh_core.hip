@@ -1,0 +1,506 @@
+// nh_core.hip -- context/memory, trapz_loglog, particle weights, the generic
+// per-walker table reduction, lnprobmodel and the stretch-move kernels.
+// gfx950 (MI355X) only; FP64 throughout, denormals on, no fast-math.
+#include "nh_common.h"
+
+static thread_local char g_err[512] = "";
+
+int nh_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* nh_last_error(void) { return g_err; }
+extern "C" int nh_version(void) { return 100; }
+
+extern "C" int nh_create(int device, nh_ctx** out) {
+  NH_REQUIRE(out != nullptr, "out is NULL");
+  int ndev = 0;
+  NH_CHECK_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    return nh_set_error(NH_EINVAL, "nh_create: device %d out of range (%d visible)", device, ndev);
+  NH_CHECK_HIP(hipSetDevice(device));
+  nh_ctx* c = new nh_ctx();
+  c->device = device;
+  c->profiling = false;
+  c->comm = nullptr;
+  c->rccl_lib = nullptr;
+  memset(c->acc_ms, 0, sizeof(c->acc_ms));
+  memset(c->acc_n, 0, sizeof(c->acc_n));
+  NH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  NH_CHECK_HIP(hipEventCreate(&c->t0));
+  NH_CHECK_HIP(hipEventCreate(&c->t1));
+  *out = c;
+  return NH_OK;
+}
+
+extern "C" int nh_destroy(nh_ctx* c) {
+  if (!c) return NH_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  nh_comm_destroy(c);
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& e : c->pool) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(c->t0);
+  (void)hipEventDestroy(c->t1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return NH_OK;
+}
+
+extern "C" int nh_device_info(nh_ctx* c, char* name, int name_len, int* cus, double* hbm,
+                              int* clock_khz) {
+  NH_REQUIRE(c, "ctx is NULL");
+  hipDeviceProp_t p;
+  NH_CHECK_HIP(hipGetDeviceProperties(&p, c->device));
+  if (name && name_len > 0) snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+  if (cus) *cus = p.multiProcessorCount;
+  if (hbm) *hbm = (double)p.totalGlobalMem;
+  if (clock_khz) *clock_khz = p.clockRate;
+  return NH_OK;
+}
+
+extern "C" int nh_alloc(nh_ctx* c, long long bytes, void** out) {
+  NH_REQUIRE(c && out && bytes >= 0, "bad argument");
+  NH_CHECK_HIP(hipSetDevice(c->device));
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 8));
+  if (e != hipSuccess) return nh_set_error(NH_ENOMEM, "hipMalloc(%lld): %s", bytes, hipGetErrorString(e));
+  *out = p;
+  return NH_OK;
+}
+
+extern "C" int nh_free(nh_ctx* c, void* p) {
+  NH_REQUIRE(c, "ctx is NULL");
+  if (p) {
+    NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    NH_CHECK_HIP(hipFree(p));
+  }
+  return NH_OK;
+}
+
+extern "C" int nh_upload(nh_ctx* c, void* dst, const void* src, long long bytes) {
+  NH_REQUIRE(c && dst && src && bytes >= 0, "bad argument");
+  // pageable source: hipMemcpyAsync stages it before returning, so the host
+  // buffer may be reused immediately; ordering on the stream is preserved
+  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_download(nh_ctx* c, void* dst, const void* src, long long bytes) {
+  NH_REQUIRE(c && dst && src && bytes >= 0, "bad argument");
+  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_memset(nh_ctx* c, void* p, int byte, long long bytes) {
+  NH_REQUIRE(c && p && bytes >= 0, "bad argument");
+  NH_CHECK_HIP(hipMemsetAsync(p, byte, (size_t)bytes, c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_sync(nh_ctx* c) {
+  NH_REQUIRE(c, "ctx is NULL");
+  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_timer_start(nh_ctx* c) {
+  NH_REQUIRE(c, "ctx is NULL");
+  NH_CHECK_HIP(hipEventRecord(c->t0, c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_timer_stop(nh_ctx* c, double* ms) {
+  NH_REQUIRE(c && ms, "bad argument");
+  NH_CHECK_HIP(hipEventRecord(c->t1, c->stream));
+  NH_CHECK_HIP(hipEventSynchronize(c->t1));
+  float f = 0;
+  NH_CHECK_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+  *ms = f;
+  return NH_OK;
+}
+
+extern "C" int nh_profile_enable(nh_ctx* c, int on) {
+  NH_REQUIRE(c, "ctx is NULL");
+  c->profiling = on != 0;
+  return NH_OK;
+}
+
+extern "C" int nh_profile_read(nh_ctx* c, double* ms, long long* n, int reset) {
+  NH_REQUIRE(c, "ctx is NULL");
+  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (auto& r : c->recs) {
+    float f = 0;
+    NH_CHECK_HIP(hipEventElapsedTime(&f, r.a, r.b));
+    c->acc_ms[r.kid] += f;
+    c->acc_n[r.kid] += 1;
+    c->pool.push_back(r.a);
+    c->pool.push_back(r.b);
+  }
+  c->recs.clear();
+  for (int i = 0; i < NH_K_COUNT; ++i) {
+    if (ms) ms[i] = c->acc_ms[i];
+    if (n) n[i] = c->acc_n[i];
+  }
+  if (reset) {
+    memset(c->acc_ms, 0, sizeof(c->acc_ms));
+    memset(c->acc_n, 0, sizeof(c->acc_n));
+  }
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// row 1: trapz_loglog as written (utils.py:336-348), one wave per row
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_trapz_loglog(const double* __restrict__ y,
+                                                       const double* __restrict__ x, int nrows,
+                                                       int n, double* __restrict__ out) {
+  int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const double* yr = y + (long long)row * n;
+  double acc = 0.0;
+  for (int s = lane; s < n - 1; s += 64) {
+    double y1 = yr[s], y2 = yr[s + 1], x1 = x[s], x2 = x[s + 1];
+    double b = log10(y2 / y1) / log10(x2 / x1);
+    double tp = (y1 * (x2 * pow(x2 / x1, b) - x1)) / (b + 1.0);
+    double tl = x1 * y1 * log(x2 / x1);
+    double t = (fabs(b + 1.0) > 1e-10) ? tp : tl;  // NaN b -> log branch
+    if (y1 == 0.0 || y2 == 0.0 || x1 == x2) t = 0.0;
+    acc += t;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc;
+}
+
+extern "C" int nh_trapz_loglog(nh_ctx* c, const double* y, const double* x, int nrows, int n,
+                               double* out) {
+  NH_REQUIRE(c && y && x && out && nrows >= 0 && n >= 1, "bad argument");
+  if (nrows == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_INTEGRATE);
+  hipLaunchKernelGGL(k_trapz_loglog, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, y, x, nrows,
+                     n, out);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rows 2,3: per-walker particle spectrum on a grid -> weights w = xg*n and the
+// log-ratios dlw[i] = ln|w[i+1]/w[i]| assembled analytically per segment
+// ---------------------------------------------------------------------------
+struct pd_par { double A, e0, al, ec, be, eb, a2; };
+
+__device__ __forceinline__ double pd_eval(int kind, const pd_par& p, double E) {
+  const double xx = E / p.e0;
+  switch (kind) {
+    case NH_PD_POWERLAW:  // models.py:88-92
+      return p.A * pow(xx, -p.al);
+    case NH_PD_ECPL:  // models.py:157-161
+      return p.A * pow(xx, -p.al) * exp(-pow(E / p.ec, p.be));
+    case NH_PD_BROKENPL:
+    case NH_PD_ECBPL: {  // models.py:234-238, 330-335
+      bool below = E < p.eb;
+      double K = below ? 1.0 : pow(p.eb / p.e0, p.a2 - p.al);
+      double n = p.A * K * pow(xx, -(below ? p.al : p.a2));
+      if (kind == NH_PD_ECBPL) n = n * exp(-pow(E / p.ec, p.be));
+      return n;
+    }
+    default: {  // NH_PD_LOGPARABOLA, models.py:402-407
+      double ex = -p.al - p.be * log(xx);
+      return p.A * pow(xx, ex);
+    }
+  }
+}
+
+// ln(f(E2)/f(E1)) of the shape, from small accurate pieces
+__device__ __forceinline__ double pd_dlog(int kind, const pd_par& p, double E1, double E2) {
+  const double lr = log(E2 / E1);
+  double d;
+  switch (kind) {
+    case NH_PD_POWERLAW:
+      d = -p.al * lr;
+      break;
+    case NH_PD_ECPL:
+      d = -p.al * lr - (pow(E2 / p.ec, p.be) - pow(E1 / p.ec, p.be));
+      break;
+    case NH_PD_BROKENPL:
+    case NH_PD_ECBPL: {
+      bool b1 = E1 < p.eb, b2 = E2 < p.eb;
+      if (b1 == b2) {
+        d = -(b1 ? p.al : p.a2) * lr;
+      } else {  // the one segment that straddles the break
+        double lK = (p.a2 - p.al) * log(p.eb / p.e0);
+        d = (b2 ? 0.0 : lK) - (b1 ? 0.0 : lK) -
+            ((b2 ? p.al : p.a2) * log(E2 / p.e0) - (b1 ? p.al : p.a2) * log(E1 / p.e0));
+      }
+      if (kind == NH_PD_ECBPL) d -= (pow(E2 / p.ec, p.be) - pow(E1 / p.ec, p.be));
+    } break;
+    default: {
+      double l1 = log(E1 / p.e0), l2 = log(E2 / p.e0);
+      d = -p.al * lr - p.be * lr * (l1 + l2);
+    } break;
+  }
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_particle_weights(
+    int kind, const double* __restrict__ params, int N, const double* __restrict__ e,
+    const double* __restrict__ xg, int nG, double unit_scale, double* __restrict__ w,
+    double* __restrict__ dlw, double* __restrict__ nout) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)N * nG) return;
+  int wi = (int)(idx / nG), i = (int)(idx % nG);
+  const double* pr = params + (long long)wi * NH_PD_NPAR;
+  pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  const double E = e[i];
+  double n = pd_eval(kind, p, E) * unit_scale;
+  const double g = xg[i];
+  w[idx] = g * n;
+  if (nout) nout[idx] = n;
+  dlw[idx] = (i + 1 < nG) ? log(xg[i + 1] / g) + pd_dlog(kind, p, E, e[i + 1]) : 0.0;
+}
+
+extern "C" int nh_particle_weights(nh_ctx* c, int kind, const double* params, int N,
+                                   const double* e_eV, const double* xg, int nG,
+                                   double unit_scale, double* w, double* dlw, double* n_out) {
+  NH_REQUIRE(c && params && e_eV && xg && w && dlw, "NULL pointer");
+  NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
+  NH_REQUIRE(N >= 0 && nG >= 2, "need N >= 0 and nG >= 2");
+  if (N == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_PDIST);
+  long long tot = (long long)N * nG;
+  hipLaunchKernelGGL(k_particle_weights, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, kind, params, N, e_eV, xg, nG, unit_scale, w, dlw, n_out);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+__global__ void k_grid_logratio(const double* __restrict__ xg, int nG, double* __restrict__ lx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nG - 1) lx[i] = log(xg[i + 1] / xg[i]);
+}
+
+extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx) {
+  NH_REQUIRE(c && xg && lx && nG >= 2, "bad argument");
+  nh_prof_scope ps(c, NH_K_PDIST);
+  hipLaunchKernelGGL(k_grid_logratio, dim3((nG + 255) / 256), dim3(256), 0, c->stream, xg, nG, lx);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the generic per-walker reduction.  Lanes run over flattened (walker, k)
+// pairs -- coalesced reads of the transposed table rows Kt[i][*] -- and the C
+// waves of a block split the abscissa range; each thread walks its chunk
+// sequentially carrying the previous node in registers (no shuffles), and the
+// C partial sums meet in LDS.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(64 * C) void k_integrate_tables(
+    const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
+    const double* __restrict__ lx, const double* __restrict__ Kt,
+    const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
+    double* __restrict__ out, int ldo) {
+  __shared__ double part[C][64];
+  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+  const long long pair = (long long)blockIdx.x * 64 + lane;
+  const bool valid = pair < (long long)N * nK;
+  const int wi = valid ? (int)(pair / nK) : 0;
+  const int k = valid ? (int)(pair % nK) : 0;
+  const int nseg = nG - 1;
+  const int per = (nseg + C - 1) / C;
+  const int s0 = ch * per;
+  const int s1 = min(nseg, s0 + per);
+  const double* wr = w + (long long)wi * nG;
+  const double* dwr = dlw + (long long)wi * nG;
+  const double* Kc = Kt + k;
+  const double* dKc = dlnKt + k;
+  double acc = 0.0;
+  if (s0 < s1) {
+    double u1 = wr[s0] * Kc[(long long)s0 * nK];
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      double u2 = wr[s + 1] * Kc[(long long)(s + 1) * nK];
+      double dl = dwr[s] + dKc[(long long)s * nK];
+      acc += nh_seg_term(u1, u2, dl, lx[s]);
+      u1 = u2;
+    }
+  }
+  part[ch][lane] = acc;
+  __syncthreads();
+  if (ch == 0 && valid) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) s += part[j][lane];
+    out[(long long)wi * ldo + k] = scale ? s * scale[k] : s;
+  }
+}
+
+extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
+                                   const double* lx, const double* Kt, const double* dlnKt,
+                                   int nK, const double* scale, double* out, int ldo) {
+  NH_REQUIRE(c && w && dlw && lx && Kt && dlnKt && out, "NULL pointer");
+  NH_REQUIRE(N >= 0 && nG >= 2 && nK >= 1 && ldo >= nK, "bad sizes");
+  if (N == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_INTEGRATE);
+  long long pairs = (long long)N * nK;
+  unsigned blocks = (unsigned)((pairs + 63) / 64);
+  int nseg = nG - 1;
+  // chunk the abscissa so that the grid has enough waves to fill 256 CUs
+  int C = nseg >= 512 ? 8 : (nseg >= 128 ? 4 : (nseg >= 32 ? 2 : 1));
+  if ((long long)blocks * C < 2048 && nseg >= 256) C = 8;
+#define NH_LAUNCH_INT(CC)                                                                     \
+  hipLaunchKernelGGL((k_integrate_tables<CC>), dim3(blocks), dim3(64 * CC), 0, c->stream, w, \
+                     dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
+  switch (C) {
+    case 8: NH_LAUNCH_INT(8); break;
+    case 4: NH_LAUNCH_INT(4); break;
+    case 2: NH_LAUNCH_INT(2); break;
+    default: NH_LAUNCH_INT(1); break;
+  }
+#undef NH_LAUNCH_INT
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// row 11: lnprobmodel (core.py:64-94), one wave per walker
+// ---------------------------------------------------------------------------
+struct nh_comps {
+  const double* p[4];
+  double s[4];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int ldc, int N, int nE,
+                                                      const double* __restrict__ conv,
+                                                      const double* __restrict__ flux,
+                                                      const double* __restrict__ elo,
+                                                      const double* __restrict__ ehi,
+                                                      const int* __restrict__ ul,
+                                                      const double* __restrict__ cl,
+                                                      double* __restrict__ model_out,
+                                                      double* __restrict__ lnl) {
+  const int lane = threadIdx.x & 63;
+  const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= N) return;
+  double acc = 0.0;
+  int nviol = 0, nul = 0;
+  for (int k = lane; k < nE; k += 64) {
+    double m = 0.0;
+    for (int j = 0; j < cs.n; ++j) m += cs.s[j] * cs.p[j][(long long)wi * ldc + k];
+    if (model_out) model_out[(long long)wi * nE + k] = m;
+    double mc = m * conv[k];
+    double f = flux[k];
+    if (ul[k]) {
+      nul += 1;
+      nviol += (mc > f) ? 1 : 0;
+    } else {
+      double d = mc - f;
+      double sg = (d > 0.0) ? ehi[k] : elo[k];
+      acc += -(d * d) / (2.0 * (sg * sg));
+    }
+  }
+  acc = wave_sum(acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nviol += __shfl_down(nviol, off, 64);
+    nul += __shfl_down(nul, off, 64);
+  }
+  if (lane == 0) {
+    // quirk kept from core.py:89-92: cl is indexed by the violation count
+    if (nul > 0) acc += (double)nviol * log(1.0 - cl[nviol]);
+    lnl[wi] = acc;
+  }
+}
+
+extern "C" int nh_lnprobmodel(nh_ctx* c, const double* const* comps, const double* cscale,
+                              int ncomp, int ldc, int N, int nE, const double* conv,
+                              const double* flux, const double* err_lo, const double* err_hi,
+                              const int* ul, const double* cl, double* model_out, double* lnl) {
+  NH_REQUIRE(c && comps && cscale && conv && flux && err_lo && err_hi && ul && cl && lnl,
+             "NULL pointer");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= 4, "ncomp must be 1..4");
+  NH_REQUIRE(N >= 0 && nE >= 1 && ldc >= nE, "bad sizes");
+  if (N == 0) return NH_OK;
+  nh_comps cs;
+  cs.n = ncomp;
+  for (int j = 0; j < 4; ++j) {
+    cs.p[j] = j < ncomp ? comps[j] : nullptr;
+    cs.s[j] = j < ncomp ? cscale[j] : 0.0;
+  }
+  nh_prof_scope ps(c, NH_K_LNPROB);
+  hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, ldc, N, nE,
+                     conv, flux, err_lo, err_hi, ul, cl, model_out, lnl);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stretch move (emcee StretchMove.get_proposal / RedBlueMove accept step)
+// ---------------------------------------------------------------------------
+__global__ void k_stretch_propose(const double* __restrict__ s, const double* __restrict__ cset,
+                                  const int* __restrict__ partner, const double* __restrict__ z,
+                                  int ns, int ndim, double* __restrict__ q,
+                                  double* __restrict__ factors) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ns * ndim) return;
+  int j = idx / ndim, d = idx % ndim;
+  double cj = cset[(long long)partner[j] * ndim + d];
+  q[idx] = cj - (cj - s[idx]) * z[j];
+  if (d == 0) factors[j] = (ndim - 1.0) * log(z[j]);
+}
+
+extern "C" int nh_stretch_propose(nh_ctx* c, const double* s, const double* cset,
+                                  const int* partner, const double* z, int ns, int ndim,
+                                  double* q, double* factors) {
+  NH_REQUIRE(c && s && cset && partner && z && q && factors && ns >= 0 && ndim >= 1,
+             "bad argument");
+  if (ns == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_SAMPLER);
+  int tot = ns * ndim;
+  hipLaunchKernelGGL(k_stretch_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, s,
+                     cset, partner, z, ns, ndim, q, factors);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+__global__ void k_stretch_accept(double* __restrict__ s, double* __restrict__ oldlp,
+                                 const double* __restrict__ q, const double* __restrict__ newlp,
+                                 const double* __restrict__ factors,
+                                 const double* __restrict__ lnu, int ns, int ndim,
+                                 int* __restrict__ accepted) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  double d = factors[j] + newlp[j] - oldlp[j];
+  bool acc = lnu[j] < d;  // NaN -> rejected, as numpy's comparison
+  if (acc) {
+    for (int k = 0; k < ndim; ++k) s[(long long)j * ndim + k] = q[(long long)j * ndim + k];
+    oldlp[j] = newlp[j];
+  }
+  accepted[j] = acc ? 1 : 0;
+}
+
+extern "C" int nh_stretch_accept(nh_ctx* c, double* s, double* oldlp, const double* q,
+                                 const double* newlp, const double* factors, const double* lnu,
+                                 int ns, int ndim, int* accepted) {
+  NH_REQUIRE(c && s && oldlp && q && newlp && factors && lnu && accepted && ns >= 0 && ndim >= 1,
+             "bad argument");
+  if (ns == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_SAMPLER);
+  hipLaunchKernelGGL(k_stretch_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, s, oldlp,
+                     q, newlp, factors, lnu, ns, ndim, accepted);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}

@@ -1,0 +1,512 @@
+// nh_tables.hip -- walker-independent emission kernels K(E_k, x_i) written as
+// transposed tables Kt[i][k] (+ ln|Kt|) for nh_integrate_tables.
+//
+// In the reference these matrices are rebuilt for every walker because emcee
+// calls lnprob one walker at a time (core.py:450-457); they depend only on the
+// grids, the photon energies and the seed-field / target parameters, so a
+// batched call builds them ONCE per call (n_E*n_x elements, microseconds) and
+// spends the per-walker work in the reduction.  Nothing is cached across calls.
+#include "nh_common.h"
+
+#define NH_TAB_PROLOGUE                                                  \
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
+  if (idx >= (long long)nG * nE) return;                                 \
+  const int i = (int)(idx / nE), k = (int)(idx % nE);
+
+#define NH_TAB_AT ((long long)i * ld + k)
+
+// second pass of every builder: dlnKt[i][k] = ln|K[i+1][k] / K[i][k]| -- the
+// log-ratio of ADJACENT nodes, accurate to ~2 ulp however large ln K itself is
+__global__ __launch_bounds__(256) void k_table_dlog(const double* __restrict__ Kt, int nG, int nE,
+                                                     int ld, double* __restrict__ dlnKt) {
+  NH_TAB_PROLOGUE
+  double v = 0.0;
+  if (i + 1 < nG) v = log(fabs(Kt[(long long)(i + 1) * ld + k] / Kt[NH_TAB_AT]));
+  dlnKt[NH_TAB_AT] = v;
+}
+
+static int table_dlog(nh_ctx* c, const double* Kt, int nG, int nE, int ld, double* dlnKt) {
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_dlog, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                     Kt, nG, nE, ld, dlnKt);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rows 6,7: Khangulyan+14 Eq. 14 / Eq. 11 (radiative.py:547-607, G12/G34 345-367)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ic_g(double x, double al, double a, double be, double b) {
+  return 1.0 / (a * pow(x, al) / (1.0 + b * pow(x, be)) + 1.0);
+}
+__device__ __forceinline__ double ic_G34(double x, double al, double a, double be, double b,
+                                         double cc) {
+  double G = NH_PI26 * ((1.0 + cc * x) / (1.0 + NH_PI26 * cc * x)) * exp(-x);
+  return G * ic_g(x, al, a, be, b);
+}
+__device__ __forceinline__ double ic_G12(double x, double al, double a, double be, double b) {
+  double G = (NH_PI26 + x) * exp(-x);
+  return G * ic_g(x, al, a, be, b);
+}
+
+__global__ __launch_bounds__(256) void k_table_ic_planck(const double* __restrict__ gam, int nG,
+                                                          const double* __restrict__ E_eV,
+                                                          int nE, double T_K, double theta,
+                                                          double* __restrict__ Kt, int ld) {
+  NH_TAB_PROLOGUE
+  const double Tp = T_K * NH_K_TO_MEC2;
+  const double g = gam[i];
+  const double eg = E_eV[k] / NH_MEC2_EV;
+  const double z = eg / g;
+  double cs;
+  if (theta < 0.0) {
+    double x = z / (1.0 - z) / (4.0 * g * Tp);
+    cs = z * z / (2.0 * (1.0 - z)) * ic_G34(x, 0.606, 0.443, 1.481, 0.540, 0.319) +
+         ic_G34(x, 0.461, 0.726, 1.457, 0.382, 6.620);
+  } else {
+    double tt = 2.0 * g * Tp * (1.0 - cos(theta));
+    double x = z / (1.0 - z) / tt;
+    cs = z * z / (2.0 * (1.0 - z)) * ic_G12(x, 0.857, 0.153, 1.840, 0.254) +
+         ic_G12(x, 0.691, 1.330, 1.668, 0.534);
+  }
+  double pref = (Tp / g) * (Tp / g);
+  pref *= NH_IC_PLANCK_NORM;
+  const bool ok = (eg < g) && (g > 1.0);
+  Kt[NH_TAB_AT] = ok ? pref * cs : 0.0;
+}
+
+extern "C" int nh_table_ic_planck(nh_ctx* c, const double* gam, int nG, const double* E_eV,
+                                  int nE, double T_K, double theta_rad, double* Kt,
+                                  double* lnKt, int ld) {
+  NH_REQUIRE(c && gam && E_eV && Kt && lnKt && nG >= 2 && nE >= 1, "bad argument");
+  NH_REQUIRE(T_K > 0.0, "seed temperature must be positive");
+  nh_prof_scope ps(c, NH_K_TABLES);
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_ic_planck, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, gam, nG, E_eV, nE, T_K, theta_rad, Kt, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  return table_dlog(c, Kt, nG, nE, ld, lnKt);
+}
+
+// ---------------------------------------------------------------------------
+// row 8: Aharonian & Atoyan 81 Eq. 22 (radiative.py:609-655)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double ic_fic_windowed(double e0, double g, double eg) {
+  double b = 4.0 * e0 * g;
+  double wq = eg / g;
+  double q = wq / (b * (1.0 - wq));
+  double bq = b * q;
+  double fic = 2.0 * q * log(q) + (1.0 + 2.0 * q) * (1.0 - q) +
+               0.5 * (bq * bq) * (1.0 - q) / (1.0 + bq);
+  double gi = fic * nh_heaviside(1.0 - q) * nh_heaviside(q - 1.0 / (4.0 * (g * g)));
+  return (gi != gi) ? 0.0 : gi;  // gamint[isnan] = 0, radiative.py:636
+}
+
+// inner reduction over the seed spectrum for one (E_k, gamma_i): trapz_loglog of
+// fic*n_ph/eps0 over eps0 (radiative.py:638-640), in the u/l form of nh_seg_term
+__device__ __forceinline__ double ic_seed_inner(const double* __restrict__ se,
+                                                const double* __restrict__ sd, int ns, double g,
+                                                double eg) {
+  if (ns == 1) {
+    double e0 = se[0] / NH_MEC2_EV;
+    double dens = sd[0] / NH_MEC2_EV;  // eV/cm3 -> mec2/cm3, radiative.py:642
+    return ic_fic_windowed(e0, g, eg) * (dens / (e0 * e0));
+  }
+  double acc = 0.0;
+  double e1 = se[0] / NH_MEC2_EV;
+  double u1 = ic_fic_windowed(e1, g, eg) * (sd[0] * NH_MEC2_EV);  // y*x = fic*n_ph
+  for (int s = 1; s < ns; ++s) {
+    double e2 = se[s] / NH_MEC2_EV;
+    double u2 = ic_fic_windowed(e2, g, eg) * (sd[s] * NH_MEC2_EV);
+    acc += nh_seg_term(u1, u2, log(fabs(u2 / u1)), log(e2 / e1));
+    e1 = e2; u1 = u2;
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void k_table_ic_seed(const double* __restrict__ gam, int nG,
+                                                        const double* __restrict__ E_eV, int nE,
+                                                        const double* __restrict__ se,
+                                                        const double* __restrict__ sd, int ns,
+                                                        double* __restrict__ Kt, int ld) {
+  NH_TAB_PROLOGUE
+  const double g = gam[i];
+  const double eg = E_eV[k] / NH_MEC2_EV;
+  double gi = ic_seed_inner(se, sd, ns, g, eg);
+  gi *= (3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g);  // radiative.py:650-653
+  Kt[NH_TAB_AT] = gi;
+}
+
+extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const double* E_eV, int nE,
+                                const double* seed_E, const double* seed_dens, int ns,
+                                double* Kt, double* lnKt, int ld) {
+  NH_REQUIRE(c && gam && E_eV && seed_E && seed_dens && Kt && lnKt, "NULL pointer");
+  NH_REQUIRE(nG >= 2 && nE >= 1 && ns >= 1, "bad sizes");
+  nh_prof_scope ps(c, NH_K_TABLES);
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_ic_seed, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, gam, nG, E_eV, nE, seed_E, seed_dens, ns, Kt, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  return table_dlog(c, Kt, nG, nE, ld, lnKt);
+}
+
+// SSC: the seed density depends on the walker, so the (n_s x n_E x n_gam) double
+// reduction is done per walker.  Lanes over (walker,k) pairs, waves over gamma
+// chunks, inner sequential loop over the seed energies.
+template <int C>
+__global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
+    const double* __restrict__ w, const double* __restrict__ dlw, int N,
+    const double* __restrict__ gam, const double* __restrict__ lx, int nG,
+    const double* __restrict__ E_eV, int nE, const double* __restrict__ se,
+    const double* __restrict__ sd, int ns, double* __restrict__ out, int ldo) {
+  __shared__ double part[C][64];
+  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+  const long long pair = (long long)blockIdx.x * 64 + lane;
+  const bool valid = pair < (long long)N * nE;
+  const int wi = valid ? (int)(pair / nE) : 0;
+  const int k = valid ? (int)(pair % nE) : 0;
+  const double E = E_eV[k];
+  const double eg = E / NH_MEC2_EV;
+  const double* sdw = sd + (long long)wi * ns;
+  const int nseg = nG - 1;
+  const int per = (nseg + C - 1) / C;
+  const int s0 = ch * per, s1 = min(nseg, s0 + per);
+  const double* wr = w + (long long)wi * nG;
+  const double* dwr = dlw + (long long)wi * nG;
+  double acc = 0.0;
+  if (s0 < s1) {
+    auto node = [&](int i) {
+      double g = gam[i];
+      return ic_seed_inner(se, sdw, ns, g, eg) * ((3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g));
+    };
+    double K1 = node(s0);
+    for (int s = s0; s < s1; ++s) {
+      double K2 = node(s + 1);
+      double dl = dwr[s] + log(fabs(K2 / K1));
+      acc += nh_seg_term(wr[s] * K1, wr[s + 1] * K2, dl, lx[s]);
+      K1 = K2;
+    }
+  }
+  part[ch][lane] = acc;
+  __syncthreads();
+  if (ch == 0 && valid) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) s += part[j][lane];
+    // lum = uf*Eph*integral, spec = lum/E   (uf = 1), radiative.py:676-687
+    out[(long long)wi * ldo + k] = s * eg / E;
+  }
+}
+
+extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw, int N,
+                                  const double* gam, const double* lx, int nG,
+                                  const double* E_eV, int nE, const double* seed_E,
+                                  const double* seed_dens, int ns, double* out, int ldo) {
+  NH_REQUIRE(c && w && dlw && gam && lx && E_eV && seed_E && seed_dens && out, "NULL pointer");
+  NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ns >= 2 && ldo >= nE, "bad sizes");
+  if (N == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_SSC);
+  long long pairs = (long long)N * nE;
+  unsigned blocks = (unsigned)((pairs + 63) / 64);
+  hipLaunchKernelGGL((k_ic_seed_walkers<16>), dim3(blocks), dim3(1024), 0, c->stream, w, dlw, N,
+                     gam, lx, nG, E_eV, nE, seed_E, seed_dens, ns, out, ldo);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// row 10: Baring+99 bremsstrahlung cross sections (radiative.py:838-928), cm2/eV
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double br_sigma_1(double g, double eps) {
+  double s1 = 4.0 * (NH_R0_CM * NH_R0_CM) * NH_ALPHA_FS / eps;
+  double s2 = 1.0 + (1.0 / 3.0 - eps / g) * (1.0 - eps / g);
+  double s3 = log(2.0 * g * (g - eps) / eps) - 0.5;
+  if (g < eps) s3 = 0.0;
+  return s1 * s2 * s3;
+}
+
+__device__ __forceinline__ double br_sigma_2(double g, double eps) {
+  double s0 = (NH_R0_CM * NH_R0_CM) * NH_ALPHA_FS / (3.0 * eps);
+  double e2 = eps * eps, e3 = e2 * eps;
+  double v;
+  if (eps <= 0.5) {
+    v = 16.0 * (1.0 - eps + e2) * log(g / eps) + (-1.0 / e2 + 3.0 / eps - 4.0 - 4.0 * eps - 8.0 * e2) +
+        (-2.0 * (1.0 - 2.0 * eps) * log(1.0 - 2.0 * eps)) *
+            (1.0 / (4.0 * e3) - 1.0 / (2.0 * e2) + 3.0 / eps - 2.0 + 4.0 * eps);
+  } else {
+    v = (2.0 / eps) * ((4.0 - 1.0 / eps + 1.0 / (4.0 * e2)) * log(2.0 * g) +
+                       (-2.0 + 2.0 / eps - 5.0 / (8.0 * e2)));
+  }
+  return s0 * v * nh_heaviside(g - eps);
+}
+
+__device__ __forceinline__ double br_F(double x, double g) {  // A6, A7
+  double g2 = g * g;
+  double beta = sqrt(1.0 - 1.0 / g2);
+  double B = 1.0 + 0.5 * (g2 - 1.0);
+  double Cc = 10.0 * x * g * beta * (2.0 + g * beta);
+  Cc = Cc / (1.0 + x * x * (g2 - 1.0));
+  double tmx = 2.0 - x;
+  double F1 = (17.0 - 3.0 * x * x / (tmx * tmx) - Cc) * sqrt(1.0 - x);
+  double F2 = 12.0 * tmx - 7.0 * x * x / tmx - 3.0 * (x * x) * (x * x) / (tmx * tmx * tmx);
+  double F3 = log((1.0 + sqrt(1.0 - x)) / sqrt(x));
+  return B * F1 + F2 * F3;
+}
+
+__global__ __launch_bounds__(256) void k_table_brems(const double* __restrict__ gam, int nG,
+                                                      const double* __restrict__ E_eV, int nE,
+                                                      double* __restrict__ Kee,
+                                                      double* __restrict__ Kep, int ld) {
+  NH_TAB_PROLOGUE
+  const double g = gam[i];
+  const double eps = E_eV[k] / NH_MEC2_EV;
+  const double gtrans = 2e6 / NH_MEC2_EV;  // 2 MeV, radiative.py:914
+  const double s1 = br_sigma_1(g, eps);
+  double see;
+  if (g <= gtrans) {  // non-relativistic, A5 (radiative.py:898-908)
+    double s0 = 4.0 * (NH_R0_CM * NH_R0_CM) * NH_ALPHA_FS / (15.0 * eps);
+    double x = 4.0 * eps / (g * g - 1.0);
+    see = s0 * br_F(x, g);
+    if (eps >= 0.25 * (g * g - 1.0)) see = 0.0;
+    if (g < 1.0) see = 0.0;
+  } else {  // relativistic, A1 + A4 (radiative.py:873-880)
+    double A = 1.0 - 8.0 / 3.0 * pow(g - 1.0, 0.2) / (g + 1.0) * pow(eps / g, 1.0 / 3.0);
+    see = (s1 + br_sigma_2(g, eps)) * A;
+  }
+  Kee[NH_TAB_AT] = see / NH_MEC2_EV;
+  Kep[NH_TAB_AT] = s1 / NH_MEC2_EV;
+}
+
+extern "C" int nh_table_brems(nh_ctx* c, const double* gam, int nG, const double* E_eV, int nE,
+                              double* Kt_ee, double* lnKt_ee, double* Kt_ep, double* lnKt_ep, int ld) {
+  NH_REQUIRE(c && gam && E_eV && Kt_ee && lnKt_ee && Kt_ep && lnKt_ep && nG >= 2 && nE >= 1,
+             "bad argument");
+  nh_prof_scope ps(c, NH_K_TABLES);
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_brems, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                     gam, nG, E_eV, nE, Kt_ee, Kt_ep, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  int rc = table_dlog(c, Kt_ee, nG, nE, ld, lnKt_ee);
+  return rc ? rc : table_dlog(c, Kt_ep, nG, nE, ld, lnKt_ep);
+}
+
+// ---------------------------------------------------------------------------
+// row 9: Kafexhiu+14 pp -> pi0 -> gamma differential cross section
+// ---------------------------------------------------------------------------
+struct pp_model {
+  double a[5];    // Table IV   (radiative.py:1179-1183)
+  double f[4];    // Table V hi (radiative.py:1194-1197)
+  double b[3];    // Table VII  (radiative.py:1202-1205)
+  double etrans;  // radiative.py:1209
+};
+
+__device__ __forceinline__ double pp_sigma_inel(double Tp) {  // radiative.py:1215-1233
+  double L = log(Tp / NH_T_TH_GEV);
+  double s = 30.7 - 0.96 * L + 0.18 * (L * L);
+  s *= pow(1.0 - pow(NH_T_TH_GEV / Tp, 1.9), 3.0);
+  return s * 1e-27;
+}
+
+__device__ double pp_sigma_pi_lo(double Tp) {  // radiative.py:1235-1266
+  const double mp = NH_M_P_GEV, mpi = NH_M_PI_GEV, Mres = 1.1883, Gres = 0.2264;
+  double s = 2.0 * mp * (Tp + 2.0 * mp);
+  double gamma = sqrt(Mres * Mres * (Mres * Mres + Gres * Gres));
+  double K = sqrt(8.0) * Mres * Gres * gamma;
+  K = K / (NH_PI * sqrt(Mres * Mres + gamma));
+  double fBW = mp * K;
+  double d = (sqrt(s) - mp) * (sqrt(s) - mp) - Mres * Mres;
+  fBW = fBW / (d * d + Mres * Mres * Gres * Gres);
+  double t = s - mpi * mpi - 4.0 * mp * mp;
+  double mu = sqrt(t * t - 16.0 * mpi * mpi * mp * mp);
+  mu = mu / (2.0 * mpi * sqrt(s));
+  double s1 = 7.66e-3 * pow(mu, 1.95) * (1.0 + mu + pow(mu, 5.0)) * pow(fBW, 1.86);
+  double s2 = 5.7 / (1.0 + exp(-9.3 * (Tp - 1.4)));
+  if (Tp < 0.56) s2 = 0.0;
+  return (s1 + s2) * 1e-27;
+}
+
+__device__ __forceinline__ double pp_sigma_pi_mid(double Tp) {  // radiative.py:1268-1275
+  double Qp = (Tp - NH_T_TH_GEV) / NH_M_P_GEV;
+  return pp_sigma_inel(Tp) * (-6e-3 + 0.237 * Qp - 0.023 * (Qp * Qp));
+}
+
+__device__ __forceinline__ double pp_sigma_pi_hi(double Tp, const double* a) {  // 1277-1286
+  double csip = (Tp - 3.0) / NH_M_P_GEV;
+  double m1 = a[0] * pow(csip, a[3]) * (1.0 + exp(-a[1] * pow(csip, a[4])));
+  double m2 = 1.0 - exp(-a[2] * pow(csip, 0.25));
+  return pp_sigma_inel(Tp) * (m1 * m2);
+}
+
+__device__ __forceinline__ double pp_EpimaxLAB(double Tp) {  // radiative.py:1325-1336
+  const double mp = NH_M_P_GEV, mpi = NH_M_PI_GEV;
+  double s = 2.0 * mp * (Tp + 2.0 * mp);
+  double EpiCM = (s - 4.0 * mp * mp + mpi * mpi) / (2.0 * sqrt(s));
+  double PpiCM = sqrt(EpiCM * EpiCM - mpi * mpi);
+  double gCM = (Tp + 2.0 * mp) / sqrt(s);
+  double betaCM = sqrt(1.0 - 1.0 / (gCM * gCM));
+  return gCM * (EpiCM + PpiCM * betaCM);
+}
+
+__device__ double pp_diffsigma(double Ep, double Eg, const pp_model& M, const double* aG4,
+                               int nuc) {
+  const double mp = NH_M_P_GEV, mpi = NH_M_PI_GEV;
+  const double Tp = Ep - mp;
+  // --- sigma_pi, radiative.py:1288-1304
+  double spi;
+  if (Tp < 2.0) spi = pp_sigma_pi_lo(Tp);
+  else if (Tp < 5.0) spi = pp_sigma_pi_mid(Tp);
+  else if (Tp < M.etrans) spi = pp_sigma_pi_hi(Tp, aG4);
+  else spi = pp_sigma_pi_hi(Tp, M.a);
+  // --- Amax, radiative.py:1306-1367
+  const double EpimaxLAB = pp_EpimaxLAB(Tp);
+  double Amax;
+  if (Tp < 1.0) {
+    Amax = 5.9 * spi / EpimaxLAB;
+  } else {
+    double b1, b2, b3;
+    if (Tp < 5.0) { b1 = 9.53; b2 = 0.52; b3 = 0.054; }
+    else if (Tp < M.etrans) { b1 = 9.13; b2 = 0.35; b3 = 9.7e-3; }
+    else { b1 = M.b[0]; b2 = M.b[1]; b3 = M.b[2]; }
+    double th = Tp / mp;
+    double lt = log(th);
+    Amax = b1 * pow(th, -b2) * exp(b3 * (lt * lt)) * spi / mp;
+  }
+  // --- F(Tp, Egamma), radiative.py:1369-1438 (later ranges override earlier)
+  double F = 0.0;
+  {
+    double lam, alp, bet, gm;
+    bool inr = true;
+    double q = (Tp - 1.0) / mp;
+    double mu = 1.25 * pow(q, 1.25) * exp(-1.25 * q);
+    if (Tp > M.etrans) { lam = M.f[0]; alp = M.f[1]; bet = M.f[2]; gm = M.f[3]; }
+    else if (Tp > 20.0 && Tp <= 100.0) { lam = 3.0; alp = 0.5; bet = 4.2; gm = 1.0; }
+    else if (Tp > 4.0 && Tp <= 20.0) { lam = 3.0; alp = 1.0; bet = 1.5 * mu + 4.95; gm = mu + 1.50; }
+    else if (Tp > 1.0 && Tp <= 4.0) { lam = 3.0; alp = 1.0; bet = mu + 2.45; gm = mu + 1.45; }
+    else if (Tp >= NH_T_TH_GEV && Tp <= 1.0) {
+      lam = 1.0; alp = 1.0; bet = 3.29 - pow(Tp / mp, -1.5) / 5.0; gm = 0.0;
+    } else { inr = false; lam = alp = bet = gm = 0.0; }
+    if (inr) {
+      double gpi = EpimaxLAB / mpi;  // radiative.py:1338-1345
+      double bpi = sqrt(1.0 - 1.0 / (gpi * gpi));
+      double Egmax = (mpi / 2.0) * gpi * (1.0 + bpi);
+      double Yg = Eg + mpi * mpi / (4.0 * Eg);
+      double Ygmax = Egmax + mpi * mpi / (4.0 * Egmax);
+      double Xg = (Yg - mpi) / (Ygmax - mpi);
+      if (Xg > 1.0) Xg = 1.0;
+      double Cc = lam * mpi / Ygmax;
+      F = pow(1.0 - pow(Xg, alp), bet);
+      F = F / pow(1.0 + Xg / Cc, gm);
+    }
+  }
+  double ds = Amax * F;
+  if (nuc) {  // radiative.py:1455-1482
+    const double sRpp = 10.0 * NH_PI * 1e-27;
+    double sin_ = pp_sigma_inel(Tp);
+    double f = sin_ / pp_sigma_inel(1e3);
+    double G = 1.0 + log(f > 1.0 ? f : 1.0);
+    double eps = (Tp > NH_T_TH_GEV) ? 1.37 + (0.29 + 0.1) * sRpp * G / sin_ : 0.0;
+    if (Tp > NH_T_TH_GEV && Tp < 1.0) eps = 1.9141;
+    ds *= eps;
+  }
+  return ds;
+}
+
+__global__ __launch_bounds__(256) void k_table_pion_analytic(const double* __restrict__ Ep,
+                                                              int nG,
+                                                              const double* __restrict__ E_eV,
+                                                              int nE, pp_model M, pp_model G4,
+                                                              int nuc, double* __restrict__ Kt, int ld) {
+  NH_TAB_PROLOGUE
+  double ds = pp_diffsigma(Ep[i], E_eV[k] * 1e-9, M, G4.a, nuc);
+  Kt[NH_TAB_AT] = ds;
+}
+
+static pp_model pp_get_model(int m) {
+  static const pp_model models[4] = {
+      {{0.728, 0.596, 0.491, 0.2503, 0.117}, {3.0, 0.5, 4.9, 1.0}, {9.13, 0.35, 9.7e-3}, 100.0},
+      {{0.652, 0.0016, 0.488, 0.1928, 0.483}, {3.5, 0.5, 4.0, 1.0}, {9.06, 0.3795, 0.01105}, 50.0},
+      {{5.436, 0.254, 0.072, 0.075, 0.166}, {3.55, 0.5, 3.6, 1.0}, {10.77, 0.412, 0.01264}, 100.0},
+      {{0.908, 0.0009, 6.089, 0.176, 0.448}, {3.55, 0.5, 4.5, 1.0}, {13.16, 0.4419, 0.01439}, 100.0}};
+  return models[m];
+}
+
+extern "C" int nh_table_pion_analytic(nh_ctx* c, const double* Ep_GeV, int nG,
+                                      const double* E_eV, int nE, int hiE, int nuc, double* Kt,
+                                      double* lnKt, int ld) {
+  NH_REQUIRE(c && Ep_GeV && E_eV && Kt && lnKt && nG >= 2 && nE >= 1, "bad argument");
+  NH_REQUIRE(hiE >= NH_PP_GEANT4 && hiE <= NH_PP_QGSJET, "unknown hiEmodel");
+  nh_prof_scope ps(c, NH_K_TABLES);
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_pion_analytic, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, Ep_GeV, nG, E_eV, nE, pp_get_model(hiE),
+                     pp_get_model(NH_PP_GEANT4), nuc, Kt, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  return table_dlog(c, Kt, nG, nE, ld, lnKt);
+}
+
+// --- LookupTable (radiative.py:1770-1797): FITPACK bispev for kx = ky = 3 ----
+__device__ __forceinline__ int bspl_locate(const double* __restrict__ t, int n, double& x) {
+  // fpbisp: clamp to [t[3], t[n-4]], then the knot interval t[l] <= x < t[l+1]
+  double tb = t[3], te = t[n - 4];
+  if (x < tb) x = tb;
+  if (x > te) x = te;
+  int lo = 3, hi = n - 5;  // largest l in [3, n-5] with t[l] <= x
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (t[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void bspl_basis(const double* __restrict__ t, int l, double x,
+                                           double h[4]) {
+  // fpbspl with k = 3 (de Boor / Cox recurrence)
+  double hh[3];
+  h[0] = 1.0;
+  for (int j = 1; j <= 3; ++j) {
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.0;
+    for (int i = 1; i <= j; ++i) {
+      double tli = t[l + i], tlj = t[l + i - j];
+      if (tli == tlj) { h[i] = 0.0; continue; }
+      double f = hh[i - 1] / (tli - tlj);
+      h[i - 1] = h[i - 1] + f * (tli - x);
+      h[i] = f * (x - tlj);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_table_pion_lut(const double* __restrict__ Ep, int nG,
+                                                         const double* __restrict__ E_eV, int nE,
+                                                         const double* __restrict__ tx, int ntx,
+                                                         const double* __restrict__ ty, int nty,
+                                                         const double* __restrict__ cf,
+                                                         double* __restrict__ Kt, int ld) {
+  NH_TAB_PROLOGUE
+  double x = log10(Ep[i]);
+  double y = log10(E_eV[k] * 1e-9);
+  int lxk = bspl_locate(tx, ntx, x);
+  int lyk = bspl_locate(ty, nty, y);
+  double hx[4], hy[4];
+  bspl_basis(tx, lxk, x, hx);
+  bspl_basis(ty, lyk, y, hy);
+  const int nky1 = nty - 4;
+  double sp = 0.0;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b)
+      sp = sp + cf[(long long)(lxk - 3 + a) * nky1 + (lyk - 3 + b)] * hx[a] * hy[b];
+  Kt[NH_TAB_AT] = sp;
+}
+
+extern "C" int nh_table_pion_lut(nh_ctx* c, const double* Ep_GeV, int nG, const double* E_eV,
+                                 int nE, const double* tx, int ntx, const double* ty, int nty,
+                                 const double* cf, double* Kt, double* lnKt, int ld) {
+  NH_REQUIRE(c && Ep_GeV && E_eV && tx && ty && cf && Kt && lnKt, "NULL pointer");
+  NH_REQUIRE(nG >= 2 && nE >= 1 && ntx >= 8 && nty >= 8, "bad sizes");
+  nh_prof_scope ps(c, NH_K_TABLES);
+  long long tot = (long long)nG * nE;
+  hipLaunchKernelGGL(k_table_pion_lut, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, Ep_GeV, nG, E_eV, nE, tx, ntx, ty, nty, cf, Kt, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  return table_dlog(c, Kt, nG, nE, ld, lnKt);
+}

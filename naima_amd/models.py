@@ -1,0 +1,186 @@
+"""Particle-distribution models with naima's class API (models.py:49-422 of the
+reference), vectorised over walkers.
+
+Every parameter may be a scalar (one walker, the reference's usage) or a 1-D
+array over walkers; a model called inside ``model(pars, data)`` with
+``pars[ndim, N]`` then describes N particle spectra at once and the radiative
+classes evaluate all of them in one batched HIP launch.  Evaluation itself
+(``__call__``) runs the ``nh_particle_weights`` kernel; there is no NumPy path.
+"""
+import numpy as np
+
+from . import units as u
+from ._lib import NH_PD_NPAR, PD_KIND, get_context
+from .validator import validate_physical_type, validate_scalar_or_batch
+
+__all__ = ["PowerLaw", "ExponentialCutoffPowerLaw", "BrokenPowerLaw",
+           "ExponentialCutoffBrokenPowerLaw", "LogParabola"]
+
+
+def _validate_ene(ene):
+    """models.py:33-46 / radiative.py:43-58: Quantity, or dict/table with 'energy'."""
+    if isinstance(ene, dict) or (hasattr(ene, "keys") and not isinstance(ene, u.Quantity)):
+        try:
+            ene = ene["energy"]
+        except KeyError:
+            raise TypeError("Table or dict does not have 'energy' column")
+    if not isinstance(ene, u.Quantity):
+        ene = u.Quantity(ene)
+    validate_physical_type("energy", ene, physical_type="energy")
+    return ene
+
+
+class _ParticleDistribution:
+    """common machinery: parameter broadcasting and device evaluation"""
+    _memoize = False
+    kind = None
+    # (attribute, slot in the NH_PD_NPAR row, is_energy)
+    _slots = ()
+
+    @property
+    def batch_size(self):
+        """number of walkers this distribution describes (1 if all parameters are scalars)"""
+        n = 1
+        for name in self.param_names:
+            v = getattr(self, name)
+            v = v.value if isinstance(v, u.Quantity) else v
+            if np.ndim(v) > 0:
+                m = np.shape(v)[0]
+                if n != 1 and m != 1 and m != n:
+                    raise ValueError("inconsistent walker-batch sizes in %s: %d vs %d"
+                                     % (type(self).__name__, n, m))
+                n = max(n, m)
+        return n
+
+    @property
+    def is_batched(self):
+        for name in self.param_names:
+            v = getattr(self, name)
+            v = v.value if isinstance(v, u.Quantity) else v
+            if np.ndim(v) > 0:
+                return True
+        return False
+
+    def _amplitude_unit(self):
+        a = self.amplitude
+        return a.unit if isinstance(a, u.Quantity) else u.dimensionless_unscaled
+
+    def param_rows(self, N, amplitude_to=None):
+        """[N, NH_PD_NPAR] float64 rows (include/naima_hip.h); amplitude converted to
+        ``amplitude_to`` (e.g. 1/eV) when given, energies in eV."""
+        rows = np.zeros((N, NH_PD_NPAR))
+        for name, slot, is_energy in self._slots:
+            v = getattr(self, name)
+            if name == "amplitude":
+                if isinstance(v, u.Quantity):
+                    v = v.to(amplitude_to).value if amplitude_to is not None else v.value
+            elif is_energy:
+                v = v.to("eV").value
+            elif isinstance(v, u.Quantity):
+                v = v.to(u.dimensionless_unscaled).value
+            rows[:, slot] = np.asarray(v, dtype=float)
+        if not any(s[0] == "beta" for s in self._slots):
+            rows[:, 4] = 1.0
+        return rows
+
+    def __call__(self, e):
+        """dN/dE at energies ``e`` -- shape (n_e,) or (N, n_e) for a walker batch.
+        Runs on the GPU (nh_particle_weights, n_out)."""
+        e = _validate_ene(e)
+        scalar_in = e.isscalar
+        e_eV = np.atleast_1d(e.to("eV").value).astype(float).ravel()
+        N = self.batch_size
+        ctx = get_context()
+        rows = ctx.array(self.param_rows(N))
+        ed = ctx.const(e_eV)
+        nG = e_eV.size
+        if nG < 2:  # the kernel wants a grid; pad a single energy
+            ed = ctx.const(np.concatenate([e_eV, e_eV * 2.0]))
+            nG2 = 2
+        else:
+            nG2 = nG
+        w, lw, n = ctx.empty((N, nG2)), ctx.empty((N, nG2)), ctx.empty((N, nG2))
+        ctx.call("nh_particle_weights", PD_KIND[self.kind], rows, N, ed, ed, nG2, 1.0, w, lw, n)
+        out = n.get()[:, :nG].reshape((N,) + e.shape if not scalar_in else (N,))
+        if not self.is_batched:
+            out = out[0]
+        return u.Quantity(out, self._amplitude_unit())
+
+
+class PowerLaw(_ParticleDistribution):
+    """f(E) = A (E/E0)^-alpha   (models.py:49-106)"""
+    param_names = ["amplitude", "e_0", "alpha"]
+    kind = "PowerLaw"
+    _slots = (("amplitude", 0, False), ("e_0", 1, True), ("alpha", 2, False))
+
+    def __init__(self, amplitude, e_0, alpha):
+        self.amplitude = amplitude
+        self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
+        self.alpha = alpha
+
+
+class ExponentialCutoffPowerLaw(_ParticleDistribution):
+    """f(E) = A (E/E0)^-alpha exp(-(E/Ecutoff)^beta)   (models.py:109-177)"""
+    param_names = ["amplitude", "e_0", "alpha", "e_cutoff", "beta"]
+    kind = "ExponentialCutoffPowerLaw"
+    _slots = (("amplitude", 0, False), ("e_0", 1, True), ("alpha", 2, False),
+              ("e_cutoff", 3, True), ("beta", 4, False))
+
+    def __init__(self, amplitude, e_0, alpha, e_cutoff, beta=1.0):
+        self.amplitude = amplitude
+        self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
+        self.alpha = alpha
+        self.e_cutoff = validate_scalar_or_batch("e_cutoff", e_cutoff, domain="positive",
+                                                 physical_type="energy")
+        self.beta = beta
+
+
+class BrokenPowerLaw(_ParticleDistribution):
+    """A (E/E0)^-alpha_1 below e_break; A (Eb/E0)^(a2-a1) (E/E0)^-alpha_2 above
+    (models.py:180-254)"""
+    param_names = ["amplitude", "e_0", "e_break", "alpha_1", "alpha_2"]
+    kind = "BrokenPowerLaw"
+    _slots = (("amplitude", 0, False), ("e_0", 1, True), ("e_break", 5, True),
+              ("alpha_1", 2, False), ("alpha_2", 6, False))
+
+    def __init__(self, amplitude, e_0, e_break, alpha_1, alpha_2):
+        self.amplitude = amplitude
+        self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
+        self.e_break = validate_scalar_or_batch("e_break", e_break, domain="positive",
+                                                physical_type="energy")
+        self.alpha_1 = alpha_1
+        self.alpha_2 = alpha_2
+
+
+class ExponentialCutoffBrokenPowerLaw(_ParticleDistribution):
+    """broken power law times exp(-(E/Ecutoff)^beta)   (models.py:257-354)"""
+    param_names = ["amplitude", "e_0", "e_break", "alpha_1", "alpha_2", "e_cutoff", "beta"]
+    kind = "ExponentialCutoffBrokenPowerLaw"
+    _slots = (("amplitude", 0, False), ("e_0", 1, True), ("e_break", 5, True),
+              ("alpha_1", 2, False), ("alpha_2", 6, False), ("e_cutoff", 3, True),
+              ("beta", 4, False))
+
+    def __init__(self, amplitude, e_0, e_break, alpha_1, alpha_2, e_cutoff, beta=1.0):
+        self.amplitude = amplitude
+        self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
+        self.e_break = validate_scalar_or_batch("e_break", e_break, domain="positive",
+                                                physical_type="energy")
+        self.alpha_1 = alpha_1
+        self.alpha_2 = alpha_2
+        self.e_cutoff = validate_scalar_or_batch("e_cutoff", e_cutoff, domain="positive",
+                                                 physical_type="energy")
+        self.beta = beta
+
+
+class LogParabola(_ParticleDistribution):
+    """f(E) = A (E/E0)^(-alpha - beta ln(E/E0))   (models.py:357-422)"""
+    param_names = ["amplitude", "e_0", "alpha", "beta"]
+    kind = "LogParabola"
+    _slots = (("amplitude", 0, False), ("e_0", 1, True), ("alpha", 2, False),
+              ("beta", 4, False))
+
+    def __init__(self, amplitude, e_0, alpha, beta):
+        self.amplitude = amplitude
+        self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
+        self.alpha = alpha
+        self.beta = beta

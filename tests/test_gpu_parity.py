@@ -1,0 +1,292 @@
+"""GPU parity: the HIP path (through the C ABI, via naima_amd's naima-shaped classes)
+against the golden vectors made by the reference and against the oracle.
+
+Tolerance: north_star asks for float64 flux rtol <= 1e-6 per energy.  The tests
+hold the kernels to 1e-9 wherever the integrand is smooth (device pow/exp/log are
+1-2 ulp and the reduction order differs) and state any looser bound next to it.
+"""
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+RT = 1e-10  # typical achieved: 1e-13 (1e-11 in exponentially suppressed tails)
+
+
+@pytest.fixture(scope="module")
+def na():
+    import naima_amd
+    from naima_amd import _lib
+    _lib.get_context()  # fails loudly when the .so or the GPU is missing
+    return naima_amd
+
+
+def _pds(na):
+    u = na.u
+    return {
+        "PowerLaw": na.PowerLaw(3e30 / u.eV, 2 * u.TeV, 2.3),
+        "ExponentialCutoffPowerLaw": na.ExponentialCutoffPowerLaw(
+            3e30 / u.eV, 2 * u.TeV, 2.3, 30 * u.TeV, 1.7),
+        "BrokenPowerLaw": na.BrokenPowerLaw(3e30 / u.eV, 2 * u.TeV, 0.5 * u.TeV, 1.6, 2.9),
+        "ExponentialCutoffBrokenPowerLaw": na.ExponentialCutoffBrokenPowerLaw(
+            3e30 / u.eV, 2 * u.TeV, 0.5 * u.TeV, 1.6, 2.9, 80 * u.TeV, 0.8),
+        "LogParabola": na.LogParabola(3e30 / u.eV, 2 * u.TeV, 2.1, 0.15),
+    }
+
+
+def test_abi_trapz_loglog(na, golden):
+    """row 1 straight through the C ABI, incl. zero nodes / sign changes / b=-1"""
+    from naima_amd._lib import get_context
+    U = golden("units")
+    ctx = get_context()
+    x = U["tz_x"]
+    y = U["tz_y"]
+    out = ctx.empty((len(y),))
+    ctx.call("nh_trapz_loglog", ctx.array(y), ctx.array(x), len(y), x.size, out)
+    assert_allclose(out.get(), U["tz_out"], rtol=1e-12)
+    yy = np.ascontiguousarray(U["tz_y2d"].T)
+    out = ctx.empty((len(yy),))
+    ctx.call("nh_trapz_loglog", ctx.array(yy), ctx.array(x), len(yy), x.size, out)
+    assert_allclose(out.get(), U["tz_out2d"], rtol=1e-12)
+
+
+def test_abi_integrate_tables_edges(na, golden):
+    """the u/l segment form used by every reduction reproduces trapz_loglog's edge
+    semantics: w = x*y with K = 1"""
+    from naima_amd._lib import get_context
+    U = golden("units")
+    ctx = get_context()
+    x, Y = U["tz_x"], U["tz_y"]
+    n = x.size
+    with np.errstate(all="ignore"):
+        w = Y * x
+        lw = np.zeros_like(w)
+        lw[:, :-1] = np.log(np.abs(w[:, 1:] / w[:, :-1]))
+    K = np.ones((n, 1))
+    xd = ctx.array(x)
+    lx = ctx.empty((n - 1,))
+    ctx.call("nh_grid_logratio", xd, n, lx)
+    out = ctx.empty((len(Y), 1))
+    ctx.call("nh_integrate_tables", ctx.array(w), ctx.array(lw), len(Y), n, lx, ctx.array(K),
+             ctx.array(np.zeros((n, 1))), 1, None, out, 1)
+    assert_allclose(out.get()[:, 0], U["tz_out"], rtol=1e-13)
+
+
+def test_particle_distributions(na, golden):
+    U = golden("units")
+    e = U["pd_e"] * na.u.eV
+    for k, pd in _pds(na).items():
+        assert_allclose(pd(e).to("1/eV").value, U["pd_" + k], rtol=1e-13)
+
+
+def test_synchrotron_and_We(na, golden):
+    u = na.u
+    U = golden("units")
+    pds = _pds(na)
+    E = U["E"] * u.eV
+    eprops = {"Eemin": 100 * u.GeV, "Eemax": 1 * u.PeV}
+    for tag, k in (("ecpl", "ExponentialCutoffPowerLaw"), ("bpl", "BrokenPowerLaw"),
+                   ("lp", "LogParabola")):
+        sy = na.Synchrotron(pds[k], B=1 * u.mG, **eprops)
+        assert_allclose(sy.flux(E, 0).to("1/(s eV)").value, U["syn_" + tag], rtol=RT, atol=1e-300)
+        assert_allclose(sy.We.to("erg").value, U["We_" + tag], rtol=RT)
+        assert_allclose(sy.compute_We(Eemin=10 * u.TeV).to("erg").value, U["We10_" + tag],
+                        rtol=RT)
+    sy = na.Synchrotron(pds["ExponentialCutoffPowerLaw"])
+    assert_allclose(sy.flux(E, 0).value, U["syn_default"], rtol=RT, atol=1e-300)
+
+
+def test_inverse_compton(na, golden):
+    u = na.u
+    U = golden("units")
+    pds = _pds(na)
+    ECPL, BPL = pds["ExponentialCutoffPowerLaw"], pds["BrokenPowerLaw"]
+    E = U["E"] * u.eV
+    eprops = {"Eemin": 100 * u.GeV, "Eemax": 1 * u.PeV}
+    ic = na.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"], **eprops)
+    assert_allclose(ic.flux(E, 0).value, U["ic_3seeds"], rtol=RT, atol=1e-300)
+    for j in range(3):
+        assert_allclose(ic.specic[j].value, U["ic_3seeds_per"][j], rtol=RT, atol=1e-300)
+        assert_allclose(ic.flux(E, 0, seed=j).value, U["ic_3seeds_per"][j], rtol=RT, atol=1e-300)
+    ic = na.InverseCompton(BPL, seed_photon_fields=[["bb", 5000 * u.K, 0],
+                                                    ["bb2", 40 * u.K, 2.0 * u.eV / u.cm ** 3]])
+    assert_allclose(ic.flux(E, 0).value, U["ic_custom"], rtol=RT, atol=1e-300)
+    for ang in (45, 90, 135):
+        ic = na.InverseCompton(ECPL, seed_photon_fields=[
+            ["Star", 20000 * u.K, 0.1 * u.erg / u.cm ** 3, ang * u.deg]], **eprops)
+        assert_allclose(ic.flux(E, 0).value, U["ic_ani_%d" % ang], rtol=RT, atol=1e-300)
+    ic = na.InverseCompton(ECPL, seed_photon_fields=[["UV", 50 * u.eV, 15 * u.eV / u.cm ** 3]],
+                           **eprops)
+    assert_allclose(ic.flux(E, 0).value, U["ic_mono"], rtol=RT, atol=1e-300)
+    Es = U["ic_arr_E"] * u.eV
+    ns = U["ic_arr_n"] * u.Unit("1/(eV cm3)")
+    ic = na.InverseCompton(ECPL, seed_photon_fields=[["arr", Es, ns]], **eprops)
+    assert_allclose(ic.flux(E, 0).value, U["ic_array"], rtol=RT, atol=1e-300)
+    ic = na.InverseCompton(ECPL, seed_photon_fields=[["arr", Es, Es ** 2 * ns]], **eprops)
+    assert_allclose(ic.flux(E, 0).value, U["ic_array_edens"], rtol=RT, atol=1e-300)
+    # the same seed given per walker (SSC path, nh_ic_seed_walkers) must agree
+    nsw = u.Quantity(np.stack([ns.value, 2 * ns.value]), ns.unit)
+    ic = na.InverseCompton(ECPL, seed_photon_fields=[["arr", Es, nsw]], **eprops)
+    f = ic.flux(E, 0).value
+    assert f.shape == (2, E.size)
+    assert_allclose(f[0], U["ic_array"], rtol=RT, atol=1e-300)
+    assert_allclose(f[1], 2 * U["ic_array"], rtol=RT, atol=1e-300)
+
+
+def test_bremsstrahlung(na, golden):
+    u = na.u
+    U = golden("units")
+    pds = _pds(na)
+    E2 = U["E_brems"] * u.eV
+    from naima_amd.constants import mec2
+    br = na.Bremsstrahlung(pds["ExponentialCutoffPowerLaw"], n0=2.5 / u.cm ** 3, Eemin=mec2)
+    assert_allclose(br.flux(E2, 0).value, U["brems_mec2"], rtol=RT, atol=1e-300)
+    br = na.Bremsstrahlung(pds["BrokenPowerLaw"])
+    assert_allclose([br.weight_ee, br.weight_ep], U["brems_weights"], rtol=1e-15)
+    assert_allclose(br.flux(E2, 0).value, U["brems_default"], rtol=RT, atol=1e-300)
+
+
+def test_pion_decay(na, golden):
+    u = na.u
+    U = golden("units")
+    pds = _pds(na)
+    Eg = U["E_pp"] * u.eV
+    for tag, k in (("ecpl", "ExponentialCutoffPowerLaw"), ("bpl", "BrokenPowerLaw")):
+        p = na.PionDecay(pds[k], useLUT=True, Epmax=1 * u.PeV)
+        # LUT mode: FITPACK spline with ringing (20 % tiny negative nodes); 1e-8 as the
+        # oracle-vs-reference bound for this mode
+        assert_allclose(p.flux(Eg, 0).value, U["pp_lut_" + tag], rtol=1e-8)
+        assert_allclose(p.Wp.to("erg").value, U["Wp_" + tag], rtol=RT)
+        p.useLUT = False
+        assert_allclose(p.flux(Eg, 0).value, U["pp_ana_" + tag], rtol=RT)
+    p = na.PionDecay(pds["ExponentialCutoffPowerLaw"], useLUT=False, nuclear_enhancement=False,
+                     nh=3.0 / u.cm ** 3)
+    assert_allclose(p.flux(Eg, 0).value, U["pp_nonuc"], rtol=RT)
+    for hiE in ("Geant4", "SIBYLL", "QGSJET"):
+        p = na.PionDecay(pds["ExponentialCutoffPowerLaw"], useLUT=False, hiEmodel=hiE)
+        assert_allclose(p.flux(Eg, 0).value, U["pp_ana_" + hiE], rtol=RT)
+
+
+def test_abi_pion_tables(na, golden):
+    """the differential cross-section tables themselves (analytic and FITPACK LUT)"""
+    from naima_amd._lib import get_context
+    from naima_amd.radiative import PionDecay, _lut_spline
+    U = golden("units")
+    ctx = get_context()
+    Ep, Eg = U["ds_Ep"], U["ds_Eg"] * 1e9
+    Kt, lnKt = ctx.empty((Ep.size, Eg.size)), ctx.empty((Ep.size, Eg.size))
+    ctx.call("nh_table_pion_analytic", ctx.array(Ep), Ep.size, ctx.array(Eg), Eg.size, 1, 1, Kt,
+             lnKt, Eg.size)
+    assert_allclose(Kt.get().T, U["ds_ana"], rtol=1e-11, atol=1e-300)
+    pd = _pds(na)["PowerLaw"]
+    tx, ty, cf = _lut_spline(PionDecay(pd)._lut_file())
+    ctx.call("nh_table_pion_lut", ctx.array(Ep), Ep.size, ctx.array(Eg), Eg.size, ctx.array(tx),
+             tx.size, ctx.array(ty), ty.size, ctx.array(cf), Kt, lnKt, Eg.size)
+    # atol: the spline rings at the 1e-41 level where the table is identically zero
+    assert_allclose(Kt.get().T, U["ds_lut"], rtol=1e-9, atol=1e-40)
+
+
+def test_lnprobmodel_and_priors(na, golden):
+    u = na.u
+    U = golden("units")
+    flux = U["ll_flux"] * u.Unit("1/(cm2 s TeV)")
+    d = dict(energy=U["ll_energy_TeV"] * u.TeV, flux=flux, flux_error_lo=0.1 * flux,
+             flux_error_hi=0.2 * flux, ul=U["ll_ul"], cl=U["ll_cl"])
+    models = U["ll_models"] * u.Unit("1/(cm2 s TeV)")
+    assert_allclose(na.lnprobmodel(models, d), U["ll_out"], rtol=1e-12)
+    assert_allclose(na.lnprobmodel(models[2], d), U["ll_out"][2], rtol=1e-12)
+    sed = (models * d["energy"] ** 2).to("erg/(cm2 s)")
+    assert_allclose(na.lnprobmodel(sed, d), U["ll_out_sedmodel"], rtol=1e-12)
+    assert_allclose(na.normal_prior(1.3, 1.0, 0.5), U["prior_normal"][0])
+    assert_allclose(na.log_uniform_prior(2.0, 1.0, 3.0), U["prior_logu"][0])
+
+
+def _data_from_npz(na, z, prefix="data_"):
+    from naima_amd.datatable import make_data
+    return make_data({k: z[prefix + k] for k in ("energy", "energy_unit", "flux", "flux_error_lo",
+                                                  "flux_error_hi", "ul", "cl", "flux_unit")})
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+def test_workloads_batched_and_single(na, golden, name):
+    """the five BASELINE workloads: flux, blob and lnprob for the fixture walkers,
+    evaluated as ONE batch (pars[ndim, N]) and one walker at a time"""
+    from naima_amd import workloads as W
+    z = golden(name)
+    data = _data_from_npz(na, z)
+    model = W.WORKLOADS[name]["model"](na)
+    pars = z["pars"]
+    tol = 1e-8 if name == "cfg5" else RT  # cfg5 default = LUT mode
+    res = na.lnprob(pars.T, data, model, None)
+    flux = res[1].to("1/(s cm2 eV)").value
+    assert flux.shape == z["flux"].shape
+    assert_allclose(flux, z["flux"], rtol=tol, atol=1e-300)
+    assert_allclose(res[0], z["lnprob"], rtol=1e-7)
+    if not np.isnan(z["blob"][0]):
+        assert_allclose(res[2].to("erg").value, z["blob"], rtol=RT)
+    one = na.lnprob(pars[1], data, model, None)
+    assert_allclose(one[1].to("1/(s cm2 eV)").value, z["flux"][1], rtol=tol, atol=1e-300)
+    assert_allclose(one[0], z["lnprob"][1], rtol=1e-7)
+    prior = W.prior_for(name, na)
+    if prior is not None:
+        assert_allclose(prior(pars.T), z["lnprior"])
+    if name == "cfg5":
+        model = W.WORKLOADS[name]["model"](na, useLUT=False)
+        data = _data_from_npz(na, z, "analytic_data_")
+        res = na.lnprob(pars.T, data, model, None)
+        assert_allclose(res[1].to("1/(s cm2 eV)").value, z["flux_analytic"], rtol=RT)
+        assert_allclose(res[0], z["lnprob_analytic"], rtol=1e-7)
+
+
+def test_cfg3_against_oracle_random_walkers(na, golden):
+    """256 seeded walkers around p0: HIP batch vs the NumPy oracle, per energy"""
+    from naima_amd import workloads as W
+    from oracle import workloads_np as WN
+    z = golden("cfg3")
+    raw = WN.raw_from_npz(z)
+    data = _data_from_npz(na, z)
+    model = W.WORKLOADS["cfg3"]["model"](na)
+    rng = np.random.default_rng(7)
+    p0 = np.asarray(W.WORKLOADS["cfg3"]["p0"])
+    pars = p0 * (1 + 0.02 * rng.standard_normal((256, p0.size)))
+    res = na.lnprob(pars.T, data, model, W.prior_for("cfg3", na))
+    flux = res[1].to("1/(s cm2 eV)").value
+    for i in range(0, 256, 16):
+        lp, f, We = WN.lnprob("cfg3", pars[i], raw)
+        assert_allclose(flux[i], f, rtol=RT, atol=1e-300)
+        assert_allclose(res[0][i], lp, rtol=1e-7)
+        assert_allclose(res[2].to("erg").value[i], We, rtol=RT)
+
+
+def test_errors_and_shapes(na):
+    u = na.u
+    ECPL = na.ExponentialCutoffPowerLaw(1e36 / u.eV, 10 * u.TeV, 2.5, 50 * u.TeV)
+    ic = na.InverseCompton(ECPL, seed_photon_fields=["CMB", ["test", 5000 * u.K, 0]])
+    ene = np.logspace(-3, 0, 5) * u.TeV
+    assert_allclose(ic.sed(ene, seed="test").value, ic.sed(ene, seed=1).value)
+    with pytest.raises(ValueError):
+        ic.sed(ene, seed="FIR")
+    with pytest.raises(ValueError):
+        ic.sed(ene, seed=10)
+    with pytest.raises(TypeError):
+        na.Synchrotron(ECPL, B=1 * u.TeV)
+    with pytest.raises(TypeError):
+        na.InverseCompton(ECPL, seed_photon_fields=["XYZ"])
+    sy = na.Synchrotron(ECPL, B=np.array([1.0, 2.0, 3.0]) * u.uG)
+    assert sy.flux(ene).shape == (3, 5)
+    assert sy.flux(ene[2]).shape == (3,)
+    assert na.Synchrotron(ECPL).flux(ene).shape == (5,)
+    # flux <-> sed <-> distance identities (tests/test_models.py:291-324 of the reference)
+    d1, d2 = 2.5 * u.kpc, 10.0 * u.kpc
+    f1, f2 = ic.flux(ene, d1).value, ic.flux(ene, d2).value
+    assert_allclose(f1 / f2, 16.0)
+    assert_allclose(ic.sed(ene, d1).value,
+                    (ic.flux(ene, 0) * ene ** 2).to("erg/s").value
+                    / (4 * np.pi * d1.to("cm").value ** 2))
+    W = 1e49 * u.erg
+    sy = na.Synchrotron(ECPL)
+    sy.set_We(W, 1 * u.GeV, 100 * u.TeV)
+    assert_allclose(sy.compute_We(1 * u.GeV, 100 * u.TeV).value, W.value, rtol=1e-12)
