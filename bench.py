@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- walker-steps/s of the ensemble log-probability on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--walkers 512]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one ensemble step of the stretch-move sampler = two half-steps =
+``walkers`` evaluations of naima's lnprob (model + likelihood) for ``cfg3``, the
+configuration BASELINE.json quotes the metric on: RXJ1713 Syn+IC joint fit, 5
+parameters, CMB+FIR+NIR seed fields, 64 photon energies, 512 walkers per GPU
+(weak scaling: every rank adds its own 512 walkers to the ensemble).  Synthetic
+spectrum (seed 20260929), inputs resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 with the contract keys plus
+  "roofline"      the dominant kernel, from HIP events recorded around every launch
+                  inside the timed region (algorithmic bytes = SURVEY.md 8d figure);
+  "fp64_valu"     the same kernel against the FP64 vector peak (the bound that
+                  actually applies: the path is transcendental-bound, not HBM-bound);
+  "cpu_baseline"  the NumPy oracle (a port of the reference's array-at-a-time
+                  algorithm) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# compulsory HBM bytes and FP64 flop-equivalents per walker-step
+ALGO = {
+    "cfg1": dict(bytes=8 * (3 + 28 + 1), flop_eq=1.0e6),
+    "cfg2": dict(bytes=8 * (4 + 179 + 1), flop_eq=2.7e6),
+    "cfg3": dict(bytes=8 * (5 + 64 + 2), flop_eq=6.4e6),
+    "cfg4": dict(bytes=8 * (6 + 261 + 1), flop_eq=1.0e9),
+    "cfg5": dict(bytes=8 * (5 + 28 + 2), flop_eq=0.5e6),
+}
+# per-kernel share of the flop-equivalents of cfg3 (op-count convention of SURVEY.md 8d:
+# Syn 50 eq./node, table reduction 30 eq./node)
+KERNEL_FLOP_EQ = {
+    "cfg3": {"synchrotron": 64 * 570 * 50.0, "integrate_tables": (64 * 3 * 370 + 270) * 30.0},
+    "cfg2": {"synchrotron": 179 * 300 * 50.0},
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VEC_PEAK_TF = 78.6    # vendor figure quoted in SURVEY.md 8d (256 CU x 128 flop/clk x 2.4 GHz)
+
+
+def build_problem(name, na):
+    from naima_amd import workloads as W
+    from naima_amd.datatable import make_data
+    wl = W.WORKLOADS[name]
+    model = wl["model"](na)
+    p0 = np.asarray(wl["p0"], dtype=float)
+
+    def flux_at_p0(E_eV):
+        out = model(p0, {"energy": E_eV * na.u.eV})
+        out = out[0] if isinstance(out, tuple) else out
+        return out.to("1/(s cm2 eV)").value
+
+    raw = W.build_data(name, flux_at_p0)
+    return model, p0, raw, make_data(raw), W.prior_for(name, na), wl["labels"]
+
+
+def _cpu_worker(args):
+    name, raw, pars, seconds = args
+    from oracle import workloads_np as WN
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        WN.lnprob(name, pars[n % len(pars)], raw)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(name, raw, p0, seconds=8.0):
+    """the oracle timed single-core and on a Pool over all host cores (the
+    reference's own parallel mode, core.py:446-448)"""
+    import multiprocessing as mp
+    rng = np.random.default_rng(1)
+    pars = p0 * (1 + 0.01 * rng.standard_normal((64, p0.size)))
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    n1, t1 = _cpu_worker((name, raw, pars, min(4.0, seconds)))
+    cores = usable_cores()
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker, [(name, raw, pars, seconds)] * cores)
+        wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    return {"value": total / wall, "unit": "walker-steps/s", "cores": cores, "kind": "port",
+            "single_core": n1 / t1,
+            "sample": "%d lnprob evaluations of %s by the NumPy oracle over %d processes in "
+                      "%.1f s (+%d on one core in %.1f s)" % (total, name, cores, wall, n1, t1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import naima_amd as na
+    from naima_amd import _lib, dist
+    from naima_amd import workloads as W
+    from naima_amd.sampler import EnsembleSampler
+
+    ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
+    comm = dist.from_env("rccl")
+    name = args.workload
+    model, p0, raw, data, prior, labels = build_problem(name, na)
+    per_gpu = args.walkers or W.WORKLOADS[name]["nwalkers"]
+    if name in ("cfg4", "cfg5") and args.walkers is None:
+        per_gpu = 256
+    nwalkers = per_gpu * comm.size
+
+    sampler = EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
+                              seed=20260929, comm=comm, naima_style=True, store_blobs=False)
+    pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
+    state = sampler.run_mcmc(pos, max(1, args.warmup), store=False)
+
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    comm.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    state = sampler.run_mcmc(state, args.steps, store=False)
+    ctx.sync()
+    comm.barrier()
+    dt = comm.max(time.perf_counter() - t0)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+
+    if rank != 0:
+        return
+    value = nwalkers * args.steps / dt
+    info = ctx.info()
+    # dominant kernel by accumulated HIP-event time
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    avg_s = prof[dom]["ms"] * 1e-3 / prof[dom]["launches"]
+    walkers_per_launch = per_gpu / 2.0  # one half-ensemble shard per launch
+    abytes = ALGO[name]["bytes"] * walkers_per_launch
+    achieved = abytes / avg_s / 1e9
+    kflop = KERNEL_FLOP_EQ.get(name, {}).get(dom)
+    out = {
+        "metric": "walker-steps/sec (ensemble lnprob evals/s)",
+        "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s" % (name, {
+            "cfg1": "ECPL -> IC(CMB), 28 energies",
+            "cfg2": "ECPL -> Synchrotron, 179 energies, 300-pt Ee grid",
+            "cfg3": "RXJ1713 Syn+IC joint fit (CMB+FIR+NIR), 5 parameters, 64 energies",
+            "cfg4": "Crab Syn+SSC, 261 energies, 869-pt Ee grid, 100 seed energies",
+            "cfg5": "PionDecay ECBPL, 28 energies, 600-pt Ep grid"}[name]),
+            "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
+            "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
+            "device": info["name"]},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_us": avg_s * 1e6,
+                     "algorithmic_bytes_per_launch": abytes,
+                     "note": "transcendental-bound FP64 path: HBM fraction is << 1 % by "
+                             "construction (SURVEY.md 8d); see fp64_valu"},
+        "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+        "kernel_launches": {k: v["launches"] for k, v in prof.items()},
+        "gpu_busy_frac": sum(v["ms"] for v in prof.values()) * 1e-3 / dt,
+        "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
+    }
+    if kflop:
+        tf = kflop * walkers_per_launch / avg_s / 1e12
+        out["fp64_valu"] = {"kernel": dom, "achieved": tf, "peak": FP64_VEC_PEAK_TF,
+                            "unit": "TFLOP-eq/s", "frac": tf / FP64_VEC_PEAK_TF,
+                            "convention": "SURVEY.md 8d: transcendental = 20 flop-eq"}
+    if not args.no_cpu and comm.size == 1:
+        out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -29,3 +29,219 @@ def make_data(raw):
     t["ul"] = np.asarray(raw["ul"], dtype=bool)
     t["cl"] = np.broadcast_to(np.asarray(raw["cl"], dtype=float), t["ul"].shape).copy()
     return t
+
+
+# ---------------------------------------------------------------------------
+# validate_data_table (utils.py:38-213 of the reference)
+# ---------------------------------------------------------------------------
+_FLUX_TYPES = ["flux", "differential flux", "power", "differential power"]
+
+
+def _column(dt, key, pt, domain="positive"):
+    from .validator import validate_array
+    try:
+        col = dt[key]
+    except KeyError:
+        raise TypeError('Data table does not contain required column "{0}"'.format(key))
+    if not isinstance(col, u.Quantity):
+        raise TypeError("{0} should be given as a Quantity object".format(key))
+    return validate_array(key, u.Quantity(np.atleast_1d(col.value), col.unit),
+                          physical_type=pt, domain=domain)
+
+
+def _generate_energy_edges(ene):
+    """geometric-mean bin edges of one group (utils.py:358-395)"""
+    v = ene.value
+    if v.size < 2:
+        return ene * 0.0, ene * 0.0
+    midene = np.sqrt(v[1:] * v[:-1])
+    elo, ehi = np.zeros(v.size), np.zeros(v.size)
+    elo[1:] = v[1:] - midene
+    ehi[:-1] = midene - v[:-1]
+    elo[0] = v[0] * (1 - v[0] / (v[0] + ehi[0]))
+    ehi[-1] = elo[-1]
+    return u.Quantity(elo, ene.unit), u.Quantity(ehi, ene.unit)
+
+
+def _validate_single(dt, group=0):
+    data = DataTable()
+    data["energy"] = _column(dt, "energy", "energy")
+    data["flux"] = _column(dt, "flux", _FLUX_TYPES)
+    n = data["energy"].size
+    if "flux_error" in dt.keys():
+        dflux = _column(dt, "flux_error", _FLUX_TYPES)
+        data["flux_error_lo"], data["flux_error_hi"] = dflux, dflux.copy()
+    elif "flux_error_lo" in dt.keys() and "flux_error_hi" in dt.keys():
+        data["flux_error_lo"] = _column(dt, "flux_error_lo", _FLUX_TYPES)
+        data["flux_error_hi"] = _column(dt, "flux_error_hi", _FLUX_TYPES)
+    else:
+        raise TypeError('Data table does not contain required column "flux_error" or columns '
+                        '"flux_error_lo" and "flux_error_hi"')
+    data["group"] = np.asarray(dt["group"]) if "group" in dt.keys() else np.full(n, group)
+    if "energy_width" in dt.keys():
+        ew = _column(dt, "energy_width", "energy")
+        data["energy_error_lo"], data["energy_error_hi"] = ew / 2.0, ew / 2.0
+    elif "energy_error" in dt.keys():
+        ee = _column(dt, "energy_error", "energy")
+        data["energy_error_lo"], data["energy_error_hi"] = ee, ee.copy()
+    elif "energy_error_lo" in dt.keys() and "energy_error_hi" in dt.keys():
+        data["energy_error_lo"] = _column(dt, "energy_error_lo", "energy")
+        data["energy_error_hi"] = _column(dt, "energy_error_hi", "energy")
+    elif "energy_lo" in dt.keys() and "energy_hi" in dt.keys():
+        data["energy_error_lo"] = data["energy"] - _column(dt, "energy_lo", "energy")
+        data["energy_error_hi"] = _column(dt, "energy_hi", "energy") - data["energy"]
+    elif "energy_edge_lo" in dt.keys() and "energy_edge_hi" in dt.keys():
+        data["energy_error_lo"] = data["energy"] - _column(dt, "energy_edge_lo", "energy")
+        data["energy_error_hi"] = _column(dt, "energy_edge_hi", "energy") - data["energy"]
+    else:
+        data["energy_error_lo"], data["energy_error_hi"] = _generate_energy_edges(data["energy"])
+    if "ul" in dt.keys():
+        ul = np.asarray(dt["ul"])
+        if ul.dtype.kind in "ib":
+            data["ul"] = ul.astype(bool)
+        elif ul.dtype.kind in "US" and all(str(x) in ("True", "False") for x in ul):
+            data["ul"] = np.array([str(x) == "True" for x in ul])
+        else:
+            raise TypeError("UL column is in wrong format")
+    else:
+        data["ul"] = np.zeros(n, dtype=bool)
+    if "flux_ul" in dt.keys():
+        f = data["flux"].value.copy()
+        f[data["ul"]] = dt["flux_ul"].to(data["flux"].unit).value[data["ul"]]
+        data["flux"] = u.Quantity(f, data["flux"].unit)
+    cl = None
+    meta = getattr(dt, "meta", {}) or {}
+    if "keywords" in meta and "cl" in meta["keywords"]:
+        cl = meta["keywords"]["cl"]
+        cl = float(cl["value"] if isinstance(cl, dict) else cl)
+    elif "cl" in dt.keys():
+        data["cl"] = np.broadcast_to(np.asarray(dt["cl"], dtype=float), (n,)).copy()
+    if "cl" not in data:
+        data["cl"] = np.full(n, 0.9 if cl is None else cl)
+    return data
+
+
+def _sed_convert(dt, sed):
+    from .core import sed_conversion
+    f_unit, sedf = sed_conversion(dt["energy"], dt["flux"].unit, sed)
+    out = DataTable(dt)
+    out.meta = dict(getattr(dt, "meta", {}))
+    for col in ("flux", "flux_error_lo", "flux_error_hi"):
+        out[col] = (dt[col] * sedf).to(f_unit)
+    return out
+
+
+def validate_data_table(data_table, sed=None):
+    """Validate all columns of a data table; a list of tables is validated,
+    converted to the representation of the first (or to SED / differential if
+    ``sed`` is given), concatenated and sorted by energy (utils.py:38-112)."""
+    if isinstance(data_table, dict):
+        data_table = [data_table]
+    try:
+        for dt in data_table:
+            if not isinstance(dt, dict):
+                raise TypeError("An object passed as data_table is not a table!")
+    except TypeError:
+        raise TypeError("Argument passed to validate_data_table is not a table and not a list")
+    data_list = [_validate_single(dt, group=g) for g, dt in enumerate(data_table)]
+    first = data_list[0]
+    f_pt = first["flux"].unit.physical_type
+    if sed is None:
+        sed = f_pt in ["flux", "power"]
+    new = _sed_convert(first, sed)
+    for dt in data_list[1:]:
+        nf_pt = dt["flux"].unit.physical_type
+        if ("flux" in nf_pt and "power" in f_pt) or ("power" in nf_pt and "flux" in f_pt):
+            raise TypeError("The physical types of the data tables could not be matched: Some "
+                            "are in flux and others in luminosity units")
+        dt = _sed_convert(dt, sed)
+        for key in list(new.keys()):
+            a, b = new[key], dt[key]
+            if isinstance(a, u.Quantity):
+                new[key] = u.Quantity(np.concatenate([a.value, b.to(a.unit).value]), a.unit)
+            else:
+                new[key] = np.concatenate([np.asarray(a), np.asarray(b)])
+    order = np.argsort(new["energy"].value, kind="stable")
+    for key in list(new.keys()):
+        new[key] = new[key][order]
+    return new
+
+
+# ---------------------------------------------------------------------------
+# minimal readers for the two table formats naima's examples ship
+# ---------------------------------------------------------------------------
+def _unit_or_none(s):
+    s = s.strip()
+    if not s or s.lower() in ("null", "none", "-"):
+        return None
+    return u.Unit(s.replace("ph", "1").replace("photon", "1"))
+
+
+def read_ipac(path):
+    """IPAC ascii table (examples/RXJ1713_HESS_2007.dat): ``\\key=value`` keywords,
+    ``|name|`` / ``|type|`` / ``|unit|`` header rows, whitespace-separated data."""
+    keywords, headers, rows = {}, [], []
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line.startswith("\\"):
+                body = line[1:].strip()
+                if "=" in body and not body.startswith(" "):
+                    k, v = body.split("=", 1)
+                    try:
+                        keywords[k.strip()] = {"value": float(v.strip().strip("'\""))}
+                    except ValueError:
+                        keywords[k.strip()] = {"value": v.strip()}
+            elif line.startswith("|"):
+                headers.append([c.strip() for c in line.strip().strip("|").split("|")])
+            elif line.strip():
+                rows.append(line.split())
+    names = headers[0]
+    types = headers[1] if len(headers) > 1 else ["double"] * len(names)
+    units = headers[2] if len(headers) > 2 else [""] * len(names)
+    t = DataTable()
+    t.meta = {"keywords": keywords}
+    cols = list(zip(*rows))
+    for name, typ, unit, col in zip(names, types, units, cols):
+        if typ.startswith(("int", "long")):
+            t[name] = np.array([int(c) for c in col])
+        elif typ.startswith(("char", "str")):
+            t[name] = np.array(col)
+        else:
+            arr = np.array([float(c) for c in col])
+            un = _unit_or_none(unit)
+            t[name] = u.Quantity(arr, un) if un is not None else arr
+    return t
+
+
+def read_ecsv(path):
+    """ECSV (examples/CrabNebula_spectrum.ecsv): YAML header in ``# `` comment lines,
+    then a space-delimited table."""
+    import yaml
+    head, body = [], []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("#"):
+                head.append(line[2:] if line.startswith("# ") else line[1:])
+            elif line.strip():
+                body.append(line.split())
+    meta = yaml.safe_load("".join(l for l in head if not l.startswith("%ECSV")))
+    names = body[0]
+    cols = list(zip(*body[1:]))
+    t = DataTable()
+    t.meta = dict(meta.get("meta", {}) or {})
+    for spec, name, col in zip(meta["datatype"], names, cols):
+        if spec["datatype"].startswith(("int", "bool")):
+            t[name] = np.array([int(c) if c not in ("True", "False") else c == "True" for c in col])
+        elif spec["datatype"] == "string":
+            t[name] = np.array(col)
+        else:
+            arr = np.array([float(c) for c in col])
+            t[name] = u.Quantity(arr, u.Unit(spec["unit"])) if spec.get("unit") else arr
+    return t
+
+
+def read(path):
+    with open(path) as fh:
+        first = fh.readline()
+    return read_ecsv(path) if first.startswith("# %ECSV") else read_ipac(path)

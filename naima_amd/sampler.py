@@ -1,0 +1,366 @@
+"""The ensemble driver: an affine-invariant stretch-move sampler with the surface
+naima reads from ``emcee.EnsembleSampler`` (core.py:127-160, 450-493, 529-530 of the
+reference), but calling the log-probability ONCE per half-ensemble with all
+proposed walkers, and sharding those walkers over the GPUs of a node.
+
+emcee itself is third-party (``emcee>=3.0``, not in the reference tree, not
+installed here): the move below restates its published algorithm
+(``RedBlueMove.propose`` + ``StretchMove.get_proposal``) -- random split of the
+ensemble into two halves; for the active half S with complement C:
+z = ((a-1)U+1)^2/a, partner j ~ randint(|C|), q = C_j - (C_j - S) z,
+accept if ln U' < (ndim-1) ln z + lnp(q) - lnp(S).  Parity with emcee is
+statistical, not bitwise ("parity unpinned").
+"""
+import time
+
+import numpy as np
+
+from . import units as u
+from .dist import LocalComm, shard_bounds, shard_counts
+
+__all__ = ["EnsembleSampler", "State", "get_sampler", "run_sampler"]
+
+
+class State:
+    """what ``sampler.sample`` yields (emcee.State): coords, log_prob, blobs"""
+
+    def __init__(self, coords, log_prob=None, blobs=None, random_state=None):
+        if isinstance(coords, State):
+            self.coords, self.log_prob = coords.coords.copy(), coords.log_prob
+            self.blobs, self.random_state = coords.blobs, coords.random_state
+            return
+        self.coords = np.atleast_2d(np.array(coords, dtype=float))
+        self.log_prob = log_prob
+        self.blobs = blobs
+        self.random_state = random_state
+
+    def __iter__(self):  # emcee allows  pos, lnp, rstate = state
+        return iter((self.coords, self.log_prob, self.random_state))
+
+
+def _split_blob(b):
+    """a blob returned by the model -> (ndarray with leading walker axis, unit or None)"""
+    if isinstance(b, u.Quantity):
+        return np.asarray(b.value, dtype=float), b.unit
+    return np.asarray(b, dtype=float), None
+
+
+class EnsembleSampler:
+    """Stretch-move ensemble sampler over a *batched* log-probability.
+
+    log_prob_fn(coords[n, ndim], *args) -> lnp[n]  or  (lnp[n], blob0[n,...], ...)
+    With ``naima_style=True`` (what ``get_sampler`` uses) the function is naima's
+    ``lnprob(pars, data, model, prior)`` and is called with ``coords.T`` so that
+    ``pars[i]`` is a vector over walkers.
+    """
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, args=(), a=2.0, seed=None, comm=None,
+                 naima_style=False, store_blobs=True):
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError("need an even number of walkers, at least twice the dimension")
+        self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
+        self.log_prob_fn, self.args = log_prob_fn, tuple(args)
+        self.comm = comm if comm is not None else LocalComm()
+        # the stream is replicated on every rank: proposals/accepts are identical
+        self._rng = np.random.default_rng(seed if seed is not None else 12345)
+        self.naima_style = naima_style
+        self.store_blobs = store_blobs
+        self.n_lnprob_calls = 0
+        self.n_walker_evals = 0
+        self.reset()
+
+    # ------------------------------------------------------------------ store
+    def reset(self):
+        self.iteration = 0
+        self._chain, self._logp, self._blobs = [], [], None
+        self.blob_units = None
+        self.naccepted = np.zeros(self.nwalkers)
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(1, self.iteration)
+
+    def get_chain(self, flat=False, discard=0, thin=1):
+        c = np.array(self._chain).reshape(-1, self.nwalkers, self.ndim)[discard::thin]
+        return c.reshape(-1, self.ndim) if flat else c
+
+    def get_log_prob(self, flat=False, discard=0, thin=1):
+        c = np.array(self._logp).reshape(-1, self.nwalkers)[discard::thin]
+        return c.reshape(-1) if flat else c
+
+    def get_blobs(self, flat=False, discard=0, thin=1):
+        """list (one entry per blob) of arrays [nsteps, nwalkers, ...]; dense, not
+        emcee's object array"""
+        if self._blobs is None:
+            return None
+        out = []
+        for per_step in self._blobs:
+            a = np.array(per_step)[discard::thin]
+            out.append(a.reshape((-1,) + a.shape[2:]) if flat else a)
+        return out
+
+    # legacy emcee-2 names that naima's analysis code touches
+    @property
+    def chain(self):
+        return np.swapaxes(self.get_chain(), 0, 1)
+
+    @property
+    def flatchain(self):
+        return self.get_chain(flat=True)
+
+    @property
+    def lnprobability(self):
+        return self.get_log_prob().T
+
+    # --------------------------------------------------------------- evaluate
+    def compute_log_prob(self, coords):
+        """lnprob of ``coords[n, ndim]``: this rank evaluates its block, the blocks
+        meet in one all-gather.  Returns (lnp[n], [local blob arrays], (lo, hi))."""
+        n = coords.shape[0]
+        lo, hi = shard_bounds(n, self.comm.rank, self.comm.size)
+        mine = coords[lo:hi]
+        if self.naima_style:
+            res = self.log_prob_fn(mine.T, *self.args)
+        else:
+            res = self.log_prob_fn(mine, *self.args)
+        self.n_lnprob_calls += 1
+        self.n_walker_evals += hi - lo
+        if isinstance(res, tuple):
+            lnp_local, blobs = np.asarray(res[0], dtype=float), list(res[1:])
+        else:
+            lnp_local, blobs = np.asarray(res, dtype=float), []
+        lnp_local = np.broadcast_to(lnp_local, (hi - lo,)).astype(float)
+        if np.any(np.isnan(lnp_local)):
+            raise ValueError("Probability function returned NaN")
+        if self.comm.size > 1:
+            m = max(shard_counts(n, self.comm.size))
+            pad = np.full((m,), -np.inf)
+            pad[:hi - lo] = lnp_local
+            allp = self.comm.allgather(pad).reshape(self.comm.size, m)
+            lnp = np.concatenate([allp[r, :c] for r, c in
+                                  enumerate(shard_counts(n, self.comm.size))])
+        else:
+            lnp = lnp_local
+        return lnp, blobs, (lo, hi)
+
+    def _blob_arrays(self, blobs, nloc):
+        arrs, units = [], []
+        for b in blobs:
+            v, un = _split_blob(b)
+            if v.ndim == 0 or v.shape[0] != nloc:
+                v = np.broadcast_to(v, (nloc,) + v.shape).copy()
+            arrs.append(v)
+            units.append(un)
+        return arrs, units
+
+    # ------------------------------------------------------------------ sample
+    def sample(self, initial_state, iterations=1, store=True, log_prob0=None):
+        state = State(initial_state)
+        coords = state.coords.copy()
+        if coords.shape != (self.nwalkers, self.ndim):
+            raise ValueError("incompatible input dimensions")
+        rng = self._rng
+        N, ndim, a = self.nwalkers, self.ndim, self.a
+        keep_blobs = self.store_blobs
+        # blobs of this rank's walkers only (flux arrays are N*n_E*8 B per step and
+        # stay rank-local)
+        if state.log_prob is None:
+            logp, blobs, (lo, hi) = self.compute_log_prob(coords)
+            cur, units = self._blob_arrays(blobs, hi - lo) if keep_blobs else ([], [])
+            self.blob_units = units
+            self._own = np.arange(lo, hi)
+            self._cur_blobs = cur
+        else:
+            logp = np.array(state.log_prob, dtype=float)
+            if not hasattr(self, "_cur_blobs"):
+                self._cur_blobs, self._own = [], np.arange(0)
+        logp = logp.copy()
+        for _ in range(int(iterations)):
+            inds = np.arange(N) % 2
+            rng.shuffle(inds)
+            for split in range(2):
+                S = np.nonzero(inds == split)[0]
+                Cidx = np.nonzero(inds != split)[0]
+                s, c = coords[S], coords[Cidx]
+                Ns, Nc = len(S), len(Cidx)
+                zz = ((a - 1.0) * rng.random(Ns) + 1) ** 2.0 / a
+                factors = (ndim - 1.0) * np.log(zz)
+                rint = rng.integers(Nc, size=Ns)
+                q = c[rint] - (c[rint] - s) * zz[:, None]
+                newlp, blobs, (lo, hi) = self.compute_log_prob(q)
+                lnpdiff = factors + newlp - logp[S]
+                accepted = np.log(rng.random(Ns)) < lnpdiff
+                acc_idx = S[accepted]
+                coords[acc_idx] = q[accepted]
+                logp[acc_idx] = newlp[accepted]
+                self.naccepted[acc_idx] += 1
+                if keep_blobs and blobs:
+                    new, _ = self._blob_arrays(blobs, hi - lo)
+                    self._update_blobs(S[lo:hi], accepted[lo:hi], new)
+            self.iteration += 1
+            if store:
+                self._chain.append(coords.copy())
+                self._logp.append(logp.copy())
+                if keep_blobs and self._cur_blobs:
+                    if self._blobs is None:
+                        self._blobs = [[] for _ in self._cur_blobs]
+                    for j, b in enumerate(self._cur_blobs):
+                        self._blobs[j].append(b.copy())
+            yield State(coords, logp, self._cur_blobs if keep_blobs else None, rng)
+
+    def _update_blobs(self, walkers, accepted, new):
+        """walkers: global indices this rank just evaluated; blobs are tracked for
+        the walkers this rank evaluated at initialisation (``self._own``)"""
+        if not self._cur_blobs:
+            return
+        pos = {w: i for i, w in enumerate(self._own)}
+        for j, (w, ok) in enumerate(zip(walkers, accepted)):
+            if ok and w in pos:
+                for cur, nb in zip(self._cur_blobs, new):
+                    cur[pos[w]] = nb[j]
+
+    def run_mcmc(self, initial_state, nsteps, **kw):
+        state = None
+        for state in self.sample(initial_state, iterations=nsteps, **kw):
+            pass
+        return state
+
+
+# --------------------------------------------------------------------------
+# naima's entry points (core.py:220-538)
+# --------------------------------------------------------------------------
+def _run_mcmc(sampler, pos, nrun, verbose=True):
+    """core.py:127-160 (progress printout every 5 %)"""
+    state = None
+    for i, state in enumerate(sampler.sample(pos, iterations=nrun, store=True)):
+        progress = 100.0 * float(i) / float(nrun)
+        if verbose and sampler.comm.rank == 0 and progress % 5 < (5.0 / float(nrun)):
+            print("\nProgress of the run: {0:.0f} percent ({1} of {2} steps)".format(
+                int(progress), i, nrun))
+            npars = state.coords.shape[-1]
+            print("                           " + (" ".join(
+                ["{%i:-^15}" % k for k in range(npars)])).format(*sampler.labels))
+            print("  Last ensemble median : " + (" ".join(
+                ["{%i:^15.3g}" % k for k in range(npars)])).format(
+                    *np.median(state.coords, axis=0)))
+            print("  Last ensemble std    : " + (" ".join(
+                ["{%i:^15.3g}" % k for k in range(npars)])).format(*np.std(state.coords, axis=0)))
+            print("  Last ensemble lnprob :  avg: {0:.3f}, max: {1:.3f}".format(
+                np.average(state.log_prob), np.max(state.log_prob)))
+    return sampler, state
+
+
+def _prefit(p0, data, model, prior):
+    """Nelder-Mead maximum-likelihood prefit (core.py:163-217), sequential batch-1
+    evaluations of the same HIP path."""
+    from scipy.optimize import minimize
+
+    from .core import lnprob
+    P0_IS_ML = False
+
+    def nll(p):
+        return -lnprob(p, data, model, None)[0]
+
+    res = minimize(nll, p0, method="Nelder-Mead",
+                   options={"maxfev": 500, "xatol": 1e-1, "fatol": 1e-3})
+    ll_prior = lnprob(res.x, data, model, prior)[0]
+    if (res.success or res.status == 1) and not np.isinf(ll_prior):
+        P0_IS_ML = res.status != 1
+        p0 = res.x
+    return p0, P0_IS_ML
+
+
+def get_sampler(data_table=None, p0=None, model=None, prior=None, nwalkers=500, nburn=100,
+                guess=True, interactive=False, prefit=False, labels=None, threads=None,
+                data_sed=None, seed=None, comm=None, verbose=True, store_blobs=True):
+    """Generate a new MCMC sampler (signature of core.py:220-233; ``threads`` is
+    accepted and ignored -- the walkers of a half-ensemble are one GPU batch;
+    ``interactive`` is out of scope).  Returns (sampler, state)."""
+    from .core import lnprob, sed_conversion
+    from .datatable import validate_data_table
+    if data_table is None:
+        raise TypeError("Data table is missing!")
+    data = validate_data_table(data_table, sed=data_sed)
+    if model is None:
+        raise TypeError("Model function is missing!")
+    p0 = np.array(p0, dtype=float)
+    if labels is None:
+        labels = ["norm"] + ["par{0}".format(i) for i in range(1, len(p0))]
+    elif len(labels) < len(p0):
+        labels = list(labels) + ["par{0}".format(i) for i in range(len(labels), len(p0))]
+
+    modelout = model(p0, data)
+    spec = modelout[0] if isinstance(modelout, (tuple, list)) else modelout
+    try:  # core.py:352-376: model and data must be convertible to differential flux
+        sed_conversion(data["energy"], spec.unit, False)
+        sed_conversion(data["energy"], data["flux"].unit, False)
+    except u.UnitsError:
+        raise u.UnitsError(
+            "The physical type of the model and data units are not compatible, please modify "
+            "your model or data so they match:\n Model units: {0} [{1}]\n Data units: {2} [{3}]\n"
+            .format(spec.unit, spec.unit.physical_type, data["flux"].unit,
+                    data["flux"].unit.physical_type))
+
+    if guess:  # core.py:378-419
+        normNames = ["norm", "ampl", "we", "wp"]
+        normNames += ["log({0}".format(n) for n in normNames[:4]] + \
+                     ["log10({0}".format(n) for n in normNames[:4]]
+        idxs = []
+        for nn in normNames:
+            for l2 in labels:
+                if l2.lower().startswith(nn):
+                    idxs.append(labels.index(l2))
+        if len(idxs) == 1:
+            e = data["energy"]
+            nunit, sedf = sed_conversion(e, spec.unit, False)
+            currFlux = np.trapezoid(e.value * (spec * sedf).to(nunit).value, e.value)
+            nunit, sedf = sed_conversion(e, data["flux"].unit, False)
+            dataFlux = np.trapezoid(e.value * (data["flux"] * sedf).to(nunit).value, e.value)
+            ratio = dataFlux / currFlux
+            if labels[idxs[0]].startswith("log("):
+                p0[idxs[0]] += np.log(ratio)
+            elif labels[idxs[0]].startswith("log10("):
+                p0[idxs[0]] += np.log10(ratio)
+            else:
+                p0[idxs[0]] *= ratio
+
+    P0_IS_ML = False
+    if prefit:
+        p0, P0_IS_ML = _prefit(p0, data, model, prior)
+
+    sampler = EnsembleSampler(nwalkers, len(p0), lnprob, args=[data, model, prior], seed=seed,
+                              comm=comm, naima_style=True, store_blobs=store_blobs)
+    sampler.data_table = data_table
+    sampler.data = data
+    sampler.labels = labels
+    sampler.modelfn = model
+    sampler.run_info = {"n_walkers": nwalkers, "n_burn": nburn,
+                        "p0": [float(p) for p in p0], "guess": guess}
+    # ball of 0.5 % (ML start) or 10 % around p0 (core.py:477-481), drawn from the
+    # sampler's replicated stream so that every rank starts from the same ensemble
+    spread = 0.005 if P0_IS_ML else 0.1
+    p0var = spread * p0
+    pos = p0 + p0var * sampler._rng.normal(size=(nwalkers, len(p0)))
+    if nburn > 0:
+        if verbose and sampler.comm.rank == 0:
+            print("Burning in the {0} walkers with {1} steps...".format(nwalkers, nburn))
+        sampler, state = _run_mcmc(sampler, pos, nburn, verbose)
+    else:
+        state = State(pos)
+    sampler.run_info["p0_burn_median"] = [float(p) for p in np.median(state.coords, axis=0)]
+    return sampler, state
+
+
+def run_sampler(nrun=100, sampler=None, pos=None, verbose=True, **kwargs):
+    """Run an MCMC sampler (core.py:496-538)."""
+    if sampler is None or pos is None:
+        sampler, pos = get_sampler(verbose=verbose, **kwargs)
+    sampler.run_info["n_run"] = nrun
+    if verbose and sampler.comm.rank == 0:
+        print("\nWalker burn in finished, running {0} steps...".format(nrun))
+    sampler.reset()
+    t0 = time.time()
+    sampler, pos = _run_mcmc(sampler, State(pos.coords if isinstance(pos, State) else pos),
+                             nrun, verbose)
+    sampler.run_info["wall_s"] = time.time() - t0
+    return sampler, pos
