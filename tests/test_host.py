@@ -1,0 +1,187 @@
+"""CPU tests of the host side: units shim, grids (the int() truncation of
+radiative.py:152-154), data ingest, the C ABI's symbol table, loud failure
+without a GPU.  No compute call is made here."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import naima_amd as na
+from naima_amd import units as u
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_units_algebra_and_physical_types():
+    q = 3 * u.TeV
+    assert_allclose(q.to("erg").value, 3 * 1.602176634)
+    assert (1 / u.eV).unit.physical_type == "differential energy"
+    assert u.Unit("1/(s cm2 eV)").physical_type == "differential flux"
+    assert u.Unit("erg/(cm2 s)").physical_type == "flux"
+    assert u.Unit("1 / (cm2 s TeV)").physical_type == "differential flux"
+    assert (0.5 * u.eV / u.cm ** 3).unit.physical_type == "pressure"
+    assert (1 / u.cm ** 3).unit.physical_type == "number density"
+    assert (1 / (u.eV * u.cm ** 3)).unit.physical_type == "differential number density"
+    assert (12 * u.uG).to("G").value == pytest.approx(1.2e-5)
+    assert (1 * u.kpc != 0) and not (0 * u.cm != 0)
+    a = 10 ** np.array([1.0, 2.0]) / u.eV  # ndarray / Unit defers to Unit
+    assert isinstance(a, u.Quantity) and a.shape == (2,)
+    sed = (np.ones((2, 3)) * u.Unit("1/(s cm2 eV)") * (np.array([1.0, 2, 3]) * u.eV) ** 2)
+    assert_allclose(sed.to("erg/(cm2 s)").value[0], np.array([1, 4, 9]) * 1.602176634e-12)
+    with pytest.raises(u.UnitConversionError):
+        (1 * u.TeV).to("cm")
+    with pytest.raises(u.UnitConversionError):
+        (1 * u.TeV) + (1 * u.cm)
+    assert_allclose(u.Quantity([1 * u.eV, 1 * u.keV]).value, [1, 1000])
+    assert_allclose((90 * u.deg).to("rad").value, np.pi / 2)
+
+
+def test_grid_sizing_matches_reference(golden):
+    """point counts and values of the particle grids for the golden specs"""
+    from naima_amd.constants import mec2
+    from naima_amd.radiative import BaseElectron
+    U = golden("units")
+    for i, (lo, hi, nd) in enumerate(U["grid_specs"]):
+        g = BaseElectron._gam_between(lo * u.eV, hi * u.eV, nd)
+        assert len(g) == U["grid_lens"][i]
+        assert_allclose(g, U["grid_%d" % i], rtol=1e-14)
+    # the cfg2 case sits exactly on an integer: 50 * 6.0 must not truncate to 299
+    assert len(BaseElectron._gam_between(1 * u.GeV, 1 * u.PeV, 50)) == 300
+    assert len(BaseElectron._gam_between(1 * u.GeV, 1e9 * mec2, 100)) == 570
+    ECPL = na.ExponentialCutoffPowerLaw(1 / u.eV, 1 * u.TeV, 2.0, 10 * u.TeV)
+    pp = na.PionDecay(ECPL)
+    assert_allclose(pp._Ep, U["pgrid_default"], rtol=1e-14)
+    pp = na.PionDecay(ECPL, Epmax=1 * u.PeV)
+    assert_allclose(pp._Ep, U["pgrid_1PeV"], rtol=1e-14)
+
+
+def test_constructor_validation_without_gpu():
+    ECPL = na.ExponentialCutoffPowerLaw(1e36 / u.eV, 10 * u.TeV, 2.5, 50 * u.TeV)
+    with pytest.raises(TypeError):
+        na.Synchrotron(ECPL, B=1 * u.TeV)
+    with pytest.raises(TypeError):
+        na.InverseCompton(ECPL, seed_photon_fields=["XYZ"])
+    with pytest.raises(TypeError):
+        na.ExponentialCutoffPowerLaw(1e36 / u.eV, 10 * u.cm, 2.5, 50 * u.TeV)
+    ic = na.InverseCompton(ECPL, seed_photon_fields=[
+        "CMB", ["star", 25000 * u.K, 3 * u.erg / u.cm ** 3, 120 * u.deg],
+        ["X-ray", [1, 10] * u.keV, [1, 1e-2] * (1 / (u.eV * u.cm ** 3))],
+        ["UV", 50 * u.eV, 15 * u.eV / u.cm ** 3]])
+    assert list(ic.seed_photon_fields) == ["CMB", "star", "X-ray", "UV"]
+    assert ic.seed_photon_fields["star"]["isotropic"] is False
+    assert ic.seed_photon_fields["X-ray"]["type"] == "array"
+    # vector-valued parameters describe a walker batch
+    pd = na.ExponentialCutoffPowerLaw(10 ** np.array([30.0, 31, 32]) / u.eV, 10 * u.TeV,
+                                      np.array([2.0, 2.1, 2.2]), 50 * u.TeV)
+    assert pd.batch_size == 3 and pd.is_batched
+    rows = pd.param_rows(3, amplitude_to=u.Unit("1/eV"))
+    assert rows.shape == (3, 8) and rows[1, 0] == 1e31 and rows[2, 2] == 2.2 and rows[0, 4] == 1.0
+    assert na.Synchrotron(pd, B=np.array([1.0, 2, 3]) * u.uG).batch_size == 3
+    with pytest.raises(ValueError):
+        na.Synchrotron(pd, B=np.array([1.0, 2]) * u.uG).batch_size
+
+
+def test_priors_vectorised():
+    assert na.uniform_prior(1.0, 0, 2) == 0.0 and na.uniform_prior(3.0, 0, 2) == -np.inf
+    assert_allclose(na.uniform_prior(np.array([1.0, 3.0]), 0, 2), [0.0, -np.inf])
+    assert na.normal_prior(1.3, 1.0, 0.5) == pytest.approx(-0.5 * np.pi - 0.09)
+    assert na.log_uniform_prior(2.0, 1.0, 3.0) == 0.5
+    assert_allclose(na.log_uniform_prior(np.array([2.0, 4.0, -1.0]), 1.0, 3.0),
+                    [0.5, -np.inf, -np.inf])
+
+
+def test_abi_exports_every_declared_symbol():
+    """the library loads on a GPU-less box and exports include/naima_hip.h"""
+    import __graft_entry__ as g
+    from naima_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = g.declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_lib.EXPORTS) == set(declared)
+
+
+def test_no_cpu_fallback():
+    """without a GPU every compute path must raise, never silently fall back"""
+    from naima_amd import _lib
+    try:
+        _lib.get_context()
+    except _lib.NaimaHipError:
+        pass
+    else:
+        pytest.skip("a GPU is present")
+    ECPL = na.ExponentialCutoffPowerLaw(1e36 / u.eV, 10 * u.TeV, 2.5, 50 * u.TeV)
+    with pytest.raises(_lib.NaimaHipError):
+        na.Synchrotron(ECPL).flux(np.logspace(0, 3, 4) * u.eV)
+    with pytest.raises(_lib.NaimaHipError):
+        ECPL(np.logspace(9, 12, 4) * u.eV)
+    # and nothing in the product imports the oracle
+    import subprocess
+    import sys
+    code = ("import sys, naima_amd, naima_amd.sampler, naima_amd.dist, naima_amd.datatable, "
+            "naima_amd.workloads; print(any(m.startswith('oracle') for m in sys.modules))")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT).decode().strip()
+    assert out == "False"
+
+
+def test_data_ingest():
+    from naima_amd import datatable as D
+    n = 6
+    t = D.DataTable()
+    t["energy"] = np.geomspace(1, 30, n) * u.TeV
+    t["flux"] = 1e-11 * np.ones(n) * u.Unit("1/(cm2 s TeV)")
+    t["flux_error"] = 1e-12 * np.ones(n) * u.Unit("1/(cm2 s TeV)")
+    t["ul"] = np.array([0, 0, 0, 0, 0, 1])
+    t.meta = {"keywords": {"cl": {"value": 0.95}}}
+    x = D.DataTable()
+    x["energy"] = np.array([3.0, 1.0, 2.0]) * u.keV
+    x["flux"] = np.array([3e-10, 1e-10, 2e-10]) * u.Unit("erg/(cm2 s)")
+    x["flux_error_lo"] = 0.1 * x["flux"]
+    x["flux_error_hi"] = 0.2 * x["flux"]
+    d = D.validate_data_table([x, t])
+    assert len(d) == 9 and d["flux"].unit.physical_type == "flux"
+    assert np.all(np.diff(d["energy"].value) > 0)  # sorted, in the first table's unit
+    assert_allclose(d["energy"].value[:3], [1, 2, 3])
+    assert_allclose(d["flux"].value[:3], [1e-10, 2e-10, 3e-10])
+    # TeV points converted to SED: E^2 * flux
+    e = t["energy"].to("erg").value
+    assert_allclose(d["flux"].value[3:], e ** 2 * 1e-11 / 1.602176634)
+    assert d["ul"].sum() == 1 and d["ul"][-1]
+    assert_allclose(d["cl"], [0.9] * 3 + [0.95] * 6)
+    d2 = D.validate_data_table([x, t], sed=False)
+    assert d2["flux"].unit.physical_type == "differential flux"
+    with pytest.raises(TypeError):
+        D.validate_data_table([{"energy": t["energy"]}])
+    with pytest.raises(TypeError):
+        D.validate_data_table(3)
+
+
+def test_readers_roundtrip(tmp_path):
+    from naima_amd import datatable as D
+    p = tmp_path / "t.dat"
+    p.write_text("\\ comment\n\\cl=0.95\n|energy|  flux|flux_error|  ul|\n|double|double|    double|long|\n"
+                 "|   TeV|1 / (cm2 s TeV)|1 / (cm2 s TeV)|    |\n 0.33 2.29e-10 3.2e-11 0\n 0.4 1.25e-10 0.0 1\n")
+    t = D.read(str(p))
+    assert t["energy"].unit == u.TeV and t["ul"].tolist() == [0, 1]
+    assert t.meta["keywords"]["cl"]["value"] == 0.95
+    d = D.validate_data_table(t)
+    assert d["cl"][0] == 0.95 and d["ul"][1]
+    q = tmp_path / "t.ecsv"
+    q.write_text("# %ECSV 0.9\n# ---\n# datatype:\n# - {name: energy, unit: MeV, datatype: float64}\n"
+                 "# - {name: flux, unit: erg / (cm2 s), datatype: float64}\n"
+                 "# - {name: flux_error, unit: erg / (cm2 s), datatype: float64}\n"
+                 "energy flux flux_error\n1.0 2e-10 1e-11\n2.0 1e-10 1e-11\n")
+    e = D.read(str(q))
+    assert e["energy"].unit == u.MeV and len(e) == 2
+
+
+def test_workload_definitions():
+    from naima_amd import workloads as W
+    assert set(W.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"}
+    raw = W.build_data("cfg3", lambda E: 1e-12 * (E / 1e3) ** -2.0)
+    assert len(raw["energy"]) == 64 and raw["flux_unit"] == "erg/(cm2 s)"
+    assert np.all(np.diff(raw["energy"]) > 0) and raw["ul"].sum() == 1
+    assert W.test_vectors("cfg3").shape == (8, 5)

@@ -1,0 +1,145 @@
+"""The ensemble driver on CPU: move statistics, shapes, sharding over ranks with
+gloo (world_size 2), and the device-side propose/accept formulas' host twins.
+The log-probability here is either analytic or the NumPy oracle (tests may use
+the oracle as a stand-in evaluator; the product never does)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from naima_amd.dist import LocalComm, shard_bounds, shard_counts
+from naima_amd.sampler import EnsembleSampler, State
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gauss(x):
+    return -0.5 * np.sum((x - 1.5) ** 2 / 0.25, axis=1), np.sum(x, axis=1), x[:, :2] * 2.0
+
+
+def test_shard_bounds():
+    for n in (0, 1, 7, 128, 255):
+        for size in (1, 2, 3, 8):
+            cnt = shard_counts(n, size)
+            assert sum(cnt) == n and max(cnt) - min(cnt) <= 1
+            assert shard_bounds(n, size - 1, size)[1] == n
+
+
+def test_stretch_move_statistics_and_surface():
+    s = EnsembleSampler(64, 3, gauss, seed=1)
+    p0 = np.random.default_rng(0).normal(size=(64, 3))
+    st = s.run_mcmc(p0, 700)
+    c = s.get_chain(discard=200, flat=True)
+    assert_allclose(c.mean(0), 1.5, atol=0.06)
+    assert_allclose(c.std(0), 0.5, atol=0.05)
+    assert 0.3 < s.acceptance_fraction.mean() < 0.9
+    assert s.get_chain().shape == (700, 64, 3) and s.chain.shape == (64, 700, 3)
+    assert s.get_log_prob().shape == (700, 64) and s.lnprobability.shape == (64, 700)
+    b = s.get_blobs()
+    assert b[0].shape == (700, 64) and b[1].shape == (700, 64, 2)
+    # blobs follow the accepted walkers
+    assert_allclose(b[0][-1], st.coords.sum(axis=1))
+    assert_allclose(b[1][-1], st.coords[:, :2] * 2)
+    assert_allclose(st.log_prob, gauss(st.coords)[0])
+    s.reset()
+    assert s.iteration == 0 and s.get_chain().shape[0] == 0
+    with pytest.raises(ValueError):
+        EnsembleSampler(5, 3, gauss)
+    with pytest.raises(ValueError):
+        EnsembleSampler(8, 3, lambda x: np.full(len(x), np.nan)).run_mcmc(p0[:8], 1)
+
+
+def test_same_seed_same_chain_and_restart():
+    a = EnsembleSampler(32, 3, gauss, seed=5)
+    b = EnsembleSampler(32, 3, gauss, seed=5)
+    p0 = np.random.default_rng(2).normal(size=(32, 3))
+    sa = a.run_mcmc(p0, 20)
+    sb = b.run_mcmc(p0, 10)
+    sb = b.run_mcmc(sb, 10)  # continuing from a State does not re-evaluate
+    assert_allclose(sa.coords, sb.coords)
+
+
+def test_reference_move_restatement_agrees():
+    """sampler.sample == oracle.stretch_move_reference for the same stream"""
+    from oracle import naima_np as O
+    p0 = np.random.default_rng(3).normal(size=(16, 2))
+    lp = lambda x: -0.5 * np.sum(x ** 2, axis=1)  # noqa: E731
+    s = EnsembleSampler(16, 2, lp, seed=9, store_blobs=False)
+    st = s.run_mcmc(p0, 5)
+    rng = np.random.default_rng(9)
+    c, l = p0.copy(), lp(p0)
+    for _ in range(5):
+        c, l, _ = O.stretch_move_reference(c, l, lp, rng)
+    assert_allclose(st.coords, c)
+    assert_allclose(st.log_prob, l)
+
+
+def test_naima_style_with_oracle_model(golden):
+    """naima's (pars, data) -> (flux, blob) contract through the sampler, with the
+    oracle standing in for the GPU evaluator (cfg1, 16 walkers, 3 steps)"""
+    from oracle import workloads_np as WN
+    z = golden("cfg1")
+    raw = WN.raw_from_npz(z)
+
+    def lnprob_batch(parsT, raw_):
+        out = [WN.lnprob("cfg1", p, raw_) for p in np.asarray(parsT).T]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]))
+
+    p0 = z["pars"][0]
+    s = EnsembleSampler(16, 3, lnprob_batch, args=[raw], seed=3, naima_style=True)
+    pos = p0 * (1 + 0.01 * s._rng.normal(size=(16, 3)))
+    st = s.run_mcmc(pos, 3)
+    assert s.get_blobs()[0].shape == (3, 16, 28)
+    assert np.all(np.isfinite(st.log_prob))
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from naima_amd.dist import GlooComm
+from naima_amd.sampler import EnsembleSampler
+comm = GlooComm()
+calls = []
+def lp(x):
+    calls.append(len(x))
+    return -0.5 * np.sum((x - 1.5) ** 2 / 0.25, axis=1), np.sum(x, axis=1)
+s = EnsembleSampler(30, 3, lp, seed=11, comm=comm)
+p0 = np.random.default_rng(0).normal(size=(30, 3))
+st = s.run_mcmc(p0, 25)
+np.save(os.path.join(%(out)r, "coords_%%d.npy" %% comm.rank), st.coords)
+np.save(os.path.join(%(out)r, "logp_%%d.npy" %% comm.rank), st.log_prob)
+np.save(os.path.join(%(out)r, "calls_%%d.npy" %% comm.rank), np.array(calls))
+g = comm.allgather(np.full((2, 3), float(comm.rank)))
+assert g.shape == (4, 3) and g[0, 0] == 0 and g[3, 0] == 1
+assert comm.max(comm.rank) == 1.0
+'''
+
+
+def test_two_ranks_gloo_match_single_process(tmp_path):
+    """world_size 2 over gloo: each rank evaluates its shard, one all-gather per
+    half-step, and the ensemble is identical on both ranks and to a 1-rank run"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000)
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+        env=env, cwd=ROOT, timeout=300)
+    c0, c1 = np.load(tmp_path / "coords_0.npy"), np.load(tmp_path / "coords_1.npy")
+    assert_allclose(c0, c1)
+    assert_allclose(np.load(tmp_path / "logp_0.npy"), np.load(tmp_path / "logp_1.npy"))
+
+    def lp(x):
+        return -0.5 * np.sum((x - 1.5) ** 2 / 0.25, axis=1), np.sum(x, axis=1)
+    s = EnsembleSampler(30, 3, lp, seed=11)
+    st = s.run_mcmc(np.random.default_rng(0).normal(size=(30, 3)), 25)
+    assert_allclose(st.coords, c0)
+    calls0, calls1 = np.load(tmp_path / "calls_0.npy"), np.load(tmp_path / "calls_1.npy")
+    # 15 proposals per half-step split 8 + 7 (initial evaluation: 30 split 15 + 15)
+    assert calls0[0] == 15 and calls1[0] == 15
+    assert set(calls0[1:]) == {8} and set(calls1[1:]) == {7}
