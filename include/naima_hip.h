@@ -182,6 +182,63 @@ int nh_stretch_accept(nh_ctx* ctx, double* s, double* oldlp, const double* q,
                       const double* newlp, const double* factors, const double* lnu, int ns,
                       int ndim, int* accepted);
 
+/* ---- device-resident step loop ------------------------------------------- */
+/* A lazy per-walker scalar: value[w] = a * tf(b * base[w*stride] + c); base NULL
+ * means the constant a.  It lets the parameter transforms a naima model function
+ * writes (10**pars[0] / u.eV, pars[3] * u.uG ...) be folded into the kernel that
+ * consumes them, with pars living in HBM. */
+enum { NH_TF_ID = 0, NH_TF_POW10 = 1, NH_TF_EXP = 2, NH_TF_LOG = 3, NH_TF_LOG10 = 4,
+       NH_TF_SQRT = 5, NH_TF_SQUARE = 6, NH_TF_RECIP = 7 };
+typedef struct { const double* base; long long stride; double a, b, c; int tf; int pad; } nh_lazy;
+#define NH_MAX_LAZY 8
+/* out[w*ld + j] = value_j[w], j < ncols <= NH_MAX_LAZY: builds the [N][NH_PD_NPAR]
+ * parameter rows of nh_particle_weights (and B[N]) on the device */
+int nh_pack_rows(nh_ctx* ctx, const nh_lazy* cols /*host [ncols]*/, int ncols, int N,
+                 double* out, int ld);
+enum { NH_OP_ADD = 0, NH_OP_SUB, NH_OP_MUL, NH_OP_DIV, NH_OP_POW, NH_OP_MAX, NH_OP_MIN,
+       NH_OP_LT, NH_OP_LE, NH_OP_GT, NH_OP_GE };
+int nh_ew_binary(nh_ctx* ctx, int op, const nh_lazy* x, const nh_lazy* y, int N, double* out);
+
+/* a spectrum component: ptr[w*ld + k] * scale */
+typedef struct { const double* ptr; long long ld; double scale; } nh_comp;
+#define NH_MAX_COMP 8
+/* out[w*ldo + k] = colfac[k] * sum_j comps[j]   (colfac may be NULL) */
+int nh_lincomb(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, const double* colfac,
+               int N, int m, double* out, int ldo);
+
+/* priors of core.py:34-58 on lazy scalars; lp[w] = sum of the terms */
+enum { NH_PRIOR_UNIFORM = 0, NH_PRIOR_NORMAL = 1, NH_PRIOR_LOGUNIFORM = 2, NH_PRIOR_VALUE = 3 };
+typedef struct { nh_lazy x; double p0, p1; int kind; int pad; } nh_prior;
+#define NH_MAX_PRIOR 16
+int nh_priors(nh_ctx* ctx, const nh_prior* terms /*host*/, int nterms, int N, double* lp);
+
+/* core.py:97-121 in one launch: model = sum comps; lnl as nh_lnprobmodel;
+ * total[w] = isinf(lp[w]) ? lp[w] : lnl + lp[w]   (lp may be NULL = 0). */
+int nh_lnprob(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, int N, int nE,
+              const double* conv, const double* flux, const double* err_lo,
+              const double* err_hi, const int* ul, const double* cl, const double* lp,
+              double* model_out /*[N][nE] or NULL*/, double* total);
+
+/* stretch move on a device-resident ensemble coords[N][ndim], logp[N].
+ * idx[0:ns] = active walkers S, idx[ns:2ns] = partner of each (a walker of the
+ * complementary half); rnd[0:ns] = z, rnd[ns:2ns] = ln U'.  propose writes the
+ * block [lo, lo+nloc) of the proposals TRANSPOSED (qT[d][j]: pars[d] is a contiguous
+ * vector over walkers); accept needs all ns new log-probabilities. */
+int nh_move_propose(nh_ctx* ctx, const double* coords, const int* idx, const double* rnd, int ns,
+                    int ndim, int lo, int nloc, double* qT, double* factors);
+int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const int* idx, const double* rnd,
+                   const double* newlp, int ns, int ndim, int* accepted, int* naccepted);
+/* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
+int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
+                    const int* idx, const int* accepted, int lo, int nloc, int m);
+int nh_copy(nh_ctx* ctx, void* dev_dst, const void* dev_src, long long bytes);
+
+/* capture everything launched on the context's stream into a hipGraph, replay it */
+int nh_graph_begin(nh_ctx* ctx);
+int nh_graph_end(nh_ctx* ctx, void** graph_exec_out);
+int nh_graph_launch(nh_ctx* ctx, void* graph_exec);
+int nh_graph_destroy(nh_ctx* ctx, void* graph_exec);
+
 /* ---- multi-GPU: one all-gather per half-step -------------- */
 #define NH_UNIQUE_ID_BYTES 128
 int nh_comm_unique_id(char* id_out /*[NH_UNIQUE_ID_BYTES]*/);

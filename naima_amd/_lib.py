@@ -54,6 +54,19 @@ _SIGS = {
                        _dp, _dp, _dp, _dp],
     "nh_stretch_propose": [_dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
     "nh_stretch_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp],
+    "nh_pack_rows": [_dp, _dp, _i, _i, _dp, _i],
+    "nh_ew_binary": [_dp, _i, _dp, _dp, _i, _dp],
+    "nh_lincomb": [_dp, _dp, _i, _dp, _i, _i, _dp, _i],
+    "nh_priors": [_dp, _dp, _i, _i, _dp],
+    "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
+    "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
+    "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
+    "nh_copy": [_dp, _dp, _dp, _ll],
+    "nh_graph_begin": [_dp],
+    "nh_graph_end": [_dp, C.POINTER(_dp)],
+    "nh_graph_launch": [_dp, _dp],
+    "nh_graph_destroy": [_dp, _dp],
     "nh_comm_unique_id": [C.c_char_p],
     "nh_comm_init": [_dp, _i, _i, C.c_char_p],
     "nh_comm_destroy": [_dp],
@@ -107,12 +120,17 @@ class DeviceArray:
         return int(np.prod(self.shape, dtype=np.int64))
 
     def get(self):
+        if self.ctx.capturing:
+            raise RuntimeError("device->host download while a hipGraph is being captured")
         out = np.empty(self.shape, dtype=self.dtype)
         if out.nbytes:
             _chk(_lib.nh_download(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
     def set(self, host):
+        if self.ctx.capturing:
+            raise RuntimeError("host->device upload while a hipGraph is being captured: the "
+                               "value must come from a device-resident input")
         host = np.ascontiguousarray(host, dtype=self.dtype)
         assert host.nbytes == self.nbytes, (host.shape, self.shape)
         if host.nbytes:
@@ -142,6 +160,8 @@ class Context:
         self._const = {}
         self._keep = {}
         self._lx = {}
+        self._tables = {}
+        self.capturing = False
 
     # -- memory -------------------------------------------------------------
     @staticmethod
@@ -180,6 +200,7 @@ class Context:
             if len(self._const) > 256:
                 self._const.clear()
                 self._lx.clear()
+                self._tables.clear()
             hit = self.array(host, dtype)
             self._const[key] = hit
         return hit
@@ -193,6 +214,39 @@ class Context:
             _chk(_lib.nh_grid_logratio(self.h, grid_dev.ptr, n, hit.ptr))
             self._lx[grid_dev.ptr] = hit
         return hit
+
+    def table(self, key, build):
+        """walker-independent emission tables, cached by what they depend on (device
+        pointers of the content-addressed grid/energy arrays + scalar parameters)"""
+        hit = self._tables.get(key)
+        if hit is None:
+            if len(self._tables) > 64:
+                self._tables.clear()
+            hit = build()
+            self._tables[key] = hit
+        return hit
+
+    # -- hipGraph capture -----------------------------------------------------
+    def graph_begin(self):
+        _chk(_lib.nh_graph_begin(self.h))
+        self.capturing = True
+
+    def graph_end(self):
+        self.capturing = False
+        g = _dp()
+        _chk(_lib.nh_graph_end(self.h, C.byref(g)))
+        return g
+
+    def graph_abort(self):
+        if self.capturing:
+            self.capturing = False
+            g = _dp()
+            _lib.nh_graph_end(self.h, C.byref(g))
+            if g:
+                _lib.nh_graph_destroy(self.h, g)
+
+    def graph_launch(self, g):
+        _chk(_lib.nh_graph_launch(self.h, g))
 
     def sync(self):
         _chk(_lib.nh_sync(self.h))
@@ -231,6 +285,7 @@ class Context:
         if self.h:
             self._const.clear()
             self._lx.clear()
+            self._tables.clear()
             _lib.nh_destroy(self.h)
             self.h = None
 

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import units as u
 from ._lib import get_context
+from .darray import DMat, DPars, DVec, LazyPrior
 
 __all__ = ["normal_prior", "uniform_prior", "log_uniform_prior", "lnprob", "lnprobmodel",
            "get_sampler", "run_sampler"]
@@ -19,6 +20,8 @@ __all__ = ["normal_prior", "uniform_prior", "log_uniform_prior", "lnprob", "lnpr
 # ---- priors (core.py:34-58), valid for scalars and for vectors over walkers ----
 def uniform_prior(value, umin, umax):
     """Uniform prior distribution: 0 inside [umin, umax], -inf outside."""
+    if isinstance(value, DVec):
+        return LazyPrior(value.ctx, value.n, [(0, value, umin, umax)])
     value = np.asarray(value, dtype=float)
     out = np.where((umin <= value) & (value <= umax), 0.0, -np.inf)
     return float(out) if out.ndim == 0 else out
@@ -26,11 +29,16 @@ def uniform_prior(value, umin, umax):
 
 def normal_prior(value, mean, sigma):
     """Normal prior distribution (as the reference writes it, core.py:42-44)."""
+    if isinstance(value, DVec):
+        return LazyPrior(value.ctx, value.n, [(1, value, mean, sigma)])
     return -0.5 * (2 * np.pi * sigma) - (value - mean) ** 2 / (2.0 * sigma)
 
 
 def log_uniform_prior(value, umin=0, umax=None):
     """Log-uniform prior distribution (returns 1/value as the reference, core.py:47-58)."""
+    if isinstance(value, DVec):
+        return LazyPrior(value.ctx, value.n,
+                         [(2, value, umin, np.inf if umax is None else umax)])
     value = np.asarray(value, dtype=float)
     ok = (value > 0) & (value >= umin)
     if umax is not None:
@@ -89,10 +97,25 @@ def _conversion_to_data(model_unit, data):
     return np.ascontiguousarray(f, dtype=float)
 
 
+def _data_on_device(ctx, data):
+    """the _DataOnDevice of a table, created once per (table, context)"""
+    cache = getattr(data, "_nh_dev", None)
+    if cache is not None and cache[0] is ctx:
+        return cache[1]
+    dd = _DataOnDevice(ctx, data)
+    try:
+        data._nh_dev = (ctx, dd)
+    except AttributeError:  # a plain dict: no place to remember it
+        pass
+    return dd
+
+
 class _DataOnDevice:
     """the data columns the likelihood needs, resident in HBM (cached per table)"""
 
     def __init__(self, ctx, data):
+        self._conv = {}
+        self._data = data
         dunit = data["flux"].unit
         self.flux = ctx.const(data["flux"].value)
         self.elo = ctx.const(data["flux_error_lo"].to(dunit).value)
@@ -102,15 +125,39 @@ class _DataOnDevice:
         # cl is indexed by the violation count (core.py:92): pad so that index n_E is valid
         self.cl = ctx.const(np.concatenate([cl, cl[-1:]]))
         self.n = int(np.size(data["flux"].value))
+        self.ctx = ctx
+
+    def conv(self, model_unit, colfac=None):
+        """device copy of the per-energy factor model unit -> data unit"""
+        key = (model_unit.dims, float(model_unit.scale),
+               None if colfac is None else hash(colfac.tobytes()))
+        hit = self._conv.get(key)
+        if hit is None:
+            f = _conversion_to_data(model_unit, self._data)
+            if colfac is not None:
+                f = f * colfac
+            hit = self.ctx.const(f)
+            self._conv[key] = hit
+        return hit
 
 
-def lnprobmodel(model, data):
+def lnprobmodel(model, data, lp=None):
     """Log-likelihood of ``model`` (Quantity, shape (n_E,) or (N, n_E)) given the data
-    table: asymmetric Gaussian errors plus the upper-limit penalty (core.py:64-94)."""
-    import ctypes as C
+    table: asymmetric Gaussian errors plus the upper-limit penalty (core.py:64-94).
+    A device-resident model (``DMat``) gives a device-resident result."""
     ctx = get_context()
-    conv = _conversion_to_data(model.unit, data)
-    dd = _DataOnDevice(ctx, data)
+    dd = _data_on_device(ctx, data)
+    if isinstance(model.value, DMat):
+        m = model.value
+        N, nE = m.shape
+        if nE != dd.n:
+            raise ValueError("model has %d energies, data table has %d" % (nE, dd.n))
+        total = ctx.empty((N,))
+        lpp = lp.dense().ptr if lp is not None else None
+        ctx.call("nh_lnprob", m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),
+                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpp, None, total)
+        return DVec(ctx, total, total.ptr, N)
+    import ctypes as C
     m = np.asarray(model.value, dtype=float)
     batched = m.ndim == 2
     m2 = np.ascontiguousarray(m if batched else m[None, :])
@@ -121,14 +168,37 @@ def lnprobmodel(model, data):
     lnl = ctx.empty((N,))
     comps = (C.c_void_p * 1)(md.ptr)
     cscale = (C.c_double * 1)(1.0)
-    ctx.call("nh_lnprobmodel", comps, cscale, 1, nE, N, nE, ctx.const(conv), dd.flux, dd.elo,
+    ctx.call("nh_lnprobmodel", comps, cscale, 1, nE, N, nE, dd.conv(model.unit), dd.flux, dd.elo,
              dd.ehi, dd.ul, dd.cl, None, lnl)
     out = lnl.get()
     return out if batched else float(out[0])
 
 
+def _lnprob_device(pars, data, modelfunc, priorfunc):
+    """core.py:97-121 with the ensemble in HBM: nothing comes back to the host"""
+    lp = None
+    if priorfunc is not None:
+        lp = priorfunc(pars)
+        if isinstance(lp, LazyPrior):
+            lp = lp.evaluate()
+        elif not isinstance(lp, DVec):
+            lp = LazyPrior(pars.ctx, pars.n, [], float(lp)).evaluate()
+    modelout = modelfunc(pars, data)
+    if isinstance(modelout, (tuple, list)):
+        model, blob = modelout[0], tuple(modelout)
+    else:
+        model, blob = modelout, (modelout,)
+    if not isinstance(model.value, DMat):
+        raise TypeError("the model function returned a host array for device-resident "
+                        "parameters; it must build its flux from naima_amd radiative models")
+    total = lnprobmodel(model, data, lp=lp)
+    return (total, *blob)
+
+
 def lnprob(pars, data, modelfunc, priorfunc):
     """(lnprob, *blobs) for one walker or for a batch (core.py:97-121)."""
+    if isinstance(pars, DPars):
+        return _lnprob_device(pars, data, modelfunc, priorfunc)
     pars = np.asarray(pars, dtype=float)
     if priorfunc is None:
         lnprob_priors = 0.0

@@ -378,18 +378,18 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
 // row 11: lnprobmodel (core.py:64-94), one wave per walker
 // ---------------------------------------------------------------------------
 struct nh_comps {
-  const double* p[4];
-  double s[4];
+  nh_comp c[NH_MAX_COMP];
   int n;
 };
 
-__global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int ldc, int N, int nE,
+__global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
                                                       const double* __restrict__ conv,
                                                       const double* __restrict__ flux,
                                                       const double* __restrict__ elo,
                                                       const double* __restrict__ ehi,
                                                       const int* __restrict__ ul,
                                                       const double* __restrict__ cl,
+                                                      const double* __restrict__ lp,
                                                       double* __restrict__ model_out,
                                                       double* __restrict__ lnl) {
   const int lane = threadIdx.x & 63;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int ldc, int N
   int nviol = 0, nul = 0;
   for (int k = lane; k < nE; k += 64) {
     double m = 0.0;
-    for (int j = 0; j < cs.n; ++j) m += cs.s[j] * cs.p[j][(long long)wi * ldc + k];
+    for (int j = 0; j < cs.n; ++j) m += cs.c[j].scale * cs.c[j].ptr[(long long)wi * cs.c[j].ld + k];
     if (model_out) model_out[(long long)wi * nE + k] = m;
     double mc = m * conv[k];
     double f = flux[k];
@@ -421,8 +421,23 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int ldc, int N
   if (lane == 0) {
     // quirk kept from core.py:89-92: cl is indexed by the violation count
     if (nul > 0) acc += (double)nviol * log(1.0 - cl[nviol]);
+    if (lp) {  // core.py:115-119: a walker forbidden by the prior keeps the prior value
+      double p = lp[wi];
+      acc = isinf(p) ? p : acc + p;
+    }
     lnl[wi] = acc;
   }
+}
+
+static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const double* conv,
+                         const double* flux, const double* err_lo, const double* err_hi,
+                         const int* ul, const double* cl, const double* lp, double* model_out,
+                         double* lnl) {
+  nh_prof_scope ps(c, NH_K_LNPROB);
+  hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, N, nE, conv,
+                     flux, err_lo, err_hi, ul, cl, lp, model_out, lnl);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
 }
 
 extern "C" int nh_lnprobmodel(nh_ctx* c, const double* const* comps, const double* cscale,
@@ -431,20 +446,30 @@ extern "C" int nh_lnprobmodel(nh_ctx* c, const double* const* comps, const doubl
                               const int* ul, const double* cl, double* model_out, double* lnl) {
   NH_REQUIRE(c && comps && cscale && conv && flux && err_lo && err_hi && ul && cl && lnl,
              "NULL pointer");
-  NH_REQUIRE(ncomp >= 1 && ncomp <= 4, "ncomp must be 1..4");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP, "ncomp must be 1..8");
   NH_REQUIRE(N >= 0 && nE >= 1 && ldc >= nE, "bad sizes");
   if (N == 0) return NH_OK;
   nh_comps cs;
   cs.n = ncomp;
-  for (int j = 0; j < 4; ++j) {
-    cs.p[j] = j < ncomp ? comps[j] : nullptr;
-    cs.s[j] = j < ncomp ? cscale[j] : 0.0;
+  for (int j = 0; j < ncomp; ++j) cs.c[j] = {comps[j], ldc, cscale[j]};
+  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, nullptr, model_out, lnl);
+}
+
+extern "C" int nh_lnprob(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int nE,
+                         const double* conv, const double* flux, const double* err_lo,
+                         const double* err_hi, const int* ul, const double* cl, const double* lp,
+                         double* model_out, double* total) {
+  NH_REQUIRE(c && comps && conv && flux && err_lo && err_hi && ul && cl && total, "NULL pointer");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP, "ncomp must be 1..8");
+  NH_REQUIRE(N >= 0 && nE >= 1, "bad sizes");
+  if (N == 0) return NH_OK;
+  nh_comps cs;
+  cs.n = ncomp;
+  for (int j = 0; j < ncomp; ++j) {
+    NH_REQUIRE(comps[j].ptr && comps[j].ld >= nE, "bad component");
+    cs.c[j] = comps[j];
   }
-  nh_prof_scope ps(c, NH_K_LNPROB);
-  hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, ldc, N, nE,
-                     conv, flux, err_lo, err_hi, ul, cl, model_out, lnl);
-  NH_CHECK_HIP(hipGetLastError());
-  return NH_OK;
+  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, model_out, total);
 }
 
 // ---------------------------------------------------------------------------

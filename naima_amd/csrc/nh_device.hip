@@ -1,0 +1,298 @@
+// nh_device.hip -- the pieces that keep a whole sampler half-step on the device:
+// lazy per-walker scalars (parameter transforms folded into the consumer),
+// elementwise fallbacks, linear combinations of spectra, priors, the stretch
+// move on device-resident ensembles, and hipGraph capture/replay of the launch
+// sequence that a naima model function produces.
+#include "nh_common.h"
+
+// value[w] = a * tf(b * base[w*stride] + c);  base == NULL -> the constant a
+__device__ __forceinline__ double lazy_eval(const nh_lazy& z, long long w) {
+  if (!z.base) return z.a;
+  double x = z.b * z.base[w * z.stride] + z.c;
+  switch (z.tf) {
+    case NH_TF_POW10: x = pow(10.0, x); break;
+    case NH_TF_EXP: x = exp(x); break;
+    case NH_TF_LOG: x = log(x); break;
+    case NH_TF_LOG10: x = log10(x); break;
+    case NH_TF_SQRT: x = sqrt(x); break;
+    case NH_TF_SQUARE: x = x * x; break;
+    case NH_TF_RECIP: x = 1.0 / x; break;
+    default: break;
+  }
+  return z.a * x;
+}
+
+struct lazy_pack { nh_lazy c[NH_MAX_LAZY]; int n; };
+
+__global__ void k_pack_rows(lazy_pack P, int N, double* __restrict__ out, int ld) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * P.n) return;
+  int w = idx / P.n, j = idx % P.n;
+  out[(long long)w * ld + j] = lazy_eval(P.c[j], w);
+}
+
+extern "C" int nh_pack_rows(nh_ctx* c, const nh_lazy* cols, int ncols, int N, double* out,
+                            int ld) {
+  NH_REQUIRE(c && cols && out && ncols >= 1 && ncols <= NH_MAX_LAZY && N >= 0 && ld >= ncols,
+             "bad argument");
+  if (N == 0) return NH_OK;
+  lazy_pack P;
+  P.n = ncols;
+  for (int j = 0; j < ncols; ++j) P.c[j] = cols[j];
+  nh_prof_scope ps(c, NH_K_PDIST);
+  int tot = N * ncols;
+  hipLaunchKernelGGL(k_pack_rows, dim3((tot + 255) / 256), dim3(256), 0, c->stream, P, N, out, ld);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// elementwise fallbacks for model functions that do arithmetic the lazy form
+// cannot express: out = op(x, y) with x, y lazy per-walker scalars
+// ---------------------------------------------------------------------------
+__global__ void k_ew_binary(int op, nh_lazy x, nh_lazy y, int N, double* __restrict__ out) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= N) return;
+  double a = lazy_eval(x, w), b = lazy_eval(y, w), r;
+  switch (op) {
+    case NH_OP_ADD: r = a + b; break;
+    case NH_OP_SUB: r = a - b; break;
+    case NH_OP_MUL: r = a * b; break;
+    case NH_OP_DIV: r = a / b; break;
+    case NH_OP_POW: r = pow(a, b); break;
+    case NH_OP_MAX: r = fmax(a, b); break;
+    case NH_OP_MIN: r = fmin(a, b); break;
+    case NH_OP_LT: r = a < b ? 1.0 : 0.0; break;
+    case NH_OP_LE: r = a <= b ? 1.0 : 0.0; break;
+    case NH_OP_GT: r = a > b ? 1.0 : 0.0; break;
+    case NH_OP_GE: r = a >= b ? 1.0 : 0.0; break;
+    default: r = a; break;
+  }
+  out[w] = r;
+}
+
+extern "C" int nh_ew_binary(nh_ctx* c, int op, const nh_lazy* x, const nh_lazy* y, int N,
+                            double* out) {
+  NH_REQUIRE(c && x && y && out && N >= 0, "bad argument");
+  if (N == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_PDIST);
+  hipLaunchKernelGGL(k_ew_binary, dim3((N + 255) / 256), dim3(256), 0, c->stream, op, *x, *y, N,
+                     out);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// out[w][k] = colfac[k] * sum_j scale_j * comp_j[w*ld_j + k]
+// ---------------------------------------------------------------------------
+struct comp_pack { nh_comp c[NH_MAX_COMP]; int n; };
+
+__global__ void k_lincomb(comp_pack P, const double* __restrict__ colfac, int N, int m,
+                          double* __restrict__ out, int ldo) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)N * m) return;
+  int w = (int)(idx / m), k = (int)(idx % m);
+  double s = 0.0;
+  for (int j = 0; j < P.n; ++j) s += P.c[j].scale * P.c[j].ptr[(long long)w * P.c[j].ld + k];
+  if (colfac) s *= colfac[k];
+  out[(long long)w * ldo + k] = s;
+}
+
+extern "C" int nh_lincomb(nh_ctx* c, const nh_comp* comps, int ncomp, const double* colfac, int N,
+                          int m, double* out, int ldo) {
+  NH_REQUIRE(c && comps && out && ncomp >= 1 && ncomp <= NH_MAX_COMP && N >= 0 && m >= 1 &&
+                 ldo >= m, "bad argument");
+  if (N == 0) return NH_OK;
+  comp_pack P;
+  P.n = ncomp;
+  for (int j = 0; j < ncomp; ++j) P.c[j] = comps[j];
+  nh_prof_scope ps(c, NH_K_LNPROB);
+  long long tot = (long long)N * m;
+  hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, P,
+                     colfac, N, m, out, ldo);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// priors (core.py:34-58) on lazy per-walker scalars, summed: lp[w] = sum_t term_t
+// ---------------------------------------------------------------------------
+struct prior_pack { nh_prior t[NH_MAX_PRIOR]; int n; };
+
+__global__ void k_priors(prior_pack P, int N, double* __restrict__ lp) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= N) return;
+  double s = 0.0;
+  for (int t = 0; t < P.n; ++t) {
+    double v = lazy_eval(P.t[t].x, w);
+    double p0 = P.t[t].p0, p1 = P.t[t].p1, r;
+    switch (P.t[t].kind) {
+      case NH_PRIOR_UNIFORM:  // core.py:34-39
+        r = (p0 <= v && v <= p1) ? 0.0 : -INFINITY;
+        break;
+      case NH_PRIOR_NORMAL:  // core.py:42-44 (as written: no log, sigma not squared)
+        r = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1);
+        break;
+      case NH_PRIOR_LOGUNIFORM:  // core.py:47-58 (returns 1/value)
+        r = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY;
+        break;
+      default:  // NH_PRIOR_VALUE: an already evaluated per-walker value
+        r = v;
+        break;
+    }
+    s += r;
+  }
+  lp[w] = s;
+}
+
+extern "C" int nh_priors(nh_ctx* c, const nh_prior* terms, int nterms, int N, double* lp) {
+  NH_REQUIRE(c && terms && lp && nterms >= 1 && nterms <= NH_MAX_PRIOR && N >= 0, "bad argument");
+  if (N == 0) return NH_OK;
+  prior_pack P;
+  P.n = nterms;
+  for (int j = 0; j < nterms; ++j) P.t[j] = terms[j];
+  nh_prof_scope ps(c, NH_K_LNPROB);
+  hipLaunchKernelGGL(k_priors, dim3((N + 255) / 256), dim3(256), 0, c->stream, P, N, lp);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident stretch move.  The host draws the random numbers (replicated
+// stream) and ships them as ONE block per half-step:
+//   rnd[0:ns]      = z            stretch factors
+//   rnd[ns:2ns]    = ln U'        accept thresholds
+//   idx[0:ns]      = S            global indices of the active walkers
+//   idx[ns:2ns]    = partner      global index of each walker's partner in C
+// ---------------------------------------------------------------------------
+__global__ void k_move_propose(const double* __restrict__ coords, const int* __restrict__ idx,
+                               const double* __restrict__ rnd, int ns, int ndim, int lo, int nloc,
+                               double* __restrict__ qT, double* __restrict__ factors) {
+  // proposals of this rank's block [lo, lo+nloc) of the active half, TRANSPOSED:
+  // qT[d][j] so that pars[d] is a contiguous vector over walkers
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nloc * ndim) return;
+  int d = t / nloc, j = t % nloc;
+  int g = lo + j;
+  double z = rnd[g];
+  double cj = coords[(long long)idx[ns + g] * ndim + d];
+  double sj = coords[(long long)idx[g] * ndim + d];
+  qT[(long long)d * nloc + j] = cj - (cj - sj) * z;
+  if (d == 0) factors[j] = (ndim - 1.0) * log(z);
+}
+
+extern "C" int nh_move_propose(nh_ctx* c, const double* coords, const int* idx,
+                               const double* rnd, int ns, int ndim, int lo, int nloc, double* qT,
+                               double* factors) {
+  NH_REQUIRE(c && coords && idx && rnd && qT && factors && ns >= 1 && ndim >= 1 && lo >= 0 &&
+                 nloc >= 0 && lo + nloc <= ns, "bad argument");
+  if (nloc == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_SAMPLER);
+  int tot = nloc * ndim;
+  hipLaunchKernelGGL(k_move_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, coords,
+                     idx, rnd, ns, ndim, lo, nloc, qT, factors);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+__global__ void k_move_accept(double* __restrict__ coords, double* __restrict__ logp,
+                              const int* __restrict__ idx, const double* __restrict__ rnd,
+                              const double* __restrict__ newlp, int ns, int ndim,
+                              int* __restrict__ accepted, int* __restrict__ naccepted) {
+  // every rank holds the full ensemble and all ns new log-probabilities: the
+  // proposal is recomputed here from (coords, z, partner) so that no coordinates
+  // ever have to be exchanged between ranks
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ns) return;
+  int me = idx[j], pa = idx[ns + j];
+  double z = rnd[j];
+  double d = (ndim - 1.0) * log(z) + newlp[j] - logp[me];
+  bool acc = rnd[ns + j] < d;  // NaN compares false, as numpy
+  if (acc) {
+    for (int k = 0; k < ndim; ++k) {
+      double cj = coords[(long long)pa * ndim + k];
+      double sj = coords[(long long)me * ndim + k];
+      coords[(long long)me * ndim + k] = cj - (cj - sj) * z;
+    }
+    logp[me] = newlp[j];
+    if (naccepted) atomicAdd(&naccepted[me], 1);
+  }
+  accepted[j] = acc ? 1 : 0;
+}
+
+extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const int* idx,
+                              const double* rnd, const double* newlp, int ns, int ndim,
+                              int* accepted, int* naccepted) {
+  NH_REQUIRE(c && coords && logp && idx && rnd && newlp && accepted && ns >= 1 && ndim >= 1,
+             "bad argument");
+  nh_prof_scope ps(c, NH_K_SAMPLER);
+  hipLaunchKernelGGL(k_move_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, coords, logp,
+                     idx, rnd, newlp, ns, ndim, accepted, naccepted);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// blob bookkeeping: dst[idx[lo+j]][:] = src[j][:] where accepted[lo+j]
+__global__ void k_scatter_rows(double* __restrict__ dst, int ldd, const double* __restrict__ src,
+                               int lds, const int* __restrict__ idx,
+                               const int* __restrict__ accepted, int lo, int nloc, int m) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nloc * m) return;
+  int j = (int)(t / m), k = (int)(t % m);
+  if (accepted == nullptr || accepted[lo + j])
+    dst[(long long)idx[lo + j] * ldd + k] = src[(long long)j * lds + k];
+}
+
+extern "C" int nh_scatter_rows(nh_ctx* c, double* dst, int ldd, const double* src, int lds,
+                               const int* idx, const int* accepted, int lo, int nloc, int m) {
+  NH_REQUIRE(c && dst && src && idx && nloc >= 0 && m >= 1 && ldd >= m && lds >= m,
+             "bad argument");
+  if (nloc == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_SAMPLER);
+  long long tot = (long long)nloc * m;
+  hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, dst, ldd, src, lds, idx, accepted, lo, nloc, m);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+extern "C" int nh_copy(nh_ctx* c, void* dst, const void* src, long long bytes) {
+  NH_REQUIRE(c && dst && src && bytes >= 0, "bad argument");
+  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+  return NH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// hipGraph capture / replay of everything launched on the context's stream
+// ---------------------------------------------------------------------------
+extern "C" int nh_graph_begin(nh_ctx* c) {
+  NH_REQUIRE(c, "ctx is NULL");
+  NH_REQUIRE(!c->profiling, "disable per-kernel profiling before capturing a graph");
+  NH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  return NH_OK;
+}
+
+extern "C" int nh_graph_end(nh_ctx* c, void** exec_out) {
+  NH_REQUIRE(c && exec_out, "bad argument");
+  hipGraph_t g = nullptr;
+  NH_CHECK_HIP(hipStreamEndCapture(c->stream, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess)
+    return nh_set_error(NH_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  *exec_out = ex;
+  return NH_OK;
+}
+
+extern "C" int nh_graph_launch(nh_ctx* c, void* exec) {
+  NH_REQUIRE(c && exec, "bad argument");
+  NH_CHECK_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_graph_destroy(nh_ctx* c, void* exec) {
+  NH_REQUIRE(c, "ctx is NULL");
+  if (exec) NH_CHECK_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec)));
+  return NH_OK;
+}

@@ -1,0 +1,246 @@
+"""The device-resident step loop of ``EnsembleSampler(device=True)``.
+
+State in HBM: coords[N][ndim], logp[N], the current blobs, per-walker acceptance
+counters, and the chain history.  Per half-step the host only draws the random
+numbers of the move (replicated numpy stream: identical on every rank and identical
+to the host-path sampler), ships them as two small blocks, and launches ONE hipGraph:
+
+    nh_move_propose -> [the launch sequence the naima model function produces:
+    nh_pack_rows, nh_particle_weights, nh_integrate_tables, nh_synchrotron, ...]
+    -> nh_priors -> nh_lnprob -> (RCCL all-gather when sharded) -> nh_move_accept
+    -> nh_scatter_rows (blobs)
+
+The graph is captured from the FIRST replay of the user's unchanged Python model
+function on lazy device parameters (``naima_amd.darray``); walker-independent
+pieces (grids, emission tables, data columns) are evaluated during a warm-up pass,
+land in the context's caches, and are therefore not part of the graph.  After
+capture no Python model code runs inside the loop.
+"""
+import numpy as np
+
+from . import _lib
+from . import units as u
+from .darray import DMat, DPars, DVec
+from .dist import shard_bounds
+
+
+class DeviceState:
+    """what the loop yields: host views are fetched on first access"""
+
+    def __init__(self, loop, rng):
+        self._loop, self.random_state = loop, rng
+        self._c = self._l = None
+
+    @property
+    def coords(self):
+        if self._c is None:
+            self._c = self._loop.coords.get().reshape(self._loop.N, self._loop.ndim)
+        return self._c
+
+    @property
+    def log_prob(self):
+        if self._l is None:
+            self._l = self._loop.logp.get()
+        return self._l
+
+    @property
+    def blobs(self):
+        return self._loop.host_blobs()
+
+    def __iter__(self):
+        return iter((self.coords, self.log_prob, self.random_state))
+
+
+class DeviceLoop:
+    def __init__(self, sampler):
+        if not sampler.naima_style:
+            raise ValueError("device=True needs naima_style=True (lnprob(pars, data, model, prior))")
+        self.s = sampler
+        self.ctx = _lib.get_context()
+        self.N, self.ndim = sampler.nwalkers, sampler.ndim
+        self.ns = self.N // 2
+        comm = sampler.comm
+        if self.ns % comm.size:
+            raise ValueError("device=True needs the half-ensemble (%d) to divide evenly over %d "
+                             "ranks" % (self.ns, comm.size))
+        self.lo, self.hi = shard_bounds(self.ns, comm.rank, comm.size)
+        self.nloc = self.hi - self.lo
+        ctx = self.ctx
+        self.coords = ctx.empty((self.N * self.ndim,))
+        self.logp = ctx.empty((self.N,))
+        self.idx = ctx.empty((2 * self.ns,), dtype=np.int32)
+        self.rnd = ctx.empty((2 * self.ns,))
+        self.qT = ctx.empty((self.ndim * self.nloc,))
+        self.factors = ctx.empty((self.nloc,))
+        self.newlp = ctx.empty((self.ns,))
+        self.accepted = ctx.empty((self.ns,), dtype=np.int32)
+        self.nacc = ctx.empty((self.N,), dtype=np.int32)
+        ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
+        self.graph = None
+        self.cur_blobs = None      # list of (device buffer [N][m], m, unit, trailing shape)
+        self.hist = []             # pending device history blocks
+        self.warm = 0
+        self._have_state = False
+
+    # ------------------------------------------------------------------ pieces
+    def reset(self):
+        self.flush()
+        self.ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
+
+    def _eval(self, qT_buf, n):
+        """run the user's model on device parameters: (total DVec, blob list)"""
+        pars = DPars(self.ctx, qT_buf, self.ndim, n)
+        res = self.s.log_prob_fn(pars, *self.s.args)
+        self.s.n_lnprob_calls += 1
+        self.s.n_walker_evals += n
+        total = res[0].dense()
+        return total, list(res[1:])
+
+    def _blob_dense(self, b):
+        """blob -> (owner, ptr, m, unit, trailing shape) with rows over walkers"""
+        unit = None
+        if isinstance(b, u.Quantity):
+            b, unit = b.value, b.unit
+        if isinstance(b, DMat):
+            own, ptr = b.buffer()
+            return own, ptr, b.shape[1], unit, (b.shape[1],)
+        if isinstance(b, DVec):
+            d = b.dense()
+            return d, d.ptr, 1, unit, ()
+        raise TypeError("blob of type %s cannot be kept on the device" % type(b).__name__)
+
+    def _half_step_body(self):
+        ctx, s = self.ctx, self.s
+        ctx.call("nh_move_propose", self.coords, self.idx, self.rnd, self.ns, self.ndim, self.lo,
+                 self.nloc, self.qT, self.factors)
+        total, blobs = self._eval(self.qT, self.nloc)
+        if s.comm.size > 1:
+            ctx.call("nh_comm_allgather", total.ptr, self.newlp, self.nloc)
+            newlp = self.newlp
+        else:
+            newlp = total.ptr
+        ctx.call("nh_move_accept", self.coords, self.logp, self.idx, self.rnd, newlp, self.ns,
+                 self.ndim, self.accepted, self.nacc)
+        if s.store_blobs and self.cur_blobs:
+            for (cur, m, _, _), b in zip(self.cur_blobs, blobs):
+                own, ptr, mb, _, _ = self._blob_dense(b)
+                ctx.call("nh_scatter_rows", cur, m, ptr, mb, self.idx, self.accepted, self.lo,
+                         self.nloc, m)
+                del own
+        del total
+
+    def _init_state(self, coords_host, logp_host):
+        ctx, s = self.ctx, self.s
+        self.coords.set(np.ascontiguousarray(coords_host, dtype=float).ravel())
+        if logp_host is not None and self._have_state:
+            self.logp.set(np.asarray(logp_host, dtype=float))
+            return
+        # initial log-probability (and blobs) of the whole ensemble: this rank's block
+        lo, hi = shard_bounds(self.N, s.comm.rank, s.comm.size)
+        qT = ctx.array(np.ascontiguousarray(coords_host[lo:hi].T))
+        total, blobs = self._eval(qT, hi - lo)
+        if s.comm.size > 1:
+            ctx.call("nh_comm_allgather", total.ptr, self.logp, hi - lo)
+        else:
+            ctx.call("nh_copy", self.logp, total.ptr, 8 * self.N)
+        if s.store_blobs and blobs:
+            self.cur_blobs, units = [], []
+            ident = ctx.array(np.arange(lo, hi, dtype=np.int32), dtype=np.int32)
+            for b in blobs:
+                own, ptr, m, unit, trail = self._blob_dense(b)
+                cur = ctx.empty((self.N, m))
+                ctx.call("nh_memset", cur, 0, cur.nbytes)
+                ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
+                self.cur_blobs.append((cur, m, unit, trail))
+                units.append(unit)
+            s.blob_units = units
+        lp = self.logp.get()
+        if np.any(np.isnan(lp)):
+            raise ValueError("Probability function returned NaN")
+        self._have_state = True
+
+    def host_blobs(self):
+        if not self.cur_blobs:
+            return None
+        return [cur.get().reshape((self.N,) + trail) for cur, m, _, trail in self.cur_blobs]
+
+    # ------------------------------------------------------------------- loop
+    def sample(self, initial_state, iterations, store):
+        from .sampler import State
+        s, ctx = self.s, self.ctx
+        if isinstance(initial_state, DeviceState) and initial_state._loop is self:
+            pass  # continue from the ensemble already in HBM
+        else:
+            st = State(initial_state)
+            if st.coords.shape != (self.N, self.ndim):
+                raise ValueError("incompatible input dimensions")
+            self._init_state(st.coords, st.log_prob)
+        rng, a, N, ns = s._rng, s.a, self.N, self.ns
+        iterations = int(iterations)
+        block = None
+        if store and iterations > 0:
+            block = dict(n=0, coords=ctx.empty((iterations, N * self.ndim)),
+                         logp=ctx.empty((iterations, N)),
+                         blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
+                                (self.cur_blobs or [])] if s.store_blobs else [])
+            self.hist.append(block)
+        idx_h = np.empty(2 * ns, dtype=np.int32)
+        rnd_h = np.empty(2 * ns)
+        for it in range(iterations):
+            inds = np.arange(N) % 2
+            rng.shuffle(inds)
+            for split in range(2):
+                S = np.nonzero(inds == split)[0]
+                Cidx = np.nonzero(inds != split)[0]
+                zz = ((a - 1.0) * rng.random(ns) + 1) ** 2.0 / a
+                rint = rng.integers(len(Cidx), size=ns)
+                lnu = np.log(rng.random(ns))
+                idx_h[:ns], idx_h[ns:] = S, Cidx[rint]
+                rnd_h[:ns], rnd_h[ns:] = zz, lnu
+                self.idx.set(idx_h)
+                self.rnd.set(rnd_h)
+                if self.graph is not None:
+                    ctx.graph_launch(self.graph)
+                elif not s.use_graph or s.comm.size > 1 or self.warm < 1:
+                    # eager pass: also the warm-up that fills the static caches
+                    self._half_step_body()
+                    self.warm += 1
+                else:
+                    ctx.sync()
+                    ctx.graph_begin()
+                    try:
+                        self._half_step_body()
+                    except Exception:
+                        ctx.graph_abort()
+                        raise
+                    self.graph = ctx.graph_end()
+                    ctx.graph_launch(self.graph)
+            s.iteration += 1
+            if block is not None:
+                k = block["n"]
+                ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim, self.coords,
+                         8 * N * self.ndim)
+                ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
+                for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
+                    ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
+                block["n"] = k + 1
+            yield DeviceState(self, rng)
+
+    def flush(self):
+        """bring the pending chain history and acceptance counters to the host"""
+        s = self.s
+        for block in self.hist:
+            n = block["n"]
+            if n == 0:
+                continue
+            c = block["coords"].get()[:n].reshape(n, self.N, self.ndim)
+            l = block["logp"].get()[:n]
+            s._chain.extend(list(c))
+            s._logp.extend(list(l))
+            if block["blobs"]:
+                if s._blobs is None:
+                    s._blobs = [[] for _ in block["blobs"]]
+                for j, (hb, (cur, m, _, trail)) in enumerate(zip(block["blobs"], self.cur_blobs)):
+                    s._blobs[j].extend(list(hb.get()[:n].reshape((n, self.N) + trail)))
+        self.hist = []
+        s.naccepted = self.nacc.get().astype(float)

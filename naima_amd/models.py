@@ -37,6 +37,11 @@ class _ParticleDistribution:
     # (attribute, slot in the NH_PD_NPAR row, is_energy)
     _slots = ()
 
+    def __setattr__(self, name, value):
+        # any parameter change invalidates the packed device rows
+        self.__dict__.pop("_rows_dev", None)
+        object.__setattr__(self, name, value)
+
     @property
     def batch_size(self):
         """number of walkers this distribution describes (1 if all parameters are scalars)"""
@@ -83,6 +88,53 @@ class _ParticleDistribution:
             rows[:, 4] = 1.0
         return rows
 
+    def device_rows(self, ctx, N, amplitude_to=None):
+        """the [N][NH_PD_NPAR] parameter rows in HBM, packed by ``nh_pack_rows`` from
+        host scalars, host vectors or lazy device scalars (no host round trip)"""
+        from .darray import DVec, lazy_const, nh_lazy
+        cache = self.__dict__.setdefault("_rows_dev", {})
+        key = (N, None if amplitude_to is None else amplitude_to.name)
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        cols = (nh_lazy * NH_PD_NPAR)()
+        for j in range(NH_PD_NPAR):
+            cols[j] = lazy_const(1.0 if j == 4 else 0.0)
+        keep = []
+        for name, slot, is_energy in self._slots:
+            v = getattr(self, name)
+            if name == "amplitude":
+                if isinstance(v, u.Quantity):
+                    v = v.to(amplitude_to).value if amplitude_to is not None else v.value
+            elif is_energy:
+                v = v.to("eV").value
+            elif isinstance(v, u.Quantity):
+                v = v.to(u.dimensionless_unscaled).value
+            if isinstance(v, DVec):
+                if v.n != N:
+                    raise ValueError("parameter %s has %d walkers, batch has %d" % (name, v.n, N))
+                cols[slot] = v.lazy()
+                keep.append(v)
+            elif np.ndim(v) == 0:
+                cols[slot] = lazy_const(v)
+            else:
+                dev = ctx.array(np.broadcast_to(np.asarray(v, dtype=float), (N,)))
+                cols[slot] = nh_lazy(dev.ptr, 1, 1.0, 1.0, 0.0, 0, 0)
+                keep.append(dev)
+        out = ctx.empty((N, NH_PD_NPAR))
+        ctx.call("nh_pack_rows", cols, NH_PD_NPAR, N, out, NH_PD_NPAR)
+        cache[key] = out
+        return out
+
+    @property
+    def on_device(self):
+        for name in self.param_names:
+            v = getattr(self, name)
+            v = v.value if isinstance(v, u.Quantity) else v
+            if getattr(v, "__array_priority__", 0) == 30000:
+                return True
+        return False
+
     def __call__(self, e):
         """dN/dE at energies ``e`` -- shape (n_e,) or (N, n_e) for a walker batch.
         Runs on the GPU (nh_particle_weights, n_out)."""
@@ -91,7 +143,7 @@ class _ParticleDistribution:
         e_eV = np.atleast_1d(e.to("eV").value).astype(float).ravel()
         N = self.batch_size
         ctx = get_context()
-        rows = ctx.array(self.param_rows(N))
+        rows = self.device_rows(ctx, N)
         ed = ctx.const(e_eV)
         nG = e_eV.size
         if nG < 2:  # the kernel wants a grid; pad a single energy

@@ -23,6 +23,7 @@ import numpy as np
 
 from . import units as u
 from ._lib import PD_KIND, PP_MODEL, get_context
+from .darray import DMat, DVec
 from .constants import (AR_CGS, ASTROPY_TO_ERG, ASTROPY_TO_GEV, C_CGS, ERG_TO_EV, MEC2_ERG,
                         MEC2_EV, M_P_GEV, T_TH_GEV, energy_ratio_to, mec2, mec2_unit)
 from .models import _validate_ene
@@ -96,6 +97,31 @@ class BaseRadiative:
             host = host[0]
         return host
 
+    def _own_device_values(self):
+        return ()
+
+    @property
+    def on_device(self):
+        """True when a parameter is a device-resident value: results then stay in HBM
+        as lazy ``DMat``/``DVec`` (no synchronising download)"""
+        if getattr(self.particle_distribution, "on_device", False):
+            return True
+        for v in self._own_device_values():
+            v = v.value if isinstance(v, u.Quantity) else v
+            if getattr(v, "__array_priority__", 0) == 30000:
+                return True
+        return False
+
+    def _result(self, ctx, out, N, nE, E, scale=1.0):
+        """spectra [N][nE] in a device buffer -> Quantity 1/(s eV) (lazy on device, or
+        downloaded with the reference's shape)"""
+        if self.on_device:
+            return u.Quantity(DMat.from_buffer(ctx, out, N, nE, scale=scale), _SPEC_UNIT)
+        host = out.get()
+        if scale != 1.0:
+            host = host * scale
+        return u.Quantity(self._finish(host, E), _SPEC_UNIT)
+
     def _weights(self, xg, e_eV, unit_scale):
         """device weights w = xg*n and log-ratios lw[i] = ln|w[i+1]/w[i]| of every walker"""
         pd = self.particle_distribution
@@ -104,11 +130,11 @@ class BaseRadiative:
                             "distribution (got %r)" % (type(pd).__name__,))
         ctx = get_context()
         N = self.batch_size
-        rows = pd.param_rows(N, amplitude_to=_PER_EV)
+        rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
         nG = xg.size
         xd, ed = ctx.const(xg), ctx.const(e_eV)
         w, lw = ctx.empty((N, nG)), ctx.empty((N, nG))
-        ctx.call("nh_particle_weights", PD_KIND[pd.kind], ctx.array(rows), N, ed, xd, nG,
+        ctx.call("nh_particle_weights", PD_KIND[pd.kind], rows, N, ed, xd, nG,
                  float(unit_scale), w, lw, None)
         return ctx, N, w, lw, xd, ctx.grid_logratio(xd)
 
@@ -206,6 +232,8 @@ class BaseElectron(BaseRadiative):
         Kt, dlnKt = ctx.const(K), ctx.const(_dlog(K))
         out = ctx.empty((N, 1))
         ctx.call("nh_integrate_tables", w, lw, N, gam.size, lx, Kt, dlnKt, 1, None, out, 1)
+        if self.on_device:
+            return u.Quantity(DVec(ctx, out, out.ptr, N), u.erg)
         We = out.get()[:, 0]
         return u.Quantity(We if self.is_batched else We[0], u.erg)
 
@@ -263,15 +291,25 @@ class Synchrotron(BaseElectron):
     def _own_batch_sizes(self):
         return (_batch_of(self.B),)
 
+    def _own_device_values(self):
+        return (self.B,)
+
     def _spectrum(self, photon_energy):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
-        B = np.broadcast_to(np.asarray(self.B.to("G").value, dtype=float), (N,))
+        Bv = self.B.to("G").value
+        if isinstance(Bv, DVec):
+            Bd = Bv.dense()
+            Bp = Bd.ptr
+        else:
+            Bd = ctx.const(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
+            Bp = Bd.ptr
         out = ctx.empty((N, E_eV.size))
-        ctx.call("nh_synchrotron", w, lw, ctx.array(B), N, gd, lx, gam.size, ctx.const(E_eV),
+        ctx.call("nh_synchrotron", w, lw, Bp, N, gd, lx, gam.size, ctx.const(E_eV),
                  E_eV.size, out, E_eV.size)
-        return u.Quantity(self._finish(out.get(), E), _SPEC_UNIT)
+        del Bd
+        return self._result(ctx, out, N, E_eV.size, E)
 
 
 class InverseCompton(BaseElectron):
@@ -296,6 +334,10 @@ class InverseCompton(BaseElectron):
             if seed["type"] == "array" and np.ndim(seed["photon_density"].value) == 2:
                 sizes.append(seed["photon_density"].shape[0])
         return tuple(sizes)
+
+    def _own_device_values(self):
+        return tuple(s["photon_density"] for s in self.seed_photon_fields.values()
+                     if s["type"] == "array")
 
     @staticmethod
     def _process_input_seed(seed_photon_fields):
@@ -349,8 +391,9 @@ class InverseCompton(BaseElectron):
                 else:
                     seed["type"] = "array"
                     T = u.Quantity(np.atleast_1d(T.value).ravel(), T.unit)
-                    uv = np.asarray(uu.value, dtype=float)
-                    uu = u.Quantity(uv if uv.ndim == 2 else np.atleast_1d(uv).ravel(), uu.unit)
+                    if not uu.on_device:
+                        uv = np.asarray(uu.value, dtype=float)
+                        uu = u.Quantity(uv if uv.ndim == 2 else np.atleast_1d(uv).ravel(), uu.unit)
                     seed["energy"] = validate_array("{0}-energy".format(name), T,
                                                     domain="positive", physical_type="energy")
                     if seed["energy"].size == 1:
@@ -367,9 +410,42 @@ class InverseCompton(BaseElectron):
             result[name] = seed
         return result
 
+    def _static_seed_key(self, seed):
+        if seed["type"] == "thermal":
+            return ("T", float(seed["T"].to("K").value),
+                    -1.0 if seed["isotropic"] else float(seed["theta"].to("rad").value))
+        se = seed["energy"].to("eV").value
+        if se.size == 1:
+            sd = np.atleast_1d(seed["photon_density"].to("eV/cm3").value)
+        else:
+            sd = seed["photon_density"].to("1/(eV cm3)").value
+        return ("A", hash(se.tobytes()), hash(np.ascontiguousarray(sd).tobytes()))
+
+    def _build_static_tables(self, ctx, static, gd, nG, Ed, nE):
+        """one transposed table [nG][S*nE]: the seeds sit side by side along k"""
+        nK = len(static) * nE
+        Kt, dlnKt = ctx.empty((nG, nK)), ctx.empty((nG, nK))
+        for j, name in enumerate(static):
+            seed = self.seed_photon_fields[name]
+            kt, lkt = Kt.ptr + 8 * j * nE, dlnKt.ptr + 8 * j * nE
+            if seed["type"] == "thermal":
+                T = seed["T"].to("K").value
+                theta = -1.0 if seed["isotropic"] else seed["theta"].to("rad").value
+                ctx.call("nh_table_ic_planck", gd, nG, Ed, nE, float(T), float(theta), kt, lkt, nK)
+            else:
+                se = seed["energy"].to("eV").value
+                if se.size == 1:
+                    sd = np.atleast_1d(seed["photon_density"].to("eV/cm3").value)
+                else:
+                    sd = seed["photon_density"].to("1/(eV cm3)").value
+                ctx.call("nh_table_ic_seed", gd, nG, Ed, nE, ctx.const(se), ctx.const(sd),
+                         int(se.size), kt, lkt, nK)
+        return Kt, dlnKt
+
     def _spectrum(self, photon_energy):
-        """radiative.py:657-710: one table per walker-independent seed, ONE reduction
-        launch over all of them, then the per-walker (SSC) seeds."""
+        """radiative.py:657-710: one table per walker-independent seed (built once and
+        cached by what it depends on), ONE reduction launch over all of them, then
+        the per-walker (SSC) seeds."""
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         nE = E_eV.size
@@ -379,47 +455,55 @@ class InverseCompton(BaseElectron):
         Eph = E_eV / MEC2_EV
         names = list(self.seed_photon_fields)
         static = [n for n in names if not self._seed_per_walker(self.seed_photon_fields[n])]
+        dev = self.on_device
         specs = {}
         if static:
             nK = len(static) * nE
-            # one transposed table [nG][nK]: the seeds sit side by side along k
-            Kt, lnKt = ctx.empty((nG, nK)), ctx.empty((nG, nK))
+            key = ("ic", gd.ptr, Ed.ptr) + tuple(
+                self._static_seed_key(self.seed_photon_fields[n]) for n in static)
+            Kt, dlnKt = ctx.table(
+                key, lambda: self._build_static_tables(ctx, static, gd, nG, Ed, nE))
             scale = np.empty(nK)
             for j, name in enumerate(static):
                 seed = self.seed_photon_fields[name]
-                kt, lkt = Kt.ptr + 8 * j * nE, lnKt.ptr + 8 * j * nE
                 if seed["type"] == "thermal":
                     T = seed["T"].to("K").value
                     uf = (seed["u"].to("erg/cm3").value / (AR_CGS * T ** 4))
-                    theta = -1.0 if seed["isotropic"] else seed["theta"].to("rad").value
-                    ctx.call("nh_table_ic_planck", gd, nG, Ed, nE, float(T), float(theta), kt, lkt,
-                             nK)
                 else:
                     uf = 1.0
-                    se = seed["energy"].to("eV").value
-                    if se.size == 1:
-                        sd = np.atleast_1d(seed["photon_density"].to("eV/cm3").value)
-                    else:
-                        sd = seed["photon_density"].to("1/(eV cm3)").value
-                    ctx.call("nh_table_ic_seed", gd, nG, Ed, nE, ctx.const(se), ctx.array(sd),
-                             int(se.size), kt, lkt, nK)
                 scale[j * nE:(j + 1) * nE] = uf * Eph / E_eV  # radiative.py:684-687
             out = ctx.empty((N, nK))
-            ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, lnKt, nK, ctx.array(scale),
+            ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
                      out, nK)
-            host = out.get()
-            for j, name in enumerate(static):
-                specs[name] = host[:, j * nE:(j + 1) * nE]
+            if dev:
+                for j, name in enumerate(static):
+                    specs[name] = DMat.from_buffer(ctx, out, N, nE, ld=nK, col0=j * nE)
+            else:
+                host = out.get()
+                for j, name in enumerate(static):
+                    specs[name] = host[:, j * nE:(j + 1) * nE]
         for name in names:
             if name in specs:
                 continue
             seed = self.seed_photon_fields[name]
             se = seed["energy"].to("eV").value
-            sd = np.broadcast_to(seed["photon_density"].to("1/(eV cm3)").value, (N, se.size))
+            sdv = seed["photon_density"].to("1/(eV cm3)").value
+            if isinstance(sdv, DMat):
+                sd_buf, sd_ptr = sdv.buffer()
+            else:
+                sd_buf = ctx.array(np.broadcast_to(sdv, (N, se.size)))
+                sd_ptr = sd_buf.ptr
             out = ctx.empty((N, nE))
             ctx.call("nh_ic_seed_walkers", w, lw, N, gd, lx, nG, Ed, nE, ctx.const(se),
-                     ctx.array(sd), int(se.size), out, nE)
-            specs[name] = out.get()
+                     sd_ptr, int(se.size), out, nE)
+            del sd_buf
+            specs[name] = DMat.from_buffer(ctx, out, N, nE) if dev else out.get()
+        if dev:
+            self.specic = [u.Quantity(specs[n], _SPEC_UNIT) for n in names]
+            total = specs[names[0]]
+            for n in names[1:]:
+                total = total + specs[n]
+            return u.Quantity(total, _SPEC_UNIT)
         self.specic = [u.Quantity(self._finish(specs[n], E), _SPEC_UNIT) for n in names]
         total = np.sum([specs[n] for n in names], axis=0)
         return u.Quantity(self._finish(total, E), _SPEC_UNIT)
@@ -494,17 +578,28 @@ class Bremsstrahlung(BaseElectron):
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         nG = gam.size
         Ed = ctx.const(E_eV)
-        kee, lkee, kep, lkep = (ctx.empty((nG, nE)) for _ in range(4))
-        ctx.call("nh_table_brems", gd, nG, Ed, nE, kee, lkee, kep, lkep, nE)
+
+        def build():
+            # [nG][2 nE]: sigma_ee | sigma_ep side by side
+            Kt, dKt = ctx.empty((nG, 2 * nE)), ctx.empty((nG, 2 * nE))
+            ctx.call("nh_table_brems", gd, nG, Ed, nE, Kt.ptr, dKt.ptr, Kt.ptr + 8 * nE,
+                     dKt.ptr + 8 * nE, 2 * nE)
+            return Kt, dKt
+
+        Kt, dKt = ctx.table(("brems", gd.ptr, Ed.ptr), build)
         n0 = validate_scalar("n0", self.n0, physical_type="number density").to("1/cm3").value
-        total = np.zeros((N, nE))
-        for wgt, kt, lkt in ((self.weight_ee, kee, lkee), (self.weight_ep, kep, lkep)):
-            if wgt == 0.0:
-                continue
-            out = ctx.empty((N, nE))
-            ctx.call("nh_integrate_tables", w, lw, N, nG, lx, kt, lkt, nE, None, out, nE)
-            total += wgt * (C_CGS * out.get())  # radiative.py:949-953, 985-987
-        return u.Quantity(self._finish(n0 * total, E), _SPEC_UNIT)
+        # spec = n0 (w_ee c int(n sigma_ee) + w_ep c int(n sigma_1)), radiative.py:949-987
+        scale = np.concatenate([np.full(nE, n0 * self.weight_ee * C_CGS),
+                                np.full(nE, n0 * self.weight_ep * C_CGS)])
+        out = ctx.empty((N, 2 * nE))
+        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, 2 * nE, ctx.const(scale), out,
+                 2 * nE)
+        if self.on_device:
+            tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE) + \
+                DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE)
+            return u.Quantity(tot, _SPEC_UNIT)
+        host = out.get()
+        return u.Quantity(self._finish(host[:, :nE] + host[:, nE:], E), _SPEC_UNIT)
 
 
 class BaseProton(BaseRadiative):
@@ -541,6 +636,8 @@ class BaseProton(BaseRadiative):
         Kt, dlnKt = ctx.const(Ep), ctx.const(_dlog(Ep))
         out = ctx.empty((N, 1))
         ctx.call("nh_integrate_tables", w, lw, N, Ep.size, lx, Kt, dlnKt, 1, None, out, 1)
+        if self.on_device:
+            return u.Quantity(DVec(ctx, out, out.ptr, N), u.GeV).to("erg")
         Wp = out.get()[:, 0]
         return u.Quantity(Wp if self.is_batched else Wp[0], u.GeV).to("erg")
 
@@ -631,7 +728,6 @@ class PionDecay(BaseProton):
         ctx, N, w, lw, xd, lx, Ep = self._proton_weights()
         nG = Ep.size
         Ed = ctx.const(E_eV)
-        Kt, lnKt = ctx.empty((nG, nE)), ctx.empty((nG, nE))
         use_lut = bool(self.useLUT)
         if use_lut and not os.path.exists(self._lut_file()):
             # radiative.py:1484-1493: only the Pythia8+NucEnh table is packaged
@@ -639,16 +735,23 @@ class PionDecay(BaseProton):
             warnings.warn("LUT {0} not found, reverting to useLUT = False".format(
                 os.path.basename(self._lut_file())))
             self.useLUT = use_lut = False
-        if use_lut:
-            tx, ty, cf = _lut_spline(self._lut_file())
-            ctx.call("nh_table_pion_lut", xd, nG, Ed, nE, ctx.const(tx), int(tx.size),
-                     ctx.const(ty), int(ty.size), ctx.const(cf), Kt, lnKt, nE)
-        else:
-            ctx.call("nh_table_pion_analytic", xd, nG, Ed, nE, PP_MODEL[self.hiEmodel],
-                     int(bool(self.nuclear_enhancement)), Kt, lnKt, nE)
+
+        def build():
+            Kt, dKt = ctx.empty((nG, nE)), ctx.empty((nG, nE))
+            if use_lut:
+                tx, ty, cf = _lut_spline(self._lut_file())
+                ctx.call("nh_table_pion_lut", xd, nG, Ed, nE, ctx.const(tx), int(tx.size),
+                         ctx.const(ty), int(ty.size), ctx.const(cf), Kt, dKt, nE)
+            else:
+                ctx.call("nh_table_pion_analytic", xd, nG, Ed, nE, PP_MODEL[self.hiEmodel],
+                         int(bool(self.nuclear_enhancement)), Kt, dKt, nE)
+            return Kt, dKt
+
+        Kt, dKt = ctx.table(("pp", xd.ptr, Ed.ptr, use_lut, self.hiEmodel,
+                             bool(self.nuclear_enhancement)), build)
         out = ctx.empty((N, nE))
-        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, lnKt, nE, None, out, nE)
+        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE)
         nh = self.nh.to("1/cm3").value
-        spec = out.get() * (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
-        self.specpp = u.Quantity(self._finish(spec, E), _SPEC_UNIT)
+        fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
+        self.specpp = self._result(ctx, out, N, nE, E, scale=fac)
         return self.specpp

@@ -55,7 +55,7 @@ class EnsembleSampler:
     """
 
     def __init__(self, nwalkers, ndim, log_prob_fn, args=(), a=2.0, seed=None, comm=None,
-                 naima_style=False, store_blobs=True):
+                 naima_style=False, store_blobs=True, device=False, use_graph=True):
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError("need an even number of walkers, at least twice the dimension")
         self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
@@ -65,12 +65,20 @@ class EnsembleSampler:
         self._rng = np.random.default_rng(seed if seed is not None else 12345)
         self.naima_style = naima_style
         self.store_blobs = store_blobs
+        # device=True: ensemble, proposals, log-probabilities and blobs live in HBM; the
+        # launch sequence of one half-step (propose -> model -> likelihood -> accept)
+        # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)
+        self.device = bool(device)
+        self.use_graph = bool(use_graph)
+        self._dev = None
         self.n_lnprob_calls = 0
         self.n_walker_evals = 0
         self.reset()
 
     # ------------------------------------------------------------------ store
     def reset(self):
+        if getattr(self, "_dev", None) is not None:
+            self._dev.reset()
         self.iteration = 0
         self._chain, self._logp, self._blobs = [], [], None
         self.blob_units = None
@@ -78,19 +86,27 @@ class EnsembleSampler:
 
     @property
     def acceptance_fraction(self):
+        self._flush()
         return self.naccepted / max(1, self.iteration)
 
+    def _flush(self):
+        if self._dev is not None:
+            self._dev.flush()
+
     def get_chain(self, flat=False, discard=0, thin=1):
+        self._flush()
         c = np.array(self._chain).reshape(-1, self.nwalkers, self.ndim)[discard::thin]
         return c.reshape(-1, self.ndim) if flat else c
 
     def get_log_prob(self, flat=False, discard=0, thin=1):
+        self._flush()
         c = np.array(self._logp).reshape(-1, self.nwalkers)[discard::thin]
         return c.reshape(-1) if flat else c
 
     def get_blobs(self, flat=False, discard=0, thin=1):
         """list (one entry per blob) of arrays [nsteps, nwalkers, ...]; dense, not
         emcee's object array"""
+        self._flush()
         if self._blobs is None:
             return None
         out = []
@@ -155,6 +171,9 @@ class EnsembleSampler:
 
     # ------------------------------------------------------------------ sample
     def sample(self, initial_state, iterations=1, store=True, log_prob0=None):
+        if self.device:
+            yield from self._sample_device(initial_state, iterations, store)
+            return
         state = State(initial_state)
         coords = state.coords.copy()
         if coords.shape != (self.nwalkers, self.ndim):
@@ -207,6 +226,13 @@ class EnsembleSampler:
                     for j, b in enumerate(self._cur_blobs):
                         self._blobs[j].append(b.copy())
             yield State(coords, logp, self._cur_blobs if keep_blobs else None, rng)
+
+    # ------------------------------------------------------------ device mode
+    def _sample_device(self, initial_state, iterations, store):
+        from .device_sampler import DeviceLoop
+        if self._dev is None:
+            self._dev = DeviceLoop(self)
+        yield from self._dev.sample(initial_state, iterations, store)
 
     def _update_blobs(self, walkers, accepted, new):
         """walkers: global indices this rank just evaluated; blobs are tracked for

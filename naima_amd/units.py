@@ -90,25 +90,27 @@ class Unit:
     def __mul__(self, other):
         if isinstance(other, Unit):
             return self._combine(other, +1)
-        if isinstance(other, Quantity):
+        if isinstance(other, _QuantityBase):
             return Quantity(other.value, other.unit * self)
         return Quantity(other, self)
 
     def __rmul__(self, other):
-        if isinstance(other, Quantity):
+        if isinstance(other, _QuantityBase):
             return Quantity(other.value, other.unit * self)
         return Quantity(other, self)
 
     def __truediv__(self, other):
         if isinstance(other, Unit):
             return self._combine(other, -1)
-        if isinstance(other, Quantity):
-            return Quantity(1.0 / np.asarray(other.value), self / other.unit)
+        if isinstance(other, _QuantityBase):
+            return Quantity(1.0 / other.value, self / other.unit)
+        if getattr(other, "__array_priority__", 0) == 30000:
+            return Quantity(1.0 / other, self)
         return Quantity(1.0 / np.asarray(other, dtype=float), self)
 
     def __rtruediv__(self, other):
         inv = self ** -1
-        if isinstance(other, Quantity):
+        if isinstance(other, _QuantityBase):
             return Quantity(other.value, other.unit * inv)
         return Quantity(other, inv)
 
@@ -321,14 +323,18 @@ class Quantity(_QuantityBase):
             value, unit = float(m.group(1)), Unit(m.group(2))
         if unit is None:
             unit = dimensionless_unscaled
-        v = np.asarray(value, dtype=dtype)
-        self.value = v if v.ndim else v[()]
+        if getattr(value, "__array_priority__", 0) == 30000:
+            self.value = value  # device-resident lazy value (naima_amd.darray)
+        else:
+            v = np.asarray(value, dtype=dtype)
+            self.value = v if v.ndim else v[()]
         self.unit = Unit(unit)
 
     # -- conversion ---------------------------------------------------------
     def to(self, unit, equivalencies=None):
         unit = Unit(unit)
-        return Quantity(self.value * self.unit._factor_to(unit), unit)
+        f = self.unit._factor_to(unit)
+        return Quantity(self.value if f == 1.0 else self.value * f, unit)
 
     def to_value(self, unit):
         return self.to(unit).value
@@ -361,6 +367,10 @@ class Quantity(_QuantityBase):
     @property
     def isscalar(self):
         return np.ndim(self.value) == 0
+
+    @property
+    def on_device(self):
+        return getattr(self.value, "__array_priority__", 0) == 30000
 
     @property
     def T(self):
@@ -410,6 +420,8 @@ class Quantity(_QuantityBase):
             return other.value, other.unit
         if isinstance(other, Unit):
             return 1.0, other
+        if getattr(other, "__array_priority__", 0) == 30000:
+            return other, dimensionless_unscaled
         return np.asarray(other, dtype=float), dimensionless_unscaled
 
     def __mul__(self, other):

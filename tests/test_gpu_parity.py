@@ -290,3 +290,87 @@ def test_errors_and_shapes(na):
     sy = na.Synchrotron(ECPL)
     sy.set_We(W, 1 * u.GeV, 100 * u.TeV)
     assert_allclose(sy.compute_We(1 * u.GeV, 100 * u.TeV).value, W.value, rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------
+# device-resident step loop: lazy device parameters, fused prior+likelihood,
+# hipGraph replay -- must reproduce the host-driven sampler step for step
+# ---------------------------------------------------------------------------
+def _cfg_problem(na, golden, name):
+    from naima_amd import workloads as W
+    z = golden(name)
+    data = _data_from_npz(na, z)
+    return W.WORKLOADS[name]["model"](na), data, W.prior_for(name, na), np.asarray(
+        W.WORKLOADS[name]["p0"], dtype=float)
+
+
+def test_lazy_device_values(na):
+    from naima_amd._lib import get_context
+    from naima_amd.darray import DPars
+    ctx = get_context()
+    host = np.random.default_rng(0).uniform(0.5, 2.0, size=(3, 40))
+    P = DPars(ctx, ctx.array(host), 3, 40)
+    u = na.u
+    assert_allclose(np.asarray(10 ** P[0]), 10 ** host[0], rtol=1e-15)
+    assert_allclose(np.asarray((10 ** P[0] / u.eV).to("1/TeV").value), 10 ** host[0] * 1e12,
+                    rtol=1e-15)
+    assert_allclose(np.asarray(P[1] * 3 + 2), host[1] * 3 + 2, rtol=1e-15)
+    assert_allclose(np.asarray(2 / (P[1] * 4)), 2 / (host[1] * 4), rtol=1e-15)
+    assert_allclose(np.asarray((P[1] - 1.0) ** 2), (host[1] - 1) ** 2, rtol=1e-14)
+    assert_allclose(np.asarray(np.log10(P[2]) + np.exp(-P[1])), np.log10(host[2]) + np.exp(
+        -host[1]), rtol=1e-14)
+    assert_allclose(np.asarray(P[0] * P[1] / P[2]), host[0] * host[1] / host[2], rtol=1e-15)
+    assert_allclose(np.asarray(2.5 ** P[0]), 2.5 ** host[0], rtol=1e-14)
+    lp = (na.uniform_prior(P[0], 0.7, 1.5) + na.normal_prior(P[1], 1.0, 0.5)
+          + na.log_uniform_prior(P[2], 0.6, 1.9) + 0.25).evaluate()
+    ref = (np.where((0.7 <= host[0]) & (host[0] <= 1.5), 0, -np.inf)
+           + (-0.5 * (2 * np.pi * 0.5) - (host[1] - 1) ** 2 / (2 * 0.5))
+           + np.where((host[2] >= 0.6) & (host[2] <= 1.9), 1 / host[2], -np.inf) + 0.25)
+    assert_allclose(np.asarray(lp), ref, rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg3", "cfg4", "cfg5"])
+def test_device_lnprob_equals_host_lnprob(na, golden, name):
+    """the same unchanged model function on device-resident parameters"""
+    from naima_amd._lib import get_context
+    from naima_amd.darray import DPars
+    model, data, prior, p0 = _cfg_problem(na, golden, name)
+    z = golden(name)
+    pars = z["pars"]
+    n = len(pars)
+    host = na.lnprob(pars.T, data, model, prior)
+    ctx = get_context()
+    P = DPars(ctx, ctx.array(np.ascontiguousarray(pars.T)), pars.shape[1], n)
+    dev = na.lnprob(P, data, model, prior)
+    assert_allclose(np.asarray(dev[0]), host[0], rtol=1e-12)
+    assert_allclose(np.asarray(dev[1].to("1/(s cm2 eV)").value),
+                    host[1].to("1/(s cm2 eV)").value, rtol=1e-13, atol=1e-300)
+    if len(host) > 2 and hasattr(host[2], "unit"):
+        assert_allclose(np.asarray(dev[2].to("erg").value), host[2].to("erg").value, rtol=1e-13)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_device_sampler_matches_host_sampler(na, golden, use_graph):
+    from naima_amd.sampler import EnsembleSampler
+    model, data, prior, p0 = _cfg_problem(na, golden, "cfg3")
+    kw = dict(args=[data, model, prior], seed=42, naima_style=True)
+    h = EnsembleSampler(32, 5, na.lnprob, **kw)
+    d = EnsembleSampler(32, 5, na.lnprob, device=True, use_graph=use_graph, **kw)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, 5)))
+    sh = h.run_mcmc(pos, 6)
+    sd = d.run_mcmc(pos, 6)
+    assert_allclose(sd.coords, sh.coords, rtol=1e-9)
+    assert_allclose(sd.log_prob, sh.log_prob, rtol=1e-7)
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-9)
+    assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-7)
+    assert_allclose(d.acceptance_fraction, h.acceptance_fraction)
+    bh, bd = h.get_blobs(), d.get_blobs()
+    assert bd[0].shape == bh[0].shape == (6, 32, 64)
+    assert_allclose(bd[0], bh[0], rtol=1e-9, atol=1e-300)
+    assert_allclose(bd[1], bh[1], rtol=1e-9)
+    if use_graph:
+        assert d._dev.graph is not None
+    # continuing from the device state does not re-upload or re-evaluate
+    sd2 = d.run_mcmc(sd, 3)
+    sh2 = h.run_mcmc(sh, 3)
+    assert_allclose(sd2.coords, sh2.coords, rtol=1e-9)
