@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="drive the step loop from the host (no device-resident ensemble)")
+    ap.add_argument("--no-graph", action="store_true", help="device loop without hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
 
@@ -137,13 +140,17 @@ def main():
         per_gpu = 256
     nwalkers = per_gpu * comm.size
 
-    sampler = EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
-                              seed=20260929, comm=comm, naima_style=True, store_blobs=False)
-    pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
-    state = sampler.run_mcmc(pos, max(1, args.warmup), store=False)
+    def make_sampler(device, graph):
+        return EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
+                               seed=20260929, comm=comm, naima_style=True, store_blobs=False,
+                               device=device, use_graph=graph)
 
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
+    device = not args.host_loop
+    sampler = make_sampler(device, not args.no_graph)
+    pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
+    state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
+
+    # ---- the timed region: K ensemble steps, barrier + device sync on both sides
     comm.barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -151,6 +158,17 @@ def main():
     ctx.sync()
     comm.barrier()
     dt = comm.max(time.perf_counter() - t0)
+    acc_frac = float(np.mean(sampler.acceptance_fraction))
+
+    # ---- per-kernel HIP-event timing: hipGraph replay hides the launches from
+    # events, so the SAME launch sequence is run eagerly (device loop, no graph)
+    # with an event pair around every launch, for the same number of steps
+    prof_sampler = make_sampler(device, False)
+    pstate = prof_sampler.run_mcmc(pos, 2, store=False)
+    ctx.sync()
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    prof_sampler.run_mcmc(pstate, args.steps, store=False)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
 
@@ -189,7 +207,9 @@ def main():
         "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
         "kernel_launches": {k: v["launches"] for k, v in prof.items()},
         "gpu_busy_frac": sum(v["ms"] for v in prof.values()) * 1e-3 / dt,
-        "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
+        "acceptance_fraction": acc_frac,
+        "loop": ("host" if not device else ("device+hipGraph" if sampler._dev.graph is not None
+                                            else "device")),
     }
     if kflop:
         tf = kflop * walkers_per_launch / avg_s / 1e12

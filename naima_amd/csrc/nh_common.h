@@ -92,37 +92,40 @@ struct nh_prof_scope {
 //   else (also NaN b: sign change)          : x1*y1*ln(x2/x1) = u1*lx
 //   y1 == 0 or y2 == 0                      : 0
 // dl is always assembled from SMALL, separately accurate pieces (log-ratios of
-// adjacent nodes), never as a difference of two large logarithms: the result is
-// as accurate as the reference's own formula (~1e-13) even at the peak of u
-// where b+1 -> 0.
-// ---------------------------------------------------------------------------
+// adjacent nodes), never as a difference of two large logarithms.
 //
-// For |dl| < 1/4 (i.e. |b+1| < ~10 on a 100-points-per-decade grid: almost every
-// segment of a smooth spectrum) the term is evaluated in the equivalent smooth form
-//   (u2-u1)/dl = u1*expm1(dl)/dl = u1*(1 + dl/2 + dl^2/6 + ...)
-// which needs no division, has no 0/0 at the peak of u, and contains the
-// reference's |b+1| <= 1e-10 log branch (u1*lx) as its dl -> 0 limit.
+// Evaluation, branch-free (lanes of a wave sit at different photon energies, so a
+// wave-level fast path would rarely be taken):
+//   |dl| >= 2^-7 : (u2-u1)*lx/dl with 1/dl from v_rcp_f64 + two Newton steps (dl is
+//                  well scaled); relative error <= 2e-16/2^-7 = 3e-14
+//   |dl| <  2^-7 : u1*lx*expm1(dl)/dl by a 5-term series (next term 4e-14): smooth
+//                  through the peak of u, and its dl -> 0 limit u1*lx IS the
+//                  reference's |b+1| <= 1e-10 branch
+// ---------------------------------------------------------------------------
+// 1/x for a well-scaled x: v_rcp_f64 + two Newton steps, without the
+// v_div_scale/v_div_fixup dance of a generic IEEE division
+__device__ __forceinline__ double nh_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
 __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, double lx) {
-  double t;
-  if (fabs(dl) < 0.25) {
-    // expm1(d)/d = sum d^n/(n+1)!, truncated after d^10 (2e-14 at |d| = 1/4)
-    double f = 2.505210838544172e-08;            // 1/11!
-    f = fma(f, dl, 2.755731922398589e-07);       // 1/10!
-    f = fma(f, dl, 2.755731922398589e-06);       // 1/9!
-    f = fma(f, dl, 2.48015873015873e-05);        // 1/8!
-    f = fma(f, dl, 1.984126984126984e-04);       // 1/7!
-    f = fma(f, dl, 1.388888888888889e-03);       // 1/6!
-    f = fma(f, dl, 8.333333333333333e-03);       // 1/5!
-    f = fma(f, dl, 4.166666666666666e-02);       // 1/4!
-    f = fma(f, dl, 1.666666666666667e-01);       // 1/3!
-    f = fma(f, dl, 0.5);
-    f = fma(f, dl, 1.0);
-    t = u1 * lx * f;
-  } else {
-    t = (u2 - u1) * lx / dl;
-  }
-  bool same = (u1 > 0.0) == (u2 > 0.0);
-  if (!same || !(dl == dl)) t = u1 * lx;  // sign change / NaN b: the reference's log branch
+  // series for |dl| < 2^-7: 1 + d/2 + d^2/6 + d^3/24 + d^4/120
+  double f = fma(dl, 8.333333333333333e-03, 4.166666666666666e-02);
+  f = fma(f, dl, 1.666666666666667e-01);
+  f = fma(f, dl, 0.5);
+  f = fma(f, dl, 1.0);
+  const double ul = u1 * lx;
+  const double ts = ul * f;
+  const double td = (u2 - u1) * lx * nh_rcp(dl);
+  double t = (fabs(dl) < 0.0078125) ? ts : td;
+  // sign change or NaN ratio -> NaN b in the reference -> its log branch x1*y1*ln(x2/x1)
+  const bool logb = ((__double2hiint(u1) ^ __double2hiint(u2)) < 0) || !(dl == dl);
+  t = logb ? ul : t;
+  // zero node (utils.py:347-348)
   return (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
 }
 

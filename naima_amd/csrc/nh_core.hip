@@ -2,6 +2,7 @@
 // per-walker table reduction, lnprobmodel and the stretch-move kernels.
 // gfx950 (MI355X) only; FP64 throughout, denormals on, no fast-math.
 #include "nh_common.h"
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -306,45 +307,100 @@ extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx)
 // sequentially carrying the previous node in registers (no shuffles), and the
 // C partial sums meet in LDS.
 // ---------------------------------------------------------------------------
-template <int C>
+// The hot reduction.  One wave = one tile of 64 consecutive k (lanes) x W walkers
+// (register-blocked) x one chunk of the abscissa.  Per segment the wave issues TWO
+// coalesced vector loads (Kt row, dlnKt row) that serve all W walkers; the walker
+// data (w, dlw) and lx are wave-uniform and come through the scalar cache
+// (s_load), not through the vector L1 -- the first version issued 5 vector loads
+// per segment and walker and was bound by the L1 tag-lookup rate (TCP), at 40 % of
+// the VALU.  The C waves of a block split the abscissa; partial sums meet in LDS.
+template <int C, int W>
 __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
     const double* __restrict__ lx, const double* __restrict__ Kt,
     const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
     double* __restrict__ out, int ldo) {
-  __shared__ double part[C][64];
-  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
-  const long long pair = (long long)blockIdx.x * 64 + lane;
-  const bool valid = pair < (long long)N * nK;
-  const int wi = valid ? (int)(pair / nK) : 0;
-  const int k = valid ? (int)(pair % nK) : 0;
+  __shared__ double part[C][W][64];
+  const int lane = threadIdx.x & 63;
+  const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ktiles = (nK + 63) >> 6;
+  const int tile = blockIdx.x % ktiles, grp = blockIdx.x / ktiles;
+  const int k = tile * 64 + lane;
+  const bool kvalid = k < nK;
+  const unsigned kk = kvalid ? (unsigned)k : (unsigned)(nK - 1);
+  const int w0 = grp * W;
   const int nseg = nG - 1;
   const int per = (nseg + C - 1) / C;
   const int s0 = ch * per;
   const int s1 = min(nseg, s0 + per);
-  const double* wr = w + (long long)wi * nG;
-  const double* dwr = dlw + (long long)wi * nG;
-  const double* Kc = Kt + k;
-  const double* dKc = dlnKt + k;
-  double acc = 0.0;
+  double acc[W], u1[W];
+  unsigned row[W];  // wave-uniform row offsets of the W walkers (tail clamped)
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    acc[j] = 0.0;
+    row[j] = (unsigned)min(w0 + j, N - 1) * (unsigned)nG;
+  }
   if (s0 < s1) {
-    double u1 = wr[s0] * Kc[(long long)s0 * nK];
-#pragma unroll 4
+    unsigned ok = (unsigned)s0 * (unsigned)nK + kk;
+    {
+      const double K0 = Kt[ok];
+#pragma unroll
+      for (int j = 0; j < W; ++j) u1[j] = w[row[j] + s0] * K0;
+    }
     for (int s = s0; s < s1; ++s) {
-      double u2 = wr[s + 1] * Kc[(long long)(s + 1) * nK];
-      double dl = dwr[s] + dKc[(long long)s * nK];
-      acc += nh_seg_term(u1, u2, dl, lx[s]);
-      u1 = u2;
+      const double K2 = Kt[ok + (unsigned)nK];
+      const double dK = dlnKt[ok];
+      const double lxs = lx[s];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const double u2 = w[row[j] + s + 1] * K2;
+        const double dl = dlw[row[j] + s] + dK;
+        acc[j] += nh_seg_term(u1[j], u2, dl, lxs);
+        u1[j] = u2;
+      }
+      ok += (unsigned)nK;
     }
   }
-  part[ch][lane] = acc;
-  __syncthreads();
-  if (ch == 0 && valid) {
-    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < C; ++j) s += part[j][lane];
-    out[(long long)wi * ldo + k] = scale ? s * scale[k] : s;
+  for (int j = 0; j < W; ++j) part[ch][j][lane] = acc[j];
+  __syncthreads();
+  if (ch == 0 && kvalid) {
+    const double sc = scale ? scale[k] : 1.0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (w0 + j < N) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < C; ++c2) sum += part[c2][j][lane];
+        out[(long long)(w0 + j) * ldo + k] = sum * sc;
+      }
+    }
   }
+}
+
+// few table rows (We, Wp: nK = 1): one wave per (walker, k), lanes over the segments
+__global__ __launch_bounds__(256) void k_integrate_rows(
+    const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
+    const double* __restrict__ lx, const double* __restrict__ Kt,
+    const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
+    double* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= (long long)N * nK) return;
+  const unsigned wi = (unsigned)(pair / nK), k = (unsigned)(pair % nK);
+  const double* wr = w + (long long)wi * nG;
+  const double* dwr = dlw + (long long)wi * nG;
+  double acc = 0.0;
+  for (int s = lane; s < nG - 1; s += 64) {
+    double u1 = wr[s] * Kt[(long long)s * nK + k];
+    double u2 = wr[s + 1] * Kt[(long long)(s + 1) * nK + k];
+    double dl = dwr[s] + dlnKt[(long long)s * nK + k];
+    // lanes are at different segments here: the uniform fast path of nh_seg_term
+    // still applies when every lane of the wave is in the smooth regime
+    acc += nh_seg_term(u1, u2, dl, lx[s]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[(long long)wi * ldo + k] = scale ? acc * scale[k] : acc;
 }
 
 extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
@@ -352,23 +408,43 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
                                    int nK, const double* scale, double* out, int ldo) {
   NH_REQUIRE(c && w && dlw && lx && Kt && dlnKt && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nK >= 1 && ldo >= nK, "bad sizes");
+  NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)nG * nK < (1LL << 31),
+             "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_INTEGRATE);
   long long pairs = (long long)N * nK;
-  unsigned blocks = (unsigned)((pairs + 63) / 64);
-  int nseg = nG - 1;
-  // chunk the abscissa so that the grid has enough waves to fill 256 CUs
-  int C = nseg >= 512 ? 8 : (nseg >= 128 ? 4 : (nseg >= 32 ? 2 : 1));
-  if ((long long)blocks * C < 2048 && nseg >= 256) C = 8;
-#define NH_LAUNCH_INT(CC)                                                                     \
-  hipLaunchKernelGGL((k_integrate_tables<CC>), dim3(blocks), dim3(64 * CC), 0, c->stream, w, \
-                     dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
-  switch (C) {
-    case 8: NH_LAUNCH_INT(8); break;
-    case 4: NH_LAUNCH_INT(4); break;
-    case 2: NH_LAUNCH_INT(2); break;
-    default: NH_LAUNCH_INT(1); break;
+  if (pairs * 4 < 4096) {  // too few (walker, k) pairs to fill the chip with pair-lanes
+    hipLaunchKernelGGL(k_integrate_rows, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0,
+                       c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo);
+    NH_CHECK_HIP(hipGetLastError());
+    return NH_OK;
   }
+  const int nseg = nG - 1;
+  const int ktiles = (nK + 63) / 64;
+  // walkers per thread (register blocking of the table rows).  Measured on cfg3
+  // (N = 256, nK = 192): W = 1 27 us, W = 2 32 us, W = 4 34 us -- more, smaller
+  // blocks balance better over 256 CUs than the saved vector loads are worth; W > 1
+  // pays once a launch has many more walkers than CUs.
+  int W = ((long long)ktiles * N >= 8192) ? 4 : ((long long)ktiles * N >= 4096 ? 2 : 1);
+  if (const char* e = getenv("NH_INT_W")) W = atoi(e);
+  const unsigned blocks = (unsigned)(ktiles * ((N + W - 1) / W));
+  // split the abscissa so that the launch has >= ~4 waves per SIMD (1024 SIMDs)
+  int C = 1;
+  while (C < 16 && (long long)blocks * C < 12288 && nseg / (2 * C) >= 8) C *= 2;
+  if (const char* e = getenv("NH_INT_C")) C = atoi(e);
+#define NH_LAUNCH_INT(CC, WW)                                                                 \
+  hipLaunchKernelGGL((k_integrate_tables<CC, WW>), dim3(blocks), dim3(64 * CC), 0, c->stream, \
+                     w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
+#define NH_LAUNCH_INT_C(CC) \
+  do { if (W == 4) NH_LAUNCH_INT(CC, 4); else if (W == 2) NH_LAUNCH_INT(CC, 2); else NH_LAUNCH_INT(CC, 1); } while (0)
+  switch (C) {
+    case 16: NH_LAUNCH_INT_C(16); break;
+    case 8: NH_LAUNCH_INT_C(8); break;
+    case 4: NH_LAUNCH_INT_C(4); break;
+    case 2: NH_LAUNCH_INT_C(2); break;
+    default: NH_LAUNCH_INT_C(1); break;
+  }
+#undef NH_LAUNCH_INT_C
 #undef NH_LAUNCH_INT
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;

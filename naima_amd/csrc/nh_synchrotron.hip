@@ -1,101 +1,206 @@
 // nh_synchrotron.hip -- Synchrotron._spectrum (radiative.py:282-342) batched
 // over walkers.  The emissivity kernel Gtilde(E/Ec(gamma,B)) depends on the
 // walker through B, so nothing can be tabulated: every (walker, E_k, gamma_i)
-// node costs one cbrt, one sqrt, one exp and one log in FP64.  The kernel is
-// FP64-VALU bound; HBM traffic is the (w, lw) rows and the output only.
+// node needs Gtilde(x) = P(x) exp(-x) in FP64.  The kernel is FP64-VALU bound;
+// HBM traffic is the (w, dlw) rows and the output only.
 //
-// Mapping: lanes run over flattened (walker, k) pairs, the C waves of a block
-// split the gamma range, each thread walks its chunk sequentially (previous
-// node kept in registers), partial sums meet in LDS.  All lanes of a wave are
-// at the same gamma_i, so the "Gtilde underflows to exactly 0" region
-// (x > 745, where the reference also produces exact zeros that trapz_loglog
-// discards) is skipped at wave granularity.
+// Mapping: one block = one walker x one tile of 64 photon energies (lanes); the C
+// waves of the block split the gamma range and each thread walks its chunk
+// sequentially (previous node in registers); partial sums meet in LDS.  The
+// walker's w/dlw and lx are wave-uniform: they come through the scalar cache.
+// All lanes of a wave sit at the same gamma_i, so the region where exp(-x)
+// underflows to exactly 0 (x > 746; the reference produces exact zeros there
+// too, which trapz_loglog discards) is skipped at wave granularity.
+//
+// Instruction diet (the first version spent ~400 FP64 instructions per node in
+// OCML cbrt/sqrt/div/exp/log):
+//   cbrt(x)     = cbrt(q) * gamma_i^(-2/3): one cube root per THREAD, the grid part
+//                 is tabulated in LDS together with 1/gamma^2 and its difference;
+//   1/sqrt, 1/y = v_rsq_f64 / v_rcp_f64 + two Newton steps (well-scaled operands);
+//   exp(-x)     = Cody-Waite reduction + degree-13 Taylor + v_ldexp_f64;
+//   ln(P2/P1)   = 2 atanh(s), s = (P2-P1)/(P2+P1), 5-term series (adjacent nodes
+//                 differ by a few per cent), log() only on coarse grids.
 #include "nh_common.h"
+#include <cstdlib>
 
-__device__ __forceinline__ void syn_node(double x, double wi, double cs1, double& u,
-                                         double& lnP) {
-  // AKP10 Eq. D7 with a single cube root (radiative.py:300-311)
-  if (x <= 746.0) {
-    double cb = cbrt(x);
-    double cb2 = cb * cb;
-    double cb4 = cb2 * cb2;
-    double gt1 = 1.808 * cb / sqrt(1.0 + 3.4 * cb2);
-    double gt2 = 1.0 + 2.210 * cb2 + 0.347 * cb4;
-    double gt3 = 1.0 + 1.353 * cb2 + 0.217 * cb4;
-    double P = gt1 * (gt2 / gt3);
-    double G = P * exp(-x);
-    u = wi * (cs1 * G);  // gamma * nelec * dNdE   (radiative.py:335-338)
-    lnP = log(P);        // |lnP| = O(1): ln|u2/u1| is assembled from small pieces
-  } else {
-    u = 0.0;  // exp(-x) == 0 in double: the reference integrand is exactly 0 here
-    lnP = 0.0;
-  }
+__device__ __forceinline__ double nh_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  double h = 0.5 * a;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
 }
+
+// exp(-x) for 0 <= x <= 746 (gradual underflow through v_ldexp_f64)
+__device__ __forceinline__ double nh_exp_neg(double x) {
+  const double t = -x;
+  const double kf = rint(t * 1.4426950408889634);
+  double r = fma(-kf, 6.93147180369123816490e-01, t);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;      // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);    // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);   // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);   // 1/10!
+  p = fma(p, r, 2.755731922398589e-06);   // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);    // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);   // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);   // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);   // 1/5!
+  p = fma(p, r, 4.166666666666666e-02);   // 1/4!
+  p = fma(p, r, 1.666666666666667e-01);   // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
+// P(x) of AKP10 Eq. D7 (radiative.py:300-311) from cb = cbrt(x)
+__device__ __forceinline__ double syn_P(double cb) {
+  const double cb2 = cb * cb;
+  const double cb4 = cb2 * cb2;
+  const double rs = nh_rsqrt(fma(3.4, cb2, 1.0));
+  const double gt2 = fma(0.347, cb4, fma(2.210, cb2, 1.0));
+  const double gt3 = fma(0.217, cb4, fma(1.353, cb2, 1.0));
+  return (1.808 * cb) * rs * (gt2 * nh_rcp(gt3));
+}
+
+// ln(P2/P1) for neighbouring nodes
+__device__ __forceinline__ double syn_dlnP(double P1, double P2) {
+  const double s = (P2 - P1) * nh_rcp(P2 + P1);
+  const double s2 = s * s;
+  if (__builtin_amdgcn_ballot_w64(s2 > 9e-4) != 0ull) return log(P2 / P1);  // coarse grid
+  double a = fma(s2, 1.0 / 9.0, 1.0 / 7.0);
+  a = fma(a, s2, 0.2);
+  a = fma(a, s2, 1.0 / 3.0);
+  a = fma(a, s2, 1.0);
+  return 2.0 * s * a;
+}
+
+// One block = one walker x one tile of 64 photon energies.  Many (energy, gamma)
+// pairs cannot contribute at all: exp(-E/Ec) is exactly 0 in double for x > 746, which
+// for a given energy removes every node below gamma0 = sqrt(q/746) -- and removes
+// TeV energies altogether (the reference computes, and trapz_loglog discards, exact
+// zeros there).  The block therefore
+//   1. finds, per energy, the first node i0 that can contribute (binary search in the
+//      LDS copy of 1/gamma^2), the number nA of live energies and sbeg = min i0 - 1;
+//   2. compacts the live energies and spreads [sbeg, nseg) x nA over ALL its threads:
+//      thread t -> live energy t % nA, chunk t / nA (Cd = T / nA chunks);
+//   3. reduces the Cd partial sums per energy in LDS; dead energies get 0.
+constexpr int SYN_MAXCH = 64;  // chunks per energy (LDS: part[SYN_MAXCH][64])
 
 template <int C>
 __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const double* __restrict__ w, const double* __restrict__ dlw, const double* __restrict__ B,
     int N, const double* __restrict__ gam, const double* __restrict__ lx, int nG,
     const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo) {
-  extern __shared__ double smem[];  // [nG] 1/gamma^2, [nG] its forward difference, [C][64]
+  extern __shared__ double smem[];  // ig2[nG] | dig2[nG] | ig23[nG] | part[SYN_MAXCH][64]
   double* ig2 = smem;
   double* dig2 = smem + nG;
-  double* part = smem + 2 * nG;
-  for (int i = threadIdx.x; i < nG; i += 64 * C) {
-    double g = gam[i];
-    double v = 1.0 / (g * g);
+  double* ig23 = smem + 2 * nG;
+  double* part = smem + 3 * nG;
+  __shared__ int amap[64];
+  __shared__ int s_min_i0, s_nA;
+  constexpr int T = 64 * C;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nG; i += T) {
+    const double g = gam[i];
+    const double v = 1.0 / (g * g);
     ig2[i] = v;
+    ig23[i] = cbrt(v);
+    double d = 0.0;
     if (i + 1 < nG) {
-      // 1/g2^2 - 1/g1^2 without cancellation
-      double r = g / gam[i + 1];
-      dig2[i] = v * (r * r - 1.0);
-    } else {
-      dig2[i] = 0.0;
+      const double r = g / gam[i + 1];  // 1/g2^2 - 1/g1^2 without cancellation
+      d = v * (r * r - 1.0);
     }
+    dig2[i] = d;
   }
+  if (tid == 0) { s_min_i0 = nG; s_nA = 0; }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
-  const long long pair = (long long)blockIdx.x * 64 + lane;
-  const bool valid = pair < (long long)N * nE;
-  const int wi = valid ? (int)(pair / nE) : 0;
-  const int k = valid ? (int)(pair % nE) : 0;
-
+  const int ktiles = (nE + 63) >> 6;
+  const int tile = blockIdx.x % ktiles, wi = blockIdx.x / ktiles;
   const double Bw = B[wi];
-  const double E_erg = E_eV[k] * NH_ERG_PER_EV;
-  // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)            radiative.py:319-328
-  const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                     (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS * E_erg);
   // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
-  const double q = E_erg * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
+  const double qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) /
+                      (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
 
-  const int nseg = nG - 1;
-  const int per = (nseg + C - 1) / C;
-  const int s0 = ch * per;
-  const int s1 = min(nseg, s0 + per);
-  const double* wr = w + (long long)wi * nG;
-  const double* dwr = dlw + (long long)wi * nG;
-  double acc = 0.0;
-  if (s0 < s1) {
-    double u1, p1;
-    syn_node(q * ig2[s0], wr[s0], cs1, u1, p1);
-    for (int s = s0; s < s1; ++s) {
-      double u2, p2;
-      syn_node(q * ig2[s + 1], wr[s + 1], cs1, u2, p2);
-      // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1)
-      double dl = dwr[s] + (p2 - p1) - q * dig2[s];
-      acc += nh_seg_term(u1, u2, dl, lx[s]);
-      u1 = u2;
-      p1 = p2;
+  // ---- 1. liveness of the tile's energies (first wave) ----------------------
+  if (tid < 64) {
+    const int k = tile * 64 + tid;
+    int i0 = nG;
+    if (k < nE) {
+      const double q = E_eV[k] * qfac;
+      // first i with q*ig2[i] <= 746 (ig2 decreases with i)
+      int lo = 0, hi = nG;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (q * ig2[mid] <= 746.0) hi = mid; else lo = mid + 1;
+      }
+      i0 = lo;
     }
+    const bool live = i0 < nG;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+    if (live) {
+      amap[__popcll(m & ((1ull << tid) - 1ull))] = k;
+      atomicMin(&s_min_i0, i0);
+    }
+    if (tid == 0) s_nA = __popcll(m);
+    if (k < nE && !live) out[(long long)wi * ldo + k] = 0.0;
   }
-  part[ch * 64 + lane] = acc;
   __syncthreads();
-  if (ch == 0 && valid) {
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < C; ++j) s += part[j * 64 + lane];
-    out[(long long)wi * ldo + k] = s * NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), radiative.py:340
+  const int nA = s_nA;
+  if (nA == 0) return;
+  const int nseg = nG - 1;
+  const int sbeg = max(s_min_i0 - 1, 0);
+
+  // ---- 2. (live energy, chunk) per thread ------------------------------------
+  const int Cd = min(T / nA, SYN_MAXCH);
+  const int a = tid % nA, ch = tid / nA;
+  double acc = 0.0;
+  if (ch < Cd) {
+    const int per = (nseg - sbeg + Cd - 1) / Cd;
+    const int s0 = sbeg + ch * per;
+    const int s1 = min(nseg, s0 + per);
+    const int k = amap[a];
+    const double E_erg = E_eV[k] * NH_ERG_PER_EV;
+    // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
+    const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                       (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS * E_erg);
+    const double q = E_eV[k] * qfac;
+    const double cbq = cbrt(q);
+    const double* wr = w + (long long)wi * nG;
+    const double* dwr = dlw + (long long)wi * nG;
+    if (s0 < s1) {
+      double u1 = 0.0, P1 = 1.0;
+      {
+        const double x = q * ig2[s0];
+        if (x <= 746.0) {
+          P1 = syn_P(cbq * ig23[s0]);
+          u1 = wr[s0] * (cs1 * (P1 * nh_exp_neg(x)));  // gamma nelec dNdE, :335-338
+        }
+      }
+      for (int s = s0; s < s1; ++s) {
+        const double x = q * ig2[s + 1];
+        double u2 = 0.0, P2 = 1.0;
+        if (x <= 746.0) {
+          P2 = syn_P(cbq * ig23[s + 1]);
+          u2 = wr[s + 1] * (cs1 * (P2 * nh_exp_neg(x)));
+        }
+        // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
+        const double dl = dwr[s] + syn_dlnP(P1, P2) - q * dig2[s];
+        acc += nh_seg_term(u1, u2, dl, lx[s]);
+        u1 = u2;
+        P1 = P2;
+      }
+    }
+    part[ch * 64 + a] = acc;
+  }
+  __syncthreads();
+  // ---- 3. per-energy reduction -------------------------------------------------
+  if (tid < nA) {
+    double sum = 0.0;
+    for (int j = 0; j < Cd; ++j) sum += part[j * 64 + tid];
+    out[(long long)wi * ldo + amap[tid]] = sum * NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
   }
 }
 
@@ -106,12 +211,22 @@ extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ldo >= nE, "bad sizes");
   if (N == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_SYNCHROTRON);
-  long long pairs = (long long)N * nE;
-  unsigned blocks = (unsigned)((pairs + 63) / 64);
-  int nseg = nG - 1;
+  const int ktiles = (nE + 63) / 64;
+  const unsigned blocks = (unsigned)(ktiles * N);
+  const int nseg = nG - 1;
   int C = nseg >= 256 ? 16 : (nseg >= 64 ? 8 : 4);
-  size_t shm = (size_t)(2 * nG + C * 64) * sizeof(double);
-  NH_REQUIRE(shm <= 160 * 1024, "electron grid too long for the LDS staging");
+  if ((long long)blocks * C > 16384 && C > 4) C /= 2;  // plenty of waves: longer chunks
+  if (const char* e = getenv("NH_SYN_C")) C = atoi(e);
+  size_t shm = (size_t)(3 * nG + SYN_MAXCH * 64) * sizeof(double);
+  NH_REQUIRE(shm <= 150 * 1024, "electron grid too long for the LDS staging");
+  if (shm > 64 * 1024) {
+    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<16>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<8>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<4>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  }
 #define NH_LAUNCH_SYN(CC)                                                                    \
   hipLaunchKernelGGL((k_synchrotron<CC>), dim3(blocks), dim3(64 * CC), shm, c->stream, w, dlw, \
                      B_G, N, gam, lx, nG, E_eV, nE, out, ldo)
