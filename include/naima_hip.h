@@ -213,10 +213,12 @@ typedef struct { nh_lazy x; double p0, p1; int kind; int pad; } nh_prior;
 int nh_priors(nh_ctx* ctx, const nh_prior* terms /*host*/, int nterms, int N, double* lp);
 
 /* core.py:97-121 in one launch: model = sum comps; lnl as nh_lnprobmodel;
- * total[w] = isinf(lp[w]) ? lp[w] : lnl + lp[w]   (lp may be NULL = 0). */
+ * p = lp[w] (NULL = 0) + sum of the prior terms (nterms may be 0);
+ * total[w] = isinf(p) ? p : lnl + p. */
 int nh_lnprob(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, int N, int nE,
               const double* conv, const double* flux, const double* err_lo,
               const double* err_hi, const int* ul, const double* cl, const double* lp,
+              const nh_prior* terms /*host*/, int nterms,
               double* model_out /*[N][nE] or NULL*/, double* total);
 
 /* stretch move on a device-resident ensemble coords[N][ndim], logp[N].

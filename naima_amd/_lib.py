@@ -58,7 +58,7 @@ _SIGS = {
     "nh_ew_binary": [_dp, _i, _dp, _dp, _i, _dp],
     "nh_lincomb": [_dp, _dp, _i, _dp, _i, _i, _dp, _i],
     "nh_priors": [_dp, _dp, _i, _i, _dp],
-    "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+    "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],

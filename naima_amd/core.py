@@ -153,9 +153,18 @@ def lnprobmodel(model, data, lp=None):
         if nE != dd.n:
             raise ValueError("model has %d energies, data table has %d" % (nE, dd.n))
         total = ctx.empty((N,))
-        lpp = lp.dense().ptr if lp is not None else None
+        lpd = terms = None
+        nterms = 0
+        if isinstance(lp, LazyPrior):
+            terms, nterms = lp.packed()  # evaluated inside the likelihood kernel
+            if terms is None:
+                lpd = lp.evaluate()
+        elif lp is not None:
+            lpd = lp.dense()
         ctx.call("nh_lnprob", m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),
-                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpp, None, total)
+                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpd.ptr if lpd is not None else None,
+                 terms, nterms, None, total)
+        del lpd
         return DVec(ctx, total, total.ptr, N)
     import ctypes as C
     m = np.asarray(model.value, dtype=float)
@@ -179,10 +188,8 @@ def _lnprob_device(pars, data, modelfunc, priorfunc):
     lp = None
     if priorfunc is not None:
         lp = priorfunc(pars)
-        if isinstance(lp, LazyPrior):
-            lp = lp.evaluate()
-        elif not isinstance(lp, DVec):
-            lp = LazyPrior(pars.ctx, pars.n, [], float(lp)).evaluate()
+        if not isinstance(lp, (LazyPrior, DVec)):
+            lp = LazyPrior(pars.ctx, pars.n, [], float(lp))
     modelout = modelfunc(pars, data)
     if isinstance(modelout, (tuple, list)):
         model, blob = modelout[0], tuple(modelout)

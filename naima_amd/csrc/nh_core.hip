@@ -202,57 +202,59 @@ extern "C" int nh_trapz_loglog(nh_ctx* c, const double* y, const double* x, int 
 // ---------------------------------------------------------------------------
 struct pd_par { double A, e0, al, ec, be, eb, a2; };
 
-__device__ __forceinline__ double pd_eval(int kind, const pd_par& p, double E) {
-  const double xx = E / p.e0;
-  switch (kind) {
-    case NH_PD_POWERLAW:  // models.py:88-92
-      return p.A * pow(xx, -p.al);
-    case NH_PD_ECPL:  // models.py:157-161
-      return p.A * pow(xx, -p.al) * exp(-pow(E / p.ec, p.be));
-    case NH_PD_BROKENPL:
-    case NH_PD_ECBPL: {  // models.py:234-238, 330-335
-      bool below = E < p.eb;
-      double K = below ? 1.0 : pow(p.eb / p.e0, p.a2 - p.al);
-      double n = p.A * K * pow(xx, -(below ? p.al : p.a2));
-      if (kind == NH_PD_ECBPL) n = n * exp(-pow(E / p.ec, p.be));
-      return n;
-    }
-    default: {  // NH_PD_LOGPARABOLA, models.py:402-407
-      double ex = -p.al - p.be * log(xx);
-      return p.A * pow(xx, ex);
-    }
-  }
+// exp(d) - 1 for |d| << 1 (d = beta * ln(E2/E1), a few per cent): 7-term series
+__device__ __forceinline__ double pd_expm1_small(double d) {
+  double f = 1.984126984126984e-04;  // 1/7!
+  f = fma(f, d, 1.388888888888889e-03);
+  f = fma(f, d, 8.333333333333333e-03);
+  f = fma(f, d, 4.166666666666666e-02);
+  f = fma(f, d, 1.666666666666667e-01);
+  f = fma(f, d, 0.5);
+  f = fma(f, d, 1.0);
+  return f * d;
 }
 
-// ln(f(E2)/f(E1)) of the shape, from small accurate pieces
-__device__ __forceinline__ double pd_dlog(int kind, const pd_par& p, double E1, double E2) {
-  const double lr = log(E2 / E1);
-  double d;
+// One node of a walker's particle spectrum: n(E) as the reference evaluates it
+// (models.py:88-92, 157-161, 234-238, 330-335, 402-407; x**p as exp(p ln x), 1e-14)
+// and the log-ratio of the SHAPE to the next node, ln f(E2)/f(E1), assembled from
+// small pieces with lr = ln(E2/E1):  power laws -> -alpha lr;  cutoff ->
+// -(t2 - t1) = -t1 expm1(beta lr);  log-parabola -> -alpha lr - beta lr (l1 + l2).
+__device__ __forceinline__ void pd_node(int kind, const pd_par& p, double E, double E2,
+                                        double lr, double& n, double& dsh) {
+  const double lxx = log(E / p.e0);
   switch (kind) {
     case NH_PD_POWERLAW:
-      d = -p.al * lr;
+      n = p.A * exp(-p.al * lxx);
+      dsh = -p.al * lr;
       break;
-    case NH_PD_ECPL:
-      d = -p.al * lr - (pow(E2 / p.ec, p.be) - pow(E1 / p.ec, p.be));
-      break;
+    case NH_PD_ECPL: {
+      const double t = exp(p.be * log(E / p.ec));
+      n = p.A * exp(-p.al * lxx - t);
+      dsh = -p.al * lr - t * pd_expm1_small(p.be * lr);
+    } break;
     case NH_PD_BROKENPL:
     case NH_PD_ECBPL: {
-      bool b1 = E1 < p.eb, b2 = E2 < p.eb;
+      const bool b1 = E < p.eb, b2 = E2 < p.eb;
+      const double lK = (p.a2 - p.al) * log(p.eb / p.e0);
+      double ex = (b1 ? 0.0 : lK) - (b1 ? p.al : p.a2) * lxx;
       if (b1 == b2) {
-        d = -(b1 ? p.al : p.a2) * lr;
+        dsh = -(b1 ? p.al : p.a2) * lr;
       } else {  // the one segment that straddles the break
-        double lK = (p.a2 - p.al) * log(p.eb / p.e0);
-        d = (b2 ? 0.0 : lK) - (b1 ? 0.0 : lK) -
-            ((b2 ? p.al : p.a2) * log(E2 / p.e0) - (b1 ? p.al : p.a2) * log(E1 / p.e0));
+        dsh = (b2 ? 0.0 : lK) - (b1 ? 0.0 : lK) -
+              ((b2 ? p.al : p.a2) * (lxx + lr) - (b1 ? p.al : p.a2) * lxx);
       }
-      if (kind == NH_PD_ECBPL) d -= (pow(E2 / p.ec, p.be) - pow(E1 / p.ec, p.be));
+      if (kind == NH_PD_ECBPL) {
+        const double t = exp(p.be * log(E / p.ec));
+        ex -= t;
+        dsh -= t * pd_expm1_small(p.be * lr);
+      }
+      n = p.A * exp(ex);
     } break;
-    default: {
-      double l1 = log(E1 / p.e0), l2 = log(E2 / p.e0);
-      d = -p.al * lr - p.be * lr * (l1 + l2);
+    default: {  // NH_PD_LOGPARABOLA
+      n = p.A * exp((-p.al - p.be * lxx) * lxx);
+      dsh = -p.al * lr - p.be * lr * (lxx + (lxx + lr));
     } break;
   }
-  return d;
 }
 
 __global__ __launch_bounds__(256) void k_particle_weights(
@@ -265,11 +267,17 @@ __global__ __launch_bounds__(256) void k_particle_weights(
   const double* pr = params + (long long)wi * NH_PD_NPAR;
   pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
   const double E = e[i];
-  double n = pd_eval(kind, p, E) * unit_scale;
+  const bool last = i + 1 >= nG;
+  const double E2 = last ? E : e[i + 1];
   const double g = xg[i];
+  const double lrE = last ? 0.0 : log(E2 / E);
+  const double lrx = last ? 0.0 : log(xg[i + 1] / g);
+  double n, dsh;
+  pd_node(kind, p, E, E2, lrE, n, dsh);
+  n *= unit_scale;
   w[idx] = g * n;
   if (nout) nout[idx] = n;
-  dlw[idx] = (i + 1 < nG) ? log(xg[i + 1] / g) + pd_dlog(kind, p, E, e[i + 1]) : 0.0;
+  dlw[idx] = last ? 0.0 : lrx + dsh;
 }
 
 extern "C" int nh_particle_weights(nh_ctx* c, int kind, const double* params, int N,
@@ -458,6 +466,46 @@ struct nh_comps {
   int n;
 };
 
+struct nh_prior_pack {
+  nh_prior t[NH_MAX_PRIOR];
+  int n;
+};
+
+// value[w] = a * tf(b * base[w*stride] + c);  base == NULL -> the constant a
+__device__ __forceinline__ double nh_lazy_eval(const nh_lazy& z, long long w) {
+  if (!z.base) return z.a;
+  double x = z.b * z.base[w * z.stride] + z.c;
+  switch (z.tf) {
+    case NH_TF_POW10: x = pow(10.0, x); break;
+    case NH_TF_EXP: x = exp(x); break;
+    case NH_TF_LOG: x = log(x); break;
+    case NH_TF_LOG10: x = log10(x); break;
+    case NH_TF_SQRT: x = sqrt(x); break;
+    case NH_TF_SQUARE: x = x * x; break;
+    case NH_TF_RECIP: x = 1.0 / x; break;
+    default: break;
+  }
+  return z.a * x;
+}
+
+// sum of the prior terms of core.py:34-58 for walker w
+__device__ __forceinline__ double nh_prior_sum(const nh_prior_pack& P, long long w) {
+  double s = 0.0;
+  for (int t = 0; t < P.n; ++t) {
+    const double v = nh_lazy_eval(P.t[t].x, w);
+    const double p0 = P.t[t].p0, p1 = P.t[t].p1;
+    double r;
+    switch (P.t[t].kind) {
+      case NH_PRIOR_UNIFORM: r = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
+      case NH_PRIOR_NORMAL: r = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
+      case NH_PRIOR_LOGUNIFORM: r = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
+      default: r = v; break;
+    }
+    s += r;
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
                                                       const double* __restrict__ conv,
                                                       const double* __restrict__ flux,
@@ -466,6 +514,7 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
                                                       const int* __restrict__ ul,
                                                       const double* __restrict__ cl,
                                                       const double* __restrict__ lp,
+                                                      nh_prior_pack pri,
                                                       double* __restrict__ model_out,
                                                       double* __restrict__ lnl) {
   const int lane = threadIdx.x & 63;
@@ -497,8 +546,8 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
   if (lane == 0) {
     // quirk kept from core.py:89-92: cl is indexed by the violation count
     if (nul > 0) acc += (double)nviol * log(1.0 - cl[nviol]);
-    if (lp) {  // core.py:115-119: a walker forbidden by the prior keeps the prior value
-      double p = lp[wi];
+    if (lp || pri.n > 0) {  // core.py:115-119: a forbidden walker keeps the prior value
+      double p = (lp ? lp[wi] : 0.0) + nh_prior_sum(pri, wi);
       acc = isinf(p) ? p : acc + p;
     }
     lnl[wi] = acc;
@@ -507,11 +556,14 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
 
 static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const double* conv,
                          const double* flux, const double* err_lo, const double* err_hi,
-                         const int* ul, const double* cl, const double* lp, double* model_out,
-                         double* lnl) {
+                         const int* ul, const double* cl, const double* lp,
+                         const nh_prior* terms, int nterms, double* model_out, double* lnl) {
+  nh_prior_pack pri;
+  pri.n = nterms;
+  for (int j = 0; j < nterms; ++j) pri.t[j] = terms[j];
   nh_prof_scope ps(c, NH_K_LNPROB);
   hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, N, nE, conv,
-                     flux, err_lo, err_hi, ul, cl, lp, model_out, lnl);
+                     flux, err_lo, err_hi, ul, cl, lp, pri, model_out, lnl);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -528,14 +580,16 @@ extern "C" int nh_lnprobmodel(nh_ctx* c, const double* const* comps, const doubl
   nh_comps cs;
   cs.n = ncomp;
   for (int j = 0; j < ncomp; ++j) cs.c[j] = {comps[j], ldc, cscale[j]};
-  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, nullptr, model_out, lnl);
+  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, nullptr, nullptr, 0,
+                       model_out, lnl);
 }
 
 extern "C" int nh_lnprob(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int nE,
                          const double* conv, const double* flux, const double* err_lo,
                          const double* err_hi, const int* ul, const double* cl, const double* lp,
-                         double* model_out, double* total) {
+                         const nh_prior* terms, int nterms, double* model_out, double* total) {
   NH_REQUIRE(c && comps && conv && flux && err_lo && err_hi && ul && cl && total, "NULL pointer");
+  NH_REQUIRE(nterms >= 0 && nterms <= NH_MAX_PRIOR && (nterms == 0 || terms), "bad prior terms");
   NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP, "ncomp must be 1..8");
   NH_REQUIRE(N >= 0 && nE >= 1, "bad sizes");
   if (N == 0) return NH_OK;
@@ -545,7 +599,8 @@ extern "C" int nh_lnprob(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int 
     NH_REQUIRE(comps[j].ptr && comps[j].ld >= nE, "bad component");
     cs.c[j] = comps[j];
   }
-  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, model_out, total);
+  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms,
+                       model_out, total);
 }
 
 // ---------------------------------------------------------------------------

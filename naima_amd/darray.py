@@ -394,6 +394,23 @@ class LazyPrior:
 
     __radd__ = __add__
 
+    def packed(self):
+        """(ctypes nh_prior array, n) when the sum fits one kernel argument block,
+        else (None, 0)"""
+        terms = list(self.terms)
+        if self.const != 0.0:
+            terms.append((3, None, self.const, 0.0))
+        if len(terms) > 16:
+            return None, 0
+        if not terms:
+            return None, 0
+        arr = (nh_prior * len(terms))()
+        for j, (kind, x, p0, p1) in enumerate(terms):
+            lz = x.lazy() if x is not None else lazy_const(p0)
+            arr[j] = nh_prior(lz, float(p0), float(p1), int(kind), 0)
+        self._keep = arr
+        return arr, len(terms)
+
     def evaluate(self):
         """dense device vector lp[n]"""
         terms = list(self.terms)
