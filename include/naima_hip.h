@@ -102,6 +102,14 @@ int nh_particle_weights(nh_ctx* ctx, int kind, const double* params /*[N][NH_PD_
                         int N, const double* e_eV /*[nG]*/, const double* xg /*[nG]*/,
                         int nG, double unit_scale, double* w, double* dlw, double* n_out);
 
+/* the same walkers on up to NH_MAX_GRIDS grids in ONE launch (the components of a model
+ * evaluation use different particle grids) */
+typedef struct { const double* e_eV; const double* xg; double* w; double* dlw;
+                 double unit_scale; int nG; int pad; } nh_grid;
+#define NH_MAX_GRIDS 4
+int nh_particle_weights_multi(nh_ctx* ctx, int kind, const double* params, int N,
+                              const nh_grid* grids /*host [ngrids]*/, int ngrids);
+
 /* lx[i] = ln(xg[i+1]/xg[i]), i < nG-1 (the abscissa ratios of utils.py:336) */
 int nh_grid_logratio(nh_ctx* ctx, const double* xg, int nG, double* lx);
 
@@ -234,6 +242,17 @@ int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const int* idx, co
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);
 int nh_copy(nh_ctx* ctx, void* dev_dst, const void* dev_src, long long bytes);
+
+/* side streams: independent pieces of one model evaluation (the radiative components)
+ * run concurrently; under capture they become branches of the graph.  fork: side stream
+ * `side` (0..3) starts after everything issued so far on the main stream and becomes
+ * the current stream; wait: stream `waiter` waits for `producer`'s work so far (-1 =
+ * main); join: the main stream waits for every forked side stream and becomes current
+ * again (nh_sync, nh_download and nh_graph_end join implicitly). */
+int nh_stream_fork(nh_ctx* ctx, int side);
+int nh_stream_switch(nh_ctx* ctx, int side);
+int nh_stream_wait(nh_ctx* ctx, int waiter, int producer);
+int nh_stream_join(nh_ctx* ctx);
 
 /* capture everything launched on the context's stream into a hipGraph, replay it */
 int nh_graph_begin(nh_ctx* ctx);

@@ -41,6 +41,7 @@ _SIGS = {
     "nh_profile_read": [_dp, C.POINTER(_d), C.POINTER(_ll), _i],
     "nh_trapz_loglog": [_dp, _dp, _dp, _i, _i, _dp],
     "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
+    "nh_particle_weights_multi": [_dp, _i, _dp, _i, _dp, _i],
     "nh_grid_logratio": [_dp, _dp, _i, _dp],
     "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i],
     "nh_synchrotron": [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _i, _dp, _i],
@@ -63,6 +64,10 @@ _SIGS = {
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
     "nh_copy": [_dp, _dp, _dp, _ll],
+    "nh_stream_fork": [_dp, _i],
+    "nh_stream_switch": [_dp, _i],
+    "nh_stream_wait": [_dp, _i, _i],
+    "nh_stream_join": [_dp],
     "nh_graph_begin": [_dp],
     "nh_graph_end": [_dp, C.POINTER(_dp)],
     "nh_graph_launch": [_dp, _dp],
@@ -109,10 +114,11 @@ def _chk(rc):
 
 class DeviceArray:
     """A float64 (or int32) array in HBM owned by a Context's pool."""
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "__weakref__")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "__weakref__")
 
     def __init__(self, ctx, ptr, shape, dtype, cap):
         self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
+        self.stream = ctx.cur_stream  # the stream whose work produces this buffer
         self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
 
     @property
@@ -122,6 +128,7 @@ class DeviceArray:
     def get(self):
         if self.ctx.capturing:
             raise RuntimeError("device->host download while a hipGraph is being captured")
+        self.ctx.join()
         out = np.empty(self.shape, dtype=self.dtype)
         if out.nbytes:
             _chk(_lib.nh_download(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes))
@@ -162,6 +169,17 @@ class Context:
         self._lx = {}
         self._tables = {}
         self.capturing = False
+        # side streams (nh_stream_fork/join): -1 = main
+        self.cur_stream = -1
+        self.multistream = os.environ.get("NAIMA_AMD_MULTISTREAM", "0") != "0"
+        self._next_side = 0
+        self._forked = False
+        self._limbo = []
+        self._waited = set()
+        # particle grids recently asked of each distribution kind: a fresh distribution
+        # evaluates all of them in one launch (nh_particle_weights_multi)
+        self._wgrids = {}
+        self._weval = 0
 
     # -- memory -------------------------------------------------------------
     @staticmethod
@@ -185,7 +203,43 @@ class Context:
         return DeviceArray(self, ptr, shape, dtype, cap)
 
     def _release(self, ptr, cap):
-        self._pool.setdefault(cap, []).append(ptr)
+        if self._forked:
+            # side streams are in flight: the buffer may still be read or written by a
+            # stream other than the one that will reuse it -> park it until the join
+            self._limbo.append((ptr, cap))
+        else:
+            self._pool.setdefault(cap, []).append(ptr)
+
+    # -- side streams ---------------------------------------------------------
+    def branch(self):
+        """context manager: run the enclosed launches on the next side stream (after
+        everything issued so far on the main stream).  No-op when already inside a
+        branch or when multistream is off."""
+        return _Branch(self)
+
+    def need(self, *objs):
+        """make the current stream wait for the streams that produced ``objs``"""
+        if not self._forked:
+            return
+        for o in objs:
+            st = getattr(o, "stream", None)
+            if st is None or st == self.cur_stream or st == -1:
+                continue  # main-stream producers are ordered by the fork itself
+            key = (self.cur_stream, st)
+            if key not in self._waited:
+                _chk(_lib.nh_stream_wait(self.h, self.cur_stream, st))
+                self._waited.add(key)
+
+    def join(self):
+        """the main stream waits for every side stream and becomes current again"""
+        if self._forked:
+            _chk(_lib.nh_stream_join(self.h))
+            self._forked = False
+            self.cur_stream = -1
+            self._waited.clear()
+            for ptr, cap in self._limbo:
+                self._pool.setdefault(cap, []).append(ptr)
+            self._limbo = []
 
     def array(self, host, dtype=np.float64):
         host = np.ascontiguousarray(host, dtype=dtype)
@@ -232,6 +286,7 @@ class Context:
         self.capturing = True
 
     def graph_end(self):
+        self.join()
         self.capturing = False
         g = _dp()
         _chk(_lib.nh_graph_end(self.h, C.byref(g)))
@@ -249,6 +304,7 @@ class Context:
         _chk(_lib.nh_graph_launch(self.h, g))
 
     def sync(self):
+        self.join()
         _chk(_lib.nh_sync(self.h))
 
     def info(self):
@@ -288,6 +344,28 @@ class Context:
             self._tables.clear()
             _lib.nh_destroy(self.h)
             self.h = None
+
+
+class _Branch:
+    def __init__(self, ctx):
+        self.ctx, self.active = ctx, False
+
+    def __enter__(self):
+        c = self.ctx
+        if c.multistream and c.cur_stream == -1:
+            side = c._next_side
+            c._next_side = (side + 1) % 4
+            _chk(_lib.nh_stream_fork(c.h, side))
+            c.cur_stream = side
+            c._forked = True
+            self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            _chk(_lib.nh_stream_switch(self.ctx.h, -1))
+            self.ctx.cur_stream = -1
+        return False
 
 
 _default = {}

@@ -152,6 +152,7 @@ def lnprobmodel(model, data, lp=None):
         N, nE = m.shape
         if nE != dd.n:
             raise ValueError("model has %d energies, data table has %d" % (nE, dd.n))
+        ctx.join()  # the emission components ran on side streams
         total = ctx.empty((N,))
         lpd = terms = None
         nterms = 0

@@ -33,9 +33,15 @@
 
 struct nh_prof_rec { hipEvent_t a, b; int kid; };
 
+#define NH_NSIDE 4
+
 struct nh_ctx {
   int device;
-  hipStream_t stream;
+  hipStream_t stream;        // the CURRENT stream: every launch goes here
+  hipStream_t main_stream;   // uploads, downloads, sync, graph capture origin
+  hipStream_t side[NH_NSIDE];
+  hipEvent_t ev_fork, ev_side[NH_NSIDE];
+  bool side_used[NH_NSIDE];
   hipEvent_t t0, t1;
   bool profiling;
   std::vector<nh_prof_rec> recs;

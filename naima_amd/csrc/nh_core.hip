@@ -31,7 +31,14 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   c->rccl_lib = nullptr;
   memset(c->acc_ms, 0, sizeof(c->acc_ms));
   memset(c->acc_n, 0, sizeof(c->acc_n));
-  NH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  NH_CHECK_HIP(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
+  c->stream = c->main_stream;
+  for (int i = 0; i < NH_NSIDE; ++i) {
+    NH_CHECK_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+    NH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+    c->side_used[i] = false;
+  }
+  NH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   NH_CHECK_HIP(hipEventCreate(&c->t0));
   NH_CHECK_HIP(hipEventCreate(&c->t1));
   *out = c;
@@ -41,13 +48,19 @@ extern "C" int nh_create(int device, nh_ctx** out) {
 extern "C" int nh_destroy(nh_ctx* c) {
   if (!c) return NH_OK;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->main_stream);
   nh_comm_destroy(c);
+  for (int i = 0; i < NH_NSIDE; ++i) {
+    (void)hipStreamSynchronize(c->side[i]);
+    (void)hipStreamDestroy(c->side[i]);
+    (void)hipEventDestroy(c->ev_side[i]);
+  }
+  (void)hipEventDestroy(c->ev_fork);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : c->pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->t0);
   (void)hipEventDestroy(c->t1);
-  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->main_stream);
   delete c;
   return NH_OK;
 }
@@ -77,7 +90,8 @@ extern "C" int nh_alloc(nh_ctx* c, long long bytes, void** out) {
 extern "C" int nh_free(nh_ctx* c, void* p) {
   NH_REQUIRE(c, "ctx is NULL");
   if (p) {
-    NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+    int rc = nh_sync(c);
+    if (rc) return rc;
     NH_CHECK_HIP(hipFree(p));
   }
   return NH_OK;
@@ -93,8 +107,10 @@ extern "C" int nh_upload(nh_ctx* c, void* dst, const void* src, long long bytes)
 
 extern "C" int nh_download(nh_ctx* c, void* dst, const void* src, long long bytes) {
   NH_REQUIRE(c && dst && src && bytes >= 0, "bad argument");
-  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
-  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  int rc = nh_stream_join(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->main_stream));
+  NH_CHECK_HIP(hipStreamSynchronize(c->main_stream));
   return NH_OK;
 }
 
@@ -106,7 +122,54 @@ extern "C" int nh_memset(nh_ctx* c, void* p, int byte, long long bytes) {
 
 extern "C" int nh_sync(nh_ctx* c) {
   NH_REQUIRE(c, "ctx is NULL");
-  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  int rc = nh_stream_join(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipStreamSynchronize(c->main_stream));
+  return NH_OK;
+}
+
+// ---- fork / join over side streams (independent emission components of one model
+// evaluation run concurrently; under graph capture these become graph branches) ----
+extern "C" int nh_stream_fork(nh_ctx* c, int side) {
+  NH_REQUIRE(c && side >= 0 && side < NH_NSIDE, "bad side stream");
+  // the side stream starts after everything issued so far on the main stream
+  NH_CHECK_HIP(hipEventRecord(c->ev_fork, c->main_stream));
+  NH_CHECK_HIP(hipStreamWaitEvent(c->side[side], c->ev_fork, 0));
+  c->side_used[side] = true;
+  c->stream = c->side[side];
+  return NH_OK;
+}
+
+extern "C" int nh_stream_switch(nh_ctx* c, int side) {
+  NH_REQUIRE(c && side >= -1 && side < NH_NSIDE, "bad side stream");
+  c->stream = side < 0 ? c->main_stream : c->side[side];
+  return NH_OK;
+}
+
+extern "C" int nh_stream_wait(nh_ctx* c, int waiter, int producer) {
+  NH_REQUIRE(c && waiter >= -1 && waiter < NH_NSIDE && producer >= -1 && producer < NH_NSIDE,
+             "bad stream index");
+  if (waiter == producer) return NH_OK;
+  hipStream_t ws = waiter < 0 ? c->main_stream : c->side[waiter];
+  if (producer < 0) {
+    NH_CHECK_HIP(hipEventRecord(c->ev_fork, c->main_stream));
+    NH_CHECK_HIP(hipStreamWaitEvent(ws, c->ev_fork, 0));
+  } else {
+    NH_CHECK_HIP(hipEventRecord(c->ev_side[producer], c->side[producer]));
+    NH_CHECK_HIP(hipStreamWaitEvent(ws, c->ev_side[producer], 0));
+  }
+  return NH_OK;
+}
+
+extern "C" int nh_stream_join(nh_ctx* c) {
+  NH_REQUIRE(c, "ctx is NULL");
+  for (int i = 0; i < NH_NSIDE; ++i) {
+    if (!c->side_used[i]) continue;
+    NH_CHECK_HIP(hipEventRecord(c->ev_side[i], c->side[i]));
+    NH_CHECK_HIP(hipStreamWaitEvent(c->main_stream, c->ev_side[i], 0));
+    c->side_used[i] = false;
+  }
+  c->stream = c->main_stream;
   return NH_OK;
 }
 
@@ -134,7 +197,8 @@ extern "C" int nh_profile_enable(nh_ctx* c, int on) {
 
 extern "C" int nh_profile_read(nh_ctx* c, double* ms, long long* n, int reset) {
   NH_REQUIRE(c, "ctx is NULL");
-  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  int rcj = nh_sync(c);
+  if (rcj) return rcj;
   for (auto& r : c->recs) {
     float f = 0;
     NH_CHECK_HIP(hipEventElapsedTime(&f, r.a, r.b));
@@ -278,6 +342,68 @@ __global__ __launch_bounds__(256) void k_particle_weights(
   w[idx] = g * n;
   if (nout) nout[idx] = n;
   dlw[idx] = last ? 0.0 : lrx + dsh;
+}
+
+struct pw_grids {
+  const double* e[NH_MAX_GRIDS];
+  const double* xg[NH_MAX_GRIDS];
+  double* w[NH_MAX_GRIDS];
+  double* dlw[NH_MAX_GRIDS];
+  double scale[NH_MAX_GRIDS];
+  int nG[NH_MAX_GRIDS];
+  long long off[NH_MAX_GRIDS + 1];  // element offsets of the grids in the flat index
+  int n;
+};
+
+// the same walkers on several grids (the components of one model evaluation use
+// different electron grids: Synchrotron from 1 GeV, IC from Eemin, We(> 1 TeV) ...)
+__global__ __launch_bounds__(256) void k_particle_weights_multi(
+    int kind, const double* __restrict__ params, int N, pw_grids G) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G.off[G.n]) return;
+  int g = 0;
+  while (g + 1 < G.n && idx >= G.off[g + 1]) ++g;
+  const long long loc = idx - G.off[g];
+  const int nG = G.nG[g];
+  const int wi = (int)(loc / nG), i = (int)(loc % nG);
+  const double* pr = params + (long long)wi * NH_PD_NPAR;
+  pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  const double* e = G.e[g];
+  const double* xg = G.xg[g];
+  const double E = e[i];
+  const bool last = i + 1 >= nG;
+  const double E2 = last ? E : e[i + 1];
+  const double gx = xg[i];
+  const double lrE = last ? 0.0 : log(E2 / E);
+  const double lrx = last ? 0.0 : log(xg[i + 1] / gx);
+  double n, dsh;
+  pd_node(kind, p, E, E2, lrE, n, dsh);
+  n *= G.scale[g];
+  G.w[g][loc] = gx * n;
+  G.dlw[g][loc] = last ? 0.0 : lrx + dsh;
+}
+
+extern "C" int nh_particle_weights_multi(nh_ctx* c, int kind, const double* params, int N,
+                                         const nh_grid* grids, int ngrids) {
+  NH_REQUIRE(c && params && grids, "NULL pointer");
+  NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
+  NH_REQUIRE(N >= 0 && ngrids >= 1 && ngrids <= NH_MAX_GRIDS, "bad sizes");
+  if (N == 0) return NH_OK;
+  pw_grids G;
+  G.n = ngrids;
+  G.off[0] = 0;
+  for (int g = 0; g < ngrids; ++g) {
+    NH_REQUIRE(grids[g].e_eV && grids[g].xg && grids[g].w && grids[g].dlw && grids[g].nG >= 2,
+               "bad grid descriptor");
+    G.e[g] = grids[g].e_eV; G.xg[g] = grids[g].xg; G.w[g] = grids[g].w; G.dlw[g] = grids[g].dlw;
+    G.scale[g] = grids[g].unit_scale; G.nG[g] = grids[g].nG;
+    G.off[g + 1] = G.off[g] + (long long)N * grids[g].nG;
+  }
+  nh_prof_scope ps(c, NH_K_PDIST);
+  hipLaunchKernelGGL(k_particle_weights_multi, dim3((unsigned)((G.off[ngrids] + 255) / 256)),
+                     dim3(256), 0, c->stream, kind, params, N, G);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
 }
 
 extern "C" int nh_particle_weights(nh_ctx* c, int kind, const double* params, int N,

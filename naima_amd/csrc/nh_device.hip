@@ -268,14 +268,17 @@ extern "C" int nh_copy(nh_ctx* c, void* dst, const void* src, long long bytes) {
 extern "C" int nh_graph_begin(nh_ctx* c) {
   NH_REQUIRE(c, "ctx is NULL");
   NH_REQUIRE(!c->profiling, "disable per-kernel profiling before capturing a graph");
-  NH_CHECK_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  NH_REQUIRE(c->stream == c->main_stream, "join the side streams before capturing");
+  NH_CHECK_HIP(hipStreamBeginCapture(c->main_stream, hipStreamCaptureModeRelaxed));
   return NH_OK;
 }
 
 extern "C" int nh_graph_end(nh_ctx* c, void** exec_out) {
   NH_REQUIRE(c && exec_out, "bad argument");
   hipGraph_t g = nullptr;
-  NH_CHECK_HIP(hipStreamEndCapture(c->stream, &g));
+  int rcj = nh_stream_join(c);
+  if (rcj) return rcj;
+  NH_CHECK_HIP(hipStreamEndCapture(c->main_stream, &g));
   hipGraphExec_t ex = nullptr;
   hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
@@ -287,7 +290,7 @@ extern "C" int nh_graph_end(nh_ctx* c, void** exec_out) {
 
 extern "C" int nh_graph_launch(nh_ctx* c, void* exec) {
   NH_REQUIRE(c && exec, "bad argument");
-  NH_CHECK_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), c->stream));
+  NH_CHECK_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), c->main_stream));
   return NH_OK;
 }
 

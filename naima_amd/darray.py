@@ -33,6 +33,11 @@ class nh_comp(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ld", C.c_longlong), ("scale", C.c_double)]
 
 
+class nh_grid(C.Structure):
+    _fields_ = [("e_eV", C.c_void_p), ("xg", C.c_void_p), ("w", C.c_void_p), ("dlw", C.c_void_p),
+                ("unit_scale", C.c_double), ("nG", C.c_int), ("pad", C.c_int)]
+
+
 class nh_prior(C.Structure):
     _fields_ = [("x", nh_lazy), ("p0", C.c_double), ("p1", C.c_double), ("kind", C.c_int),
                 ("pad", C.c_int)]
@@ -90,12 +95,14 @@ class DVec:
         """a contiguous device vector holding the values (one tiny launch unless plain)"""
         if self.is_plain():
             return self
+        self.ctx.need(self.owner)
         out = self.ctx.empty((self.n,))
         cols = (nh_lazy * 1)(self.lazy())
         self.ctx.call("nh_pack_rows", cols, 1, self.n, out, 1)
         return DVec(self.ctx, out, out.ptr, self.n)
 
     def get(self):
+        self.ctx.join()
         d = self.dense()
         host = np.empty(self.n)
         _lib._chk(_lib._lib.nh_download(self.ctx.h, host.ctypes.data, d.ptr, host.nbytes))
@@ -140,6 +147,7 @@ class DVec:
             keep = (self.owner, dev)
         if reverse:
             x, y = y, x
+        self.ctx.need(*keep)
         out = self.ctx.empty((self.n,))
         self.ctx.call("nh_ew_binary", OPS[op], C.byref(x), C.byref(y), self.n, out)
         del keep
@@ -353,6 +361,7 @@ class DMat:
         if len(self.terms) == 1 and self.colfac is None and self.terms[0][3] == 1.0 \
                 and self.terms[0][2] == m:
             return self
+        self.ctx.need(*[t[0] for t in self.terms])
         out = self.ctx.empty((N, m))
         cf = self.ctx.const(self.colfac) if self.colfac is not None else None
         self.ctx.call("nh_lincomb", self.comps(), len(self.terms), cf, N, m, out, m)
@@ -363,6 +372,7 @@ class DMat:
         return d.terms[0][0], d.terms[0][1]
 
     def get(self):
+        self.ctx.join()
         d = self.dense()
         host = np.empty(self.shape)
         _lib._chk(_lib._lib.nh_download(self.ctx.h, host.ctypes.data, d.terms[0][1], host.nbytes))

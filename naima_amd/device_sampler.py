@@ -68,8 +68,10 @@ class DeviceLoop:
         ctx = self.ctx
         self.coords = ctx.empty((self.N * self.ndim,))
         self.logp = ctx.empty((self.N,))
-        self.idx = ctx.empty((2 * self.ns,), dtype=np.int32)
-        self.rnd = ctx.empty((2 * self.ns,))
+        # ONE host->device block per half-step: rnd[2 ns] float64 | idx[2 ns] int32
+        self.blk = ctx.empty((3 * self.ns,))
+        self.rnd = self.blk.ptr
+        self.idx = self.blk.ptr + 16 * self.ns
         self.qT = ctx.empty((self.ndim * self.nloc,))
         self.factors = ctx.empty((self.nloc,))
         self.newlp = ctx.empty((self.ns,))
@@ -184,8 +186,9 @@ class DeviceLoop:
                          blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
                                 (self.cur_blobs or [])] if s.store_blobs else [])
             self.hist.append(block)
-        idx_h = np.empty(2 * ns, dtype=np.int32)
-        rnd_h = np.empty(2 * ns)
+        blk_h = np.empty(3 * ns)
+        rnd_h = blk_h[:2 * ns]
+        idx_h = blk_h[2 * ns:].view(np.int32)
         for it in range(iterations):
             inds = np.arange(N) % 2
             rng.shuffle(inds)
@@ -197,8 +200,7 @@ class DeviceLoop:
                 lnu = np.log(rng.random(ns))
                 idx_h[:ns], idx_h[ns:] = S, Cidx[rint]
                 rnd_h[:ns], rnd_h[ns:] = zz, lnu
-                self.idx.set(idx_h)
-                self.rnd.set(rnd_h)
+                self.blk.set(blk_h)
                 if self.graph is not None:
                     ctx.graph_launch(self.graph)
                 elif not s.use_graph or s.comm.size > 1 or self.warm < 1:

@@ -38,8 +38,9 @@ class _ParticleDistribution:
     _slots = ()
 
     def __setattr__(self, name, value):
-        # any parameter change invalidates the packed device rows
+        # any parameter change invalidates the packed device rows and weights
         self.__dict__.pop("_rows_dev", None)
+        self.__dict__.pop("_w_dev", None)
         object.__setattr__(self, name, value)
 
     @property
@@ -96,6 +97,7 @@ class _ParticleDistribution:
         key = (N, None if amplitude_to is None else amplitude_to.name)
         hit = cache.get(key)
         if hit is not None:
+            ctx.need(hit)  # packed on another side stream of this evaluation
             return hit
         cols = (nh_lazy * NH_PD_NPAR)()
         for j in range(NH_PD_NPAR):
@@ -121,6 +123,7 @@ class _ParticleDistribution:
                 dev = ctx.array(np.broadcast_to(np.asarray(v, dtype=float), (N,)))
                 cols[slot] = nh_lazy(dev.ptr, 1, 1.0, 1.0, 0.0, 0, 0)
                 keep.append(dev)
+        ctx.need(*[getattr(k, "owner", k) for k in keep])
         out = ctx.empty((N, NH_PD_NPAR))
         ctx.call("nh_pack_rows", cols, NH_PD_NPAR, N, out, NH_PD_NPAR)
         cache[key] = out

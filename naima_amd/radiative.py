@@ -123,26 +123,74 @@ class BaseRadiative:
         return u.Quantity(self._finish(host, E), _SPEC_UNIT)
 
     def _weights(self, xg, e_eV, unit_scale):
-        """device weights w = xg*n and log-ratios lw[i] = ln|w[i+1]/w[i]| of every walker"""
+        """device weights w = xg*n and log-ratios lw[i] = ln|w[i+1]/w[i]| of every walker.
+
+        The components of one model evaluation share the particle distribution but use
+        different grids (Synchrotron from 1 GeV, IC from Eemin, We above 1 TeV ...).
+        The context remembers which grids were recently asked of a distribution kind; a
+        fresh distribution evaluates all of them in ONE launch and later requests hit
+        its cache."""
         pd = self.particle_distribution
-        if not hasattr(pd, "param_rows"):
+        if not hasattr(pd, "device_rows"):
             raise TypeError("naima_amd radiative models need a naima_amd.models particle "
                             "distribution (got %r)" % (type(pd).__name__,))
+        from .darray import nh_grid
         ctx = get_context()
         N = self.batch_size
-        rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
         nG = xg.size
         xd, ed = ctx.const(xg), ctx.const(e_eV)
-        w, lw = ctx.empty((N, nG)), ctx.empty((N, nG))
-        ctx.call("nh_particle_weights", PD_KIND[pd.kind], rows, N, ed, xd, nG,
-                 float(unit_scale), w, lw, None)
-        return ctx, N, w, lw, xd, ctx.grid_logratio(xd)
+        lx = ctx.grid_logratio(xd)
+        key = (xd.ptr, ed.ptr, float(unit_scale), nG)
+        cache = pd.__dict__.setdefault("_w_dev", {}).setdefault(N, {})
+        reg = ctx._wgrids.setdefault((pd.kind, N), {})
+        hit = cache.get(key)
+        if hit is None:
+            if not cache:
+                ctx._weval += 1
+            reg[key] = (ctx._weval, xd, ed)
+            # every grid used by the last two evaluations of this kind, this one first
+            todo = [key] + [k for k, v in reg.items() if k != key and k not in cache
+                            and ctx._weval - v[0] <= 2][:3]
+            for k in [k for k, v in reg.items() if ctx._weval - v[0] > 2]:
+                del reg[k]
+            rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
+            desc = (nh_grid * len(todo))()
+            for j, k in enumerate(todo):
+                _, xdk, edk = reg[k]
+                wk, lwk = ctx.empty((N, k[3])), ctx.empty((N, k[3]))
+                desc[j] = nh_grid(edk.ptr, xdk.ptr, wk.ptr, lwk.ptr, k[2], k[3], 0)
+                cache[k] = (wk, lwk)
+            ctx.call("nh_particle_weights_multi", PD_KIND[pd.kind], rows, N, desc, len(todo))
+            hit = cache[key]
+        else:
+            reg[key] = (ctx._weval, xd, ed)
+        ctx.need(hit[0])
+        return ctx, N, hit[0], hit[1], xd, lx
 
     # -- public ---------------------------------------------------------------
+    def _spectrum_branch(self, photon_energy):
+        """``_spectrum`` on its own side stream when the values stay on the device:
+        the emission components of a model evaluation are independent of each
+        other, so their launch sequences run concurrently (graph branches)"""
+        if self.on_device:
+            ctx = get_context()
+            self._prefork(ctx)
+            with ctx.branch():
+                return self._spectrum(photon_energy)
+        return self._spectrum(photon_energy)
+
+    def _prefork(self, ctx):
+        """launch what several components share (the packed parameter rows) on the
+        MAIN stream before forking, so that a side stream never has to wait for
+        another side stream's whole queue"""
+        pd = self.particle_distribution
+        if hasattr(pd, "device_rows"):
+            pd.device_rows(ctx, self.batch_size, amplitude_to=_PER_EV)
+
     def flux(self, photon_energy, distance=1 * u.kpc):
         """Differential flux at ``distance``; ``distance=0`` gives the intrinsic
         differential luminosity (radiative.py:88-111)."""
-        spec = self._spectrum(photon_energy)
+        spec = self._spectrum_branch(photon_energy)
         if not _dist_is_zero(distance):
             distance = validate_scalar("distance", distance, physical_type="length")
             spec = spec / (4 * np.pi * distance.to("cm") ** 2)
@@ -227,6 +275,13 @@ class BaseElectron(BaseRadiative):
         return n if self.is_batched else n[0]
 
     def _We_on(self, gam):
+        if self.on_device:
+            self._prefork(get_context())
+            with get_context().branch():
+                return self._We_on_impl(gam)
+        return self._We_on_impl(gam)
+
+    def _We_on_impl(self, gam):
         ctx, N, w, lw, xd, lx, gam = self._electron_weights(gam)
         K = gam * MEC2_ERG  # u = x*y = (gam mec2)(gam nelec)
         Kt, dlnKt = ctx.const(K), ctx.const(_dlog(K))
@@ -294,13 +349,19 @@ class Synchrotron(BaseElectron):
     def _own_device_values(self):
         return (self.B,)
 
+    def _prefork(self, ctx):
+        super()._prefork(ctx)
+        Bv = self.B.to("G").value
+        if isinstance(Bv, DVec) and self.__dict__.get("_B_dense") is None:
+            self._B_dense = Bv.dense()
+
     def _spectrum(self, photon_energy):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         Bv = self.B.to("G").value
         if isinstance(Bv, DVec):
-            Bd = Bv.dense()
+            Bd = self.__dict__.get("_B_dense") or Bv.dense()
             Bp = Bd.ptr
         else:
             Bd = ctx.const(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
@@ -632,6 +693,13 @@ class BaseProton(BaseRadiative):
         return J if self.is_batched else J[0]
 
     def _Wp_on(self, Ep):
+        if self.on_device:
+            self._prefork(get_context())
+            with get_context().branch():
+                return self._Wp_on_impl(Ep)
+        return self._Wp_on_impl(Ep)
+
+    def _Wp_on_impl(self, Ep):
         ctx, N, w, lw, xd, lx, Ep = self._proton_weights(Ep)
         Kt, dlnKt = ctx.const(Ep), ctx.const(_dlog(Ep))
         out = ctx.empty((N, 1))
