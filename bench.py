@@ -38,14 +38,37 @@ ALGO = {
     "cfg4": dict(bytes=8 * (6 + 261 + 1), flop_eq=1.0e9),
     "cfg5": dict(bytes=8 * (5 + 28 + 2), flop_eq=0.5e6),
 }
-# per-kernel share of the flop-equivalents of cfg3 (op-count convention of SURVEY.md 8d:
-# Syn 50 eq./node, table reduction 30 eq./node)
+# flop-equivalents per launch-walker of the two hot kernels (op-count convention of
+# a node of Synchrotron 50 eq., a segment of a table reduction 30 eq.)
 KERNEL_FLOP_EQ = {
-    "cfg3": {"synchrotron": 64 * 570 * 50.0, "integrate_tables": (64 * 3 * 370 + 270) * 30.0},
+    "cfg3": {"synchrotron": 64 * 570 * 50.0, "integrate_tables": 64 * 3 * 370 * 30.0},
     "cfg2": {"synchrotron": 179 * 300 * 50.0},
+    "cfg1": {"integrate_tables": 28 * 570 * 30.0},
+    "cfg5": {"integrate_tables": 28 * 600 * 30.0},
 }
+# profiler category -> kernel symbol in the rocprofv3 kernel trace
+KERNEL_SYMBOL = {"integrate_tables": "k_integrate_tables", "synchrotron": "k_synchrotron",
+                 "particle_weights": "k_particle_weights_multi", "lnprob": "k_lnprobmodel",
+                 "integrate_rows": "k_integrate_rows", "ic_seed_walkers": "k_ic_seed_walkers",
+                 "tables": "k_table_*", "glue": "k_pack_rows/k_move_*"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VEC_PEAK_TF = 78.6    # vendor figure quoted in SURVEY.md 8d (256 CU x 128 flop/clk x 2.4 GHz)
+
+
+def measured_traffic(name, symbol):
+    """HBM-side bytes per launch of ``symbol`` from the committed TCC counter run
+    (profiles/*_hbm_counters*.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    rocprofv3 --pmc passes, KB per launch; see profiles/README.md).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_hbm_counters*.json" % name)))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    f = [v for k, v in d.get("fetch", {}).items() if symbol in k]
+    w = [v for k, v in d.get("write", {}).items() if symbol in k]
+    if not f:
+        return None, None
+    return (max(f) + (max(w) if w else 0.0)) * 1024.0, os.path.basename(files[-1])
 
 
 def build_problem(name, na):
@@ -171,18 +194,28 @@ def main():
     prof_sampler.run_mcmc(pstate, args.steps, store=False)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
+    ev_us = ctx.profile_overhead_us()  # what an event pair adds to every launch
 
     if rank != 0:
         return
     value = nwalkers * args.steps / dt
     info = ctx.info()
-    # dominant kernel by accumulated HIP-event time
-    dom = max(prof, key=lambda k: prof[k]["ms"])
-    avg_s = prof[dom]["ms"] * 1e-3 / prof[dom]["launches"]
+    # dominant kernel by accumulated HIP-event time (one category = one kernel symbol;
+    # "glue"/"tables" aggregate several small kernels and are not candidates).  The fixed
+    # cost of the event pair (an empty kernel bracketed the same way, minus its ~1 us of
+    # execution) is removed so that the figure is comparable with rocprofv3's durations.
+    ev_fix = max(ev_us - 1.0, 0.0)
+
+    def launch_us(cat):
+        return max(prof[cat]["ms"] * 1e3 / prof[cat]["launches"] - ev_fix, 0.1)
+
+    dom = max((k for k in prof if k not in ("glue", "tables")),
+              key=lambda k: launch_us(k) * prof[k]["launches"])
+    avg_s = launch_us(dom) * 1e-6
     walkers_per_launch = per_gpu / 2.0  # one half-ensemble shard per launch
     abytes = ALGO[name]["bytes"] * walkers_per_launch
     achieved = abytes / avg_s / 1e9
-    kflop = KERNEL_FLOP_EQ.get(name, {}).get(dom)
+    traffic, traffic_src = measured_traffic(name, KERNEL_SYMBOL.get(dom, dom).split("/")[0])
     out = {
         "metric": "walker-steps/sec (ensemble lnprob evals/s)",
         "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
@@ -198,24 +231,36 @@ def main():
             "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
             "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
             "device": info["name"]},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_us": avg_s * 1e6,
+                     "avg_launch_us_raw_events": prof[dom]["ms"] * 1e3 / prof[dom]["launches"],
+                     "event_pair_overhead_us": ev_us,
                      "algorithmic_bytes_per_launch": abytes,
-                     "note": "transcendental-bound FP64 path: HBM fraction is << 1 % by "
-                             "construction (SURVEY.md 8d); see fp64_valu"},
-        "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
-        "kernel_launches": {k: v["launches"] for k, v in prof.items()},
-        "gpu_busy_frac": sum(v["ms"] for v in prof.values()) * 1e-3 / dt,
+                     "walkers_per_launch": walkers_per_launch,
+                     "note": "FP64-transcendental-bound path: the HBM fraction is << 1 % by "
+                             "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
+                             "traffic = L2 memory-side bytes (mostly Infinity-Cache hits: each "
+                             "of the 8 XCD L2s pulls its own copy of the shared emission table)"},
+        "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
+        "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
+        "eager_kernel_time_frac": sum(v["ms"] for v in prof.values()) * 1e-3 / dt,
         "acceptance_fraction": acc_frac,
         "loop": ("host" if not device else ("device+hipGraph" if sampler._dev.graph is not None
                                             else "device")),
     }
-    if kflop:
-        tf = kflop * walkers_per_launch / avg_s / 1e12
-        out["fp64_valu"] = {"kernel": dom, "achieved": tf, "peak": FP64_VEC_PEAK_TF,
-                            "unit": "TFLOP-eq/s", "frac": tf / FP64_VEC_PEAK_TF,
-                            "convention": "SURVEY.md 8d: transcendental = 20 flop-eq"}
+    fp = {}
+    for cat, kflop in KERNEL_FLOP_EQ.get(name, {}).items():
+        if cat in prof:
+            t = launch_us(cat) * 1e-6
+            tf = kflop * walkers_per_launch / t / 1e12
+            fp[KERNEL_SYMBOL[cat]] = {"achieved": tf, "frac": tf / FP64_VEC_PEAK_TF,
+                                      "avg_launch_us": t * 1e6}
+    if fp:
+        out["fp64_valu"] = {"peak": FP64_VEC_PEAK_TF, "unit": "TFLOP-eq/s", "kernels": fp,
+                            "convention": "SURVEY.md 8d: transcendental = 20 flop-eq; "
+                                          "Synchrotron node 50, table-reduction segment 30"}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out))

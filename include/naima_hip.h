@@ -82,8 +82,11 @@ int nh_timer_start(nh_ctx* ctx);
 int nh_timer_stop(nh_ctx* ctx, double* elapsed_ms);
 /* per-kernel accumulated HIP-event time since the last reset; kernel ids NH_K_* */
 enum { NH_K_PDIST = 0, NH_K_INTEGRATE = 1, NH_K_SYNCHROTRON = 2, NH_K_TABLES = 3,
-       NH_K_LNPROB = 4, NH_K_SSC = 5, NH_K_SAMPLER = 6, NH_K_COUNT = 8 };
+       NH_K_LNPROB = 4, NH_K_SSC = 5, NH_K_GLUE = 6 /* pack, move, scatter, lincomb */,
+       NH_K_ROWS = 7 /* k_integrate_rows (We/Wp) */, NH_K_COUNT = 8 };
 int nh_profile_enable(nh_ctx* ctx, int on);
+/* HIP-event time of an empty kernel: the fixed cost an event pair adds per launch */
+int nh_profile_calibrate(nh_ctx* ctx, int reps, double* overhead_us);
 int nh_profile_read(nh_ctx* ctx, double* ms_per_kernel /*[NH_K_COUNT]*/,
                     long long* launches /*[NH_K_COUNT]*/, int reset);
 

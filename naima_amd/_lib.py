@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaima_hip.so")
 
 NH_PD_NPAR = 8
-NH_K_NAMES = ("particle_weights", "integrate_tables", "synchrotron", "tables", "lnprobmodel",
-              "ic_seed_walkers", "sampler", "reserved")
+NH_K_NAMES = ("particle_weights", "integrate_tables", "synchrotron", "tables", "lnprob",
+              "ic_seed_walkers", "glue", "integrate_rows")
 PD_KIND = {"PowerLaw": 0, "ExponentialCutoffPowerLaw": 1, "BrokenPowerLaw": 2,
            "ExponentialCutoffBrokenPowerLaw": 3, "LogParabola": 4}
 PP_MODEL = {"Geant4": 0, "Pythia8": 1, "SIBYLL": 2, "QGSJET": 3}
@@ -39,6 +39,7 @@ _SIGS = {
     "nh_timer_stop": [_dp, C.POINTER(_d)],
     "nh_profile_enable": [_dp, _i],
     "nh_profile_read": [_dp, C.POINTER(_d), C.POINTER(_ll), _i],
+    "nh_profile_calibrate": [_dp, _i, C.POINTER(_d)],
     "nh_trapz_loglog": [_dp, _dp, _dp, _i, _i, _dp],
     "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
     "nh_particle_weights_multi": [_dp, _i, _dp, _i, _dp, _i],
@@ -325,6 +326,11 @@ class Context:
 
     def profile(self, on):
         _chk(_lib.nh_profile_enable(self.h, int(bool(on))))
+
+    def profile_overhead_us(self, reps=200):
+        v = _d()
+        _chk(_lib.nh_profile_calibrate(self.h, int(reps), C.byref(v)))
+        return v.value
 
     def profile_read(self, reset=True):
         ms = (_d * 8)()

@@ -84,7 +84,7 @@ extern "C" int nh_comm_destroy(nh_ctx* c) {
 extern "C" int nh_comm_allgather(nh_ctx* c, const double* send, double* recv, long long count) {
   NH_REQUIRE(c && send && recv && count >= 0, "bad argument");
   NH_REQUIRE(c->comm != nullptr, "nh_comm_init has not been called");
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   NH_CHECK_RCCL(g_rccl.AllGather(send, recv, (size_t)count, ncclDouble,
                                  reinterpret_cast<ncclComm_t>(c->comm), c->stream));
   return NH_OK;

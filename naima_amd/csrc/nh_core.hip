@@ -195,6 +195,32 @@ extern "C" int nh_profile_enable(nh_ctx* c, int on) {
   return NH_OK;
 }
 
+__global__ void k_empty() {}
+
+// mean HIP-event time of an EMPTY kernel bracketed exactly like the profiled launches:
+// the fixed cost the event pair adds to every measurement (subtract it to compare with
+// rocprofv3's kernel durations)
+extern "C" int nh_profile_calibrate(nh_ctx* c, int reps, double* overhead_us) {
+  NH_REQUIRE(c && overhead_us && reps >= 1, "bad argument");
+  hipEvent_t a, b;
+  NH_CHECK_HIP(hipEventCreate(&a));
+  NH_CHECK_HIP(hipEventCreate(&b));
+  double tot = 0.0;
+  for (int i = 0; i < reps + 3; ++i) {
+    NH_CHECK_HIP(hipEventRecord(a, c->stream));
+    hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, c->stream);
+    NH_CHECK_HIP(hipEventRecord(b, c->stream));
+    NH_CHECK_HIP(hipEventSynchronize(b));
+    float f = 0;
+    NH_CHECK_HIP(hipEventElapsedTime(&f, a, b));
+    if (i >= 3) tot += f;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *overhead_us = tot / reps * 1e3;
+  return NH_OK;
+}
+
 extern "C" int nh_profile_read(nh_ctx* c, double* ms, long long* n, int reset) {
   NH_REQUIRE(c, "ctx is NULL");
   int rcj = nh_sync(c);
@@ -428,7 +454,7 @@ __global__ void k_grid_logratio(const double* __restrict__ xg, int nG, double* _
 
 extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx) {
   NH_REQUIRE(c && xg && lx && nG >= 2, "bad argument");
-  nh_prof_scope ps(c, NH_K_PDIST);
+  nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_grid_logratio, dim3((nG + 255) / 256), dim3(256), 0, c->stream, xg, nG, lx);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
@@ -545,8 +571,8 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)nG * nK < (1LL << 31),
              "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_INTEGRATE);
   long long pairs = (long long)N * nK;
+  nh_prof_scope ps(c, pairs * 4 < 4096 ? NH_K_ROWS : NH_K_INTEGRATE);
   if (pairs * 4 < 4096) {  // too few (walker, k) pairs to fill the chip with pair-lanes
     hipLaunchKernelGGL(k_integrate_rows, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0,
                        c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo);
@@ -750,7 +776,7 @@ extern "C" int nh_stretch_propose(nh_ctx* c, const double* s, const double* cset
   NH_REQUIRE(c && s && cset && partner && z && q && factors && ns >= 0 && ndim >= 1,
              "bad argument");
   if (ns == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   int tot = ns * ndim;
   hipLaunchKernelGGL(k_stretch_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, s,
                      cset, partner, z, ns, ndim, q, factors);
@@ -780,7 +806,7 @@ extern "C" int nh_stretch_accept(nh_ctx* c, double* s, double* oldlp, const doub
   NH_REQUIRE(c && s && oldlp && q && newlp && factors && lnu && accepted && ns >= 0 && ndim >= 1,
              "bad argument");
   if (ns == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_stretch_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, s, oldlp,
                      q, newlp, factors, lnu, ns, ndim, accepted);
   NH_CHECK_HIP(hipGetLastError());

@@ -39,7 +39,7 @@ extern "C" int nh_pack_rows(nh_ctx* c, const nh_lazy* cols, int ncols, int N, do
   lazy_pack P;
   P.n = ncols;
   for (int j = 0; j < ncols; ++j) P.c[j] = cols[j];
-  nh_prof_scope ps(c, NH_K_PDIST);
+  nh_prof_scope ps(c, NH_K_GLUE);
   int tot = N * ncols;
   hipLaunchKernelGGL(k_pack_rows, dim3((tot + 255) / 256), dim3(256), 0, c->stream, P, N, out, ld);
   NH_CHECK_HIP(hipGetLastError());
@@ -75,7 +75,7 @@ extern "C" int nh_ew_binary(nh_ctx* c, int op, const nh_lazy* x, const nh_lazy* 
                             double* out) {
   NH_REQUIRE(c && x && y && out && N >= 0, "bad argument");
   if (N == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_PDIST);
+  nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_ew_binary, dim3((N + 255) / 256), dim3(256), 0, c->stream, op, *x, *y, N,
                      out);
   NH_CHECK_HIP(hipGetLastError());
@@ -106,7 +106,7 @@ extern "C" int nh_lincomb(nh_ctx* c, const nh_comp* comps, int ncomp, const doub
   comp_pack P;
   P.n = ncomp;
   for (int j = 0; j < ncomp; ++j) P.c[j] = comps[j];
-  nh_prof_scope ps(c, NH_K_LNPROB);
+  nh_prof_scope ps(c, NH_K_GLUE);
   long long tot = (long long)N * m;
   hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, P,
                      colfac, N, m, out, ldo);
@@ -151,7 +151,7 @@ extern "C" int nh_priors(nh_ctx* c, const nh_prior* terms, int nterms, int N, do
   prior_pack P;
   P.n = nterms;
   for (int j = 0; j < nterms; ++j) P.t[j] = terms[j];
-  nh_prof_scope ps(c, NH_K_LNPROB);
+  nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_priors, dim3((N + 255) / 256), dim3(256), 0, c->stream, P, N, lp);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
@@ -187,7 +187,7 @@ extern "C" int nh_move_propose(nh_ctx* c, const double* coords, const int* idx,
   NH_REQUIRE(c && coords && idx && rnd && qT && factors && ns >= 1 && ndim >= 1 && lo >= 0 &&
                  nloc >= 0 && lo + nloc <= ns, "bad argument");
   if (nloc == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   int tot = nloc * ndim;
   hipLaunchKernelGGL(k_move_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, coords,
                      idx, rnd, ns, ndim, lo, nloc, qT, factors);
@@ -225,7 +225,7 @@ extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const int
                               int* accepted, int* naccepted) {
   NH_REQUIRE(c && coords && logp && idx && rnd && newlp && accepted && ns >= 1 && ndim >= 1,
              "bad argument");
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_move_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, coords, logp,
                      idx, rnd, newlp, ns, ndim, accepted, naccepted);
   NH_CHECK_HIP(hipGetLastError());
@@ -248,7 +248,7 @@ extern "C" int nh_scatter_rows(nh_ctx* c, double* dst, int ldd, const double* sr
   NH_REQUIRE(c && dst && src && idx && nloc >= 0 && m >= 1 && ldd >= m && lds >= m,
              "bad argument");
   if (nloc == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_SAMPLER);
+  nh_prof_scope ps(c, NH_K_GLUE);
   long long tot = (long long)nloc * m;
   hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                      c->stream, dst, ldd, src, lds, idx, accepted, lo, nloc, m);

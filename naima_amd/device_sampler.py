@@ -75,6 +75,10 @@ class DeviceLoop:
         self.qT = ctx.empty((self.ndim * self.nloc,))
         self.factors = ctx.empty((self.nloc,))
         self.newlp = ctx.empty((self.ns,))
+        self.mylp = ctx.empty((max(self.nloc, 1),))
+        self.new_blobs = None
+        self.ident = ctx.array(np.arange(max(self.nloc, 1), dtype=np.int32), dtype=np.int32)
+        self.graph2 = None
         self.accepted = ctx.empty((self.ns,), dtype=np.int32)
         self.nacc = ctx.empty((self.N,), dtype=np.int32)
         ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
@@ -111,25 +115,52 @@ class DeviceLoop:
             return d, d.ptr, 1, unit, ()
         raise TypeError("blob of type %s cannot be kept on the device" % type(b).__name__)
 
-    def _half_step_body(self):
-        ctx, s = self.ctx, self.s
+    def _part_evaluate(self):
+        """propose this rank's block and evaluate it: everything up to the new
+        log-probabilities (the part that precedes the exchange)"""
+        ctx = self.ctx
         ctx.call("nh_move_propose", self.coords, self.idx, self.rnd, self.ns, self.ndim, self.lo,
                  self.nloc, self.qT, self.factors)
         total, blobs = self._eval(self.qT, self.nloc)
-        if s.comm.size > 1:
-            ctx.call("nh_comm_allgather", total.ptr, self.newlp, self.nloc)
-            newlp = self.newlp
+        if self.s.comm.size > 1:
+            # fixed hand-over buffer so that the two graphs and the collective between
+            # them always see the same addresses
+            ctx.call("nh_copy", self.mylp, total.ptr, 8 * self.nloc)
+            self._newlp_ptr = self.newlp.ptr
         else:
-            newlp = total.ptr
-        ctx.call("nh_move_accept", self.coords, self.logp, self.idx, self.rnd, newlp, self.ns,
-                 self.ndim, self.accepted, self.nacc)
-        if s.store_blobs and self.cur_blobs:
-            for (cur, m, _, _), b in zip(self.cur_blobs, blobs):
-                own, ptr, mb, _, _ = self._blob_dense(b)
-                ctx.call("nh_scatter_rows", cur, m, ptr, mb, self.idx, self.accepted, self.lo,
+            self._total = total  # single rank: the accept kernel reads it in place
+            self._newlp_ptr = total.ptr
+        self._stage_blobs(blobs)
+
+    def _stage_blobs(self, blobs):
+        """copy the proposal's blobs into fixed staging buffers (only when kept)"""
+        if not (self.s.store_blobs and self.cur_blobs):
+            return
+        if self.new_blobs is None:
+            self.new_blobs = [self.ctx.empty((self.nloc, m)) for _, m, _, _ in self.cur_blobs]
+        for nb, (cur, m, _, _), b in zip(self.new_blobs, self.cur_blobs, blobs):
+            own, ptr, mb, _, _ = self._blob_dense(b)
+            self.ctx.call("nh_scatter_rows", nb, m, ptr, mb, self.ident, None, 0, self.nloc, m)
+            del own
+
+    def _part_accept(self):
+        ctx = self.ctx
+        ctx.call("nh_move_accept", self.coords, self.logp, self.idx, self.rnd, self._newlp_ptr,
+                 self.ns, self.ndim, self.accepted, self.nacc)
+        if self.s.store_blobs and self.cur_blobs:
+            for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
+                ctx.call("nh_scatter_rows", cur, m, nb, m, self.idx, self.accepted, self.lo,
                          self.nloc, m)
-                del own
-        del total
+
+    def _exchange(self):
+        """the one collective of the path: every rank's new log-probabilities"""
+        if self.s.comm.size > 1:
+            self.s.comm.allgather_device(self.ctx, self.mylp.ptr, self.newlp, self.nloc)
+
+    def _half_step_body(self):
+        self._part_evaluate()
+        self._exchange()
+        self._part_accept()
 
     def _init_state(self, coords_host, logp_host):
         ctx, s = self.ctx, self.s
@@ -142,9 +173,13 @@ class DeviceLoop:
         qT = ctx.array(np.ascontiguousarray(coords_host[lo:hi].T))
         total, blobs = self._eval(qT, hi - lo)
         if s.comm.size > 1:
-            ctx.call("nh_comm_allgather", total.ptr, self.logp, hi - lo)
+            s.comm.allgather_device(ctx, total.ptr, self.logp, hi - lo)
         else:
             ctx.call("nh_copy", self.logp, total.ptr, 8 * self.N)
+        if s.store_blobs and blobs and s.comm.size > 1:
+            raise NotImplementedError(
+                "device=True keeps blobs only for a single rank (a walker's evaluating rank "
+                "changes every step); use store_blobs=False or the host loop when sharded")
         if s.store_blobs and blobs:
             self.cur_blobs, units = [], []
             ident = ctx.array(np.arange(lo, hi, dtype=np.int32), dtype=np.int32)
@@ -201,22 +236,7 @@ class DeviceLoop:
                 idx_h[:ns], idx_h[ns:] = S, Cidx[rint]
                 rnd_h[:ns], rnd_h[ns:] = zz, lnu
                 self.blk.set(blk_h)
-                if self.graph is not None:
-                    ctx.graph_launch(self.graph)
-                elif not s.use_graph or s.comm.size > 1 or self.warm < 1:
-                    # eager pass: also the warm-up that fills the static caches
-                    self._half_step_body()
-                    self.warm += 1
-                else:
-                    ctx.sync()
-                    ctx.graph_begin()
-                    try:
-                        self._half_step_body()
-                    except Exception:
-                        ctx.graph_abort()
-                        raise
-                    self.graph = ctx.graph_end()
-                    ctx.graph_launch(self.graph)
+                self._run_half_step()
             s.iteration += 1
             if block is not None:
                 k = block["n"]
@@ -227,6 +247,43 @@ class DeviceLoop:
                     ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
                 block["n"] = k + 1
             yield DeviceState(self, rng)
+
+    def _capture(self, fn):
+        ctx = self.ctx
+        ctx.sync()
+        ctx.graph_begin()
+        try:
+            fn()
+        except Exception:
+            ctx.graph_abort()
+            raise
+        return ctx.graph_end()
+
+    def _run_half_step(self):
+        """eager warm-up (fills the static caches), then capture, then replay.  One
+        graph on a single GPU; with walkers sharded over ranks the collective sits
+        between two graphs (evaluate | all-gather | accept)."""
+        s, ctx = self.s, self.ctx
+        multi = s.comm.size > 1
+        if self.graph is not None:
+            ctx.graph_launch(self.graph)
+            if multi:
+                self._exchange()
+                ctx.graph_launch(self.graph2)
+            return
+        if not s.use_graph or self.warm < 1:
+            self._half_step_body()
+            self.warm += 1
+            return
+        if not multi:
+            self.graph = self._capture(self._half_step_body)
+            ctx.graph_launch(self.graph)
+            return
+        self.graph = self._capture(self._part_evaluate)
+        ctx.graph_launch(self.graph)
+        self._exchange()
+        self.graph2 = self._capture(self._part_accept)
+        ctx.graph_launch(self.graph2)
 
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""

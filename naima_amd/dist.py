@@ -32,6 +32,11 @@ class LocalComm:
     def max(self, v):
         return float(v)
 
+    in_stream = True  # allgather_device enqueues on the context's stream
+
+    def allgather_device(self, ctx, send_ptr, recv, n):
+        ctx.call("nh_copy", recv, send_ptr, 8 * n)
+
 
 def shard_bounds(n, rank, size):
     """contiguous block [lo, hi) of n items owned by ``rank``; blocks differ by <= 1"""
@@ -79,6 +84,15 @@ class GlooComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    in_stream = False  # host-staged: synchronises the stream (tests only)
+
+    def allgather_device(self, ctx, send_ptr, recv, n):
+        host = np.empty(n)
+        from . import _lib
+        ctx.join()
+        _lib._chk(_lib._lib.nh_download(ctx.h, host.ctypes.data, send_ptr, host.nbytes))
+        recv.set(self.allgather(host))
+
 
 class RcclComm:
     """RCCL all-gather through the C ABI (nh_comm_allgather) on device buffers"""
@@ -110,6 +124,11 @@ class RcclComm:
         self._send.set(x.ravel())
         self.ctx.call("nh_comm_allgather", self._send, self._recv, n)
         return self._recv.get().reshape((self.size * x.shape[0],) + x.shape[1:])
+
+    in_stream = True  # RCCL on the context's stream: no host synchronisation
+
+    def allgather_device(self, ctx, send_ptr, recv, n):
+        ctx.call("nh_comm_allgather", send_ptr, recv, n)
 
     def barrier(self):
         self.ctx.sync()

@@ -1,0 +1,26 @@
+"""worker of tests/test_gpu_parity.py::test_device_loop_two_ranks_one_gpu"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["NAIMA_AMD_DEVICE"] = "0"  # both ranks share the one GPU of the test box
+import naima_amd as na  # noqa: E402
+from bench import build_problem  # noqa: E402
+from naima_amd.dist import GlooComm  # noqa: E402
+from naima_amd.sampler import EnsembleSampler  # noqa: E402
+
+out = sys.argv[1]
+comm = GlooComm()
+model, p0, raw, data, prior, labels = build_problem("cfg3", na)
+s = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, comm=comm,
+                    naima_style=True, store_blobs=False, device=True)
+pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, 5)))
+st = s.run_mcmc(pos, 6)
+np.save(os.path.join(out, "coords_%d.npy" % comm.rank), st.coords)
+np.save(os.path.join(out, "logp_%d.npy" % comm.rank), st.log_prob)
+np.save(os.path.join(out, "chain_%d.npy" % comm.rank), s.get_chain())
+assert s._dev.graph is not None and s._dev.graph2 is not None
+assert s.n_walker_evals < 32 * 7  # each rank evaluated only its shard

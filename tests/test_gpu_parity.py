@@ -436,3 +436,30 @@ def test_abi_move_kernels(na):
     ref = np.zeros((N, 4))
     ref[S[ok]] = src[ok]
     assert_allclose(dst.get(), ref)
+
+
+def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
+    """walker sharding of the device-resident loop with 2 processes (gloo stands in for
+    RCCL, which refuses two ranks on one GPU): split graphs around the exchange, same
+    ensemble on both ranks and equal to the single-process run"""
+    import subprocess
+    import sys
+    from naima_amd.sampler import EnsembleSampler
+    from bench import build_problem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() % 1000)
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.join(root, "tests", "gpu_two_ranks_worker.py"), str(tmp_path)],
+        cwd=root, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    c0, c1 = np.load(tmp_path / "coords_0.npy"), np.load(tmp_path / "coords_1.npy")
+    assert_allclose(c0, c1, rtol=1e-12)
+    model, p0, raw, data, prior, labels = build_problem("cfg3", na)
+    s = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                        store_blobs=False, device=True)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, 5)))
+    st = s.run_mcmc(pos, 6)
+    assert_allclose(c0, st.coords, rtol=1e-9)
+    assert_allclose(np.load(tmp_path / "logp_0.npy"), st.log_prob, rtol=1e-7)
+    assert_allclose(np.load(tmp_path / "chain_1.npy"), s.get_chain(), rtol=1e-9)
