@@ -77,6 +77,15 @@ int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes)
 int nh_download(nh_ctx* ctx, void* host_dst, const void* dev_src, long long bytes);
 int nh_memset(nh_ctx* ctx, void* dev, int byte, long long bytes);
 int nh_sync(nh_ctx* ctx);
+/* pinned host staging + markers: nh_upload from a pinned buffer is truly asynchronous, so
+ * the host can prepare half-step h+1 while the device runs h; a marker recorded after the
+ * upload tells the host when the pinned buffer may be overwritten */
+int nh_host_alloc(nh_ctx* ctx, long long bytes, void** host_out);
+int nh_host_free(nh_ctx* ctx, void* host);
+int nh_marker_create(nh_ctx* ctx, void** marker_out);
+int nh_marker_record(nh_ctx* ctx, void* marker);
+int nh_marker_wait(nh_ctx* ctx, void* marker);
+int nh_marker_destroy(nh_ctx* ctx, void* marker);
 /* HIP-event timing on the context's stream (used by bench.py for the roofline) */
 int nh_timer_start(nh_ctx* ctx);
 int nh_timer_stop(nh_ctx* ctx, double* elapsed_ms);
@@ -184,15 +193,6 @@ int nh_lnprobmodel(nh_ctx* ctx, const double* const* comps /*host array of dev p
                    const double* err_hi, const int* ul, const double* cl,
                    double* model_out, double* lnl);
 
-/* ---- ensemble move (emcee StretchMove; call sites core.py:128,450-457) --- */
-/* q[j] = c[r_j] - (c[r_j]-s[j])*z_j ; factors[j] = (ndim-1) ln z_j */
-int nh_stretch_propose(nh_ctx* ctx, const double* s, const double* c, const int* partner,
-                       const double* z, int ns, int ndim, double* q, double* factors);
-/* accept where ln u < factors + newlp - oldlp; updates s/oldlp in place, accepted[j] */
-int nh_stretch_accept(nh_ctx* ctx, double* s, double* oldlp, const double* q,
-                      const double* newlp, const double* factors, const double* lnu, int ns,
-                      int ndim, int* accepted);
-
 /* ---- device-resident step loop ------------------------------------------- */
 /* A lazy per-walker scalar: value[w] = a * tf(b * base[w*stride] + c); base NULL
  * means the constant a.  It lets the parameter transforms a naima model function
@@ -232,15 +232,19 @@ int nh_lnprob(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, int N, int 
               const nh_prior* terms /*host*/, int nterms,
               double* model_out /*[N][nE] or NULL*/, double* total);
 
-/* stretch move on a device-resident ensemble coords[N][ndim], logp[N].
- * idx[0:ns] = active walkers S, idx[ns:2ns] = partner of each (a walker of the
- * complementary half); rnd[0:ns] = z, rnd[ns:2ns] = ln U'.  propose writes the
- * block [lo, lo+nloc) of the proposals TRANSPOSED (qT[d][j]: pars[d] is a contiguous
- * vector over walkers); accept needs all ns new log-probabilities. */
-int nh_move_propose(nh_ctx* ctx, const double* coords, const int* idx, const double* rnd, int ns,
-                    int ndim, int lo, int nloc, double* qT, double* factors);
-int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const int* idx, const double* rnd,
-                   const double* newlp, int ns, int ndim, int* accepted, int* naccepted);
+/* stretch move on a device-resident ensemble coords[N][ndim], logp[N].  The host ships the
+ * random numbers of many half-steps as one block, slice h (stride 3*ns doubles) =
+ * { z[ns] | lnU'[ns] (float64) | S[ns] | partner[ns] (int32) }: S = active walkers,
+ * partner = each one's partner in the complementary half.  cursor[0] (device int) selects
+ * the slice; accept advances it (advance != 0), so a captured graph replays unchanged.
+ * propose writes the block [lo, lo+nloc) of the proposals TRANSPOSED (qT[d][j]: pars[d] is
+ * a contiguous vector over walkers); accept needs all ns new log-probabilities and
+ * optionally leaves the slice's S in sel[ns] for nh_scatter_rows. */
+int nh_move_propose(nh_ctx* ctx, const double* coords, const double* blk, const int* cursor,
+                    int ns, int ndim, int lo, int nloc, double* qT, double* factors);
+int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const double* blk, int* cursor,
+                   const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
+                   int* sel, int advance);
 /* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);

@@ -54,15 +54,19 @@ _SIGS = {
     "nh_table_pion_lut": [_dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _dp, _dp, _i],
     "nh_lnprobmodel": [_dp, C.POINTER(_dp), C.POINTER(_d), _i, _i, _i, _i, _dp, _dp, _dp, _dp,
                        _dp, _dp, _dp, _dp],
-    "nh_stretch_propose": [_dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
-    "nh_stretch_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp],
+    "nh_host_alloc": [_dp, _ll, C.POINTER(_dp)],
+    "nh_host_free": [_dp, _dp],
+    "nh_marker_create": [_dp, C.POINTER(_dp)],
+    "nh_marker_record": [_dp, _dp],
+    "nh_marker_wait": [_dp, _dp],
+    "nh_marker_destroy": [_dp, _dp],
     "nh_pack_rows": [_dp, _dp, _i, _i, _dp, _i],
     "nh_ew_binary": [_dp, _i, _dp, _dp, _i, _dp],
     "nh_lincomb": [_dp, _dp, _i, _dp, _i, _i, _dp, _i],
     "nh_priors": [_dp, _dp, _i, _i, _dp],
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
-    "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp],
+    "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
     "nh_copy": [_dp, _dp, _dp, _ll],
     "nh_stream_fork": [_dp, _i],
@@ -303,6 +307,18 @@ class Context:
 
     def graph_launch(self, g):
         _chk(_lib.nh_graph_launch(self.h, g))
+
+    def pinned(self, nbytes):
+        """(numpy uint8 view, address) of a page-locked host buffer"""
+        p = _dp()
+        _chk(_lib.nh_host_alloc(self.h, int(nbytes), C.byref(p)))
+        buf = (C.c_ubyte * int(nbytes)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8), p.value
+
+    def marker(self):
+        m = _dp()
+        _chk(_lib.nh_marker_create(self.h, C.byref(m)))
+        return m
 
     def sync(self):
         self.join()

@@ -756,59 +756,44 @@ extern "C" int nh_lnprob(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int 
 }
 
 // ---------------------------------------------------------------------------
-// stretch move (emcee StretchMove.get_proposal / RedBlueMove accept step)
+// pinned host staging: lets the host run ahead of the device (the random block of
+// half-step h+1 is drawn and shipped while the graph of half-step h executes)
 // ---------------------------------------------------------------------------
-__global__ void k_stretch_propose(const double* __restrict__ s, const double* __restrict__ cset,
-                                  const int* __restrict__ partner, const double* __restrict__ z,
-                                  int ns, int ndim, double* __restrict__ q,
-                                  double* __restrict__ factors) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ns * ndim) return;
-  int j = idx / ndim, d = idx % ndim;
-  double cj = cset[(long long)partner[j] * ndim + d];
-  q[idx] = cj - (cj - s[idx]) * z[j];
-  if (d == 0) factors[j] = (ndim - 1.0) * log(z[j]);
-}
-
-extern "C" int nh_stretch_propose(nh_ctx* c, const double* s, const double* cset,
-                                  const int* partner, const double* z, int ns, int ndim,
-                                  double* q, double* factors) {
-  NH_REQUIRE(c && s && cset && partner && z && q && factors && ns >= 0 && ndim >= 1,
-             "bad argument");
-  if (ns == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_GLUE);
-  int tot = ns * ndim;
-  hipLaunchKernelGGL(k_stretch_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, s,
-                     cset, partner, z, ns, ndim, q, factors);
-  NH_CHECK_HIP(hipGetLastError());
+extern "C" int nh_host_alloc(nh_ctx* c, long long bytes, void** out) {
+  NH_REQUIRE(c && out && bytes > 0, "bad argument");
+  NH_CHECK_HIP(hipSetDevice(c->device));
+  NH_CHECK_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
   return NH_OK;
 }
 
-__global__ void k_stretch_accept(double* __restrict__ s, double* __restrict__ oldlp,
-                                 const double* __restrict__ q, const double* __restrict__ newlp,
-                                 const double* __restrict__ factors,
-                                 const double* __restrict__ lnu, int ns, int ndim,
-                                 int* __restrict__ accepted) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ns) return;
-  double d = factors[j] + newlp[j] - oldlp[j];
-  bool acc = lnu[j] < d;  // NaN -> rejected, as numpy's comparison
-  if (acc) {
-    for (int k = 0; k < ndim; ++k) s[(long long)j * ndim + k] = q[(long long)j * ndim + k];
-    oldlp[j] = newlp[j];
-  }
-  accepted[j] = acc ? 1 : 0;
+extern "C" int nh_host_free(nh_ctx* c, void* p) {
+  NH_REQUIRE(c, "ctx is NULL");
+  if (p) NH_CHECK_HIP(hipHostFree(p));
+  return NH_OK;
 }
 
-extern "C" int nh_stretch_accept(nh_ctx* c, double* s, double* oldlp, const double* q,
-                                 const double* newlp, const double* factors, const double* lnu,
-                                 int ns, int ndim, int* accepted) {
-  NH_REQUIRE(c && s && oldlp && q && newlp && factors && lnu && accepted && ns >= 0 && ndim >= 1,
-             "bad argument");
-  if (ns == 0) return NH_OK;
-  nh_prof_scope ps(c, NH_K_GLUE);
-  hipLaunchKernelGGL(k_stretch_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, s, oldlp,
-                     q, newlp, factors, lnu, ns, ndim, accepted);
-  NH_CHECK_HIP(hipGetLastError());
+extern "C" int nh_marker_create(nh_ctx* c, void** out) {
+  NH_REQUIRE(c && out, "bad argument");
+  hipEvent_t e;
+  NH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *out = e;
+  return NH_OK;
+}
+
+extern "C" int nh_marker_record(nh_ctx* c, void* m) {
+  NH_REQUIRE(c && m, "bad argument");
+  NH_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(m), c->stream));
+  return NH_OK;
+}
+
+extern "C" int nh_marker_wait(nh_ctx* c, void* m) {  // host blocks until the marker is reached
+  NH_REQUIRE(c && m, "bad argument");
+  NH_CHECK_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(m)));
+  return NH_OK;
+}
+
+extern "C" int nh_marker_destroy(nh_ctx* c, void* m) {
+  NH_REQUIRE(c, "ctx is NULL");
+  if (m) NH_CHECK_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(m)));
   return NH_OK;
 }

@@ -159,75 +159,93 @@ extern "C" int nh_priors(nh_ctx* c, const nh_prior* terms, int nterms, int N, do
 
 // ---------------------------------------------------------------------------
 // device-resident stretch move.  The host draws the random numbers (replicated
-// stream) and ships them as ONE block per half-step:
-//   rnd[0:ns]      = z            stretch factors
-//   rnd[ns:2ns]    = ln U'        accept thresholds
-//   idx[0:ns]      = S            global indices of the active walkers
-//   idx[ns:2ns]    = partner      global index of each walker's partner in C
+// stream) for MANY half-steps at once and ships them as one block
+//   blk[h] = { z[ns] | lnU[ns] (float64) | S[ns] | partner[ns] (int32) },  h < nhalf
+// (stride 3*ns doubles).  A device-side cursor says which slice the current
+// half-step uses; k_move_accept advances it, so that a captured graph can be
+// replayed for every half-step of the block without touching its arguments.
+//   S        global indices of the active walkers
+//   partner  global index of each active walker's partner in the other half
 // ---------------------------------------------------------------------------
-__global__ void k_move_propose(const double* __restrict__ coords, const int* __restrict__ idx,
-                               const double* __restrict__ rnd, int ns, int ndim, int lo, int nloc,
+struct move_slice { const double* rnd; const int* idx; };
+
+__device__ __forceinline__ move_slice move_get(const double* blk, const int* cursor, int ns) {
+  const double* r = blk + (long long)cursor[0] * 3 * ns;
+  return {r, reinterpret_cast<const int*>(r + 2 * ns)};
+}
+
+__global__ void k_move_propose(const double* __restrict__ coords, const double* __restrict__ blk,
+                               const int* __restrict__ cursor, int ns, int ndim, int lo, int nloc,
                                double* __restrict__ qT, double* __restrict__ factors) {
   // proposals of this rank's block [lo, lo+nloc) of the active half, TRANSPOSED:
   // qT[d][j] so that pars[d] is a contiguous vector over walkers
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nloc * ndim) return;
+  const move_slice m = move_get(blk, cursor, ns);
   int d = t / nloc, j = t % nloc;
   int g = lo + j;
-  double z = rnd[g];
-  double cj = coords[(long long)idx[ns + g] * ndim + d];
-  double sj = coords[(long long)idx[g] * ndim + d];
+  double z = m.rnd[g];
+  double cj = coords[(long long)m.idx[ns + g] * ndim + d];
+  double sj = coords[(long long)m.idx[g] * ndim + d];
   qT[(long long)d * nloc + j] = cj - (cj - sj) * z;
   if (d == 0) factors[j] = (ndim - 1.0) * log(z);
 }
 
-extern "C" int nh_move_propose(nh_ctx* c, const double* coords, const int* idx,
-                               const double* rnd, int ns, int ndim, int lo, int nloc, double* qT,
+extern "C" int nh_move_propose(nh_ctx* c, const double* coords, const double* blk,
+                               const int* cursor, int ns, int ndim, int lo, int nloc, double* qT,
                                double* factors) {
-  NH_REQUIRE(c && coords && idx && rnd && qT && factors && ns >= 1 && ndim >= 1 && lo >= 0 &&
+  NH_REQUIRE(c && coords && blk && cursor && qT && factors && ns >= 1 && ndim >= 1 && lo >= 0 &&
                  nloc >= 0 && lo + nloc <= ns, "bad argument");
   if (nloc == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_GLUE);
   int tot = nloc * ndim;
   hipLaunchKernelGGL(k_move_propose, dim3((tot + 255) / 256), dim3(256), 0, c->stream, coords,
-                     idx, rnd, ns, ndim, lo, nloc, qT, factors);
+                     blk, cursor, ns, ndim, lo, nloc, qT, factors);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
 
 __global__ void k_move_accept(double* __restrict__ coords, double* __restrict__ logp,
-                              const int* __restrict__ idx, const double* __restrict__ rnd,
+                              const double* __restrict__ blk, int* __restrict__ cursor,
                               const double* __restrict__ newlp, int ns, int ndim,
-                              int* __restrict__ accepted, int* __restrict__ naccepted) {
+                              int* __restrict__ accepted, int* __restrict__ naccepted,
+                              int* __restrict__ sel, int advance) {
   // every rank holds the full ensemble and all ns new log-probabilities: the
   // proposal is recomputed here from (coords, z, partner) so that no coordinates
-  // ever have to be exchanged between ranks
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ns) return;
-  int me = idx[j], pa = idx[ns + j];
-  double z = rnd[j];
-  double d = (ndim - 1.0) * log(z) + newlp[j] - logp[me];
-  bool acc = rnd[ns + j] < d;  // NaN compares false, as numpy
-  if (acc) {
-    for (int k = 0; k < ndim; ++k) {
-      double cj = coords[(long long)pa * ndim + k];
-      double sj = coords[(long long)me * ndim + k];
-      coords[(long long)me * ndim + k] = cj - (cj - sj) * z;
+  // ever have to be exchanged between ranks.  Single block (ns <= 1024 per pass).
+  const move_slice m = move_get(blk, cursor, ns);
+  for (int j = threadIdx.x; j < ns; j += blockDim.x) {
+    int me = m.idx[j], pa = m.idx[ns + j];
+    double z = m.rnd[j];
+    double d = (ndim - 1.0) * log(z) + newlp[j] - logp[me];
+    bool acc = m.rnd[ns + j] < d;  // NaN compares false, as numpy
+    if (acc) {
+      for (int k = 0; k < ndim; ++k) {
+        double cj = coords[(long long)pa * ndim + k];
+        double sj = coords[(long long)me * ndim + k];
+        coords[(long long)me * ndim + k] = cj - (cj - sj) * z;
+      }
+      logp[me] = newlp[j];
+      if (naccepted) atomicAdd(&naccepted[me], 1);
     }
-    logp[me] = newlp[j];
-    if (naccepted) atomicAdd(&naccepted[me], 1);
+    accepted[j] = acc ? 1 : 0;
+    if (sel) sel[j] = me;  // the slice's active walkers, for the blob scatter that follows
   }
-  accepted[j] = acc ? 1 : 0;
+  __syncthreads();
+  if (advance && threadIdx.x == 0) cursor[0] += 1;
 }
 
-extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const int* idx,
-                              const double* rnd, const double* newlp, int ns, int ndim,
-                              int* accepted, int* naccepted) {
-  NH_REQUIRE(c && coords && logp && idx && rnd && newlp && accepted && ns >= 1 && ndim >= 1,
+extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const double* blk,
+                              int* cursor, const double* newlp, int ns, int ndim, int* accepted,
+                              int* naccepted, int* sel, int advance) {
+  NH_REQUIRE(c && coords && logp && blk && cursor && newlp && accepted && ns >= 1 && ndim >= 1,
              "bad argument");
   nh_prof_scope ps(c, NH_K_GLUE);
-  hipLaunchKernelGGL(k_move_accept, dim3((ns + 255) / 256), dim3(256), 0, c->stream, coords, logp,
-                     idx, rnd, newlp, ns, ndim, accepted, naccepted);
+  // one block: the partner rows it reads are never rows it writes (partners are in the
+  // complementary half), so no ordering between threads is needed; the cursor is
+  // advanced after the barrier
+  hipLaunchKernelGGL(k_move_accept, dim3(1), dim3(1024), 0, c->stream, coords, logp, blk, cursor,
+                     newlp, ns, ndim, accepted, naccepted, sel, advance);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

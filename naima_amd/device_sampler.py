@@ -68,10 +68,12 @@ class DeviceLoop:
         ctx = self.ctx
         self.coords = ctx.empty((self.N * self.ndim,))
         self.logp = ctx.empty((self.N,))
-        # ONE host->device block per half-step: rnd[2 ns] float64 | idx[2 ns] int32
-        self.blk = ctx.empty((3 * self.ns,))
-        self.rnd = self.blk.ptr
-        self.idx = self.blk.ptr + 16 * self.ns
+        # the random numbers of up to KSTEPS ensemble steps travel as ONE block; a device
+        # cursor selects the current half-step's slice (advanced by the accept kernel)
+        self.KSTEPS = 32
+        self.blk = ctx.empty((2 * self.KSTEPS, 3 * self.ns))
+        self.cursor = ctx.empty((1,), dtype=np.int32)
+        self.sel = ctx.empty((self.ns,), dtype=np.int32)
         self.qT = ctx.empty((self.ndim * self.nloc,))
         self.factors = ctx.empty((self.nloc,))
         self.newlp = ctx.empty((self.ns,))
@@ -79,6 +81,7 @@ class DeviceLoop:
         self.new_blobs = None
         self.ident = ctx.array(np.arange(max(self.nloc, 1), dtype=np.int32), dtype=np.int32)
         self.graph2 = None
+        self.step_graph = None
         self.accepted = ctx.empty((self.ns,), dtype=np.int32)
         self.nacc = ctx.empty((self.N,), dtype=np.int32)
         ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
@@ -119,8 +122,8 @@ class DeviceLoop:
         """propose this rank's block and evaluate it: everything up to the new
         log-probabilities (the part that precedes the exchange)"""
         ctx = self.ctx
-        ctx.call("nh_move_propose", self.coords, self.idx, self.rnd, self.ns, self.ndim, self.lo,
-                 self.nloc, self.qT, self.factors)
+        ctx.call("nh_move_propose", self.coords, self.blk, self.cursor, self.ns, self.ndim,
+                 self.lo, self.nloc, self.qT, self.factors)
         total, blobs = self._eval(self.qT, self.nloc)
         if self.s.comm.size > 1:
             # fixed hand-over buffer so that the two graphs and the collective between
@@ -145,11 +148,11 @@ class DeviceLoop:
 
     def _part_accept(self):
         ctx = self.ctx
-        ctx.call("nh_move_accept", self.coords, self.logp, self.idx, self.rnd, self._newlp_ptr,
-                 self.ns, self.ndim, self.accepted, self.nacc)
+        ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor, self._newlp_ptr,
+                 self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
         if self.s.store_blobs and self.cur_blobs:
             for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
-                ctx.call("nh_scatter_rows", cur, m, nb, m, self.idx, self.accepted, self.lo,
+                ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
                          self.nloc, m)
 
     def _exchange(self):
@@ -221,32 +224,51 @@ class DeviceLoop:
                          blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
                                 (self.cur_blobs or [])] if s.store_blobs else [])
             self.hist.append(block)
-        blk_h = np.empty(3 * ns)
-        rnd_h = blk_h[:2 * ns]
-        idx_h = blk_h[2 * ns:].view(np.int32)
-        for it in range(iterations):
-            inds = np.arange(N) % 2
-            rng.shuffle(inds)
-            for split in range(2):
-                S = np.nonzero(inds == split)[0]
-                Cidx = np.nonzero(inds != split)[0]
-                zz = ((a - 1.0) * rng.random(ns) + 1) ** 2.0 / a
-                rint = rng.integers(len(Cidx), size=ns)
-                lnu = np.log(rng.random(ns))
-                idx_h[:ns], idx_h[ns:] = S, Cidx[rint]
-                rnd_h[:ns], rnd_h[ns:] = zz, lnu
-                self.blk.set(blk_h)
-                self._run_half_step()
-            s.iteration += 1
-            if block is not None:
-                k = block["n"]
-                ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim, self.coords,
-                         8 * N * self.ndim)
-                ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
-                for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
-                    ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
-                block["n"] = k + 1
-            yield DeviceState(self, rng)
+        from .sampler import draw_moves
+        ring = self._ring()
+        nblk = 0
+        it = 0
+        while it < iterations:
+            K = min(self.KSTEPS, iterations - it)
+            # ---- draw and ship the moves of the next K steps (one upload) ----------
+            raw, addr, mark, used = ring[nblk % len(ring)]
+            if used[0]:
+                ctx.call("nh_marker_wait", mark)  # its previous upload has long finished
+            Sm, Pm, Zm, Lm = draw_moves(rng, N, K, a)
+            f = raw[:2 * K * 3 * ns].reshape(2 * K, 3 * ns)
+            f[:, :ns] = Zm.reshape(2 * K, ns)
+            f[:, ns:2 * ns] = Lm.reshape(2 * K, ns)
+            iv = f[:, 2 * ns:].view(np.int32)
+            iv[:, :ns] = Sm.reshape(2 * K, ns)
+            iv[:, ns:] = Pm.reshape(2 * K, ns)
+            ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
+            ctx.call("nh_memset", self.cursor, 0, 4)
+            ctx.call("nh_marker_record", mark)
+            used[0] = True
+            nblk += 1
+            for _k in range(K):
+                self._run_step()
+                it += 1
+                s.iteration += 1
+                if block is not None:
+                    k = block["n"]
+                    ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim, self.coords,
+                             8 * N * self.ndim)
+                    ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
+                    for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
+                        ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
+                    block["n"] = k + 1
+                yield DeviceState(self, rng)
+
+    def _ring(self, depth=3):
+        """page-locked staging blocks for the random numbers of KSTEPS steps: uploads
+        from them are asynchronous, so the host draws block b+1 while the device runs b"""
+        if getattr(self, "_ring_bufs", None) is None:
+            self._ring_bufs = []
+            for _ in range(depth):
+                raw, addr = self.ctx.pinned(8 * 2 * self.KSTEPS * 3 * self.ns)
+                self._ring_bufs.append((raw.view(np.float64), addr, self.ctx.marker(), [False]))
+        return self._ring_bufs
 
     def _capture(self, fn):
         ctx = self.ctx
@@ -258,6 +280,31 @@ class DeviceLoop:
             ctx.graph_abort()
             raise
         return ctx.graph_end()
+
+    def _run_step(self):
+        """one ensemble step = two half-steps.  Single GPU: after the eager warm-up and
+        the per-half-step capture check, BOTH half-steps are one graph (the cursor
+        advances inside it), i.e. one host call per step."""
+        s, ctx = self.s, self.ctx
+        if s.comm.size > 1 or not s.use_graph:
+            self._run_half_step()
+            self._run_half_step()
+            return
+        if self.step_graph is not None:
+            ctx.graph_launch(self.step_graph)
+            return
+        if self.warm < 1:
+            self._half_step_body()
+            self.warm += 1
+            self._half_step_body()
+            return
+
+        def two():
+            self._half_step_body()
+            self._half_step_body()
+
+        self.step_graph = self.graph = self._capture(two)
+        ctx.graph_launch(self.step_graph)
 
     def _run_half_step(self):
         """eager warm-up (fills the static caches), then capture, then replay.  One

@@ -38,6 +38,32 @@ class State:
         return iter((self.coords, self.log_prob, self.random_state))
 
 
+def draw_moves(rng, N, nsteps, a=2.0):
+    """The random numbers of ``nsteps`` ensemble steps (two half-steps each), drawn in a
+    fixed order per step -- one permutation (the red/blue split), one uniform block -- so the
+    stream does not depend on how many steps are drawn at once (the host-driven and the
+    device-resident loops, and every rank of a sharded run, see the same moves).
+
+    Returns S, P (int32 [nsteps, 2, N/2]: active walkers and each one's partner in the
+    complementary half), Z (stretch factors), L (ln U' accept thresholds)."""
+    ns = N // 2
+    S = np.empty((nsteps, 2, ns), dtype=np.int32)
+    R = np.empty((nsteps, 2, ns), dtype=np.int64)
+    U = np.empty((nsteps, 3, 2, ns))
+    for k in range(nsteps):
+        # a random balanced split of the ensemble: first / second half of a permutation
+        S[k] = rng.permutation(N).reshape(2, ns)
+        rng.random(out=U[k])
+    Z = ((a - 1.0) * U[:, 0] + 1) ** 2.0 / a
+    np.multiply(U[:, 1], ns, out=U[:, 1])
+    R[:] = U[:, 1]  # partner index within the complementary half
+    P = np.empty_like(S)
+    P[:, 0] = np.take_along_axis(S[:, 1], R[:, 0], axis=1)
+    P[:, 1] = np.take_along_axis(S[:, 0], R[:, 1], axis=1)
+    L = np.log(U[:, 2])
+    return S, P, Z, L
+
+
 def _split_blob(b):
     """a blob returned by the model -> (ndarray with leading walker axis, unit or None)"""
     if isinstance(b, u.Quantity):
@@ -195,20 +221,15 @@ class EnsembleSampler:
                 self._cur_blobs, self._own = [], np.arange(0)
         logp = logp.copy()
         for _ in range(int(iterations)):
-            inds = np.arange(N) % 2
-            rng.shuffle(inds)
+            Sm, Pm, Zm, Lm = draw_moves(rng, N, 1, a)
             for split in range(2):
-                S = np.nonzero(inds == split)[0]
-                Cidx = np.nonzero(inds != split)[0]
-                s, c = coords[S], coords[Cidx]
-                Ns, Nc = len(S), len(Cidx)
-                zz = ((a - 1.0) * rng.random(Ns) + 1) ** 2.0 / a
+                S, zz = Sm[0, split], Zm[0, split]
+                s, cp = coords[S], coords[Pm[0, split]]
                 factors = (ndim - 1.0) * np.log(zz)
-                rint = rng.integers(Nc, size=Ns)
-                q = c[rint] - (c[rint] - s) * zz[:, None]
+                q = cp - (cp - s) * zz[:, None]
                 newlp, blobs, (lo, hi) = self.compute_log_prob(q)
                 lnpdiff = factors + newlp - logp[S]
-                accepted = np.log(rng.random(Ns)) < lnpdiff
+                accepted = Lm[0, split] < lnpdiff
                 acc_idx = S[accepted]
                 coords[acc_idx] = q[accepted]
                 logp[acc_idx] = newlp[accepted]

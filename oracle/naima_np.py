@@ -670,24 +670,27 @@ def stretch_move_reference(coords, logp, lnprob_fn, rng, a=2.0):
     """One emcee-3 ``StretchMove`` step restated from its published algorithm
     (Goodman & Weare 2010; emcee.moves.RedBlueMove.propose + StretchMove.
     get_proposal).  Call sites in the reference: core.py:128, 450-457.
-    lnprob_fn maps (n, ndim) -> (n,).  Returns (coords, logp, accepted)."""
+    lnprob_fn maps (n, ndim) -> (n,).  Returns (coords, logp, accepted).
+
+    Random-number protocol (this build's; emcee's own draw order is not part of any
+    contract): per step one permutation whose halves are the two sets, then ONE
+    uniform block u[3][2][n/2]: u[0] -> z = ((a-1)u+1)^2/a, u[1] -> partner =
+    floor(u n/2), u[2] -> accept if ln u < (ndim-1) ln z + lnp(q) - lnp(s)."""
     nwalkers, ndim = coords.shape
+    ns = nwalkers // 2
     coords, logp = coords.copy(), logp.copy()
     accepted = np.zeros(nwalkers, dtype=bool)
-    inds = np.arange(nwalkers) % 2
-    rng.shuffle(inds)
+    halves = rng.permutation(nwalkers).reshape(2, ns)
+    u = rng.random((3, 2, ns))
     for split in range(2):
-        S = inds == split
-        s, c = coords[S], coords[~S]
-        Ns, Nc = len(s), len(c)
-        zz = ((a - 1.0) * rng.random(Ns) + 1) ** 2.0 / a
-        factors = (ndim - 1.0) * np.log(zz)
-        rint = rng.integers(Nc, size=Ns)
-        q = c[rint] - (c[rint] - s) * zz[:, None]
+        S, C = halves[split], halves[1 - split]
+        zz = ((a - 1.0) * u[0, split] + 1) ** 2.0 / a
+        partner = C[(u[1, split] * ns).astype(int)]
+        q = coords[partner] - (coords[partner] - coords[S]) * zz[:, None]
         newlp = lnprob_fn(q)
-        lnpdiff = factors + newlp - logp[S]
-        acc = np.log(rng.random(Ns)) < lnpdiff
-        idx = np.nonzero(S)[0][acc]
+        lnpdiff = (ndim - 1.0) * np.log(zz) + newlp - logp[S]
+        acc = np.log(u[2, split]) < lnpdiff
+        idx = S[acc]
         coords[idx] = q[acc]
         logp[idx] = newlp[acc]
         accepted[idx] = True

@@ -398,7 +398,8 @@ def test_rccl_single_rank_allgather(na):
 
 
 def test_abi_move_kernels(na):
-    """nh_move_propose / nh_move_accept / nh_scatter_rows against their NumPy twins"""
+    """nh_move_propose / nh_move_accept / nh_scatter_rows against their NumPy twins, on
+    the second slice of a two-half-step block (cursor = 1)"""
     from naima_amd._lib import get_context
     ctx = get_context()
     rng = np.random.default_rng(3)
@@ -410,29 +411,36 @@ def test_abi_move_kernels(na):
     partner = Cset[rng.integers(ns, size=ns)]
     z = ((2 - 1.0) * rng.random(ns) + 1) ** 2 / 2
     lnu = np.log(rng.random(ns))
-    idx = ctx.array(np.concatenate([S, partner]).astype(np.int32), dtype=np.int32)
-    rnd = ctx.array(np.concatenate([z, lnu]))
+    blk_h = np.zeros((2, 3 * ns))
+    blk_h[1, :ns], blk_h[1, ns:2 * ns] = z, lnu
+    iv = blk_h[:, 2 * ns:].view(np.int32)
+    iv[1, :ns], iv[1, ns:] = S, partner
+    blk = ctx.array(blk_h)
+    cursor = ctx.array(np.array([1], dtype=np.int32), dtype=np.int32)
     cd, ld = ctx.array(coords.ravel()), ctx.array(logp)
     qT, fac = ctx.empty((ndim * ns,)), ctx.empty((ns,))
-    ctx.call("nh_move_propose", cd, idx, rnd, ns, ndim, 0, ns, qT, fac)
+    ctx.call("nh_move_propose", cd, blk, cursor, ns, ndim, 0, ns, qT, fac)
     q = coords[partner] - (coords[partner] - coords[S]) * z[:, None]
     # the device contracts c - (c - s) z into an fma: last-bit differences
     assert_allclose(qT.get().reshape(ndim, ns).T, q, rtol=1e-13, atol=1e-15)
     assert_allclose(fac.get(), (ndim - 1) * np.log(z), rtol=1e-15)
     newlp = rng.normal(size=ns)
     acc = ctx.empty((ns,), dtype=np.int32)
+    sel = ctx.empty((ns,), dtype=np.int32)
     nacc = ctx.array(np.zeros(N, dtype=np.int32), dtype=np.int32)
-    ctx.call("nh_move_accept", cd, ld, idx, rnd, ctx.array(newlp), ns, ndim, acc, nacc)
+    ctx.call("nh_move_accept", cd, ld, blk, cursor, ctx.array(newlp), ns, ndim, acc, nacc, sel, 1)
     ok = lnu < (ndim - 1) * np.log(z) + newlp - logp[S]
     ref_c, ref_l = coords.copy(), logp.copy()
     ref_c[S[ok]], ref_l[S[ok]] = q[ok], newlp[ok]
     assert_allclose(acc.get(), ok.astype(int))
+    assert_allclose(sel.get(), S)
+    assert cursor.get()[0] == 2
     assert_allclose(cd.get().reshape(N, ndim), ref_c, rtol=1e-13, atol=1e-15)
     assert_allclose(ld.get(), ref_l)
     assert nacc.get().sum() == ok.sum()
     dst = ctx.array(np.zeros((N, 4)))
     src = rng.normal(size=(ns, 4))
-    ctx.call("nh_scatter_rows", dst, 4, ctx.array(src), 4, idx, acc, 0, ns, 4)
+    ctx.call("nh_scatter_rows", dst, 4, ctx.array(src), 4, sel, acc, 0, ns, 4)
     ref = np.zeros((N, 4))
     ref[S[ok]] = src[ok]
     assert_allclose(dst.get(), ref)
