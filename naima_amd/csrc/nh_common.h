@@ -50,7 +50,12 @@ struct nh_ctx {
   long long acc_n[NH_K_COUNT];
   void* comm;      // ncclComm_t
   void* rccl_lib;  // dlopen handle
+  void* scratch;   // library-owned device scratch (grown outside graph capture)
+  size_t scratch_bytes;
 };
+
+// device scratch of at least `bytes`; contents are only valid within one entry point
+int nh_scratch(nh_ctx* c, size_t bytes, void** out);
 
 int nh_set_error(int code, const char* fmt, ...);
 

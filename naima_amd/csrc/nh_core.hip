@@ -29,6 +29,8 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   c->profiling = false;
   c->comm = nullptr;
   c->rccl_lib = nullptr;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
   memset(c->acc_ms, 0, sizeof(c->acc_ms));
   memset(c->acc_n, 0, sizeof(c->acc_n));
   NH_CHECK_HIP(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
@@ -56,12 +58,34 @@ extern "C" int nh_destroy(nh_ctx* c) {
     (void)hipEventDestroy(c->ev_side[i]);
   }
   (void)hipEventDestroy(c->ev_fork);
+  if (c->scratch) (void)hipFree(c->scratch);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : c->pool) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->t0);
   (void)hipEventDestroy(c->t1);
   (void)hipStreamDestroy(c->main_stream);
   delete c;
+  return NH_OK;
+}
+
+int nh_scratch(nh_ctx* c, size_t bytes, void** out) {
+  if (bytes > c->scratch_bytes) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->main_stream, &st);
+    if (st != hipStreamCaptureStatusNone)
+      return nh_set_error(NH_ENOMEM, "scratch must grow to %zu B during graph capture: run the "
+                          "same call once eagerly first", bytes);
+    NH_CHECK_HIP(hipStreamSynchronize(c->main_stream));
+    if (c->scratch) NH_CHECK_HIP(hipFree(c->scratch));
+    size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&c->scratch, want);
+    if (e != hipSuccess) {
+      c->scratch = nullptr; c->scratch_bytes = 0;
+      return nh_set_error(NH_ENOMEM, "hipMalloc(%zu) for scratch: %s", want, hipGetErrorString(e));
+    }
+    c->scratch_bytes = want;
+  }
+  *out = c->scratch;
   return NH_OK;
 }
 

@@ -150,52 +150,120 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
   return table_dlog(c, Kt, nG, nE, ld, lnKt);
 }
 
-// SSC: the seed density depends on the walker, so the (n_s x n_E x n_gam) double
-// reduction is done per walker.  Lanes over (walker,k) pairs, waves over gamma
-// chunks, inner sequential loop over the seed energies.
-template <int C>
+// ---------------------------------------------------------------------------
+// SSC: the seed density depends on the walker (examples/CrabNebula_SynSSC.py:29-31), so
+// the (n_s x n_E x n_gam) double reduction of radiative.py:609-655 + 684 cannot be
+// tabulated.  What CAN be shared is the Aharonian-Atoyan kernel fic(eps0_s, gamma_i,
+// E_k): it does not depend on the walker.  One wave = 64 photon energies (lanes) x W
+// walkers (register-blocked) x one chunk of gamma; per (s, i, k) the kernel and the
+// log-ratio ln|fic_{s+1}/fic_s| are evaluated ONCE and applied to the W walkers, whose
+// seed densities n_w(eps0_s) (pre-scaled) and log-ratios are wave-uniform scalars.
+// The gamma range is additionally split over gridDim.y; the partial sums are reduced
+// deterministically by k_ssc_finish.
+// ---------------------------------------------------------------------------
+__global__ void k_ssc_prep(const double* __restrict__ se, const double* __restrict__ sd, int N,
+                           int ns, double* __restrict__ e0, double* __restrict__ lxs,
+                           double* __restrict__ sdm, double* __restrict__ dlnd) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < ns) {
+    e0[idx] = se[idx] / NH_MEC2_EV;
+    if (idx + 1 < ns) lxs[idx] = log(se[idx + 1] / se[idx]);
+  }
+  if (idx >= (long long)N * ns) return;
+  int s = (int)(idx % ns);
+  double d = sd[idx] * NH_MEC2_EV;  // 1/(eV cm3) -> 1/(mec2 cm3), radiative.py:639
+  sdm[idx] = d;
+  dlnd[idx] = (s + 1 < ns) ? log(fabs(sd[idx + 1] / sd[idx])) : 0.0;
+}
+
+template <int C, int W>
 __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, const double* __restrict__ se,
-    const double* __restrict__ sd, int ns, double* __restrict__ out, int ldo) {
-  __shared__ double part[C][64];
-  const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
-  const long long pair = (long long)blockIdx.x * 64 + lane;
-  const bool valid = pair < (long long)N * nE;
-  const int wi = valid ? (int)(pair / nE) : 0;
-  const int k = valid ? (int)(pair % nE) : 0;
-  const double E = E_eV[k];
-  const double eg = E / NH_MEC2_EV;
-  const double* sdw = sd + (long long)wi * ns;
+    const double* __restrict__ E_eV, int nE, const double* __restrict__ e0,
+    const double* __restrict__ lxs, const double* __restrict__ sdm,
+    const double* __restrict__ dlnd, int ns, double* __restrict__ partial) {
+  __shared__ double part[C][W][64];
+  const int lane = threadIdx.x & 63;
+  const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ktiles = (nE + 63) >> 6;
+  const int tile = blockIdx.x % ktiles, grp = blockIdx.x / ktiles;
+  const int k = tile * 64 + lane;
+  const bool kvalid = k < nE;
+  const double eg = E_eV[kvalid ? k : nE - 1] / NH_MEC2_EV;
+  const int w0 = grp * W;
+  // this block's share of the segments: gridDim.y super-chunks, C chunks each
   const int nseg = nG - 1;
-  const int per = (nseg + C - 1) / C;
-  const int s0 = ch * per, s1 = min(nseg, s0 + per);
-  const double* wr = w + (long long)wi * nG;
-  const double* dwr = dlw + (long long)wi * nG;
-  double acc = 0.0;
-  if (s0 < s1) {
-    auto node = [&](int i) {
-      double g = gam[i];
-      return ic_seed_inner(se, sdw, ns, g, eg) * ((3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g));
-    };
-    double K1 = node(s0);
-    for (int s = s0; s < s1; ++s) {
-      double K2 = node(s + 1);
-      double dl = dwr[s] + log(fabs(K2 / K1));
-      acc += nh_seg_term(wr[s] * K1, wr[s + 1] * K2, dl, lx[s]);
-      K1 = K2;
+  const int nch = gridDim.y * C;
+  const int per = (nseg + nch - 1) / nch;
+  const int s0 = (blockIdx.y * C + ch) * per;
+  const int s1 = min(nseg, s0 + per);
+  unsigned row[W], srow[W];
+  double acc[W], Kp[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const unsigned wj = (unsigned)min(w0 + j, N - 1);
+    row[j] = wj * (unsigned)nG;
+    srow[j] = wj * (unsigned)ns;
+    acc[j] = 0.0;
+    Kp[j] = 0.0;
+  }
+  for (int i = s0; i <= s1 && s0 < s1; ++i) {  // nodes s0..s1 of the chunk
+    const double g = gam[i];
+    // inner reduction over the seed spectrum for W walkers at once
+    double in[W], u1[W];
+    double f1 = ic_fic_windowed(e0[0], g, eg);
+#pragma unroll
+    for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * sdm[srow[j]]; }
+    for (int s = 1; s < ns; ++s) {
+      const double f2 = ic_fic_windowed(e0[s], g, eg);
+      const double dlf = log(fabs(f2 / f1));
+      const double lxv = lxs[s - 1];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const double u2 = f2 * sdm[srow[j] + s];
+        in[j] += nh_seg_term(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
+        u1[j] = u2;
+      }
+      f1 = f2;
+    }
+    const double pref = (3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g);  // radiative.py:650-653
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const double Kv = in[j] * pref;
+      if (i > s0) {  // outer segment (i-1, i) of trapz_loglog(nelec*gamint, gam), :684
+        const double dl = dlw[row[j] + i - 1] + log(fabs(Kv / Kp[j]));
+        acc[j] += nh_seg_term(w[row[j] + i - 1] * Kp[j], w[row[j] + i] * Kv, dl, lx[i - 1]);
+      }
+      Kp[j] = Kv;
     }
   }
-  part[ch][lane] = acc;
-  __syncthreads();
-  if (ch == 0 && valid) {
-    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < C; ++j) s += part[j][lane];
-    // lum = uf*Eph*integral, spec = lum/E   (uf = 1), radiative.py:676-687
-    out[(long long)wi * ldo + k] = s * eg / E;
+  for (int j = 0; j < W; ++j) part[ch][j][lane] = acc[j];
+  __syncthreads();
+  if (ch == 0 && kvalid) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (w0 + j < N) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < C; ++c2) sum += part[c2][j][lane];
+        partial[((long long)blockIdx.y * N + (w0 + j)) * nE + k] = sum;
+      }
+    }
   }
+}
+
+__global__ void k_ssc_finish(const double* __restrict__ partial, int nsuper, int N, int nE,
+                             const double* __restrict__ E_eV, double* __restrict__ out, int ldo) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)N * nE) return;
+  int wi = (int)(idx / nE), k = (int)(idx % nE);
+  double s = 0.0;
+  for (int y = 0; y < nsuper; ++y) s += partial[((long long)y * N + wi) * nE + k];
+  const double E = E_eV[k];
+  // lum = uf*Eph*integral, spec = lum/E   (uf = 1), radiative.py:676-687
+  out[(long long)wi * ldo + k] = s * (E / NH_MEC2_EV) / E;
 }
 
 extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw, int N,
@@ -204,12 +272,36 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
                                   const double* seed_dens, int ns, double* out, int ldo) {
   NH_REQUIRE(c && w && dlw && gam && lx && E_eV && seed_E && seed_dens && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ns >= 2 && ldo >= nE, "bad sizes");
+  NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)N * ns < (1LL << 31),
+             "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
+  constexpr int C = 8, W = 4;
+  const int ktiles = (nE + 63) / 64;
+  const int groups = (N + W - 1) / W;
+  const int nseg = nG - 1;
+  // super-chunks over gamma so that the launch has ~4 waves per SIMD
+  int nsuper = 1;
+  while (nsuper < 8 && (long long)ktiles * groups * nsuper * C < 4096 &&
+         nseg / ((nsuper * 2) * C) >= 4)
+    nsuper *= 2;
+  const size_t nd = (size_t)N * ns;
+  const size_t need = (2 * (size_t)ns + 2 * nd + (size_t)nsuper * N * nE) * sizeof(double);
+  void* sc = nullptr;
+  int rc = nh_scratch(c, need, &sc);
+  if (rc) return rc;
+  double* e0 = static_cast<double*>(sc);
+  double* lxs = e0 + ns;
+  double* sdm = lxs + ns;
+  double* dlnd = sdm + nd;
+  double* partial = dlnd + nd;
   nh_prof_scope ps(c, NH_K_SSC);
-  long long pairs = (long long)N * nE;
-  unsigned blocks = (unsigned)((pairs + 63) / 64);
-  hipLaunchKernelGGL((k_ic_seed_walkers<16>), dim3(blocks), dim3(1024), 0, c->stream, w, dlw, N,
-                     gam, lx, nG, E_eV, nE, seed_E, seed_dens, ns, out, ldo);
+  hipLaunchKernelGGL(k_ssc_prep, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream,
+                     seed_E, seed_dens, N, ns, e0, lxs, sdm, dlnd);
+  hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(ktiles * groups, nsuper), dim3(64 * C), 0,
+                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, e0, lxs, sdm, dlnd, ns, partial);
+  long long tot = (long long)N * nE;
+  hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                     partial, nsuper, N, nE, E_eV, out, ldo);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

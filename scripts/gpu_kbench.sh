@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 python scripts/kbench.py 256 2>&1 | tail -8
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -25
+for c in 8 16; do echo -n "C=$c "; NH_INT_C=$c python scripts/kbench.py 256 2>&1 | grep -E "integrate\(IC"; done
