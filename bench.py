@@ -155,7 +155,7 @@ def main():
     from naima_amd.sampler import EnsembleSampler
 
     ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
-    comm = dist.from_env("rccl")
+    comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # gloo: test hook
     name = args.workload
     model, p0, raw, data, prior, labels = build_problem(name, na)
     per_gpu = args.walkers or W.WORKLOADS[name]["nwalkers"]
@@ -263,7 +263,7 @@ def main():
                                           "Synchrotron node 50, table-reduction segment 30"}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
