@@ -471,3 +471,43 @@ def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
     assert_allclose(c0, st.coords, rtol=1e-9)
     assert_allclose(np.load(tmp_path / "logp_0.npy"), st.log_prob, rtol=1e-7)
     assert_allclose(np.load(tmp_path / "chain_1.npy"), s.get_chain(), rtol=1e-9)
+
+
+def test_edge_shapes_against_oracle(na):
+    """ragged and extreme sizes: minimum grid (10 nodes), a 3000-node grid (LDS staging
+    above 64 KB in the synchrotron kernel), odd walker counts, one photon energy, photon
+    energies that are all dead for synchrotron, and a batch of one"""
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(11)
+
+    def check(N, nE, Eemin_eV, Eemax_eV, nEed, Elo, Ehi, B0):
+        E = np.geomspace(Elo, Ehi, nE) if nE > 1 else np.array([Elo])
+        amp = 10 ** (33 + 0.05 * rng.standard_normal(N))
+        alpha = 2.3 + 0.1 * rng.standard_normal(N)
+        B = B0 * (1 + 0.05 * rng.standard_normal(N))
+        sq = (lambda v: v[0]) if N == 1 else (lambda v: v)
+        pd = na.ExponentialCutoffPowerLaw(sq(amp) / u.eV, 10 * u.TeV, sq(alpha), 30 * u.TeV)
+        kw = dict(Eemin=Eemin_eV * u.eV, Eemax=Eemax_eV * u.eV, nEed=nEed)
+        Eq = E * u.eV if nE > 1 else E[0] * u.eV
+        syn = na.Synchrotron(pd, B=sq(B) * u.uG, **kw).flux(Eq, 0).value
+        ic = na.InverseCompton(pd, seed_photon_fields=["CMB", "NIR"], **kw).flux(Eq, 0).value
+        syn, ic = np.asarray(syn).reshape(N, nE), np.asarray(ic).reshape(N, nE)
+        gam = O.electron_grid(Eemin_eV, Eemax_eV, nEed)
+        for i in sorted(set([0, N // 2, N - 1])):
+            opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13,
+                                 alpha=alpha[i], e_cutoff=30e12, beta=1.0)
+            ne = O.nelec_on(opd, gam)
+            # RT down to 200 orders of magnitude below the peak; further out in the
+            # exp(-x) tail (x ~ 700) the relative error grows like x * 1e-15 (checked at 1e-6)
+            ref = O.synchrotron_spectrum(E, gam, ne, B[i] * 1e-6)
+            assert_allclose(syn[i], ref, rtol=RT, atol=ref.max() * 1e-200)
+            assert_allclose(syn[i], ref, rtol=1e-6, atol=1e-300)
+            ref, _ = O.ic_spectrum(E, gam, ne, [O.thermal_seed("CMB"), O.thermal_seed("NIR")])
+            assert_allclose(ic[i], ref, rtol=RT, atol=ref.max() * 1e-200)
+
+    check(N=3, nE=5, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, Elo=1e-6, Ehi=1e-3, B0=10.0)  # 17 -> min grid
+    check(N=1, nE=1, Eemin_eV=1e9, Eemax_eV=1e15, nEed=100, Elo=2e3, Ehi=2e3, B0=12.0)
+    check(N=257, nE=70, Eemin_eV=1e10, Eemax_eV=1e13, nEed=1000, Elo=1e-2, Ehi=1e12, B0=50.0)  # 3000 nodes
+    check(N=5, nE=7, Eemin_eV=1e9, Eemax_eV=1e14, nEed=30, Elo=1e12, Ehi=1e14, B0=3.0)  # synchrotron all dead
+    check(N=64, nE=130, Eemin_eV=1e8, Eemax_eV=5e16, nEed=10, Elo=1e-5, Ehi=1e13, B0=100.0)  # coarse grid
