@@ -14,5 +14,7 @@ from .core import (lnprob, lnprobmodel, log_uniform_prior, normal_prior,  # noqa
 from .models import (BrokenPowerLaw, ExponentialCutoffBrokenPowerLaw,  # noqa: F401
                      ExponentialCutoffPowerLaw, LogParabola, PowerLaw)
 from .radiative import Bremsstrahlung, InverseCompton, PionDecay, Synchrotron  # noqa: F401
+from .analysis import read_run, save_run  # noqa: F401
+from .datatable import validate_data_table  # noqa: F401
 
 __version__ = "0.1.0"

@@ -143,3 +143,29 @@ def test_two_ranks_gloo_match_single_process(tmp_path):
     # 15 proposals per half-step split 8 + 7 (initial evaluation: 30 split 15 + 15)
     assert calls0[0] == 15 and calls1[0] == 15
     assert set(calls0[1:]) == {8} and set(calls1[1:]) == {7}
+
+
+def test_save_read_run_roundtrip(tmp_path):
+    """naima's save_run layout (mcmc/chain, log_prob, blobN, data + attributes) in .npz"""
+    import naima_amd as na
+    from naima_amd import units as u
+    from naima_amd.datatable import make_data
+    s = EnsembleSampler(16, 3, gauss, seed=4)
+    s.run_mcmc(np.random.default_rng(0).normal(size=(16, 3)), 7)
+    s.labels = ["norm", "index", "cutoff"]
+    s.run_info = {"n_walkers": 16, "n_burn": 0, "n_run": 7}
+    n = 5
+    s.data = make_data(dict(energy=np.geomspace(1, 10, n), energy_unit="TeV",
+                            flux=np.ones(n), flux_error_lo=0.1 * np.ones(n),
+                            flux_error_hi=0.1 * np.ones(n), ul=np.zeros(n, bool), cl=0.9,
+                            flux_unit="1/(cm2 s TeV)"))
+    fn = na.save_run(str(tmp_path / "run"), s)
+    r = na.read_run(fn)
+    assert_allclose(r.get_chain(), s.get_chain())
+    assert_allclose(r.get_log_prob(), s.get_log_prob())
+    assert_allclose(r.get_blobs()[1], s.get_blobs()[1])
+    assert r.labels == s.labels and r.run_info["n_run"] == 7
+    assert r.data["energy"].unit == u.TeV and r.data["flux"].unit.physical_type == "differential flux"
+    assert r.chain.shape == (16, 7, 3) and r.flatchain.shape == (112, 3)
+    with pytest.raises(OSError):
+        na.save_run(str(tmp_path / "run"), s)
