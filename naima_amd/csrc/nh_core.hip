@@ -634,46 +634,6 @@ struct nh_comps {
   int n;
 };
 
-struct nh_prior_pack {
-  nh_prior t[NH_MAX_PRIOR];
-  int n;
-};
-
-// value[w] = a * tf(b * base[w*stride] + c);  base == NULL -> the constant a
-__device__ __forceinline__ double nh_lazy_eval(const nh_lazy& z, long long w) {
-  if (!z.base) return z.a;
-  double x = z.b * z.base[w * z.stride] + z.c;
-  switch (z.tf) {
-    case NH_TF_POW10: x = pow(10.0, x); break;
-    case NH_TF_EXP: x = exp(x); break;
-    case NH_TF_LOG: x = log(x); break;
-    case NH_TF_LOG10: x = log10(x); break;
-    case NH_TF_SQRT: x = sqrt(x); break;
-    case NH_TF_SQUARE: x = x * x; break;
-    case NH_TF_RECIP: x = 1.0 / x; break;
-    default: break;
-  }
-  return z.a * x;
-}
-
-// sum of the prior terms of core.py:34-58 for walker w
-__device__ __forceinline__ double nh_prior_sum(const nh_prior_pack& P, long long w) {
-  double s = 0.0;
-  for (int t = 0; t < P.n; ++t) {
-    const double v = nh_lazy_eval(P.t[t].x, w);
-    const double p0 = P.t[t].p0, p1 = P.t[t].p1;
-    double r;
-    switch (P.t[t].kind) {
-      case NH_PRIOR_UNIFORM: r = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
-      case NH_PRIOR_NORMAL: r = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
-      case NH_PRIOR_LOGUNIFORM: r = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
-      default: r = v; break;
-    }
-    s += r;
-  }
-  return s;
-}
-
 __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
                                                       const double* __restrict__ conv,
                                                       const double* __restrict__ flux,

@@ -5,30 +5,13 @@
 // sequence that a naima model function produces.
 #include "nh_common.h"
 
-// value[w] = a * tf(b * base[w*stride] + c);  base == NULL -> the constant a
-__device__ __forceinline__ double lazy_eval(const nh_lazy& z, long long w) {
-  if (!z.base) return z.a;
-  double x = z.b * z.base[w * z.stride] + z.c;
-  switch (z.tf) {
-    case NH_TF_POW10: x = pow(10.0, x); break;
-    case NH_TF_EXP: x = exp(x); break;
-    case NH_TF_LOG: x = log(x); break;
-    case NH_TF_LOG10: x = log10(x); break;
-    case NH_TF_SQRT: x = sqrt(x); break;
-    case NH_TF_SQUARE: x = x * x; break;
-    case NH_TF_RECIP: x = 1.0 / x; break;
-    default: break;
-  }
-  return z.a * x;
-}
-
 struct lazy_pack { nh_lazy c[NH_MAX_LAZY]; int n; };
 
 __global__ void k_pack_rows(lazy_pack P, int N, double* __restrict__ out, int ld) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * P.n) return;
   int w = idx / P.n, j = idx % P.n;
-  out[(long long)w * ld + j] = lazy_eval(P.c[j], w);
+  out[(long long)w * ld + j] = nh_lazy_eval(P.c[j], w);
 }
 
 extern "C" int nh_pack_rows(nh_ctx* c, const nh_lazy* cols, int ncols, int N, double* out,
@@ -53,7 +36,7 @@ extern "C" int nh_pack_rows(nh_ctx* c, const nh_lazy* cols, int ncols, int N, do
 __global__ void k_ew_binary(int op, nh_lazy x, nh_lazy y, int N, double* __restrict__ out) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= N) return;
-  double a = lazy_eval(x, w), b = lazy_eval(y, w), r;
+  double a = nh_lazy_eval(x, w), b = nh_lazy_eval(y, w), r;
   switch (op) {
     case NH_OP_ADD: r = a + b; break;
     case NH_OP_SUB: r = a - b; break;
@@ -117,38 +100,15 @@ extern "C" int nh_lincomb(nh_ctx* c, const nh_comp* comps, int ncomp, const doub
 // ---------------------------------------------------------------------------
 // priors (core.py:34-58) on lazy per-walker scalars, summed: lp[w] = sum_t term_t
 // ---------------------------------------------------------------------------
-struct prior_pack { nh_prior t[NH_MAX_PRIOR]; int n; };
-
-__global__ void k_priors(prior_pack P, int N, double* __restrict__ lp) {
+__global__ void k_priors(nh_prior_pack P, int N, double* __restrict__ lp) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= N) return;
-  double s = 0.0;
-  for (int t = 0; t < P.n; ++t) {
-    double v = lazy_eval(P.t[t].x, w);
-    double p0 = P.t[t].p0, p1 = P.t[t].p1, r;
-    switch (P.t[t].kind) {
-      case NH_PRIOR_UNIFORM:  // core.py:34-39
-        r = (p0 <= v && v <= p1) ? 0.0 : -INFINITY;
-        break;
-      case NH_PRIOR_NORMAL:  // core.py:42-44 (as written: no log, sigma not squared)
-        r = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1);
-        break;
-      case NH_PRIOR_LOGUNIFORM:  // core.py:47-58 (returns 1/value)
-        r = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY;
-        break;
-      default:  // NH_PRIOR_VALUE: an already evaluated per-walker value
-        r = v;
-        break;
-    }
-    s += r;
-  }
-  lp[w] = s;
+  if (w < N) lp[w] = nh_prior_sum(P, w);
 }
 
 extern "C" int nh_priors(nh_ctx* c, const nh_prior* terms, int nterms, int N, double* lp) {
   NH_REQUIRE(c && terms && lp && nterms >= 1 && nterms <= NH_MAX_PRIOR && N >= 0, "bad argument");
   if (N == 0) return NH_OK;
-  prior_pack P;
+  nh_prior_pack P;
   P.n = nterms;
   for (int j = 0; j < nterms; ++j) P.t[j] = terms[j];
   nh_prof_scope ps(c, NH_K_GLUE);

@@ -4,13 +4,7 @@
 // node needs Gtilde(x) = P(x) exp(-x) in FP64.  The kernel is FP64-VALU bound;
 // HBM traffic is the (w, dlw) rows and the output only.
 //
-// Mapping: one block = one walker x one tile of 64 photon energies (lanes); the C
-// waves of the block split the gamma range and each thread walks its chunk
-// sequentially (previous node in registers); partial sums meet in LDS.  The
-// walker's w/dlw and lx are wave-uniform: they come through the scalar cache.
-// All lanes of a wave sit at the same gamma_i, so the region where exp(-x)
-// underflows to exactly 0 (x > 746; the reference produces exact zeros there
-// too, which trapz_loglog discards) is skipped at wave granularity.
+// Mapping: see k_synchrotron below (live-energy compaction per block).
 //
 // Instruction diet (the first version spent ~400 FP64 instructions per node in
 // OCML cbrt/sqrt/div/exp/log):
