@@ -261,6 +261,17 @@ int nh_stream_switch(nh_ctx* ctx, int side);
 int nh_stream_wait(nh_ctx* ctx, int waiter, int producer);
 int nh_stream_join(nh_ctx* ctx);
 
+/* host-side generator of the move's random numbers: a worker thread fills a ring of
+ * (page-locked) blocks ahead of the consumer, in exactly the slice layout above.  The
+ * stream (xoshiro256** from `seed`; per step: permutation, z, partners, ln U') does not
+ * depend on how many steps are taken at once, nor on the rank. */
+typedef struct nh_moves nh_moves;
+int nh_moves_create(unsigned long long seed, int N, double a, int ksteps_per_block, int depth,
+                    int pinned, nh_moves** out);
+/* up to `want` consecutive steps, contiguous in host memory (2*got slices) */
+int nh_moves_take(nh_moves* m, int want, const void** host_ptr, int* got);
+int nh_moves_destroy(nh_moves* m);
+
 /* capture everything launched on the context's stream into a hipGraph, replay it */
 int nh_graph_begin(nh_ctx* ctx);
 int nh_graph_end(nh_ctx* ctx, void** graph_exec_out);

@@ -73,6 +73,9 @@ _SIGS = {
     "nh_stream_switch": [_dp, _i],
     "nh_stream_wait": [_dp, _i, _i],
     "nh_stream_join": [_dp],
+    "nh_moves_create": [C.c_ulonglong, _i, _d, _i, _i, _i, C.POINTER(_dp)],
+    "nh_moves_take": [_dp, _i, C.POINTER(_dp), C.POINTER(_i)],
+    "nh_moves_destroy": [_dp],
     "nh_graph_begin": [_dp],
     "nh_graph_end": [_dp, C.POINTER(_dp)],
     "nh_graph_launch": [_dp, _dp],
@@ -115,6 +118,44 @@ def load():
 def _chk(rc):
     if rc != 0:
         raise NaimaHipError("libnaima_hip error %d: %s" % (rc, _lib.nh_last_error().decode()))
+
+
+class Moves:
+    """the stretch-move random stream (nh_moves_*): a C++ worker thread draws ahead.
+    ``take(k)`` -> (address, got, S, P, Z, L views for `got` consecutive steps)"""
+
+    def __init__(self, seed, N, a=2.0, ksteps=32, depth=4, pinned=False):
+        load()
+        h = _dp()
+        _chk(_lib.nh_moves_create(int(seed) & (2 ** 64 - 1), int(N), float(a), int(ksteps),
+                                  int(depth), int(bool(pinned)), C.byref(h)))
+        self.h, self.N, self.ns, self.ksteps = h, int(N), int(N) // 2, int(ksteps)
+
+    def take(self, want):
+        p, got = _dp(), _i()
+        _chk(_lib.nh_moves_take(self.h, int(want), C.byref(p), C.byref(got)))
+        return p.value, got.value
+
+    def view(self, addr, got):
+        """numpy views (no copy) of `got` steps at `addr`: S, P int32 and Z, L float64,
+        each [got, 2, ns]"""
+        ns = self.ns
+        n = got * 2 * 3 * ns
+        f = np.frombuffer((C.c_double * n).from_address(addr), dtype=np.float64).reshape(
+            got, 2, 3 * ns)
+        iv = f[:, :, 2 * ns:].view(np.int32)
+        return iv[:, :, :ns], iv[:, :, ns:], f[:, :, :ns], f[:, :, ns:2 * ns]
+
+    def close(self):
+        if self.h:
+            _lib.nh_moves_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceArray:

@@ -82,6 +82,9 @@ class DeviceLoop:
         self.ident = ctx.array(np.arange(max(self.nloc, 1), dtype=np.int32), dtype=np.int32)
         self.graph2 = None
         self.step_graph = None
+        self._markers = [ctx.marker() for _ in range(4)]
+        self._inflight = []
+        self._nmark = 0
         self.accepted = ctx.empty((self.ns,), dtype=np.int32)
         self.nacc = ctx.empty((self.N,), dtype=np.int32)
         ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
@@ -215,7 +218,7 @@ class DeviceLoop:
             if st.coords.shape != (self.N, self.ndim):
                 raise ValueError("incompatible input dimensions")
             self._init_state(st.coords, st.log_prob)
-        rng, a, N, ns = s._rng, s.a, self.N, self.ns
+        rng, N, ns = s._rng, self.N, self.ns
         iterations = int(iterations)
         block = None
         if store and iterations > 0:
@@ -224,28 +227,20 @@ class DeviceLoop:
                          blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
                                 (self.cur_blobs or [])] if s.store_blobs else [])
             self.hist.append(block)
-        from .sampler import draw_moves
-        ring = self._ring()
-        nblk = 0
+        moves = s.moves(pinned=True)
         it = 0
         while it < iterations:
-            K = min(self.KSTEPS, iterations - it)
-            # ---- draw and ship the moves of the next K steps (one upload) ----------
-            raw, addr, mark, used = ring[nblk % len(ring)]
-            if used[0]:
-                ctx.call("nh_marker_wait", mark)  # its previous upload has long finished
-            Sm, Pm, Zm, Lm = draw_moves(rng, N, K, a)
-            f = raw[:2 * K * 3 * ns].reshape(2 * K, 3 * ns)
-            f[:, :ns] = Zm.reshape(2 * K, ns)
-            f[:, ns:2 * ns] = Lm.reshape(2 * K, ns)
-            iv = f[:, 2 * ns:].view(np.int32)
-            iv[:, :ns] = Sm.reshape(2 * K, ns)
-            iv[:, ns:] = Pm.reshape(2 * K, ns)
+            # ---- ship the moves of the next K steps: ONE asynchronous upload from the
+            # generator's page-locked ring (filled ahead by its worker thread) ----------
+            while len(self._inflight) >= 2:  # ring depth 4: keep <= 3 blocks in play
+                ctx.call("nh_marker_wait", self._inflight.pop(0))
+            addr, K = moves.take(min(self.KSTEPS, iterations - it))
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
             ctx.call("nh_memset", self.cursor, 0, 4)
+            mark = self._markers[self._nmark % len(self._markers)]
+            self._nmark += 1
             ctx.call("nh_marker_record", mark)
-            used[0] = True
-            nblk += 1
+            self._inflight.append(mark)
             for _k in range(K):
                 self._run_step()
                 it += 1
@@ -259,16 +254,6 @@ class DeviceLoop:
                         ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
                     block["n"] = k + 1
                 yield DeviceState(self, rng)
-
-    def _ring(self, depth=3):
-        """page-locked staging blocks for the random numbers of KSTEPS steps: uploads
-        from them are asynchronous, so the host draws block b+1 while the device runs b"""
-        if getattr(self, "_ring_bufs", None) is None:
-            self._ring_bufs = []
-            for _ in range(depth):
-                raw, addr = self.ctx.pinned(8 * 2 * self.KSTEPS * 3 * self.ns)
-                self._ring_bufs.append((raw.view(np.float64), addr, self.ctx.marker(), [False]))
-        return self._ring_bufs
 
     def _capture(self, fn):
         ctx = self.ctx

@@ -38,32 +38,6 @@ class State:
         return iter((self.coords, self.log_prob, self.random_state))
 
 
-def draw_moves(rng, N, nsteps, a=2.0):
-    """The random numbers of ``nsteps`` ensemble steps (two half-steps each), drawn in a
-    fixed order per step -- one permutation (the red/blue split), one uniform block -- so the
-    stream does not depend on how many steps are drawn at once (the host-driven and the
-    device-resident loops, and every rank of a sharded run, see the same moves).
-
-    Returns S, P (int32 [nsteps, 2, N/2]: active walkers and each one's partner in the
-    complementary half), Z (stretch factors), L (ln U' accept thresholds)."""
-    ns = N // 2
-    S = np.empty((nsteps, 2, ns), dtype=np.int32)
-    R = np.empty((nsteps, 2, ns), dtype=np.int64)
-    U = np.empty((nsteps, 3, 2, ns))
-    for k in range(nsteps):
-        # a random balanced split of the ensemble: first / second half of a permutation
-        S[k] = rng.permutation(N).reshape(2, ns)
-        rng.random(out=U[k])
-    Z = ((a - 1.0) * U[:, 0] + 1) ** 2.0 / a
-    np.multiply(U[:, 1], ns, out=U[:, 1])
-    R[:] = U[:, 1]  # partner index within the complementary half
-    P = np.empty_like(S)
-    P[:, 0] = np.take_along_axis(S[:, 1], R[:, 0], axis=1)
-    P[:, 1] = np.take_along_axis(S[:, 0], R[:, 1], axis=1)
-    L = np.log(U[:, 2])
-    return S, P, Z, L
-
-
 def _split_blob(b):
     """a blob returned by the model -> (ndarray with leading walker axis, unit or None)"""
     if isinstance(b, u.Quantity):
@@ -87,8 +61,11 @@ class EnsembleSampler:
         self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
         self.log_prob_fn, self.args = log_prob_fn, tuple(args)
         self.comm = comm if comm is not None else LocalComm()
-        # the stream is replicated on every rank: proposals/accepts are identical
-        self._rng = np.random.default_rng(seed if seed is not None else 12345)
+        # the streams are replicated on every rank: proposals/accepts are identical.
+        # _rng: numpy, for the initial ball; _moves: the C++ stretch-move stream
+        self.seed = int(seed if seed is not None else 12345)
+        self._rng = np.random.default_rng(self.seed)
+        self._moves = None
         self.naima_style = naima_style
         self.store_blobs = store_blobs
         # device=True: ensemble, proposals, log-probabilities and blobs live in HBM; the
@@ -100,6 +77,14 @@ class EnsembleSampler:
         self.n_lnprob_calls = 0
         self.n_walker_evals = 0
         self.reset()
+
+    def moves(self, pinned=False):
+        """the stretch-move random stream (one per sampler, created on first use)"""
+        if self._moves is None:
+            from ._lib import Moves
+            self._moves = Moves(self.seed, self.nwalkers, self.a, ksteps=32, depth=4,
+                                pinned=pinned)
+        return self._moves
 
     # ------------------------------------------------------------------ store
     def reset(self):
@@ -220,8 +205,10 @@ class EnsembleSampler:
             if not hasattr(self, "_cur_blobs"):
                 self._cur_blobs, self._own = [], np.arange(0)
         logp = logp.copy()
+        moves = self.moves()
         for _ in range(int(iterations)):
-            Sm, Pm, Zm, Lm = draw_moves(rng, N, 1, a)
+            addr, got = moves.take(1)
+            Sm, Pm, Zm, Lm = moves.view(addr, got)
             for split in range(2):
                 S, zz = Sm[0, split], Zm[0, split]
                 s, cp = coords[S], coords[Pm[0, split]]

@@ -666,31 +666,26 @@ def lnprob(pars, data, modelfunc, priorfunc):
 # ---------------------------------------------------------------------------
 # ensemble move (emcee >= 3, third party, NOT in /root/reference; parity unpinned)
 # ---------------------------------------------------------------------------
-def stretch_move_reference(coords, logp, lnprob_fn, rng, a=2.0):
+def stretch_move_reference(coords, logp, lnprob_fn, S, P, Z, L):
     """One emcee-3 ``StretchMove`` step restated from its published algorithm
     (Goodman & Weare 2010; emcee.moves.RedBlueMove.propose + StretchMove.
     get_proposal).  Call sites in the reference: core.py:128, 450-457.
     lnprob_fn maps (n, ndim) -> (n,).  Returns (coords, logp, accepted).
 
-    Random-number protocol (this build's; emcee's own draw order is not part of any
-    contract): per step one permutation whose halves are the two sets, then ONE
-    uniform block u[3][2][n/2]: u[0] -> z = ((a-1)u+1)^2/a, u[1] -> partner =
-    floor(u n/2), u[2] -> accept if ln u < (ndim-1) ln z + lnp(q) - lnp(s)."""
+    The random numbers are inputs (emcee's own draw order is not part of any contract):
+    for half h = 0, 1:  S[h] the active walkers, P[h] each one's partner in the other
+    half, Z[h] = ((a-1)U+1)^2/a the stretch factors, L[h] = ln U' the accept thresholds.
+    q = c - (c - s) z ;  accept if ln U' < (ndim-1) ln z + lnp(q) - lnp(s)."""
     nwalkers, ndim = coords.shape
-    ns = nwalkers // 2
     coords, logp = coords.copy(), logp.copy()
     accepted = np.zeros(nwalkers, dtype=bool)
-    halves = rng.permutation(nwalkers).reshape(2, ns)
-    u = rng.random((3, 2, ns))
-    for split in range(2):
-        S, C = halves[split], halves[1 - split]
-        zz = ((a - 1.0) * u[0, split] + 1) ** 2.0 / a
-        partner = C[(u[1, split] * ns).astype(int)]
-        q = coords[partner] - (coords[partner] - coords[S]) * zz[:, None]
+    for h in range(2):
+        s, c, zz = coords[S[h]], coords[P[h]], Z[h]
+        q = c - (c - s) * zz[:, None]
         newlp = lnprob_fn(q)
-        lnpdiff = (ndim - 1.0) * np.log(zz) + newlp - logp[S]
-        acc = np.log(u[2, split]) < lnpdiff
-        idx = S[acc]
+        lnpdiff = (ndim - 1.0) * np.log(zz) + newlp - logp[S[h]]
+        acc = L[h] < lnpdiff
+        idx = S[h][acc]
         coords[idx] = q[acc]
         logp[idx] = newlp[acc]
         accepted[idx] = True

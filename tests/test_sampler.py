@@ -63,18 +63,33 @@ def test_same_seed_same_chain_and_restart():
 
 
 def test_reference_move_restatement_agrees():
-    """sampler.sample == oracle.stretch_move_reference for the same stream"""
+    """sampler.sample == oracle.stretch_move_reference fed with the same move stream;
+    the stream is independent of how many steps are taken at once"""
+    from naima_amd._lib import Moves
     from oracle import naima_np as O
     p0 = np.random.default_rng(3).normal(size=(16, 2))
     lp = lambda x: -0.5 * np.sum(x ** 2, axis=1)  # noqa: E731
     s = EnsembleSampler(16, 2, lp, seed=9, store_blobs=False)
     st = s.run_mcmc(p0, 5)
-    rng = np.random.default_rng(9)
+    m = Moves(9, 16, 2.0, ksteps=32, depth=4)
     c, l = p0.copy(), lp(p0)
-    for _ in range(5):
-        c, l, _ = O.stretch_move_reference(c, l, lp, rng)
+    addr, got = m.take(5)
+    S, P, Z, L = m.view(addr, got)
+    for k in range(5):
+        c, l, _ = O.stretch_move_reference(c, l, lp, S[k], P[k], Z[k], L[k])
     assert_allclose(st.coords, c)
     assert_allclose(st.log_prob, l)
+    m2 = Moves(9, 16, 2.0, ksteps=3, depth=2)  # other blocking, one step at a time
+    for k in range(5):
+        a2, g2 = m2.take(1)
+        S2, P2, Z2, L2 = m2.view(a2, g2)
+        assert g2 == 1 and (S2[0] == S[k]).all() and (P2[0] == P[k]).all()
+        assert_allclose(Z2[0], Z[k]) and assert_allclose(L2[0], L[k])
+    # every step: a permutation split in halves, partners from the other half
+    for k in range(5):
+        assert sorted(np.concatenate([S[k, 0], S[k, 1]])) == list(range(16))
+        assert np.isin(P[k, 0], S[k, 1]).all() and np.isin(P[k, 1], S[k, 0]).all()
+    assert (Z >= 0.5).all() and (Z <= 2.0).all() and (L <= 0).all()
 
 
 def test_naima_style_with_oracle_model(golden):
