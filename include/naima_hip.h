@@ -137,9 +137,10 @@ int nh_integrate_tables(nh_ctx* ctx, const double* w, const double* dlw, int N, 
                         const double* scale, double* out, int ldo);
 
 /* ---- row 5: radiative.py:282-342 Synchrotron._spectrum ------------------- */
-/* out[w*ldo+k] = spectrum 1/(s eV) at photon energy E_eV[k] for field B_G[w]
- * (Gauss); walker-dependent through both w/lw and B. */
-int nh_synchrotron(nh_ctx* ctx, const double* w, const double* dlw, const double* B_G /*[N]*/,
+/* out[w*ldo+k] = spectrum 1/(s eV) at photon energy E_eV[k] for field B_G[w*ldB]
+ * (Gauss; ldB = 1 for a plain vector, NH_PD_NPAR when B rides in slot 7 of the packed
+ * parameter rows); walker-dependent through both w/dlw and B. */
+int nh_synchrotron(nh_ctx* ctx, const double* w, const double* dlw, const double* B_G, int ldB,
                    int N, const double* gam, const double* lx, int nG,
                    const double* E_eV, int nE, double* out, int ldo);
 

@@ -85,7 +85,7 @@ constexpr int SYN_MAXCH = 64;  // chunks per energy (LDS: part[SYN_MAXCH][64])
 template <int C>
 __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const double* __restrict__ w, const double* __restrict__ dlw, const double* __restrict__ B,
-    int N, const double* __restrict__ gam, const double* __restrict__ lx, int nG,
+    int ldB, int N, const double* __restrict__ gam, const double* __restrict__ lx, int nG,
     const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo) {
   extern __shared__ double smem[];  // ig2[nG] | dig2[nG] | ig23[nG] | part[SYN_MAXCH][64]
   double* ig2 = smem;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
 
   const int ktiles = (nE + 63) >> 6;
   const int tile = blockIdx.x % ktiles, wi = blockIdx.x / ktiles;
-  const double Bw = B[wi];
+  const double Bw = B[(long long)wi * ldB];
   // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
   const double qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) /
                       (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
 }
 
 extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, const double* B_G,
-                              int N, const double* gam, const double* lx, int nG,
+                              int ldB, int N, const double* gam, const double* lx, int nG,
                               const double* E_eV, int nE, double* out, int ldo) {
   NH_REQUIRE(c && w && dlw && B_G && gam && lx && E_eV && out, "NULL pointer");
-  NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ldo >= nE, "bad sizes");
+  NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ldo >= nE && ldB >= 1, "bad sizes");
   if (N == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_SYNCHROTRON);
   const int ktiles = (nE + 63) / 64;
@@ -223,7 +223,7 @@ extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   }
 #define NH_LAUNCH_SYN(CC)                                                                    \
   hipLaunchKernelGGL((k_synchrotron<CC>), dim3(blocks), dim3(64 * CC), shm, c->stream, w, dlw, \
-                     B_G, N, gam, lx, nG, E_eV, nE, out, ldo)
+                     B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo)
   switch (C) {
     case 16: NH_LAUNCH_SYN(16); break;
     case 8: NH_LAUNCH_SYN(8); break;

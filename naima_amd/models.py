@@ -41,6 +41,7 @@ class _ParticleDistribution:
         # any parameter change invalidates the packed device rows and weights
         self.__dict__.pop("_rows_dev", None)
         self.__dict__.pop("_w_dev", None)
+        self.__dict__.pop("_slot7_packed", None)
         object.__setattr__(self, name, value)
 
     @property
@@ -103,6 +104,13 @@ class _ParticleDistribution:
         for j in range(NH_PD_NPAR):
             cols[j] = lazy_const(1.0 if j == 4 else 0.0)
         keep = []
+        # slot 7 is free: a Synchrotron built on this distribution parks its (device)
+        # magnetic field there so that one pack launch serves every component
+        rider = self.__dict__.get("_slot7")
+        if isinstance(rider, DVec) and rider.n == N:
+            cols[7] = rider.lazy()
+            keep.append(rider)
+            self.__dict__["_slot7_packed"] = rider
         for name, slot, is_energy in self._slots:
             v = getattr(self, name)
             if name == "amplitude":

@@ -342,6 +342,12 @@ class Synchrotron(BaseElectron):
         self.nEed = 100
         self.param_names += ["B"]
         self.__dict__.update(**kwargs)
+        # a device-resident B rides in the free slot 7 of the distribution's packed rows
+        Bv = self.B.to("G").value
+        pd = particle_distribution
+        if isinstance(Bv, DVec) and hasattr(pd, "device_rows") and "_slot7" not in pd.__dict__ \
+                and not pd.__dict__.get("_rows_dev"):
+            pd.__dict__["_slot7"] = Bv
 
     def _own_batch_sizes(self):
         return (_batch_of(self.B),)
@@ -352,22 +358,33 @@ class Synchrotron(BaseElectron):
     def _prefork(self, ctx):
         super()._prefork(ctx)
         Bv = self.B.to("G").value
-        if isinstance(Bv, DVec) and self.__dict__.get("_B_dense") is None:
+        if isinstance(Bv, DVec) and self.__dict__.get("_B_dense") is None \
+                and not self._B_in_rows(Bv):
             self._B_dense = Bv.dense()
+
+    def _B_in_rows(self, Bv):
+        pd = self.particle_distribution
+        rider = pd.__dict__.get("_slot7_packed")
+        return rider is not None and rider.ptr == Bv.ptr and rider.stride == Bv.stride \
+            and (rider.a, rider.b, rider.c, rider.tf) == (Bv.a, Bv.b, Bv.c, Bv.tf)
 
     def _spectrum(self, photon_energy):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         Bv = self.B.to("G").value
-        if isinstance(Bv, DVec):
+        ldB = 1
+        if isinstance(Bv, DVec) and self._B_in_rows(Bv):
+            Bd = self.particle_distribution.device_rows(ctx, N, amplitude_to=_PER_EV)
+            Bp, ldB = Bd.ptr + 8 * 7, 8
+        elif isinstance(Bv, DVec):
             Bd = self.__dict__.get("_B_dense") or Bv.dense()
             Bp = Bd.ptr
         else:
             Bd = ctx.const(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
             Bp = Bd.ptr
         out = ctx.empty((N, E_eV.size))
-        ctx.call("nh_synchrotron", w, lw, Bp, N, gd, lx, gam.size, ctx.const(E_eV),
+        ctx.call("nh_synchrotron", w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV),
                  E_eV.size, out, E_eV.size)
         del Bd
         return self._result(ctx, out, N, E_eV.size, E)

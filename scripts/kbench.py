@@ -34,7 +34,7 @@ res = {}
 gam, gd, w, dlw, lx, f = weights(1.0)
 res["weights(570)"] = timeit(f)
 Ed = ctx.const(E); Bd = ctx.array(B); out = ctx.empty((N, nE))
-res["synchrotron"] = timeit(lambda: ctx.call("nh_synchrotron", w, dlw, Bd, N, gd, lx, gam.size, Ed, nE, out, nE))
+res["synchrotron"] = timeit(lambda: ctx.call("nh_synchrotron", w, dlw, Bd, 1, N, gd, lx, gam.size, Ed, nE, out, nE))
 gam2, gd2, w2, dlw2, lx2, f2 = weights(100.0)
 res["weights(370)"] = timeit(f2)
 nK = 3 * nE
