@@ -44,7 +44,7 @@ _SIGS = {
     "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
     "nh_particle_weights_multi": [_dp, _i, _dp, _i, _dp, _i],
     "nh_grid_logratio": [_dp, _dp, _i, _dp],
-    "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i],
+    "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _i],
     "nh_synchrotron": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _i, _dp, _i, _dp, _i],
     "nh_table_ic_planck": [_dp, _dp, _i, _dp, _i, _d, _d, _dp, _dp, _i],
     "nh_table_ic_seed": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _i],

@@ -123,6 +123,16 @@ __device__ __forceinline__ double nh_rcp(double x) {
   return fma(r, e, r);
 }
 
+// one Newton step: v_rcp_f64 is good to ~2^-23, so this is ~2^-46 = 1.4e-14 relative --
+// enough for the factor 1/dl of a segment term
+__device__ __forceinline__ double nh_rcp1(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+
+// SIGNED = false promises u1, u2 >= 0 (non-negative table and amplitude): the
+// sign-change / NaN-ratio test of the log branch is then dead code
+template <bool SIGNED = true>
 __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, double lx) {
   // series for |dl| < 2^-7: 1 + d/2 + d^2/6 + d^3/24 + d^4/120
   double f = fma(dl, 8.333333333333333e-03, 4.166666666666666e-02);
@@ -131,13 +141,22 @@ __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, d
   f = fma(f, dl, 1.0);
   const double ul = u1 * lx;
   const double ts = ul * f;
-  const double td = (u2 - u1) * lx * nh_rcp(dl);
+  const double td = (u2 - u1) * lx * nh_rcp1(dl);
   double t = (fabs(dl) < 0.0078125) ? ts : td;
-  // sign change or NaN ratio -> NaN b in the reference -> its log branch x1*y1*ln(x2/x1)
-  const bool logb = ((__double2hiint(u1) ^ __double2hiint(u2)) < 0) || !(dl == dl);
-  t = logb ? ul : t;
+  if (SIGNED) {
+    // sign change or NaN ratio -> NaN b in the reference -> its log branch x1*y1*ln(x2/x1)
+    const bool logb = ((__double2hiint(u1) ^ __double2hiint(u2)) < 0) || !(dl == dl);
+    t = logb ? ul : t;
+  }
   // zero node (utils.py:347-348)
   return (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
+}
+
+typedef unsigned int nh_u32x2 __attribute__((ext_vector_type(2)));
+// 8-byte load through a buffer descriptor at a 32-bit byte offset
+__device__ __forceinline__ double nh_buf_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  nh_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
 }
 
 __device__ __forceinline__ double nh_heaviside(double x) {  // radiative.py:1539-1540

@@ -490,7 +490,7 @@ extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx)
 // (s_load), not through the vector L1 -- the first version issued 5 vector loads
 // per segment and walker and was bound by the L1 tag-lookup rate (TCP), at 40 % of
 // the VALU.  The C waves of a block split the abscissa; partial sums meet in LDS.
-template <int C, int W>
+template <int C, int W, bool SIGNED>
 __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
     const double* __restrict__ lx, const double* __restrict__ Kt,
@@ -517,24 +517,32 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     row[j] = (unsigned)min(w0 + j, N - 1) * (unsigned)nG;
   }
   if (s0 < s1) {
-    unsigned ok = (unsigned)s0 * (unsigned)nK + kk;
+    // table rows through buffer descriptors: base in SGPRs + one 32-bit byte offset per
+    // lane (a single v_add per load instead of 64-bit address arithmetic)
+    const unsigned tbytes = (unsigned)nG * (unsigned)nK * 8u;
+    const __amdgpu_buffer_rsrc_t rK =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Kt, 0, (int)tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dlnKt, 0, (int)tbytes, 0x00020000);
+    const unsigned rowb = (unsigned)nK * 8u;
+    unsigned ob = ((unsigned)s0 * (unsigned)nK + kk) * 8u;
     {
-      const double K0 = Kt[ok];
+      const double K0 = nh_buf_f64(rK, ob);
 #pragma unroll
       for (int j = 0; j < W; ++j) u1[j] = w[row[j] + s0] * K0;
     }
     for (int s = s0; s < s1; ++s) {
-      const double K2 = Kt[ok + (unsigned)nK];
-      const double dK = dlnKt[ok];
+      const double K2 = nh_buf_f64(rK, ob + rowb);
+      const double dK = nh_buf_f64(rD, ob);
       const double lxs = lx[s];
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         const double u2 = w[row[j] + s + 1] * K2;
         const double dl = dlw[row[j] + s] + dK;
-        acc[j] += nh_seg_term(u1[j], u2, dl, lxs);
+        acc[j] += nh_seg_term<SIGNED>(u1[j], u2, dl, lxs);
         u1[j] = u2;
       }
-      ok += (unsigned)nK;
+      ob += rowb;
     }
   }
 #pragma unroll
@@ -571,8 +579,6 @@ __global__ __launch_bounds__(256) void k_integrate_rows(
     double u1 = wr[s] * Kt[(long long)s * nK + k];
     double u2 = wr[s + 1] * Kt[(long long)(s + 1) * nK + k];
     double dl = dwr[s] + dlnKt[(long long)s * nK + k];
-    // lanes are at different segments here: the uniform fast path of nh_seg_term
-    // still applies when every lane of the wave is in the smooth regime
     acc += nh_seg_term(u1, u2, dl, lx[s]);
   }
   acc = wave_sum(acc);
@@ -581,11 +587,12 @@ __global__ __launch_bounds__(256) void k_integrate_rows(
 
 extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
                                    const double* lx, const double* Kt, const double* dlnKt,
-                                   int nK, const double* scale, double* out, int ldo) {
+                                   int nK, const double* scale, double* out, int ldo,
+                                   int nonnegative) {
   NH_REQUIRE(c && w && dlw && lx && Kt && dlnKt && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nK >= 1 && ldo >= nK, "bad sizes");
-  NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)nG * nK < (1LL << 31),
-             "arrays too large for 32-bit element offsets");
+  NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)nG * nK < (1LL << 28),
+             "arrays too large for 32-bit offsets");
   if (N == 0) return NH_OK;
   long long pairs = (long long)N * nK;
   nh_prof_scope ps(c, pairs * 4 < 4096 ? NH_K_ROWS : NH_K_INTEGRATE);
@@ -608,9 +615,11 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   int C = 1;
   while (C < 16 && (long long)blocks * C < 12288 && nseg / (2 * C) >= 8) C *= 2;
   if (const char* e = getenv("NH_INT_C")) C = atoi(e);
-#define NH_LAUNCH_INT(CC, WW)                                                                 \
-  hipLaunchKernelGGL((k_integrate_tables<CC, WW>), dim3(blocks), dim3(64 * CC), 0, c->stream, \
-                     w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
+#define NH_LAUNCH_INT_S(CC, WW, SS)                                                          \
+  hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS>), dim3(blocks), dim3(64 * CC), 0,       \
+                     c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
+#define NH_LAUNCH_INT(CC, WW) \
+  do { if (nonnegative) NH_LAUNCH_INT_S(CC, WW, false); else NH_LAUNCH_INT_S(CC, WW, true); } while (0)
 #define NH_LAUNCH_INT_C(CC) \
   do { if (W == 4) NH_LAUNCH_INT(CC, 4); else if (W == 2) NH_LAUNCH_INT(CC, 2); else NH_LAUNCH_INT(CC, 1); } while (0)
   switch (C) {
@@ -622,6 +631,7 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   }
 #undef NH_LAUNCH_INT_C
 #undef NH_LAUNCH_INT
+#undef NH_LAUNCH_INT_S
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

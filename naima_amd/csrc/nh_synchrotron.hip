@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         }
         // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
         const double dl = dwr[s] + syn_dlnP(P1, P2) - q * dig2[s];
-        acc += nh_seg_term(u1, u2, dl, lx[s]);
+        acc += nh_seg_term<false>(u1, u2, dl, lx[s]);  // P(x) exp(-x) > 0: one sign
         u1 = u2;
         P1 = P2;
       }

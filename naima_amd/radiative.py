@@ -286,7 +286,7 @@ class BaseElectron(BaseRadiative):
         K = gam * MEC2_ERG  # u = x*y = (gam mec2)(gam nelec)
         Kt, dlnKt = ctx.const(K), ctx.const(_dlog(K))
         out = ctx.empty((N, 1))
-        ctx.call("nh_integrate_tables", w, lw, N, gam.size, lx, Kt, dlnKt, 1, None, out, 1)
+        ctx.call("nh_integrate_tables", w, lw, N, gam.size, lx, Kt, dlnKt, 1, None, out, 1, 0)
         if self.on_device:
             return u.Quantity(DVec(ctx, out, out.ptr, N), u.erg)
         We = out.get()[:, 0]
@@ -551,8 +551,9 @@ class InverseCompton(BaseElectron):
                     uf = 1.0
                 scale[j * nE:(j + 1) * nE] = uf * Eph / E_eV  # radiative.py:684-687
             out = ctx.empty((N, nK))
+            # IC kernels are >= 0; a user-supplied array seed is validated positive
             ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
-                     out, nK)
+                     out, nK, 1)
             if dev:
                 for j, name in enumerate(static):
                     specs[name] = DMat.from_buffer(ctx, out, N, nE, ld=nK, col0=j * nE)
@@ -671,7 +672,7 @@ class Bremsstrahlung(BaseElectron):
                                 np.full(nE, n0 * self.weight_ep * C_CGS)])
         out = ctx.empty((N, 2 * nE))
         ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, 2 * nE, ctx.const(scale), out,
-                 2 * nE)
+                 2 * nE, 0)  # the Baring+99 fits go negative near their edges
         if self.on_device:
             tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE) + \
                 DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE)
@@ -720,7 +721,7 @@ class BaseProton(BaseRadiative):
         ctx, N, w, lw, xd, lx, Ep = self._proton_weights(Ep)
         Kt, dlnKt = ctx.const(Ep), ctx.const(_dlog(Ep))
         out = ctx.empty((N, 1))
-        ctx.call("nh_integrate_tables", w, lw, N, Ep.size, lx, Kt, dlnKt, 1, None, out, 1)
+        ctx.call("nh_integrate_tables", w, lw, N, Ep.size, lx, Kt, dlnKt, 1, None, out, 1, 0)
         if self.on_device:
             return u.Quantity(DVec(ctx, out, out.ptr, N), u.GeV).to("erg")
         Wp = out.get()[:, 0]
@@ -835,7 +836,9 @@ class PionDecay(BaseProton):
         Kt, dKt = ctx.table(("pp", xd.ptr, Ed.ptr, use_lut, self.hiEmodel,
                              bool(self.nuclear_enhancement)), build)
         out = ctx.empty((N, nE))
-        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE)
+        # the FITPACK look-up table rings below zero; the analytic form does not
+        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE,
+                 0 if use_lut else 1)
         nh = self.nh.to("1/cm3").value
         fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
         self.specpp = self._result(ctx, out, N, nE, E, scale=fac)

@@ -44,11 +44,11 @@ def tabs():
         ctx.call("nh_table_ic_planck", gd2, gam2.size, Ed, nE, T, -1.0, Kt.ptr + 8 * j * nE, dKt.ptr + 8 * j * nE, nK)
 res["tables(3 seeds)"] = timeit(tabs, 10)
 out2 = ctx.empty((N, nK))
-res["integrate(IC nK=192)"] = timeit(lambda: ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK))
+res["integrate(IC nK=192)"] = timeit(lambda: ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK, 1))
 gam3, gd3, w3, dlw3, lx3, f3 = weights(1000.0); f3()
 K = gam3 * MEC2_ERG
 Kd, dKd = ctx.const(K), ctx.const(_dlog(K)); out3 = ctx.empty((N, 1))
-res["integrate(We nK=1)"] = timeit(lambda: ctx.call("nh_integrate_tables", w3, dlw3, N, gam3.size, lx3, Kd, dKd, 1, None, out3, 1))
+res["integrate(We nK=1)"] = timeit(lambda: ctx.call("nh_integrate_tables", w3, dlw3, N, gam3.size, lx3, Kd, dKd, 1, None, out3, 1, 0))
 for k, v in res.items():
     print("%-24s %8.2f us" % (k, v))
 print("checksum", float(out.get().sum()), float(out2.get().sum()), float(out3.get().sum()))

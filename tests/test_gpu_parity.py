@@ -71,7 +71,7 @@ def test_abi_integrate_tables_edges(na, golden):
     ctx.call("nh_grid_logratio", xd, n, lx)
     out = ctx.empty((len(Y), 1))
     ctx.call("nh_integrate_tables", ctx.array(w), ctx.array(lw), len(Y), n, lx, ctx.array(K),
-             ctx.array(np.zeros((n, 1))), 1, None, out, 1)
+             ctx.array(np.zeros((n, 1))), 1, None, out, 1, 0)
     assert_allclose(out.get()[:, 0], U["tz_out"], rtol=1e-13)
 
 
