@@ -117,7 +117,10 @@ int nh_particle_weights(nh_ctx* ctx, int kind, const double* params /*[N][NH_PD_
 /* the same walkers on up to NH_MAX_GRIDS grids in ONE launch (the components of a model
  * evaluation use different particle grids) */
 typedef struct { const double* e_eV; const double* xg; double* w; double* dlw;
-                 double unit_scale; int nG; int pad; } nh_grid;
+                 double unit_scale; int nG; int pad;
+                 const double* ln_e; /* ln e_eV[i], or NULL: taken per node */
+                 const double* lx;   /* ln(xg[i+1]/xg[i]) (nh_grid_logratio), or NULL */
+               } nh_grid;
 #define NH_MAX_GRIDS 4
 int nh_particle_weights_multi(nh_ctx* ctx, int kind, const double* params, int N,
                               const nh_grid* grids /*host [ngrids]*/, int ngrids);
@@ -248,6 +251,23 @@ int nh_move_propose(nh_ctx* ctx, const double* coords, const double* blk, const 
 int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const double* blk, int* cursor,
                    const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
                    int* sel, int advance);
+
+/* The two move kernels and the parameter packs of the NEXT evaluation as one launch (what
+ * the device step loop replays between two model evaluations): accept slice cursor[0]
+ * with newlp (skipped when newlp is NULL), advance the cursor, propose block
+ * [lo, lo+nloc) of the new slice into qT/factors, then evaluate `packs` (the
+ * nh_pack_rows requests of the model, recorded on its first evaluation; their lazy
+ * columns read qT) for the nloc proposed walkers. */
+typedef struct { nh_lazy cols[NH_MAX_LAZY]; int ncols; int ld; double* out; } nh_pack;
+/* chain history, DEVICE-resident (the host rewrites it between runs): after the second
+ * accept of an ensemble step (cursor even) the kernel appends coords[N][ndim] and logp[N]
+ * as row n and increments n, while n < cap.  coords == NULL: nothing is kept. */
+typedef struct { double* coords; double* logp; long long n; long long cap; } nh_hist;
+#define NH_MAX_PACK 4
+int nh_move_cycle(nh_ctx* ctx, double* coords, double* logp, const double* blk, int* cursor,
+                  const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
+                  int* sel, int lo, int nloc, double* qT, double* factors,
+                  const nh_pack* packs /*host*/, int npacks, nh_hist* hist /*device or NULL*/);
 /* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);
@@ -260,6 +280,9 @@ int nh_copy(nh_ctx* ctx, void* dev_dst, const void* dev_src, long long bytes);
  * main); join: the main stream waits for every forked side stream and becomes current
  * again (nh_sync, nh_download and nh_graph_end join implicitly). */
 int nh_stream_fork(nh_ctx* ctx, int side);
+/* as nh_stream_fork, but the side stream waits only for `marker` (nh_marker_record on the
+ * main stream right after the launch whose output the branch consumes) */
+int nh_stream_fork_at(nh_ctx* ctx, int side, void* marker);
 int nh_stream_switch(nh_ctx* ctx, int side);
 int nh_stream_wait(nh_ctx* ctx, int waiter, int producer);
 int nh_stream_join(nh_ctx* ctx);

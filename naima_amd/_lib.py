@@ -67,9 +67,12 @@ _SIGS = {
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
+    "nh_move_cycle": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i,
+                      _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
     "nh_copy": [_dp, _dp, _dp, _ll],
     "nh_stream_fork": [_dp, _i],
+    "nh_stream_fork_at": [_dp, _i, _dp],
     "nh_stream_switch": [_dp, _i],
     "nh_stream_wait": [_dp, _i, _i],
     "nh_stream_join": [_dp],
@@ -160,11 +163,13 @@ class Moves:
 
 class DeviceArray:
     """A float64 (or int32) array in HBM owned by a Context's pool."""
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "__weakref__")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "anchor",
+                 "__weakref__")
 
     def __init__(self, ctx, ptr, shape, dtype, cap):
         self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
         self.stream = ctx.cur_stream  # the stream whose work produces this buffer
+        self.anchor = None
         self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
 
     @property
@@ -213,6 +218,11 @@ class Context:
         self._const = {}
         self._keep = {}
         self._lx = {}
+        self._lne = {}
+        self._pack_plan = None
+        self._anchors = []
+        self._nanchor = 0
+        self.side_small = os.environ.get("NAIMA_AMD_SIDE_SMALL", "0") != "0"
         self._tables = {}
         self.capturing = False
         # side streams (nh_stream_fork/join): -1 = main
@@ -256,12 +266,53 @@ class Context:
         else:
             self._pool.setdefault(cap, []).append(ptr)
 
+    # -- parameter-row packs (nh_pack_rows), recordable for the fused move kernel --
+    def pack_rows(self, cols, ncols, N):
+        """out[N][ncols] from lazy columns.  Normally one nh_pack_rows launch.  The
+        device step loop first RECORDS the requests of a model evaluation (persistent
+        output buffers) and from then on has nh_move_cycle evaluate them right after the
+        proposal; in that REPLAY mode a request only checks that it is the recorded one
+        and returns its buffer."""
+        import ctypes as C
+        raw = bytes(C.string_at(C.addressof(cols), C.sizeof(cols)))
+        plan = self._pack_plan
+        if plan is not None and plan["mode"] == "replay":
+            i = plan["i"]
+            if i >= len(plan["reqs"]) or plan["reqs"][i][:3] != (raw, ncols, N):
+                raise NaimaHipError("the model's parameter packing changed between evaluations; "
+                                    "run the sampler with use_graph=False")
+            plan["i"] = i + 1
+            return plan["reqs"][i][3]
+        out = self.empty((N, ncols))
+        self.call("nh_pack_rows", cols, ncols, N, out, ncols)
+        if plan is not None and plan["mode"] == "record":
+            plan["reqs"].append((raw, ncols, N, out))
+        return out
+
     # -- side streams ---------------------------------------------------------
     def branch(self):
         """context manager: run the enclosed launches on the next side stream (after
         everything issued so far on the main stream).  No-op when already inside a
         branch or when multistream is off."""
         return _Branch(self)
+
+    def anchor(self):
+        """a marker recorded now on the main stream (ring of 16): ``branch_at`` hangs a
+        side stream off this point"""
+        if self.cur_stream != -1:
+            return None
+        if not self._anchors:
+            self._anchors = [self.marker() for _ in range(16)]
+        m = self._anchors[self._nanchor % 16]
+        self._nanchor += 1
+        _chk(_lib.nh_marker_record(self.h, m))
+        return m
+
+    def branch_at(self, anchor):
+        """context manager: the enclosed launches go to a side stream that waits only
+        for ``anchor`` -- small reductions (We, Wp) then run beside the emission kernels
+        issued before them.  No-op without an anchor or inside another branch."""
+        return _Branch(self, anchor=anchor)
 
     def need(self, *objs):
         """make the current stream wait for the streams that produced ``objs``"""
@@ -300,6 +351,7 @@ class Context:
             if len(self._const) > 256:
                 self._const.clear()
                 self._lx.clear()
+                self._lne.clear()
                 self._tables.clear()
             hit = self.array(host, dtype)
             self._const[key] = hit
@@ -313,6 +365,15 @@ class Context:
             hit = self.empty((n - 1,))
             _chk(_lib.nh_grid_logratio(self.h, grid_dev.ptr, n, hit.ptr))
             self._lx[grid_dev.ptr] = hit
+        return hit
+
+    def grid_ln(self, e_dev, e_host):
+        """ln(e[i]) of a cached grid (walker-independent; lets the particle-weights
+        kernel skip its per-node logarithms)"""
+        hit = self._lne.get(e_dev.ptr)
+        if hit is None:
+            hit = self.array(np.log(np.asarray(e_host, dtype=float)))
+            self._lne[e_dev.ptr] = hit
         return hit
 
     def table(self, key, build):
@@ -410,11 +471,20 @@ class Context:
 
 
 class _Branch:
-    def __init__(self, ctx):
-        self.ctx, self.active = ctx, False
+    def __init__(self, ctx, anchor=None):
+        self.ctx, self.active, self.anchor = ctx, False, anchor
 
     def __enter__(self):
         c = self.ctx
+        if self.anchor is not None:
+            if c.cur_stream == -1 and c.side_small:
+                side = c._next_side
+                c._next_side = (side + 1) % 4
+                _chk(_lib.nh_stream_fork_at(c.h, side, self.anchor))
+                c.cur_stream = side
+                c._forked = True
+                self.active = True
+            return self
         if c.multistream and c.cur_stream == -1:
             side = c._next_side
             c._next_side = (side + 1) % 4

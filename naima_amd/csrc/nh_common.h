@@ -173,9 +173,8 @@ struct nh_prior_pack {
 };
 
 // value[w] = a * tf(b * base[w*stride] + c);  base == NULL -> the constant a
-__device__ __forceinline__ double nh_lazy_eval(const nh_lazy& z, long long w) {
-  if (!z.base) return z.a;
-  double x = z.b * z.base[w * z.stride] + z.c;
+__device__ __forceinline__ double nh_lazy_apply(const nh_lazy& z, double raw) {
+  double x = z.b * raw + z.c;
   switch (z.tf) {
     case NH_TF_POW10: x = pow(10.0, x); break;
     case NH_TF_EXP: x = exp(x); break;
@@ -187,6 +186,11 @@ __device__ __forceinline__ double nh_lazy_eval(const nh_lazy& z, long long w) {
     default: break;
   }
   return z.a * x;
+}
+
+__device__ __forceinline__ double nh_lazy_eval(const nh_lazy& z, long long w) {
+  if (!z.base) return z.a;
+  return nh_lazy_apply(z, z.base[w * z.stride]);
 }
 
 // sum of the prior terms of core.py:34-58 for walker w

@@ -164,6 +164,17 @@ extern "C" int nh_stream_fork(nh_ctx* c, int side) {
   return NH_OK;
 }
 
+// the side stream starts after a marker recorded earlier on the main stream (the launch
+// that produced its inputs) instead of after everything issued so far: under capture the
+// branch hangs off that node only and runs beside whatever followed it
+extern "C" int nh_stream_fork_at(nh_ctx* c, int side, void* marker) {
+  NH_REQUIRE(c && side >= 0 && side < NH_NSIDE && marker, "bad argument");
+  NH_CHECK_HIP(hipStreamWaitEvent(c->side[side], reinterpret_cast<hipEvent_t>(marker), 0));
+  c->side_used[side] = true;
+  c->stream = c->side[side];
+  return NH_OK;
+}
+
 extern "C" int nh_stream_switch(nh_ctx* c, int side) {
   NH_REQUIRE(c && side >= -1 && side < NH_NSIDE, "bad side stream");
   c->stream = side < 0 ? c->main_stream : c->side[side];
@@ -325,23 +336,24 @@ __device__ __forceinline__ double pd_expm1_small(double d) { return expm1(d); }
 // and the log-ratio of the SHAPE to the next node, ln f(E2)/f(E1), assembled from
 // small pieces with lr = ln(E2/E1):  power laws -> -alpha lr;  cutoff ->
 // -(t2 - t1) = -t1 expm1(beta lr);  log-parabola -> -alpha lr - beta lr (l1 + l2).
-__device__ __forceinline__ void pd_node(int kind, const pd_par& p, double E, double E2,
-                                        double lr, double& n, double& dsh) {
-  const double lxx = log(E / p.e0);
+// Inputs are logarithms: lxx = ln(E/e_0), lxc = ln(E/e_cutoff), lkb = ln(e_break/e_0);
+// b1, b2 say whether this node / the next one lie below the break.
+__device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, double lxc,
+                                        double lkb, bool b1, bool b2, double lr, double& n,
+                                        double& dsh) {
   switch (kind) {
     case NH_PD_POWERLAW:
       n = p.A * exp(-p.al * lxx);
       dsh = -p.al * lr;
       break;
     case NH_PD_ECPL: {
-      const double t = exp(p.be * log(E / p.ec));
+      const double t = exp(p.be * lxc);
       n = p.A * exp(-p.al * lxx - t);
       dsh = -p.al * lr - t * pd_expm1_small(p.be * lr);
     } break;
     case NH_PD_BROKENPL:
     case NH_PD_ECBPL: {
-      const bool b1 = E < p.eb, b2 = E2 < p.eb;
-      const double lK = (p.a2 - p.al) * log(p.eb / p.e0);
+      const double lK = (p.a2 - p.al) * lkb;
       double ex = (b1 ? 0.0 : lK) - (b1 ? p.al : p.a2) * lxx;
       if (b1 == b2) {
         dsh = -(b1 ? p.al : p.a2) * lr;
@@ -350,7 +362,7 @@ __device__ __forceinline__ void pd_node(int kind, const pd_par& p, double E, dou
               ((b2 ? p.al : p.a2) * (lxx + lr) - (b1 ? p.al : p.a2) * lxx);
       }
       if (kind == NH_PD_ECBPL) {
-        const double t = exp(p.be * log(E / p.ec));
+        const double t = exp(p.be * lxc);
         ex -= t;
         dsh -= t * pd_expm1_small(p.be * lr);
       }
@@ -361,6 +373,22 @@ __device__ __forceinline__ void pd_node(int kind, const pd_par& p, double E, dou
       dsh = -p.al * lr - p.be * lr * (lxx + (lxx + lr));
     } break;
   }
+}
+
+__device__ __forceinline__ bool pd_has_cutoff(int kind) {
+  return kind == NH_PD_ECPL || kind == NH_PD_ECBPL;
+}
+__device__ __forceinline__ bool pd_has_break(int kind) {
+  return kind == NH_PD_BROKENPL || kind == NH_PD_ECBPL;
+}
+
+// the same from energies (three logarithms per node)
+__device__ __forceinline__ void pd_node(int kind, const pd_par& p, double E, double E2,
+                                        double lr, double& n, double& dsh) {
+  const double lxx = log(E / p.e0);
+  const double lxc = pd_has_cutoff(kind) ? log(E / p.ec) : 0.0;
+  const double lkb = pd_has_break(kind) ? log(p.eb / p.e0) : 0.0;
+  pd_core(kind, p, lxx, lxc, lkb, E < p.eb, E2 < p.eb, lr, n, dsh);
 }
 
 __global__ __launch_bounds__(256) void k_particle_weights(
@@ -389,40 +417,54 @@ __global__ __launch_bounds__(256) void k_particle_weights(
 struct pw_grids {
   const double* e[NH_MAX_GRIDS];
   const double* xg[NH_MAX_GRIDS];
+  const double* lne[NH_MAX_GRIDS];  // ln e_eV per node, or NULL
+  const double* lx[NH_MAX_GRIDS];   // ln(xg[i+1]/xg[i]) per segment, or NULL
   double* w[NH_MAX_GRIDS];
   double* dlw[NH_MAX_GRIDS];
   double scale[NH_MAX_GRIDS];
   int nG[NH_MAX_GRIDS];
-  long long off[NH_MAX_GRIDS + 1];  // element offsets of the grids in the flat index
+  int off[NH_MAX_GRIDS + 1];  // node offsets of the grids in one walker's flat index
   int n;
 };
 
 // the same walkers on several grids (the components of one model evaluation use
-// different electron grids: Synchrotron from 1 GeV, IC from Eemin, We(> 1 TeV) ...)
+// different electron grids: Synchrotron from 1 GeV, IC from Eemin, We(> 1 TeV) ...).
+// Block = (walker, 256 nodes of the concatenated grids): the walker's parameter row
+// arrives through the scalar cache and its logarithms are taken once per block; with
+// the grid's own logarithms (ln e, lx: walker-independent, cached by the host) a node
+// costs two exponentials instead of four logarithms, four divisions and two exponentials.
 __global__ __launch_bounds__(256) void k_particle_weights_multi(
     int kind, const double* __restrict__ params, int N, pw_grids G) {
-  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G.off[G.n]) return;
-  int g = 0;
-  while (g + 1 < G.n && idx >= G.off[g + 1]) ++g;
-  const long long loc = idx - G.off[g];
-  const int nG = G.nG[g];
-  const int wi = (int)(loc / nG), i = (int)(loc % nG);
+  const int wi = blockIdx.x;
   const double* pr = params + (long long)wi * NH_PD_NPAR;
-  pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  const pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  __shared__ double lg[3];
+  if (threadIdx.x < 3) {
+    const double v = threadIdx.x == 0 ? p.e0 : (threadIdx.x == 1 ? p.ec : p.eb);
+    lg[threadIdx.x] = v > 0.0 ? log(v) : 0.0;
+  }
+  __syncthreads();
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= G.off[G.n]) return;
+  int g = 0;
+  while (g + 1 < G.n && j >= G.off[g + 1]) ++g;
+  const int i = j - G.off[g];
+  const int nG = G.nG[g];
   const double* e = G.e[g];
   const double* xg = G.xg[g];
-  const double E = e[i];
   const bool last = i + 1 >= nG;
+  const double E = e[i];
   const double E2 = last ? E : e[i + 1];
   const double gx = xg[i];
-  const double lrE = last ? 0.0 : log(E2 / E);
-  const double lrx = last ? 0.0 : log(xg[i + 1] / gx);
+  double lr = 0.0;
+  if (!last) lr = G.lx[g] ? G.lx[g][i] : log(xg[i + 1] / gx);
+  const double lnE = G.lne[g] ? G.lne[g][i] : log(E);
   double n, dsh;
-  pd_node(kind, p, E, E2, lrE, n, dsh);
+  pd_core(kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, n, dsh);
   n *= G.scale[g];
+  const long long loc = (long long)wi * nG + i;
   G.w[g][loc] = gx * n;
-  G.dlw[g][loc] = last ? 0.0 : lrx + dsh;
+  G.dlw[g][loc] = last ? 0.0 : lr + dsh;
 }
 
 extern "C" int nh_particle_weights_multi(nh_ctx* c, int kind, const double* params, int N,
@@ -438,12 +480,15 @@ extern "C" int nh_particle_weights_multi(nh_ctx* c, int kind, const double* para
     NH_REQUIRE(grids[g].e_eV && grids[g].xg && grids[g].w && grids[g].dlw && grids[g].nG >= 2,
                "bad grid descriptor");
     G.e[g] = grids[g].e_eV; G.xg[g] = grids[g].xg; G.w[g] = grids[g].w; G.dlw[g] = grids[g].dlw;
+    G.lne[g] = grids[g].ln_e; G.lx[g] = grids[g].lx;
     G.scale[g] = grids[g].unit_scale; G.nG[g] = grids[g].nG;
-    G.off[g + 1] = G.off[g] + (long long)N * grids[g].nG;
+    NH_REQUIRE((long long)G.off[g] + grids[g].nG < (1LL << 30), "grids too long");
+    G.off[g + 1] = G.off[g] + grids[g].nG;
   }
   nh_prof_scope ps(c, NH_K_PDIST);
-  hipLaunchKernelGGL(k_particle_weights_multi, dim3((unsigned)((G.off[ngrids] + 255) / 256)),
-                     dim3(256), 0, c->stream, kind, params, N, G);
+  hipLaunchKernelGGL(k_particle_weights_multi,
+                     dim3((unsigned)N, (unsigned)((G.off[ngrids] + 255) / 256)), dim3(256), 0,
+                     c->stream, kind, params, N, G);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

@@ -35,7 +35,12 @@ class nh_comp(C.Structure):
 
 class nh_grid(C.Structure):
     _fields_ = [("e_eV", C.c_void_p), ("xg", C.c_void_p), ("w", C.c_void_p), ("dlw", C.c_void_p),
-                ("unit_scale", C.c_double), ("nG", C.c_int), ("pad", C.c_int)]
+                ("unit_scale", C.c_double), ("nG", C.c_int), ("pad", C.c_int),
+                ("ln_e", C.c_void_p), ("lx", C.c_void_p)]
+
+
+class nh_pack(C.Structure):
+    _fields_ = [("cols", nh_lazy * 8), ("ncols", C.c_int), ("ld", C.c_int), ("out", C.c_void_p)]
 
 
 class nh_prior(C.Structure):

@@ -71,7 +71,18 @@ class DeviceLoop:
         # the random numbers of up to KSTEPS ensemble steps travel as ONE block; a device
         # cursor selects the current half-step's slice (advanced by the accept kernel)
         self.KSTEPS = 32
-        self.blk = ctx.empty((2 * self.KSTEPS, 3 * self.ns))
+        # one spare slice: the fused move kernel proposes the half-step AFTER the one it
+        # accepts, so the last one of a block reads (and discards) slice 2*KSTEPS
+        self.blk = ctx.empty((2 * self.KSTEPS + 1, 3 * self.ns))
+        ctx.call("nh_memset", self.blk, 0, self.blk.nbytes)
+        # nh_move_cycle mode: set after the first (eager, recording) evaluation when all
+        # of the model's parameter packs read the proposal buffer
+        self.fused = False
+        self._plan = None
+        self._packs = None
+        # nh_hist descriptor in HBM: the fused kernel appends the chain history itself
+        self.histd = ctx.empty((4,), dtype=np.int64)
+        ctx.call("nh_memset", self.histd, 0, self.histd.nbytes)
         self.cursor = ctx.empty((1,), dtype=np.int32)
         self.sel = ctx.empty((self.ns,), dtype=np.int32)
         self.qT = ctx.empty((self.ndim * self.nloc,))
@@ -125,9 +136,18 @@ class DeviceLoop:
         """propose this rank's block and evaluate it: everything up to the new
         log-probabilities (the part that precedes the exchange)"""
         ctx = self.ctx
-        ctx.call("nh_move_propose", self.coords, self.blk, self.cursor, self.ns, self.ndim,
-                 self.lo, self.nloc, self.qT, self.factors)
-        total, blobs = self._eval(self.qT, self.nloc)
+        if self.fused:
+            # proposal and parameter rows were written by the previous nh_move_cycle
+            self._plan["i"] = 0
+            ctx._pack_plan = self._plan
+        else:
+            ctx.call("nh_move_propose", self.coords, self.blk, self.cursor, self.ns, self.ndim,
+                     self.lo, self.nloc, self.qT, self.factors)
+        try:
+            total, blobs = self._eval(self.qT, self.nloc)
+        finally:
+            if self.fused:
+                ctx._pack_plan = None
         if self.s.comm.size > 1:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses
@@ -151,12 +171,50 @@ class DeviceLoop:
 
     def _part_accept(self):
         ctx = self.ctx
-        ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor, self._newlp_ptr,
-                 self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
+        if self.fused:
+            self._cycle(self._newlp_ptr)
+        else:
+            ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
+                     self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
         if self.s.store_blobs and self.cur_blobs:
             for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
                 ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
                          self.nloc, m)
+
+    def _cycle(self, newlp):
+        """accept (when ``newlp``) + advance + propose + parameter packs: one launch"""
+        self.ctx.call("nh_move_cycle", self.coords, self.logp, self.blk, self.cursor, newlp,
+                      self.ns, self.ndim, self.accepted, self.nacc, self.sel, self.lo, self.nloc,
+                      self.qT, self.factors, self._packs, len(self._plan["reqs"]), self.histd)
+
+    def _record_half_step(self):
+        """the first half-step: launched piece by piece while the model's nh_pack_rows
+        requests are recorded; if they all read the proposal buffer (or constants) the
+        loop switches to nh_move_cycle"""
+        import ctypes as C
+        from .darray import nh_lazy, nh_pack
+        ctx = self.ctx
+        ctx._pack_plan = plan = dict(mode="record", reqs=[], i=0)
+        try:
+            self._half_step_body()
+        finally:
+            ctx._pack_plan = None
+        lo_a, hi_a = self.qT.ptr, self.qT.ptr + self.qT.nbytes
+        ok = 0 < len(plan["reqs"]) <= 4
+        packs = (nh_pack * 4)()
+        for q, (raw, ncols, N, out) in enumerate(plan["reqs"][:4]):
+            cols = (nh_lazy * 8).from_buffer_copy(raw.ljust(C.sizeof(nh_lazy) * 8, b"\0"))
+            for j in range(ncols):
+                base = cols[j].base or 0
+                ok = ok and (base == 0 or lo_a <= base < hi_a)
+            ok = ok and N == self.nloc and ncols <= 8
+            packs[q].cols = cols
+            packs[q].ncols, packs[q].ld, packs[q].out = ncols, ncols, out.ptr
+        if not ok or not self.s.fuse_moves:
+            return
+        plan["mode"] = "replay"
+        self._plan, self._packs, self.fused = plan, packs, True
+        self._cycle(None)  # proposal + rows of the next half-step
 
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
@@ -227,6 +285,12 @@ class DeviceLoop:
                          blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
                                 (self.cur_blobs or [])] if s.store_blobs else [])
             self.hist.append(block)
+        # chain history: appended on the device by nh_move_cycle when it is active for
+        # the whole call, else one pair of copies per step
+        dev_hist = self.fused and block is not None
+        if self.fused:
+            self.histd.set(np.array([block["coords"].ptr, block["logp"].ptr, 0, iterations]
+                                    if dev_hist else [0, 0, 0, 0], dtype=np.int64))
         moves = s.moves(pinned=True)
         it = 0
         while it < iterations:
@@ -237,6 +301,8 @@ class DeviceLoop:
             addr, K = moves.take(min(self.KSTEPS, iterations - it))
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
             ctx.call("nh_memset", self.cursor, 0, 4)
+            if self.fused:
+                self._cycle(None)  # slice 0 of the new block
             mark = self._markers[self._nmark % len(self._markers)]
             self._nmark += 1
             ctx.call("nh_marker_record", mark)
@@ -247,9 +313,10 @@ class DeviceLoop:
                 s.iteration += 1
                 if block is not None:
                     k = block["n"]
-                    ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim, self.coords,
-                             8 * N * self.ndim)
-                    ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
+                    if not dev_hist:
+                        ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim,
+                                 self.coords, 8 * N * self.ndim)
+                        ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
                     for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
                         ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
                     block["n"] = k + 1
@@ -279,7 +346,7 @@ class DeviceLoop:
             ctx.graph_launch(self.step_graph)
             return
         if self.warm < 1:
-            self._half_step_body()
+            self._record_half_step()
             self.warm += 1
             self._half_step_body()
             return
@@ -303,9 +370,12 @@ class DeviceLoop:
                 self._exchange()
                 ctx.graph_launch(self.graph2)
             return
-        if not s.use_graph or self.warm < 1:
-            self._half_step_body()
+        if self.warm < 1:
+            self._record_half_step()
             self.warm += 1
+            return
+        if not s.use_graph:
+            self._half_step_body()
             return
         if not multi:
             self.graph = self._capture(self._half_step_body)

@@ -132,8 +132,7 @@ class _ParticleDistribution:
                 cols[slot] = nh_lazy(dev.ptr, 1, 1.0, 1.0, 0.0, 0, 0)
                 keep.append(dev)
         ctx.need(*[getattr(k, "owner", k) for k in keep])
-        out = ctx.empty((N, NH_PD_NPAR))
-        ctx.call("nh_pack_rows", cols, NH_PD_NPAR, N, out, NH_PD_NPAR)
+        out = ctx.pack_rows(cols, NH_PD_NPAR, N)
         cache[key] = out
         return out
 

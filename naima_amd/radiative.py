@@ -147,7 +147,7 @@ class BaseRadiative:
         if hit is None:
             if not cache:
                 ctx._weval += 1
-            reg[key] = (ctx._weval, xd, ed)
+            reg[key] = (ctx._weval, xd, ed, ctx.grid_ln(ed, e_eV), lx)
             # every grid used by the last two evaluations of this kind, this one first
             todo = [key] + [k for k, v in reg.items() if k != key and k not in cache
                             and ctx._weval - v[0] <= 2][:3]
@@ -156,14 +156,20 @@ class BaseRadiative:
             rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
             desc = (nh_grid * len(todo))()
             for j, k in enumerate(todo):
-                _, xdk, edk = reg[k]
+                _, xdk, edk, lnek, lxk = reg[k]
                 wk, lwk = ctx.empty((N, k[3])), ctx.empty((N, k[3]))
-                desc[j] = nh_grid(edk.ptr, xdk.ptr, wk.ptr, lwk.ptr, k[2], k[3], 0)
+                desc[j] = nh_grid(edk.ptr, xdk.ptr, wk.ptr, lwk.ptr, k[2], k[3], 0, lnek.ptr,
+                                  lxk.ptr)
                 cache[k] = (wk, lwk)
             ctx.call("nh_particle_weights_multi", PD_KIND[pd.kind], rows, N, desc, len(todo))
+            if self.on_device:
+                # We/Wp reductions hang a side stream off this launch (ctx.branch_at)
+                mark = ctx.anchor()
+                for k in todo:
+                    cache[k][0].anchor = mark
             hit = cache[key]
         else:
-            reg[key] = (ctx._weval, xd, ed)
+            reg[key] = (ctx._weval, xd, ed, ctx.grid_ln(ed, e_eV), lx)
         ctx.need(hit[0])
         return ctx, N, hit[0], hit[1], xd, lx
 
@@ -275,9 +281,15 @@ class BaseElectron(BaseRadiative):
         return n if self.is_batched else n[0]
 
     def _We_on(self, gam):
+        ctx = get_context()
+        if self.on_device and ctx.multistream:
+            self._prefork(ctx)
+            with ctx.branch():
+                return self._We_on_impl(gam)
         if self.on_device:
-            self._prefork(get_context())
-            with get_context().branch():
+            # the weights on the main stream, the small reduction beside what follows them
+            w = self._electron_weights(gam)[2]
+            with ctx.branch_at(getattr(w, "anchor", None)):
                 return self._We_on_impl(gam)
         return self._We_on_impl(gam)
 
@@ -711,9 +723,14 @@ class BaseProton(BaseRadiative):
         return J if self.is_batched else J[0]
 
     def _Wp_on(self, Ep):
+        ctx = get_context()
+        if self.on_device and ctx.multistream:
+            self._prefork(ctx)
+            with ctx.branch():
+                return self._Wp_on_impl(Ep)
         if self.on_device:
-            self._prefork(get_context())
-            with get_context().branch():
+            w = self._proton_weights(Ep)[2]
+            with ctx.branch_at(getattr(w, "anchor", None)):
                 return self._Wp_on_impl(Ep)
         return self._Wp_on_impl(Ep)
 

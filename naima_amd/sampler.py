@@ -13,6 +13,8 @@ statistical, not bitwise ("parity unpinned").
 """
 import time
 
+import os
+
 import numpy as np
 
 from . import units as u
@@ -73,6 +75,8 @@ class EnsembleSampler:
         # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)
         self.device = bool(device)
         self.use_graph = bool(use_graph)
+        # accept + next proposal + parameter packs as ONE launch (nh_move_cycle)
+        self.fuse_moves = os.environ.get("NAIMA_AMD_FUSE_MOVES", "1") != "0"
         self._dev = None
         self.n_lnprob_calls = 0
         self.n_walker_evals = 0
