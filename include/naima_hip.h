@@ -252,22 +252,42 @@ int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const double* blk,
                    const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
                    int* sel, int advance);
 
-/* The two move kernels and the parameter packs of the NEXT evaluation as one launch (what
- * the device step loop replays between two model evaluations): accept slice cursor[0]
- * with newlp (skipped when newlp is NULL), advance the cursor, propose block
- * [lo, lo+nloc) of the new slice into qT/factors, then evaluate `packs` (the
- * nh_pack_rows requests of the model, recorded on its first evaluation; their lazy
- * columns read qT) for the nloc proposed walkers. */
+/* ---- the two launches that bracket a model evaluation in the device step loop ------
+ * Slice protocol of these two: cursor[0] = index of the slice whose proposals are being
+ * evaluated (-1 right after a block upload).
+ *
+ * nh_step_front (one block per proposed walker): proposes block [lo, lo+nloc) of slice
+ * cursor[0]+1 into qT/factors, evaluates `packs` (the nh_pack_rows requests the model
+ * made on its first evaluation; their lazy columns read qT or are constants) for the
+ * proposed walkers, then the particle weights of nh_particle_weights_multi(kind, params,
+ * nloc, grids) -- params must be one of the pack outputs -- and `moms`: single-row
+ * reductions (We, Wp: nh_integrate_tables with nK = 1) over one of those grids.  When the
+ * slice just accepted closed an ensemble step (cursor odd) the chain history row is
+ * appended first.  The last block to finish advances the cursor.  `done` is a zeroed
+ * device int the launch uses to find that block. */
 typedef struct { nh_lazy cols[NH_MAX_LAZY]; int ncols; int ld; double* out; } nh_pack;
-/* chain history, DEVICE-resident (the host rewrites it between runs): after the second
- * accept of an ensemble step (cursor even) the kernel appends coords[N][ndim] and logp[N]
- * as row n and increments n, while n < cap.  coords == NULL: nothing is kept. */
-typedef struct { double* coords; double* logp; long long n; long long cap; } nh_hist;
 #define NH_MAX_PACK 4
-int nh_move_cycle(nh_ctx* ctx, double* coords, double* logp, const double* blk, int* cursor,
-                  const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
-                  int* sel, int lo, int nloc, double* qT, double* factors,
-                  const nh_pack* packs /*host*/, int npacks, nh_hist* hist /*device or NULL*/);
+/* chain history, DEVICE-resident (the host rewrites it between runs): row n receives
+ * coords[N][ndim] and logp[N], n is incremented, while n < cap.  coords == NULL: off. */
+typedef struct { double* coords; double* logp; long long n; long long cap; } nh_hist;
+typedef struct { int grid; int pad; const double* Kt; const double* dlnKt; double* out; } nh_moment;
+#define NH_MAX_MOMENT 4
+int nh_step_front(nh_ctx* ctx, const double* coords, const double* logp, const double* blk,
+                  int* cursor, int* done, int ns, int ndim, int lo, int nloc, double* qT,
+                  double* factors, const nh_pack* packs /*host*/, int npacks, int kind,
+                  const double* params, const nh_grid* grids /*host*/, int ngrids,
+                  const nh_moment* moms /*host*/, int nmoms, nh_hist* hist /*device or NULL*/);
+
+/* nh_lnprob followed, in the same launch, by the accept of nh_move_accept for walkers
+ * [lo, lo+N) of slice cursor[0] (single-rank loop: every walker's new log-probability is
+ * the one this launch just computed).  The cursor is not advanced (nh_step_front does). */
+typedef struct { double* coords; double* logp; const double* blk; const int* cursor; int ns;
+                 int ndim; int lo; int pad; int* accepted; int* naccepted; int* sel; } nh_accept;
+int nh_lnprob_accept(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, int N, int nE,
+                     const double* conv, const double* flux, const double* err_lo,
+                     const double* err_hi, const int* ul, const double* cl, const double* lp,
+                     const nh_prior* terms /*host*/, int nterms, double* model_out,
+                     double* total, const nh_accept* mv /*host*/);
 /* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);

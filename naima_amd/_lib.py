@@ -67,8 +67,10 @@ _SIGS = {
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
-    "nh_move_cycle": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i,
-                      _dp],
+    "nh_step_front": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp,
+                      _i, _dp, _i, _dp],
+    "nh_lnprob_accept": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp,
+                         _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
     "nh_copy": [_dp, _dp, _dp, _ll],
     "nh_stream_fork": [_dp, _i],
@@ -219,7 +221,10 @@ class Context:
         self._keep = {}
         self._lx = {}
         self._lne = {}
-        self._pack_plan = None
+        self._plan = None
+        self._accept_hook = None
+        self._pinned = set()
+        self._pinned_ptrs = set()
         self._anchors = []
         self._nanchor = 0
         self.side_small = os.environ.get("NAIMA_AMD_SIDE_SMALL", "0") != "0"
@@ -266,28 +271,83 @@ class Context:
         else:
             self._pool.setdefault(cap, []).append(ptr)
 
-    # -- parameter-row packs (nh_pack_rows), recordable for the fused move kernel --
+    # -- launches that the device step loop folds into nh_step_front ------------------
+    # The loop first RECORDS what a model evaluation asks for (parameter packs, the
+    # particle-weights launch, single-row reductions such as We; persistent output
+    # buffers), then has nh_step_front produce all of it right after the proposal; in
+    # REPLAY mode a request only checks that it is the recorded one and returns its
+    # buffers.
+    def plan_begin(self):
+        self._plan = dict(mode="record", packs=[], weights=[], moments=[], i=[0, 0, 0])
+        return self._plan
+
+    def _replayed(self, kind, slot, key):
+        plan = self._plan
+        if plan is None or plan["mode"] != "replay":
+            return None
+        i = plan["i"][slot]
+        if i >= len(plan[kind]) or plan[kind][i][0] != key:
+            raise NaimaHipError("the model's launch sequence changed between evaluations (%s); "
+                                "run the sampler with use_graph=False" % kind)
+        plan["i"][slot] = i + 1
+        return plan[kind][i][1]
+
+    def _recorded(self, kind, key, value):
+        if self._plan is not None and self._plan["mode"] == "record":
+            self._plan[kind].append((key, value))
+        return value
+
     def pack_rows(self, cols, ncols, N):
-        """out[N][ncols] from lazy columns.  Normally one nh_pack_rows launch.  The
-        device step loop first RECORDS the requests of a model evaluation (persistent
-        output buffers) and from then on has nh_move_cycle evaluate them right after the
-        proposal; in that REPLAY mode a request only checks that it is the recorded one
-        and returns its buffer."""
+        """out[N][ncols] from lazy columns (one nh_pack_rows launch unless replayed)"""
         import ctypes as C
-        raw = bytes(C.string_at(C.addressof(cols), C.sizeof(cols)))
-        plan = self._pack_plan
-        if plan is not None and plan["mode"] == "replay":
-            i = plan["i"]
-            if i >= len(plan["reqs"]) or plan["reqs"][i][:3] != (raw, ncols, N):
-                raise NaimaHipError("the model's parameter packing changed between evaluations; "
-                                    "run the sampler with use_graph=False")
-            plan["i"] = i + 1
-            return plan["reqs"][i][3]
+        key = (bytes(C.string_at(C.addressof(cols), C.sizeof(cols))), ncols, N)
+        hit = self._replayed("packs", 0, key)
+        if hit is not None:
+            return hit
         out = self.empty((N, ncols))
         self.call("nh_pack_rows", cols, ncols, N, out, ncols)
-        if plan is not None and plan["mode"] == "record":
-            plan["reqs"].append((raw, ncols, N, out))
-        return out
+        return self._recorded("packs", key, out)
+
+    def weights_multi(self, kind, rows, N, grids):
+        """particle weights of N walkers on several grids: ``grids`` is a list of
+        (e_eV, xg, ln_e, lx, unit_scale, nG) with device arrays; returns [(w, dlw)]"""
+        from .darray import nh_grid
+        key = (kind, rows.ptr, N, tuple((g[0].ptr, g[1].ptr, g[2].ptr, g[3].ptr, g[4], g[5])
+                                        for g in grids))
+        hit = self._replayed("weights", 1, key)
+        if hit is not None:
+            return hit
+        desc = (nh_grid * len(grids))()
+        out = []
+        for j, (ed, xd, lne, lx, scale, nG) in enumerate(grids):
+            wk, lwk = self.empty((N, nG)), self.empty((N, nG))
+            desc[j] = nh_grid(ed.ptr, xd.ptr, wk.ptr, lwk.ptr, scale, nG, 0, lne.ptr, lx.ptr)
+            out.append((wk, lwk))
+        self.call("nh_particle_weights_multi", kind, rows, N, desc, len(grids))
+        return self._recorded("weights", key, out)
+
+    def weights_replay(self, kind, rows, N):
+        """REPLAY mode: the grids and buffers of the recorded weights launch (the grid
+        bookkeeping of the radiative classes is shared state and is bypassed), else None"""
+        plan = self._plan
+        if plan is None or plan["mode"] != "replay":
+            return None
+        i = plan["i"][1]
+        if i >= len(plan["weights"]) or plan["weights"][i][0][:3] != (kind, rows.ptr, N):
+            raise NaimaHipError("the model's launch sequence changed between evaluations "
+                                "(weights); run the sampler with use_graph=False")
+        plan["i"][1] = i + 1
+        return plan["weights"][i][0][3], plan["weights"][i][1]
+
+    def moment(self, w, lw, N, nG, lx, Kt, dlnKt):
+        """out[N] = trapz_loglog(n * K, x) for ONE table row K (We, Wp)"""
+        key = (w.ptr, lw.ptr, N, nG, lx.ptr, Kt.ptr, dlnKt.ptr)
+        hit = self._replayed("moments", 2, key)
+        if hit is not None:
+            return hit
+        out = self.empty((N, 1))
+        self.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, 1, None, out, 1, 0)
+        return self._recorded("moments", key, out)
 
     # -- side streams ---------------------------------------------------------
     def branch(self):
@@ -348,14 +408,24 @@ class Context:
         key = (host.shape, host.dtype.str, hash(host.tobytes()))
         hit = self._const.get(key)
         if hit is None:
-            if len(self._const) > 256:
-                self._const.clear()
-                self._lx.clear()
-                self._lne.clear()
-                self._tables.clear()
+            if len(self._const) > 256 + len(self._pinned):
+                self._evict()
             hit = self.array(host, dtype)
             self._const[key] = hit
         return hit
+
+    def pin_caches(self):
+        """a captured graph (or a recorded step plan) holds raw pointers into the cached
+        constants, grids and tables that exist now: they are never evicted"""
+        self._pinned = set(self._const) | set(self._tables)
+        self._pinned_ptrs = {v.ptr for v in self._const.values()}
+
+    def _evict(self):
+        keep = self._pinned
+        self._const = {k: v for k, v in self._const.items() if k in keep}
+        self._tables = {k: v for k, v in self._tables.items() if k in keep}
+        self._lx = {k: v for k, v in self._lx.items() if k in self._pinned_ptrs}
+        self._lne = {k: v for k, v in self._lne.items() if k in self._pinned_ptrs}
 
     def grid_logratio(self, grid_dev):
         """lx[i] = ln(x[i+1]/x[i]) for a cached grid (computed once on device)"""
@@ -381,8 +451,8 @@ class Context:
         pointers of the content-addressed grid/energy arrays + scalar parameters)"""
         hit = self._tables.get(key)
         if hit is None:
-            if len(self._tables) > 64:
-                self._tables.clear()
+            if len(self._tables) > 64 + len(self._pinned):
+                self._tables = {k: v for k, v in self._tables.items() if k in self._pinned}
             hit = build()
             self._tables[key] = hit
         return hit

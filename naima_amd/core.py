@@ -162,9 +162,17 @@ def lnprobmodel(model, data, lp=None):
                 lpd = lp.evaluate()
         elif lp is not None:
             lpd = lp.dense()
-        ctx.call("nh_lnprob", m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),
-                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpd.ptr if lpd is not None else None,
-                 terms, nterms, None, total)
+        args = (m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),
+                dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpd.ptr if lpd is not None else None,
+                terms, nterms, None, total)
+        hook = ctx._accept_hook
+        if hook is not None and hook["N"] == N and not hook["used"]:
+            # device step loop, single rank: the stretch move's accept rides on this launch
+            import ctypes as C
+            ctx.call("nh_lnprob_accept", *args, C.addressof(hook["mv"]))
+            hook["used"] = True
+        else:
+            ctx.call("nh_lnprob", *args)
         del lpd
         return DVec(ctx, total, total.ptr, N)
     import ctypes as C

@@ -493,6 +493,209 @@ extern "C" int nh_particle_weights_multi(nh_ctx* c, int kind, const double* para
   return NH_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The launch in FRONT of a model evaluation in the device step loop: proposal of the
+// stretch move (emcee StretchMove.get_proposal; call sites core.py:128, 450-457), the
+// parameter rows the model packs from it, the particle weights on all of the model's
+// grids and the single-row reductions (We/Wp) -- four dependent small launches as one.
+// One block per proposed walker; everything a later stage needs from an earlier one
+// stays in LDS.  See include/naima_hip.h for the slice protocol.
+// ---------------------------------------------------------------------------
+struct front_args {
+  const double* coords; const double* logp; const double* blk;
+  int* cursor; int* done;
+  int ns, ndim, lo, nloc;
+  double* qT; double* factors;
+  nh_hist* hist;
+  nh_pack pk[NH_MAX_PACK]; int npk;
+  int kind; const double* params;
+  pw_grids G;
+  nh_moment mom[NH_MAX_MOMENT]; int nmom;
+  int mom_off[NH_MAX_GRIDS];  // LDS offset (nodes) of a grid's w/dlw copy, or -1
+  int mom_nodes;              // LDS nodes in total
+};
+
+__global__ __launch_bounds__(1024) void k_step_front(front_args A) {
+  extern __shared__ double sm[];
+  double* qs = sm;                       // [ndim]    this walker's proposal
+  double* row = qs + A.ndim;             // [8]       its particle-distribution row
+  double* lg = row + NH_PD_NPAR;         // [3]       ln e_0, ln e_cutoff, ln e_break
+  double* ws = lg + 3;                   // [mom_nodes] w of the grids that have a reduction
+  double* ds = ws + A.mom_nodes;         // [mom_nodes] dlw
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const int c = A.cursor[0];             // slice accepted last (-1: none yet)
+  const int cn = c + 1;                  // slice proposed here
+  const double* r = A.blk + (long long)cn * 3 * A.ns;
+  const int* idx = reinterpret_cast<const int*>(r + 2 * A.ns);
+  // ---- chain history of the ensemble step that the last accept closed -------------
+  bool appended = false;
+  if (A.hist && c >= 0 && (c & 1)) {
+    const long long rowh = A.hist->n;
+    if (A.hist->coords && rowh < A.hist->cap) {
+      appended = true;
+      const long long N = 2LL * A.ns, nc = N * A.ndim;
+      double* hc = A.hist->coords + rowh * nc;
+      double* hl = A.hist->logp + rowh * N;
+      for (long long t = (long long)j * blockDim.x + tid; t < nc; t += (long long)gridDim.x * blockDim.x)
+        hc[t] = A.coords[t];
+      for (long long t = (long long)j * blockDim.x + tid; t < N; t += (long long)gridDim.x * blockDim.x)
+        hl[t] = A.logp[t];
+    }
+  }
+  // ---- proposal -------------------------------------------------------------------
+  if (tid < A.ndim) {
+    const int g = A.lo + j;
+    const double z = r[g];
+    const double cj = A.coords[(long long)idx[A.ns + g] * A.ndim + tid];
+    const double sj = A.coords[(long long)idx[g] * A.ndim + tid];
+    const double q = cj - (cj - sj) * z;
+    A.qT[(long long)tid * A.nloc + j] = q;
+    qs[tid] = q;
+    if (tid == 0) A.factors[j] = (A.ndim - 1.0) * log(z);
+  }
+  __syncthreads();
+  // ---- parameter packs (columns read this walker's proposal or are constants) -----
+  if (tid < A.npk * NH_MAX_LAZY) {
+    const int q = tid / NH_MAX_LAZY, col = tid % NH_MAX_LAZY;
+    if (col < A.pk[q].ncols) {
+      const nh_lazy& z = A.pk[q].cols[col];
+      double v = z.a;
+      if (z.base) v = nh_lazy_apply(z, qs[(z.base - A.qT) / A.nloc]);
+      A.pk[q].out[(long long)j * A.pk[q].ld + col] = v;
+      if (A.pk[q].out == A.params) row[col] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const double v = row[tid == 0 ? 1 : (tid == 1 ? 3 : 5)];
+    lg[tid] = v > 0.0 ? log(v) : 0.0;
+  }
+  __syncthreads();
+  // ---- particle weights on every grid ---------------------------------------------
+  const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
+  const pw_grids& G = A.G;
+  for (int n = tid; n < G.off[G.n]; n += blockDim.x) {
+    int g = 0;
+    while (g + 1 < G.n && n >= G.off[g + 1]) ++g;
+    const int i = n - G.off[g];
+    const int nG = G.nG[g];
+    const double* e = G.e[g];
+    const double* xg = G.xg[g];
+    const bool last = i + 1 >= nG;
+    const double E = e[i];
+    const double E2 = last ? E : e[i + 1];
+    const double gx = xg[i];
+    double lr = 0.0;
+    if (!last) lr = G.lx[g] ? G.lx[g][i] : log(xg[i + 1] / gx);
+    const double lnE = G.lne[g] ? G.lne[g][i] : log(E);
+    double nn, dsh;
+    pd_core(A.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn, dsh);
+    nn *= G.scale[g];
+    const long long loc = (long long)j * nG + i;
+    const double wv = gx * nn, dv = last ? 0.0 : lr + dsh;
+    G.w[g][loc] = wv;
+    G.dlw[g][loc] = dv;
+    if (A.mom_off[g] >= 0) {
+      ws[A.mom_off[g] + i] = wv;
+      ds[A.mom_off[g] + i] = dv;
+    }
+  }
+  // ---- single-row reductions over those weights (We, Wp), one wave each ------------
+  if (A.nmom > 0) {
+    __syncthreads();
+    const int wv = tid >> 6, lane = tid & 63;
+    if (wv < A.nmom) {
+      const nh_moment& m = A.mom[wv];
+      const int g = m.grid, nG = G.nG[g], o = A.mom_off[g];
+      double acc = 0.0;
+      for (int sgm = lane; sgm < nG - 1; sgm += 64) {
+        const double u1 = ws[o + sgm] * m.Kt[sgm];
+        const double u2 = ws[o + sgm + 1] * m.Kt[sgm + 1];
+        const double dl = ds[o + sgm] + m.dlnKt[sgm];
+        const double lxs = G.lx[g] ? G.lx[g][sgm] : log(G.xg[g][sgm + 1] / G.xg[g][sgm]);
+        acc += nh_seg_term(u1, u2, dl, lxs);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) m.out[j] = acc;
+    }
+  }
+  // ---- the last block to finish moves the cursor on ---------------------------------
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(A.done, 1) == (int)gridDim.x - 1) {
+      *A.done = 0;
+      A.cursor[0] = cn;
+      if (appended) A.hist->n += 1;
+    }
+  }
+}
+
+extern "C" int nh_step_front(nh_ctx* c, const double* coords, const double* logp,
+                             const double* blk, int* cursor, int* done, int ns, int ndim, int lo,
+                             int nloc, double* qT, double* factors, const nh_pack* packs,
+                             int npacks, int kind, const double* params, const nh_grid* grids,
+                             int ngrids, const nh_moment* moms, int nmoms, nh_hist* hist) {
+  NH_REQUIRE(c && coords && logp && blk && cursor && done && qT && factors && params && grids,
+             "NULL pointer");
+  NH_REQUIRE(ns >= 1 && ndim >= 1 && ndim <= 64 && lo >= 0 && nloc >= 1 && lo + nloc <= ns,
+             "bad proposal block");
+  NH_REQUIRE(npacks >= 1 && npacks <= NH_MAX_PACK && packs, "bad pack plan");
+  NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
+  NH_REQUIRE(ngrids >= 1 && ngrids <= NH_MAX_GRIDS, "bad grid count");
+  NH_REQUIRE(nmoms >= 0 && nmoms <= NH_MAX_MOMENT && (nmoms == 0 || moms), "bad reductions");
+  front_args A;
+  A.coords = coords; A.logp = logp; A.blk = blk; A.cursor = cursor; A.done = done;
+  A.ns = ns; A.ndim = ndim; A.lo = lo; A.nloc = nloc; A.qT = qT; A.factors = factors;
+  A.hist = hist; A.npk = npacks; A.kind = kind; A.params = params; A.nmom = nmoms;
+  bool have_params = false;
+  for (int q = 0; q < npacks; ++q) {
+    NH_REQUIRE(packs[q].out && packs[q].ncols >= 1 && packs[q].ncols <= NH_MAX_LAZY &&
+                   packs[q].ld >= packs[q].ncols, "bad pack request");
+    for (int k = 0; k < packs[q].ncols; ++k) {
+      const double* b = packs[q].cols[k].base;
+      NH_REQUIRE(b == nullptr || (b >= qT && b < qT + (long long)ndim * nloc &&
+                                  (b - qT) % nloc == 0 && packs[q].cols[k].stride == 1),
+                 "a pack column must read one proposal coordinate (or be a constant)");
+    }
+    if (packs[q].out == params) {
+      NH_REQUIRE(packs[q].ncols >= 7, "the particle rows need 7 columns");
+      have_params = true;
+    }
+    A.pk[q] = packs[q];
+  }
+  NH_REQUIRE(have_params, "params must be the output of one of the packs");
+  pw_grids& G = A.G;
+  G.n = ngrids;
+  G.off[0] = 0;
+  for (int g = 0; g < ngrids; ++g) {
+    NH_REQUIRE(grids[g].e_eV && grids[g].xg && grids[g].w && grids[g].dlw && grids[g].nG >= 2,
+               "bad grid descriptor");
+    G.e[g] = grids[g].e_eV; G.xg[g] = grids[g].xg; G.w[g] = grids[g].w; G.dlw[g] = grids[g].dlw;
+    G.lne[g] = grids[g].ln_e; G.lx[g] = grids[g].lx;
+    G.scale[g] = grids[g].unit_scale; G.nG[g] = grids[g].nG;
+    NH_REQUIRE((long long)G.off[g] + grids[g].nG < (1LL << 30), "grids too long");
+    G.off[g + 1] = G.off[g] + grids[g].nG;
+    A.mom_off[g] = -1;
+  }
+  A.mom_nodes = 0;
+  for (int m = 0; m < nmoms; ++m) {
+    NH_REQUIRE(moms[m].grid >= 0 && moms[m].grid < ngrids && moms[m].Kt && moms[m].dlnKt &&
+                   moms[m].out, "bad reduction");
+    A.mom[m] = moms[m];
+    if (A.mom_off[moms[m].grid] < 0) {
+      A.mom_off[moms[m].grid] = A.mom_nodes;
+      A.mom_nodes += grids[moms[m].grid].nG;
+    }
+  }
+  const size_t lds = ((size_t)ndim + NH_PD_NPAR + 3 + 2 * (size_t)A.mom_nodes) * sizeof(double);
+  NH_REQUIRE(lds <= 60 * 1024, "reduction grids do not fit in LDS");
+  nh_prof_scope ps(c, NH_K_PDIST);
+  hipLaunchKernelGGL(k_step_front, dim3((unsigned)nloc), dim3(1024), lds, c->stream, A);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
 extern "C" int nh_particle_weights(nh_ctx* c, int kind, const double* params, int N,
                                    const double* e_eV, const double* xg, int nG,
                                    double unit_scale, double* w, double* dlw, double* n_out) {
@@ -699,10 +902,27 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
                                                       const double* __restrict__ lp,
                                                       nh_prior_pack pri,
                                                       double* __restrict__ model_out,
-                                                      double* __restrict__ lnl) {
+                                                      double* __restrict__ lnl, nh_accept mv) {
   const int lane = threadIdx.x & 63;
   const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wi >= N) return;
+  // the accept's inputs are requested first so that their latency hides behind the sum
+  int me = 0, pa = 0;
+  double mz = 1.0, mlnu = 0.0, mold = 0.0, cpa = 0.0, cme = 0.0;
+  if (mv.coords) {
+    const int g = mv.lo + wi;
+    const double* r = mv.blk + (long long)mv.cursor[0] * 3 * mv.ns;
+    const int* idx = reinterpret_cast<const int*>(r + 2 * mv.ns);
+    me = idx[g];
+    pa = idx[mv.ns + g];
+    mz = r[g];
+    mlnu = r[mv.ns + g];
+    mold = mv.logp[me];
+    if (lane < mv.ndim) {
+      cpa = mv.coords[(long long)pa * mv.ndim + lane];
+      cme = mv.coords[(long long)me * mv.ndim + lane];
+    }
+  }
   double acc = 0.0;
   int nviol = 0, nul = 0;
   for (int k = lane; k < nE; k += 64) {
@@ -735,18 +955,36 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
     }
     lnl[wi] = acc;
   }
+  if (mv.coords) {  // nh_move_accept for this walker (emcee RedBlueMove.propose)
+    acc = __shfl(acc, 0, 64);
+    const double d = (mv.ndim - 1.0) * log(mz) + acc - mold;
+    const bool ok = mlnu < d;  // NaN compares false, as numpy
+    if (ok && lane < mv.ndim) mv.coords[(long long)me * mv.ndim + lane] = cpa - (cpa - cme) * mz;
+    if (lane == 0) {
+      const int g = mv.lo + wi;
+      if (ok) {
+        mv.logp[me] = acc;
+        if (mv.naccepted) mv.naccepted[me] += 1;
+      }
+      mv.accepted[g] = ok ? 1 : 0;
+      if (mv.sel) mv.sel[g] = me;
+    }
+  }
 }
 
 static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const double* conv,
                          const double* flux, const double* err_lo, const double* err_hi,
                          const int* ul, const double* cl, const double* lp,
-                         const nh_prior* terms, int nterms, double* model_out, double* lnl) {
+                         const nh_prior* terms, int nterms, double* model_out, double* lnl,
+                         const nh_accept* mv = nullptr) {
+  nh_accept m = {};
+  if (mv) m = *mv;
   nh_prior_pack pri;
   pri.n = nterms;
   for (int j = 0; j < nterms; ++j) pri.t[j] = terms[j];
   nh_prof_scope ps(c, NH_K_LNPROB);
   hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, N, nE, conv,
-                     flux, err_lo, err_hi, ul, cl, lp, pri, model_out, lnl);
+                     flux, err_lo, err_hi, ul, cl, lp, pri, model_out, lnl, m);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -784,6 +1022,30 @@ extern "C" int nh_lnprob(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int 
   }
   return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms,
                        model_out, total);
+}
+
+extern "C" int nh_lnprob_accept(nh_ctx* c, const nh_comp* comps, int ncomp, int N, int nE,
+                                const double* conv, const double* flux, const double* err_lo,
+                                const double* err_hi, const int* ul, const double* cl,
+                                const double* lp, const nh_prior* terms, int nterms,
+                                double* model_out, double* total, const nh_accept* mv) {
+  NH_REQUIRE(c && comps && conv && flux && err_lo && err_hi && ul && cl && total && mv,
+             "NULL pointer");
+  NH_REQUIRE(mv->coords && mv->logp && mv->blk && mv->cursor && mv->accepted, "bad accept block");
+  NH_REQUIRE(mv->ns >= 1 && mv->ndim >= 1 && mv->ndim <= 64 && mv->lo >= 0 && mv->lo + N <= mv->ns,
+             "bad accept sizes");
+  NH_REQUIRE(nterms >= 0 && nterms <= NH_MAX_PRIOR && (nterms == 0 || terms), "bad prior terms");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP, "ncomp must be 1..8");
+  NH_REQUIRE(N >= 0 && nE >= 1, "bad sizes");
+  if (N == 0) return NH_OK;
+  nh_comps cs;
+  cs.n = ncomp;
+  for (int j = 0; j < ncomp; ++j) {
+    NH_REQUIRE(comps[j].ptr && comps[j].ld >= nE, "bad component");
+    cs.c[j] = comps[j];
+  }
+  return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms,
+                       model_out, total, mv);
 }
 
 // ---------------------------------------------------------------------------

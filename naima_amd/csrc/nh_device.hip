@@ -210,137 +210,6 @@ extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const dou
   return NH_OK;
 }
 
-// ---------------------------------------------------------------------------
-// One launch between two model evaluations: accept the half-step that was just
-// evaluated (newlp != NULL), advance the cursor, propose the NEXT half-step's block and
-// evaluate the parameter-row packs the model will ask for (nh_pack_rows requests
-// recorded from the first, eager evaluation).  Single block: the proposals read rows the
-// accept may just have written, so a block barrier orders them; the three stages are
-// dependent-latency chains of a few hundred elements, not throughput work.
-// ---------------------------------------------------------------------------
-struct pack_plan { nh_pack p[NH_MAX_PACK]; int n; };
-
-template <bool LDS>
-__global__ __launch_bounds__(1024) void k_move_cycle(
-    double* coords, double* logp, const double* __restrict__ blk, int* cursor,
-    const double* newlp, int ns, int ndim, int* accepted, int* naccepted, int* sel, int lo,
-    int nloc, double* qT, double* factors, pack_plan P, nh_hist* hist) {
-  // LDS: the proposals (the packs read them back), and the NEXT slice's random numbers,
-  // fetched while the accept's own loads are in flight
-  extern __shared__ double sm[];
-  double* qs = sm;                                   // [ndim][nloc]
-  double* z1 = sm + (LDS ? (long long)ndim * nloc : 0);       // [ns]
-  int* i1 = reinterpret_cast<int*>(z1 + (LDS ? ns : 0));      // [2 ns]
-  const int cur0 = cursor[0];
-  const int cur1 = newlp ? cur0 + 1 : cur0;
-  const double* r1 = blk + (long long)cur1 * 3 * ns;
-  const int* idx1 = reinterpret_cast<const int*>(r1 + 2 * ns);
-  if (LDS) {
-    for (int j = threadIdx.x; j < ns; j += blockDim.x) z1[j] = r1[j];
-    for (int j = threadIdx.x; j < 2 * ns; j += blockDim.x) i1[j] = idx1[j];
-  }
-  if (newlp) {
-    const double* r = blk + (long long)cur0 * 3 * ns;
-    const int* idx = reinterpret_cast<const int*>(r + 2 * ns);
-    for (int j = threadIdx.x; j < ns; j += blockDim.x) {
-      const int me = idx[j], pa = idx[ns + j];
-      const double z = r[j];
-      const double d = (ndim - 1.0) * log(z) + newlp[j] - logp[me];
-      const bool acc = r[ns + j] < d;  // NaN compares false, as numpy
-      if (acc) {
-        for (int k = 0; k < ndim; ++k) {
-          const double cj = coords[(long long)pa * ndim + k];
-          const double sj = coords[(long long)me * ndim + k];
-          coords[(long long)me * ndim + k] = cj - (cj - sj) * z;
-        }
-        logp[me] = newlp[j];
-        if (naccepted) atomicAdd(&naccepted[me], 1);
-      }
-      accepted[j] = acc ? 1 : 0;
-      if (sel) sel[j] = me;
-    }
-  }
-  __syncthreads();
-  if (newlp && threadIdx.x == 0) cursor[0] = cur1;
-  // chain history: a full ensemble step ends on every second accept
-  if (newlp && hist && (cur1 & 1) == 0) {
-    const long long row = hist->n;
-    if (hist->coords && row < hist->cap) {
-      const int N = 2 * ns;
-      double* hc = hist->coords + row * N * ndim;
-      double* hl = hist->logp + row * N;
-      for (int t = threadIdx.x; t < N * ndim; t += blockDim.x) hc[t] = coords[t];
-      for (int t = threadIdx.x; t < N; t += blockDim.x) hl[t] = logp[t];
-      __syncthreads();
-      if (threadIdx.x == 0) hist->n = row + 1;
-    }
-  }
-  if (nloc <= 0) return;
-  for (int t = threadIdx.x; t < nloc * ndim; t += blockDim.x) {
-    const int d = t / nloc, j = t % nloc;
-    const int g = lo + j;
-    const double z = LDS ? z1[g] : r1[g];
-    const int pa = LDS ? i1[ns + g] : idx1[ns + g];
-    const int me = LDS ? i1[g] : idx1[g];
-    const double cj = coords[(long long)pa * ndim + d];
-    const double sj = coords[(long long)me * ndim + d];
-    const double q = cj - (cj - sj) * z;
-    qT[(long long)d * nloc + j] = q;
-    if (LDS) qs[(long long)d * nloc + j] = q;
-    if (d == 0) factors[j] = (ndim - 1.0) * log(z);
-  }
-  if (P.n == 0) return;
-  __syncthreads();
-  const double* qend = qT + (long long)ndim * nloc;
-  for (int q = 0; q < P.n; ++q) {
-    const int nc = P.p[q].ncols;
-    for (int t = threadIdx.x; t < nloc * nc; t += blockDim.x) {
-      const int w = t / nc, j = t % nc;
-      const nh_lazy& z = P.p[q].cols[j];
-      double v;
-      if (!z.base) {
-        v = z.a;
-      } else if (LDS && z.base >= qT && z.base < qend) {
-        v = nh_lazy_apply(z, qs[(z.base - qT) + (long long)w * z.stride]);
-      } else {
-        v = nh_lazy_apply(z, z.base[(long long)w * z.stride]);
-      }
-      P.p[q].out[(long long)w * P.p[q].ld + j] = v;
-    }
-  }
-}
-
-extern "C" int nh_move_cycle(nh_ctx* c, double* coords, double* logp, const double* blk,
-                             int* cursor, const double* newlp, int ns, int ndim, int* accepted,
-                             int* naccepted, int* sel, int lo, int nloc, double* qT,
-                             double* factors, const nh_pack* packs, int npacks, nh_hist* hist) {
-  NH_REQUIRE(c && coords && logp && blk && cursor && ns >= 1 && ndim >= 1, "bad argument");
-  NH_REQUIRE(newlp == nullptr || accepted, "accept needs the accepted[] output");
-  NH_REQUIRE(lo >= 0 && nloc >= 0 && lo + nloc <= ns && (nloc == 0 || (qT && factors)),
-             "bad proposal block");
-  NH_REQUIRE(npacks >= 0 && npacks <= NH_MAX_PACK && (npacks == 0 || packs), "bad pack plan");
-  pack_plan P;
-  P.n = npacks;
-  for (int q = 0; q < npacks; ++q) {
-    NH_REQUIRE(packs[q].out && packs[q].ncols >= 1 && packs[q].ncols <= NH_MAX_LAZY &&
-                   packs[q].ld >= packs[q].ncols, "bad pack request");
-    P.p[q] = packs[q];
-  }
-  nh_prof_scope ps(c, NH_K_GLUE);
-  const size_t lds = ((size_t)ndim * nloc + ns) * sizeof(double) + 2 * (size_t)ns * sizeof(int);
-  if (lds <= 60 * 1024) {
-    hipLaunchKernelGGL(k_move_cycle<true>, dim3(1), dim3(1024), lds, c->stream, coords, logp, blk,
-                       cursor, newlp, ns, ndim, accepted, naccepted, sel, lo, nloc, qT, factors,
-                       P, hist);
-  } else {
-    hipLaunchKernelGGL(k_move_cycle<false>, dim3(1), dim3(1024), 0, c->stream, coords, logp, blk,
-                       cursor, newlp, ns, ndim, accepted, naccepted, sel, lo, nloc, qT, factors,
-                       P, hist);
-  }
-  NH_CHECK_HIP(hipGetLastError());
-  return NH_OK;
-}
-
 // blob bookkeeping: dst[idx[lo+j]][:] = src[j][:] where accepted[lo+j]
 __global__ void k_scatter_rows(double* __restrict__ dst, int ldd, const double* __restrict__ src,
                                int lds, const int* __restrict__ idx,

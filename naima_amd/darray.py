@@ -43,6 +43,18 @@ class nh_pack(C.Structure):
     _fields_ = [("cols", nh_lazy * 8), ("ncols", C.c_int), ("ld", C.c_int), ("out", C.c_void_p)]
 
 
+class nh_moment(C.Structure):
+    _fields_ = [("grid", C.c_int), ("pad", C.c_int), ("Kt", C.c_void_p), ("dlnKt", C.c_void_p),
+                ("out", C.c_void_p)]
+
+
+class nh_accept(C.Structure):
+    _fields_ = [("coords", C.c_void_p), ("logp", C.c_void_p), ("blk", C.c_void_p),
+                ("cursor", C.c_void_p), ("ns", C.c_int), ("ndim", C.c_int), ("lo", C.c_int),
+                ("pad", C.c_int), ("accepted", C.c_void_p), ("naccepted", C.c_void_p),
+                ("sel", C.c_void_p)]
+
+
 class nh_prior(C.Structure):
     _fields_ = [("x", nh_lazy), ("p0", C.c_double), ("p1", C.c_double), ("kind", C.c_int),
                 ("pad", C.c_int)]

@@ -71,15 +71,20 @@ class DeviceLoop:
         # the random numbers of up to KSTEPS ensemble steps travel as ONE block; a device
         # cursor selects the current half-step's slice (advanced by the accept kernel)
         self.KSTEPS = 32
+        self.GSTEPS = 8   # ensemble steps per hipGraph launch when the host has nothing to do
+        self.multi_graph = None
         # one spare slice: the fused move kernel proposes the half-step AFTER the one it
         # accepts, so the last one of a block reads (and discards) slice 2*KSTEPS
         self.blk = ctx.empty((2 * self.KSTEPS + 1, 3 * self.ns))
         ctx.call("nh_memset", self.blk, 0, self.blk.nbytes)
-        # nh_move_cycle mode: set after the first (eager, recording) evaluation when all
-        # of the model's parameter packs read the proposal buffer
+        # nh_step_front mode: set after a recording evaluation when the model's parameter
+        # packs read the proposal buffer and it asks for ONE particle-weights launch
         self.fused = False
         self._plan = None
-        self._packs = None
+        self._front_args = None
+        self.done = ctx.empty((1,), dtype=np.int32)
+        ctx.call("nh_memset", self.done, 0, 4)
+        self._hook = None
         # nh_hist descriptor in HBM: the fused kernel appends the chain history itself
         self.histd = ctx.empty((4,), dtype=np.int64)
         ctx.call("nh_memset", self.histd, 0, self.histd.nbytes)
@@ -137,17 +142,20 @@ class DeviceLoop:
         log-probabilities (the part that precedes the exchange)"""
         ctx = self.ctx
         if self.fused:
-            # proposal and parameter rows were written by the previous nh_move_cycle
-            self._plan["i"] = 0
-            ctx._pack_plan = self._plan
+            # proposal, parameter rows, weights, We: written by the preceding nh_step_front
+            self._plan["i"] = [0, 0, 0]
+            ctx._plan = self._plan
+            if self.s.comm.size == 1:
+                self._hook["used"] = False
+                ctx._accept_hook = self._hook
         else:
             ctx.call("nh_move_propose", self.coords, self.blk, self.cursor, self.ns, self.ndim,
                      self.lo, self.nloc, self.qT, self.factors)
         try:
             total, blobs = self._eval(self.qT, self.nloc)
         finally:
-            if self.fused:
-                ctx._pack_plan = None
+            ctx._plan = None
+            ctx._accept_hook = None
         if self.s.comm.size > 1:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses
@@ -172,7 +180,10 @@ class DeviceLoop:
     def _part_accept(self):
         ctx = self.ctx
         if self.fused:
-            self._cycle(self._newlp_ptr)
+            if not (self._hook and self._hook["used"]):  # sharded, or a foreign likelihood
+                ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
+                         self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc,
+                         self.sel, 0)
         else:
             ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
                      self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
@@ -180,41 +191,77 @@ class DeviceLoop:
             for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
                 ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
                          self.nloc, m)
+        if self.fused:
+            self._front()
 
-    def _cycle(self, newlp):
-        """accept (when ``newlp``) + advance + propose + parameter packs: one launch"""
-        self.ctx.call("nh_move_cycle", self.coords, self.logp, self.blk, self.cursor, newlp,
-                      self.ns, self.ndim, self.accepted, self.nacc, self.sel, self.lo, self.nloc,
-                      self.qT, self.factors, self._packs, len(self._plan["reqs"]), self.histd)
+    def _front(self):
+        """proposal of the next half-step + parameter packs + particle weights + We/Wp
+        reductions (+ chain history, cursor advance): one launch"""
+        self.ctx.call("nh_step_front", self.coords, self.logp, self.blk, self.cursor, self.done,
+                      self.ns, self.ndim, self.lo, self.nloc, self.qT, self.factors,
+                      *self._front_args, self.histd)
 
     def _record_half_step(self):
-        """the first half-step: launched piece by piece while the model's nh_pack_rows
-        requests are recorded; if they all read the proposal buffer (or constants) the
-        loop switches to nh_move_cycle"""
+        """a half-step launched piece by piece while the model's parameter packs, weights
+        launch and single-row reductions are recorded; if nh_step_front can produce them
+        the loop switches to it"""
         import ctypes as C
-        from .darray import nh_lazy, nh_pack
+        from .darray import nh_accept, nh_grid, nh_lazy, nh_moment, nh_pack
         ctx = self.ctx
-        ctx._pack_plan = plan = dict(mode="record", reqs=[], i=0)
+        plan = ctx.plan_begin()
         try:
             self._half_step_body()
         finally:
-            ctx._pack_plan = None
-        lo_a, hi_a = self.qT.ptr, self.qT.ptr + self.qT.nbytes
-        ok = 0 < len(plan["reqs"]) <= 4
-        packs = (nh_pack * 4)()
-        for q, (raw, ncols, N, out) in enumerate(plan["reqs"][:4]):
+            ctx._plan = None
+        if not self.s.fuse_moves:
+            return
+        packs, weights, moments = plan["packs"], plan["weights"], plan["moments"]
+        if not (1 <= len(packs) <= 4 and len(weights) == 1 and len(moments) <= 4):
+            return
+        lo_a = self.qT.ptr
+        hi_a = lo_a + 8 * self.ndim * self.nloc
+        pk = (nh_pack * 4)()
+        for q, ((raw, ncols, N), out) in enumerate(packs):
             cols = (nh_lazy * 8).from_buffer_copy(raw.ljust(C.sizeof(nh_lazy) * 8, b"\0"))
+            if N != self.nloc or ncols > 8:
+                return
             for j in range(ncols):
                 base = cols[j].base or 0
-                ok = ok and (base == 0 or lo_a <= base < hi_a)
-            ok = ok and N == self.nloc and ncols <= 8
-            packs[q].cols = cols
-            packs[q].ncols, packs[q].ld, packs[q].out = ncols, ncols, out.ptr
-        if not ok or not self.s.fuse_moves:
+                if base and not (lo_a <= base < hi_a and (base - lo_a) % (8 * self.nloc) == 0
+                                 and cols[j].stride == 1):
+                    return
+            pk[q].cols = cols
+            pk[q].ncols, pk[q].ld, pk[q].out = ncols, ncols, out.ptr
+        (kind, rows_ptr, N, grids), bufs = weights[0]
+        if N != self.nloc or rows_ptr not in [out.ptr for _, out in packs] or len(grids) > 4:
+            return
+        gd = (nh_grid * 4)()
+        wptr = {}
+        for g, ((e, x, lne, lx, scale, nG), (wk, lwk)) in enumerate(zip(grids, bufs)):
+            gd[g] = nh_grid(e, x, wk.ptr, lwk.ptr, scale, nG, 0, lne, lx)
+            wptr[wk.ptr] = g
+        mm = (nh_moment * 4)()
+        lds_nodes = set()
+        for k, ((w, lw, N, nG, lx, Kt, dlnKt), out) in enumerate(moments):
+            if w not in wptr or N != self.nloc:
+                return
+            mm[k] = nh_moment(wptr[w], 0, Kt, dlnKt, out.ptr)
+            lds_nodes.add(wptr[w])
+        if 16 * sum(grids[g][5] for g in lds_nodes) > 48 * 1024:
             return
         plan["mode"] = "replay"
-        self._plan, self._packs, self.fused = plan, packs, True
-        self._cycle(None)  # proposal + rows of the next half-step
+        ctx.pin_caches()
+        self._plan = plan
+        self._front_args = (pk, len(packs), kind, rows_ptr, gd, len(grids), mm, len(moments))
+        self._hook = dict(N=self.nloc, used=False,
+                          mv=nh_accept(self.coords.ptr, self.logp.ptr, self.blk.ptr,
+                                       self.cursor.ptr, self.ns, self.ndim, self.lo, 0,
+                                       self.accepted.ptr, self.nacc.ptr, self.sel.ptr))
+        self.fused = True
+        # new slice protocol: cursor = the slice accepted last.  The two piecewise
+        # half-steps (slices 0 and 1 of the first block) left it at 2.
+        self.cursor.set(np.array([1], dtype=np.int32))
+        self._front()
 
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
@@ -266,7 +313,7 @@ class DeviceLoop:
         return [cur.get().reshape((self.N,) + trail) for cur, m, _, trail in self.cur_blobs]
 
     # ------------------------------------------------------------------- loop
-    def sample(self, initial_state, iterations, store):
+    def sample(self, initial_state, iterations, store, yield_every=1):
         from .sampler import State
         s, ctx = self.s, self.ctx
         if isinstance(initial_state, DeviceState) and initial_state._loop is self:
@@ -300,30 +347,47 @@ class DeviceLoop:
                 ctx.call("nh_marker_wait", self._inflight.pop(0))
             addr, K = moves.take(min(self.KSTEPS, iterations - it))
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
-            ctx.call("nh_memset", self.cursor, 0, 4)
             if self.fused:
-                self._cycle(None)  # slice 0 of the new block
+                ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
+                self._front()  # slice 0 of the new block
+            else:
+                ctx.call("nh_memset", self.cursor, 0, 4)
             mark = self._markers[self._nmark % len(self._markers)]
             self._nmark += 1
             ctx.call("nh_marker_record", mark)
             self._inflight.append(mark)
-            for _k in range(K):
-                self._run_step()
-                it += 1
-                s.iteration += 1
+            k = 0
+            while k < K:
+                # several steps per graph launch when nothing has to happen on the host
+                # between them (history is kept by the kernel, nobody reads the states)
+                g = 1
+                if (self.step_graph is not None and self.fused and K - k >= self.GSTEPS and
+                        yield_every >= self.GSTEPS and (block is None or dev_hist) and
+                        not (block is not None and block["blobs"])):
+                    g = self.GSTEPS
+                    if self.multi_graph is None:
+                        self.multi_graph = self._capture(
+                            lambda: [self._half_step_body() for _ in range(2 * self.GSTEPS)])
+                    ctx.graph_launch(self.multi_graph)
+                else:
+                    self._run_step()
+                k += g
+                it += g
+                s.iteration += g
                 if block is not None:
-                    k = block["n"]
+                    kk = block["n"]
                     if not dev_hist:
-                        ctx.call("nh_copy", block["coords"].ptr + 8 * k * N * self.ndim,
+                        ctx.call("nh_copy", block["coords"].ptr + 8 * kk * N * self.ndim,
                                  self.coords, 8 * N * self.ndim)
-                        ctx.call("nh_copy", block["logp"].ptr + 8 * k * N, self.logp, 8 * N)
+                        ctx.call("nh_copy", block["logp"].ptr + 8 * kk * N, self.logp, 8 * N)
                     for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
-                        ctx.call("nh_copy", hb.ptr + 8 * k * N * m, cur, 8 * N * m)
-                    block["n"] = k + 1
+                        ctx.call("nh_copy", hb.ptr + 8 * kk * N * m, cur, 8 * N * m)
+                    block["n"] = kk + g
                 yield DeviceState(self, rng)
 
     def _capture(self, fn):
         ctx = self.ctx
+        ctx.pin_caches()
         ctx.sync()
         ctx.graph_begin()
         try:
@@ -346,9 +410,11 @@ class DeviceLoop:
             ctx.graph_launch(self.step_graph)
             return
         if self.warm < 1:
-            self._record_half_step()
-            self.warm += 1
+            # the first evaluation settles which grids share a weights launch, the
+            # second one is recorded
             self._half_step_body()
+            self._record_half_step()
+            self.warm += 2
             return
 
         def two():
@@ -370,8 +436,11 @@ class DeviceLoop:
                 self._exchange()
                 ctx.graph_launch(self.graph2)
             return
-        if self.warm < 1:
-            self._record_half_step()
+        if self.warm < 2:
+            if self.warm == 0:
+                self._half_step_body()
+            else:
+                self._record_half_step()
             self.warm += 1
             return
         if not s.use_graph:

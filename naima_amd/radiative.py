@@ -134,7 +134,6 @@ class BaseRadiative:
         if not hasattr(pd, "device_rows"):
             raise TypeError("naima_amd radiative models need a naima_amd.models particle "
                             "distribution (got %r)" % (type(pd).__name__,))
-        from .darray import nh_grid
         ctx = get_context()
         N = self.batch_size
         nG = xg.size
@@ -144,6 +143,16 @@ class BaseRadiative:
         cache = pd.__dict__.setdefault("_w_dev", {}).setdefault(N, {})
         reg = ctx._wgrids.setdefault((pd.kind, N), {})
         hit = cache.get(key)
+        if hit is None and not cache and ctx._plan is not None:
+            rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
+            rec = ctx.weights_replay(PD_KIND[pd.kind], rows, N)
+            if rec is not None:  # produced by nh_step_front on the recorded grids
+                for g, wl in zip(*rec):
+                    cache[(g[1], g[0], g[4], g[5])] = wl
+                hit = cache.get(key)
+                if hit is None:
+                    raise ValueError("the model asked for a particle grid it did not use when "
+                                     "the step was recorded; run with use_graph=False")
         if hit is None:
             if not cache:
                 ctx._weval += 1
@@ -154,15 +163,11 @@ class BaseRadiative:
             for k in [k for k, v in reg.items() if ctx._weval - v[0] > 2]:
                 del reg[k]
             rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
-            desc = (nh_grid * len(todo))()
-            for j, k in enumerate(todo):
-                _, xdk, edk, lnek, lxk = reg[k]
-                wk, lwk = ctx.empty((N, k[3])), ctx.empty((N, k[3]))
-                desc[j] = nh_grid(edk.ptr, xdk.ptr, wk.ptr, lwk.ptr, k[2], k[3], 0, lnek.ptr,
-                                  lxk.ptr)
-                cache[k] = (wk, lwk)
-            ctx.call("nh_particle_weights_multi", PD_KIND[pd.kind], rows, N, desc, len(todo))
-            if self.on_device:
+            bufs = ctx.weights_multi(PD_KIND[pd.kind], rows, N,
+                                     [reg[k][1:3][::-1] + reg[k][3:5] + (k[2], k[3]) for k in todo])
+            for k, wl in zip(todo, bufs):
+                cache[k] = wl
+            if self.on_device and ctx.side_small:
                 # We/Wp reductions hang a side stream off this launch (ctx.branch_at)
                 mark = ctx.anchor()
                 for k in todo:
@@ -297,8 +302,7 @@ class BaseElectron(BaseRadiative):
         ctx, N, w, lw, xd, lx, gam = self._electron_weights(gam)
         K = gam * MEC2_ERG  # u = x*y = (gam mec2)(gam nelec)
         Kt, dlnKt = ctx.const(K), ctx.const(_dlog(K))
-        out = ctx.empty((N, 1))
-        ctx.call("nh_integrate_tables", w, lw, N, gam.size, lx, Kt, dlnKt, 1, None, out, 1, 0)
+        out = ctx.moment(w, lw, N, gam.size, lx, Kt, dlnKt)
         if self.on_device:
             return u.Quantity(DVec(ctx, out, out.ptr, N), u.erg)
         We = out.get()[:, 0]
@@ -393,7 +397,7 @@ class Synchrotron(BaseElectron):
             Bd = self.__dict__.get("_B_dense") or Bv.dense()
             Bp = Bd.ptr
         else:
-            Bd = ctx.const(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
+            Bd = ctx.array(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
             Bp = Bd.ptr
         out = ctx.empty((N, E_eV.size))
         ctx.call("nh_synchrotron", w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV),
@@ -737,8 +741,7 @@ class BaseProton(BaseRadiative):
     def _Wp_on_impl(self, Ep):
         ctx, N, w, lw, xd, lx, Ep = self._proton_weights(Ep)
         Kt, dlnKt = ctx.const(Ep), ctx.const(_dlog(Ep))
-        out = ctx.empty((N, 1))
-        ctx.call("nh_integrate_tables", w, lw, N, Ep.size, lx, Kt, dlnKt, 1, None, out, 1, 0)
+        out = ctx.moment(w, lw, N, Ep.size, lx, Kt, dlnKt)
         if self.on_device:
             return u.Quantity(DVec(ctx, out, out.ptr, N), u.GeV).to("erg")
         Wp = out.get()[:, 0]

@@ -185,9 +185,12 @@ class EnsembleSampler:
         return arrs, units
 
     # ------------------------------------------------------------------ sample
-    def sample(self, initial_state, iterations=1, store=True, log_prob0=None):
+    def sample(self, initial_state, iterations=1, store=True, log_prob0=None, yield_every=1):
+        """emcee's generator: one State per ensemble step.  ``yield_every`` > 1 (what
+        ``run_mcmc`` asks for) lets the device loop replay several steps as one hipGraph
+        and yield only after each such group."""
         if self.device:
-            yield from self._sample_device(initial_state, iterations, store)
+            yield from self._sample_device(initial_state, iterations, store, yield_every)
             return
         state = State(initial_state)
         coords = state.coords.copy()
@@ -240,11 +243,11 @@ class EnsembleSampler:
             yield State(coords, logp, self._cur_blobs if keep_blobs else None, rng)
 
     # ------------------------------------------------------------ device mode
-    def _sample_device(self, initial_state, iterations, store):
+    def _sample_device(self, initial_state, iterations, store, yield_every=1):
         from .device_sampler import DeviceLoop
         if self._dev is None:
             self._dev = DeviceLoop(self)
-        yield from self._dev.sample(initial_state, iterations, store)
+        yield from self._dev.sample(initial_state, iterations, store, yield_every)
 
     def _update_blobs(self, walkers, accepted, new):
         """walkers: global indices this rank just evaluated; blobs are tracked for
@@ -259,6 +262,7 @@ class EnsembleSampler:
 
     def run_mcmc(self, initial_state, nsteps, **kw):
         state = None
+        kw.setdefault("yield_every", 1 << 30)  # nobody looks at the intermediate states
         for state in self.sample(initial_state, iterations=nsteps, **kw):
             pass
         return state

