@@ -132,9 +132,11 @@ int nh_grid_logratio(nh_ctx* ctx, const double* xg, int nG, double* lx);
 /* out[w*ldo + k] = scale[k] * trapz_loglog(n_w * K_k, xg)  for k < nK,
  * evaluated as sum_i  lx_i * (u2-u1)/ln(u2/u1),  u = w_i*Kt[i][k],
  * ln(u2/u1) = dlw[i] + dlnKt[i][k].
- * scale may be NULL (=1).  nonnegative != 0 promises Kt >= 0 and w of one sign (true for
- * every emission table except the FITPACK look-up table, which rings below zero): the
- * sign-change handling is then compiled out.  Replaces the trapz_loglog(nelec*gamint, gam) calls of
+ * scale may be NULL (=1).  nonnegative != 0 promises Kt >= 0, w of one sign, and dlnKt
+ * finite with dlnKt[i][k] >= 1e300 wherever Kt[i][k] or Kt[i+1][k] is zero (what every
+ * nh_table_* builder writes; true for all emission tables except the FITPACK look-up
+ * table, which rings below zero, and the Baring+99 fits): sign-change and zero-node
+ * handling are then compiled out of the inner loop.  Replaces the trapz_loglog(nelec*gamint, gam) calls of
  * radiative.py:684 (IC), 949-953/966-970 (bremsstrahlung), 1530 (pion decay),
  * 165/193/1020/1053 (We, Wp). */
 int nh_integrate_tables(nh_ctx* ctx, const double* w, const double* dlw, int N, int nG,

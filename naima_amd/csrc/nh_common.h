@@ -152,6 +152,43 @@ __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, d
   return (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
 }
 
+// The same term for the hot loops over non-negative integrands (u1, u2 >= 0).  The series
+// is needed only where |dl| is tiny (the few segments around the peak of u, b + 1 -> 0 in
+// utils.py:336-345): it sits behind a wave-uniform branch, so a wave whose 64 lanes are
+// all away from their peaks pays for (u2-u1) lx / dl only.  The main form loses
+// eps/|dl| to the cancellation in u2 - u1: 2e-13 at the threshold 2^-10.
+// ZERO = true keeps the reference's explicit test (a zero node -> 0, utils.py:347-348);
+// ZERO = false relies on the caller's encoding: dl >= NH_DL_ZERO where a node is zero
+// because its TABLE entry is zero (then the term is (u2-u1) lx 1e-300 ~ 0; two zero
+// nodes give exactly 0).
+#ifndef NH_SEG_SMALL_POS
+#define NH_SEG_SMALL_POS 0x1p-10
+#endif
+#define NH_DL_ZERO 1e300
+// 1/x seeded in single precision (v_cvt + v_rcp_f32 + v_cvt: 9 cycles against 18 for
+// v_rcp_f64, same 2^-23 seed) + one Newton step: 3e-14 relative.  |x| beyond the float
+// range gives 0 (the NH_DL_ZERO marker relies on it), |x| < 1e-38 is the caller's series.
+__device__ __forceinline__ double nh_rcp1f(double x) {
+  const double r = (double)__builtin_amdgcn_rcpf((float)x);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+
+template <bool ZERO>
+__device__ __forceinline__ double nh_seg_pos(double u1, double u2, double dl, double lx) {
+  double t = ((u2 - u1) * lx) * nh_rcp1f(dl);
+  const bool small = fabs(dl) < NH_SEG_SMALL_POS;
+  if (__builtin_amdgcn_ballot_w64(small) != 0) {
+    asm volatile("" ::: "memory");  // keep this a branch: the compiler would if-convert it
+    double f = fma(dl, 8.333333333333333e-03, 4.166666666666666e-02);
+    f = fma(f, dl, 1.666666666666667e-01);
+    f = fma(f, dl, 0.5);
+    f = fma(f, dl, 1.0);
+    t = small ? (u1 * lx) * f : t;
+  }
+  if (ZERO) t = (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
+  return t;
+}
+
 typedef unsigned int nh_u32x2 __attribute__((ext_vector_type(2)));
 // 8-byte load through a buffer descriptor at a 32-bit byte offset
 __device__ __forceinline__ double nh_buf_f64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {

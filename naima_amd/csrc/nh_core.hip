@@ -691,7 +691,9 @@ extern "C" int nh_step_front(nh_ctx* c, const double* coords, const double* logp
   const size_t lds = ((size_t)ndim + NH_PD_NPAR + 3 + 2 * (size_t)A.mom_nodes) * sizeof(double);
   NH_REQUIRE(lds <= 60 * 1024, "reduction grids do not fit in LDS");
   nh_prof_scope ps(c, NH_K_PDIST);
-  hipLaunchKernelGGL(k_step_front, dim3((unsigned)nloc), dim3(1024), lds, c->stream, A);
+  int threads = 1024;
+  if (const char* e = getenv("NH_FRONT_T")) threads = atoi(e);
+  hipLaunchKernelGGL(k_step_front, dim3((unsigned)nloc), dim3(threads), lds, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -738,13 +740,19 @@ extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx)
 // (s_load), not through the vector L1 -- the first version issued 5 vector loads
 // per segment and walker and was bound by the L1 tag-lookup rate (TCP), at 40 % of
 // the VALU.  The C waves of a block split the abscissa; partial sums meet in LDS.
-template <int C, int W, bool SIGNED>
+// STG: the block first copies its walkers' w and dlw rows into LDS with one coalesced
+// sweep.  They were written by the launch just before this one, i.e. they sit in
+// HBM / Infinity Cache, not in this XCD's L2: read through the scalar cache inside the
+// loop, every new 64-byte line was a serialized ~1 us miss (measured: +3 us per launch
+// inside the step loop against a warm micro-benchmark).
+template <int C, int W, bool SIGNED, bool STG>
 __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
     const double* __restrict__ lx, const double* __restrict__ Kt,
     const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
     double* __restrict__ out, int ldo) {
   __shared__ double part[C][W][64];
+  extern __shared__ double stg[];  // [W][nG] w | [W][nG] dlw   (STG only)
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ktiles = (nK + 63) >> 6;
@@ -764,6 +772,16 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     acc[j] = 0.0;
     row[j] = (unsigned)min(w0 + j, N - 1) * (unsigned)nG;
   }
+  if (STG) {
+    for (int t = threadIdx.x; t < W * nG; t += 64 * C) {
+      const int j = t / nG, i = t - j * nG;
+      stg[t] = w[row[j] + i];
+      stg[W * nG + t] = dlw[row[j] + i];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) row[j] = (unsigned)(j * nG);
+    __syncthreads();
+  }
   if (s0 < s1) {
     // table rows through buffer descriptors: base in SGPRs + one 32-bit byte offset per
     // lane (a single v_add per load instead of 64-bit address arithmetic)
@@ -777,17 +795,42 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     {
       const double K0 = nh_buf_f64(rK, ob);
 #pragma unroll
-      for (int j = 0; j < W; ++j) u1[j] = w[row[j] + s0] * K0;
+      for (int j = 0; j < W; ++j) u1[j] = (STG ? stg[row[j] + s0] : w[row[j] + s0]) * K0;
     }
-    for (int s = s0; s < s1; ++s) {
+    // four segments per trip: their eight table loads are in flight together, so the
+    // L2 latency is paid once per four segments (the loop is latency-, not issue-bound)
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      double K2[4], dK[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        K2[q] = nh_buf_f64(rK, ob + (q + 1) * rowb);
+        dK[q] = nh_buf_f64(rD, ob + q * rowb);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double lxs = lx[s + q];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const double u2 = (STG ? stg[row[j] + s + q + 1] : w[row[j] + s + q + 1]) * K2[q];
+          const double dl = (STG ? stg[W * nG + row[j] + s + q] : dlw[row[j] + s + q]) + dK[q];
+          acc[j] += SIGNED ? nh_seg_term<true>(u1[j], u2, dl, lxs)
+                           : nh_seg_pos<false>(u1[j], u2, dl, lxs);
+          u1[j] = u2;
+        }
+      }
+      ob += 4 * rowb;
+    }
+    for (; s < s1; ++s) {
       const double K2 = nh_buf_f64(rK, ob + rowb);
       const double dK = nh_buf_f64(rD, ob);
       const double lxs = lx[s];
 #pragma unroll
       for (int j = 0; j < W; ++j) {
-        const double u2 = w[row[j] + s + 1] * K2;
-        const double dl = dlw[row[j] + s] + dK;
-        acc[j] += nh_seg_term<SIGNED>(u1[j], u2, dl, lxs);
+        const double u2 = (STG ? stg[row[j] + s + 1] : w[row[j] + s + 1]) * K2;
+        const double dl = (STG ? stg[W * nG + row[j] + s] : dlw[row[j] + s]) + dK;
+        acc[j] += SIGNED ? nh_seg_term<true>(u1[j], u2, dl, lxs)
+                         : nh_seg_pos<false>(u1[j], u2, dl, lxs);
         u1[j] = u2;
       }
       ob += rowb;
@@ -852,20 +895,25 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   }
   const int nseg = nG - 1;
   const int ktiles = (nK + 63) / 64;
-  // walkers per thread (register blocking of the table rows).  Measured on cfg3
-  // (N = 256, nK = 192): W = 1 27 us, W = 2 32 us, W = 4 34 us -- more, smaller
-  // blocks balance better over 256 CUs than the saved vector loads are worth; W > 1
-  // pays once a launch has many more walkers than CUs.
-  int W = ((long long)ktiles * N >= 8192) ? 4 : ((long long)ktiles * N >= 4096 ? 2 : 1);
+  // walkers per thread (register blocking: the table rows are loaded once for W
+  // walkers).  Measured inside the cfg3 step loop (N = 256, nK = 192, C = 16): W = 1
+  // 20.8 us, W = 2 17.0 us, W = 4 18.1 us -- halving the L2->L1 table traffic pays as
+  // long as the launch keeps >= ~4 waves per SIMD.
+  int W = ((long long)ktiles * N >= 8192) ? 4 : ((long long)ktiles * N >= 512 ? 2 : 1);
   if (const char* e = getenv("NH_INT_W")) W = atoi(e);
   const unsigned blocks = (unsigned)(ktiles * ((N + W - 1) / W));
   // split the abscissa so that the launch has >= ~4 waves per SIMD (1024 SIMDs)
   int C = 1;
   while (C < 16 && (long long)blocks * C < 12288 && nseg / (2 * C) >= 8) C *= 2;
   if (const char* e = getenv("NH_INT_C")) C = atoi(e);
-#define NH_LAUNCH_INT_S(CC, WW, SS)                                                          \
-  hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS>), dim3(blocks), dim3(64 * CC), 0,       \
-                     c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo)
+  const size_t stg_bytes = 2 * (size_t)W * nG * sizeof(double);
+  const bool stage = stg_bytes <= 48 * 1024;
+#define NH_LAUNCH_INT_T(CC, WW, SS, TT)                                                      \
+  hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS, TT>), dim3(blocks), dim3(64 * CC),      \
+                     TT ? stg_bytes : 0, c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, \
+                     out, ldo)
+#define NH_LAUNCH_INT_S(CC, WW, SS) \
+  do { if (stage) NH_LAUNCH_INT_T(CC, WW, SS, true); else NH_LAUNCH_INT_T(CC, WW, SS, false); } while (0)
 #define NH_LAUNCH_INT(CC, WW) \
   do { if (nonnegative) NH_LAUNCH_INT_S(CC, WW, false); else NH_LAUNCH_INT_S(CC, WW, true); } while (0)
 #define NH_LAUNCH_INT_C(CC) \
@@ -880,6 +928,7 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
 #undef NH_LAUNCH_INT_C
 #undef NH_LAUNCH_INT
 #undef NH_LAUNCH_INT_S
+#undef NH_LAUNCH_INT_T
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -923,6 +972,11 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
       cme = mv.coords[(long long)me * mv.ndim + lane];
     }
   }
+  // prior terms and the confidence-level table are requested before the sum as well
+  double prior = 0.0;
+  const bool has_prior = lp || pri.n > 0;
+  if (has_prior && lane == 0) prior = (lp ? lp[wi] : 0.0) + nh_prior_sum(pri, wi);
+  const double cl_lane = lane < nE ? cl[lane] : 0.0;
   double acc = 0.0;
   int nviol = 0, nul = 0;
   for (int k = lane; k < nE; k += 64) {
@@ -946,13 +1000,13 @@ __global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
     nviol += __shfl_down(nviol, off, 64);
     nul += __shfl_down(nul, off, 64);
   }
+  // quirk kept from core.py:89-92: cl is indexed by the violation count
+  nviol = __shfl(nviol, 0, 64);
+  const double clv = (nviol < 64 && nviol < nE) ? __shfl(cl_lane, nviol, 64) : cl[nviol];
   if (lane == 0) {
-    // quirk kept from core.py:89-92: cl is indexed by the violation count
-    if (nul > 0) acc += (double)nviol * log(1.0 - cl[nviol]);
-    if (lp || pri.n > 0) {  // core.py:115-119: a forbidden walker keeps the prior value
-      double p = (lp ? lp[wi] : 0.0) + nh_prior_sum(pri, wi);
-      acc = isinf(p) ? p : acc + p;
-    }
+    if (nul > 0) acc += (double)nviol * log(1.0 - clv);
+    if (has_prior)  // core.py:115-119: a forbidden walker keeps the prior value
+      acc = isinf(prior) ? prior : acc + prior;
     lnl[wi] = acc;
   }
   if (mv.coords) {  // nh_move_accept for this walker (emcee RedBlueMove.propose)

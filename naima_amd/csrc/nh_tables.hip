@@ -21,7 +21,11 @@ __global__ __launch_bounds__(256) void k_table_dlog(const double* __restrict__ K
                                                      int ld, double* __restrict__ dlnKt) {
   NH_TAB_PROLOGUE
   double v = 0.0;
-  if (i + 1 < nG) v = log(fabs(Kt[(long long)(i + 1) * ld + k] / Kt[NH_TAB_AT]));
+  if (i + 1 < nG) {
+    const double k1 = Kt[NH_TAB_AT], k2 = Kt[(long long)(i + 1) * ld + k];
+    // a zero node ends the power-law segment (utils.py:347-348): marked for nh_seg_pos
+    v = (k1 == 0.0 || k2 == 0.0) ? NH_DL_ZERO : log(fabs(k2 / k1));
+  }
   dlnKt[NH_TAB_AT] = v;
 }
 
