@@ -48,7 +48,7 @@ KERNEL_FLOP_EQ = {
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
 KERNEL_SYMBOL = {"integrate_tables": "k_integrate_tables", "synchrotron": "k_synchrotron",
-                 "particle_weights": "k_particle_weights_multi", "lnprob": "k_lnprobmodel",
+                 "particle_weights": "k_step_front (proposal+packs+weights+We)", "lnprob": "k_lnprobmodel",
                  "integrate_rows": "k_integrate_rows", "ic_seed_walkers": "k_ic_seed_walkers",
                  "tables": "k_table_*", "glue": "k_pack_rows/k_move_*"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

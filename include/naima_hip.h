@@ -221,9 +221,11 @@ int nh_ew_binary(nh_ctx* ctx, int op, const nh_lazy* x, const nh_lazy* y, int N,
 /* a spectrum component: ptr[w*ld + k] * scale */
 typedef struct { const double* ptr; long long ld; double scale; } nh_comp;
 #define NH_MAX_COMP 8
-/* out[w*ldo + k] = colfac[k] * sum_j comps[j]   (colfac may be NULL) */
+/* out[w*ldo + k] = rowfac[w] * colfac[k] * sum_j comps[j]   (colfac, rowfac may be NULL):
+ * rowfac carries a per-walker physical factor (target density n0 / nh, seed energy
+ * density) that the reference applies as a scalar, radiative.py:684-687, 949-987, 1534 */
 int nh_lincomb(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, const double* colfac,
-               int N, int m, double* out, int ldo);
+               const nh_lazy* rowfac /*host*/, int N, int m, double* out, int ldo);
 
 /* priors of core.py:34-58 on lazy scalars; lp[w] = sum of the terms */
 enum { NH_PRIOR_UNIFORM = 0, NH_PRIOR_NORMAL = 1, NH_PRIOR_LOGUNIFORM = 2, NH_PRIOR_VALUE = 3 };

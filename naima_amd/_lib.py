@@ -62,7 +62,7 @@ _SIGS = {
     "nh_marker_destroy": [_dp, _dp],
     "nh_pack_rows": [_dp, _dp, _i, _i, _dp, _i],
     "nh_ew_binary": [_dp, _i, _dp, _dp, _i, _dp],
-    "nh_lincomb": [_dp, _dp, _i, _dp, _i, _i, _dp, _i],
+    "nh_lincomb": [_dp, _dp, _i, _dp, _dp, _i, _i, _dp, _i],
     "nh_priors": [_dp, _dp, _i, _i, _dp],
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],

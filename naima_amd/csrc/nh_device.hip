@@ -66,33 +66,36 @@ extern "C" int nh_ew_binary(nh_ctx* c, int op, const nh_lazy* x, const nh_lazy* 
 }
 
 // ---------------------------------------------------------------------------
-// out[w][k] = colfac[k] * sum_j scale_j * comp_j[w*ld_j + k]
+// out[w][k] = rowfac[w] * colfac[k] * sum_j scale_j * comp_j[w*ld_j + k]
 // ---------------------------------------------------------------------------
 struct comp_pack { nh_comp c[NH_MAX_COMP]; int n; };
 
-__global__ void k_lincomb(comp_pack P, const double* __restrict__ colfac, int N, int m,
-                          double* __restrict__ out, int ldo) {
+__global__ void k_lincomb(comp_pack P, const double* __restrict__ colfac, nh_lazy rowfac, int N,
+                          int m, double* __restrict__ out, int ldo) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)N * m) return;
   int w = (int)(idx / m), k = (int)(idx % m);
   double s = 0.0;
   for (int j = 0; j < P.n; ++j) s += P.c[j].scale * P.c[j].ptr[(long long)w * P.c[j].ld + k];
   if (colfac) s *= colfac[k];
+  s *= nh_lazy_eval(rowfac, w);
   out[(long long)w * ldo + k] = s;
 }
 
-extern "C" int nh_lincomb(nh_ctx* c, const nh_comp* comps, int ncomp, const double* colfac, int N,
-                          int m, double* out, int ldo) {
+extern "C" int nh_lincomb(nh_ctx* c, const nh_comp* comps, int ncomp, const double* colfac,
+                          const nh_lazy* rowfac, int N, int m, double* out, int ldo) {
   NH_REQUIRE(c && comps && out && ncomp >= 1 && ncomp <= NH_MAX_COMP && N >= 0 && m >= 1 &&
                  ldo >= m, "bad argument");
   if (N == 0) return NH_OK;
   comp_pack P;
   P.n = ncomp;
   for (int j = 0; j < ncomp; ++j) P.c[j] = comps[j];
+  nh_lazy rf = {nullptr, 0, 1.0, 0.0, 0.0, NH_TF_ID, 0};  // constant 1
+  if (rowfac) rf = *rowfac;
   nh_prof_scope ps(c, NH_K_GLUE);
   long long tot = (long long)N * m;
   hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, P,
-                     colfac, N, m, out, ldo);
+                     colfac, rf, N, m, out, ldo);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

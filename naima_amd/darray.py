@@ -328,6 +328,10 @@ class DMat:
             return NotImplemented
         if _is_number(o):
             return self._scaled(float(o))
+        if isinstance(o, DVec):  # per-walker factor (a target density that is a fit parameter)
+            if o.n != self.shape[0]:
+                raise ValueError("factor has %d walkers, matrix has %d" % (o.n, self.shape[0]))
+            return self._rows_scaled(o)
         o = np.asarray(o, dtype=float)
         if o.shape == (self.shape[1],):  # per-energy factor (e.g. E**2 of sed())
             cf = o if self.colfac is None else self.colfac * o
@@ -372,6 +376,17 @@ class DMat:
             arr[j] = nh_comp(p, ld, s)
         return arr
 
+    def _rows_scaled(self, rf):
+        import ctypes as C
+        N, m = self.shape
+        self.ctx.need(*[t[0] for t in self.terms])
+        out = self.ctx.empty((N, m))
+        cf = self.ctx.const(self.colfac) if self.colfac is not None else None
+        lz = rf.lazy()
+        self.ctx.call("nh_lincomb", self.comps(), len(self.terms), cf, C.addressof(lz), N, m, out,
+                      m)
+        return DMat.from_buffer(self.ctx, out, N, m)
+
     def dense(self):
         """one contiguous [N][m] buffer (nh_lincomb) unless already so"""
         N, m = self.shape
@@ -381,7 +396,7 @@ class DMat:
         self.ctx.need(*[t[0] for t in self.terms])
         out = self.ctx.empty((N, m))
         cf = self.ctx.const(self.colfac) if self.colfac is not None else None
-        self.ctx.call("nh_lincomb", self.comps(), len(self.terms), cf, N, m, out, m)
+        self.ctx.call("nh_lincomb", self.comps(), len(self.terms), cf, None, N, m, out, m)
         return DMat.from_buffer(self.ctx, out, N, m)
 
     def buffer(self):

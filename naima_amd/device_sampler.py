@@ -95,6 +95,7 @@ class DeviceLoop:
         self.newlp = ctx.empty((self.ns,))
         self.mylp = ctx.empty((max(self.nloc, 1),))
         self.new_blobs = None
+        self.all_blobs = None
         self.ident = ctx.array(np.arange(max(self.nloc, 1), dtype=np.int32), dtype=np.int32)
         self.graph2 = None
         self.step_graph = None
@@ -172,6 +173,8 @@ class DeviceLoop:
             return
         if self.new_blobs is None:
             self.new_blobs = [self.ctx.empty((self.nloc, m)) for _, m, _, _ in self.cur_blobs]
+            if self.s.comm.size > 1:  # every rank keeps every walker's blobs
+                self.all_blobs = [self.ctx.empty((self.ns, m)) for _, m, _, _ in self.cur_blobs]
         for nb, (cur, m, _, _), b in zip(self.new_blobs, self.cur_blobs, blobs):
             own, ptr, mb, _, _ = self._blob_dense(b)
             self.ctx.call("nh_scatter_rows", nb, m, ptr, mb, self.ident, None, 0, self.nloc, m)
@@ -188,9 +191,14 @@ class DeviceLoop:
             ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
                      self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
         if self.s.store_blobs and self.cur_blobs:
-            for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
-                ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
-                         self.nloc, m)
+            if self.s.comm.size > 1:
+                for ab, (cur, m, _, _) in zip(self.all_blobs, self.cur_blobs):
+                    ctx.call("nh_scatter_rows", cur, m, ab, m, self.sel, self.accepted, 0,
+                             self.ns, m)
+            else:
+                for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
+                    ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
+                             self.nloc, m)
         if self.fused:
             self._front()
 
@@ -267,6 +275,11 @@ class DeviceLoop:
         """the one collective of the path: every rank's new log-probabilities"""
         if self.s.comm.size > 1:
             self.s.comm.allgather_device(self.ctx, self.mylp.ptr, self.newlp, self.nloc)
+            if self.s.store_blobs and self.cur_blobs:
+                # blobs of the proposals follow their log-probabilities: the walker a rank
+                # evaluates changes every step, so every rank keeps all of them
+                for nb, ab, (cur, m, _, _) in zip(self.new_blobs, self.all_blobs, self.cur_blobs):
+                    self.s.comm.allgather_device(self.ctx, nb.ptr, ab, self.nloc * m)
 
     def _half_step_body(self):
         self._part_evaluate()
@@ -287,18 +300,16 @@ class DeviceLoop:
             s.comm.allgather_device(ctx, total.ptr, self.logp, hi - lo)
         else:
             ctx.call("nh_copy", self.logp, total.ptr, 8 * self.N)
-        if s.store_blobs and blobs and s.comm.size > 1:
-            raise NotImplementedError(
-                "device=True keeps blobs only for a single rank (a walker's evaluating rank "
-                "changes every step); use store_blobs=False or the host loop when sharded")
         if s.store_blobs and blobs:
             self.cur_blobs, units = [], []
             ident = ctx.array(np.arange(lo, hi, dtype=np.int32), dtype=np.int32)
             for b in blobs:
                 own, ptr, m, unit, trail = self._blob_dense(b)
                 cur = ctx.empty((self.N, m))
-                ctx.call("nh_memset", cur, 0, cur.nbytes)
-                ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
+                if s.comm.size > 1:
+                    s.comm.allgather_device(ctx, ptr, cur, (hi - lo) * m)
+                else:
+                    ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
                 self.cur_blobs.append((cur, m, unit, trail))
                 units.append(unit)
             s.blob_units = units

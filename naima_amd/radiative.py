@@ -48,6 +48,23 @@ def _is_batched(x):
     return np.ndim(v) > 0
 
 
+def _is_dev(x):
+    v = x.value if isinstance(x, u.Quantity) else x
+    return getattr(v, "__array_priority__", 0) == 30000
+
+
+def _per_walker(x):
+    """True for a parameter given per walker: host vector or device value"""
+    return _is_batched(x) or _is_dev(x)
+
+
+def _as_dvec(ctx, rows, N):
+    if isinstance(rows, DVec):
+        return rows
+    buf = ctx.array(np.broadcast_to(np.asarray(rows, dtype=float), (N,)))
+    return DVec(ctx, buf, buf.ptr, N)
+
+
 def _merge_batch(*sizes):
     n = 1
     for s in sizes:
@@ -79,15 +96,74 @@ class BaseRadiative:
     @property
     def batch_size(self):
         return _merge_batch(getattr(self.particle_distribution, "batch_size", 1),
-                            *self._own_batch_sizes())
+                            *(self._own_batch_sizes() + self._structural_batch()))
 
     @property
     def is_batched(self):
         return bool(getattr(self.particle_distribution, "is_batched", False)) or any(
-            s != 1 for s in self._own_batch_sizes()) or self._own_batched()
+            s != 1 for s in self._own_batch_sizes() + self._structural_batch()) \
+            or self._own_batched()
 
     def _own_batched(self):
         return False
+
+    # -- the general path: parameters that shape the grids or the emission tables ----
+    # Grid limits, grid densities, seed temperatures ... are walker-independent in the
+    # batched launches (that is what lets tables be shared and cached).  When one of
+    # them IS given per walker (a fit parameter), every walker is evaluated as a batch
+    # of one through the same kernels: always correct, table caches do not help.
+    _structural = ()
+
+    def _structural_values(self):
+        return [(n, getattr(self, n)) for n in self._structural if hasattr(self, n)]
+
+    def _needs_walker_loop(self):
+        for n, v in self._structural_values():
+            if _is_dev(v):
+                raise NotImplementedError(
+                    "%s is a device-resident per-walker value: the particle grid / emission "
+                    "tables would differ per walker.  Run the sampler with device=False (host "
+                    "loop), which evaluates such walkers one by one" % n)
+            if _is_batched(v):
+                return True
+        return False
+
+    def _structural_batch(self):
+        return tuple(_batch_of(v) for _, v in self._structural_values())
+
+    def _walker(self, k):
+        """this model for walker k alone (scalars everywhere)"""
+        import copy
+        one = copy.copy(self)
+        one.__dict__ = dict(self.__dict__)
+        for c in ("_cache", "_queue"):
+            if c in one.__dict__:
+                one.__dict__[c] = type(one.__dict__[c])()
+        pd = copy.copy(self.particle_distribution)
+        pd.__dict__ = {a: b for a, b in self.particle_distribution.__dict__.items()
+                       if not a.startswith("_")}
+        for name in getattr(pd, "param_names", ()):
+            v = getattr(pd, name)
+            if _is_batched(v):
+                setattr(pd, name, v[k])
+        one.particle_distribution = pd
+        for name in tuple(self._structural) + tuple(self._walker_scalars):
+            if hasattr(self, name):
+                v = getattr(self, name)
+                if _is_batched(v):
+                    one.__dict__[name] = v[k]
+        return one
+
+    _walker_scalars = ()
+
+    def _loop_walkers(self, what, *args, **kw):
+        N = self.batch_size
+        res = []
+        for k in range(N):
+            r = getattr(self._walker(k), what)
+            res.append(r(*args, **kw) if callable(r) else r)
+        unit = res[0].unit
+        return u.Quantity(np.stack([np.asarray(r.to(unit).value, dtype=float) for r in res]), unit)
 
     def _finish(self, host, E):
         """(N, nE) ndarray -> Quantity with the reference's shape"""
@@ -112,14 +188,21 @@ class BaseRadiative:
                 return True
         return False
 
-    def _result(self, ctx, out, N, nE, E, scale=1.0):
+    def _result(self, ctx, out, N, nE, E, scale=1.0, rows=None):
         """spectra [N][nE] in a device buffer -> Quantity 1/(s eV) (lazy on device, or
-        downloaded with the reference's shape)"""
+        downloaded with the reference's shape).  ``rows``: per-walker factor (host
+        vector or device scalar per walker) for physical parameters that the reference
+        applies as one scalar and that may be fit parameters here (n0, nh, seed u)."""
         if self.on_device:
-            return u.Quantity(DMat.from_buffer(ctx, out, N, nE, scale=scale), _SPEC_UNIT)
+            m = DMat.from_buffer(ctx, out, N, nE, scale=scale)
+            if rows is not None:
+                m = m * _as_dvec(ctx, rows, N)
+            return u.Quantity(m, _SPEC_UNIT)
         host = out.get()
         if scale != 1.0:
             host = host * scale
+        if rows is not None:
+            host = host * np.broadcast_to(np.asarray(rows, dtype=float), (N,))[:, None]
         return u.Quantity(self._finish(host, E), _SPEC_UNIT)
 
     def _weights(self, xg, e_eV, unit_scale):
@@ -201,6 +284,8 @@ class BaseRadiative:
     def flux(self, photon_energy, distance=1 * u.kpc):
         """Differential flux at ``distance``; ``distance=0`` gives the intrinsic
         differential luminosity (radiative.py:88-111)."""
+        if self._needs_walker_loop():
+            return self._loop_walkers("flux", photon_energy, distance=distance)
         spec = self._spectrum_branch(photon_energy)
         if not _dist_is_zero(distance):
             distance = validate_scalar("distance", distance, physical_type="length")
@@ -251,6 +336,7 @@ def _scalar_energy(name, q):
 
 class BaseElectron(BaseRadiative):
     """electron grid, nelec, We (radiative.py:137-236)"""
+    _structural = ("Eemin", "Eemax", "nEed")
 
     def __init__(self, particle_distribution):
         super().__init__(particle_distribution)
@@ -311,12 +397,16 @@ class BaseElectron(BaseRadiative):
     @property
     def We(self):
         """Total energy in electrons used for the radiative calculation"""
+        if self._needs_walker_loop():
+            return self._loop_walkers("We")
         return self._We_on(self._gam)
 
     def compute_We(self, Eemin=None, Eemax=None):
         """Total energy in electrons between Eemin and Eemax (radiative.py:168-195)"""
         if Eemin is None and Eemax is None:
             return self.We
+        if self._needs_walker_loop():
+            return self._loop_walkers("compute_We", Eemin=Eemin, Eemax=Eemax)
         if Eemax is None:
             Eemax = self.Eemax
         if Eemin is None:
@@ -349,6 +439,8 @@ class Synchrotron(BaseElectron):
     and the keyword overrides ``Eemin`` (1 GeV), ``Eemax`` (1e9 mec2), ``nEed`` (100).
     ``B`` may be a 1-D array over walkers.
     """
+
+    _walker_scalars = ("B",)
 
     def __init__(self, particle_distribution, B=3.24e-6 * u.G, **kwargs):
         super().__init__(particle_distribution)
@@ -422,16 +514,44 @@ class InverseCompton(BaseElectron):
         self.param_names += ["seed_photon_fields"]
         self.__dict__.update(**kwargs)
 
+    def _structural_values(self):
+        """grid parameters + the temperatures / angles of thermal seeds (their emission
+        tables depend on them)"""
+        vals = super()._structural_values()
+        for name, seed in self.seed_photon_fields.items():
+            if seed["type"] == "thermal":
+                vals.append((name + "-T", seed["T"]))
+                if not seed["isotropic"]:
+                    vals.append((name + "-theta", seed["theta"]))
+        return vals
+
+    def _walker(self, k):
+        one = super()._walker(k)
+        seeds = OrderedDict()
+        for name, seed in self.seed_photon_fields.items():
+            sd = dict(seed)
+            for key in ("T", "u", "theta"):
+                if key in sd and _is_batched(sd[key]):
+                    sd[key] = sd[key][k]
+            if sd["type"] == "array" and np.ndim(sd["photon_density"].value) == 2:
+                sd["photon_density"] = sd["photon_density"][k]
+            seeds[name] = sd
+        one.__dict__["seed_photon_fields"] = seeds
+        return one
+
     def _own_batch_sizes(self):
         sizes = []
         for seed in self.seed_photon_fields.values():
             if seed["type"] == "array" and np.ndim(seed["photon_density"].value) == 2:
                 sizes.append(seed["photon_density"].shape[0])
+            if seed["type"] == "thermal":
+                sizes.append(_batch_of(seed["u"]))
         return tuple(sizes)
 
     def _own_device_values(self):
         return tuple(s["photon_density"] for s in self.seed_photon_fields.values()
-                     if s["type"] == "array")
+                     if s["type"] == "array") + tuple(
+            s["u"] for s in self.seed_photon_fields.values() if s["type"] == "thermal")
 
     @staticmethod
     def _process_input_seed(seed_photon_fields):
@@ -468,16 +588,26 @@ class InverseCompton(BaseElectron):
                 else:
                     name, T, uu, theta = inseed
                     seed["isotropic"] = False
-                    seed["theta"] = validate_scalar("{0}-theta".format(name), theta,
-                                                    physical_type="angle")
+                    if _is_batched(theta):
+                        validate_physical_type("{0}-theta".format(name), theta, "angle")
+                        seed["theta"] = theta
+                    else:
+                        seed["theta"] = validate_scalar("{0}-theta".format(name), theta,
+                                                        physical_type="angle")
                 thermal = T.unit.physical_type == "temperature"
                 if thermal:
                     seed["type"] = "thermal"
-                    validate_scalar("{0}-T".format(name), T, domain="positive",
-                                    physical_type="temperature")
+                    if _is_batched(T):  # one temperature per walker: the general path
+                        validate_physical_type("{0}-T".format(name), T, "temperature")
+                    else:
+                        validate_scalar("{0}-T".format(name), T, domain="positive",
+                                        physical_type="temperature")
                     seed["T"] = T
                     if not isinstance(uu, u.Quantity) and uu == 0:
                         seed["u"] = ar * T ** 4
+                    elif _per_walker(uu):  # one energy density per walker (fit parameter)
+                        validate_physical_type("{0}-u".format(name), uu, "pressure")
+                        seed["u"] = uu
                     else:
                         validate_scalar("{0}-u".format(name), uu, domain="positive",
                                         physical_type="pressure")
@@ -558,11 +688,14 @@ class InverseCompton(BaseElectron):
             Kt, dlnKt = ctx.table(
                 key, lambda: self._build_static_tables(ctx, static, gd, nG, Ed, nE))
             scale = np.empty(nK)
+            rowfac = {}
             for j, name in enumerate(static):
                 seed = self.seed_photon_fields[name]
                 if seed["type"] == "thermal":
                     T = seed["T"].to("K").value
                     uf = (seed["u"].to("erg/cm3").value / (AR_CGS * T ** 4))
+                    if _per_walker(seed["u"]):  # energy density as a fit parameter
+                        rowfac[name], uf = uf, 1.0
                 else:
                     uf = 1.0
                 scale[j * nE:(j + 1) * nE] = uf * Eph / E_eV  # radiative.py:684-687
@@ -573,10 +706,15 @@ class InverseCompton(BaseElectron):
             if dev:
                 for j, name in enumerate(static):
                     specs[name] = DMat.from_buffer(ctx, out, N, nE, ld=nK, col0=j * nE)
+                    if name in rowfac:
+                        specs[name] = specs[name] * _as_dvec(ctx, rowfac[name], N)
             else:
                 host = out.get()
                 for j, name in enumerate(static):
                     specs[name] = host[:, j * nE:(j + 1) * nE]
+                    if name in rowfac:
+                        specs[name] = specs[name] * np.broadcast_to(
+                            np.asarray(rowfac[name], dtype=float), (N,))[:, None]
         for name in names:
             if name in specs:
                 continue
@@ -625,6 +763,8 @@ class InverseCompton(BaseElectron):
     def flux(self, photon_energy, distance=1 * u.kpc, seed=None):
         """Differential flux, optionally from a single seed photon field
         (radiative.py:712-759)"""
+        if self._needs_walker_loop():
+            return self._loop_walkers("flux", photon_energy, distance=distance, seed=seed)
         model = super().flux(photon_energy, distance=distance)
         if seed is not None:
             idx = self._seed_index(seed)
@@ -651,6 +791,9 @@ class Bremsstrahlung(BaseElectron):
     """Bremsstrahlung on a completely ionised gas (Baring et al. 1999);
     radiative.py:794-989.  ``n0``: total ion number density; ``weight_ee`` /
     ``weight_ep`` default to ISM abundances."""
+
+    _structural = BaseElectron._structural + ("weight_ee", "weight_ep")
+    _walker_scalars = ("n0",)
 
     def __init__(self, particle_distribution, n0=1 / u.cm ** 3, **kwargs):
         super().__init__(particle_distribution)
@@ -682,7 +825,12 @@ class Bremsstrahlung(BaseElectron):
             return Kt, dKt
 
         Kt, dKt = ctx.table(("brems", gd.ptr, Ed.ptr), build)
-        n0 = validate_scalar("n0", self.n0, physical_type="number density").to("1/cm3").value
+        rows = None
+        if _per_walker(self.n0):  # the target density is a fit parameter: one factor per walker
+            validate_physical_type("n0", self.n0, "number density")
+            rows, n0 = self.n0.to("1/cm3").value, 1.0
+        else:
+            n0 = validate_scalar("n0", self.n0, physical_type="number density").to("1/cm3").value
         # spec = n0 (w_ee c int(n sigma_ee) + w_ep c int(n sigma_1)), radiative.py:949-987
         scale = np.concatenate([np.full(nE, n0 * self.weight_ee * C_CGS),
                                 np.full(nE, n0 * self.weight_ep * C_CGS)])
@@ -692,13 +840,25 @@ class Bremsstrahlung(BaseElectron):
         if self.on_device:
             tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE) + \
                 DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE)
+            if rows is not None:
+                tot = tot * _as_dvec(ctx, rows, N)
             return u.Quantity(tot, _SPEC_UNIT)
         host = out.get()
-        return u.Quantity(self._finish(host[:, :nE] + host[:, nE:], E), _SPEC_UNIT)
+        host = host[:, :nE] + host[:, nE:]
+        if rows is not None:
+            host = host * np.broadcast_to(np.asarray(rows, dtype=float), (N,))[:, None]
+        return u.Quantity(self._finish(host, E), _SPEC_UNIT)
+
+    def _own_batch_sizes(self):
+        return (_batch_of(self.n0),)
+
+    def _own_device_values(self):
+        return (self.n0,)
 
 
 class BaseProton(BaseRadiative):
     """proton grid, J, Wp (radiative.py:992-1096)"""
+    _structural = ("Epmin", "Epmax", "nEpd")
 
     def __init__(self, particle_distribution):
         super().__init__(particle_distribution)
@@ -750,12 +910,16 @@ class BaseProton(BaseRadiative):
     @property
     def Wp(self):
         """Total energy in protons"""
+        if self._needs_walker_loop():
+            return self._loop_walkers("Wp")
         return self._Wp_on(self._Ep)
 
     def compute_Wp(self, Epmin=None, Epmax=None):
         """Total energy in protons between Epmin and Epmax (radiative.py:1023-1055)"""
         if Epmin is None and Epmax is None:
             return self.Wp
+        if self._needs_walker_loop():
+            return self._loop_walkers("compute_Wp", Epmin=Epmin, Epmax=Epmax)
         if Epmax is None:
             Epmax = self.Epmax
         if Epmin is None:
@@ -807,10 +971,16 @@ class PionDecay(BaseProton):
     _m_p = M_P_GEV
     _Tth = T_TH_GEV
 
+    _walker_scalars = ("nh",)
+
     def __init__(self, particle_distribution, nh=1.0 / u.cm ** 3, nuclear_enhancement=True,
                  **kwargs):
         super().__init__(particle_distribution)
-        self.nh = validate_scalar("nh", nh, physical_type="number density")
+        if _per_walker(nh):  # a fit parameter: one value per walker
+            validate_physical_type("nh", nh, "number density")
+            self.nh = nh
+        else:
+            self.nh = validate_scalar("nh", nh, physical_type="number density")
         self.nuclear_enhancement = nuclear_enhancement
         self.useLUT = True
         self.hiEmodel = "Pythia8"
@@ -861,5 +1031,14 @@ class PionDecay(BaseProton):
                  0 if use_lut else 1)
         nh = self.nh.to("1/cm3").value
         fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
-        self.specpp = self._result(ctx, out, N, nE, E, scale=fac)
+        if _per_walker(self.nh):
+            self.specpp = self._result(ctx, out, N, nE, E, rows=fac)
+        else:
+            self.specpp = self._result(ctx, out, N, nE, E, scale=fac)
         return self.specpp
+
+    def _own_batch_sizes(self):
+        return (_batch_of(self.nh),)
+
+    def _own_device_values(self):
+        return (self.nh,)

@@ -16,11 +16,14 @@ out = sys.argv[1]
 comm = GlooComm()
 model, p0, raw, data, prior, labels = build_problem("cfg3", na)
 s = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, comm=comm,
-                    naima_style=True, store_blobs=False, device=True)
+                    naima_style=True, store_blobs=True, device=True)
 pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, 5)))
 st = s.run_mcmc(pos, 6)
 np.save(os.path.join(out, "coords_%d.npy" % comm.rank), st.coords)
 np.save(os.path.join(out, "logp_%d.npy" % comm.rank), st.log_prob)
 np.save(os.path.join(out, "chain_%d.npy" % comm.rank), s.get_chain())
+blobs = s.get_blobs()
+np.save(os.path.join(out, "blob0_%d.npy" % comm.rank), np.asarray(blobs[0]))
+np.save(os.path.join(out, "blob1_%d.npy" % comm.rank), np.asarray(blobs[1]))
 assert s._dev.graph is not None and s._dev.graph2 is not None
 assert s.n_walker_evals < 32 * 7  # each rank evaluated only its shard

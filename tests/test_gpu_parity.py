@@ -608,12 +608,19 @@ def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
     assert_allclose(c0, c1, rtol=1e-12)
     model, p0, raw, data, prior, labels = build_problem("cfg3", na)
     s = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
-                        store_blobs=False, device=True)
+                        store_blobs=True, device=True)
     pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, 5)))
     st = s.run_mcmc(pos, 6)
     assert_allclose(c0, st.coords, rtol=1e-9)
     assert_allclose(np.load(tmp_path / "logp_0.npy"), st.log_prob, rtol=1e-7)
     assert_allclose(np.load(tmp_path / "chain_1.npy"), s.get_chain(), rtol=1e-9)
+    # blobs (model spectra, We) are kept on every rank although a walker's evaluating
+    # rank changes from step to step
+    blobs = s.get_blobs()
+    for r in (0, 1):
+        assert_allclose(np.load(tmp_path / ("blob0_%d.npy" % r)), np.asarray(blobs[0]),
+                        rtol=1e-9, atol=1e-300)
+        assert_allclose(np.load(tmp_path / ("blob1_%d.npy" % r)), np.asarray(blobs[1]), rtol=1e-9)
 
 
 def test_edge_shapes_against_oracle(na):
