@@ -190,6 +190,18 @@ int nh_table_pion_lut(nh_ctx* ctx, const double* Ep_GeV, int nG, const double* E
                       double* Kt, double* dlnKt, int ld);
 
 /* ---- row 11: core.py:64-94 lnprobmodel ----------------------------------- */
+/* PionDecayKelner06._spectrum (radiative.py:1716-1767; Kelner, Aharonian & Bugayov 2006):
+ * out[w*ldo + k] = differential luminosity 1/(s eV) for nh = 1 cm^-3 at photon energies
+ * E_eV[k]: full calculation (Eq. 71, :1665-1684) at E >= Etrans_eV, delta-functional
+ * approximation (:1693-1714) below, joined at Etrans by nhat (:1743-1748) when `mixed`
+ * (the host sets it when energies lie on both sides).  params: the [N][8] particle rows of
+ * nh_particle_weights (eV).  The reference's adaptive quad (epsrel 1e-3) is replaced by a
+ * converged fixed Gauss-Legendre rule.  nhat_out[N], wp_TeV_out[N] (the `Wp` property,
+ * :1716-1728, in TeV) may be NULL. */
+int nh_pion_kelner06(nh_ctx* ctx, int kind, const double* params, int N, const double* E_eV,
+                     int nE, double Etrans_eV, int mixed, double* out, int ldo,
+                     double* nhat_out, double* wp_TeV_out);
+
 /* model[w][k] = sum_j cscale[j] * comp_j[w*ldc + k]        (1/(s cm2 eV))
  * m' = model*conv[k] (SED<->differential factor, utils.py:219-282)
  * lnl[w] = -sum_{!ul} (m'-flux)^2/(2 sigma^2), sigma = err_hi if m'>flux else err_lo,

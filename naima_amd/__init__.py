@@ -12,8 +12,10 @@ from . import units as u  # noqa: F401
 from .core import (lnprob, lnprobmodel, log_uniform_prior, normal_prior,  # noqa: F401
                    uniform_prior, get_sampler, run_sampler)
 from .models import (BrokenPowerLaw, ExponentialCutoffBrokenPowerLaw,  # noqa: F401
-                     ExponentialCutoffPowerLaw, LogParabola, PowerLaw)
-from .radiative import Bremsstrahlung, InverseCompton, PionDecay, Synchrotron  # noqa: F401
+                     ExponentialCutoffPowerLaw, LogParabola, PowerLaw, TableModel,
+                     EblAbsorptionModel)
+from .radiative import (Bremsstrahlung, InverseCompton, PionDecay,  # noqa: F401
+                        PionDecayKelner06, Synchrotron)
 from .analysis import read_run, save_run  # noqa: F401
 from .datatable import validate_data_table  # noqa: F401
 

@@ -69,6 +69,7 @@ _SIGS = {
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
     "nh_step_front": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp,
                       _i, _dp, _i, _dp],
+    "nh_pion_kelner06": [_dp, _i, _dp, _i, _dp, _i, _d, _i, _dp, _i, _dp, _dp],
     "nh_lnprob_accept": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp,
                          _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],

@@ -246,3 +246,116 @@ class LogParabola(_ParticleDistribution):
         self.e_0 = validate_scalar_or_batch("e_0", e_0, domain="positive", physical_type="energy")
         self.alpha = alpha
         self.beta = beta
+
+
+class TableModel:
+    """A model from a table of energies and values, interpolated with a cubic spline in
+    log-log space; zero outside the table (models.py:425-467).  As the particle
+    distribution of a radiative model its SHAPE on the particle grid is
+    walker-independent (evaluated once on the host, as the reference does, and cached in
+    HBM); only ``amplitude`` may vary per walker or live on the device."""
+    param_names = ["amplitude"]
+    kind = "table"
+
+    def __init__(self, energy, values, amplitude=1):
+        from scipy.interpolate import interp1d
+
+        from .validator import validate_array
+        self._energy = validate_array("energy", energy, domain="positive", physical_type="energy")
+        self._values = values
+        self.amplitude = amplitude
+        loge = np.log10(self._energy.to("eV").value)
+        if isinstance(values, u.Quantity):
+            self.unit = values.unit
+            with np.errstate(divide="ignore"):
+                logy = np.log10(values.value)
+        else:
+            self.unit = u.dimensionless_unscaled
+            with np.errstate(divide="ignore"):
+                logy = np.log10(values)
+        self._interplogy = interp1d(loge, logy, fill_value=-np.inf, bounds_error=False,
+                                    kind="cubic")
+
+    def __setattr__(self, name, value):
+        self.__dict__[name] = value
+        if name == "amplitude":
+            self.__dict__.pop("_w_dev", None)
+
+    def _shape(self, e_eV):
+        """10**interp(log10 E): the table's values (in ``self.unit``) at E [eV]"""
+        with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+            return np.power(10, self._interplogy(np.log10(np.asarray(e_eV, dtype=float))))
+
+    @property
+    def _amp(self):
+        a = self.amplitude
+        return a.value if isinstance(a, u.Quantity) else a
+
+    @property
+    def on_device(self):
+        return getattr(self._amp, "__array_priority__", 0) == 30000
+
+    @property
+    def batch_size(self):
+        a = self._amp
+        return int(np.shape(a)[0]) if np.ndim(a) > 0 else 1
+
+    @property
+    def is_batched(self):
+        return np.ndim(self._amp) > 0
+
+    def __call__(self, e):
+        e = _validate_ene(e)
+        interpy = self._shape(e.to("eV").value)
+        a = self._amp
+        if np.ndim(a) > 0 and np.ndim(interpy) > 0:
+            a = np.asarray(a, dtype=float)[:, None]
+        return u.Quantity(a * interpy, self.unit)
+
+
+class EblAbsorptionModel(TableModel):
+    """Opacity of the extragalactic background light (Dominguez et al. 2011) at a given
+    redshift as a TableModel; ``transmission(e)`` is the factor to multiply a flux with
+    (models.py:470-552).  No interpolation in redshift: the closest tabulated z
+    (step 0.01) is used, as in the reference."""
+
+    def __init__(self, redshift, ebl_absorption_model="Dominguez"):
+        import os
+
+        from .validator import validate_scalar
+        if not isinstance(redshift, u.Quantity):
+            redshift = redshift * u.dimensionless_unscaled
+        self.redshift = validate_scalar("redshift", redshift, domain="positive",
+                                        physical_type="dimensionless")
+        self.model = ebl_absorption_model
+        if self.model != "Dominguez":
+            raise ValueError('Model should be one of: ["Dominguez"]')
+        fname = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
+                             "tau_dominguez11.npz")
+        tab = np.load(fname)
+        energy = tab["energy_TeV"] * u.TeV
+        z = float(self.redshift.value)
+        if z >= 0.01:
+            redshift_list = np.arange(0.01, 4, 0.01)
+            col = int(np.abs(redshift_list - z).argmin())
+            table_values = np.array(tab["table"][:, col], dtype=float)
+            table_values[table_values > 150.0] = 150.0  # high enough; avoids overflow later
+            taus = 10 ** table_values * u.dimensionless_unscaled
+        else:
+            taus = 10 ** np.zeros(len(tab["energy_TeV"])) * u.dimensionless_unscaled
+        super().__init__(energy, taus)
+
+    def transmission(self, e):
+        e = _validate_ene(e)
+        ev = np.atleast_1d(e.to("eV").value).astype(float)
+        e_GeV = np.atleast_1d(e.to("GeV").value)
+        e_TeV = np.atleast_1d(e.to("TeV").value)
+        taus = np.zeros(len(ev))
+        for i in range(len(ev)):
+            if e_GeV[i] < 1.0:
+                taus[i] = 0.0
+            elif e_TeV[i] > 100.0:
+                taus[i] = np.log10(6000.0)
+            else:
+                taus[i] = np.log10(float(np.asarray(self(ev[i] * u.eV).value)))
+        return np.exp(-taus)

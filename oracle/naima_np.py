@@ -592,6 +592,73 @@ def pion_spectrum(E_eV, Ep_GeV, J, nh=1.0, diffsigma=None, hiE="Pythia8",
 
 
 # ---------------------------------------------------------------------------
+# PionDecayKelner06 (radiative.py:1543-1767), Kelner, Aharonian & Bugayov 2006.
+# Energies in TeV as in the reference; J in 1/TeV.
+# ---------------------------------------------------------------------------
+K06_KPI = 0.17                    # radiative.py:1689
+K06_MP_TEV = M_P_GEV * 1e-3       # (m_p c^2).to("TeV"), radiative.py:1690
+K06_MPI_TEV = 1.349766e-4         # radiative.py:1691
+K06_ETH_TEV = 1.22e-3             # radiative.py:1643
+
+
+def k06_Fgamma(x, Ep):
+    """KAB06 Eq. 58-61 (radiative.py:1597-1623)"""
+    L = np.log(Ep)
+    B = 1.30 + 0.14 * L + 0.011 * L ** 2
+    beta = (1.79 + 0.11 * L + 0.008 * L ** 2) ** -1
+    k = (0.801 + 0.049 * L + 0.014 * L ** 2) ** -1
+    xb = x ** beta
+    F1 = B * (np.log(x) / x) * ((1 - xb) / (1 + k * xb * (1 - xb))) ** 4
+    F2 = (1.0 / np.log(x) - (4 * beta * xb) / (1 - xb)
+          - (4 * k * beta * xb * (1 - 2 * xb)) / (1 + k * xb * (1 - xb)))
+    return F1 * F2
+
+
+def k06_sigma_inel(Ep):
+    """KAB06 Eq. 73, 79 (radiative.py:1625-1647), cm^2; scalar Ep [TeV]"""
+    L = np.log(Ep)
+    sigma = 34.3 + 1.88 * L + 0.25 * L ** 2
+    if Ep <= 0.1:
+        sigma *= (1 - (K06_ETH_TEV / Ep) ** 4) ** 2 * heaviside(Ep - K06_ETH_TEV)
+    return sigma * 1e-27
+
+
+def k06_spectrum(E_eV, J_per_TeV, nh=1.0, Etrans_TeV=0.1, epsrel=1e-3):
+    """radiative.py:1649-1767: differential luminosity 1/(s eV) at photon energies E_eV.
+    ``J_per_TeV(E_TeV)``: particles per TeV.  ``epsrel`` = the reference's quad
+    tolerance (1e-3); smaller values give the converged integrals.  Returns (spec, nhat)."""
+    from scipy.integrate import quad
+    Eg = np.atleast_1d(np.asarray(E_eV, dtype=float)) * 1e-12
+
+    def hiE(Egamma):  # Eq. 72, radiative.py:1665-1684
+        def f(x):
+            try:
+                return (k06_sigma_inel(Egamma / x) * J_per_TeV(Egamma / x)
+                        * k06_Fgamma(x, Egamma / x) / x)
+            except ZeroDivisionError:
+                return np.nan
+        return C_CGS * quad(f, 0.0, 1.0, epsrel=epsrel, epsabs=0)[0]
+
+    def loE(Egamma, nhat):  # delta-functional approximation, radiative.py:1693-1714
+        def f(Epi):
+            Ep0 = K06_MP_TEV + Epi / K06_KPI
+            qpi = C_CGS * (nhat / K06_KPI) * k06_sigma_inel(Ep0) * J_per_TeV(Ep0)
+            return qpi / np.sqrt(Epi ** 2 - K06_MPI_TEV ** 2)
+        Epimin = Egamma + K06_MPI_TEV ** 2 / (4 * Egamma)
+        return 2 * quad(f, Epimin, np.inf, epsrel=epsrel, epsabs=0)[0]
+
+    nhat = 1.0
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if np.any(Eg < Etrans_TeV) and np.any(Eg >= Etrans_TeV):
+                nhat = hiE(Etrans_TeV) / loE(Etrans_TeV, 1.0)
+            spec = np.array([hiE(e) if e >= Etrans_TeV else loE(e, nhat) for e in Eg])
+    return nh * spec * 1e-12, nhat  # 1/(s TeV) -> 1/(s eV)
+
+
+# ---------------------------------------------------------------------------
 # row 4: flux / sed
 # ---------------------------------------------------------------------------
 def to_flux(spec, distance_cm):

@@ -119,3 +119,100 @@ def test_general_path_refuses_device_values(na):
     pd = na.ExponentialCutoffPowerLaw(10 ** P[0] / u.eV, 10 * u.TeV, 2.4, 50 * u.TeV)
     with pytest.raises(NotImplementedError):
         na.InverseCompton(pd, Eemin=P[1] * u.GeV).flux(E_GAMMA * u.eV, 1 * u.kpc)
+
+
+def test_table_model_particle_distribution(na, golden):
+    """TableModel (models.py:425-467) as the particle distribution of every radiative
+    class, against the reference (tests/golden/extra.npz, gen_golden_extra.py)"""
+    u = na.u
+    z = golden("extra")
+    tm = na.TableModel(z["tm_energy_eV"] * u.eV, z["tm_values_per_eV"] / u.eV, amplitude=2.5)
+    assert_allclose(tm(z["tm_call_e_eV"] * u.eV).to("1/eV").value, z["tm_call"], rtol=1e-13)
+    Eg, Ex = z["tm_Egamma_eV"] * u.eV, z["tm_Ex_eV"] * u.eV
+    d = 1.5 * u.kpc
+    ic = na.InverseCompton(tm, seed_photon_fields=["CMB", "FIR"])
+    assert_allclose(ic.flux(Eg, d).to("1/(s cm2 eV)").value, z["tm_ic_flux"], rtol=1e-10)
+    assert_allclose(ic.compute_We(Eemin=1 * u.TeV).to("erg").value, z["tm_We_gt_1TeV_erg"],
+                    rtol=1e-10)
+    syn = na.Synchrotron(tm, B=15 * u.uG)
+    assert_allclose(syn.flux(Ex, d).to("1/(s cm2 eV)").value, z["tm_syn_flux"], rtol=1e-10,
+                    atol=1e-300)
+    br = na.Bremsstrahlung(tm, n0=2 / u.cm ** 3)
+    assert_allclose(br.flux(Eg, d).to("1/(s cm2 eV)").value, z["tm_brems_flux"], rtol=1e-10)
+    tp = na.TableModel(z["tm_energy_eV"] * u.eV, z["tm_values_per_eV"] / u.eV)
+    pp = na.PionDecay(tp, nh=3 / u.cm ** 3, useLUT=False)
+    assert_allclose(pp.flux(Eg, d).to("1/(s cm2 eV)").value, z["tm_pp_flux"], rtol=1e-10,
+                    atol=1e-300)
+    assert_allclose(pp.Wp.to("erg").value, z["tm_Wp_erg"], rtol=1e-10)
+    # amplitude per walker: rows scale, shape shared
+    tmb = na.TableModel(z["tm_energy_eV"] * u.eV, z["tm_values_per_eV"] / u.eV,
+                        amplitude=np.array([2.5, 5.0, 0.25]))
+    fb = na.InverseCompton(tmb, seed_photon_fields=["CMB", "FIR"]).flux(Eg, d)
+    assert fb.shape == (3, Eg.size)
+    assert_allclose(fb.to("1/(s cm2 eV)").value,
+                    np.outer([1.0, 2.0, 0.1], z["tm_ic_flux"]), rtol=1e-10)
+
+
+def test_ebl_absorption_model(na, golden):
+    """EblAbsorptionModel.transmission (models.py:470-552) against the reference, and as a
+    per-energy factor on a batched flux"""
+    u = na.u
+    z = golden("extra")
+    e = z["ebl_e_eV"] * u.eV
+    inside = (z["ebl_e_eV"] >= 1e9) & (z["ebl_e_eV"] <= 1e14)
+    for zz in (0.005, 0.5, 1.234, 3.99):
+        ebl = na.EblAbsorptionModel(zz)
+        assert_allclose(ebl.transmission(e), z["ebl_transmission_z%s" % zz], rtol=1e-12)
+        assert_allclose(np.asarray(ebl(e[inside]).value), z["ebl_call_z%s" % zz], rtol=1e-11)
+    with pytest.raises(ValueError):
+        na.EblAbsorptionModel(0.5, ebl_absorption_model="Franceschini")
+    pd = _ecpl(na, np.array([1e33, 2e33]), np.array([30.0, 50.0]))
+    ic = na.InverseCompton(pd, seed_photon_fields=["CMB"])
+    Eg = np.geomspace(1e10, 5e13, 9) * u.eV
+    att = na.EblAbsorptionModel(0.5).transmission(Eg)
+    f = ic.flux(Eg, 1 * u.kpc)
+    assert_allclose((f * att).value, f.value * att[None, :], rtol=1e-15)
+
+
+def test_pion_decay_kelner06(na, golden):
+    """PionDecayKelner06 (radiative.py:1543-1767): the reference integrates with adaptive
+    quad at epsrel = 1e-3, the kernel with a converged fixed rule -- agreement with the
+    reference within its tolerance (measured 4e-5), with the converged oracle to 1e-8"""
+    from oracle import naima_np as O
+    u = na.u
+    z = golden("extra")
+    E = z["k06_E_eV"]
+    pl = na.PowerLaw(4e35 / u.eV, 1 * u.TeV, 2.2)
+    ecpl = na.ExponentialCutoffPowerLaw(4e35 / u.eV, 1 * u.TeV, 2.0, 100 * u.TeV)
+    opd = {"pl": O.ParticleDist("PowerLaw", amplitude=4e35, e_0=1e12, alpha=2.2),
+           "ecpl": O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=4e35, e_0=1e12,
+                                  alpha=2.0, e_cutoff=1e14, beta=1.0)}
+    for tag, pd in (("pl", pl), ("ecpl", ecpl)):
+        k = na.PionDecayKelner06(pd, nh=2 / u.cm ** 3)
+        f = k.flux(E * u.eV, 1 * u.kpc).to("1/(s cm2 eV)").value
+        assert_allclose(f, z["k06_%s_flux" % tag], rtol=2e-4)
+        assert_allclose(k.nhat, float(z["k06_%s_nhat" % tag]), rtol=2e-4)
+        conv, nhat = O.k06_spectrum(E, lambda Et, p=opd[tag]: float(p(Et * 1e12)) * 1e12,
+                                    nh=2.0, epsrel=1e-11)
+        assert_allclose(f, O.to_flux(conv, O.KPC_CM), rtol=1e-8)
+        assert_allclose(k.nhat, nhat, rtol=1e-8)
+    hi = E >= 1e11
+    k = na.PionDecayKelner06(pl, nh=2 / u.cm ** 3)
+    assert_allclose(k.flux(E[hi] * u.eV, 1 * u.kpc).to("1/(s cm2 eV)").value,
+                    z["k06_pl_flux_hi_only"], rtol=2e-4)
+    assert k.nhat == 1.0
+    # Wp above threshold: int E J dE from 1.22 GeV (analytic for a power law)
+    Wp = k.Wp.to("erg").value
+    a = 2.2
+    ref_TeV = 4e35 * 1e12 * (1.22e-3 ** (2 - a)) / (a - 2)  # J = 4e47 (E/TeV)^-2.2 per TeV
+    assert_allclose(Wp, ref_TeV * 1.602176634, rtol=1e-9)
+    # walkers in one launch == one at a time
+    amp = np.array([4e35, 1e35, 9e35])
+    al = np.array([2.2, 2.0, 2.6])
+    kb = na.PionDecayKelner06(na.PowerLaw(amp / u.eV, 1 * u.TeV, al),
+                              nh=np.array([2.0, 1.0, 0.5]) / u.cm ** 3)
+    fb = kb.flux(E * u.eV, 1 * u.kpc).value
+    for j in range(3):
+        kj = na.PionDecayKelner06(na.PowerLaw(amp[j] / u.eV, 1 * u.TeV, al[j]),
+                                  nh=[2.0, 1.0, 0.5][j] / u.cm ** 3)
+        assert_allclose(fb[j], kj.flux(E * u.eV, 1 * u.kpc).value, rtol=1e-13)
