@@ -293,22 +293,31 @@ def _run_mcmc(sampler, pos, nrun, verbose=True):
 
 
 def _prefit(p0, data, model, prior):
-    """Nelder-Mead maximum-likelihood prefit (core.py:163-217), sequential batch-1
-    evaluations of the same HIP path."""
-    from scipy.optimize import minimize
-
+    """Nelder-Mead maximum-likelihood prefit (core.py:163-217).  Same algorithm, options
+    (maxfev 500, relative xtol 0.1, ftol 1e-3) and acceptance rules as the reference; the
+    candidate points of each simplex iteration are evaluated as one walker batch
+    (naima_amd.neldermead)."""
     from .core import lnprob
+    from .neldermead import minimize_batched
     P0_IS_ML = False
 
-    def nll(p):
-        return -lnprob(p, data, model, None)[0]
+    def flat_prior(*args):
+        return 0.0
 
-    res = minimize(nll, p0, method="Nelder-Mead",
-                   options={"maxfev": 500, "xatol": 1e-1, "fatol": 1e-3})
-    ll_prior = lnprob(res.x, data, model, prior)[0]
-    if (res.success or res.status == 1) and not np.isinf(ll_prior):
-        P0_IS_ML = res.status != 1
-        p0 = res.x
+    if prior is None:
+        prior = flat_prior
+
+    def nll(X):  # (m, ndim) points -> m values of -lnprob under the flat prior
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        return -np.asarray(lnprob(np.ascontiguousarray(X.T), data, model, flat_prior)[0],
+                           dtype=float).reshape(-1)
+
+    res = minimize_batched(nll, p0, maxfev=500, xtol=1e-1, ftol=1e-3)
+    ll_prior = float(np.asarray(lnprob(res["x"], data, model, prior)[0]))
+    if (res["success"] or res["status"] == 1) and not np.isinf(ll_prior):
+        # also kept when maxfev was reached: likely better than p0 (core.py:193-195)
+        P0_IS_ML = res["status"] != 1
+        p0 = res["x"]
     return p0, P0_IS_ML
 
 

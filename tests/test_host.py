@@ -185,3 +185,24 @@ def test_workload_definitions():
     assert len(raw["energy"]) == 64 and raw["flux_unit"] == "erg/(cm2 s)"
     assert np.all(np.diff(raw["energy"]) > 0) and raw["ul"].sum() == 1
     assert W.test_vectors("cfg3").shape == (8, 5)
+
+
+def test_batched_nelder_mead_follows_the_sequential_algorithm():
+    """the prefit's simplex search with its candidate points evaluated as a batch takes
+    the decisions, and counts the evaluations, of the sequential algorithm"""
+    from naima_amd.neldermead import minimize_batched
+    from oracle.neldermead_np import minimize_sequential
+
+    def f(x):
+        return 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2 + 3 * (x[2] - 2) ** 2 + 1
+
+    def fb(X):
+        return np.array([f(x) for x in X])
+
+    for opts in (dict(xtol=1e-1, ftol=1e-3, maxfev=500), dict(xtol=1e-6, ftol=1e-8, maxfev=60),
+                 dict()):
+        a = minimize_batched(fb, [-1.2, 1.0, 0.0], **opts)
+        b = minimize_sequential(f, [-1.2, 1.0, 0.0], **opts)
+        assert np.array_equal(a["x"], b["x"])
+        assert (a["nfev"], a["nit"], a["status"]) == (b["nfev"], b["nit"], b["status"])
+        assert a["fun"] == b["fun"]
