@@ -133,11 +133,13 @@ def cpu_baseline(name, raw, p0, seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="do not keep the chain (emcee's store=False); default keeps it in HBM")
     ap.add_argument("--host-loop", action="store_true",
                     help="drive the step loop from the host (no device-resident ensemble)")
     ap.add_argument("--no-graph", action="store_true", help="device loop without hipGraph replay")
@@ -171,13 +173,27 @@ def main():
     device = not args.host_loop
     sampler = make_sampler(device, not args.no_graph)
     pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
+    ctx.sync()
+    tw = time.perf_counter()
     state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
+    ctx.sync()
+    # Spin-up, untimed and reported as config.untimed_spinup_steps: the first ~20 ms after
+    # an idle period run measurably slower (device clocks ramp, first replays of the
+    # multi-step graph), measured 3.1e6 -> 4.4e6 walker-steps/s between --warmup 5 and
+    # --warmup 100.  A short --warmup is topped up to 160 steps (at most 0.5 s of them);
+    # every rank takes the same number so the collectives stay matched.
+    per_step = comm.max((time.perf_counter() - tw) / max(2, args.warmup))
+    spinup = int(min(max(0, 160 - args.warmup), 0.5 / max(per_step, 1e-6)))
+    if spinup > 0 and device:
+        state = sampler.run_mcmc(state, spinup, store=False)
+    else:
+        spinup = 0
 
     # ---- the timed region: K ensemble steps, barrier + device sync on both sides
     comm.barrier()
     ctx.sync()
     t0 = time.perf_counter()
-    state = sampler.run_mcmc(state, args.steps, store=False)
+    state = sampler.run_mcmc(state, args.steps, store=not args.no_chain)
     ctx.sync()
     comm.barrier()
     dt = comm.max(time.perf_counter() - t0)
@@ -230,7 +246,9 @@ def main():
             "cfg5": "PionDecay ECBPL, 28 energies, 600-pt Ep grid"}[name]),
             "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
             "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
-            "device": info["name"]},
+            "device": info["name"], "untimed_spinup_steps": spinup,
+            "chain": "discarded (store=False)" if args.no_chain else
+            "kept: every step's coords and log-prob appended in HBM by the step kernels"},
         "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
