@@ -213,7 +213,7 @@ struct nh_prior_pack {
 __device__ __forceinline__ double nh_lazy_apply(const nh_lazy& z, double raw) {
   double x = z.b * raw + z.c;
   switch (z.tf) {
-    case NH_TF_POW10: x = pow(10.0, x); break;
+    case NH_TF_POW10: x = exp10(x); break;  // 10**x, <= 1 ulp, a fifth of the generic pow
     case NH_TF_EXP: x = exp(x); break;
     case NH_TF_LOG: x = log(x); break;
     case NH_TF_LOG10: x = log10(x); break;

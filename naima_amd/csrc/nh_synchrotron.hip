@@ -26,6 +26,14 @@ __device__ __forceinline__ double nh_fma3(double a, double b, double c) {
   return d;
 }
 
+// the same with the addend in a scalar register pair (one SGPR source is allowed): the
+// coefficients of a polynomial then cost no vector registers at all
+__device__ __forceinline__ double nh_fma3s(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+
 // 1/sqrt(a), 1/a for well-scaled a (1 <= a < 1e5 here): single-precision seed
 // (v_cvt + v_rsq_f32/v_rcp_f32 + v_cvt, 9 cycles against 18 for the f64 instruction,
 // same 2^-23 accuracy) + two Newton steps
@@ -52,16 +60,16 @@ __device__ __forceinline__ double nh_exp_neg(double x) {
   double r = fma(-kf, 6.93147180369123816490e-01, t);
   r = fma(-kf, 1.90821492927058770002e-10, r);
   double p = 1.6059043836821613e-10;           // 1/13!
-  p = nh_fma3(p, r, 2.08767569878681e-09);     // 1/12!
-  p = nh_fma3(p, r, 2.505210838544172e-08);    // 1/11!
-  p = nh_fma3(p, r, 2.755731922398589e-07);    // 1/10!
-  p = nh_fma3(p, r, 2.755731922398589e-06);    // 1/9!
-  p = nh_fma3(p, r, 2.48015873015873e-05);     // 1/8!
-  p = nh_fma3(p, r, 1.984126984126984e-04);    // 1/7!
-  p = nh_fma3(p, r, 1.388888888888889e-03);    // 1/6!
-  p = nh_fma3(p, r, 8.333333333333333e-03);    // 1/5!
-  p = nh_fma3(p, r, 4.166666666666666e-02);    // 1/4!
-  p = nh_fma3(p, r, 1.666666666666667e-01);    // 1/3!
+  p = nh_fma3s(p, r, 2.08767569878681e-09);     // 1/12!
+  p = nh_fma3s(p, r, 2.505210838544172e-08);    // 1/11!
+  p = nh_fma3s(p, r, 2.755731922398589e-07);    // 1/10!
+  p = nh_fma3s(p, r, 2.755731922398589e-06);    // 1/9!
+  p = nh_fma3s(p, r, 2.48015873015873e-05);     // 1/8!
+  p = nh_fma3s(p, r, 1.984126984126984e-04);    // 1/7!
+  p = nh_fma3s(p, r, 1.388888888888889e-03);    // 1/6!
+  p = nh_fma3s(p, r, 8.333333333333333e-03);    // 1/5!
+  p = nh_fma3s(p, r, 4.166666666666666e-02);    // 1/4!
+  p = nh_fma3s(p, r, 1.666666666666667e-01);    // 1/3!
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -109,7 +117,7 @@ template <int C>
 __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const double* __restrict__ w, const double* __restrict__ dlw, const double* __restrict__ B,
     int ldB, int N, const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo) {
+    const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo, int tw) {
   extern __shared__ double smem[];  // ig2[nG] | dig2[nG] | ig23[nG] | part[SYN_MAXCH][64]
   double* ig2 = smem;
   double* dig2 = smem + nG;
@@ -134,7 +142,10 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   if (tid == 0) { s_min_i0 = nG; s_nA = 0; }
   __syncthreads();
 
-  const int ktiles = (nE + 63) >> 6;
+  // a tile = tw (<= 64) photon energies, INTERLEAVED over the ktiles tiles (energy
+  // k = lane*ktiles + tile): live and dead energies come in runs (X-ray points live, TeV
+  // points dead), so neighbouring tiles get the same share of live ones
+  const int ktiles = (nE + tw - 1) / tw;
   const int tile = blockIdx.x % ktiles, wi = blockIdx.x / ktiles;
   const double Bw = B[(long long)wi * ldB];
   // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
 
   // ---- 1. liveness of the tile's energies (first wave) ----------------------
   if (tid < 64) {
-    const int k = tile * 64 + tid;
+    const int k = tid < tw ? tid * ktiles + tile : nE;
     int i0 = nG;
     if (k < nE) {
       const double q = E_eV[k] * qfac;
@@ -228,7 +239,13 @@ extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ldo >= nE && ldB >= 1, "bad sizes");
   if (N == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_SYNCHROTRON);
-  const int ktiles = (nE + 63) / 64;
+  // tile width: 64 measured best at every (C, tw) tried on cfg3 (C=16: 20.0 / 24.2 / 28.9 us
+  // for tw = 64 / 32 / 22; C=8: 21.3 / 20.7 / 20.7) -- the kernel is bound by its total
+  // instruction count, not by how the blocks are cut
+  int tw = 64;
+  if (const char* e = getenv("NH_SYN_TW")) tw = atoi(e);
+  NH_REQUIRE(tw >= 1 && tw <= 64, "bad tile width");
+  const int ktiles = (nE + tw - 1) / tw;
   const unsigned blocks = (unsigned)(ktiles * N);
   const int nseg = nG - 1;
   int C = nseg >= 256 ? 16 : (nseg >= 64 ? 8 : 4);
@@ -246,7 +263,7 @@ extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   }
 #define NH_LAUNCH_SYN(CC)                                                                    \
   hipLaunchKernelGGL((k_synchrotron<CC>), dim3(blocks), dim3(64 * CC), shm, c->stream, w, dlw, \
-                     B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo)
+                     B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, tw)
   switch (C) {
     case 16: NH_LAUNCH_SYN(16); break;
     case 8: NH_LAUNCH_SYN(8); break;

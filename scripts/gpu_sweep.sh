@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do echo "chain   $(timeout 600 python bench.py --no-cpu 2>&1 | tail -1 | cut -c60-100)"; echo "nochain $(timeout 600 python bench.py --no-cpu --no-chain 2>&1 | tail -1 | cut -c60-100)"; done
-timeout 600 python bench.py --no-cpu --steps 50 --warmup 5 2>&1 | tail -1 | cut -c1-1200
+for c in 16 8; do for tw in 64 32 22 16; do echo "C=$c TW=$tw $(NH_SYN_C=$c NH_SYN_TW=$tw python scripts/kbench.py 256 2>&1 | grep synchrotron)"; done; done
