@@ -130,6 +130,7 @@ int nh_grid_logratio(nh_ctx* ctx, const double* xg, int nG, double* lx);
 
 /* ---- the generic per-walker reduction (rows 1+6..10) --------------------- */
 /* out[w*ldo + k] = scale[k] * trapz_loglog(n_w * K_k, xg)  for k < nK,
+ * (summed over the nsplit planes, see below)
  * evaluated as sum_i  lx_i * (u2-u1)/ln(u2/u1),  u = w_i*Kt[i][k],
  * ln(u2/u1) = dlw[i] + dlnKt[i][k].
  * scale may be NULL (=1).  nonnegative != 0 promises Kt >= 0, w of one sign, and dlnKt
@@ -141,7 +142,14 @@ int nh_grid_logratio(nh_ctx* ctx, const double* xg, int nG, double* lx);
  * 165/193/1020/1053 (We, Wp). */
 int nh_integrate_tables(nh_ctx* ctx, const double* w, const double* dlw, int N, int nG,
                         const double* lx, const double* Kt, const double* dlnKt, int nK,
-                        const double* scale, double* out, int ldo, int nonnegative);
+                        const double* scale, double* out, int ldo, int nonnegative,
+                        int nsplit);
+/* nsplit > 1 cuts the abscissa into nsplit ranges handled by different workgroups, each
+ * writing its partial sums to its own plane out + h*N*ldo (h < nsplit): the result is the
+ * sum of the planes, which the consumer forms (nh_lnprob / nh_lincomb take the planes as
+ * components).  It evens out the work per CU when (tiles x walkers) does not fill the
+ * 256 CUs evenly; nh_integrate_tables_nsplit gives the recommended value. */
+int nh_integrate_tables_nsplit(int N, int nG, int nK);
 
 /* ---- row 5: radiative.py:282-342 Synchrotron._spectrum ------------------- */
 /* out[w*ldo+k] = spectrum 1/(s eV) at photon energy E_eV[k] for field B_G[w*ldB]

@@ -44,7 +44,7 @@ _SIGS = {
     "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
     "nh_particle_weights_multi": [_dp, _i, _dp, _i, _dp, _i],
     "nh_grid_logratio": [_dp, _dp, _i, _dp],
-    "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _i],
+    "nh_integrate_tables": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _i, _i],
     "nh_synchrotron": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _i, _dp, _i, _dp, _i],
     "nh_table_ic_planck": [_dp, _dp, _i, _dp, _i, _d, _d, _dp, _dp, _i],
     "nh_table_ic_seed": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _i],
@@ -64,6 +64,7 @@ _SIGS = {
     "nh_ew_binary": [_dp, _i, _dp, _dp, _i, _dp],
     "nh_lincomb": [_dp, _dp, _i, _dp, _dp, _i, _i, _dp, _i],
     "nh_priors": [_dp, _dp, _i, _i, _dp],
+    "nh_integrate_tables_nsplit": [_i, _i, _i],
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
@@ -167,12 +168,15 @@ class Moves:
 class DeviceArray:
     """A float64 (or int32) array in HBM owned by a Context's pool."""
     __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "anchor",
-                 "__weakref__")
+                 "graph_owned", "__weakref__")
 
     def __init__(self, ctx, ptr, shape, dtype, cap):
         self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
         self.stream = ctx.cur_stream  # the stream whose work produces this buffer
         self.anchor = None
+        # allocated while a hipGraph was being captured: the graph keeps using the address
+        # on every replay, so the buffer never returns to the general pool
+        self.graph_owned = bool(ctx.capturing)
         self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
 
     @property
@@ -201,7 +205,7 @@ class DeviceArray:
     def __del__(self):
         try:
             if self._cap > 0 and self.ctx is not None and self.ctx.h:
-                self.ctx._release(self.ptr, self._cap)
+                self.ctx._release(self.ptr, self._cap, self.graph_owned)
         except Exception:
             pass
 
@@ -224,6 +228,8 @@ class Context:
         self._lne = {}
         self._plan = None
         self._accept_hook = None
+        self._cap_pool = {}
+        self._retained = []
         self._pinned = set()
         self._pinned_ptrs = set()
         self._anchors = []
@@ -255,7 +261,11 @@ class Context:
         shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
         cap = self._bucket(nbytes)
-        free = self._pool.get(cap)
+        # during a capture, buffers released earlier in the SAME capture may be reused
+        # (graph order is stream order); nothing else may ever alias them
+        free = self._cap_pool.get(cap) if self.capturing else None
+        if not free:
+            free = self._pool.get(cap)
         if free:
             ptr = free.pop()
         else:
@@ -264,8 +274,13 @@ class Context:
             ptr = p.value
         return DeviceArray(self, ptr, shape, dtype, cap)
 
-    def _release(self, ptr, cap):
-        if self._forked:
+    def _release(self, ptr, cap, graph_owned=False):
+        if graph_owned:
+            if self.capturing:
+                self._cap_pool.setdefault(cap, []).append(ptr)
+            else:
+                self._retained.append((ptr, cap))  # a captured graph still writes here
+        elif self._forked:
             # side streams are in flight: the buffer may still be read or written by a
             # stream other than the one that will reuse it -> park it until the join
             self._limbo.append((ptr, cap))
@@ -347,7 +362,7 @@ class Context:
         if hit is not None:
             return hit
         out = self.empty((N, 1))
-        self.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, 1, None, out, 1, 0)
+        self.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, 1, None, out, 1, 0, 1)
         return self._recorded("moments", key, out)
 
     # -- side streams ---------------------------------------------------------
@@ -466,6 +481,9 @@ class Context:
     def graph_end(self):
         self.join()
         self.capturing = False
+        for cap, ptrs in self._cap_pool.items():  # scratch of the captured launches
+            self._retained.extend((p, cap) for p in ptrs)
+        self._cap_pool = {}
         g = _dp()
         _chk(_lib.nh_graph_end(self.h, C.byref(g)))
         return g
@@ -473,6 +491,9 @@ class Context:
     def graph_abort(self):
         if self.capturing:
             self.capturing = False
+            for cap, ptrs in self._cap_pool.items():
+                self._retained.extend((p, cap) for p in ptrs)
+            self._cap_pool = {}
             g = _dp()
             _lib.nh_graph_end(self.h, C.byref(g))
             if g:

@@ -686,21 +686,26 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
     const double* __restrict__ lx, const double* __restrict__ Kt,
     const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
-    double* __restrict__ out, int ldo) {
+    double* __restrict__ out, int ldo, int nsplit) {
   __shared__ double part[C][W][64];
   extern __shared__ double stg[];  // [W][nG] w | [W][nG] dlw   (STG only)
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ktiles = (nK + 63) >> 6;
-  const int tile = blockIdx.x % ktiles, grp = blockIdx.x / ktiles;
+  // blockIdx -> (split h, tile, walker group): h selects 1/nsplit of the abscissa and
+  // its own output plane out + h*N*ldo (the consumer adds the planes)
+  const int h = blockIdx.x % nsplit, bx = blockIdx.x / nsplit;
+  const int tile = bx % ktiles, grp = bx / ktiles;
   const int k = tile * 64 + lane;
   const bool kvalid = k < nK;
   const unsigned kk = kvalid ? (unsigned)k : (unsigned)(nK - 1);
   const int w0 = grp * W;
   const int nseg = nG - 1;
-  const int per = (nseg + C - 1) / C;
-  const int s0 = ch * per;
-  const int s1 = min(nseg, s0 + per);
+  const int hper = (nseg + nsplit - 1) / nsplit;
+  const int hs0 = h * hper, hs1 = min(nseg, hs0 + hper);
+  const int per = (max(hs1 - hs0, 0) + C - 1) / C;
+  const int s0 = hs0 + ch * per;
+  const int s1 = min(hs1, s0 + per);
   double acc[W], u1[W];
   unsigned row[W];  // wave-uniform row offsets of the W walkers (tail clamped)
 #pragma unroll
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
         double sum = 0.0;
 #pragma unroll
         for (int c2 = 0; c2 < C; ++c2) sum += part[c2][j][lane];
-        out[(long long)(w0 + j) * ldo + k] = sum * sc;
+        out[((long long)h * N + (w0 + j)) * ldo + k] = sum * sc;
       }
     }
   }
@@ -812,12 +817,26 @@ __global__ __launch_bounds__(256) void k_integrate_rows(
   if (lane == 0) out[(long long)wi * ldo + k] = scale ? acc * scale[k] : acc;
 }
 
+// recommended nsplit: with W walkers per thread the launch has ktiles*ceil(N/W) workgroups
+// of up to 16 waves; when that is between one and two per CU (256 CUs) half of the CUs
+// carry twice the work of the others -- two half-range workgroups of 8 waves each spread
+// evenly instead
+extern "C" int nh_integrate_tables_nsplit(int N, int nG, int nK) {
+  if (const char* e = getenv("NH_INT_SPLIT")) return atoi(e);
+  const long long ktiles = (nK + 63) / 64;
+  if ((long long)N * nK * 4 < 4096 || nG < 66) return 1;
+  const int W = (ktiles * N >= 8192) ? 4 : (ktiles * N >= 512 ? 2 : 1);
+  const long long blocks = ktiles * ((N + W - 1) / W);
+  return (blocks > 256 && blocks < 512) ? 2 : 1;
+}
+
 extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
                                    const double* lx, const double* Kt, const double* dlnKt,
                                    int nK, const double* scale, double* out, int ldo,
-                                   int nonnegative) {
+                                   int nonnegative, int nsplit) {
   NH_REQUIRE(c && w && dlw && lx && Kt && dlnKt && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nK >= 1 && ldo >= nK, "bad sizes");
+  NH_REQUIRE(nsplit >= 1 && nsplit <= 8, "nsplit must be 1..8");
   NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)nG * nK < (1LL << 28),
              "arrays too large for 32-bit offsets");
   if (N == 0) return NH_OK;
@@ -827,6 +846,9 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
     hipLaunchKernelGGL(k_integrate_rows, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0,
                        c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo);
     NH_CHECK_HIP(hipGetLastError());
+    if (nsplit > 1)  // everything is in plane 0
+      NH_CHECK_HIP(hipMemsetAsync(out + (long long)N * ldo, 0,
+                                  (size_t)(nsplit - 1) * N * ldo * sizeof(double), c->stream));
     return NH_OK;
   }
   const int nseg = nG - 1;
@@ -837,17 +859,19 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   // long as the launch keeps >= ~4 waves per SIMD.
   int W = ((long long)ktiles * N >= 8192) ? 4 : ((long long)ktiles * N >= 512 ? 2 : 1);
   if (const char* e = getenv("NH_INT_W")) W = atoi(e);
-  const unsigned blocks = (unsigned)(ktiles * ((N + W - 1) / W));
+  const unsigned blocks = (unsigned)(ktiles * ((N + W - 1) / W) * nsplit);
   // split the abscissa so that the launch has >= ~4 waves per SIMD (1024 SIMDs)
+  // (split launches use 8-wave workgroups: four fit on a CU, so 768 of them spread evenly)
   int C = 1;
-  while (C < 16 && (long long)blocks * C < 12288 && nseg / (2 * C) >= 8) C *= 2;
+  const int Cmax = nsplit > 1 ? 8 : 16;
+  while (C < Cmax && (long long)blocks * C < 12288 && nseg / nsplit / (2 * C) >= 8) C *= 2;
   if (const char* e = getenv("NH_INT_C")) C = atoi(e);
   const size_t stg_bytes = 2 * (size_t)W * nG * sizeof(double);
   const bool stage = stg_bytes <= 48 * 1024;
 #define NH_LAUNCH_INT_T(CC, WW, SS, TT)                                                      \
   hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS, TT>), dim3(blocks), dim3(64 * CC),      \
                      TT ? stg_bytes : 0, c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, \
-                     out, ldo)
+                     out, ldo, nsplit)
 #define NH_LAUNCH_INT_S(CC, WW, SS) \
   do { if (stage) NH_LAUNCH_INT_T(CC, WW, SS, true); else NH_LAUNCH_INT_T(CC, WW, SS, false); } while (0)
 #define NH_LAUNCH_INT(CC, WW) \

@@ -22,6 +22,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import units as u
+from . import _lib as _lib_mod
 from ._lib import PD_KIND, PP_MODEL, get_context
 from .darray import DMat, DVec
 from .constants import (AR_CGS, ASTROPY_TO_ERG, ASTROPY_TO_GEV, C_CGS, ERG_TO_EV, MEC2_ERG,
@@ -741,17 +742,21 @@ class InverseCompton(BaseElectron):
                 else:
                     uf = 1.0
                 scale[j * nE:(j + 1) * nE] = uf * Eph / E_eV  # radiative.py:684-687
-            out = ctx.empty((N, nK))
+            # the abscissa may be cut into planes that different workgroups reduce (evens out
+            # the load per CU); the planes are summed by whoever consumes the spectrum
+            ns = _lib_mod._lib.nh_integrate_tables_nsplit(N, nG, nK)
+            out = ctx.empty((ns * N, nK))
             # IC kernels are >= 0; a user-supplied array seed is validated positive
             ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
-                     out, nK, 1)
+                     out, nK, 1, ns)
             if dev:
                 for j, name in enumerate(static):
-                    specs[name] = DMat.from_buffer(ctx, out, N, nE, ld=nK, col0=j * nE)
+                    specs[name] = DMat(ctx, [(out, out.ptr + 8 * (h * N * nK + j * nE), nK, 1.0)
+                                             for h in range(ns)], (N, nE))
                     if name in rowfac:
                         specs[name] = specs[name] * _as_dvec(ctx, rowfac[name], N)
             else:
-                host = out.get()
+                host = out.get().reshape(ns, N, nK).sum(axis=0)
                 for j, name in enumerate(static):
                     specs[name] = host[:, j * nE:(j + 1) * nE]
                     if name in rowfac:
@@ -878,7 +883,7 @@ class Bremsstrahlung(BaseElectron):
                                 np.full(nE, n0 * self.weight_ep * C_CGS)])
         out = ctx.empty((N, 2 * nE))
         ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, 2 * nE, ctx.const(scale), out,
-                 2 * nE, 0)  # the Baring+99 fits go negative near their edges
+                 2 * nE, 0, 1)  # the Baring+99 fits go negative near their edges
         if self.on_device:
             tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE) + \
                 DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE)
@@ -1070,7 +1075,7 @@ class PionDecay(BaseProton):
         out = ctx.empty((N, nE))
         # the FITPACK look-up table rings below zero; the analytic form does not
         ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE,
-                 0 if use_lut else 1)
+                 0 if use_lut else 1, 1)
         nh = self.nh.to("1/cm3").value
         fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
         if _per_walker(self.nh):

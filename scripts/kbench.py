@@ -43,12 +43,13 @@ def tabs():
     for j, T in enumerate((2.72548, 30.0, 3000.0)):
         ctx.call("nh_table_ic_planck", gd2, gam2.size, Ed, nE, T, -1.0, Kt.ptr + 8 * j * nE, dKt.ptr + 8 * j * nE, nK)
 res["tables(3 seeds)"] = timeit(tabs, 10)
-out2 = ctx.empty((N, nK))
-res["integrate(IC nK=192)"] = timeit(lambda: ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK, 1))
+NS = int(os.environ.get("KB_NSPLIT", "1"))
+out2 = ctx.empty((NS * N, nK))
+res["integrate(IC nK=192)"] = timeit(lambda: ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK, 1, NS))
 gam3, gd3, w3, dlw3, lx3, f3 = weights(1000.0); f3()
 K = gam3 * MEC2_ERG
 Kd, dKd = ctx.const(K), ctx.const(_dlog(K)); out3 = ctx.empty((N, 1))
-res["integrate(We nK=1)"] = timeit(lambda: ctx.call("nh_integrate_tables", w3, dlw3, N, gam3.size, lx3, Kd, dKd, 1, None, out3, 1, 0))
+res["integrate(We nK=1)"] = timeit(lambda: ctx.call("nh_integrate_tables", w3, dlw3, N, gam3.size, lx3, Kd, dKd, 1, None, out3, 1, 0, 1))
 for k, v in res.items():
     print("%-24s %8.2f us" % (k, v))
 print("checksum", float(out.get().sum()), float(out2.get().sum()), float(out3.get().sum()))

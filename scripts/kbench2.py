@@ -36,7 +36,7 @@ for _ in range(60):
     if "w" in mode:
         f1(); f2()
     if "i" in mode:
-        ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK, 1)
+        ctx.call("nh_integrate_tables", w2, dlw2, N, gam2.size, lx2, Kt, dKt, nK, None, out2, nK, 1, 1)
     if "s" in mode:
         ctx.call("nh_synchrotron", w, dlw, Bd, 1, N, gd, lx, gam.size, Ed, nE, out, nE)
 ctx.sync()

@@ -71,7 +71,7 @@ def test_abi_integrate_tables_edges(na, golden):
     ctx.call("nh_grid_logratio", xd, n, lx)
     out = ctx.empty((len(Y), 1))
     ctx.call("nh_integrate_tables", ctx.array(w), ctx.array(lw), len(Y), n, lx, ctx.array(K),
-             ctx.array(np.zeros((n, 1))), 1, None, out, 1, 0)
+             ctx.array(np.zeros((n, 1))), 1, None, out, 1, 0, 1)
     assert_allclose(out.get()[:, 0], U["tz_out"], rtol=1e-13)
 
 
@@ -523,7 +523,7 @@ def test_abi_step_front_and_lnprob_accept(na):
     w2, dlw2, We2 = ctx.empty((ns, gam.size)), ctx.empty((ns, gam.size)), ctx.empty((ns, 1))
     ctx.call("nh_particle_weights", 1, rows, ns, ed, gd, gam.size, 510998.9499961643, w2, dlw2,
              None)
-    ctx.call("nh_integrate_tables", w2, dlw2, ns, gam.size, lx, Kt, dK, 1, None, We2, 1, 0)
+    ctx.call("nh_integrate_tables", w2, dlw2, ns, gam.size, lx, Kt, dK, 1, None, We2, 1, 0, 1)
     assert_allclose(w.get(), w2.get(), rtol=5e-13)
     assert_allclose(dlw.get(), dlw2.get(), rtol=1e-11, atol=1e-14)
     assert_allclose(We.get(), We2.get(), rtol=1e-12)
@@ -587,6 +587,29 @@ def test_device_loop_front_kernel_history_and_multistep_graph(na, golden):
     # a generator consumer sees every step (no multi-step launches)
     n = sum(1 for _ in d.sample(sd, iterations=5))
     assert n == 5 and d.get_chain().shape == (53, 32, 5)
+
+
+def test_graph_scratch_is_never_handed_out_again(na, golden):
+    """buffers a captured graph writes on every replay stay out of the pool: foreign
+    allocations of every bucket size, filled with NaN between two runs, change nothing"""
+    from naima_amd._lib import get_context
+    from naima_amd.sampler import EnsembleSampler
+    model, data, prior, p0 = _cfg_problem(na, golden, "cfg3")
+    kw = dict(args=[data, model, prior], seed=3, naima_style=True, store_blobs=False)
+    h = EnsembleSampler(64, 5, na.lnprob, **kw)
+    d = EnsembleSampler(64, 5, na.lnprob, device=True, **kw)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(4).standard_normal((64, 5)))
+    sh, sd = h.run_mcmc(pos, 12), d.run_mcmc(pos, 12)
+    ctx = get_context()
+    junk = []
+    for nb in [2 ** k for k in range(8, 23)]:
+        for _ in range(3):
+            junk.append(ctx.array(np.full(nb // 8, np.nan)))
+    sh, sd = h.run_mcmc(sh, 12), d.run_mcmc(sd, 12)
+    for a in junk:
+        assert np.isnan(a.get()).all()  # and the graph did not write into them either
+    assert_allclose(sd.coords, sh.coords, rtol=1e-9)
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-9)
 
 
 def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
