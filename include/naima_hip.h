@@ -312,6 +312,19 @@ int nh_lnprob_accept(nh_ctx* ctx, const nh_comp* comps /*host*/, int ncomp, int 
                      const double* err_hi, const int* ul, const double* cl, const double* lp,
                      const nh_prior* terms /*host*/, int nterms, double* model_out,
                      double* total, const nh_accept* mv /*host*/);
+
+/* nh_synchrotron whose workgroups go on to evaluate nh_lnprob (+ nh_lnprob_accept's move
+ * when mv != NULL) for their own walker: for models where the synchrotron spectrum is the
+ * last component the likelihood waits for, the step loop saves a launch.  comps[syn_comp]
+ * must be this launch's output (it is taken from LDS); nE <= 64. */
+int nh_synchrotron_lnprob(nh_ctx* ctx, const double* w, const double* dlw, const double* B_G,
+                          int ldB, int N, const double* gam, const double* lx, int nG,
+                          const double* E_eV, int nE, double* out, int ldo,
+                          const nh_comp* comps /*host*/, int ncomp, int syn_comp,
+                          const double* conv, const double* flux, const double* err_lo,
+                          const double* err_hi, const int* ul, const double* cl,
+                          const double* lp, const nh_prior* terms /*host*/, int nterms,
+                          double* total, const nh_accept* mv /*host or NULL*/);
 /* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);

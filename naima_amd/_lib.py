@@ -71,6 +71,8 @@ _SIGS = {
     "nh_step_front": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp,
                       _i, _dp, _i, _dp],
     "nh_pion_kelner06": [_dp, _i, _dp, _i, _dp, _i, _d, _i, _dp, _i, _dp, _dp],
+    "nh_synchrotron_lnprob": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i,
+                              _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_lnprob_accept": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp,
                          _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],
@@ -168,7 +170,7 @@ class Moves:
 class DeviceArray:
     """A float64 (or int32) array in HBM owned by a Context's pool."""
     __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "anchor",
-                 "graph_owned", "__weakref__")
+                 "graph_owned", "pending", "__weakref__")
 
     def __init__(self, ctx, ptr, shape, dtype, cap):
         self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
@@ -177,6 +179,8 @@ class DeviceArray:
         # allocated while a hipGraph was being captured: the graph keeps using the address
         # on every replay, so the buffer never returns to the general pool
         self.graph_owned = bool(ctx.capturing)
+        # a deferred launch that will fill this buffer (see Context.defer)
+        self.pending = None
         self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
 
     @property
@@ -230,6 +234,7 @@ class Context:
         self._accept_hook = None
         self._cap_pool = {}
         self._retained = []
+        self._deferred = []
         self._pinned = set()
         self._pinned_ptrs = set()
         self._anchors = []
@@ -286,6 +291,24 @@ class Context:
             self._limbo.append((ptr, cap))
         else:
             self._pool.setdefault(cap, []).append(ptr)
+
+    # -- deferred launches --------------------------------------------------------------
+    # Inside the device step loop the producer of the LAST spectrum the likelihood needs
+    # (the synchrotron kernel) may be held back so that the likelihood can ride on its
+    # launch (nh_synchrotron_lnprob).  Any other reader of the buffer flushes it first.
+    def defer(self, arr, name, args, keep=()):
+        arr.pending = (name, args, keep)  # keep: buffers the arguments point into
+        self._deferred.append(arr)
+
+    def flush(self, *arrs):
+        """launch what is still deferred for these buffers (all of them when none given)"""
+        todo = arrs if arrs else tuple(self._deferred)
+        for a in todo:
+            p = getattr(a, "pending", None)
+            if p is not None:
+                a.pending = None
+                self.call(p[0], *p[1])
+        self._deferred = [a for a in self._deferred if a.pending is not None]
 
     # -- launches that the device step loop folds into nh_step_front ------------------
     # The loop first RECORDS what a model evaluation asks for (parameter packs, the

@@ -166,12 +166,28 @@ def lnprobmodel(model, data, lp=None):
                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpd.ptr if lpd is not None else None,
                 terms, nterms, None, total)
         hook = ctx._accept_hook
+        owners = [t[0] for t in m.terms]
+        held = [j for j, o in enumerate(owners) if getattr(o, "pending", None) is not None]
         if hook is not None and hook["N"] == N and not hook["used"]:
             # device step loop, single rank: the stretch move's accept rides on this launch
             import ctypes as C
-            ctx.call("nh_lnprob_accept", *args, C.addressof(hook["mv"]))
+            j = held[0] if len(held) == 1 else -1
+            o = owners[j] if j >= 0 else None
+            if o is not None and o.pending[0] == "nh_synchrotron" and m.terms[j][1] == o.ptr \
+                    and m.terms[j][2] == nE and nE <= 64:
+                # ... and both ride on the held-back synchrotron launch: its workgroups
+                # finish their walker's likelihood themselves
+                sa = o.pending[1]
+                o.pending = None
+                ctx._deferred = [a for a in ctx._deferred if a is not o]
+                ctx.call("nh_synchrotron_lnprob", *sa, args[0], args[1], j, *args[4:13],
+                         total, C.addressof(hook["mv"]))
+            else:
+                ctx.flush(*owners)
+                ctx.call("nh_lnprob_accept", *args, C.addressof(hook["mv"]))
             hook["used"] = True
         else:
+            ctx.flush(*owners)
             ctx.call("nh_lnprob", *args)
         del lpd
         return DVec(ctx, total, total.ptr, N)

@@ -896,94 +896,13 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
 // ---------------------------------------------------------------------------
 // row 11: lnprobmodel (core.py:64-94), one wave per walker
 // ---------------------------------------------------------------------------
-struct nh_comps {
-  nh_comp c[NH_MAX_COMP];
-  int n;
-};
+#include "nh_lnprob.h"
 
-__global__ __launch_bounds__(256) void k_lnprobmodel(nh_comps cs, int N, int nE,
-                                                      const double* __restrict__ conv,
-                                                      const double* __restrict__ flux,
-                                                      const double* __restrict__ elo,
-                                                      const double* __restrict__ ehi,
-                                                      const int* __restrict__ ul,
-                                                      const double* __restrict__ cl,
-                                                      const double* __restrict__ lp,
-                                                      nh_prior_pack pri,
-                                                      double* __restrict__ model_out,
-                                                      double* __restrict__ lnl, nh_accept mv) {
+__global__ __launch_bounds__(256) void k_lnprobmodel(nh_lnprob_args A) {
   const int lane = threadIdx.x & 63;
   const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wi >= N) return;
-  // the accept's inputs are requested first so that their latency hides behind the sum
-  int me = 0, pa = 0;
-  double mz = 1.0, mlnu = 0.0, mold = 0.0, cpa = 0.0, cme = 0.0;
-  if (mv.coords) {
-    const int g = mv.lo + wi;
-    const double* r = mv.blk + (long long)mv.cursor[0] * 3 * mv.ns;
-    const int* idx = reinterpret_cast<const int*>(r + 2 * mv.ns);
-    me = idx[g];
-    pa = idx[mv.ns + g];
-    mz = r[g];
-    mlnu = r[mv.ns + g];
-    mold = mv.logp[me];
-    if (lane < mv.ndim) {
-      cpa = mv.coords[(long long)pa * mv.ndim + lane];
-      cme = mv.coords[(long long)me * mv.ndim + lane];
-    }
-  }
-  // prior terms and the confidence-level table are requested before the sum as well
-  double prior = 0.0;
-  const bool has_prior = lp || pri.n > 0;
-  if (has_prior && lane == 0) prior = (lp ? lp[wi] : 0.0) + nh_prior_sum(pri, wi);
-  const double cl_lane = lane < nE ? cl[lane] : 0.0;
-  double acc = 0.0;
-  int nviol = 0, nul = 0;
-  for (int k = lane; k < nE; k += 64) {
-    double m = 0.0;
-    for (int j = 0; j < cs.n; ++j) m += cs.c[j].scale * cs.c[j].ptr[(long long)wi * cs.c[j].ld + k];
-    if (model_out) model_out[(long long)wi * nE + k] = m;
-    double mc = m * conv[k];
-    double f = flux[k];
-    if (ul[k]) {
-      nul += 1;
-      nviol += (mc > f) ? 1 : 0;
-    } else {
-      double d = mc - f;
-      double sg = (d > 0.0) ? ehi[k] : elo[k];
-      acc += -(d * d) / (2.0 * (sg * sg));
-    }
-  }
-  acc = wave_sum(acc);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    nviol += __shfl_down(nviol, off, 64);
-    nul += __shfl_down(nul, off, 64);
-  }
-  // quirk kept from core.py:89-92: cl is indexed by the violation count
-  nviol = __shfl(nviol, 0, 64);
-  const double clv = (nviol < 64 && nviol < nE) ? __shfl(cl_lane, nviol, 64) : cl[nviol];
-  if (lane == 0) {
-    if (nul > 0) acc += (double)nviol * log(1.0 - clv);
-    if (has_prior)  // core.py:115-119: a forbidden walker keeps the prior value
-      acc = isinf(prior) ? prior : acc + prior;
-    lnl[wi] = acc;
-  }
-  if (mv.coords) {  // nh_move_accept for this walker (emcee RedBlueMove.propose)
-    acc = __shfl(acc, 0, 64);
-    const double d = (mv.ndim - 1.0) * log(mz) + acc - mold;
-    const bool ok = mlnu < d;  // NaN compares false, as numpy
-    if (ok && lane < mv.ndim) mv.coords[(long long)me * mv.ndim + lane] = cpa - (cpa - cme) * mz;
-    if (lane == 0) {
-      const int g = mv.lo + wi;
-      if (ok) {
-        mv.logp[me] = acc;
-        if (mv.naccepted) mv.naccepted[me] += 1;
-      }
-      mv.accepted[g] = ok ? 1 : 0;
-      if (mv.sel) mv.sel[g] = me;
-    }
-  }
+  if (wi >= A.N) return;
+  nh_lnprob_wave(A, wi, lane, nullptr, -1);
 }
 
 static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const double* conv,
@@ -991,14 +910,11 @@ static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const dou
                          const int* ul, const double* cl, const double* lp,
                          const nh_prior* terms, int nterms, double* model_out, double* lnl,
                          const nh_accept* mv = nullptr) {
-  nh_accept m = {};
-  if (mv) m = *mv;
-  nh_prior_pack pri;
-  pri.n = nterms;
-  for (int j = 0; j < nterms; ++j) pri.t[j] = terms[j];
+  nh_lnprob_args A;
+  nh_lnprob_fill(A, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, model_out,
+                 lnl, mv);
   nh_prof_scope ps(c, NH_K_LNPROB);
-  hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, cs, N, nE, conv,
-                     flux, err_lo, err_hi, ul, cl, lp, pri, model_out, lnl, m);
+  hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

@@ -14,7 +14,7 @@
 //   exp(-x)     = Cody-Waite reduction + degree-13 Taylor + v_ldexp_f64;
 //   ln(P2/P1)   = 2 atanh(s), s = (P2-P1)/(P2+P1), 5-term series (adjacent nodes
 //                 differ by a few per cent), log() only on coarse grids.
-#include "nh_common.h"
+#include "nh_lnprob.h"
 #include <cstdlib>
 
 // d = a*b + c as the three-address v_fma_f64.  The compiler prefers the two-address
@@ -113,11 +113,15 @@ __device__ __forceinline__ double syn_dlnP(double P1, double P2) {
 //   3. reduces the Cd partial sums per energy in LDS; dead energies get 0.
 constexpr int SYN_MAXCH = 64;  // chunks per energy (LDS: part[SYN_MAXCH][64])
 
-template <int C>
+// EPI: the block goes on to evaluate the likelihood (+ priors, + the stretch move's
+// accept) of ITS walker -- nh_lnprob_wave -- with its own spectrum taken from LDS.  Only
+// for one tile per walker (nE <= 64), when this launch is the last producer.
+template <int C, bool EPI>
 __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const double* __restrict__ w, const double* __restrict__ dlw, const double* __restrict__ B,
     int ldB, int N, const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo, int tw) {
+    const double* __restrict__ E_eV, int nE, double* __restrict__ out, int ldo, int tw,
+    nh_lnprob_args L, int syn_comp) {
   extern __shared__ double smem[];  // ig2[nG] | dig2[nG] | ig23[nG] | part[SYN_MAXCH][64]
   double* ig2 = smem;
   double* dig2 = smem + nG;
@@ -125,8 +129,13 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   double* part = smem + 3 * nG;
   __shared__ int amap[64];
   __shared__ int s_min_i0, s_nA;
+  __shared__ double synv[64];  // EPI: this walker's spectrum, by energy index
   constexpr int T = 64 * C;
   const int tid = threadIdx.x;
+  // EPI: the first wave asks for everything the likelihood needs besides this kernel's
+  // own spectrum now; the answers wait in registers until the epilogue
+  nh_lnprob_pre PRE = {};
+  if (EPI && tid < 64) nh_lnprob64_prefetch_a(PRE, L, blockIdx.x, tid, syn_comp);
   for (int i = tid; i < nG; i += T) {
     const double g = gam[i];
     const double v = 1.0 / (g * g);
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
                       (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
 
   // ---- 1. liveness of the tile's energies (first wave) ----------------------
+  if (EPI && tid < 64) nh_lnprob64_prefetch_b(PRE, L, wi);
   if (tid < 64) {
     const int k = tid < tw ? tid * ktiles + tile : nE;
     int i0 = nG;
@@ -174,10 +184,15 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     }
     if (tid == 0) s_nA = __popcll(m);
     if (k < nE && !live) out[(long long)wi * ldo + k] = 0.0;
+    if (EPI && k < nE && !live) synv[k] = 0.0;
   }
   __syncthreads();
   const int nA = s_nA;
-  if (nA == 0) return;
+  if (EPI && tid < 64) nh_lnprob64_prefetch_c(PRE, L, tid);
+  if (nA == 0) {
+    if (EPI && tid < 64) nh_lnprob64_finish(L, PRE, wi, tid, synv, syn_comp);
+    return;
+  }
   const int nseg = nG - 1;
   const int sbeg = max(s_min_i0 - 1, 0);
 
@@ -228,48 +243,97 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   if (tid < nA) {
     double sum = 0.0;
     for (int j = 0; j < Cd; ++j) sum += part[j * 64 + tid];
-    out[(long long)wi * ldo + amap[tid]] = sum * NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
+    sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
+    out[(long long)wi * ldo + amap[tid]] = sum;
+    if (EPI) synv[amap[tid]] = sum;
+  }
+  if (EPI) {
+    __syncthreads();
+    if (tid < 64) nh_lnprob64_finish(L, PRE, wi, tid, synv, syn_comp);
   }
 }
 
-extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, const double* B_G,
+static int launch_synchrotron(nh_ctx* c, const double* w, const double* dlw, const double* B_G,
                               int ldB, int N, const double* gam, const double* lx, int nG,
-                              const double* E_eV, int nE, double* out, int ldo) {
+                              const double* E_eV, int nE, double* out, int ldo,
+                              const nh_lnprob_args* L, int syn_comp) {
   NH_REQUIRE(c && w && dlw && B_G && gam && lx && E_eV && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ldo >= nE && ldB >= 1, "bad sizes");
   if (N == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_SYNCHROTRON);
+  const int nseg = nG - 1;
+  int C = nseg >= 256 ? 16 : (nseg >= 64 ? 8 : 4);
   // tile width: 64 measured best at every (C, tw) tried on cfg3 (C=16: 20.0 / 24.2 / 28.9 us
   // for tw = 64 / 32 / 22; C=8: 21.3 / 20.7 / 20.7) -- the kernel is bound by its total
   // instruction count, not by how the blocks are cut
   int tw = 64;
   if (const char* e = getenv("NH_SYN_TW")) tw = atoi(e);
+  if (L) tw = 64;
   NH_REQUIRE(tw >= 1 && tw <= 64, "bad tile width");
   const int ktiles = (nE + tw - 1) / tw;
+  NH_REQUIRE(!L || ktiles == 1, "the likelihood epilogue needs all energies in one tile");
   const unsigned blocks = (unsigned)(ktiles * N);
-  const int nseg = nG - 1;
-  int C = nseg >= 256 ? 16 : (nseg >= 64 ? 8 : 4);
   if ((long long)blocks * C > 16384 && C > 4) C /= 2;  // plenty of waves: longer chunks
   if (const char* e = getenv("NH_SYN_C")) C = atoi(e);
   size_t shm = (size_t)(3 * nG + SYN_MAXCH * 64) * sizeof(double);
   NH_REQUIRE(shm <= 150 * 1024, "electron grid too long for the LDS staging");
-  if (shm > 64 * 1024) {
-    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<16>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<8>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  }
-#define NH_LAUNCH_SYN(CC)                                                                    \
-  hipLaunchKernelGGL((k_synchrotron<CC>), dim3(blocks), dim3(64 * CC), shm, c->stream, w, dlw, \
-                     B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, tw)
+  nh_lnprob_args none = {};
+  const nh_lnprob_args& A = L ? *L : none;
+#define NH_LAUNCH_SYN_E(CC, EE)                                                               \
+  do {                                                                                        \
+    if (shm > 64 * 1024)                                                                      \
+      NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_synchrotron<CC, EE>,                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    hipLaunchKernelGGL((k_synchrotron<CC, EE>), dim3(blocks), dim3(64 * CC), shm, c->stream, w, \
+                       dlw, B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, tw, A, syn_comp);   \
+  } while (0)
+#define NH_LAUNCH_SYN(CC) \
+  do { if (L) NH_LAUNCH_SYN_E(CC, true); else NH_LAUNCH_SYN_E(CC, false); } while (0)
   switch (C) {
     case 16: NH_LAUNCH_SYN(16); break;
     case 8: NH_LAUNCH_SYN(8); break;
     default: NH_LAUNCH_SYN(4); break;
   }
 #undef NH_LAUNCH_SYN
+#undef NH_LAUNCH_SYN_E
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
+}
+
+extern "C" int nh_synchrotron(nh_ctx* c, const double* w, const double* dlw, const double* B_G,
+                              int ldB, int N, const double* gam, const double* lx, int nG,
+                              const double* E_eV, int nE, double* out, int ldo) {
+  return launch_synchrotron(c, w, dlw, B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, nullptr, -1);
+}
+
+extern "C" int nh_synchrotron_lnprob(nh_ctx* c, const double* w, const double* dlw,
+                                     const double* B_G, int ldB, int N, const double* gam,
+                                     const double* lx, int nG, const double* E_eV, int nE,
+                                     double* out, int ldo, const nh_comp* comps, int ncomp,
+                                     int syn_comp, const double* conv, const double* flux,
+                                     const double* err_lo, const double* err_hi, const int* ul,
+                                     const double* cl, const double* lp, const nh_prior* terms,
+                                     int nterms, double* total, const nh_accept* mv) {
+  NH_REQUIRE(c && comps && conv && flux && err_lo && err_hi && ul && cl && total, "NULL pointer");
+  NH_REQUIRE(nE <= 64, "the likelihood epilogue needs nE <= 64 (one tile per walker)");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP && syn_comp >= 0 && syn_comp < ncomp,
+             "bad components");
+  NH_REQUIRE(nterms >= 0 && nterms <= NH_MAX_PRIOR && (nterms == 0 || terms), "bad prior terms");
+  NH_REQUIRE(comps[syn_comp].ptr == out && comps[syn_comp].ld == ldo,
+             "component syn_comp must be this launch's output");
+  if (mv) {
+    NH_REQUIRE(mv->coords && mv->logp && mv->blk && mv->cursor && mv->accepted &&
+                   mv->ns >= 1 && mv->ndim >= 1 && mv->ndim <= 64 && mv->lo >= 0 &&
+                   mv->lo + N <= mv->ns, "bad accept block");
+  }
+  nh_comps cs;
+  cs.n = ncomp;
+  for (int j = 0; j < ncomp; ++j) {
+    NH_REQUIRE(comps[j].ptr && comps[j].ld >= nE, "bad component");
+    cs.c[j] = comps[j];
+  }
+  nh_lnprob_args A;
+  nh_lnprob_fill(A, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, nullptr,
+                 total, mv);
+  return launch_synchrotron(c, w, dlw, B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, &A, syn_comp);
 }

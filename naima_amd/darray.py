@@ -378,6 +378,7 @@ class DMat:
 
     def _rows_scaled(self, rf):
         import ctypes as C
+        self.ctx.flush(*[t[0] for t in self.terms])
         N, m = self.shape
         self.ctx.need(*[t[0] for t in self.terms])
         out = self.ctx.empty((N, m))
@@ -389,6 +390,7 @@ class DMat:
 
     def dense(self):
         """one contiguous [N][m] buffer (nh_lincomb) unless already so"""
+        self.ctx.flush(*[t[0] for t in self.terms])
         N, m = self.shape
         if len(self.terms) == 1 and self.colfac is None and self.terms[0][3] == 1.0 \
                 and self.terms[0][2] == m:

@@ -157,6 +157,7 @@ class DeviceLoop:
         finally:
             ctx._plan = None
             ctx._accept_hook = None
+            ctx.flush()  # a held-back launch nobody consumed
         if self.s.comm.size > 1:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses

@@ -535,8 +535,14 @@ class Synchrotron(BaseElectron):
             Bd = ctx.array(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
             Bp = Bd.ptr
         out = ctx.empty((N, E_eV.size))
-        ctx.call("nh_synchrotron", w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV),
-                 E_eV.size, out, E_eV.size)
+        args = (w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV), E_eV.size, out, E_eV.size)
+        hook = ctx._accept_hook
+        if hook is not None and not hook["used"] and hook["N"] == N and E_eV.size <= 64 \
+                and not ctx._deferred:
+            # device step loop: hold the launch back, the likelihood may ride on it
+            ctx.defer(out, "nh_synchrotron", args, keep=(Bd,))
+        else:
+            ctx.call("nh_synchrotron", *args)
         del Bd
         return self._result(ctx, out, N, E_eV.size, E)
 
