@@ -458,7 +458,48 @@ __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
   double* lg = row + NH_PD_NPAR;         // [3]       ln e_0, ln e_cutoff, ln e_break
   double* ws = lg + 3;                   // [mom_nodes] w of the grids that have a reduction
   double* ds = ws + A.mom_nodes;         // [mom_nodes] dlw
+  double* mlx = ds + A.mom_nodes;        // [mom_nodes] lx of the grids that have a reduction
+  double* mkt = mlx + A.mom_nodes;       // [sum over reductions of nG] K | dlnK
   const int j = blockIdx.x, tid = threadIdx.x;
+  const pw_grids& G = A.G;
+  const bool skip_nodes = G.off[G.n] == 0;
+  // Everything below is a chain of dependent ~1 us trips to memory that other launches
+  // wrote (cursor -> slice -> coordinates -> ... ).  What does NOT depend on the proposal
+  // -- the grids' own arrays for the weight nodes, the tables of the single-row
+  // reductions -- is requested first, by the waves that are not on that chain.
+  double nE_[NH_MAX_GRIDS], nE2_[NH_MAX_GRIDS], ngx_[NH_MAX_GRIDS], nlr_[NH_MAX_GRIDS],
+      nln_[NH_MAX_GRIDS];
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
+    nE_[g] = nE2_[g] = ngx_[g] = 1.0;
+    nlr_[g] = nln_[g] = 0.0;
+  }
+#define NH_FRONT_LOAD_NODES()                                                              \
+  _Pragma("unroll") for (int g = 0; g < NH_MAX_GRIDS; ++g) {                                \
+    if (g < G.n && !skip_nodes && tid < G.nG[g]) {                                         \
+      const int nG = G.nG[g], i = tid;                                                     \
+      const bool last = i + 1 >= nG;                                                       \
+      nE_[g] = G.e[g][i];                                                                  \
+      nE2_[g] = last ? nE_[g] : G.e[g][i + 1];                                             \
+      ngx_[g] = G.xg[g][i];                                                                \
+      if (!last) nlr_[g] = G.lx[g] ? G.lx[g][i] : log(G.xg[g][i + 1] / ngx_[g]);           \
+      nln_[g] = G.lne[g] ? G.lne[g][i] : log(nE_[g]);                                      \
+    }                                                                                      \
+  }
+  if (tid >= 64) {
+    NH_FRONT_LOAD_NODES()
+    int ko = 0;
+    for (int m = 0; m < A.nmom; ++m) {
+      const int g = A.mom[m].grid, nG = G.nG[g], o = A.mom_off[g];
+      for (int i = tid - 64; i < nG; i += blockDim.x - 64) {
+        mkt[ko + i] = A.mom[m].Kt[i];
+        mkt[ko + nG + i] = A.mom[m].dlnKt[i];
+        if (i < nG - 1)
+          mlx[o + i] = G.lx[g] ? G.lx[g][i] : log(G.xg[g][i + 1] / G.xg[g][i]);
+      }
+      ko += 2 * nG;
+    }
+  }
   const int c = A.cursor[0];             // slice accepted last (-1: none yet)
   const int cn = c + 1;                  // slice proposed here
   const double* r = A.blk + (long long)cn * 3 * A.ns;
@@ -489,6 +530,10 @@ __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
     qs[tid] = q;
     if (tid == 0) A.factors[j] = (A.ndim - 1.0) * log(z);
   }
+  if (tid < 64) {
+    NH_FRONT_LOAD_NODES()
+  }
+#undef NH_FRONT_LOAD_NODES
   __syncthreads();
   // ---- parameter packs (columns read this walker's proposal or are constants) -----
   if (tid < A.npk * NH_MAX_LAZY) {
@@ -509,31 +554,47 @@ __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
   __syncthreads();
   // ---- particle weights on every grid ---------------------------------------------
   const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
-  const pw_grids& G = A.G;
-  for (int n = tid; n < G.off[G.n]; n += blockDim.x) {
-    int g = 0;
-    while (g + 1 < G.n && n >= G.off[g + 1]) ++g;
-    const int i = n - G.off[g];
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
+    if (g < G.n && !skip_nodes && tid < G.nG[g]) {
+      const int nG = G.nG[g], i = tid;
+      const bool last = i + 1 >= nG;
+      double nn, dsh;
+      pd_core(A.kind, p, nln_[g] - lg[0], nln_[g] - lg[1], lg[2] - lg[0], nE_[g] < p.eb,
+              nE2_[g] < p.eb, nlr_[g], nn, dsh);
+      nn *= G.scale[g];
+      const double wv = ngx_[g] * nn, dv = last ? 0.0 : nlr_[g] + dsh;
+      G.w[g][(long long)j * nG + i] = wv;
+      G.dlw[g][(long long)j * nG + i] = dv;
+      if (A.mom_off[g] >= 0) {
+        ws[A.mom_off[g] + i] = wv;
+        ds[A.mom_off[g] + i] = dv;
+      }
+    }
+  }
+  for (int g = 0; g < G.n && !skip_nodes; ++g) {  // grids longer than the workgroup
     const int nG = G.nG[g];
     const double* e = G.e[g];
     const double* xg = G.xg[g];
-    const bool last = i + 1 >= nG;
-    const double E = e[i];
-    const double E2 = last ? E : e[i + 1];
-    const double gx = xg[i];
-    double lr = 0.0;
-    if (!last) lr = G.lx[g] ? G.lx[g][i] : log(xg[i + 1] / gx);
-    const double lnE = G.lne[g] ? G.lne[g][i] : log(E);
-    double nn, dsh;
-    pd_core(A.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn, dsh);
-    nn *= G.scale[g];
-    const long long loc = (long long)j * nG + i;
-    const double wv = gx * nn, dv = last ? 0.0 : lr + dsh;
-    G.w[g][loc] = wv;
-    G.dlw[g][loc] = dv;
-    if (A.mom_off[g] >= 0) {
-      ws[A.mom_off[g] + i] = wv;
-      ds[A.mom_off[g] + i] = dv;
+    for (int i = tid + blockDim.x; i < nG; i += blockDim.x) {
+      const bool last = i + 1 >= nG;
+      const double E = e[i];
+      const double E2 = last ? E : e[i + 1];
+      const double gx = xg[i];
+      double lr = 0.0;
+      if (!last) lr = G.lx[g] ? G.lx[g][i] : log(xg[i + 1] / gx);
+      const double lnE = G.lne[g] ? G.lne[g][i] : log(E);
+      double nn, dsh;
+      pd_core(A.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
+              dsh);
+      nn *= G.scale[g];
+      const double wv = gx * nn, dv = last ? 0.0 : lr + dsh;
+      G.w[g][(long long)j * nG + i] = wv;
+      G.dlw[g][(long long)j * nG + i] = dv;
+      if (A.mom_off[g] >= 0) {
+        ws[A.mom_off[g] + i] = wv;
+        ds[A.mom_off[g] + i] = dv;
+      }
     }
   }
   // ---- single-row reductions over those weights (We, Wp), one wave each ------------
@@ -543,13 +604,14 @@ __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
     if (wv < A.nmom) {
       const nh_moment& m = A.mom[wv];
       const int g = m.grid, nG = G.nG[g], o = A.mom_off[g];
+      int ko = 0;
+      for (int q = 0; q < wv; ++q) ko += 2 * G.nG[A.mom[q].grid];
       double acc = 0.0;
       for (int sgm = lane; sgm < nG - 1; sgm += 64) {
-        const double u1 = ws[o + sgm] * m.Kt[sgm];
-        const double u2 = ws[o + sgm + 1] * m.Kt[sgm + 1];
-        const double dl = ds[o + sgm] + m.dlnKt[sgm];
-        const double lxs = G.lx[g] ? G.lx[g][sgm] : log(G.xg[g][sgm + 1] / G.xg[g][sgm]);
-        acc += nh_seg_term(u1, u2, dl, lxs);
+        const double u1 = ws[o + sgm] * mkt[ko + sgm];
+        const double u2 = ws[o + sgm + 1] * mkt[ko + sgm + 1];
+        const double dl = ds[o + sgm] + mkt[ko + nG + sgm];
+        acc += nh_seg_term(u1, u2, dl, mlx[o + sgm]);
       }
       acc = wave_sum(acc);
       if (lane == 0) m.out[j] = acc;
@@ -624,7 +686,9 @@ extern "C" int nh_step_front(nh_ctx* c, const double* coords, const double* logp
       A.mom_nodes += grids[moms[m].grid].nG;
     }
   }
-  const size_t lds = ((size_t)ndim + NH_PD_NPAR + 3 + 2 * (size_t)A.mom_nodes) * sizeof(double);
+  size_t momk = 0;
+  for (int m = 0; m < nmoms; ++m) momk += 2 * (size_t)grids[moms[m].grid].nG;
+  const size_t lds = ((size_t)ndim + NH_PD_NPAR + 3 + 3 * (size_t)A.mom_nodes + momk) * sizeof(double);
   NH_REQUIRE(lds <= 60 * 1024, "reduction grids do not fit in LDS");
   nh_prof_scope ps(c, NH_K_PDIST);
   int threads = 1024;

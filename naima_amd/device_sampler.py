@@ -256,7 +256,7 @@ class DeviceLoop:
                 return
             mm[k] = nh_moment(wptr[w], 0, Kt, dlnKt, out.ptr)
             lds_nodes.add(wptr[w])
-        if 16 * sum(grids[g][5] for g in lds_nodes) > 48 * 1024:
+        if 40 * sum(grids[g][5] for g in lds_nodes) * max(len(moments), 1) > 48 * 1024:
             return
         plan["mode"] = "replay"
         ctx.pin_caches()
