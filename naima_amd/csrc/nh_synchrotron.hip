@@ -132,10 +132,13 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   __shared__ double synv[64];  // EPI: this walker's spectrum, by energy index
   constexpr int T = 64 * C;
   const int tid = threadIdx.x;
-  // EPI: the first wave asks for everything the likelihood needs besides this kernel's
+  // EPI: the LAST wave (the first one is on the critical path of the liveness search)
+  // asks for everything the likelihood needs besides this kernel's
   // own spectrum now; the answers wait in registers until the epilogue
   nh_lnprob_pre PRE = {};
-  if (EPI && tid < 64) nh_lnprob64_prefetch_a(PRE, L, blockIdx.x, tid, syn_comp);
+  const bool epw = EPI && tid >= T - 64;  // the epilogue's wave
+  const int el = tid - (T - 64);          // its lane = energy index
+  if (epw) nh_lnprob64_prefetch_a(PRE, L, blockIdx.x, el, syn_comp);
   for (int i = tid; i < nG; i += T) {
     const double g = gam[i];
     const double v = 1.0 / (g * g);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
                       (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
 
   // ---- 1. liveness of the tile's energies (first wave) ----------------------
-  if (EPI && tid < 64) nh_lnprob64_prefetch_b(PRE, L, wi);
+  if (epw) nh_lnprob64_prefetch_b(PRE, L, wi);
   if (tid < 64) {
     const int k = tid < tw ? tid * ktiles + tile : nE;
     int i0 = nG;
@@ -188,9 +191,9 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   }
   __syncthreads();
   const int nA = s_nA;
-  if (EPI && tid < 64) nh_lnprob64_prefetch_c(PRE, L, tid);
+  if (epw) nh_lnprob64_prefetch_c(PRE, L, el);
   if (nA == 0) {
-    if (EPI && tid < 64) nh_lnprob64_finish(L, PRE, wi, tid, synv, syn_comp);
+    if (epw) nh_lnprob64_finish(L, PRE, wi, el, synv, syn_comp);
     return;
   }
   const int nseg = nG - 1;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   }
   if (EPI) {
     __syncthreads();
-    if (tid < 64) nh_lnprob64_finish(L, PRE, wi, tid, synv, syn_comp);
+    if (epw) nh_lnprob64_finish(L, PRE, wi, el, synv, syn_comp);
   }
 }
 
