@@ -10,8 +10,9 @@
 // OCML cbrt/sqrt/div/exp/log):
 //   cbrt(x)     = cbrt(q) * gamma_i^(-2/3): one cube root per THREAD, the grid part
 //                 is tabulated in LDS together with 1/gamma^2 and its difference;
-//   1/sqrt, 1/y = v_rsq_f64 / v_rcp_f64 + two Newton steps (well-scaled operands);
-//   exp(-x)     = Cody-Waite reduction + degree-13 Taylor + v_ldexp_f64;
+//   1/sqrt, 1/y = single-precision v_rsq/v_rcp seed + two Newton steps (well-scaled operands);
+//   exp(-x)     = Cody-Waite reduction + degree-13 Taylor (three-address FMAs, coefficients
+//                 in scalar registers) + v_ldexp_f64;
 //   ln(P2/P1)   = 2 atanh(s), s = (P2-P1)/(P2+P1), 5-term series (adjacent nodes
 //                 differ by a few per cent), log() only on coarse grids.
 #include "nh_lnprob.h"
