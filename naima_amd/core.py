@@ -153,7 +153,12 @@ def lnprobmodel(model, data, lp=None):
         if nE != dd.n:
             raise ValueError("model has %d energies, data table has %d" % (nE, dd.n))
         ctx.join()  # the emission components ran on side streams
-        total = ctx.empty((N,))
+        hook = ctx._accept_hook
+        if hook is not None and (hook["N"] != N or hook["used"]):
+            hook = None
+        # the sharded step loop wants the result in its all-gather send buffer
+        total = hook["total"] if hook is not None and hook.get("total") is not None \
+            else ctx.empty((N,))
         lpd = terms = None
         nterms = 0
         if isinstance(lp, LazyPrior):
@@ -165,12 +170,13 @@ def lnprobmodel(model, data, lp=None):
         args = (m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),
                 dd.flux, dd.elo, dd.ehi, dd.ul, dd.cl, lpd.ptr if lpd is not None else None,
                 terms, nterms, None, total)
-        hook = ctx._accept_hook
         owners = [t[0] for t in m.terms]
         held = [j for j, o in enumerate(owners) if getattr(o, "pending", None) is not None]
-        if hook is not None and hook["N"] == N and not hook["used"]:
-            # device step loop, single rank: the stretch move's accept rides on this launch
+        if hook is not None:
+            # device step loop: the stretch move's accept rides on this launch (single
+            # rank; sharded, the accept has to wait for the all-gather: mv is None)
             import ctypes as C
+            mv = C.addressof(hook["mv"]) if hook["mv"] is not None else None
             j = held[0] if len(held) == 1 else -1
             o = owners[j] if j >= 0 else None
             if o is not None and o.pending[0] == "nh_synchrotron" and m.terms[j][1] == o.ptr \
@@ -181,10 +187,13 @@ def lnprobmodel(model, data, lp=None):
                 o.pending = None
                 ctx._deferred = [a for a in ctx._deferred if a is not o]
                 ctx.call("nh_synchrotron_lnprob", *sa, args[0], args[1], j, *args[4:13],
-                         total, C.addressof(hook["mv"]))
+                         total, mv)
             else:
                 ctx.flush(*owners)
-                ctx.call("nh_lnprob_accept", *args, C.addressof(hook["mv"]))
+                if mv is not None:
+                    ctx.call("nh_lnprob_accept", *args, mv)
+                else:
+                    ctx.call("nh_lnprob", *args)
             hook["used"] = True
         else:
             ctx.flush(*owners)

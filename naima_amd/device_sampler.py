@@ -146,9 +146,8 @@ class DeviceLoop:
             # proposal, parameter rows, weights, We: written by the preceding nh_step_front
             self._plan["i"] = [0, 0, 0]
             ctx._plan = self._plan
-            if self.s.comm.size == 1:
-                self._hook["used"] = False
-                ctx._accept_hook = self._hook
+            self._hook["used"] = False
+            ctx._accept_hook = self._hook
         else:
             ctx.call("nh_move_propose", self.coords, self.blk, self.cursor, self.ns, self.ndim,
                      self.lo, self.nloc, self.qT, self.factors)
@@ -161,7 +160,8 @@ class DeviceLoop:
         if self.s.comm.size > 1:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses
-            ctx.call("nh_copy", self.mylp, total.ptr, 8 * self.nloc)
+            if total.ptr != self.mylp.ptr:  # (the fused likelihood wrote it there itself)
+                ctx.call("nh_copy", self.mylp, total.ptr, 8 * self.nloc)
             self._newlp_ptr = self.newlp.ptr
         else:
             self._total = total  # single rank: the accept kernel reads it in place
@@ -184,7 +184,8 @@ class DeviceLoop:
     def _part_accept(self):
         ctx = self.ctx
         if self.fused:
-            if not (self._hook and self._hook["used"]):  # sharded, or a foreign likelihood
+            if not (self._hook and self._hook["used"] and self._hook["mv"] is not None):
+                # sharded (the accept waits for the all-gather), or a foreign likelihood
                 ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
                          self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc,
                          self.sel, 0)
@@ -262,10 +263,13 @@ class DeviceLoop:
         ctx.pin_caches()
         self._plan = plan
         self._front_args = (pk, len(packs), kind, rows_ptr, gd, len(grids), mm, len(moments))
-        self._hook = dict(N=self.nloc, used=False,
-                          mv=nh_accept(self.coords.ptr, self.logp.ptr, self.blk.ptr,
-                                       self.cursor.ptr, self.ns, self.ndim, self.lo, 0,
-                                       self.accepted.ptr, self.nacc.ptr, self.sel.ptr))
+        if self.s.comm.size == 1:
+            self._hook = dict(N=self.nloc, used=False, total=None,
+                              mv=nh_accept(self.coords.ptr, self.logp.ptr, self.blk.ptr,
+                                           self.cursor.ptr, self.ns, self.ndim, self.lo, 0,
+                                           self.accepted.ptr, self.nacc.ptr, self.sel.ptr))
+        else:  # sharded: likelihood into the all-gather send buffer, accept afterwards
+            self._hook = dict(N=self.nloc, used=False, total=self.mylp, mv=None)
         self.fused = True
         # new slice protocol: cursor = the slice accepted last.  The two piecewise
         # half-steps (slices 0 and 1 of the first block) left it at 2.
