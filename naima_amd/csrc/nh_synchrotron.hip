@@ -108,8 +108,9 @@ __device__ __forceinline__ double syn_dlnP(double P1, double P2) {
 // TeV energies altogether (the reference computes, and trapz_loglog discards, exact
 // zeros there).  The block therefore
 //   1. finds, per energy, the first node i0 that can contribute (binary search in the
-//      LDS copy of 1/gamma^2), the number nA of live energies and sbeg = min i0 - 1;
-//   2. compacts the live energies and spreads [sbeg, nseg) x nA over ALL its threads:
+//      LDS copy of 1/gamma^2) and the number nA of live energies;
+//   2. compacts the live energies and spreads each one's [i0 - 1, nseg) over its share of
+//      ALL the block's threads:
 //      thread t -> live energy t % nA, chunk t / nA (Cd = T / nA chunks);
 //   3. reduces the Cd partial sums per energy in LDS; dead energies get 0.
 constexpr int SYN_MAXCH = 64;  // chunks per energy (LDS: part[SYN_MAXCH][64])
@@ -128,8 +129,9 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   double* dig2 = smem + nG;
   double* ig23 = smem + 2 * nG;
   double* part = smem + 3 * nG;
-  __shared__ int amap[64];
-  __shared__ int s_min_i0, s_nA;
+  __shared__ int amap[64];   // compacted live energy -> energy index
+  __shared__ int ai0[64];    //                       -> its first segment that can contribute
+  __shared__ int s_nA;
   __shared__ double synv[64];  // EPI: this walker's spectrum, by energy index
   constexpr int T = 64 * C;
   const int tid = threadIdx.x;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     }
     dig2[i] = d;
   }
-  if (tid == 0) { s_min_i0 = nG; s_nA = 0; }
+  if (tid == 0) s_nA = 0;
   __syncthreads();
 
   // a tile = tw (<= 64) photon energies, INTERLEAVED over the ktiles tiles (energy
@@ -183,8 +185,9 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const bool live = i0 < nG;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
     if (live) {
-      amap[__popcll(m & ((1ull << tid) - 1ull))] = k;
-      atomicMin(&s_min_i0, i0);
+      const int pos = __popcll(m & ((1ull << tid) - 1ull));
+      amap[pos] = k;
+      ai0[pos] = max(i0 - 1, 0);
     }
     if (tid == 0) s_nA = __popcll(m);
     if (k < nE && !live) out[(long long)wi * ldo + k] = 0.0;
@@ -198,13 +201,15 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     return;
   }
   const int nseg = nG - 1;
-  const int sbeg = max(s_min_i0 - 1, 0);
 
   // ---- 2. (live energy, chunk) per thread ------------------------------------
   const int Cd = min(T / nA, SYN_MAXCH);
   const int a = tid % nA, ch = tid / nA;
   double acc = 0.0;
   if (ch < Cd) {
+    // every energy spreads ITS live range over its Cd threads (the first live node moves
+    // up with the photon energy: 65 nodes between 0.55 and 11 keV on the default grid)
+    const int sbeg = ai0[a];
     const int per = (nseg - sbeg + Cd - 1) / Cd;
     const int s0 = sbeg + ch * per;
     const int s1 = min(nseg, s0 + per);
