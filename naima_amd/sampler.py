@@ -75,6 +75,7 @@ class EnsembleSampler:
         # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)
         self.device = bool(device)
         self.use_graph = bool(use_graph)
+        self._device_ok = None
         # accept + next proposal + parameter packs as ONE launch (nh_move_cycle)
         self.fuse_moves = os.environ.get("NAIMA_AMD_FUSE_MOVES", "1") != "0"
         self._dev = None
@@ -190,8 +191,13 @@ class EnsembleSampler:
         ``run_mcmc`` asks for) lets the device loop replay several steps as one hipGraph
         and yield only after each such group."""
         if self.device:
-            yield from self._sample_device(initial_state, iterations, store, yield_every)
-            return
+            if self._dev is None and self._device_ok is None:
+                self._device_ok = self._probe_device(initial_state)
+            if self._device_ok is not False:
+                yield from self._sample_device(initial_state, iterations, store, yield_every)
+                return
+            # the model shapes a grid / table per walker (Eemin, a seed temperature ... as
+            # fit parameters): the general path needs the values on the host
         state = State(initial_state)
         coords = state.coords.copy()
         if coords.shape != (self.nwalkers, self.ndim):
@@ -243,6 +249,28 @@ class EnsembleSampler:
             yield State(coords, logp, self._cur_blobs if keep_blobs else None, rng)
 
     # ------------------------------------------------------------ device mode
+    def _probe_device(self, initial_state):
+        """one evaluation of two walkers on lazy device parameters: does the model run
+        with its parameters in HBM?  Models that shape a particle grid or an emission
+        table per walker do not (NotImplementedError from the radiative classes); they
+        are sampled by the host-driven loop, which evaluates such walkers one by one."""
+        import warnings
+
+        from . import _lib
+        from .darray import DPars
+        if not self.naima_style:
+            return True
+        ctx = _lib.get_context()
+        c = np.ascontiguousarray(State(initial_state).coords[:2].T, dtype=float)
+        try:
+            self.log_prob_fn(DPars(ctx, ctx.array(c), self.ndim, c.shape[1]), *self.args)
+        except NotImplementedError as e:
+            warnings.warn("device=True is not possible for this model (%s); using the "
+                          "host-driven loop" % (e,))
+            self.device = False
+            return False
+        return True
+
     def _sample_device(self, initial_state, iterations, store, yield_every=1):
         from .device_sampler import DeviceLoop
         if self._dev is None:

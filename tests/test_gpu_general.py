@@ -233,3 +233,37 @@ def test_prefit_batched_simplex(na, golden):
     assert is_ml == (seq["status"] == 0)
     assert float(np.asarray(na.lnprob(x, data, model, None)[0])) > \
         float(np.asarray(na.lnprob(start, data, model, None)[0]))
+
+
+def test_device_sampler_falls_back_for_grid_shaping_parameters(na):
+    """a model whose fit parameters include Eemin cannot keep its parameters in HBM (every
+    walker has its own particle grid): device=True warns and samples with the host loop,
+    which evaluates such walkers through the general path"""
+    from bench import build_problem
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    _, p0, raw, data, prior, labels = build_problem("cfg1", na)
+
+    def model(pars, data):
+        pd = na.ExponentialCutoffPowerLaw(pars[0] / u.eV, 10 * u.TeV, pars[1],
+                                          10 ** pars[2] * u.TeV)
+        ic = na.InverseCompton(pd, seed_photon_fields=["CMB"], Eemin=pars[3] * u.GeV)
+        return ic.flux(data, distance=1 * u.kpc)
+
+    def pri(pars):
+        return na.uniform_prior(pars[1], -1, 5) + na.uniform_prior(pars[3], 0.1, 100)
+
+    start = np.append(p0, 3.0)
+    kw = dict(args=[data, model, pri], seed=2, naima_style=True, store_blobs=False)
+    pos = start * (1 + 0.01 * np.random.default_rng(0).standard_normal((12, 4)))
+    with pytest.warns(UserWarning, match="host-driven loop"):
+        d = EnsembleSampler(12, 4, na.lnprob, device=True, **kw)
+        sd = d.run_mcmc(pos, 3)
+    h = EnsembleSampler(12, 4, na.lnprob, **kw)
+    sh = h.run_mcmc(pos, 3)
+    assert d.device is False
+    assert_allclose(sd.coords, sh.coords, rtol=1e-12)
+    assert np.all(np.isfinite(sd.log_prob))
+    # ... and the per-walker evaluation is the scalar one
+    one = na.lnprob(sd.coords[5], data, model, pri)
+    assert_allclose(np.asarray(sd.log_prob)[5], np.asarray(one[0]), rtol=1e-10)
