@@ -75,15 +75,20 @@ __device__ __forceinline__ void nh_lnprob_wave(const nh_lnprob_args& A, int wi, 
       acc += -(d * d) / (2.0 * (sg * sg));
     }
   }
-  acc = nh_wave_sum(acc);
+  // one reduction for both counters (16 bits each: a table has far fewer than 65536
+  // upper limits), interleaved with the sum of squares so that the cross-lane latencies overlap
+  int cnt = nviol | (nul << 16);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    nviol += __shfl_down(nviol, off, 64);
-    nul += __shfl_down(nul, off, 64);
+    const double a2 = __shfl_down(acc, off, 64);
+    const int c2 = __shfl_down(cnt, off, 64);
+    acc += a2;
+    cnt += c2;
   }
   // quirk kept from core.py:89-92: cl is indexed by the violation count
-  nviol = __shfl(nviol, 0, 64);
-  nul = __shfl(nul, 0, 64);
+  cnt = __shfl(cnt, 0, 64);
+  nviol = cnt & 0xffff;
+  nul = cnt >> 16;
   const double clv = (nviol < 64 && nviol < nE) ? __shfl(cl_lane, nviol, 64) : A.cl[nviol];
   if (lane == 0) {
     if (nul > 0) acc += (double)nviol * log(1.0 - clv);
@@ -181,14 +186,17 @@ __device__ __forceinline__ void nh_lnprob64_finish(const nh_lnprob_args& A, cons
       acc = -(d * d) / (2.0 * (sg * sg));
     }
   }
-  acc = nh_wave_sum(acc);
+  int cnt = nviol | (nul << 16);  // both counters in one reduction, interleaved with the sum
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    nviol += __shfl_down(nviol, off, 64);
-    nul += __shfl_down(nul, off, 64);
+    const double a2 = __shfl_down(acc, off, 64);
+    const int c2 = __shfl_down(cnt, off, 64);
+    acc += a2;
+    cnt += c2;
   }
-  nviol = __shfl(nviol, 0, 64);
-  nul = __shfl(nul, 0, 64);
+  cnt = __shfl(cnt, 0, 64);
+  nviol = cnt & 0xffff;
+  nul = cnt >> 16;
   const double clv = (nviol < 64 && nviol < nE) ? __shfl(P.cl_lane, nviol, 64) : A.cl[nviol];
   const bool has_prior = A.lp || A.pri.n > 0;
   if (lane == 0) {
