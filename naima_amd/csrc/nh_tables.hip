@@ -167,10 +167,14 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
 // ---------------------------------------------------------------------------
 __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restrict__ sd, int N,
                            int ns, double* __restrict__ e0, double* __restrict__ lxs,
+                           double* __restrict__ ie0, double* __restrict__ le0,
                            double* __restrict__ sdm, double* __restrict__ dlnd) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < ns) {
-    e0[idx] = se[idx] / NH_MEC2_EV;
+    const double e = se[idx] / NH_MEC2_EV;
+    e0[idx] = e;
+    ie0[idx] = 1.0 / e;
+    le0[idx] = log(e);
     if (idx + 1 < ns) lxs[idx] = log(se[idx + 1] / se[idx]);
   }
   if (idx >= (long long)N * ns) return;
@@ -180,13 +184,41 @@ __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restri
   dlnd[idx] = (s + 1 < ns) ? log(fabs(sd[idx + 1] / sd[idx])) : 0.0;
 }
 
+// fic of Eq. 22 along the seed axis for fixed (gamma, E_gamma): with w = E_gamma/gamma,
+//   q = w / (4 eps0 gamma (1 - w)) = c1 / eps0,   b q = w / (1 - w) =: B  (no eps0 in it),
+//   fic = 2 q ln q + (1 + 2 q)(1 - q) + (B^2 / (2 (1 + B))) (1 - q),   ln q = ln c1 - ln eps0,
+// so one seed node costs a dozen FMAs: the divisions and the logarithm of ic_fic_windowed
+// are taken once per (gamma, E_gamma).  Windows and the NaN -> 0 rule as there.
+struct ssc_gk { double c1, lnc1, hB, qmin; bool valid; };
+
+__device__ __forceinline__ ssc_gk ssc_setup(double g, double eg) {
+  ssc_gk r;
+  const double wq = eg / g, omw = 1.0 - wq;
+  r.valid = omw > 0.0 && wq > 0.0;  // else q <= 0 or infinite: log(q) NaN -> 0 (radiative.py:636)
+  r.c1 = wq / (4.0 * g * omw);
+  r.lnc1 = r.valid ? log(r.c1) : 0.0;
+  const double B = wq / omw;
+  r.hB = 0.5 * (B * B) / (1.0 + B);
+  r.qmin = 1.0 / (4.0 * (g * g));
+  return r;
+}
+
+__device__ __forceinline__ double ssc_fic(const ssc_gk& r, double ie0, double le0) {
+  const double q = r.c1 * ie0;
+  const double omq = 1.0 - q;
+  const double f = 2.0 * q * (r.lnc1 - le0) + fma(2.0, q, 1.0) * omq + r.hB * omq;
+  const double win = nh_heaviside(omq) * nh_heaviside(q - r.qmin);
+  return r.valid ? f * win : 0.0;
+}
+
 template <int C, int W>
 __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, const double* __restrict__ e0,
-    const double* __restrict__ lxs, const double* __restrict__ sdm,
-    const double* __restrict__ dlnd, int ns, double* __restrict__ partial) {
+    const double* __restrict__ E_eV, int nE, const double* __restrict__ ie0,
+    const double* __restrict__ le0, const double* __restrict__ lxs,
+    const double* __restrict__ sdm, const double* __restrict__ dlnd, int ns,
+    double* __restrict__ partial) {
   __shared__ double part[C][W][64];
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -216,18 +248,25 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double g = gam[i];
     // inner reduction over the seed spectrum for W walkers at once
     double in[W], u1[W];
-    double f1 = ic_fic_windowed(e0[0], g, eg);
+    const ssc_gk gk = ssc_setup(g, eg);
+    double f1 = ssc_fic(gk, ie0[0], le0[0]);
 #pragma unroll
     for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * sdm[srow[j]]; }
     for (int s = 1; s < ns; ++s) {
-      const double f2 = ic_fic_windowed(e0[s], g, eg);
-      const double dlf = log(fabs(f2 / f1));
-      const double lxv = lxs[s - 1];
+      const double f2 = ssc_fic(gk, ie0[s], le0[s]);
+      // both zero for a whole wave (outside every lane's window): nothing to add
+      if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
+        const double dlf = log(fabs(f2 / f1));
+        const double lxv = lxs[s - 1];
 #pragma unroll
-      for (int j = 0; j < W; ++j) {
-        const double u2 = f2 * sdm[srow[j] + s];
-        in[j] += nh_seg_term(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
-        u1[j] = u2;
+        for (int j = 0; j < W; ++j) {
+          const double u2 = f2 * sdm[srow[j] + s];
+          in[j] += nh_seg_pos<true>(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
+          u1[j] = u2;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < W; ++j) u1[j] = 0.0;
       }
       f1 = f2;
     }
@@ -279,30 +318,32 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)N * ns < (1LL << 31),
              "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
-  constexpr int C = 8, W = 4;
+  constexpr int C = 8, W = 8;
   const int ktiles = (nE + 63) / 64;
   const int groups = (N + W - 1) / W;
   const int nseg = nG - 1;
   // super-chunks over gamma so that the launch has ~4 waves per SIMD
   int nsuper = 1;
-  while (nsuper < 8 && (long long)ktiles * groups * nsuper * C < 4096 &&
+  while (nsuper < 16 && (long long)ktiles * groups * nsuper * C < 4096 &&
          nseg / ((nsuper * 2) * C) >= 4)
     nsuper *= 2;
   const size_t nd = (size_t)N * ns;
-  const size_t need = (2 * (size_t)ns + 2 * nd + (size_t)nsuper * N * nE) * sizeof(double);
+  const size_t need = (4 * (size_t)ns + 2 * nd + (size_t)nsuper * N * nE) * sizeof(double);
   void* sc = nullptr;
   int rc = nh_scratch(c, need, &sc);
   if (rc) return rc;
   double* e0 = static_cast<double*>(sc);
   double* lxs = e0 + ns;
-  double* sdm = lxs + ns;
+  double* ie0 = lxs + ns;
+  double* le0 = ie0 + ns;
+  double* sdm = le0 + ns;
   double* dlnd = sdm + nd;
   double* partial = dlnd + nd;
   nh_prof_scope ps(c, NH_K_SSC);
   hipLaunchKernelGGL(k_ssc_prep, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream,
-                     seed_E, seed_dens, N, ns, e0, lxs, sdm, dlnd);
+                     seed_E, seed_dens, N, ns, e0, lxs, ie0, le0, sdm, dlnd);
   hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(ktiles * groups, nsuper), dim3(64 * C), 0,
-                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, e0, lxs, sdm, dlnd, ns, partial);
+                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, ie0, le0, lxs, sdm, dlnd, ns, partial);
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                      partial, nsuper, N, nE, E_eV, out, ldo);
