@@ -181,7 +181,12 @@ __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restri
   int s = (int)(idx % ns);
   double d = sd[idx] * NH_MEC2_EV;  // 1/(eV cm3) -> 1/(mec2 cm3), radiative.py:639
   sdm[idx] = d;
-  dlnd[idx] = (s + 1 < ns) ? log(fabs(sd[idx + 1] / sd[idx])) : 0.0;
+  double dl = 0.0;
+  if (s + 1 < ns) {  // a zero node ends the power-law segment: marked as in the tables
+    const double a = sd[idx], b = sd[idx + 1];
+    dl = (a == 0.0 || b == 0.0) ? NH_DL_ZERO : log(fabs(b / a));
+  }
+  dlnd[idx] = dl;
 }
 
 // fic of Eq. 22 along the seed axis for fixed (gamma, E_gamma): with w = E_gamma/gamma,
@@ -250,21 +255,28 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     double in[W], u1[W];
     const ssc_gk gk = ssc_setup(g, eg);
     double f1 = ssc_fic(gk, ie0[0], le0[0]);
+    double lf1 = log(fabs(f1));  // seed nodes are ~0.16 decades apart: ln f2 - ln f1 is O(1),
+                                 // the difference of logarithms loses nothing here
 #pragma unroll
     for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * sdm[srow[j]]; }
     for (int s = 1; s < ns; ++s) {
       const double f2 = ssc_fic(gk, ie0[s], le0[s]);
       // both zero for a whole wave (outside every lane's window): nothing to add
       if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
-        const double dlf = log(fabs(f2 / f1));
+        const double lf2 = log(fabs(f2));
+        // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
+        // segment contributes (u2 - u1) lx 0 = 0 (utils.py:347-348) without a test per walker
+        const double dlf = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO);
+        lf1 = lf2;
         const double lxv = lxs[s - 1];
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           const double u2 = f2 * sdm[srow[j] + s];
-          in[j] += nh_seg_pos<true>(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
+          in[j] += nh_seg_pos<false>(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
           u1[j] = u2;
         }
       } else {
+        lf1 = -INFINITY;
 #pragma unroll
         for (int j = 0; j < W; ++j) u1[j] = 0.0;
       }
