@@ -104,6 +104,10 @@ int nh_profile_read(nh_ctx* ctx, double* ms_per_kernel /*[NH_K_COUNT]*/,
  * zero nodes, NaN/sign-change -> log branch, |b+1| <= 1e-10 -> log branch). */
 int nh_trapz_loglog(nh_ctx* ctx, const double* y, const double* x, int nrows, int n,
                     double* out);
+/* the same with intervals=True (utils.py:350-351): out[row*(n-1) + i] = the term of
+ * segment (x_i, x_{i+1}) */
+int nh_trapz_loglog_intervals(nh_ctx* ctx, const double* y, const double* x, int nrows, int n,
+                              double* out);
 
 /* ---- rows 2,3: models.py eval statics + radiative.py:147-160,1002-1015 -- */
 /* w[N][nG] = xg_i * unit_scale * f_kind(e_eV_i; params_w), dlw[i] = ln|w[i+1]/w[i]|.

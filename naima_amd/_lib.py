@@ -41,6 +41,7 @@ _SIGS = {
     "nh_profile_read": [_dp, C.POINTER(_d), C.POINTER(_ll), _i],
     "nh_profile_calibrate": [_dp, _i, C.POINTER(_d)],
     "nh_trapz_loglog": [_dp, _dp, _dp, _i, _i, _dp],
+    "nh_trapz_loglog_intervals": [_dp, _dp, _dp, _i, _i, _dp],
     "nh_particle_weights": [_dp, _i, _dp, _i, _dp, _dp, _i, _d, _dp, _dp, _dp],
     "nh_particle_weights_multi": [_dp, _i, _dp, _i, _dp, _i],
     "nh_grid_logratio": [_dp, _dp, _i, _dp],

@@ -310,6 +310,36 @@ __global__ __launch_bounds__(256) void k_trapz_loglog(const double* __restrict__
   if (lane == 0) out[row] = acc;
 }
 
+// the per-segment terms (utils.py:350-351, intervals=True)
+__global__ __launch_bounds__(256) void k_trapz_loglog_intervals(const double* __restrict__ y,
+                                                                 const double* __restrict__ x,
+                                                                 int nrows, int n,
+                                                                 double* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)nrows * (n - 1)) return;
+  const int row = (int)(idx / (n - 1)), s = (int)(idx % (n - 1));
+  const double y1 = y[(long long)row * n + s], y2 = y[(long long)row * n + s + 1];
+  const double x1 = x[s], x2 = x[s + 1];
+  const double b = log10(y2 / y1) / log10(x2 / x1);
+  const double tp = (y1 * (x2 * pow(x2 / x1, b) - x1)) / (b + 1.0);
+  const double tl = x1 * y1 * log(x2 / x1);
+  double t = (fabs(b + 1.0) > 1e-10) ? tp : tl;  // NaN b -> log branch
+  if (y1 == 0.0 || y2 == 0.0 || x1 == x2) t = 0.0;
+  out[idx] = t;
+}
+
+extern "C" int nh_trapz_loglog_intervals(nh_ctx* c, const double* y, const double* x, int nrows,
+                                         int n, double* out) {
+  NH_REQUIRE(c && y && x && out && nrows >= 0 && n >= 2, "bad argument");
+  if (nrows == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_INTEGRATE);
+  const long long tot = (long long)nrows * (n - 1);
+  hipLaunchKernelGGL(k_trapz_loglog_intervals, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                     c->stream, y, x, nrows, n, out);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
 extern "C" int nh_trapz_loglog(nh_ctx* c, const double* y, const double* x, int nrows, int n,
                                double* out) {
   NH_REQUIRE(c && y && x && out && nrows >= 0 && n >= 1, "bad argument");

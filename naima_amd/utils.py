@@ -12,8 +12,6 @@ __all__ = ["trapz_loglog", "sed_conversion"]
 def trapz_loglog(y, x, axis=-1, intervals=False):
     """Integrate ``y(x)`` along ``axis`` with the composite trapezoid rule in log-log
     space (exact for power laws).  Quantity-aware like the reference."""
-    if intervals:
-        raise NotImplementedError("intervals=True (per-segment terms) is not exposed")
     y_unit = x_unit = u.dimensionless_unscaled
     if isinstance(y, u.Quantity):
         y, y_unit = y.value, y.unit
@@ -29,9 +27,14 @@ def trapz_loglog(y, x, axis=-1, intervals=False):
         raise ValueError("x and y have different lengths along the integration axis")
     rows = ym.reshape(-1, n)
     ctx = get_context()
-    out = ctx.empty((rows.shape[0],))
-    ctx.call("nh_trapz_loglog", ctx.array(rows), ctx.array(x), rows.shape[0], n, out)
-    res = out.get().reshape(ym.shape[:-1])
+    if intervals:  # the per-segment terms, along the integration axis (utils.py:350-351)
+        out = ctx.empty((rows.shape[0], n - 1))
+        ctx.call("nh_trapz_loglog_intervals", ctx.array(rows), ctx.array(x), rows.shape[0], n, out)
+        res = np.moveaxis(out.get().reshape(ym.shape[:-1] + (n - 1,)), -1, axis)
+    else:
+        out = ctx.empty((rows.shape[0],))
+        ctx.call("nh_trapz_loglog", ctx.array(rows), ctx.array(x), rows.shape[0], n, out)
+        res = out.get().reshape(ym.shape[:-1])
     if res.ndim == 0:
         res = float(res)
     unit = y_unit * x_unit

@@ -267,3 +267,21 @@ def test_device_sampler_falls_back_for_grid_shaping_parameters(na):
     # ... and the per-walker evaluation is the scalar one
     one = na.lnprob(sd.coords[5], data, model, pri)
     assert_allclose(np.asarray(sd.log_prob)[5], np.asarray(one[0]), rtol=1e-10)
+
+
+def test_trapz_loglog_intervals(na):
+    """utils.trapz_loglog(..., intervals=True) (utils.py:350-351): the per-segment terms,
+    along any axis, against the oracle; their sum is the integral"""
+    from naima_amd.utils import trapz_loglog
+    from oracle import naima_np as O
+    rng = np.random.default_rng(6)
+    x = np.geomspace(1.0, 1e4, 37)
+    y = 10 ** rng.normal(size=(5, 37)) * x ** -1.7
+    y[2, 10] = 0.0  # a zero node: both neighbouring terms vanish
+    got = trapz_loglog(y, x, axis=-1, intervals=True)
+    ref = O.trapz_loglog(y, x, axis=-1, intervals=True)
+    assert got.shape == (5, 36)
+    assert_allclose(got, ref, rtol=1e-12)
+    assert_allclose(got.sum(axis=-1), trapz_loglog(y, x), rtol=1e-13)
+    got0 = trapz_loglog(y.T, x, axis=0, intervals=True)
+    assert_allclose(got0, ref.T, rtol=1e-12)
