@@ -145,4 +145,20 @@ def from_env(prefer="rccl"):
     """LocalComm for a single process, else RCCL (GPU) or gloo (CPU tests)"""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return LocalComm()
-    return RcclComm() if prefer == "rccl" else GlooComm()
+    if prefer != "rccl":
+        return GlooComm()
+    comm = err = None
+    try:
+        comm = RcclComm()
+    except Exception as e:  # librccl missing / communicator refused
+        err = e
+    import torch
+    dist = _ensure_gloo()
+    ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
+    if float(ok.item()) == 1.0:
+        return comm
+    import warnings
+    warnings.warn("RCCL communicator unavailable (%s); all-gathers are staged through the host "
+                  "with gloo: correct, slower" % (err,))
+    return GlooComm()
