@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         const double x = q * ig2[s0];
         if (x <= 746.0) {
           P1 = syn_P(cbq * ig23[s0]);
-          u1 = wr[s0] * (cs1 * (P1 * nh_exp_neg(x)));  // gamma nelec dNdE, :335-338
+          u1 = wr[s0] * (P1 * nh_exp_neg(x));  // gamma nelec dNdE / CS1, :335-338
         }
       }
       for (int s = s0; s < s1; ++s) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         double u2 = 0.0, P2 = 1.0;
         if (x <= 746.0) {
           P2 = syn_P(cbq * ig23[s + 1]);
-          u2 = wr[s + 1] * (cs1 * (P2 * nh_exp_neg(x)));
+          u2 = wr[s + 1] * (P2 * nh_exp_neg(x));
         }
         // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
         const double dl = dwr[s] + syn_dlnP(P1, P2) - q * dig2[s];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         P1 = P2;
       }
     }
-    part[ch * 64 + a] = acc;
+    part[ch * 64 + a] = acc * cs1;  // the terms are linear in u: CS1 once per thread
   }
   __syncthreads();
   // ---- 3. per-energy reduction -------------------------------------------------
