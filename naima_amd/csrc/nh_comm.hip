@@ -2,6 +2,9 @@
 // rank has just moved, straight on RCCL over xGMI.  librccl is
 // dlopen()ed on first use so that single-GPU users never load it.
 #include <dlfcn.h>
+
+#include <cstdlib>
+#include <string>
 #include <rccl/rccl.h>
 
 #include "nh_common.h"
@@ -22,10 +25,19 @@ static rccl_api g_rccl;
 
 static int rccl_load() {
   if (g_rccl.lib) return NH_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // The RCCL that belongs to the HIP runtime THIS library is linked against, by absolute
+  // path.  A process that has imported PyTorch (torch.distributed hands the unique id
+  // around) already holds PyTorch's own bundled librccl.so.1 -- bound to PyTorch's own
+  // bundled HIP runtime, a second one in the process -- and a dlopen by soname would
+  // return that copy, whose ncclCommInitRank then fails on our streams ("unhandled cuda
+  // error").  RTLD_DEEPBIND keeps the two copies' symbols apart.
+  std::string first = "/opt/rocm/lib/librccl.so.1";
+  if (const char* rp = getenv("ROCM_PATH")) first = std::string(rp) + "/lib/librccl.so.1";
+  const char* names[] = {first.c_str(), "/opt/rocm/lib/librccl.so.1", "librccl.so.1",
+                         "librccl.so"};
   void* h = nullptr;
   for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (h) break;
   }
   if (!h) return nh_set_error(NH_ECOMM, "cannot dlopen librccl: %s", dlerror());

@@ -397,6 +397,24 @@ def test_rccl_single_rank_allgather(na):
     ctx.close()
 
 
+def test_rccl_communicator_after_torch_import(na):
+    """bench.py's order of events: torch.distributed (gloo) first, then the RCCL
+    communicator.  PyTorch bundles its own librccl and HIP runtime; the communicator must
+    come from the RCCL of the runtime libnaima_hip is linked against (a dlopen by soname
+    returned PyTorch's copy and ncclCommInitRank failed).  Also: the all-gather survives
+    hipGraph capture and replay.  Separate process: it initialises a process group."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 100),
+               RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "rccl_graph_probe.py")],
+                         cwd=root, env=env, timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "eager ok: True" in out.stdout
+    assert "captured + replayed ok: True" in out.stdout
+
+
 def test_abi_move_kernels(na):
     """nh_move_propose / nh_move_accept / nh_scatter_rows against their NumPy twins, on
     the second slice of a two-half-step block (cursor = 1)"""
