@@ -106,6 +106,10 @@ class RcclComm:
         self.dist = dist
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
         lib = _lib.load()
+        # NCCL_DEBUG=VERSION makes RCCL print a banner on STDOUT, where bench.py owes the
+        # driver exactly one JSON line
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
         buf = C.create_string_buffer(128)
         if self.rank == 0:
             _lib._chk(lib.nh_comm_unique_id(buf))
