@@ -16,6 +16,8 @@ pieces (grids, emission tables, data columns) are evaluated during a warm-up pas
 land in the context's caches, and are therefore not part of the graph.  After
 capture no Python model code runs inside the loop.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -64,6 +66,9 @@ class DeviceLoop:
             raise ValueError("device=True needs the half-ensemble (%d) to divide evenly over %d "
                              "ranks" % (self.ns, comm.size))
         self.lo, self.hi = shard_bounds(self.ns, comm.rank, comm.size)
+        # the sharded code path (split graphs around the all-gather) even for ONE rank:
+        # lets a 1-GPU box run everything but the multi-process part (tests)
+        self.sharded = comm.size > 1 or os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") == "1"
         self.nloc = self.hi - self.lo
         ctx = self.ctx
         self.coords = ctx.empty((self.N * self.ndim,))
@@ -157,7 +162,7 @@ class DeviceLoop:
             ctx._plan = None
             ctx._accept_hook = None
             ctx.flush()  # a held-back launch nobody consumed
-        if self.s.comm.size > 1:
+        if self.sharded:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses
             if total.ptr != self.mylp.ptr:  # (the fused likelihood wrote it there itself)
@@ -174,7 +179,7 @@ class DeviceLoop:
             return
         if self.new_blobs is None:
             self.new_blobs = [self.ctx.empty((self.nloc, m)) for _, m, _, _ in self.cur_blobs]
-            if self.s.comm.size > 1:  # every rank keeps every walker's blobs
+            if self.sharded:  # every rank keeps every walker's blobs
                 self.all_blobs = [self.ctx.empty((self.ns, m)) for _, m, _, _ in self.cur_blobs]
         for nb, (cur, m, _, _), b in zip(self.new_blobs, self.cur_blobs, blobs):
             own, ptr, mb, _, _ = self._blob_dense(b)
@@ -193,7 +198,7 @@ class DeviceLoop:
             ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
                      self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
         if self.s.store_blobs and self.cur_blobs:
-            if self.s.comm.size > 1:
+            if self.sharded:
                 for ab, (cur, m, _, _) in zip(self.all_blobs, self.cur_blobs):
                     ctx.call("nh_scatter_rows", cur, m, ab, m, self.sel, self.accepted, 0,
                              self.ns, m)
@@ -263,7 +268,7 @@ class DeviceLoop:
         ctx.pin_caches()
         self._plan = plan
         self._front_args = (pk, len(packs), kind, rows_ptr, gd, len(grids), mm, len(moments))
-        if self.s.comm.size == 1:
+        if not self.sharded:
             self._hook = dict(N=self.nloc, used=False, total=None,
                               mv=nh_accept(self.coords.ptr, self.logp.ptr, self.blk.ptr,
                                            self.cursor.ptr, self.ns, self.ndim, self.lo, 0,
@@ -278,7 +283,7 @@ class DeviceLoop:
 
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
-        if self.s.comm.size > 1:
+        if self.sharded:
             self.s.comm.allgather_device(self.ctx, self.mylp.ptr, self.newlp, self.nloc)
             if self.s.store_blobs and self.cur_blobs:
                 # blobs of the proposals follow their log-probabilities: the walker a rank
@@ -301,7 +306,7 @@ class DeviceLoop:
         lo, hi = shard_bounds(self.N, s.comm.rank, s.comm.size)
         qT = ctx.array(np.ascontiguousarray(coords_host[lo:hi].T))
         total, blobs = self._eval(qT, hi - lo)
-        if s.comm.size > 1:
+        if self.sharded:
             s.comm.allgather_device(ctx, total.ptr, self.logp, hi - lo)
         else:
             ctx.call("nh_copy", self.logp, total.ptr, 8 * self.N)
@@ -311,7 +316,7 @@ class DeviceLoop:
             for b in blobs:
                 own, ptr, m, unit, trail = self._blob_dense(b)
                 cur = ctx.empty((self.N, m))
-                if s.comm.size > 1:
+                if self.sharded:
                     s.comm.allgather_device(ctx, ptr, cur, (hi - lo) * m)
                 else:
                     ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
@@ -418,7 +423,7 @@ class DeviceLoop:
         the per-half-step capture check, BOTH half-steps are one graph (the cursor
         advances inside it), i.e. one host call per step."""
         s, ctx = self.s, self.ctx
-        if s.comm.size > 1 or not s.use_graph:
+        if self.sharded or not s.use_graph:
             self._run_half_step()
             self._run_half_step()
             return
@@ -445,7 +450,7 @@ class DeviceLoop:
         graph on a single GPU; with walkers sharded over ranks the collective sits
         between two graphs (evaluate | all-gather | accept)."""
         s, ctx = self.s, self.ctx
-        multi = s.comm.size > 1
+        multi = self.sharded
         if self.graph is not None:
             ctx.graph_launch(self.graph)
             if multi:

@@ -147,7 +147,8 @@ class RcclComm:
 
 def from_env(prefer="rccl"):
     """LocalComm for a single process, else RCCL (GPU) or gloo (CPU tests)"""
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and \
+            os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") != "1":
         return LocalComm()
     if prefer != "rccl":
         return GlooComm()

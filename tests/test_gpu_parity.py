@@ -415,6 +415,36 @@ def test_rccl_communicator_after_torch_import(na):
     assert "captured + replayed ok: True" in out.stdout
 
 
+def test_sharded_path_with_rccl_on_one_rank(na, golden, tmp_path):
+    """everything of the multi-GPU loop except the second process: torch.distributed
+    rendezvous, RCCL communicator, split graphs with the all-gathers between them, the
+    likelihood written into the send buffer, accept after the exchange, gathered blobs --
+    with a one-rank communicator, against the ordinary single-GPU loop"""
+    import subprocess
+    import sys
+    from naima_amd.sampler import EnsembleSampler
+    from bench import build_problem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests",
+                                                       "gpu_sharded_one_rank_worker.py"),
+                          str(tmp_path)], cwd=root, env=env, timeout=600, capture_output=True,
+                         text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    model, p0, raw, data, prior, labels = build_problem("cfg3", na)
+    s = EnsembleSampler(64, 5, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                        store_blobs=True, device=True)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((64, 5)))
+    st = s.run_mcmc(pos, 4)
+    st = s.run_mcmc(st, 40)
+    assert_allclose(np.load(tmp_path / "chain.npy"), s.get_chain(), rtol=1e-9)
+    assert_allclose(np.load(tmp_path / "logp.npy"), s.get_log_prob(), rtol=1e-7)
+    blobs = s.get_blobs()
+    assert_allclose(np.load(tmp_path / "blob0.npy"), np.asarray(blobs[0]), rtol=1e-9, atol=1e-300)
+    assert_allclose(np.load(tmp_path / "blob1.npy"), np.asarray(blobs[1]), rtol=1e-9)
+
+
 def test_abi_move_kernels(na):
     """nh_move_propose / nh_move_accept / nh_scatter_rows against their NumPy twins, on
     the second slice of a two-half-step block (cursor = 1)"""
