@@ -69,6 +69,12 @@ class DeviceLoop:
         # the sharded code path (split graphs around the all-gather) even for ONE rank:
         # lets a 1-GPU box run everything but the multi-process part (tests)
         self.sharded = comm.size > 1 or os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") == "1"
+        # opt-in: capture the all-gather INTO the step graphs (RCCL supports stream capture;
+        # verified here with a one-rank communicator only, hence not the default): the
+        # sharded loop then replays whole steps like the single-GPU loop
+        self.coll_in_graph = self.sharded and getattr(comm, "in_stream", False) and \
+            os.environ.get("NAIMA_AMD_RCCL_IN_GRAPH", "0") == "1"
+        self.split = self.sharded and not self.coll_in_graph  # collective between two graphs
         self.nloc = self.hi - self.lo
         ctx = self.ctx
         self.coords = ctx.empty((self.N * self.ndim,))
@@ -423,7 +429,7 @@ class DeviceLoop:
         the per-half-step capture check, BOTH half-steps are one graph (the cursor
         advances inside it), i.e. one host call per step."""
         s, ctx = self.s, self.ctx
-        if self.sharded or not s.use_graph:
+        if self.split or not s.use_graph:
             self._run_half_step()
             self._run_half_step()
             return
@@ -450,7 +456,7 @@ class DeviceLoop:
         graph on a single GPU; with walkers sharded over ranks the collective sits
         between two graphs (evaluate | all-gather | accept)."""
         s, ctx = self.s, self.ctx
-        multi = self.sharded
+        multi = self.split
         if self.graph is not None:
             ctx.graph_launch(self.graph)
             if multi:

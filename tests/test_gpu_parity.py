@@ -415,18 +415,20 @@ def test_rccl_communicator_after_torch_import(na):
     assert "captured + replayed ok: True" in out.stdout
 
 
-def test_sharded_path_with_rccl_on_one_rank(na, golden, tmp_path):
+@pytest.mark.parametrize("in_graph", ["0", "1"])
+def test_sharded_path_with_rccl_on_one_rank(na, golden, tmp_path, in_graph):
     """everything of the multi-GPU loop except the second process: torch.distributed
     rendezvous, RCCL communicator, split graphs with the all-gathers between them, the
     likelihood written into the send buffer, accept after the exchange, gathered blobs --
-    with a one-rank communicator, against the ordinary single-GPU loop"""
+    with a one-rank communicator, against the ordinary single-GPU loop.  in_graph = 1: the
+    opt-in variant with the all-gathers captured into the step graphs."""
     import subprocess
     import sys
     from naima_amd.sampler import EnsembleSampler
     from bench import build_problem
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90),
-               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", NAIMA_AMD_RCCL_IN_GRAPH=in_graph)
     out = subprocess.run([sys.executable, os.path.join(root, "tests",
                                                        "gpu_sharded_one_rank_worker.py"),
                           str(tmp_path)], cwd=root, env=env, timeout=600, capture_output=True,
