@@ -36,12 +36,14 @@ class DeviceState:
     @property
     def coords(self):
         if self._c is None:
+            self._loop._flush_pending()
             self._c = self._loop.coords.get().reshape(self._loop.N, self._loop.ndim)
         return self._c
 
     @property
     def log_prob(self):
         if self._l is None:
+            self._loop._flush_pending()
             self._l = self._loop.logp.get()
         return self._l
 
@@ -109,6 +111,8 @@ class DeviceLoop:
         self.all_blobs = None
         self.ident = ctx.array(np.arange(max(self.nloc, 1), dtype=np.int32), dtype=np.int32)
         self.graph2 = None
+        self.graph21 = None
+        self._pending = False
         self.step_graph = None
         self._markers = [ctx.marker() for _ in range(4)]
         self._inflight = []
@@ -368,6 +372,7 @@ class DeviceLoop:
         moves = s.moves(pinned=True)
         it = 0
         while it < iterations:
+            self._flush_pending()  # (merged sharded mode) the block's last accept
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the
             # generator's page-locked ring (filled ahead by its worker thread) ----------
             while len(self._inflight) >= 2:  # ring depth 4: keep <= 3 blocks in play
@@ -396,7 +401,17 @@ class DeviceLoop:
                         self.multi_graph = self._capture(
                             lambda: [self._half_step_body() for _ in range(2 * self.GSTEPS)])
                     ctx.graph_launch(self.multi_graph)
+                elif (self.split and self.graph2 is not None and self.fused and
+                        yield_every >= 2 and (block is None or dev_hist) and
+                        not (block is not None and block["blobs"])):
+                    # sharded, nobody looks at the intermediate states: the accept of a
+                    # half-step and the evaluation of the next are ONE graph, with the
+                    # all-gather between two such graphs (two host calls per half-step
+                    # instead of three)
+                    self._run_half_step_merged()
+                    self._run_half_step_merged()
                 else:
+                    self._flush_pending()
                     self._run_step()
                 k += g
                 it += g
@@ -410,7 +425,26 @@ class DeviceLoop:
                     for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
                         ctx.call("nh_copy", hb.ptr + 8 * kk * N * m, cur, 8 * N * m)
                     block["n"] = kk + g
+                if yield_every < 2:
+                    self._flush_pending()
                 yield DeviceState(self, rng)
+        self._flush_pending()
+
+    def _run_half_step_merged(self):
+        ctx = self.ctx
+        if self._pending:
+            if self.graph21 is None:
+                self.graph21 = self._capture(lambda: (self._part_accept(), self._part_evaluate()))
+            ctx.graph_launch(self.graph21)  # accept + next proposal + evaluation
+        else:
+            ctx.graph_launch(self.graph)    # evaluation (the proposal is already there)
+        self._exchange()
+        self._pending = True
+
+    def _flush_pending(self):
+        if self._pending:
+            self.ctx.graph_launch(self.graph2)
+            self._pending = False
 
     def _capture(self, fn):
         ctx = self.ctx
@@ -485,6 +519,7 @@ class DeviceLoop:
 
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""
+        self._flush_pending()
         s = self.s
         for block in self.hist:
             n = block["n"]

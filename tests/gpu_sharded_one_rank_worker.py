@@ -33,3 +33,14 @@ np.save(os.path.join(out, "logp.npy"), s.get_log_prob())
 blobs = s.get_blobs()
 np.save(os.path.join(out, "blob0.npy"), np.asarray(blobs[0]))
 np.save(os.path.join(out, "blob1.npy"), np.asarray(blobs[1]))
+
+# without blobs run_mcmc takes the merged form: accept of a half-step + evaluation of the
+# next as one graph, the all-gather between two such graphs
+s2 = EnsembleSampler(64, 5, na.lnprob, args=[data, model, prior], seed=42, comm=comm,
+                     naima_style=True, store_blobs=False, device=True)
+st2 = s2.run_mcmc(pos, 4)
+st2 = s2.run_mcmc(st2, 70)
+if not s2._dev.coll_in_graph:
+    assert s2._dev.graph21 is not None and not s2._dev._pending
+np.save(os.path.join(out, "chain_noblobs.npy"), s2.get_chain())
+np.save(os.path.join(out, "final_noblobs.npy"), st2.coords)

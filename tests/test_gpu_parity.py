@@ -445,6 +445,12 @@ def test_sharded_path_with_rccl_on_one_rank(na, golden, tmp_path, in_graph):
     blobs = s.get_blobs()
     assert_allclose(np.load(tmp_path / "blob0.npy"), np.asarray(blobs[0]), rtol=1e-9, atol=1e-300)
     assert_allclose(np.load(tmp_path / "blob1.npy"), np.asarray(blobs[1]), rtol=1e-9)
+    s2 = EnsembleSampler(64, 5, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                         store_blobs=False, device=True)
+    st2 = s2.run_mcmc(pos, 4)
+    st2 = s2.run_mcmc(st2, 70)
+    assert_allclose(np.load(tmp_path / "chain_noblobs.npy"), s2.get_chain(), rtol=1e-9)
+    assert_allclose(np.load(tmp_path / "final_noblobs.npy"), st2.coords, rtol=1e-9)
 
 
 def test_abi_move_kernels(na):
