@@ -573,13 +573,12 @@ __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
       double v = z.a;
       if (z.base) v = nh_lazy_apply(z, qs[(z.base - A.qT) / A.nloc]);
       A.pk[q].out[(long long)j * A.pk[q].ld + col] = v;
-      if (A.pk[q].out == A.params) row[col] = v;
+      if (A.pk[q].out == A.params) {
+        row[col] = v;
+        // ln e_0, ln e_cutoff, ln e_break by the threads that hold those columns
+        if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
+      }
     }
-  }
-  __syncthreads();
-  if (tid < 3) {
-    const double v = row[tid == 0 ? 1 : (tid == 1 ? 3 : 5)];
-    lg[tid] = v > 0.0 ? log(v) : 0.0;
   }
   __syncthreads();
   // ---- particle weights on every grid ---------------------------------------------
