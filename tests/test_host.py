@@ -206,3 +206,20 @@ def test_batched_nelder_mead_follows_the_sequential_algorithm():
         assert np.array_equal(a["x"], b["x"])
         assert (a["nfev"], a["nit"], a["status"]) == (b["nfev"], b["nit"], b["status"])
         assert a["fun"] == b["fun"]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/naima_hip.h is the drop-in boundary: it must compile as C99 (and C++) on
+    its own -- plain pointers and sizes, no C++ or torch types"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "naima_hip.h"\nint main(void) { return NH_MAX_GRIDS > 0 ? 0 : 1; }\n')
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, "-c", str(src), "-o",
+                           str(tmp_path / "t.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-I", inc, "-x", "c++", "-c", str(src), "-o",
+                           str(tmp_path / "t2.o")])
