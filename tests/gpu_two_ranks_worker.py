@@ -27,3 +27,12 @@ np.save(os.path.join(out, "blob0_%d.npy" % comm.rank), np.asarray(blobs[0]))
 np.save(os.path.join(out, "blob1_%d.npy" % comm.rank), np.asarray(blobs[1]))
 assert s._dev.graph is not None and s._dev.graph2 is not None
 assert s.n_walker_evals < 32 * 7  # each rank evaluated only its shard
+
+# without blobs run_mcmc takes the merged form of the sharded loop (accept + next evaluation
+# as one graph between all-gathers)
+s2 = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, comm=comm,
+                     naima_style=True, store_blobs=False, device=True)
+st2 = s2.run_mcmc(pos, 3)
+st2 = s2.run_mcmc(st2, 37)
+assert s2._dev.graph21 is not None and not s2._dev._pending
+np.save(os.path.join(out, "chain_noblobs_%d.npy" % comm.rank), s2.get_chain())

@@ -700,6 +700,12 @@ def test_device_loop_two_ranks_one_gpu(na, golden, tmp_path):
         assert_allclose(np.load(tmp_path / ("blob0_%d.npy" % r)), np.asarray(blobs[0]),
                         rtol=1e-9, atol=1e-300)
         assert_allclose(np.load(tmp_path / ("blob1_%d.npy" % r)), np.asarray(blobs[1]), rtol=1e-9)
+    s2 = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                         store_blobs=False, device=True)
+    st2 = s2.run_mcmc(pos, 3)
+    st2 = s2.run_mcmc(st2, 37)
+    for r in (0, 1):
+        assert_allclose(np.load(tmp_path / ("chain_noblobs_%d.npy" % r)), s2.get_chain(), rtol=1e-9)
 
 
 def test_edge_shapes_against_oracle(na):
