@@ -165,6 +165,7 @@ __device__ __forceinline__ void nh_lnprob64_prefetch_c(nh_lnprob_pre& P, const n
     P.cpa = mv.coords[(long long)P.pa * mv.ndim + lane];
     P.cme = mv.coords[(long long)P.me * mv.ndim + lane];
   }
+  P.mlnu -= (mv.ndim - 1.0) * log(P.mz);  // ln U' - (ndim-1) ln z: off the epilogue's path
 }
 
 __device__ __forceinline__ void nh_lnprob64_finish(const nh_lnprob_args& A, const nh_lnprob_pre& P,
@@ -206,8 +207,7 @@ __device__ __forceinline__ void nh_lnprob64_finish(const nh_lnprob_args& A, cons
   }
   if (mv.coords) {
     acc = __shfl(acc, 0, 64);
-    const double d = (mv.ndim - 1.0) * log(P.mz) + acc - P.mold;
-    const bool ok = P.mlnu < d;
+    const bool ok = P.mlnu < acc - P.mold;  // ln U' < (ndim-1) ln z + lnp(q) - lnp(s)
     if (ok && lane < mv.ndim)
       mv.coords[(long long)P.me * mv.ndim + lane] = P.cpa - (P.cpa - P.cme) * P.mz;
     if (lane == 0) {
