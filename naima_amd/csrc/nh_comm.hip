@@ -3,6 +3,8 @@
 // dlopen()ed on first use so that single-GPU users never load it.
 #include <dlfcn.h>
 
+#include <strings.h>
+
 #include <cstdlib>
 #include <string>
 #include <rccl/rccl.h>
@@ -25,6 +27,10 @@ static rccl_api g_rccl;
 
 static int rccl_load() {
   if (g_rccl.lib) return NH_OK;
+  // NCCL_DEBUG=VERSION makes RCCL write a banner to STDOUT (where a caller may owe someone
+  // exactly one line of output); real debug levels are left alone
+  if (const char* dbg = getenv("NCCL_DEBUG"))
+    if (strcasecmp(dbg, "VERSION") == 0) unsetenv("NCCL_DEBUG");
   // The RCCL that belongs to the HIP runtime THIS library is linked against, by absolute
   // path.  A process that has imported PyTorch (torch.distributed hands the unique id
   // around) already holds PyTorch's own bundled librccl.so.1 -- bound to PyTorch's own
