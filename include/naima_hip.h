@@ -329,6 +329,20 @@ int nh_synchrotron_lnprob(nh_ctx* ctx, const double* w, const double* dlw, const
                           const double* err_hi, const int* ul, const double* cl,
                           const double* lp, const nh_prior* terms /*host*/, int nterms,
                           double* total, const nh_accept* mv /*host or NULL*/);
+
+/* the same for a table reduction that is the last producer (pi0 decay, a single-seed IC
+ * model): nh_integrate_tables (one plane) whose workgroups finish their walkers' nh_lnprob
+ * (+ accept when mv != NULL).  The spectrum has nK energies; comps[loc_comp] must be this
+ * launch's output.  Shapes that cannot carry the epilogue (more than 64 columns, ...) are
+ * run as the two launches. */
+int nh_integrate_tables_lnprob(nh_ctx* ctx, const double* w, const double* dlw, int N, int nG,
+                               const double* lx, const double* Kt, const double* dlnKt, int nK,
+                               const double* scale, double* out, int ldo, int nonnegative,
+                               const nh_comp* comps /*host*/, int ncomp, int loc_comp,
+                               const double* conv, const double* flux, const double* err_lo,
+                               const double* err_hi, const int* ul, const double* cl,
+                               const double* lp, const nh_prior* terms /*host*/, int nterms,
+                               double* total, const nh_accept* mv /*host or NULL*/);
 /* dst[idx[lo+j]][0:m] = src[j][0:m] where accepted[lo+j] (accepted NULL = all) */
 int nh_scatter_rows(nh_ctx* ctx, double* dst, int ldd, const double* src, int lds,
                     const int* idx, const int* accepted, int lo, int nloc, int m);

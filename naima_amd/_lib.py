@@ -74,6 +74,9 @@ _SIGS = {
     "nh_pion_kelner06": [_dp, _i, _dp, _i, _dp, _i, _d, _i, _dp, _i, _dp, _dp],
     "nh_synchrotron_lnprob": [_dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _i,
                               _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
+    "nh_integrate_tables_lnprob": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _i,
+                                   _dp, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp,
+                                   _dp],
     "nh_lnprob_accept": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp,
                          _dp],
     "nh_scatter_rows": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _i, _i],

@@ -188,6 +188,15 @@ def lnprobmodel(model, data, lp=None):
                 ctx._deferred = [a for a in ctx._deferred if a is not o]
                 ctx.call("nh_synchrotron_lnprob", *sa, args[0], args[1], j, *args[4:13],
                          total, mv)
+            elif o is not None and o.pending[0] == "nh_integrate_tables" \
+                    and m.terms[j][1] == o.ptr and m.terms[j][2] == nE \
+                    and o.pending[1][7] == nE:
+                # ... or on a held-back table reduction that is the whole spectrum
+                ia = o.pending[1][:12]  # without nsplit (one plane)
+                o.pending = None
+                ctx._deferred = [a for a in ctx._deferred if a is not o]
+                ctx.call("nh_integrate_tables_lnprob", *ia, args[0], args[1], j, *args[4:13],
+                         total, mv)
             else:
                 ctx.flush(*owners)
                 if mv is not None:

@@ -2,6 +2,7 @@
 // per-walker table reduction, lnprobmodel and the stretch-move kernels.
 // gfx950 (MI355X) only; FP64 throughout, denormals on, no fast-math.
 #include "nh_common.h"
+#include "nh_lnprob.h"
 #include <cstdlib>
 
 static thread_local char g_err[512] = "";
@@ -774,12 +775,15 @@ extern "C" int nh_grid_logratio(nh_ctx* c, const double* xg, int nG, double* lx)
 // HBM / Infinity Cache, not in this XCD's L2: read through the scalar cache inside the
 // loop, every new 64-byte line was a serialized ~1 us miss (measured: +3 us per launch
 // inside the step loop against a warm micro-benchmark).
-template <int C, int W, bool SIGNED, bool STG>
+// EPI (one tile, nsplit = 1: the block holds its walkers' complete spectra): waves 0..W-1 go
+// on to evaluate the likelihood (+ priors, + accept) of walker w0 + wave, nh_lnprob.h, as
+// the synchrotron kernel does when it is the last producer.
+template <int C, int W, bool SIGNED, bool STG, bool EPI = false>
 __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     const double* __restrict__ w, const double* __restrict__ dlw, int N, int nG,
     const double* __restrict__ lx, const double* __restrict__ Kt,
     const double* __restrict__ dlnKt, int nK, const double* __restrict__ scale,
-    double* __restrict__ out, int ldo, int nsplit) {
+    double* __restrict__ out, int ldo, int nsplit, nh_lnprob_args L, int loc_comp) {
   __shared__ double part[C][W][64];
   extern __shared__ double stg[];  // [W][nG] w | [W][nG] dlw   (STG only)
   const int lane = threadIdx.x & 63;
@@ -793,6 +797,9 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
   const bool kvalid = k < nK;
   const unsigned kk = kvalid ? (unsigned)k : (unsigned)(nK - 1);
   const int w0 = grp * W;
+  nh_lnprob_pre PRE = {};
+  const bool epw = EPI && ch < W && w0 + ch < N;  // this wave runs walker w0 + ch's epilogue
+  if (epw) nh_lnprob64_prefetch_a(PRE, L, w0 + ch, lane, loc_comp);
   const int nseg = nG - 1;
   const int hper = (nseg + nsplit - 1) / nsplit;
   const int hs0 = h * hper, hs1 = min(nseg, hs0 + hper);
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
     for (int j = 0; j < W; ++j) row[j] = (unsigned)(j * nG);
     __syncthreads();
   }
+  if (epw) nh_lnprob64_prefetch_b(PRE, L, w0 + ch);
   if (s0 < s1) {
     // table rows through buffer descriptors: base in SGPRs + one 32-bit byte offset per
     // lane (a single v_add per load instead of 64-bit address arithmetic)
@@ -872,18 +880,25 @@ __global__ __launch_bounds__(64 * C) void k_integrate_tables(
   }
 #pragma unroll
   for (int j = 0; j < W; ++j) part[ch][j][lane] = acc[j];
+  if (epw) nh_lnprob64_prefetch_c(PRE, L, lane);
   __syncthreads();
-  if (ch == 0 && kvalid) {
-    const double sc = scale ? scale[k] : 1.0;
+  if (ch == 0) {
+    const double sc = (scale && kvalid) ? scale[k] : 1.0;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       if (w0 + j < N) {
         double sum = 0.0;
 #pragma unroll
         for (int c2 = 0; c2 < C; ++c2) sum += part[c2][j][lane];
-        out[((long long)h * N + (w0 + j)) * ldo + k] = sum * sc;
+        sum *= sc;
+        if (kvalid) out[((long long)h * N + (w0 + j)) * ldo + k] = sum;
+        if (EPI) part[0][j][lane] = sum;  // (each lane overwrites only what it has read)
       }
     }
+  }
+  if (EPI) {
+    __syncthreads();
+    if (epw) nh_lnprob64_finish(L, PRE, w0 + ch, lane, &part[0][ch][0], loc_comp);
   }
 }
 
@@ -923,10 +938,14 @@ extern "C" int nh_integrate_tables_nsplit(int N, int nG, int nK) {
   return (blocks > 256 && blocks < 512) ? 2 : 1;
 }
 
-extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
-                                   const double* lx, const double* Kt, const double* dlnKt,
-                                   int nK, const double* scale, double* out, int ldo,
-                                   int nonnegative, int nsplit) {
+// L != NULL asks for the likelihood epilogue; *fused says whether this launch could carry it
+// (one tile, one plane, staged rows, at most two walkers per thread) -- if not, the caller
+// launches the likelihood itself
+static int integrate_impl(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
+                          const double* lx, const double* Kt, const double* dlnKt, int nK,
+                          const double* scale, double* out, int ldo, int nonnegative, int nsplit,
+                          const nh_lnprob_args* L, int loc_comp, bool* fused) {
+  if (fused) *fused = false;
   NH_REQUIRE(c && w && dlw && lx && Kt && dlnKt && out, "NULL pointer");
   NH_REQUIRE(N >= 0 && nG >= 2 && nK >= 1 && ldo >= nK, "bad sizes");
   NH_REQUIRE(nsplit >= 1 && nsplit <= 8, "nsplit must be 1..8");
@@ -961,10 +980,29 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
   if (const char* e = getenv("NH_INT_C")) C = atoi(e);
   const size_t stg_bytes = 2 * (size_t)W * nG * sizeof(double);
   const bool stage = stg_bytes <= 48 * 1024;
+  nh_lnprob_args none = {};
+  const nh_lnprob_args& LA = L ? *L : none;
+  const bool epi = L && stage && nsplit == 1 && ktiles == 1 && W <= 2 && (C == 16 || C == 8);
+  if (fused) *fused = epi;
 #define NH_LAUNCH_INT_T(CC, WW, SS, TT)                                                      \
   hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS, TT>), dim3(blocks), dim3(64 * CC),      \
                      TT ? stg_bytes : 0, c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, \
-                     out, ldo, nsplit)
+                     out, ldo, nsplit, LA, loc_comp)
+#define NH_LAUNCH_INT_E(CC, WW, SS)                                                          \
+  hipLaunchKernelGGL((k_integrate_tables<CC, WW, SS, true, true>), dim3(blocks),             \
+                     dim3(64 * CC), stg_bytes, c->stream, w, dlw, N, nG, lx, Kt, dlnKt, nK,  \
+                     scale, out, ldo, nsplit, LA, loc_comp)
+  if (epi) {
+    if (C == 16) {
+      if (W == 2) { if (nonnegative) NH_LAUNCH_INT_E(16, 2, false); else NH_LAUNCH_INT_E(16, 2, true); }
+      else { if (nonnegative) NH_LAUNCH_INT_E(16, 1, false); else NH_LAUNCH_INT_E(16, 1, true); }
+    } else {
+      if (W == 2) { if (nonnegative) NH_LAUNCH_INT_E(8, 2, false); else NH_LAUNCH_INT_E(8, 2, true); }
+      else { if (nonnegative) NH_LAUNCH_INT_E(8, 1, false); else NH_LAUNCH_INT_E(8, 1, true); }
+    }
+    NH_CHECK_HIP(hipGetLastError());
+    return NH_OK;
+  }
 #define NH_LAUNCH_INT_S(CC, WW, SS) \
   do { if (stage) NH_LAUNCH_INT_T(CC, WW, SS, true); else NH_LAUNCH_INT_T(CC, WW, SS, false); } while (0)
 #define NH_LAUNCH_INT(CC, WW) \
@@ -982,15 +1020,22 @@ extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw
 #undef NH_LAUNCH_INT
 #undef NH_LAUNCH_INT_S
 #undef NH_LAUNCH_INT_T
+#undef NH_LAUNCH_INT_E
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
+}
+
+extern "C" int nh_integrate_tables(nh_ctx* c, const double* w, const double* dlw, int N, int nG,
+                                   const double* lx, const double* Kt, const double* dlnKt,
+                                   int nK, const double* scale, double* out, int ldo,
+                                   int nonnegative, int nsplit) {
+  return integrate_impl(c, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo, nonnegative,
+                        nsplit, nullptr, -1, nullptr);
 }
 
 // ---------------------------------------------------------------------------
 // row 11: lnprobmodel (core.py:64-94), one wave per walker
 // ---------------------------------------------------------------------------
-#include "nh_lnprob.h"
-
 __global__ __launch_bounds__(256) void k_lnprobmodel(nh_lnprob_args A) {
   const int lane = threadIdx.x & 63;
   const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1069,6 +1114,42 @@ extern "C" int nh_lnprob_accept(nh_ctx* c, const nh_comp* comps, int ncomp, int 
   }
   return launch_lnprob(c, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms,
                        model_out, total, mv);
+}
+
+extern "C" int nh_integrate_tables_lnprob(
+    nh_ctx* c, const double* w, const double* dlw, int N, int nG, const double* lx,
+    const double* Kt, const double* dlnKt, int nK, const double* scale, double* out, int ldo,
+    int nonnegative, const nh_comp* comps, int ncomp, int loc_comp, const double* conv,
+    const double* flux, const double* err_lo, const double* err_hi, const int* ul,
+    const double* cl, const double* lp, const nh_prior* terms, int nterms, double* total,
+    const nh_accept* mv) {
+  NH_REQUIRE(c && comps && conv && flux && err_lo && err_hi && ul && cl && total, "NULL pointer");
+  NH_REQUIRE(ncomp >= 1 && ncomp <= NH_MAX_COMP && loc_comp >= 0 && loc_comp < ncomp,
+             "bad components");
+  NH_REQUIRE(nterms >= 0 && nterms <= NH_MAX_PRIOR && (nterms == 0 || terms), "bad prior terms");
+  NH_REQUIRE(comps[loc_comp].ptr == out && comps[loc_comp].ld == ldo,
+             "component loc_comp must be this launch's output");
+  if (mv) {
+    NH_REQUIRE(mv->coords && mv->logp && mv->blk && mv->cursor && mv->accepted &&
+                   mv->ns >= 1 && mv->ndim >= 1 && mv->ndim <= 64 && mv->lo >= 0 &&
+                   mv->lo + N <= mv->ns, "bad accept block");
+  }
+  nh_comps cs;
+  cs.n = ncomp;
+  for (int j = 0; j < ncomp; ++j) {
+    NH_REQUIRE(comps[j].ptr && comps[j].ld >= nK, "bad component");
+    cs.c[j] = comps[j];
+  }
+  nh_lnprob_args A;
+  nh_lnprob_fill(A, cs, N, nK, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, nullptr,
+                 total, mv);
+  bool fused = false;
+  int rc = integrate_impl(c, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo, nonnegative, 1,
+                          nK <= 64 ? &A : nullptr, loc_comp, &fused);
+  if (rc || fused || N == 0) return rc;
+  // this shape cannot carry the epilogue (several tiles, very long grids ...): two launches
+  return launch_lnprob(c, cs, N, nK, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms,
+                       nullptr, total, mv);
 }
 
 // ---------------------------------------------------------------------------

@@ -264,6 +264,18 @@ class BaseRadiative:
         ctx.need(hit[0])
         return ctx, N, hit[0], hit[1], xd, lx
 
+    @staticmethod
+    def _integrate_or_defer(ctx, out, args, N, nK):
+        """launch nh_integrate_tables(*args) -- or, inside the device step loop when this
+        is a one-plane reduction of at most 64 columns and nothing else is held back, hold
+        it back so that the likelihood can ride on it (nh_integrate_tables_lnprob)"""
+        hook = ctx._accept_hook
+        if hook is not None and not hook["used"] and hook["N"] == N and nK <= 64 \
+                and args[-1] == 1 and not ctx._deferred:
+            ctx.defer(out, "nh_integrate_tables", args)
+        else:
+            ctx.call("nh_integrate_tables", *args)
+
     def _weights_table(self, pd, xg, e_eV, unit_scale):
         """weights of a TableModel distribution: amplitude[w] times a walker-independent
         shape on the grid (host spline once, cached in HBM); rows by nh_lincomb"""
@@ -753,8 +765,8 @@ class InverseCompton(BaseElectron):
             ns = _lib_mod._lib.nh_integrate_tables_nsplit(N, nG, nK)
             out = ctx.empty((ns * N, nK))
             # IC kernels are >= 0; a user-supplied array seed is validated positive
-            ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
-                     out, nK, 1, ns)
+            self._integrate_or_defer(ctx, out, (w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
+                                                out, nK, 1, ns), N, nK)
             if dev:
                 for j, name in enumerate(static):
                     specs[name] = DMat(ctx, [(out, out.ptr + 8 * (h * N * nK + j * nE), nK, 1.0)
@@ -1080,8 +1092,8 @@ class PionDecay(BaseProton):
                              bool(self.nuclear_enhancement)), build)
         out = ctx.empty((N, nE))
         # the FITPACK look-up table rings below zero; the analytic form does not
-        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE,
-                 0 if use_lut else 1, 1)
+        self._integrate_or_defer(ctx, out, (w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE,
+                                            0 if use_lut else 1, 1), N, nE)
         nh = self.nh.to("1/cm3").value
         fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
         if _per_walker(self.nh):
