@@ -620,6 +620,93 @@ def test_abi_step_front_and_lnprob_accept(na):
     assert cursor.get()[0] == 2
 
 
+def test_abi_last_producer_epilogues(na):
+    """nh_synchrotron_lnprob and nh_integrate_tables_lnprob (the likelihood + accept as the
+    epilogue of the last producer) against the separate entry points on the same inputs"""
+    import ctypes as C
+    from naima_amd._lib import get_context
+    from naima_amd.constants import MEC2_EV
+    from naima_amd.darray import nh_accept, nh_comp
+    ctx = get_context()
+    rng = np.random.default_rng(8)
+    N, ndim, ns, nE = 12, 3, 12, 40
+    gam = np.logspace(3, 8.5, 150)
+    e_eV = gam * MEC2_EV
+    rows = np.zeros((N, 8))
+    rows[:, 0] = 10 ** rng.normal(33, 0.1, N)
+    rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 4] = 1e13, rng.uniform(2, 3, N), 5e13, 1.0
+    gd, ed, rd = ctx.array(gam), ctx.array(e_eV), ctx.array(rows)
+    w, dlw, lx = ctx.empty((N, gam.size)), ctx.empty((N, gam.size)), ctx.empty((gam.size - 1,))
+    ctx.call("nh_particle_weights", 1, rd, N, ed, gd, gam.size, MEC2_EV, w, dlw, None)
+    ctx.call("nh_grid_logratio", gd, gam.size, lx)
+    E = np.geomspace(1e2, 1e5, nE)
+    Ed, Bd = ctx.array(E), ctx.array(rng.uniform(5, 50, N) * 1e-6)
+    other = ctx.array(rng.random((N, nE)) * 1e20)
+    conv = ctx.array(np.ones(nE))
+    flux, err = ctx.array(rng.random(nE) * 1e21), ctx.array(np.full(nE, 3e20))
+    ulh = np.zeros(nE, dtype=np.int32)
+    ulh[-2:] = 1
+    ul, cl = ctx.array(ulh, dtype=np.int32), ctx.array(np.full(nE + 1, 0.9))
+    coords, logp = rng.normal(size=(2 * ns, ndim)), rng.normal(-50, 5, 2 * ns)
+    blk_h = np.zeros((1, 3 * ns))
+    perm = rng.permutation(2 * ns)
+    blk_h[0, :ns], blk_h[0, ns:2 * ns] = (rng.random(ns) + 1) ** 2 / 2, np.log(rng.random(ns))
+    iv = blk_h[:, 2 * ns:].view(np.int32)
+    iv[0, :ns], iv[0, ns:] = perm[:ns], perm[ns:][rng.integers(ns, size=ns)]
+    logp[perm[:ns:2]] = -1e300  # every other active walker accepts whatever comes
+    blk = ctx.array(blk_h)
+    cursor = ctx.array(np.zeros(1, dtype=np.int32), dtype=np.int32)
+
+    def state():
+        return (ctx.array(coords.ravel()), ctx.array(logp), ctx.empty((ns,), dtype=np.int32),
+                ctx.array(np.zeros(2 * ns, dtype=np.int32), dtype=np.int32),
+                ctx.empty((ns,), dtype=np.int32))
+
+    def mv_of(st):
+        return nh_accept(st[0].ptr, st[1].ptr, blk.ptr, cursor.ptr, ns, ndim, 0, 0, st[2].ptr,
+                         st[3].ptr, st[4].ptr)
+
+    def comps_of(out, scale):
+        c = (nh_comp * 2)()
+        c[0], c[1] = nh_comp(other.ptr, nE, 1.0), nh_comp(out.ptr, nE, scale)
+        return c
+
+    def same(a, b):
+        for x, y in zip(a, b):
+            assert_allclose(x.get(), y.get(), rtol=1e-13)
+
+    # ---- synchrotron -----------------------------------------------------------------
+    o1, o2, t1, t2 = ctx.empty((N, nE)), ctx.empty((N, nE)), ctx.empty((N,)), ctx.empty((N,))
+    s1, s2 = state(), state()
+    m1, m2 = mv_of(s1), mv_of(s2)
+    sa = (w, dlw, Bd, 1, N, gd, lx, gam.size, Ed, nE)
+    ctx.call("nh_synchrotron", *sa, o1, nE)
+    ctx.call("nh_lnprob_accept", comps_of(o1, 0.5), 2, N, nE, conv, flux, err, err, ul, cl, None,
+             None, 0, None, t1, C.addressof(m1))
+    ctx.call("nh_synchrotron_lnprob", *sa, o2, nE, comps_of(o2, 0.5), 2, 1, conv, flux, err, err,
+             ul, cl, None, None, 0, t2, C.addressof(m2))
+    assert_allclose(o2.get(), o1.get(), rtol=0)
+    assert_allclose(t2.get(), t1.get(), rtol=1e-12)
+    same(s1, s2)
+    assert 0 < s1[2].get().sum() <= ns
+    # ---- table reduction (one tile, one plane) ------------------------------------------
+    K = rng.random((gam.size, nE)) + 0.1
+    dK = np.zeros_like(K)
+    dK[:-1] = np.log(K[1:] / K[:-1])
+    Kt, dKt, sc = ctx.array(K), ctx.array(dK), ctx.array(rng.random(nE) + 0.5)
+    s1, s2 = state(), state()
+    m1, m2 = mv_of(s1), mv_of(s2)
+    ia = (w, dlw, N, gam.size, lx, Kt, dKt, nE, sc)
+    ctx.call("nh_integrate_tables", *ia, o1, nE, 1, 1)
+    ctx.call("nh_lnprob_accept", comps_of(o1, 2.0), 2, N, nE, conv, flux, err, err, ul, cl, None,
+             None, 0, None, t1, C.addressof(m1))
+    ctx.call("nh_integrate_tables_lnprob", *ia, o2, nE, 1, comps_of(o2, 2.0), 2, 1, conv, flux, err,
+             err, ul, cl, None, None, 0, t2, C.addressof(m2))
+    assert_allclose(o2.get(), o1.get(), rtol=0)
+    assert_allclose(t2.get(), t1.get(), rtol=1e-12)
+    same(s1, s2)
+
+
 def test_device_loop_front_kernel_history_and_multistep_graph(na, golden):
     """store_blobs=False: the loop runs on nh_step_front / nh_lnprob_accept, keeps the
     chain history on the device across block boundaries (32 steps) and replays eight
