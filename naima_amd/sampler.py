@@ -300,24 +300,32 @@ class EnsembleSampler:
 # naima's entry points (core.py:220-538)
 # --------------------------------------------------------------------------
 def _run_mcmc(sampler, pos, nrun, verbose=True):
-    """core.py:127-160 (progress printout every 5 %)"""
-    state = None
-    for i, state in enumerate(sampler.sample(pos, iterations=nrun, store=True)):
-        progress = 100.0 * float(i) / float(nrun)
-        if verbose and sampler.comm.rank == 0 and progress % 5 < (5.0 / float(nrun)):
-            print("\nProgress of the run: {0:.0f} percent ({1} of {2} steps)".format(
-                int(progress), i, nrun))
-            npars = state.coords.shape[-1]
-            print("                           " + (" ".join(
-                ["{%i:-^15}" % k for k in range(npars)])).format(*sampler.labels))
-            print("  Last ensemble median : " + (" ".join(
-                ["{%i:^15.3g}" % k for k in range(npars)])).format(
-                    *np.median(state.coords, axis=0)))
-            print("  Last ensemble std    : " + (" ".join(
-                ["{%i:^15.3g}" % k for k in range(npars)])).format(*np.std(state.coords, axis=0)))
-            print("  Last ensemble lnprob :  avg: {0:.3f}, max: {1:.3f}".format(
-                np.average(state.log_prob), np.max(state.log_prob)))
+    """core.py:127-160: the run with a progress printout every 5 %.  The steps between two
+    printouts are one ``run_mcmc`` call, so the device loop replays whole groups of steps
+    and the ensemble is only brought to the host for the printouts."""
+    state = pos
+    nrun = int(nrun)
+    edges = sorted(set(int(round(x)) for x in np.linspace(0, nrun, 21)))
+    for a, b in zip(edges[:-1], edges[1:]):
+        if verbose and sampler.comm.rank == 0 and a > 0:
+            _print_progress(sampler, state, a, nrun)
+        state = sampler.run_mcmc(state, b - a, store=True)
     return sampler, state
+
+
+def _print_progress(sampler, state, i, nrun):
+    print("\nProgress of the run: {0:.0f} percent ({1} of {2} steps)".format(
+        int(100.0 * i / nrun), i, nrun))
+    coords = np.asarray(state.coords)
+    npars = coords.shape[-1]
+    print("                           " + (" ".join(
+        ["{%i:-^15}" % k for k in range(npars)])).format(*sampler.labels))
+    print("  Last ensemble median : " + (" ".join(
+        ["{%i:^15.3g}" % k for k in range(npars)])).format(*np.median(coords, axis=0)))
+    print("  Last ensemble std    : " + (" ".join(
+        ["{%i:^15.3g}" % k for k in range(npars)])).format(*np.std(coords, axis=0)))
+    lp = np.asarray(state.log_prob)
+    print("  Last ensemble lnprob :  avg: {0:.3f}, max: {1:.3f}".format(np.average(lp), np.max(lp)))
 
 
 def _prefit(p0, data, model, prior):
@@ -351,10 +359,13 @@ def _prefit(p0, data, model, prior):
 
 def get_sampler(data_table=None, p0=None, model=None, prior=None, nwalkers=500, nburn=100,
                 guess=True, interactive=False, prefit=False, labels=None, threads=None,
-                data_sed=None, seed=None, comm=None, verbose=True, store_blobs=True):
+                data_sed=None, seed=None, comm=None, verbose=True, store_blobs=True,
+                device=True):
     """Generate a new MCMC sampler (signature of core.py:220-233; ``threads`` is
     accepted and ignored -- the walkers of a half-ensemble are one GPU batch;
-    ``interactive`` is out of scope).  Returns (sampler, state)."""
+    ``interactive`` is out of scope).  ``device=True`` (default): the ensemble and the step
+    loop live on the GPU (models that cannot keep their parameters in HBM fall back to the
+    host-driven loop with a warning).  Returns (sampler, state)."""
     from .core import lnprob, sed_conversion
     from .datatable import validate_data_table
     if data_table is None:
@@ -408,7 +419,8 @@ def get_sampler(data_table=None, p0=None, model=None, prior=None, nwalkers=500, 
         p0, P0_IS_ML = _prefit(p0, data, model, prior)
 
     sampler = EnsembleSampler(nwalkers, len(p0), lnprob, args=[data, model, prior], seed=seed,
-                              comm=comm, naima_style=True, store_blobs=store_blobs)
+                              comm=comm, naima_style=True, store_blobs=store_blobs,
+                              device=device)
     sampler.data_table = data_table
     sampler.data = data
     sampler.labels = labels
@@ -439,7 +451,10 @@ def run_sampler(nrun=100, sampler=None, pos=None, verbose=True, **kwargs):
         print("\nWalker burn in finished, running {0} steps...".format(nrun))
     sampler.reset()
     t0 = time.time()
-    sampler, pos = _run_mcmc(sampler, State(pos.coords if isinstance(pos, State) else pos),
-                             nrun, verbose)
+    if isinstance(pos, State):
+        pos = State(pos.coords)
+    elif not hasattr(pos, "_loop"):  # (a DeviceState continues from the ensemble in HBM)
+        pos = State(pos)
+    sampler, pos = _run_mcmc(sampler, pos, nrun, verbose)
     sampler.run_info["wall_s"] = time.time() - t0
     return sampler, pos

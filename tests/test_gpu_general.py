@@ -285,3 +285,28 @@ def test_trapz_loglog_intervals(na):
     assert_allclose(got.sum(axis=-1), trapz_loglog(y, x), rtol=1e-13)
     got0 = trapz_loglog(y.T, x, axis=0, intervals=True)
     assert_allclose(got0, ref.T, rtol=1e-12)
+
+
+def test_run_sampler_surface_on_the_device_loop(na, tmp_path):
+    """naima's workflow get_sampler -> run_sampler -> save_run/read_run (core.py:220-538,
+    analysis.py:366-471) with the ensemble on the GPU: prefit, burn-in, run, the attributes
+    naima's analysis reads, the host loop as cross-check"""
+    from bench import build_problem
+    model, p0, raw, data, prior, labels = build_problem("cfg3", na)
+    kw = dict(data_table=data, p0=p0, labels=labels, model=model, prior=prior, nwalkers=32,
+              nburn=6, nrun=20, prefit=True, seed=4, verbose=False)
+    s, pos = na.run_sampler(**kw)
+    assert s.device and s._dev is not None and s._dev.fused
+    assert s.get_chain().shape == (20, 32, 5) and s.get_log_prob().shape == (20, 32)
+    blobs = s.get_blobs()
+    assert np.shape(blobs[0]) == (20, 32, 64) and np.shape(blobs[1]) == (20, 32)
+    assert s.labels == list(labels) and s.run_info["n_walkers"] == 32
+    assert s.run_info["n_burn"] == 6 and s.run_info["n_run"] == 20
+    assert 0.1 < np.mean(s.acceptance_fraction) < 0.9
+    h, _ = na.run_sampler(device=False, **kw)
+    assert_allclose(s.get_chain(), h.get_chain(), rtol=1e-8)
+    assert_allclose(np.asarray(blobs[1]), np.asarray(h.get_blobs()[1]), rtol=1e-8)
+    na.save_run(str(tmp_path / "run"), s)
+    back = na.read_run(str(tmp_path / "run"))
+    assert np.array_equal(back.get_chain(), s.get_chain())
+    assert back.labels == s.labels
