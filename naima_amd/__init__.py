@@ -16,7 +16,7 @@ from .models import (BrokenPowerLaw, ExponentialCutoffBrokenPowerLaw,  # noqa: F
                      EblAbsorptionModel)
 from .radiative import (Bremsstrahlung, InverseCompton, PionDecay,  # noqa: F401
                         PionDecayKelner06, Synchrotron)
-from .analysis import read_run, save_run  # noqa: F401
+from .analysis import find_ML, read_run, save_results_table, save_run  # noqa: F401
 from .datatable import validate_data_table  # noqa: F401
 
 __version__ = "0.1.0"

@@ -9,7 +9,7 @@ import numpy as np
 from . import units as u
 from .datatable import DataTable
 
-__all__ = ["save_run", "read_run"]
+__all__ = ["save_run", "read_run", "save_results_table", "find_ML"]
 
 
 def save_run(filename, sampler, compression=True, clobber=False):
@@ -97,3 +97,80 @@ def read_run(filename):
     units = [None if s is None else u.Unit(s) for s in meta["blob_units"]]
     return _Result(z["mcmc/chain"], z["mcmc/log_prob"], blobs, units, data, meta["labels"],
                    meta["run_info"], meta["acceptance_fraction"])
+
+
+def find_ML(sampler):
+    """(max log-probability, its parameter vector): the most probable sample of the chain
+    (the first return values of analysis-time ``find_ML`` in the reference, which
+    ``save_results_table`` stores as ``MaxLogLikelihood`` / ``ML_pars``; no refit)"""
+    lp = np.asarray(sampler.get_log_prob())
+    chain = np.asarray(sampler.get_chain())
+    idx = np.unravel_index(np.argmax(lp), lp.shape)
+    return float(lp[idx]), chain[idx]
+
+
+def save_results_table(outname, sampler, convert_log=True, last_step=False, include_blobs=True,
+                       overwrite=False):
+    """Write ``<outname>_results.ecsv``: median and 16th/84th-percentile distances of every
+    parameter (plus the de-logged value for ``log10(x)`` / ``log(x)`` labels and every
+    scalar blob), with the run information, the most probable parameters and the BIC as
+    metadata (analysis.py:165-363 of the reference; ECSV written directly, astropy is not
+    available).  Returns the table as a dict of columns + ``meta``."""
+    import os
+
+    import yaml
+    fname = "{0}_results.ecsv".format(outname)
+    if os.path.exists(fname) and not overwrite:
+        raise OSError("{0} exists; pass overwrite=True".format(fname))
+    labels = list(sampler.labels)
+    chain = np.asarray(sampler.get_chain())
+    dists = chain[-1] if last_step else chain.reshape(-1, chain.shape[-1])
+    quant = [16, 50, 84]
+    rows = []
+
+    def add(label, dist):
+        lo, med, hi = np.percentile(dist, quant)
+        rows.append((label, float(med), float(med - lo), float(hi - med)))
+
+    for p, label in enumerate(labels):
+        add(label, dists[:, p])
+        if convert_log and ("log10(" in label or "log(" in label):
+            nlabel = label.split("(")[-1].split(")")[0]
+            add(nlabel, 10 ** dists[:, p] if label.split("(")[0] == "log10" else np.exp(dists[:, p]))
+    meta = {"n_samples": int(dists.shape[0])}
+    ML, MLp = find_ML(sampler)
+    meta["ML_pars"] = [float(x) for x in MLp]
+    meta["MaxLogLikelihood"] = ML
+    ndata = len(sampler.data["energy"]) if getattr(sampler, "data", None) is not None else 0
+    if ndata:
+        meta["BIC"] = float(len(MLp) * np.log(ndata) - 2 * ML)
+    for k, v in dict(getattr(sampler, "run_info", {})).items():
+        meta[k] = v.tolist() if isinstance(v, np.ndarray) else (v.item() if isinstance(
+            v, np.generic) else v)
+    if include_blobs:
+        blobs = sampler.get_blobs() or []
+        units = list(getattr(sampler, "blob_units", None) or [None] * len(blobs))
+        for idx, b in enumerate(blobs):
+            b = np.asarray(b)
+            if b.ndim == 2:  # one scalar per walker and step
+                add("blob{0}".format(idx), b[-1] if last_step else b.ravel())
+                if units[idx] is not None:
+                    meta["blob{0}_unit".format(idx)] = units[idx].name
+    cols = [("label", "string", "Name of the parameter"),
+            ("median", "float64", "Median of the posterior distribution function"),
+            ("unc_lo", "float64", "Difference between the median and the 16th percentile of the "
+                                  "pdf, ~1sigma lower uncertainty"),
+            ("unc_hi", "float64", "Difference between the 84th percentile and the median of the "
+                                  "pdf, ~1sigma upper uncertainty")]
+    header = {"datatype": [dict(name=n, datatype=t, description=d) for n, t, d in cols],
+              "meta": meta}
+    with open(fname, "w") as f:
+        f.write("# %ECSV 1.0\n# ---\n")
+        for line in yaml.safe_dump(header, default_flow_style=None, sort_keys=False).splitlines():
+            f.write("# " + line + "\n")
+        f.write("label median unc_lo unc_hi\n")
+        for label, med, lo, hi in rows:
+            f.write('"{0}" {1!r} {2!r} {3!r}\n'.format(label, med, lo, hi))
+    return {"label": [r[0] for r in rows], "median": np.array([r[1] for r in rows]),
+            "unc_lo": np.array([r[2] for r in rows]), "unc_hi": np.array([r[3] for r in rows]),
+            "meta": meta}

@@ -184,3 +184,40 @@ def test_save_read_run_roundtrip(tmp_path):
     assert r.chain.shape == (16, 7, 3) and r.flatchain.shape == (112, 3)
     with pytest.raises(OSError):
         na.save_run(str(tmp_path / "run"), s)
+
+
+def test_save_results_table(tmp_path):
+    """analysis.save_results_table: medians / 1-sigma distances per parameter, de-logged
+    labels, scalar blobs, run info + ML + BIC as ECSV metadata (analysis.py:165-363)"""
+    import yaml
+    from naima_amd.analysis import read_run, save_results_table, save_run
+    from naima_amd.datatable import read_ecsv
+    rng = np.random.default_rng(0)
+
+    def lp(x):
+        return -0.5 * np.sum((x - np.array([1.0, 2.0])) ** 2, axis=1), x[:, 0] ** 2
+
+    s = EnsembleSampler(20, 2, lp, seed=3)
+    s.run_mcmc(np.array([1.0, 2.0]) + 0.1 * rng.normal(size=(20, 2)), 60)
+    s.labels = ["log10(norm)", "index"]
+    s.run_info = {"n_walkers": 20, "n_burn": 0, "n_run": 60, "p0": [1.0, 2.0]}
+    s.data = {"energy": np.arange(7.0)}
+    t = save_results_table(str(tmp_path / "fit"), s)
+    assert t["label"] == ["log10(norm)", "norm", "index", "blob0"]
+    flat = s.get_chain(flat=True)
+    assert_allclose(t["median"][0], np.median(flat[:, 0]))
+    assert_allclose(t["median"][1], np.median(10 ** flat[:, 0]))
+    assert_allclose(t["unc_hi"][2], np.percentile(flat[:, 1], 84) - np.median(flat[:, 1]))
+    assert_allclose(t["median"][3], np.median(np.asarray(s.get_blobs()[0])))
+    assert t["meta"]["n_samples"] == 1200 and t["meta"]["n_run"] == 60
+    assert_allclose(t["meta"]["BIC"], 2 * np.log(7) - 2 * t["meta"]["MaxLogLikelihood"])
+    assert_allclose(t["meta"]["MaxLogLikelihood"], np.max(s.get_log_prob()))
+    text = open(tmp_path / "fit_results.ecsv").read().splitlines()
+    assert text[0] == "# %ECSV 1.0"
+    hdr = yaml.safe_load("\n".join(l[2:] for l in text[2:] if l.startswith("# ")))
+    assert [c["name"] for c in hdr["datatype"]] == ["label", "median", "unc_lo", "unc_hi"]
+    assert hdr["meta"]["ML_pars"] == t["meta"]["ML_pars"]
+    with pytest.raises(OSError):
+        save_results_table(str(tmp_path / "fit"), s)
+    t2 = save_results_table(str(tmp_path / "fit"), s, last_step=True, overwrite=True)
+    assert t2["meta"]["n_samples"] == 20
