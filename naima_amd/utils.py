@@ -6,7 +6,7 @@ from . import units as u
 from ._lib import get_context
 from .core import sed_conversion  # noqa: F401  (re-export, utils.py:219-282)
 
-__all__ = ["trapz_loglog", "sed_conversion"]
+__all__ = ["trapz_loglog", "sed_conversion", "estimate_B"]
 
 
 def trapz_loglog(y, x, axis=-1, intervals=False):
@@ -41,3 +41,20 @@ def trapz_loglog(y, x, axis=-1, intervals=False):
     if unit.dims == u.dimensionless_unscaled.dims and unit.scale == 1.0:
         return res
     return u.Quantity(res, unit)
+
+
+def estimate_B(xray_table, vhe_table, photon_energy_density=0.261 * u.eV / u.cm ** 3):
+    """Magnetic field from the ratio of X-ray to gamma-ray luminosity,
+    L_x / L_gamma = u_B / u_ph = B^2 / (8 pi u_ph) (utils.py:484-542 of the reference;
+    Thomson regime, both bands assumed to hold the bulk of the emission): a starting
+    value of B for joint X-ray / gamma-ray fits.  Tables as for ``get_sampler``."""
+    from .datatable import validate_data_table
+    xray = validate_data_table(xray_table, sed=False)
+    vhe = validate_data_table(vhe_table, sed=False)
+    lum = []
+    for t in (xray, vhe):
+        e = t["energy"].to("erg")
+        f = t["flux"].to("1/(s cm2 erg)")
+        lum.append(float(trapz_loglog(f.value * e.value, e.value)))  # erg / (cm2 s)
+    uph = photon_energy_density.to("erg/cm3").value
+    return u.Quantity(np.sqrt(lum[0] / lum[1] * 8 * np.pi * uph) * 1e6, u.uG)

@@ -310,3 +310,27 @@ def test_run_sampler_surface_on_the_device_loop(na, tmp_path):
     back = na.read_run(str(tmp_path / "run"))
     assert np.array_equal(back.get_chain(), s.get_chain())
     assert back.labels == s.labels
+
+
+def test_estimate_B(na):
+    """utils.estimate_B (utils.py:484-542): sqrt(8 pi u_ph L_x / L_gamma) from two data
+    tables, with the oracle's trapz_loglog as the reference"""
+    from naima_amd.datatable import make_data
+    from naima_amd.utils import estimate_B
+    from oracle import naima_np as O
+    ex = np.geomspace(0.5, 10, 25)          # keV
+    fx = 3e-2 * ex ** -2.2                  # 1/(cm2 s keV)
+    eg = np.geomspace(0.3, 80, 18)          # TeV
+    fg = 2e-11 * eg ** -2.4 * np.exp(-eg / 30)   # 1/(cm2 s TeV)
+
+    def table(e, eu, f, fu):
+        return make_data(dict(energy=e, energy_unit=eu, flux=f, flux_error_lo=0.1 * f,
+                              flux_error_hi=0.1 * f, ul=np.zeros(e.size, dtype=bool),
+                              cl=np.full(e.size, 0.9), flux_unit=fu))
+    B = estimate_B(table(ex, "keV", fx, "1/(cm2 s keV)"), table(eg, "TeV", fg, "1/(cm2 s TeV)"))
+    kev, tev = 1.602176634e-9, 1.602176634
+    Lx = O.trapz_loglog(fx / kev * ex * kev, ex * kev)
+    Lg = O.trapz_loglog(fg / tev * eg * tev, eg * tev)
+    ref = np.sqrt(Lx / Lg * 8 * np.pi * 0.261 * 1.602176634e-12) * 1e6
+    assert_allclose(B.to("uG").value, ref, rtol=1e-12)
+    assert 1.0 < B.to("uG").value < 1e4
