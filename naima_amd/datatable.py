@@ -245,3 +245,53 @@ def read(path):
     with open(path) as fh:
         first = fh.readline()
     return read_ecsv(path) if first.startswith("# %ECSV") else read_ipac(path)
+
+
+# ---------------------------------------------------------------------------
+# utils.py:369-482 of the reference: tables from arrays
+# ---------------------------------------------------------------------------
+def generate_energy_edges(ene, groups=None):
+    """(energy_error_lo, energy_error_hi) from the geometric means of neighbouring
+    energies, separately per group of points when ``groups`` labels them
+    (utils.py:369-395)"""
+    if groups is None or len(ene) != len(groups):
+        return _generate_energy_edges(ene)
+    groups = np.asarray(groups)
+    elo, ehi = np.zeros(len(ene)), np.zeros(len(ene))
+    for g in np.unique(groups):
+        sel = groups == g
+        lo, hi = _generate_energy_edges(u.Quantity(ene.value[sel], ene.unit))
+        elo[sel], ehi[sel] = lo.value, hi.value
+    return u.Quantity(elo, ene.unit), u.Quantity(ehi, ene.unit)
+
+
+def build_data_table(energy, flux, flux_error=None, flux_error_lo=None, flux_error_hi=None,
+                     energy_width=None, energy_lo=None, energy_hi=None, ul=None, cl=None):
+    """A data table from arrays with units (utils.py:398-482): symmetric or asymmetric flux
+    errors, optional bin widths / edges, upper-limit flags and their confidence level.
+    The result is checked with ``validate_data_table`` and can be handed to
+    ``get_sampler``."""
+    from .validator import validate_scalar
+    table = DataTable()
+    if cl is not None:
+        cl = validate_scalar("cl", cl)
+        table.meta["keywords"] = {"cl": {"value": float(np.asarray(cl))}}
+    table["energy"] = energy
+    if energy_width is not None:
+        table["energy_width"] = energy_width
+    elif energy_lo is not None and energy_hi is not None:
+        table["energy_lo"] = energy_lo
+        table["energy_hi"] = energy_hi
+    table["flux"] = flux
+    if flux_error is not None:
+        table["flux_error"] = flux_error
+    elif flux_error_lo is not None and flux_error_hi is not None:
+        table["flux_error_lo"] = flux_error_lo
+        table["flux_error_hi"] = flux_error_hi
+    else:
+        raise TypeError("Flux error not provided!")
+    if ul is not None:
+        table["ul"] = np.array(ul, dtype=int)
+    table.meta["comments"] = ["Table generated with naima.build_data_table"]
+    validate_data_table(table)  # units, shapes, column names
+    return table

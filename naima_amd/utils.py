@@ -5,8 +5,11 @@ import numpy as np
 from . import units as u
 from ._lib import get_context
 from .core import sed_conversion  # noqa: F401  (re-export, utils.py:219-282)
+from .datatable import (build_data_table, generate_energy_edges,  # noqa: F401
+                        validate_data_table)
 
-__all__ = ["trapz_loglog", "sed_conversion", "estimate_B"]
+__all__ = ["trapz_loglog", "sed_conversion", "estimate_B", "build_data_table",
+           "generate_energy_edges", "validate_data_table"]
 
 
 def trapz_loglog(y, x, axis=-1, intervals=False):

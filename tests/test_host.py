@@ -223,3 +223,32 @@ def test_header_is_plain_c(tmp_path):
                            str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-std=c++11", "-I", inc, "-x", "c++", "-c", str(src), "-o",
                            str(tmp_path / "t2.o")])
+
+
+def test_build_data_table_and_energy_edges():
+    """utils.build_data_table / generate_energy_edges (utils.py:358-482)"""
+    from naima_amd.utils import build_data_table, generate_energy_edges, validate_data_table
+    e = np.array([1.0, 2.0, 4.0, 8.0]) * u.TeV
+    f = np.array([4.0, 2.0, 1.0, 0.5]) * u.Unit("1/(cm2 s TeV)")
+    lo, hi = generate_energy_edges(e)
+    mid = np.sqrt(e.value[1:] * e.value[:-1])
+    assert_allclose(hi.value[:-1], mid - e.value[:-1])
+    assert_allclose(lo.value[1:], e.value[1:] - mid)
+    assert_allclose(lo.value[0], e.value[0] * (1 - e.value[0] / (e.value[0] + hi.value[0])))
+    assert hi.value[-1] == lo.value[-1]
+    glo, ghi = generate_energy_edges(e, groups=[0, 0, 1, 1])
+    a, b = generate_energy_edges(e[:2])
+    assert_allclose(glo.value[:2], a.value) and assert_allclose(ghi.value[:2], b.value)
+    t = build_data_table(e, f, flux_error=0.1 * f, ul=[0, 0, 0, 1], cl=0.95)
+    d = validate_data_table(t)
+    assert_allclose(d["flux_error_lo"].value, 0.1 * f.value)
+    assert list(np.asarray(d["ul"]).astype(int)) == [0, 0, 0, 1] and np.all(d["cl"] == 0.95)
+    assert_allclose(d["energy_error_hi"].value, hi.value)
+    t2 = build_data_table(e, f, flux_error_lo=0.1 * f, flux_error_hi=0.2 * f, energy_width=0.5 * e)
+    d2 = validate_data_table(t2)
+    assert_allclose(d2["flux_error_hi"].value, 0.2 * f.value)
+    assert_allclose(d2["energy_error_lo"].value, 0.25 * e.value)
+    with pytest.raises(TypeError):
+        build_data_table(e, f)
+    with pytest.raises(TypeError):
+        build_data_table(e.value, f, flux_error=0.1 * f)
