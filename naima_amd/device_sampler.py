@@ -71,11 +71,14 @@ class DeviceLoop:
         # the sharded code path (split graphs around the all-gather) even for ONE rank:
         # lets a 1-GPU box run everything but the multi-process part (tests)
         self.sharded = comm.size > 1 or os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") == "1"
-        # opt-in: capture the all-gather INTO the step graphs (RCCL supports stream capture;
-        # verified here with a one-rank communicator only, hence not the default): the
-        # sharded loop then replays whole steps like the single-GPU loop
-        self.coll_in_graph = self.sharded and getattr(comm, "in_stream", False) and \
-            os.environ.get("NAIMA_AMD_RCCL_IN_GRAPH", "0") == "1"
+        # the all-gather captured INTO the step graphs (the sharded loop then replays whole
+        # steps like the single-GPU loop) when the communicator's ranks have been seen to
+        # survive that in a throw-away probe process (RcclComm.graph_capture_ok); else the
+        # collective sits between two graphs.  NAIMA_AMD_RCCL_IN_GRAPH = auto | 0 | 1
+        mode = os.environ.get("NAIMA_AMD_RCCL_IN_GRAPH", "auto")
+        self.coll_in_graph = self.sharded and getattr(comm, "in_stream", False) and (
+            mode == "1" or (mode == "auto" and hasattr(comm, "graph_capture_ok")
+                            and comm.graph_capture_ok()))
         self.split = self.sharded and not self.coll_in_graph  # collective between two graphs
         self.nloc = self.hi - self.lo
         ctx = self.ctx

@@ -117,6 +117,42 @@ class RcclComm:
         dist.broadcast_object_list(box, src=0)
         _lib._chk(lib.nh_comm_init(self.ctx.h, self.rank, self.size, box[0]))
         self._send = self._recv = None
+        self._graph_ok = None
+
+    def graph_capture_ok(self, timeout=120.0):
+        """True when an all-gather of this communicator's ranks has been seen to survive
+        hipGraph capture and replay.  Probed once, in a throw-away process per rank with
+        its own rendezvous (``python -m naima_amd._rccl_probe``): a collective that hangs
+        under capture then costs the probe its timeout, not the run.  Every rank gets the
+        same answer (minimum over ranks)."""
+        if self._graph_ok is None:
+            import subprocess
+            import sys
+
+            import torch
+            ok = False
+            proc = None
+            try:
+                env = dict(os.environ)
+                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+                env["NAIMA_AMD_DEVICE"] = str(self.ctx.device)
+                env["RANK"], env["WORLD_SIZE"] = str(self.rank), str(self.size)
+                env.pop("NAIMA_AMD_FORCE_SHARDED", None)
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                proc = subprocess.Popen([sys.executable, "-m", "naima_amd._rccl_probe"], env=env,
+                                        cwd=root, stdout=subprocess.PIPE,
+                                        stderr=subprocess.DEVNULL)
+                out, _ = proc.communicate(timeout=timeout)
+                ok = proc.returncode == 0 and b"captured + replayed ok: True" in out
+            except Exception:
+                ok = False
+                if proc is not None and proc.poll() is None:
+                    proc.kill()  # this probe only: the PID we started
+                    proc.wait()
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            self._graph_ok = float(t.item()) == 1.0
+        return self._graph_ok
 
     def allgather(self, x):
         """ranks contribute equal-sized blocks (the sampler pads to the largest shard)"""

@@ -415,13 +415,14 @@ def test_rccl_communicator_after_torch_import(na):
     assert "captured + replayed ok: True" in out.stdout
 
 
-@pytest.mark.parametrize("in_graph", ["0", "1"])
+@pytest.mark.parametrize("in_graph", ["0", "1", "auto"])
 def test_sharded_path_with_rccl_on_one_rank(na, golden, tmp_path, in_graph):
     """everything of the multi-GPU loop except the second process: torch.distributed
     rendezvous, RCCL communicator, split graphs with the all-gathers between them, the
     likelihood written into the send buffer, accept after the exchange, gathered blobs --
     with a one-rank communicator, against the ordinary single-GPU loop.  in_graph = 1: the
-    opt-in variant with the all-gathers captured into the step graphs."""
+    variant with the all-gathers captured into the step graphs; auto (the default): after
+    the probe process has seen that work."""
     import subprocess
     import sys
     from naima_amd.sampler import EnsembleSampler
