@@ -173,21 +173,23 @@ def main():
     device = not args.host_loop
     sampler = make_sampler(device, not args.no_graph)
     pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
-    ctx.sync()
-    tw = time.perf_counter()
     state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
     ctx.sync()
     # Spin-up, untimed and reported as config.untimed_spinup_steps: the first ~20 ms after
     # an idle period run measurably slower (device clocks ramp, first replays of the
     # multi-step graph), measured 3.1e6 -> 4.4e6 walker-steps/s between --warmup 5 and
-    # --warmup 100.  A short --warmup is topped up to 160 steps (at most 0.5 s of them);
+    # --warmup 100.  A short --warmup is topped up to 160 steps (at most 0.5 s of them, judged
+    # by eight steps timed after the warm-up -- the warm-up itself contains one-off set-up);
     # every rank takes the same number so the collectives stay matched.
-    per_step = comm.max((time.perf_counter() - tw) / max(2, args.warmup))
-    spinup = int(min(max(0, 160 - args.warmup), 0.5 / max(per_step, 1e-6)))
-    if spinup > 0 and device:
-        state = sampler.run_mcmc(state, spinup, store=False)
-    else:
-        spinup = 0
+    spinup = 0
+    if device:
+        tw = time.perf_counter()
+        state = sampler.run_mcmc(state, 8, store=False)
+        ctx.sync()
+        per_step = comm.max((time.perf_counter() - tw) / 8)
+        spinup = 8 + int(min(max(0, 152 - args.warmup), 0.5 / max(per_step, 1e-6)))
+        if spinup > 8:
+            state = sampler.run_mcmc(state, spinup - 8, store=False)
 
     # ---- the timed region: K ensemble steps, barrier + device sync on both sides
     comm.barrier()
@@ -247,6 +249,10 @@ def main():
             "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
             "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
             "device": info["name"], "untimed_spinup_steps": spinup,
+            "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
+                           "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
+                           else "all-gather between two graphs per half-step")
+            if device else "host loop",
             "chain": "discarded (store=False)" if args.no_chain else
             "kept: every step's coords and log-prob appended in HBM by the step kernels"},
         "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,

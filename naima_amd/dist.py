@@ -138,6 +138,9 @@ class RcclComm:
                 env["NAIMA_AMD_DEVICE"] = str(self.ctx.device)
                 env["RANK"], env["WORLD_SIZE"] = str(self.rank), str(self.size)
                 env.pop("NAIMA_AMD_FORCE_SHARDED", None)
+                # under torchrun the workers are clients of the AGENT's store on
+                # MASTER_PORT; the probes make their own store on the shifted port
+                env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                 proc = subprocess.Popen([sys.executable, "-m", "naima_amd._rccl_probe"], env=env,
                                         cwd=root, stdout=subprocess.PIPE,
