@@ -157,7 +157,7 @@ def main():
     from naima_amd.sampler import EnsembleSampler
 
     ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
-    comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # gloo: test hook
+    comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # host: test hook
     name = args.workload
     model, p0, raw, data, prior, labels = build_problem(name, na)
     per_gpu = args.walkers or W.WORKLOADS[name]["nwalkers"]

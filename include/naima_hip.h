@@ -369,7 +369,9 @@ int nh_stream_join(nh_ctx* ctx);
 typedef struct nh_moves nh_moves;
 int nh_moves_create(unsigned long long seed, int N, double a, int ksteps_per_block, int depth,
                     int pinned, nh_moves** out);
-/* up to `want` consecutive steps, contiguous in host memory (2*got slices) */
+/* up to `want` consecutive steps, contiguous in host memory (2*got slices); depth >= 3.
+ * A used-up block goes back to the producer one block late: an asynchronous copy out of
+ * the MOST RECENT take may still be pending at the next take, all earlier ones must be done. */
 int nh_moves_take(nh_moves* m, int want, const void** host_ptr, int* got);
 int nh_moves_destroy(nh_moves* m);
 

@@ -237,7 +237,7 @@ def _lnprob_device(pars, data, modelfunc, priorfunc):
     if isinstance(modelout, (tuple, list)):
         model, blob = modelout[0], tuple(modelout)
     else:
-        model, blob = modelout, (modelout,)
+        model, blob = modelout, (modelout, np.nan)  # core.py:108-110
     if not isinstance(model.value, DMat):
         raise TypeError("the model function returned a host array for device-resident "
                         "parameters; it must build its flux from naima_amd radiative models")

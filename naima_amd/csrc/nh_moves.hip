@@ -27,7 +27,7 @@ struct nh_moves {
   bool pinned;
   uint64_t s[4];
   std::vector<double*> blocks;   // depth blocks of ksteps*2 slices
-  std::vector<int> ready;        // 1 = filled, not yet released
+  std::vector<int> ready;        // 0 = free, 1 = filled, 2 = consumed but not yet handed back
   int head = 0;                  // block the consumer reads
   int offset = 0;                // steps of blocks[head] already taken
   int tail = 0;                  // block the producer fills next
@@ -114,7 +114,7 @@ static void producer(nh_moves* m) {
 
 extern "C" int nh_moves_create(unsigned long long seed, int N, double a, int ksteps, int depth,
                                int pinned, nh_moves** out) {
-  NH_REQUIRE(out && N >= 2 && N % 2 == 0 && a > 1.0 && ksteps >= 1 && depth >= 2, "bad argument");
+  NH_REQUIRE(out && N >= 2 && N % 2 == 0 && a > 1.0 && ksteps >= 1 && depth >= 3, "bad argument");
   nh_moves* m = new nh_moves();
   m->N = N; m->ns = N / 2; m->ksteps = ksteps; m->depth = depth; m->a = a; m->pinned = pinned != 0;
   uint64_t z = seed;  // splitmix64 seeding
@@ -147,13 +147,20 @@ extern "C" int nh_moves_create(unsigned long long seed, int N, double a, int kst
   return NH_OK;
 }
 
-// up to `want` consecutive steps of the stream, contiguous in (pinned) host memory; the
-// pointer stays valid until `depth - 1` further blocks have been consumed
+// up to `want` consecutive steps of the stream, contiguous in (pinned) host memory.
+// Lifetime of the pointer: a used-up block is handed back to the producer ONE BLOCK LATE --
+// when the consumer moves on from block j to block j+1, block j-1 is released, not block j.
+// A caller that ships the steps with an asynchronous copy (the device loop: hipMemcpyAsync
+// from this pinned memory) may therefore have the copy of its MOST RECENT take still queued
+// when it takes again; every earlier copy must have completed (device_sampler waits on the
+// marker recorded after the last-but-one upload before each take).
 extern "C" int nh_moves_take(nh_moves* m, int want, const void** ptr, int* got) {
   NH_REQUIRE(m && ptr && got && want >= 1, "bad argument");
   std::unique_lock<std::mutex> lk(m->mu);
-  if (m->offset >= m->ksteps) {  // current block used up: hand it back, move on
-    m->ready[m->head] = 0;
+  if (m->offset >= m->ksteps) {  // current block used up: move on, hand the PREVIOUS one back
+    const int prev = (m->head + m->depth - 1) % m->depth;
+    if (m->ready[prev] == 2) m->ready[prev] = 0;
+    m->ready[m->head] = 2;
     m->head = (m->head + 1) % m->depth;
     m->offset = 0;
     m->cv.notify_all();

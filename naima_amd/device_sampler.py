@@ -125,6 +125,7 @@ class DeviceLoop:
         ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
         self.graph = None
         self.cur_blobs = None      # list of (device buffer [N][m], m, unit, trailing shape)
+        self.const_blobs = []      # (position, value) of blobs that are plain numbers
         self.hist = []             # pending device history blocks
         self.warm = 0
         self._have_state = False
@@ -141,7 +142,13 @@ class DeviceLoop:
         self.s.n_lnprob_calls += 1
         self.s.n_walker_evals += n
         total = res[0].dense()
-        return total, list(res[1:])
+        blobs = list(res[1:])
+        # plain numbers among the blobs (lnprob's (model, nan) for a model that returns no
+        # blob of its own, core.py:108-110) are the same for every walker and every step:
+        # they are not kept in HBM but put back where they belong when the blobs are read
+        self.const_blobs = [(j, float(b)) for j, b in enumerate(blobs)
+                            if isinstance(b, (float, int))]
+        return total, [b for b in blobs if not isinstance(b, (float, int))]
 
     def _blob_dense(self, b):
         """blob -> (owner, ptr, m, unit, trailing shape) with rows over walkers"""
@@ -335,6 +342,8 @@ class DeviceLoop:
                     ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
                 self.cur_blobs.append((cur, m, unit, trail))
                 units.append(unit)
+            for j, _ in self.const_blobs:
+                units.insert(j, None)
             s.blob_units = units
         lp = self.logp.get()
         if np.any(np.isnan(lp)):
@@ -344,7 +353,10 @@ class DeviceLoop:
     def host_blobs(self):
         if not self.cur_blobs:
             return None
-        return [cur.get().reshape((self.N,) + trail) for cur, m, _, trail in self.cur_blobs]
+        out = [cur.get().reshape((self.N,) + trail) for cur, m, _, trail in self.cur_blobs]
+        for j, v in self.const_blobs:
+            out.insert(j, np.full((self.N,), v))
+        return out
 
     # ------------------------------------------------------------------- loop
     def sample(self, initial_state, iterations, store, yield_every=1):
@@ -378,7 +390,11 @@ class DeviceLoop:
             self._flush_pending()  # (merged sharded mode) the block's last accept
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the
             # generator's page-locked ring (filled ahead by its worker thread) ----------
-            while len(self._inflight) >= 2:  # ring depth 4: keep <= 3 blocks in play
+            # nh_moves_take's contract: only the copy of the MOST RECENT take may still be
+            # queued when the next one is taken (the generator hands a used-up block back
+            # one block late, so that copy's source is still intact); every earlier upload
+            # has to be complete -- wait on the marker recorded after it
+            while len(self._inflight) >= 2:
                 ctx.call("nh_marker_wait", self._inflight.pop(0))
             addr, K = moves.take(min(self.KSTEPS, iterations - it))
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
@@ -533,9 +549,13 @@ class DeviceLoop:
             s._chain.extend(list(c))
             s._logp.extend(list(l))
             if block["blobs"]:
+                per = [hb.get()[:n].reshape((n, self.N) + trail)
+                       for hb, (cur, m, _, trail) in zip(block["blobs"], self.cur_blobs)]
+                for j, v in self.const_blobs:
+                    per.insert(j, np.full((n, self.N), v))
                 if s._blobs is None:
-                    s._blobs = [[] for _ in block["blobs"]]
-                for j, (hb, (cur, m, _, trail)) in enumerate(zip(block["blobs"], self.cur_blobs)):
-                    s._blobs[j].extend(list(hb.get()[:n].reshape((n, self.N) + trail)))
+                    s._blobs = [[] for _ in per]
+                for j, a in enumerate(per):
+                    s._blobs[j].extend(list(a))
         self.hist = []
         s.naccepted = self.nacc.get().astype(float)

@@ -10,12 +10,22 @@ coordinates have to move.
 
 Backends
   * ``RcclComm``  -- the product path: RCCL straight from libnaima_hip
-    (nh_comm_*), device buffers, the context's stream.  torch.distributed (gloo)
-    is used once, to hand the RCCL unique id to the other ranks.
-  * ``GlooComm``  -- CPU-only, for the world_size-2 tests that run without a GPU.
+    (nh_comm_*), device buffers, the context's stream.
+  * ``HostComm``  -- all-gathers staged through the host over the control plane
+    (CPU-only tests; the fallback when no RCCL communicator can be built).
   * ``LocalComm`` -- a single process.
+
+Control plane: ``SocketGroup``, a stdlib-``socket`` rendezvous (rank 0 is the hub of a
+star over TCP on MASTER_ADDR).  It carries the 128-byte RCCL unique id, barriers and the
+max/min of a scalar -- nothing on the data path.  No PyTorch anywhere: the launcher only
+has to provide RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``torch.distributed.run``
+does, so does any other launcher).
 """
+import hashlib
 import os
+import socket
+import struct
+import time
 
 import numpy as np
 
@@ -49,73 +59,262 @@ def shard_counts(n, size):
     return [shard_bounds(n, r, size)[1] - shard_bounds(n, r, size)[0] for r in range(size)]
 
 
-def _ensure_gloo():
-    import datetime
+# ----------------------------------------------------------------------------------------
+# control plane
+# ----------------------------------------------------------------------------------------
+_MAGIC = b"NHRV1"
+_PORT_OFFSET = 101   # the launcher's own store usually sits on MASTER_PORT itself
+_PORT_STRIDE = 7
+_PORT_TRIES = 24
 
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
-    return dist
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
-class GlooComm:
-    """torch.distributed/gloo on CPU tensors (tests; also the control plane)"""
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control-plane peer closed the connection")
+        buf.extend(chunk)
+    return bytes(buf)
 
-    def __init__(self):
-        self.dist = _ensure_gloo()
-        self.rank = self.dist.get_rank()
-        self.size = self.dist.get_world_size()
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class SocketGroup:
+    """rank 0 listens, everyone else connects; every collective is a gather to rank 0
+    followed by a broadcast of the gathered list (payloads are tens of bytes).
+
+    The port is ``MASTER_PORT + 101 + 7 k`` for the first k whose bind succeeds; clients
+    try the same candidates and recognise THEIR hub by a token derived from the job's
+    rendezvous variables (another service, or another job's hub, fails the handshake and
+    the client moves on).  ``salt`` separates several groups of one job (the RCCL capture
+    probes make their own)."""
+
+    def __init__(self, rank, size, addr=None, port=None, salt="", timeout=300.0):
+        self.rank, self.size, self.timeout = int(rank), int(size), float(timeout)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
+        ident = "%s:%d:%d:%s:%s" % (addr, base, self.size,
+                                    os.environ.get("TORCHELASTIC_RUN_ID", ""), salt)
+        self.token = hashlib.sha256(ident.encode()).digest()[:16]
+        self.peers = {}     # rank 0: rank -> socket
+        self.sock = None    # other ranks: the socket to rank 0
+        self._srv = None
+        ports = [base + _PORT_OFFSET + _PORT_STRIDE * k for k in range(_PORT_TRIES)]
+        ports = [p for p in ports if p < 65536] or [base]
+        if self.size == 1:
+            return
+        if self.rank == 0:
+            self._serve(addr, ports)
+        else:
+            self._connect(addr, ports)
+
+    def _serve(self, addr, ports):
+        srv = None
+        for p in ports:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind(("0.0.0.0", p))
+            except OSError:
+                s.close()
+                continue
+            srv = s
+            break
+        if srv is None:
+            raise RuntimeError("no free control-plane port among %s" % (ports,))
+        srv.listen(self.size + 8)
+        srv.settimeout(1.0)
+        self._srv = srv
+        deadline = time.time() + self.timeout
+        while len(self.peers) < self.size - 1:
+            if time.time() > deadline:
+                raise TimeoutError("control plane: %d of %d ranks joined within %.0f s"
+                                   % (len(self.peers) + 1, self.size, self.timeout))
+            try:
+                c, _ = srv.accept()
+            except socket.timeout:
+                continue
+            try:
+                c.settimeout(10.0)
+                hello = _recv_exact(c, len(_MAGIC) + 16 + 4)
+                r = struct.unpack("<i", hello[-4:])[0]
+                if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != self.token or \
+                        not (0 < r < self.size) or r in self.peers:
+                    c.close()
+                    continue
+                c.sendall(_MAGIC + self.token)
+                c.settimeout(self.timeout)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self.peers[r] = c
+            except (OSError, ConnectionError, struct.error):
+                c.close()
+
+    def _connect(self, addr, ports):
+        deadline = time.time() + self.timeout
+        hello = _MAGIC + self.token + struct.pack("<i", self.rank)
+        while True:
+            for p in ports:
+                try:
+                    s = socket.create_connection((addr, p), timeout=2.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(10.0)
+                    s.sendall(hello)
+                    if _recv_exact(s, len(_MAGIC) + 16) == _MAGIC + self.token:
+                        s.settimeout(self.timeout)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.sock = s
+                        return
+                except (OSError, ConnectionError):
+                    pass
+                s.close()
+            if time.time() > deadline:
+                raise TimeoutError("control plane: rank %d found no hub on %s ports %s"
+                                   % (self.rank, addr, ports[:4]))
+            time.sleep(0.05)
+
+    # -- collectives (every rank calls them in the same order) -------------------------
+    def allgather_bytes(self, payload):
+        payload = bytes(payload)
+        if self.size == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(self.peers[r]) for r in range(1, self.size)]
+            blob = b"".join(struct.pack("<Q", len(x)) + x for x in parts)
+            for r in range(1, self.size):
+                _send_msg(self.peers[r], blob)
+            return parts
+        _send_msg(self.sock, payload)
+        blob, parts, off = _recv_msg(self.sock), [], 0
+        for _ in range(self.size):
+            (n,) = struct.unpack_from("<Q", blob, off)
+            parts.append(blob[off + 8:off + 8 + n])
+            off += 8 + n
+        return parts
+
+    def bcast(self, payload, src=0):
+        return self.allgather_bytes(payload if self.rank == src else b"")[src]
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def reduce_scalar(self, v, op):
+        vals = [struct.unpack("<d", x)[0] for x in self.allgather_bytes(struct.pack("<d", float(v)))]
+        return max(vals) if op == "max" else min(vals)
+
+    def free_port(self):
+        """a TCP port that is free on rank 0 right now, agreed by every rank"""
+        p = b""
+        if self.rank == 0:
+            s = socket.socket()
+            s.bind(("", 0))
+            p = struct.pack("<i", s.getsockname()[1])
+            s.close()
+        return struct.unpack("<i", self.bcast(p))[0]
+
+    def close(self):
+        for c in list(self.peers.values()) + [self.sock, self._srv]:
+            try:
+                if c is not None:
+                    c.close()
+            except OSError:
+                pass
+        self.peers, self.sock, self._srv = {}, None, None
+
+
+_group = None
+
+
+def default_group():
+    """the process-wide control plane built from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT"""
+    global _group
+    if _group is None:
+        _group = SocketGroup(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                             salt=os.environ.get("NAIMA_AMD_GROUP_SALT", ""))
+    return _group
+
+
+class HostComm:
+    """all-gathers staged through the host over the control plane: the CPU tests, and the
+    (slow, correct) fallback when RCCL is unavailable"""
+
+    in_stream = False  # synchronises the stream
+
+    def __init__(self, group=None):
+        self.group = group if group is not None else default_group()
+        self.rank, self.size = self.group.rank, self.group.size
 
     def allgather(self, x):
         """ranks contribute equal-sized blocks (the sampler pads to the largest shard)"""
-        import torch
         x = np.ascontiguousarray(x, dtype=float)
-        outs = [torch.zeros(x.shape, dtype=torch.float64) for _ in range(self.size)]
-        self.dist.all_gather(outs, torch.from_numpy(x))
-        return np.concatenate([o.numpy() for o in outs], axis=0)
+        parts = self.group.allgather_bytes(x.tobytes())
+        return np.concatenate([np.frombuffer(p, dtype=float).reshape(x.shape) for p in parts],
+                              axis=0)
 
     def barrier(self):
-        self.dist.barrier()
+        self.group.barrier()
 
     def max(self, v):
-        import torch
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    in_stream = False  # host-staged: synchronises the stream (tests only)
+        return self.group.reduce_scalar(v, "max")
 
     def allgather_device(self, ctx, send_ptr, recv, n):
-        host = np.empty(n)
         from . import _lib
+        host = np.empty(n)
         ctx.join()
         _lib._chk(_lib._lib.nh_download(ctx.h, host.ctypes.data, send_ptr, host.nbytes))
         recv.set(self.allgather(host))
 
 
 class RcclComm:
-    """RCCL all-gather through the C ABI (nh_comm_allgather) on device buffers"""
+    """RCCL all-gather through the C ABI (nh_comm_allgather) on device buffers.  Building
+    one is a collective over ``group``: every rank takes the same branch at every step,
+    so a rank that cannot load librccl (or a hub that cannot make the unique id) makes ALL
+    ranks raise ``RcclUnavailable`` together instead of leaving the others waiting."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, group=None):
         import ctypes as C
 
         from . import _lib
         self.ctx = ctx if ctx is not None else _lib.get_context()
-        dist = _ensure_gloo()
-        self.dist = dist
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.group = group if group is not None else default_group()
+        self.rank, self.size = self.group.rank, self.group.size
         lib = _lib.load()
         # NCCL_DEBUG=VERSION makes RCCL print a banner on STDOUT, where bench.py owes the
         # driver exactly one JSON line
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             del os.environ["NCCL_DEBUG"]
         buf = C.create_string_buffer(128)
+        err = ""
+        # 1. rank 0 makes the id (this is also where librccl gets loaded); ALWAYS broadcasts:
+        #    the id, or an empty message that says "no RCCL here"
         if self.rank == 0:
-            _lib._chk(lib.nh_comm_unique_id(buf))
-        box = [buf.raw]
-        dist.broadcast_object_list(box, src=0)
-        _lib._chk(lib.nh_comm_init(self.ctx.h, self.rank, self.size, box[0]))
+            try:
+                _lib._chk(lib.nh_comm_unique_id(buf))
+                msg = buf.raw
+            except Exception as e:  # librccl missing / ncclGetUniqueId refused
+                msg, err = b"", str(e)
+        else:
+            msg = b""
+        uid = self.group.bcast(msg)
+        if len(uid) != 128:
+            raise RcclUnavailable("rank 0 could not create an RCCL unique id %s" % err)
+        # 2. the communicator; whoever fails says so before anybody uses it
+        ok = 1.0
+        try:
+            _lib._chk(lib.nh_comm_init(self.ctx.h, self.rank, self.size, uid))
+        except Exception as e:
+            ok, err = 0.0, str(e)
+        if self.group.reduce_scalar(ok, "min") != 1.0:
+            raise RcclUnavailable("ncclCommInitRank failed on some rank %s" % err)
         self._send = self._recv = None
         self._graph_ok = None
 
@@ -128,19 +327,16 @@ class RcclComm:
         if self._graph_ok is None:
             import subprocess
             import sys
-
-            import torch
             ok = False
             proc = None
+            port = self.group.free_port()  # the probes' own rendezvous (agreed by all ranks)
             try:
                 env = dict(os.environ)
-                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 23)
+                env["MASTER_PORT"] = str(port)
                 env["NAIMA_AMD_DEVICE"] = str(self.ctx.device)
                 env["RANK"], env["WORLD_SIZE"] = str(self.rank), str(self.size)
+                env["NAIMA_AMD_GROUP_SALT"] = "rccl-probe"
                 env.pop("NAIMA_AMD_FORCE_SHARDED", None)
-                # under torchrun the workers are clients of the AGENT's store on
-                # MASTER_PORT; the probes make their own store on the shifted port
-                env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                 proc = subprocess.Popen([sys.executable, "-m", "naima_amd._rccl_probe"], env=env,
                                         cwd=root, stdout=subprocess.PIPE,
@@ -152,9 +348,7 @@ class RcclComm:
                 if proc is not None and proc.poll() is None:
                     proc.kill()  # this probe only: the PID we started
                     proc.wait()
-            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-            self._graph_ok = float(t.item()) == 1.0
+            self._graph_ok = self.group.reduce_scalar(1.0 if ok else 0.0, "min") == 1.0
         return self._graph_ok
 
     def allgather(self, x):
@@ -175,34 +369,28 @@ class RcclComm:
 
     def barrier(self):
         self.ctx.sync()
-        self.dist.barrier()
+        self.group.barrier()
 
     def max(self, v):
-        import torch
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return self.group.reduce_scalar(v, "max")
+
+
+class RcclUnavailable(RuntimeError):
+    pass
 
 
 def from_env(prefer="rccl"):
-    """LocalComm for a single process, else RCCL (GPU) or gloo (CPU tests)"""
+    """LocalComm for a single process, else RCCL (GPU) or the host-staged control plane
+    (``prefer="host"``: CPU tests)"""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and \
             os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") != "1":
         return LocalComm()
     if prefer != "rccl":
-        return GlooComm()
-    comm = err = None
+        return HostComm()
     try:
-        comm = RcclComm()
-    except Exception as e:  # librccl missing / communicator refused
-        err = e
-    import torch
-    dist = _ensure_gloo()
-    ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
-    if float(ok.item()) == 1.0:
-        return comm
-    import warnings
-    warnings.warn("RCCL communicator unavailable (%s); all-gathers are staged through the host "
-                  "with gloo: correct, slower" % (err,))
-    return GlooComm()
+        return RcclComm()  # collective: succeeds or raises on every rank alike
+    except RcclUnavailable as e:
+        import warnings
+        warnings.warn("RCCL communicator unavailable (%s); all-gathers are staged through the "
+                      "host over the control plane: correct, slower" % (e,))
+        return HostComm()

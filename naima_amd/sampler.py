@@ -205,18 +205,20 @@ class EnsembleSampler:
         rng = self._rng
         N, ndim, a = self.nwalkers, self.ndim, self.a
         keep_blobs = self.store_blobs
-        # blobs of this rank's walkers only (flux arrays are N*n_E*8 B per step and
-        # stay rank-local)
+        # every rank keeps the blobs of ALL walkers: the rank that evaluates a walker
+        # changes from half-step to half-step (a random split, contiguous shards of it), so
+        # the proposals' blobs follow their log-probabilities through one more all-gather
+        # per blob (as the device loop does; this host-driven loop is the general /
+        # fallback path and pays for it with the control plane's bandwidth)
         if state.log_prob is None:
             logp, blobs, (lo, hi) = self.compute_log_prob(coords)
             cur, units = self._blob_arrays(blobs, hi - lo) if keep_blobs else ([], [])
             self.blob_units = units
-            self._own = np.arange(lo, hi)
-            self._cur_blobs = cur
+            self._cur_blobs = [np.array(self._gather_rows(b, N)) for b in cur]
         else:
             logp = np.array(state.log_prob, dtype=float)
             if not hasattr(self, "_cur_blobs"):
-                self._cur_blobs, self._own = [], np.arange(0)
+                self._cur_blobs = []
         logp = logp.copy()
         moves = self.moves()
         for _ in range(int(iterations)):
@@ -236,7 +238,8 @@ class EnsembleSampler:
                 self.naccepted[acc_idx] += 1
                 if keep_blobs and blobs:
                     new, _ = self._blob_arrays(blobs, hi - lo)
-                    self._update_blobs(S[lo:hi], accepted[lo:hi], new)
+                    for cur, nb in zip(self._cur_blobs, new):
+                        cur[acc_idx] = self._gather_rows(nb, len(S))[accepted]
             self.iteration += 1
             if store:
                 self._chain.append(coords.copy())
@@ -262,11 +265,28 @@ class EnsembleSampler:
             return True
         ctx = _lib.get_context()
         c = np.ascontiguousarray(State(initial_state).coords[:2].T, dtype=float)
+        why = None
         try:
-            self.log_prob_fn(DPars(ctx, ctx.array(c), self.ndim, c.shape[1]), *self.args)
-        except NotImplementedError as e:
+            res = self.log_prob_fn(DPars(ctx, ctx.array(c), self.ndim, c.shape[1]), *self.args)
+            if self.store_blobs:
+                from . import units as u
+                from .darray import DMat, DVec
+                for b in res[1:]:
+                    v = b.value if isinstance(b, u.Quantity) else b
+                    if not isinstance(v, (DMat, DVec, float, int)):
+                        why = "a blob of type %s cannot be kept in HBM" % type(v).__name__
+        except NotImplementedError as e:  # grid-/table-shaping parameters per walker
+            why = str(e)
+        except (TypeError, ValueError) as e:
+            # a model that is not built from naima_amd's radiative classes: plain numpy
+            # arithmetic on the parameters (ValueError from DVec), a functional model that
+            # returns a host array (TypeError from the device likelihood) ...
+            why = "%s: %s" % (type(e).__name__, e)
+        finally:
+            ctx.flush()
+        if why is not None:
             warnings.warn("device=True is not possible for this model (%s); using the "
-                          "host-driven loop" % (e,))
+                          "host-driven loop (pass device=False to silence this)" % (why,))
             self.device = False
             return False
         return True
@@ -277,16 +297,16 @@ class EnsembleSampler:
             self._dev = DeviceLoop(self)
         yield from self._dev.sample(initial_state, iterations, store, yield_every)
 
-    def _update_blobs(self, walkers, accepted, new):
-        """walkers: global indices this rank just evaluated; blobs are tracked for
-        the walkers this rank evaluated at initialisation (``self._own``)"""
-        if not self._cur_blobs:
-            return
-        pos = {w: i for i, w in enumerate(self._own)}
-        for j, (w, ok) in enumerate(zip(walkers, accepted)):
-            if ok and w in pos:
-                for cur, nb in zip(self._cur_blobs, new):
-                    cur[pos[w]] = nb[j]
+    def _gather_rows(self, rows, n):
+        """this rank's block of an n-row array -> all n rows, on every rank"""
+        size = self.comm.size
+        if size == 1:
+            return rows
+        counts = shard_counts(n, size)
+        pad = np.zeros((max(counts),) + rows.shape[1:])
+        pad[:len(rows)] = rows
+        allp = self.comm.allgather(pad).reshape((size, max(counts)) + rows.shape[1:])
+        return np.concatenate([allp[r, :c] for r, c in enumerate(counts)], axis=0)
 
     def run_mcmc(self, initial_state, nsteps, **kw):
         state = None

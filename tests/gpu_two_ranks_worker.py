@@ -9,11 +9,12 @@ sys.path.insert(0, ROOT)
 os.environ["NAIMA_AMD_DEVICE"] = "0"  # both ranks share the one GPU of the test box
 import naima_amd as na  # noqa: E402
 from bench import build_problem  # noqa: E402
-from naima_amd.dist import GlooComm  # noqa: E402
+from naima_amd.dist import HostComm  # noqa: E402
 from naima_amd.sampler import EnsembleSampler  # noqa: E402
 
 out = sys.argv[1]
-comm = GlooComm()
+comm = HostComm()  # (RCCL refuses two ranks on one GPU)
+assert "torch" not in sys.modules
 model, p0, raw, data, prior, labels = build_problem("cfg3", na)
 s = EnsembleSampler(32, 5, na.lnprob, args=[data, model, prior], seed=42, comm=comm,
                     naima_style=True, store_blobs=True, device=True)

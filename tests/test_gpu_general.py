@@ -269,6 +269,41 @@ def test_device_sampler_falls_back_for_grid_shaping_parameters(na):
     assert_allclose(np.asarray(sd.log_prob)[5], np.asarray(one[0]), rtol=1e-10)
 
 
+def test_device_sampler_falls_back_for_models_outside_naima_amd(na):
+    """models the reference accepts but that are not built from naima_amd's radiative
+    classes -- plain numpy arithmetic on the parameters, a functional model returning a
+    host array -- cannot run on device-resident parameters; get_sampler's default
+    device=True warns and samples them with the host loop instead of crashing"""
+    from bench import build_problem
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    _, p0, raw, data, prior, labels = build_problem("cfg1", na)
+    E = data["energy"].to("TeV").value
+
+    def numpy_model(pars, data):  # a power law written with numpy
+        amp = np.exp(np.asarray(pars[0]))
+        idx = np.asarray(pars[1])
+        f = amp[..., None] * E ** (-idx[..., None]) if amp.ndim else amp * E ** (-idx)
+        return f * u.Unit("1/(cm2 s TeV)")
+
+    def functional_model(pars, data):  # the particle-distribution class used as a function
+        pl = na.PowerLaw(10 ** pars[0] / u.Unit("cm2 s TeV"), 1 * u.TeV, pars[1])
+        return pl(data)
+
+    for model, start in ((numpy_model, np.array([-25.0, 2.3])),
+                         (functional_model, np.array([-11.0, 2.3]))):
+        kw = dict(args=[data, model, None], seed=2, naima_style=True)
+        pos = start * (1 + 0.01 * np.random.default_rng(0).standard_normal((8, 2)))
+        with pytest.warns(UserWarning, match="host-driven loop"):
+            d = EnsembleSampler(8, 2, na.lnprob, device=True, **kw)
+            sd = d.run_mcmc(pos, 3)
+        assert d.device is False
+        h = EnsembleSampler(8, 2, na.lnprob, **kw)
+        sh = h.run_mcmc(pos, 3)
+        assert_allclose(sd.coords, sh.coords, rtol=1e-12)
+        assert d.get_blobs()[0].shape == (3, 8, len(E))
+
+
 def test_trapz_loglog_intervals(na):
     """utils.trapz_loglog(..., intervals=True) (utils.py:350-351): the per-segment terms,
     along any axis, against the oracle; their sum is the integral"""

@@ -1,0 +1,111 @@
+"""Loop-level parity on EVERY BASELINE configuration (core.py:97-121, 128, 450-457).
+
+The device-resident step loop (k_step_front -> table reductions / synchrotron -> likelihood
++ accept, captured in hipGraphs, eight steps per launch) takes a different launch sequence
+per workload: single-row reductions (cfg1), three energy tiles and a separate likelihood
+launch (cfg2), the fused three-launch half-step (cfg3), the SSC seed inside the graph
+(cfg4), the signed LUT reduction with the likelihood as its epilogue (cfg5, and cfg5 with
+the analytic cross-section).  For each of them, at the per-GPU walker count bench.py
+uses, with blobs kept and not kept:
+
+  * device loop == host-driven loop on the same move stream, chain / log-prob / blobs /
+    acceptance, across a random-block boundary (32 steps) and through the multi-step graph;
+  * device loop == the NumPy oracle driving ``stretch_move_reference`` one walker at a
+    time (small ensembles: the oracle needs ~1 s per cfg4 evaluation).
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+# (id, workload, model kwargs, walkers per GPU in bench.py)
+CONFIGS = [("cfg1", "cfg1", {}, 32), ("cfg2", "cfg2", {}, 256), ("cfg3", "cfg3", {}, 512),
+           ("cfg4", "cfg4", {}, 256), ("cfg5-lut", "cfg5", {}, 256),
+           ("cfg5-analytic", "cfg5", {"useLUT": False}, 256)]
+
+
+@pytest.fixture(scope="module")
+def na():
+    import naima_amd
+    from naima_amd import _lib
+    _lib.get_context()
+    return naima_amd
+
+
+def _problem(na, name, mkw):
+    from bench import build_problem
+    from naima_amd import workloads as W
+    model, p0, raw, data, prior, labels = build_problem(name, na)
+    if mkw:  # same data, other evaluation mode of the model (cfg5: analytic cross-section)
+        model = W.WORKLOADS[name]["model"](na, **mkw)
+    return model, p0, raw, data, prior
+
+
+@pytest.mark.parametrize("store_blobs", [False, True], ids=["noblobs", "blobs"])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_device_loop_equals_host_loop(na, cfg, store_blobs):
+    from naima_amd.sampler import EnsembleSampler
+    _, name, mkw, nw = cfg
+    model, p0, raw, data, prior = _problem(na, name, mkw)
+    nd = p0.size
+    kw = dict(args=[data, model, prior], seed=31, naima_style=True, store_blobs=store_blobs)
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(5).standard_normal((nw, nd)))
+    first, more = (2, 8) if name == "cfg4" else (3, 37)  # 40 steps cross a 32-step block
+    sh, sd = h.run_mcmc(pos, first), d.run_mcmc(pos, first)
+    sh, sd = h.run_mcmc(sh, more), d.run_mcmc(sd, more)
+    assert d._dev is not None and d.device  # no silent fall-back to the host loop
+    assert d._dev.graph is not None or d._dev.step_graph is not None
+    assert_allclose(sd.coords, sh.coords, rtol=1e-8)
+    assert_allclose(sd.log_prob, sh.log_prob, rtol=1e-6)
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+    assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)
+    assert_allclose(d.acceptance_fraction, h.acceptance_fraction)
+    assert 0.05 < np.mean(d.acceptance_fraction) < 0.95
+    bh, bd = h.get_blobs(), d.get_blobs()
+    if store_blobs:
+        assert bd is not None and len(bd) == len(bh)
+        for x, y in zip(bd, bh):
+            x, y = np.asarray(x, dtype=float), np.asarray(y, dtype=float)
+            assert x.shape == y.shape and x.shape[:2] == (first + more, nw)
+            assert_allclose(x, y, rtol=1e-8, atol=1e-300, equal_nan=True)
+    else:
+        assert bd is None
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_device_loop_equals_oracle_driven_sampler(na, cfg):
+    """>= 4 ensemble steps of the device loop against oracle.stretch_move_reference fed with
+    the same move stream and the oracle's lnprob (NumPy, one walker at a time)"""
+    from naima_amd._lib import Moves
+    from naima_amd.sampler import EnsembleSampler
+    from oracle import naima_np as O
+    from oracle import workloads_np as WN
+    _, name, mkw, _ = cfg
+    model, p0, raw, data, prior = _problem(na, name, mkw)
+    nd = p0.size
+    nw, nsteps = 2 * nd + 2, 4
+    s = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=17,
+                        naima_style=True, store_blobs=False, device=True)
+    start = p0 * (1 + 0.003 * np.random.default_rng(9).standard_normal((nw, nd)))
+    st = s.run_mcmc(start, nsteps)
+    assert s._dev is not None and s.device
+
+    def oprior(q):
+        return 0.0 if prior is None else float(np.asarray(prior(q)))
+
+    def lnp(x):
+        return np.array([WN.lnprob(name, p, raw, prior=oprior, **mkw)[0]
+                         for p in np.atleast_2d(x)])
+
+    m = Moves(17, nw, 2.0, ksteps=32, depth=4)
+    addr, got = m.take(nsteps)
+    S, P, Z, L = m.view(addr, got)
+    c, l = start.copy(), lnp(start)
+    for k in range(nsteps):
+        c, l, _ = O.stretch_move_reference(c, l, lnp, S[k], P[k], Z[k], L[k])
+    assert_allclose(st.coords, c, rtol=1e-8)
+    assert_allclose(st.log_prob, l, rtol=1e-6)
+    assert_allclose(s.get_chain()[-1], c, rtol=1e-8)

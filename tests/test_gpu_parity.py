@@ -331,7 +331,7 @@ def test_lazy_device_values(na):
     assert_allclose(np.asarray(lp), ref, rtol=1e-14)
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_device_lnprob_equals_host_lnprob(na, golden, name):
     """the same unchanged model function on device-resident parameters"""
     from naima_amd._lib import get_context
@@ -612,7 +612,7 @@ def test_abi_step_front_and_lnprob_accept(na):
     ctx.call("nh_lnprob_accept", comps, 1, ns, nE, one, flux, err, err, ul, cl, None, None, 0,
              None, tot, C.addressof(mv))
     assert_allclose(tot.get(), tot_ref.get(), rtol=0)
-    assert 0 < acc1.get().sum() < ns or True
+    assert 0 <= acc1.get().sum() <= ns
     assert_allclose(acc1.get(), acc2.get())
     assert_allclose(sel1.get(), sel2.get())
     assert_allclose(nacc1.get(), nacc2.get())

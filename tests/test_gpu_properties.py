@@ -125,7 +125,10 @@ def test_zero_residual_likelihood(na):
 
 def test_full_size_device_loop_equals_host_loop(na):
     """512 walkers, the sampler of bench.py: device-resident loop (fused launches, graphs,
-    chain kept on the device) against the host-driven loop on the same move stream"""
+    chain kept on the device) against the host-driven loop on the same move stream.  240
+    steps in ONE run_mcmc: eight blocks of the move generator's pinned ring (depth 4) go by
+    while the GPU lags the host by whole blocks -- an upload whose source block had been
+    handed back to the generator too early would tear the stream"""
     from bench import build_problem
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior, labels = build_problem("cfg3", na)
@@ -134,7 +137,8 @@ def test_full_size_device_loop_equals_host_loop(na):
     d = EnsembleSampler(512, 5, na.lnprob, device=True, **kw)
     pos = p0 * (1 + 0.005 * np.random.default_rng(0).standard_normal((512, 5)))
     sh, sd = h.run_mcmc(pos, 3), d.run_mcmc(pos, 3)
-    sh, sd = h.run_mcmc(sh, 40), d.run_mcmc(sd, 40)
+    sd = d.run_mcmc(sd, 240)  # (the device loop first: nothing slows the host down)
+    sh = h.run_mcmc(sh, 240)
     assert_allclose(sd.coords, sh.coords, rtol=1e-8)
     assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
     assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)

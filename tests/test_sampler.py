@@ -79,7 +79,7 @@ def test_reference_move_restatement_agrees():
         c, l, _ = O.stretch_move_reference(c, l, lp, S[k], P[k], Z[k], L[k])
     assert_allclose(st.coords, c)
     assert_allclose(st.log_prob, l)
-    m2 = Moves(9, 16, 2.0, ksteps=3, depth=2)  # other blocking, one step at a time
+    m2 = Moves(9, 16, 2.0, ksteps=3, depth=3)  # other blocking, one step at a time
     for k in range(5):
         a2, g2 = m2.take(1)
         S2, P2, Z2, L2 = m2.view(a2, g2)
@@ -90,6 +90,33 @@ def test_reference_move_restatement_agrees():
         assert sorted(np.concatenate([S[k, 0], S[k, 1]])) == list(range(16))
         assert np.isin(P[k, 0], S[k, 1]).all() and np.isin(P[k, 1], S[k, 0]).all()
     assert (Z >= 0.5).all() and (Z <= 2.0).all() and (L <= 0).all()
+
+
+def test_move_ring_keeps_the_previous_block_intact():
+    """nh_moves_take's lifetime contract (the device loop ships a block with an asynchronous
+    copy and takes the next one while that copy may still be queued): the memory of take
+    j-1 is untouched while take j is current -- the producer gets block j-1 back only when
+    the consumer moves on to j+1 -- whatever the blocking and however eager the producer"""
+    import time
+
+    from naima_amd._lib import Moves
+    for ks, depth, takes in ((4, 3, (4,) * 12), (4, 4, (4,) * 12), (5, 3, (2, 3, 5, 1, 4, 5, 5))):
+        ref = Moves(77, 64, 2.0, ksteps=64, depth=3)
+        a, g = ref.take(sum(takes))
+        want = np.concatenate([v.reshape(g, -1) for v in ref.view(a, g)], axis=1).copy()
+        m = Moves(77, 64, 2.0, ksteps=ks, depth=depth)
+        prev, done = None, 0
+        for t in takes:
+            addr, got = m.take(t)
+            assert got == t  # (the takes above never straddle a block)
+            time.sleep(0.01)  # let the producer run as far ahead as the ring allows
+            cur = np.concatenate([v.reshape(got, -1) for v in m.view(addr, got)], axis=1)
+            assert_allclose(cur, want[done:done + got])
+            if prev is not None:  # the previous take's memory, read again NOW
+                pa, pg, pd = prev
+                old = np.concatenate([v.reshape(pg, -1) for v in m.view(pa, pg)], axis=1)
+                assert_allclose(old, want[pd:pd + pg])
+            prev, done = (addr, got, done), done + got
 
 
 def test_naima_style_with_oracle_model(golden):
@@ -115,9 +142,15 @@ WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
-from naima_amd.dist import GlooComm
 from naima_amd.sampler import EnsembleSampler
-comm = GlooComm()
+if %(backend)r == "gloo":
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    from gloo_comm import GlooComm
+    comm = GlooComm()
+else:
+    from naima_amd import dist
+    comm = dist.from_env("host")
+    assert type(comm).__name__ == "HostComm" and "torch" not in sys.modules
 calls = []
 def lp(x):
     calls.append(len(x))
@@ -128,17 +161,26 @@ st = s.run_mcmc(p0, 25)
 np.save(os.path.join(%(out)r, "coords_%%d.npy" %% comm.rank), st.coords)
 np.save(os.path.join(%(out)r, "logp_%%d.npy" %% comm.rank), st.log_prob)
 np.save(os.path.join(%(out)r, "calls_%%d.npy" %% comm.rank), np.array(calls))
+# the blob of this log-probability is a function of the position: every rank holds the
+# blob that belongs to every walker's CURRENT position, whoever evaluated it
+blob = s.get_blobs()[0]
+assert blob.shape == (25, 30)
+np.testing.assert_allclose(blob, s.get_chain().sum(axis=2), rtol=1e-13)
 g = comm.allgather(np.full((2, 3), float(comm.rank)))
 assert g.shape == (4, 3) and g[0, 0] == 0 and g[3, 0] == 1
 assert comm.max(comm.rank) == 1.0
+comm.barrier()
 '''
 
 
-def test_two_ranks_gloo_match_single_process(tmp_path):
-    """world_size 2 over gloo: each rank evaluates its shard, one all-gather per
-    half-step, and the ensemble is identical on both ranks and to a 1-rank run"""
+@pytest.mark.parametrize("backend", ["gloo", "host"])
+def test_two_ranks_gloo_match_single_process(tmp_path, backend):
+    """world_size 2 -- over torch.distributed/gloo (test-only helper tests/gloo_comm.py) and
+    over the product's own torch-free control plane (dist.HostComm): each rank evaluates
+    its shard, one all-gather per half-step, and the ensemble is identical on both ranks
+    and to a 1-rank run"""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
+    script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path), "backend": backend})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     port = 29500 + (os.getpid() % 2000)
     subprocess.check_call(
