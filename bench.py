@@ -3,13 +3,18 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--walkers 512]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --gpus 8 --scaling strong --workload cfg5 --walkers-total 2048   (BASELINE's
+        multi-GPU configurations: cfg5 2048 walkers over 8 GPUs, cfg4 1024 over 4)
 
 One "step" = one ensemble step of the stretch-move sampler = two half-steps =
 ``walkers`` evaluations of naima's lnprob (model + likelihood) for ``cfg3``, the
 configuration BASELINE.json quotes the metric on: RXJ1713 Syn+IC joint fit, 5
 parameters, CMB+FIR+NIR seed fields, 64 photon energies, 512 walkers per GPU
-(weak scaling: every rank adds its own 512 walkers to the ensemble).  Synthetic
-spectrum (seed 20260929), inputs resident in HBM before the timed region.
+(weak scaling, the default: every rank adds its own 512 walkers to the ensemble;
+``--scaling strong`` keeps the ensemble fixed and splits it).  Synthetic spectrum (seed
+20260929), inputs resident in HBM before the timed region.  The timed region is EXACTLY
+K steps between barriers; it is repeated until >= 0.5 s have been timed and ``value`` is
+the median region (min / max / first in ``timing``).
 
 Prints ONE JSON line on rank 0 with the contract keys plus
   "roofline"      the dominant kernel, from HIP events recorded around every launch
@@ -47,7 +52,8 @@ KERNEL_FLOP_EQ = {
     "cfg5": {"integrate_tables": 28 * 600 * 30.0},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
-KERNEL_SYMBOL = {"integrate_tables": "k_integrate_tables", "synchrotron": "k_synchrotron",
+KERNEL_SYMBOL = {"half_step": "k_half_step", "integrate_tables": "k_integrate_tables",
+                 "synchrotron": "k_synchrotron",
                  "particle_weights": "k_step_front (proposal+packs+weights+We)", "lnprob": "k_lnprobmodel",
                  "integrate_rows": "k_integrate_rows", "ic_seed_walkers": "k_ic_seed_walkers",
                  "tables": "k_table_*", "glue": "k_pack_rows/k_move_*"}
@@ -87,6 +93,30 @@ def build_problem(name, na):
     return model, p0, raw, make_data(raw), W.prior_for(name, na), wl["labels"]
 
 
+def executed_flop_eq(name, raw, coords):
+    """flop-equivalents per walker that the hot kernels actually EXECUTE (mean over the
+    ensemble ``coords``): the table reductions visit every segment; the synchrotron kernel
+    only the (energy, gamma) nodes with x = E/Ec(gamma, B) <= 746 (nh_synchrotron.hip: the
+    liveness search), which depends on each walker's B"""
+    out = dict(KERNEL_FLOP_EQ.get(name, {}))
+    if "synchrotron" not in out:
+        return out
+    from naima_amd import constants as K
+    # (Eemin, Eemax, nEed) of the workload's Synchrotron grid and the index of B [uG]
+    lo, hi, per, iB = {"cfg2": (1e9, 1e15, 50, 3), "cfg3": (1e9, 1e9 * K.MEC2_EV, 100, 3)}[name]
+    l0, l1 = np.log10(lo / K.MEC2_EV), np.log10(hi / K.MEC2_EV)
+    gam = np.logspace(l0, l1, max(10, int(per * (l1 - l0))))
+    E_eV = np.asarray(raw["energy"], dtype=float) * {"eV": 1.0, "keV": 1e3, "MeV": 1e6,
+                                                     "GeV": 1e9, "TeV": 1e12}[raw["energy_unit"]]
+    B = np.abs(np.asarray(coords)[:, iB]) * 1e-6
+    qfac = K.ERG_PER_EV * 2.0 * K.M_E_G * K.C_CGS / (3.0 * K.E_GAUSS * K.HBAR_CGS * B)  # [N]
+    x = (E_eV[None, :, None] * qfac[:, None, None]) / gam[None, None, :] ** 2           # [N][nE][nG]
+    live = (x <= 746.0).sum(axis=2)               # nodes from the first live one on
+    nodes = np.where(live > 0, np.minimum(live + 1, gam.size), 0).sum(axis=1)  # + its left neighbour
+    out["synchrotron"] = float(nodes.mean()) * 50.0
+    return out
+
+
 def _cpu_worker(args):
     name, raw, pars, seconds = args
     from oracle import workloads_np as WN
@@ -109,6 +139,21 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    """CPU model name, sockets and logical CPUs of this host (/proc/cpuinfo)"""
+    model, phys, n = "unknown", set(), 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                n += 1
+            elif line.startswith("physical id"):
+                phys.add(line.split(":", 1)[1].strip())
+    except OSError:
+        pass
+    return {"cpu_model": model, "sockets": max(1, len(phys)), "logical_cpus": n}
+
+
 def cpu_baseline(name, raw, p0, seconds=8.0):
     """the oracle timed single-core and on a Pool over all host cores (the
     reference's own parallel mode, core.py:446-448)"""
@@ -125,7 +170,7 @@ def cpu_baseline(name, raw, p0, seconds=8.0):
         wall = time.perf_counter() - t0
     total = sum(r[0] for r in res)
     return {"value": total / wall, "unit": "walker-steps/s", "cores": cores, "kind": "port",
-            "single_core": n1 / t1,
+            "single_core": n1 / t1, **cpu_model(),
             "sample": "%d lnprob evaluations of %s by the NumPy oracle over %d processes in "
                       "%.1f s (+%d on one core in %.1f s)" % (total, name, cores, wall, n1, t1)}
 
@@ -137,6 +182,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --walkers per GPU (default); strong: --walkers-total split over the GPUs")
+    ap.add_argument("--walkers-total", type=int, default=None,
+                    help="strong scaling: size of the whole ensemble (default: the workload's "
+                         "BASELINE figure -- cfg5 2048, cfg4 1024, cfg3 512)")
+    ap.add_argument("--ball", type=float, default=0.1,
+                    help="relative spread of the initial ensemble around p0 (naima: 10 %%, core.py:477-481)")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="repeat the K-step timed region until this many seconds have been timed")
+    ap.add_argument("--no-blobs-run", action="store_true",
+                    help="skip the extra store_blobs=True measurement")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-chain", action="store_true",
                     help="do not keep the chain (emcee's store=False); default keeps it in HBM")
@@ -160,27 +216,32 @@ def main():
     comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # host: test hook
     name = args.workload
     model, p0, raw, data, prior, labels = build_problem(name, na)
-    per_gpu = args.walkers or W.WORKLOADS[name]["nwalkers"]
-    if name in ("cfg4", "cfg5") and args.walkers is None:
-        per_gpu = 256
-    nwalkers = per_gpu * comm.size
+    if args.scaling == "strong":
+        nwalkers = args.walkers_total or W.WORKLOADS[name]["nwalkers"]
+        if nwalkers % (2 * comm.size):
+            raise SystemExit("--walkers-total %d does not split into two halves over %d GPUs"
+                             % (nwalkers, comm.size))
+        per_gpu = nwalkers // comm.size
+    else:
+        per_gpu = args.walkers or (256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"])
+        nwalkers = per_gpu * comm.size
 
-    def make_sampler(device, graph):
+    def make_sampler(device, graph, blobs=False):
         return EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
-                               seed=20260929, comm=comm, naima_style=True, store_blobs=False,
+                               seed=20260929, comm=comm, naima_style=True, store_blobs=blobs,
                                device=device, use_graph=graph)
 
     device = not args.host_loop
     sampler = make_sampler(device, not args.no_graph)
-    pos = p0 * (1 + 0.005 * sampler._rng.normal(size=(nwalkers, p0.size)))
+    # naima's initial ensemble: a ball of 10 % of p0 around p0 (core.py:477-481)
+    pos = p0 + args.ball * p0 * sampler._rng.normal(size=(nwalkers, p0.size))
     state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
     ctx.sync()
     # Spin-up, untimed and reported as config.untimed_spinup_steps: the first ~20 ms after
     # an idle period run measurably slower (device clocks ramp, first replays of the
-    # multi-step graph), measured 3.1e6 -> 4.4e6 walker-steps/s between --warmup 5 and
-    # --warmup 100.  A short --warmup is topped up to 160 steps (at most 0.5 s of them, judged
-    # by eight steps timed after the warm-up -- the warm-up itself contains one-off set-up);
-    # every rank takes the same number so the collectives stay matched.
+    # multi-step graph).  A short --warmup is topped up to 160 steps (at most 0.5 s of them,
+    # judged by eight steps timed after the warm-up -- the warm-up itself contains one-off
+    # set-up); every rank takes the same number so the collectives stay matched.
     spinup = 0
     if device:
         tw = time.perf_counter()
@@ -191,25 +252,53 @@ def main():
         if spinup > 8:
             state = sampler.run_mcmc(state, spinup - 8, store=False)
 
-    # ---- the timed region: K ensemble steps, barrier + device sync on both sides
-    comm.barrier()
-    ctx.sync()
-    t0 = time.perf_counter()
-    state = sampler.run_mcmc(state, args.steps, store=not args.no_chain)
-    ctx.sync()
-    comm.barrier()
-    dt = comm.max(time.perf_counter() - t0)
+    # ---- the timed region: EXACTLY K ensemble steps, barrier + device sync on both sides.
+    # Repeated (every rank the same number of times) until --min-time seconds have been
+    # timed: a 20-step region of cfg3 lasts 2 ms, which is noise.
+    def timed_region(smp, st):
+        comm.barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        st = smp.run_mcmc(st, args.steps, store=not args.no_chain)
+        ctx.sync()
+        comm.barrier()
+        return comm.max(time.perf_counter() - t0), st
+
+    first, state = timed_region(sampler, state)
     acc_frac = float(np.mean(sampler.acceptance_fraction))
+    sampler.reset()  # (the chain of a region is dropped before the next one)
+    times = [first]
+    nrep = int(min(400, max(0, np.ceil((args.min_time - first) / max(first, 1e-6)))))
+    for _ in range(nrep):
+        dt_i, state = timed_region(sampler, state)
+        times.append(dt_i)
+        sampler.reset()
+    dt = float(np.median(times))
+    final_coords = np.asarray(state.coords)
+
+    # ---- the same loop keeping blobs (the reference always stores (flux, We) per walker
+    # and step, core.py:450-457): reported in an extra key
+    blobs_value = None
+    if device and not args.no_blobs_run:
+        bs = make_sampler(device, not args.no_graph, blobs=True)
+        bst = bs.run_mcmc(final_coords, 6, store=False)
+        bt = []
+        for _ in range(int(min(40, max(1, np.ceil(args.min_time / 2 / max(dt, 1e-6)))))):
+            dt_i, bst = timed_region(bs, bst)
+            bt.append(dt_i)
+            bs.reset()
+        blobs_value = nwalkers * args.steps / float(np.median(bt))
+        del bs, bst
 
     # ---- per-kernel HIP-event timing: hipGraph replay hides the launches from
     # events, so the SAME launch sequence is run eagerly (device loop, no graph)
     # with an event pair around every launch, for the same number of steps
     prof_sampler = make_sampler(device, False)
-    pstate = prof_sampler.run_mcmc(pos, 2, store=False)
+    pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
     ctx.sync()
     ctx.profile(True)
     ctx.profile_read(reset=True)
-    prof_sampler.run_mcmc(pstate, args.steps, store=False)
+    prof_sampler.run_mcmc(pstate, max(args.steps, 50), store=False)
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
     ev_us = ctx.profile_overhead_us()  # what an event pair adds to every launch
@@ -238,7 +327,7 @@ def main():
         "metric": "walker-steps/sec (ensemble lnprob evals/s)",
         "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: %s" % (name, {
             "cfg1": "ECPL -> IC(CMB), 28 energies",
@@ -246,8 +335,10 @@ def main():
             "cfg3": "RXJ1713 Syn+IC joint fit (CMB+FIR+NIR), 5 parameters, 64 energies",
             "cfg4": "Crab Syn+SSC, 261 energies, 869-pt Ee grid, 100 seed energies",
             "cfg5": "PionDecay ECBPL, 28 energies, 600-pt Ep grid"}[name]),
+            "scaling": args.scaling,
             "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
             "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
+            "initial_ball": args.ball,
             "device": info["name"], "untimed_spinup_steps": spinup,
             "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
                            "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
@@ -255,6 +346,14 @@ def main():
             if device else "host loop",
             "chain": "discarded (store=False)" if args.no_chain else
             "kept: every step's coords and log-prob appended in HBM by the step kernels"},
+        "timing": {"regions": len(times), "steps_per_region": args.steps,
+                   "statistic": "median region (every region: barrier + sync, K steps, sync + "
+                                "barrier, max over ranks)",
+                   "timed_s_total": float(np.sum(times)),
+                   "value_first_region": nwalkers * args.steps / times[0],
+                   "value_min": nwalkers * args.steps / max(times),
+                   "value_max": nwalkers * args.steps / min(times)},
+        "value_store_blobs": blobs_value,
         "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
@@ -269,22 +368,31 @@ def main():
                              "of the 8 XCD L2s pulls its own copy of the shared emission table)"},
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
-        "eager_kernel_time_frac": sum(v["ms"] for v in prof.values()) * 1e-3 / dt,
         "acceptance_fraction": acc_frac,
         "loop": ("host" if not device else ("device+hipGraph" if sampler._dev.graph is not None
                                             else "device")),
     }
     fp = {}
-    for cat, kflop in KERNEL_FLOP_EQ.get(name, {}).items():
+    executed = executed_flop_eq(name, raw, final_coords)
+    if "half_step" in prof:  # one launch does the table reductions AND the synchrotron nodes
+        executed = {"half_step": sum(executed.values())}
+        KERNEL_FLOP_EQ[name]["half_step"] = sum(KERNEL_FLOP_EQ[name].values())
+    for cat, kflop in executed.items():
         if cat in prof:
             t = launch_us(cat) * 1e-6
             tf = kflop * walkers_per_launch / t / 1e12
             fp[KERNEL_SYMBOL[cat]] = {"achieved": tf, "frac": tf / FP64_VEC_PEAK_TF,
-                                      "avg_launch_us": t * 1e6}
+                                      "avg_launch_us": t * 1e6,
+                                      "flop_eq_per_walker": kflop,
+                                      "flop_eq_per_walker_all_nodes": KERNEL_FLOP_EQ[name][cat]}
     if fp:
         out["fp64_valu"] = {"peak": FP64_VEC_PEAK_TF, "unit": "TFLOP-eq/s", "kernels": fp,
                             "convention": "SURVEY.md 8d: transcendental = 20 flop-eq; "
-                                          "Synchrotron node 50, table-reduction segment 30"}
+                                          "Synchrotron node 50, table-reduction segment 30.  "
+                                          "EXECUTED nodes only: the synchrotron kernel skips "
+                                          "every (energy, gamma) node with E/Ec > 746 "
+                                          "(exp(-x) == 0 in double) -- counted on the host "
+                                          "from the final ensemble's B, mean over walkers"}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out), flush=True)

@@ -92,7 +92,8 @@ int nh_timer_stop(nh_ctx* ctx, double* elapsed_ms);
 /* per-kernel accumulated HIP-event time since the last reset; kernel ids NH_K_* */
 enum { NH_K_PDIST = 0, NH_K_INTEGRATE = 1, NH_K_SYNCHROTRON = 2, NH_K_TABLES = 3,
        NH_K_LNPROB = 4, NH_K_SSC = 5, NH_K_GLUE = 6 /* pack, move, scatter, lincomb */,
-       NH_K_ROWS = 7 /* k_integrate_rows (We/Wp) */, NH_K_COUNT = 8 };
+       NH_K_ROWS = 7 /* k_integrate_rows (We/Wp) */,
+       NH_K_HALFSTEP = 8 /* k_half_step: the whole half-step in one launch */, NH_K_COUNT = 9 };
 int nh_profile_enable(nh_ctx* ctx, int on);
 /* HIP-event time of an empty kernel: the fixed cost an event pair adds per launch */
 int nh_profile_calibrate(nh_ctx* ctx, int reps, double* overhead_us);
@@ -361,6 +362,61 @@ int nh_stream_fork_at(nh_ctx* ctx, int side, void* marker);
 int nh_stream_switch(nh_ctx* ctx, int side);
 int nh_stream_wait(nh_ctx* ctx, int waiter, int producer);
 int nh_stream_join(nh_ctx* ctx);
+
+/* ---- ONE launch per half-step ---------------------------------------------------------
+ * nh_step_front + every table reduction of the model + its synchrotron component +
+ * nh_lnprob (+ the accept of nh_lnprob_accept when do_accept) for the proposed walkers
+ * [lo, lo+nloc) of slice cursor[0]+1, one workgroup per walker: emcee's
+ * StretchMove.get_proposal / RedBlueMove.propose around core.py:97-121 around
+ * radiative.py:282-342, 657-710, 1495-1536.  The particle weights stay in LDS (they are
+ * also written to grids[].w/.dlw when write_weights), every spectrum is written to its
+ * `out` as the separate entry points would.  Slice protocol as nh_step_front, except that
+ * the slice proposed is the slice accepted (no look-ahead): cursor[0] = slice evaluated
+ * last, advanced by the launch.  hist->n counts the closed ensemble steps (the launch that
+ * accepts an odd slice increments it); the history row n - 1 of the step closed last is
+ * written by the NEXT launch of the same block of moves (cursor odd, >= 1); after the last
+ * half-step of a block, and whenever the chain may be read, the caller writes it with
+ * nh_hist_append(row = -1) (writing a row twice is harmless).  The descriptor is copied to the device once (nh_half_step_create);
+ * a launch takes no other argument, so it can be captured into a hipGraph and replayed. */
+typedef struct { int grid; int nK; int ldo; int nonnegative;
+                 const double* Kt; const double* dlnKt; const double* scale /*[nK] or NULL*/;
+                 double* out /*[nloc][ldo]*/; } nh_hs_table;
+typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
+                 int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB; int pad;
+                 const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;
+                 double* out /*[nloc][ldo]*/; } nh_hs_syn;
+#define NH_HS_MAX_TAB 4
+typedef struct {
+  double* coords; double* logp; const double* blk; int* cursor; int* done;
+  int ns, ndim, lo, nloc;
+  double* qT; double* factors; nh_hist* hist /* device, or NULL */;
+  int* accepted; int* naccepted; int* sel;
+  int do_accept;      /* 1: single rank, the launch accepts; 0: total[] only (sharded loop) */
+  int write_weights;  /* also store w / dlw in grids[].w / .dlw */
+  nh_pack packs[NH_MAX_PACK]; int npacks;
+  int kind; const double* params;
+  nh_grid grids[NH_MAX_GRIDS]; int ngrids;
+  nh_moment moms[NH_MAX_MOMENT]; int nmoms;
+  nh_hs_table tab[NH_HS_MAX_TAB]; int ntab;
+  nh_hs_syn syn;
+  nh_comp comps[NH_MAX_COMP]; int ncomp; int nE;
+  const double* conv; const double* flux; const double* err_lo; const double* err_hi;
+  const int* ul; const double* cl; const double* lp /* [nloc] or NULL */;
+  nh_prior terms[NH_MAX_PRIOR]; int nterms;
+  double* model_out /* [nloc][nE] or NULL */; double* total /* [nloc] */;
+} nh_hs_desc;
+typedef struct nh_halfstep_plan nh_halfstep_plan;
+int nh_half_step_create(nh_ctx* ctx, const nh_hs_desc* desc /*host*/, nh_halfstep_plan** out);
+int nh_half_step_launch(nh_ctx* ctx, nh_halfstep_plan* plan);
+int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
+                      long long* lds_bytes);
+int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
+/* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the
+ * first 8 workgroups of the last launch, out[8][16]; all zero otherwise */
+int nh_half_step_stamps(nh_ctx* ctx, const nh_halfstep_plan* plan, long long* out);
+/* row `row` (-1: hist->n - 1) of the device-resident history := coords[N][ndim] / logp[N] */
+int nh_hist_append(nh_ctx* ctx, const double* coords, const double* logp, long long N, int ndim,
+                   const nh_hist* hist /*device*/, long long row);
 
 /* host-side generator of the move's random numbers: a worker thread fills a ring of
  * (page-locked) blocks ahead of the consumer, in exactly the slice layout above.  The

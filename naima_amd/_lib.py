@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnaima_hip.so")
 
 NH_PD_NPAR = 8
 NH_K_NAMES = ("particle_weights", "integrate_tables", "synchrotron", "tables", "lnprob",
-              "ic_seed_walkers", "glue", "integrate_rows")
+              "ic_seed_walkers", "glue", "integrate_rows", "half_step")
 PD_KIND = {"PowerLaw": 0, "ExponentialCutoffPowerLaw": 1, "BrokenPowerLaw": 2,
            "ExponentialCutoffBrokenPowerLaw": 3, "LogParabola": 4}
 PP_MODEL = {"Geant4": 0, "Pythia8": 1, "SIBYLL": 2, "QGSJET": 3}
@@ -97,6 +97,12 @@ _SIGS = {
     "nh_comm_init": [_dp, _i, _i, C.c_char_p],
     "nh_comm_destroy": [_dp],
     "nh_comm_allgather": [_dp, _dp, _dp, _ll],
+    "nh_half_step_create": [_dp, _dp, C.POINTER(_dp)],
+    "nh_half_step_launch": [_dp, _dp],
+    "nh_half_step_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
+    "nh_half_step_destroy": [_dp, _dp],
+    "nh_half_step_stamps": [_dp, _dp, _dp],
+    "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
 }
 EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")
 
@@ -235,6 +241,7 @@ class Context:
         self._lx = {}
         self._lne = {}
         self._plan = None
+        self._in_eval = False
         self._accept_hook = None
         self._cap_pool = {}
         self._retained = []
@@ -321,7 +328,8 @@ class Context:
     # REPLAY mode a request only checks that it is the recorded one and returns its
     # buffers.
     def plan_begin(self):
-        self._plan = dict(mode="record", packs=[], weights=[], moments=[], i=[0, 0, 0])
+        self._plan = dict(mode="record", packs=[], weights=[], moments=[], i=[0, 0, 0, 0],
+                          emit=[], calls=[], mega=False, hs=None)
         return self._plan
 
     def _replayed(self, kind, slot, key):
@@ -391,6 +399,137 @@ class Context:
         out = self.empty((N, 1))
         self.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, 1, None, out, 1, 0, 1)
         return self._recorded("moments", key, out)
+
+    # -- emission launches of a model evaluation ------------------------------------------
+    # In the one-launch-per-half-step mode of the device loop (plan["mega"]) these are not
+    # launched at all: nh_half_step produces every spectrum of the model, into buffers that
+    # belong to the plan.  While a half-step is RECORDED they run as usual and leave their
+    # arguments in plan["emit"]; outside the step loop they are plain launches.
+    def _emit_replayed(self, kind, key, shape):
+        plan = self._plan
+        i = plan["i"][3]
+        if i >= len(plan["emit"]) or plan["emit"][i]["key"] != key:
+            raise NaimaHipError("the model's launch sequence changed between evaluations (%s); "
+                                "run the sampler with use_graph=False" % kind)
+        plan["i"][3] = i + 1
+        ent = plan["emit"][i]
+        if ent["out"] is None:
+            ent["out"] = self.empty(shape)
+        return ent["out"]
+
+    def emit_tables(self, w, lw, N, nG, lx, Kt, dlnKt, nK, scale, nonneg, may_split=True):
+        """out[N][nK] = scale[k] * trapz_loglog(n K_k, x) for every walker (nh_integrate_tables).
+        Returns (out, nsplit): out has nsplit planes of N rows that the consumer adds."""
+        plan = self._plan
+        key = ("tab", w.ptr, lw.ptr, N, nG, lx.ptr, Kt.ptr, dlnKt.ptr, nK,
+               scale.ptr if scale is not None else 0, int(nonneg))
+        if plan is not None and plan["mega"] and plan["mode"] == "replay":
+            return self._emit_replayed("tables", key, (N, nK)), 1
+        ns = _lib.nh_integrate_tables_nsplit(N, nG, nK) if may_split else 1
+        out = self.empty((ns * N, nK))
+        args = (w, lw, N, nG, lx, Kt, dlnKt, nK, scale, out, nK, int(nonneg), ns)
+        if plan is not None and plan["mode"] == "record":
+            plan["emit"].append(dict(kind="tab", key=key, out=None, N=N,
+                                     keep=(w, lw, lx, Kt, dlnKt, scale)))
+        hook = self._accept_hook
+        if hook is not None and not hook["used"] and hook["N"] == N and nK <= 64 and ns == 1 \
+                and not self._deferred:
+            # device step loop: hold the launch back, the likelihood may ride on it
+            self.defer(out, "nh_integrate_tables", args)
+        else:
+            self.call("nh_integrate_tables", *args)
+        return out, ns
+
+    def emit_synchrotron(self, w, lw, Bp, ldB, N, gd, lx, nG, Ed, nE, keep=()):
+        """out[N][nE] = Synchrotron._spectrum of every walker (nh_synchrotron)"""
+        plan = self._plan
+        key = ("syn", w.ptr, lw.ptr, int(Bp), int(ldB), N, gd.ptr, lx.ptr, nG, Ed.ptr, nE)
+        if plan is not None and plan["mega"] and plan["mode"] == "replay":
+            return self._emit_replayed("synchrotron", key, (N, nE))
+        out = self.empty((N, nE))
+        args = (w, lw, Bp, ldB, N, gd, lx, nG, Ed, nE, out, nE)
+        if plan is not None and plan["mode"] == "record":
+            plan["emit"].append(dict(kind="syn", key=key, out=None, N=N, keep=(w, lw, gd, lx, Ed) + tuple(keep)))
+        hook = self._accept_hook
+        if hook is not None and not hook["used"] and hook["N"] == N and nE <= 64 \
+                and not self._deferred:
+            self.defer(out, "nh_synchrotron", args, keep=keep)
+        else:
+            self.call("nh_synchrotron", *args)
+        return out
+
+    def half_step(self, hook, comps, ncomp, nE, conv, dd, lpd, terms, nterms, total):
+        """the plan's nh_half_step launch: everything the recorded model evaluation asked
+        for plus the likelihood of ``comps`` (created on first use, then checked and reused)"""
+        import ctypes as C
+
+        from . import darray as D
+        plan = self._plan
+        if plan["i"][3] != len(plan["emit"]):
+            raise NaimaHipError("the model's launch sequence changed between evaluations "
+                                "(fewer emission components); run with use_graph=False")
+        key = (bytes(C.string_at(C.addressof(comps), C.sizeof(comps))), ncomp, nE, conv.ptr,
+               lpd.ptr if lpd is not None else 0,
+               bytes(C.string_at(C.addressof(terms), C.sizeof(terms))) if nterms else b"",
+               total.ptr)
+        hs = plan["hs"]
+        if hs is not None:
+            if hs["key"] != key:
+                raise NaimaHipError("the model's likelihood inputs changed between evaluations; "
+                                    "run the sampler with use_graph=False")
+            self.call("nh_half_step_launch", hs["plan"])
+            return
+        f = plan["front"]  # filled in by the device loop when it chose this mode
+        d = D.nh_hs_desc()
+        for name in ("coords", "logp", "blk", "cursor", "done", "qT", "factors", "hist",
+                     "accepted", "naccepted", "sel"):
+            setattr(d, name, f[name])
+        d.ns, d.ndim, d.lo, d.nloc = f["ns"], f["ndim"], f["lo"], f["nloc"]
+        d.do_accept, d.write_weights = int(hook["mv"] is not None), 0
+        pk, npk, kind, rows_ptr, gd, ngr, mm, nmm = f["front_args"]
+        for q in range(npk):
+            d.packs[q] = pk[q]
+        d.npacks, d.kind, d.params = npk, kind, rows_ptr
+        wgrid = {}
+        for g in range(ngr):
+            d.grids[g] = gd[g]
+            wgrid[gd[g].w] = g
+        d.ngrids = ngr
+        for q in range(nmm):
+            d.moms[q] = mm[q]
+        d.nmoms = nmm
+        d.syn.grid = -1
+        nt = 0
+        for ent in plan["emit"]:
+            k = ent["key"]
+            if ent["kind"] == "tab":
+                _, w, lw, N, nG, lx, Kt, dKt, nK, sc, nonneg = k
+                d.tab[nt] = D.nh_hs_table(wgrid[w], nK, nK, nonneg, Kt, dKt, sc or None,
+                                          ent["out"].ptr)
+                nt += 1
+            else:
+                _, w, lw, Bp, ldB, N, gdp, lx, nG, Ed, nEs = k
+                in_rows = ldB == NH_PD_NPAR and 0 <= Bp - rows_ptr < 8 * NH_PD_NPAR
+                d.syn = D.nh_hs_syn(wgrid[w], nEs, nEs, (Bp - rows_ptr) // 8 if in_rows else -1,
+                                    ldB, 0, Ed, None if in_rows else Bp, ent["out"].ptr)
+        d.ntab = nt
+        for q in range(ncomp):
+            d.comps[q] = comps[q]
+        d.ncomp, d.nE = ncomp, nE
+        d.conv, d.flux, d.err_lo, d.err_hi = conv.ptr, dd.flux.ptr, dd.elo.ptr, dd.ehi.ptr
+        d.ul, d.cl = dd.ul.ptr, dd.cl.ptr
+        d.lp = lpd.ptr if lpd is not None else None
+        for q in range(nterms):
+            d.terms[q] = terms[q]
+        d.nterms = nterms
+        d.model_out, d.total = None, total.ptr
+        h = _dp()
+        _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))
+        thr, blk, lds = _i(), _i(), _ll()
+        _chk(_lib.nh_half_step_info(h, C.byref(thr), C.byref(blk), C.byref(lds)))
+        plan["hs"] = dict(key=key, plan=h, keep=(conv, lpd, total, dd), threads=thr.value,
+                          blocks=blk.value, lds_bytes=lds.value)
+        self.call("nh_half_step_launch", h)
 
     # -- side streams ---------------------------------------------------------
     def branch(self):
@@ -570,14 +709,18 @@ class Context:
         return v.value
 
     def profile_read(self, reset=True):
-        ms = (_d * 8)()
-        n = (_ll * 8)()
+        nk = len(NH_K_NAMES)
+        ms = (_d * nk)()
+        n = (_ll * nk)()
         _chk(_lib.nh_profile_read(self.h, ms, n, int(reset)))
-        return {NH_K_NAMES[i]: dict(ms=ms[i], launches=int(n[i])) for i in range(8) if n[i]}
+        return {NH_K_NAMES[i]: dict(ms=ms[i], launches=int(n[i])) for i in range(nk) if n[i]}
 
     def call(self, name, *args):
         """invoke an entry point; DeviceArray arguments are passed as their pointers"""
         conv = [a.ptr if isinstance(a, DeviceArray) else a for a in args]
+        plan = self._plan
+        if plan is not None and plan["mode"] == "record" and self._in_eval:
+            plan["calls"].append(name)
         _chk(getattr(_lib, name)(self.h, *conv))
 
     def close(self):

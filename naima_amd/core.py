@@ -172,6 +172,14 @@ def lnprobmodel(model, data, lp=None):
                 terms, nterms, None, total)
         owners = [t[0] for t in m.terms]
         held = [j for j, o in enumerate(owners) if getattr(o, "pending", None) is not None]
+        plan = ctx._plan
+        if hook is not None and plan is not None and plan["mega"] and plan["mode"] == "replay":
+            # ONE launch for the whole half-step: proposal, packs, weights, We/Wp, every
+            # spectrum of the model, this likelihood, the priors and the accept
+            ctx.half_step(hook, m.comps(), len(m.terms), nE, args[4], dd, lpd, terms, nterms, total)
+            hook["used"] = True
+            del lpd
+            return DVec(ctx, total, total.ptr, N)
         if hook is not None:
             # device step loop: the stretch move's accept rides on this launch (single
             # rank; sharded, the accept has to wait for the all-gather: mv is None)

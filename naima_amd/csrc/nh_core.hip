@@ -356,7 +356,7 @@ extern "C" int nh_trapz_loglog(nh_ctx* c, const double* y, const double* x, int 
 // rows 2,3: per-walker particle spectrum on a grid -> weights w = xg*n and the
 // log-ratios dlw[i] = ln|w[i+1]/w[i]| assembled analytically per segment
 // ---------------------------------------------------------------------------
-#include "nh_pdist.h"
+#include "nh_front.h"
 
 __global__ __launch_bounds__(256) void k_particle_weights(
     int kind, const double* __restrict__ params, int N, const double* __restrict__ e,
@@ -380,19 +380,6 @@ __global__ __launch_bounds__(256) void k_particle_weights(
   if (nout) nout[idx] = n;
   dlw[idx] = last ? 0.0 : lrx + dsh;
 }
-
-struct pw_grids {
-  const double* e[NH_MAX_GRIDS];
-  const double* xg[NH_MAX_GRIDS];
-  const double* lne[NH_MAX_GRIDS];  // ln e_eV per node, or NULL
-  const double* lx[NH_MAX_GRIDS];   // ln(xg[i+1]/xg[i]) per segment, or NULL
-  double* w[NH_MAX_GRIDS];
-  double* dlw[NH_MAX_GRIDS];
-  double scale[NH_MAX_GRIDS];
-  int nG[NH_MAX_GRIDS];
-  int off[NH_MAX_GRIDS + 1];  // node offsets of the grids in one walker's flat index
-  int n;
-};
 
 // the same walkers on several grids (the components of one model evaluation use
 // different electron grids: Synchrotron from 1 GeV, IC from Eemin, We(> 1 TeV) ...).
@@ -468,20 +455,6 @@ extern "C" int nh_particle_weights_multi(nh_ctx* c, int kind, const double* para
 // One block per proposed walker; everything a later stage needs from an earlier one
 // stays in LDS.  See include/naima_hip.h for the slice protocol.
 // ---------------------------------------------------------------------------
-struct front_args {
-  const double* coords; const double* logp; const double* blk;
-  int* cursor; int* done;
-  int ns, ndim, lo, nloc;
-  double* qT; double* factors;
-  nh_hist* hist;
-  nh_pack pk[NH_MAX_PACK]; int npk;
-  int kind; const double* params;
-  pw_grids G;
-  nh_moment mom[NH_MAX_MOMENT]; int nmom;
-  int mom_off[NH_MAX_GRIDS];  // LDS offset (nodes) of a grid's w/dlw copy, or -1
-  int mom_nodes;              // LDS nodes in total
-};
-
 __global__ __launch_bounds__(1024) void k_step_front(front_args A) {
   extern __shared__ double sm[];
   double* qs = sm;                       // [ndim]    this walker's proposal

@@ -60,6 +60,40 @@ class nh_prior(C.Structure):
                 ("pad", C.c_int)]
 
 
+class nh_hs_table(C.Structure):
+    _fields_ = [("grid", C.c_int), ("nK", C.c_int), ("ldo", C.c_int), ("nonnegative", C.c_int),
+                ("Kt", C.c_void_p), ("dlnKt", C.c_void_p), ("scale", C.c_void_p),
+                ("out", C.c_void_p)]
+
+
+class nh_hs_syn(C.Structure):
+    _fields_ = [("grid", C.c_int), ("nE", C.c_int), ("ldo", C.c_int), ("bcol", C.c_int),
+                ("ldB", C.c_int), ("pad", C.c_int), ("E_eV", C.c_void_p), ("B", C.c_void_p),
+                ("out", C.c_void_p)]
+
+
+class nh_hs_desc(C.Structure):
+    """include/naima_hip.h: the descriptor of nh_half_step_create"""
+    _fields_ = [("coords", C.c_void_p), ("logp", C.c_void_p), ("blk", C.c_void_p),
+                ("cursor", C.c_void_p), ("done", C.c_void_p),
+                ("ns", C.c_int), ("ndim", C.c_int), ("lo", C.c_int), ("nloc", C.c_int),
+                ("qT", C.c_void_p), ("factors", C.c_void_p), ("hist", C.c_void_p),
+                ("accepted", C.c_void_p), ("naccepted", C.c_void_p), ("sel", C.c_void_p),
+                ("do_accept", C.c_int), ("write_weights", C.c_int),
+                ("packs", nh_pack * 4), ("npacks", C.c_int),
+                ("kind", C.c_int), ("params", C.c_void_p),
+                ("grids", nh_grid * 4), ("ngrids", C.c_int),
+                ("moms", nh_moment * 4), ("nmoms", C.c_int),
+                ("tab", nh_hs_table * 4), ("ntab", C.c_int),
+                ("syn", nh_hs_syn),
+                ("comps", nh_comp * 8), ("ncomp", C.c_int), ("nE", C.c_int),
+                ("conv", C.c_void_p), ("flux", C.c_void_p), ("err_lo", C.c_void_p),
+                ("err_hi", C.c_void_p), ("ul", C.c_void_p), ("cl", C.c_void_p),
+                ("lp", C.c_void_p),
+                ("terms", nh_prior * 16), ("nterms", C.c_int),
+                ("model_out", C.c_void_p), ("total", C.c_void_p)]
+
+
 def lazy_const(v):
     return nh_lazy(None, 0, float(v), 0.0, 0.0, TF_ID, 0)
 

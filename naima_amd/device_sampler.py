@@ -96,6 +96,10 @@ class DeviceLoop:
         # nh_step_front mode: set after a recording evaluation when the model's parameter
         # packs read the proposal buffer and it asks for ONE particle-weights launch
         self.fused = False
+        # ... and, when every launch of the model evaluation is one nh_half_step can absorb
+        # (table reductions, a synchrotron component, the likelihood), the whole half-step is
+        # ONE launch: proposal -> ... -> accept (NAIMA_AMD_MEGA=0 keeps the three launches)
+        self.mega = False
         self._plan = None
         self._front_args = None
         self.done = ctx.empty((1,), dtype=np.int32)
@@ -138,7 +142,11 @@ class DeviceLoop:
     def _eval(self, qT_buf, n):
         """run the user's model on device parameters: (total DVec, blob list)"""
         pars = DPars(self.ctx, qT_buf, self.ndim, n)
-        res = self.s.log_prob_fn(pars, *self.s.args)
+        self.ctx._in_eval = True
+        try:
+            res = self.s.log_prob_fn(pars, *self.s.args)
+        finally:
+            self.ctx._in_eval = False
         self.s.n_lnprob_calls += 1
         self.s.n_walker_evals += n
         total = res[0].dense()
@@ -169,7 +177,7 @@ class DeviceLoop:
         ctx = self.ctx
         if self.fused:
             # proposal, parameter rows, weights, We: written by the preceding nh_step_front
-            self._plan["i"] = [0, 0, 0]
+            self._plan["i"] = [0, 0, 0, 0]
             ctx._plan = self._plan
             self._hook["used"] = False
             ctx._accept_hook = self._hook
@@ -226,7 +234,7 @@ class DeviceLoop:
                 for nb, (cur, m, _, _) in zip(self.new_blobs, self.cur_blobs):
                     ctx.call("nh_scatter_rows", cur, m, nb, m, self.sel, self.accepted, self.lo,
                              self.nloc, m)
-        if self.fused:
+        if self.fused and not self.mega:
             self._front()
 
     def _front(self):
@@ -296,10 +304,57 @@ class DeviceLoop:
         else:  # sharded: likelihood into the all-gather send buffer, accept afterwards
             self._hook = dict(N=self.nloc, used=False, total=self.mylp, mv=None)
         self.fused = True
+        self.mega = self._can_be_one_launch(plan, grids, wptr, moments)
+        if self.mega:
+            plan["mega"] = True
+            plan["front"] = dict(coords=self.coords.ptr, logp=self.logp.ptr, blk=self.blk.ptr,
+                                 cursor=self.cursor.ptr, done=self.done.ptr, qT=self.qT.ptr,
+                                 factors=self.factors.ptr, hist=self.histd.ptr,
+                                 accepted=self.accepted.ptr, naccepted=self.nacc.ptr,
+                                 sel=self.sel.ptr, ns=self.ns, ndim=self.ndim, lo=self.lo,
+                                 nloc=self.nloc, front_args=self._front_args)
+            if self._hook.get("total") is None:
+                self._hook["total"] = ctx.empty((self.nloc,))  # persistent: the plan points at it
         # new slice protocol: cursor = the slice accepted last.  The two piecewise
         # half-steps (slices 0 and 1 of the first block) left it at 2.
         self.cursor.set(np.array([1], dtype=np.int32))
-        self._front()
+        if not self.mega:
+            self._front()
+
+    def _can_be_one_launch(self, plan, grids, wptr, moments):
+        """every launch the recorded model evaluation made is one nh_half_step absorbs, and
+        its working set fits in one workgroup's LDS"""
+        if os.environ.get("NAIMA_AMD_MEGA", "1") == "0":
+            return False
+        allowed = {"nh_pack_rows", "nh_particle_weights_multi", "nh_integrate_tables",
+                   "nh_synchrotron", "nh_lnprob"}
+        emit = plan["emit"]
+        ntab = sum(1 for e in emit if e["kind"] == "tab")
+        nsyn = len(emit) - ntab
+        if not set(plan["calls"]) <= allowed or not emit or ntab > 4 or nsyn > 1:
+            return False
+        if plan["calls"].count("nh_lnprob") != 1:
+            return False
+        # every integrate call is either a recorded single-row reduction or an emission table
+        if plan["calls"].count("nh_integrate_tables") != ntab + len(moments) or \
+                plan["calls"].count("nh_synchrotron") != nsyn:
+            return False
+        lds = 88 + 3 * sum(g[5] for g in grids) + sum(2 * grids[wptr[m[0][0]]][5] for m in moments)
+        items = nspec = 0
+        for e in emit:
+            k = e["key"]
+            if e["N"] != self.nloc or k[1] not in wptr:
+                return False
+            if e["kind"] == "tab":
+                nG, nK = k[4], k[8]
+                items += ((nK + 63) // 64) * ((nG - 1 + 31) // 32)
+                nspec += nK
+            else:
+                nG, nE = k[8], k[10]
+                lds += 3 * nG + 4 * nE + 1 + 32 * nE
+                nspec += nE
+        lds += min(items, 96) * 64 + nspec
+        return 8 * lds <= 140 * 1024
 
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
@@ -400,7 +455,8 @@ class DeviceLoop:
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
             if self.fused:
                 ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
-                self._front()  # slice 0 of the new block
+                if not self.mega:
+                    self._front()  # slice 0 of the new block
             else:
                 ctx.call("nh_memset", self.cursor, 0, 4)
             mark = self._markers[self._nmark % len(self._markers)]
@@ -446,6 +502,12 @@ class DeviceLoop:
                     block["n"] = kk + g
                 if yield_every < 2:
                     self._flush_pending()
+                if self.mega and dev_hist:
+                    # one launch per half-step: the row of a closed step is written by the
+                    # NEXT launch of the same block of moves; nothing follows the last one of
+                    # a block, and whoever is handed this state may read the chain
+                    self._flush_pending()
+                    ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim, self.histd, -1)
                 yield DeviceState(self, rng)
         self._flush_pending()
 
@@ -496,6 +558,12 @@ class DeviceLoop:
             self._record_half_step()
             self.warm += 2
             return
+        if self.mega and self._plan["hs"] is None:
+            # the first one-launch half-step creates the kernel's descriptor (device
+            # allocation + upload): not inside a stream capture
+            self._half_step_body()
+            self._half_step_body()
+            return
 
         def two():
             self._half_step_body()
@@ -523,8 +591,8 @@ class DeviceLoop:
                 self._record_half_step()
             self.warm += 1
             return
-        if not s.use_graph:
-            self._half_step_body()
+        if not s.use_graph or (self.mega and self._plan["hs"] is None):
+            self._half_step_body()  # (a first one-launch half-step: never inside a capture)
             return
         if not multi:
             self.graph = self._capture(self._half_step_body)

@@ -264,18 +264,6 @@ class BaseRadiative:
         ctx.need(hit[0])
         return ctx, N, hit[0], hit[1], xd, lx
 
-    @staticmethod
-    def _integrate_or_defer(ctx, out, args, N, nK):
-        """launch nh_integrate_tables(*args) -- or, inside the device step loop when this
-        is a one-plane reduction of at most 64 columns and nothing else is held back, hold
-        it back so that the likelihood can ride on it (nh_integrate_tables_lnprob)"""
-        hook = ctx._accept_hook
-        if hook is not None and not hook["used"] and hook["N"] == N and nK <= 64 \
-                and args[-1] == 1 and not ctx._deferred:
-            ctx.defer(out, "nh_integrate_tables", args)
-        else:
-            ctx.call("nh_integrate_tables", *args)
-
     def _weights_table(self, pd, xg, e_eV, unit_scale):
         """weights of a TableModel distribution: amplitude[w] times a walker-independent
         shape on the grid (host spline once, cached in HBM); rows by nh_lincomb"""
@@ -546,15 +534,8 @@ class Synchrotron(BaseElectron):
         else:
             Bd = ctx.array(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
             Bp = Bd.ptr
-        out = ctx.empty((N, E_eV.size))
-        args = (w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV), E_eV.size, out, E_eV.size)
-        hook = ctx._accept_hook
-        if hook is not None and not hook["used"] and hook["N"] == N and E_eV.size <= 64 \
-                and not ctx._deferred:
-            # device step loop: hold the launch back, the likelihood may ride on it
-            ctx.defer(out, "nh_synchrotron", args, keep=(Bd,))
-        else:
-            ctx.call("nh_synchrotron", *args)
+        out = ctx.emit_synchrotron(w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV),
+                                   E_eV.size, keep=(Bd,))
         del Bd
         return self._result(ctx, out, N, E_eV.size, E)
 
@@ -761,12 +742,9 @@ class InverseCompton(BaseElectron):
                     uf = 1.0
                 scale[j * nE:(j + 1) * nE] = uf * Eph / E_eV  # radiative.py:684-687
             # the abscissa may be cut into planes that different workgroups reduce (evens out
-            # the load per CU); the planes are summed by whoever consumes the spectrum
-            ns = _lib_mod._lib.nh_integrate_tables_nsplit(N, nG, nK)
-            out = ctx.empty((ns * N, nK))
+            # the load per CU); the planes are summed by whoever consumes the spectrum.
             # IC kernels are >= 0; a user-supplied array seed is validated positive
-            self._integrate_or_defer(ctx, out, (w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale),
-                                                out, nK, 1, ns), N, nK)
+            out, ns = ctx.emit_tables(w, lw, N, nG, lx, Kt, dlnKt, nK, ctx.const(scale), 1)
             if dev:
                 for j, name in enumerate(static):
                     specs[name] = DMat(ctx, [(out, out.ptr + 8 * (h * N * nK + j * nE), nK, 1.0)
@@ -899,9 +877,9 @@ class Bremsstrahlung(BaseElectron):
         # spec = n0 (w_ee c int(n sigma_ee) + w_ep c int(n sigma_1)), radiative.py:949-987
         scale = np.concatenate([np.full(nE, n0 * self.weight_ee * C_CGS),
                                 np.full(nE, n0 * self.weight_ep * C_CGS)])
-        out = ctx.empty((N, 2 * nE))
-        ctx.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dKt, 2 * nE, ctx.const(scale), out,
-                 2 * nE, 0, 1)  # the Baring+99 fits go negative near their edges
+        # (the Baring+99 fits go negative near their edges: signed reduction)
+        out, _ = ctx.emit_tables(w, lw, N, nG, lx, Kt, dKt, 2 * nE, ctx.const(scale), 0,
+                                 may_split=False)
         if self.on_device:
             tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE) + \
                 DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE)
@@ -1090,10 +1068,9 @@ class PionDecay(BaseProton):
 
         Kt, dKt = ctx.table(("pp", xd.ptr, Ed.ptr, use_lut, self.hiEmodel,
                              bool(self.nuclear_enhancement)), build)
-        out = ctx.empty((N, nE))
         # the FITPACK look-up table rings below zero; the analytic form does not
-        self._integrate_or_defer(ctx, out, (w, lw, N, nG, lx, Kt, dKt, nE, None, out, nE,
-                                            0 if use_lut else 1, 1), N, nE)
+        out, _ = ctx.emit_tables(w, lw, N, nG, lx, Kt, dKt, nE, None, 0 if use_lut else 1,
+                                 may_split=False)
         nh = self.nh.to("1/cm3").value
         fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
         if _per_walker(self.nh):
