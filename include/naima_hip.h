@@ -370,24 +370,31 @@ int nh_stream_join(nh_ctx* ctx);
  * StretchMove.get_proposal / RedBlueMove.propose around core.py:97-121 around
  * radiative.py:282-342, 657-710, 1495-1536.  The particle weights stay in LDS (they are
  * also written to grids[].w/.dlw when write_weights), every spectrum is written to its
- * `out` as the separate entry points would.  Slice protocol as nh_step_front, except that
- * the slice proposed is the slice accepted (no look-ahead): cursor[0] = slice evaluated
- * last, advanced by the launch.  hist->n counts the closed ensemble steps (the launch that
- * accepts an odd slice increments it); the history row n - 1 of the step closed last is
- * written by the NEXT launch of the same block of moves (cursor odd, >= 1); after the last
- * half-step of a block, and whenever the chain may be read, the caller writes it with
- * nh_hist_append(row = -1) (writing a row twice is harmless).  The descriptor is copied to the device once (nh_half_step_create);
+ * `out` as the separate entry points would.
+ * Slices: nh_half_step_begin_block tells the plan that a new block of moves sits in `blk`;
+ * the k-th launch after it proposes, evaluates and (do_accept) accepts slice first_slice + k -- the plan
+ * counts its own launches on the device, nothing has to be advanced by the caller.  The
+ * history row of a closed ensemble step (row steps_before + k/2 - 1 of hist, hist->n is not
+ * used) is written by the NEXT launch of the same block of moves; after the last half-step
+ * of a block, and whenever the chain may be read, the caller writes it with nh_hist_append
+ * (writing a row twice is harmless).  The descriptor is copied once (nh_half_step_create);
  * a launch takes no other argument, so it can be captured into a hipGraph and replayed. */
+/* KD: the emission table of nh_integrate_tables in the interleaved layout the kernel streams,
+ * KD[(i*nK + k)*2 + {0,1}] = {Kt[i][k], dlnKt[i][k]} (nh_table_interleave) */
 typedef struct { int grid; int nK; int ldo; int nonnegative;
-                 const double* Kt; const double* dlnKt; const double* scale /*[nK] or NULL*/;
+                 const double* KD; const double* reserved; const double* scale /*[nK] or NULL*/;
                  double* out /*[nloc][ldo]*/; } nh_hs_table;
+int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt, long long n,
+                        double* KD /*[2n]*/);
 typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
                  int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB; int pad;
                  const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;
                  double* out /*[nloc][ldo]*/; } nh_hs_syn;
 #define NH_HS_MAX_TAB 4
 typedef struct {
-  double* coords; double* logp; const double* blk; int* cursor; int* done;
+  double* coords; double* logp; const double* blk;
+  int* cursor; /* out: the slice of the launch, for nh_move_accept(advance = 0) after it */
+  int* reserved;
   int ns, ndim, lo, nloc;
   double* qT; double* factors; nh_hist* hist /* device, or NULL */;
   int* accepted; int* naccepted; int* sel;
@@ -407,12 +414,17 @@ typedef struct {
 } nh_hs_desc;
 typedef struct nh_halfstep_plan nh_halfstep_plan;
 int nh_half_step_create(nh_ctx* ctx, const nh_hs_desc* desc /*host*/, nh_halfstep_plan** out);
-int nh_half_step_launch(nh_ctx* ctx, nh_halfstep_plan* plan);
+int nh_half_step_begin_block(nh_ctx* ctx, nh_halfstep_plan* plan, int first_slice,
+                             int steps_before);
+/* slice >= 0: the launch works on that slice of the block of moves (a captured graph replays
+ * it for the same slice); slice < 0: the slice the plan's own launch counter says is next */
+int nh_half_step_launch(nh_ctx* ctx, nh_halfstep_plan* plan, int slice);
 int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
                       long long* lds_bytes);
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
 /* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the
- * first 8 workgroups of the last launch, out[8][16]; all zero otherwise */
+ * first 8 workgroups of the last launch, out[8][16], followed by 4 x 16 per-wave figures of
+ * workgroup 0 (256 values in all); all zero otherwise */
 int nh_half_step_stamps(nh_ctx* ctx, const nh_halfstep_plan* plan, long long* out);
 /* row `row` (-1: hist->n - 1) of the device-resident history := coords[N][ndim] / logp[N] */
 int nh_hist_append(nh_ctx* ctx, const double* coords, const double* logp, long long N, int ndim,

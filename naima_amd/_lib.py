@@ -98,10 +98,12 @@ _SIGS = {
     "nh_comm_destroy": [_dp],
     "nh_comm_allgather": [_dp, _dp, _dp, _ll],
     "nh_half_step_create": [_dp, _dp, C.POINTER(_dp)],
-    "nh_half_step_launch": [_dp, _dp],
+    "nh_half_step_begin_block": [_dp, _dp, _i, _i],
+    "nh_half_step_launch": [_dp, _dp, _i],
     "nh_half_step_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_half_step_stamps": [_dp, _dp, _dp],
+    "nh_table_interleave": [_dp, _dp, _dp, _ll, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
 }
 EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")
@@ -477,11 +479,12 @@ class Context:
             if hs["key"] != key:
                 raise NaimaHipError("the model's likelihood inputs changed between evaluations; "
                                     "run the sampler with use_graph=False")
-            self.call("nh_half_step_launch", hs["plan"])
+            self.call("nh_half_step_launch", hs["plan"],
+                      plan["front"]["pos"]["slice"] if plan["front"]["pos"]["bake"] else -1)
             return
         f = plan["front"]  # filled in by the device loop when it chose this mode
         d = D.nh_hs_desc()
-        for name in ("coords", "logp", "blk", "cursor", "done", "qT", "factors", "hist",
+        for name in ("coords", "logp", "blk", "cursor", "qT", "factors", "hist",
                      "accepted", "naccepted", "sel"):
             setattr(d, name, f[name])
         d.ns, d.ndim, d.lo, d.nloc = f["ns"], f["ndim"], f["lo"], f["nloc"]
@@ -504,7 +507,15 @@ class Context:
             k = ent["key"]
             if ent["kind"] == "tab":
                 _, w, lw, N, nG, lx, Kt, dKt, nK, sc, nonneg = k
-                d.tab[nt] = D.nh_hs_table(wgrid[w], nK, nK, nonneg, Kt, dKt, sc or None,
+
+                def interleaved(Kt=Kt, dKt=dKt, n=nG * nK):
+                    kd = self.empty((2 * n,))
+                    self.call("nh_table_interleave", Kt, dKt, n, kd)
+                    return kd
+
+                kd = self.table(("kd", Kt, dKt, nG * nK), interleaved)
+                self._pinned.add(("kd", Kt, dKt, nG * nK))  # the plan points into it
+                d.tab[nt] = D.nh_hs_table(wgrid[w], nK, nK, nonneg, kd.ptr, None, sc or None,
                                           ent["out"].ptr)
                 nt += 1
             else:
@@ -529,7 +540,9 @@ class Context:
         _chk(_lib.nh_half_step_info(h, C.byref(thr), C.byref(blk), C.byref(lds)))
         plan["hs"] = dict(key=key, plan=h, keep=(conv, lpd, total, dd), threads=thr.value,
                           blocks=blk.value, lds_bytes=lds.value)
-        self.call("nh_half_step_launch", h)
+        # where the step loop stands in the current block of moves
+        self.call("nh_half_step_begin_block", h, f["pos"]["slice"], f["pos"]["steps"])
+        self.call("nh_half_step_launch", h, -1)
 
     # -- side streams ---------------------------------------------------------
     def branch(self):

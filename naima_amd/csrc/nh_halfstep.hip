@@ -33,57 +33,87 @@
 #include "nh_syn.h"
 
 #define HS_MAX_TAB 4
+#ifndef HS_SYN_NODES
 #define HS_SYN_NODES 10  // synchrotron nodes per thread and work item (besides the start node)
+#endif
+#ifndef HS_ORDER
+#define HS_ORDER 0  // work items: 0 = tables and synchrotron alternate, 1 = tables first, 2 = synchrotron first
+#endif
 
 struct hs_tab {
-  const double* Kt; const double* dlnKt; const double* scale; double* out;
+  const double* KD; const double* scale; double* out;  // KD: interleaved {K, dlnK}, [nG][nK][2]
   int grid, nK, ldo, nonneg, spec_off, tiles, item0, chunks;
-};
-
-struct hs_syn {
-  const double* E_eV; const double* B; double* out;
-  int grid, nE, ldo, bcol, ldB, spec_off, cdmax, pad;
 };
 
 struct hs_comp { const double* ptr; long long ld; double scale; int off; int pad; };
 
+// The descriptor's COLD part, in device memory: what a workgroup needs only after its
+// proposal is known (its loads hide behind the proposal's chain of dependent reads).
 struct hs_dev {
-  front_args F;
+  nh_pack pk[NH_MAX_PACK];
+  int npk, kind;
+  const double* params;
+  double* w[NH_MAX_GRIDS]; double* dlw[NH_MAX_GRIDS];
+  double* mom_out[NH_MAX_MOMENT];
   int* accepted; int* naccepted; int* sel;
   int do_accept, write_weights;
   hs_tab tab[HS_MAX_TAB];
   int ntab, nT, seg;  // table items in total; segments per item
-  hs_syn syn;
+  const double* synB; double* syn_out;
+  int syn_ldo, syn_bcol, syn_ldB, syn_cdmax;
   hs_comp comp[NH_MAX_COMP];
-  int ncomp, nE;
-  const double* conv; const double* flux; const double* elo; const double* ehi;
-  const int* ul; const double* cl; const double* lp;
+  int ncomp, pad0;
+  const double* lp;
   nh_prior_pack pri;
   double* model_out; double* total;
-  // LDS layout, offsets in doubles
+  long long* dbg;  // NH_HS_DEBUG=1: wall-clock stamps of the first 8 workgroups, [8][16]
+};
+
+// ... and its HOT part, passed by value: every pointer and size the first phases touch, so
+// that the kernel's first round trip to memory already fetches data, not descriptors.
+struct hs_hot {
+  const hs_dev* D;
+  const double* coords; const double* logp; const double* blk;
+  int* done; const int* hbase; int* cursor;
+  double* qT; double* factors; const nh_hist* hist;
+  int ns, ndim, lo, nloc;
+  const double* e[NH_MAX_GRIDS]; const double* xg[NH_MAX_GRIDS];
+  const double* lne[NH_MAX_GRIDS]; const double* lx[NH_MAX_GRIDS];
+  double scale[NH_MAX_GRIDS];
+  int nG[NH_MAX_GRIDS];
   int o_w[NH_MAX_GRIDS], o_d[NH_MAX_GRIDS], o_lx[NH_MAX_GRIDS];
-  int o_mkt, o_ig2, o_dig2, o_ig23, o_sq, o_amap, o_part_s, o_part_t, o_spec, nspec;
-  int lds_doubles, threads;
-  long long* dbg;  // NH_HS_DEBUG=1: shader-clock stamps of the first 8 workgroups, [8][16]
+  int ngrids, nmom;
+  const double* mKt[NH_MAX_MOMENT]; const double* mdK[NH_MAX_MOMENT];
+  int mgrid[NH_MAX_MOMENT];
+  int o_mkt, o_part_t, o_spec, o_lik;
+  int syn_grid, syn_nE, syn_spec_off, o_ig2, o_dig2, o_ig23, o_sq, o_amap, o_part_s, pad1;
+  const double* syn_E;
+  const double* conv; const double* flux; const double* elo; const double* ehi;
+  const int* ul; const double* cl;
+  int nE, npf;
+  const double* pfKD[HS_MAX_TAB];   // the interleaved tables, for the L2 prefetch
+  unsigned pfbytes[HS_MAX_TAB];
 };
 
 struct nh_halfstep_plan {
-  hs_dev* dev;       // device copy of the descriptor
+  hs_hot hot;
+  hs_dev* dev;       // device copy of the cold part
+  int* words;        // device: done counter | hbase
   size_t lds_bytes;
   int threads, blocks;
   long long* dbg;
 };
 
 // ints at the head of the LDS block (after qs/row/lg/acc)
-enum { HI_ME = 0, HI_PA, HI_NA, HI_CD, HI_NS, HI_CNT };
+enum { HI_ME = 0, HI_PA, HI_NA, HI_CD, HI_NS, HI_CNT, HI_LIVE };
 #define HS_O_ROW 64
 #define HS_O_LG 72
 #define HS_O_ACC 76   // z, lnU, old logp, (pad)
 #define HS_O_INT 80   // 16 ints
 #define HS_O_FREE 88
-#define HS_STAMP(k)                                                                  \
-  do {                                                                                \
-    if (D.dbg && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64(); \
+#define HS_STAMP(k)                                                                    \
+  do {                                                                                  \
+    if (D.dbg && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64();   \
   } while (0)
 
 __device__ __forceinline__ double hs_wave_sum(double v) {
@@ -92,60 +122,92 @@ __device__ __forceinline__ double hs_wave_sum(double v) {
   return v;
 }
 
+typedef unsigned int hs_u32x4 __attribute__((ext_vector_type(4)));
+// one 16-byte element {K[i][k], dlnK[i][k]} of the interleaved table
+__device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double& K,
+                                          double& d) {
+  const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  K = __hiloint2double((int)v.y, (int)v.x);
+  d = __hiloint2double((int)v.w, (int)v.z);
+}
+
 // one table work item: columns [64 tile, 64 tile + 64) x segments [s0, s1) of table t for
-// this workgroup's walker, whose w / dlw / lx live in LDS (wave-uniform reads)
+// this workgroup's walker, whose w / dlw / lx live in LDS (wave-uniform reads).  The table
+// is the interleaved copy KD[i][k] = {K, dlnK}: ONE 16-byte load per lane and node instead of
+// two 8-byte ones (8-byte accesses reach 0.54-0.70 of the L2 rate of 16-byte ones; with one
+// walker per workgroup the rows stream from L2 once per walker and that rate is the bound:
+// 23 us of table items became XX).  Eight nodes per trip = eight kilobytes in flight per
+// wave (a double-buffered four-node version, half of that in flight, measured 25 % slower).
 template <bool SIGNED>
 __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
                                                 const double* ws, const double* ds,
                                                 const double* lxs, int lane) {
+  // the table's address and width come out of the descriptor in memory: the compiler cannot
+  // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
+  // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
+  // the 25 the loop then costs) -- say so once per work item instead
+  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
+  const unsigned long long kd = (unsigned long long)t.KD;
+  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
+  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+  const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
   const int k = tile * 64 + lane;
-  const unsigned kk = k < t.nK ? (unsigned)k : (unsigned)(t.nK - 1);
-  const unsigned tbytes = (unsigned)nG * (unsigned)t.nK * 8u;
-  const __amdgpu_buffer_rsrc_t rK =
-      __builtin_amdgcn_make_buffer_rsrc((void*)t.Kt, 0, (int)tbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rD =
-      __builtin_amdgcn_make_buffer_rsrc((void*)t.dlnKt, 0, (int)tbytes, 0x00020000);
-  const unsigned rowb = (unsigned)t.nK * 8u;
-  unsigned ob = ((unsigned)s0 * (unsigned)t.nK + kk) * 8u;
+  const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
+  const unsigned tbytes = (unsigned)nG * nK * 16u;
+  const __amdgpu_buffer_rsrc_t rKD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
+  const unsigned rowb = nK * 16u;
+  unsigned ob = ((unsigned)s0 * nK + kk) * 16u;
   double acc = 0.0;
-  double u1 = ws[s0] * nh_buf_f64(rK, ob);
+  double K1, d1;  // node s: its K and the log-ratio of the segment that starts there
+  hs_buf_kd(rKD, ob, K1, d1);
+  double u1 = ws[s0] * K1;
   int s = s0;
-  // eight segments per trip: sixteen table loads in flight per wave (one walker per
-  // workgroup: the loop is bound by the L2 round trip, not by issue)
   for (; s + 8 <= s1; s += 8) {
     double K2[8], dK[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      K2[q] = nh_buf_f64(rK, ob + (q + 1) * rowb);
-      dK[q] = nh_buf_f64(rD, ob + q * rowb);
-    }
+    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const double u2 = ws[s + q + 1] * K2[q];
-      const double dl = ds[s + q] + dK[q];
+      const double dl = ds[s + q] + d1;
       acc += SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[s + q])
                     : nh_seg_pos<false>(u1, u2, dl, lxs[s + q]);
       u1 = u2;
+      d1 = dK[q];
     }
     ob += 8 * rowb;
   }
-  for (; s < s1; ++s) {
-    const double K2 = nh_buf_f64(rK, ob + rowb);
-    const double dK = nh_buf_f64(rD, ob);
-    const double u2 = ws[s + 1] * K2;
-    const double dl = ds[s] + dK;
-    acc += SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[s]) : nh_seg_pos<false>(u1, u2, dl, lxs[s]);
-    u1 = u2;
-    ob += rowb;
+  if (s < s1) {  // tail: the remaining (< 8) nodes in one trip; rows past the table read 0
+    double K2[7], dK[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      if (s + q < s1) {
+        const double u2 = ws[s + q + 1] * K2[q];
+        const double dl = ds[s + q] + d1;
+        acc += SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[s + q])
+                      : nh_seg_pos<false>(u1, u2, dl, lxs[s + q]);
+        u1 = u2;
+        d1 = dK[q];
+      }
+    }
   }
   return acc;
 }
 
-__global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ Dp) {
+// The first arguments are what the proposal's chain of dependent reads starts from: scalar
+// kernel arguments can be preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count),
+// so the chain does not begin with a trip to the kernel-argument segment.
+// slice >= 0: the slice of the block of moves this launch works on (baked into a captured
+// graph); slice < 0: derived from the plan's own launch counter.
+__global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done_,
+                                                    const double* __restrict__ blk_,
+                                                    const double* coords_, int slice, int ns_,
+                                                    int ndim_, int lo_, const hs_hot H) {
   extern __shared__ double sm[];
-  const hs_dev& D = *Dp;
-  const front_args& A = D.F;
-  const pw_grids& G = A.G;
+  const hs_dev& D = *H.D;
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
   const int j = blockIdx.x;
@@ -154,125 +216,205 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
   double* lg = sm + HS_O_LG;
   double* accs = sm + HS_O_ACC;
   int* hi = reinterpret_cast<int*>(sm + HS_O_INT);
-  const bool has_syn = D.syn.grid >= 0;
-
+  const bool has_syn = H.syn_grid >= 0;
   HS_STAMP(0);
-  // ---- 0. everything that does not depend on the proposal is requested first -----------
+
+  // ---- 0. the first round trip: everything whose address is known at launch ---------------
+  // which slice?  `done` counts the workgroups that have finished since the current block of
+  // moves was uploaded (every one adds 1 on its way out, nh_half_step_begin_block zeroes it):
+  // launches completed = done / grid size, whatever this launch's own early finishers have
+  // already added.  hbase = ensemble steps of the run completed before this block of moves.
+  const int cn = slice >= 0 ? slice : done_[0] / (int)gridDim.x;  // the slice worked on here
+  const int c = cn - 1;  // slice accepted by the previous launch
+  // ---- the proposal's chain FIRST: slice -> (me, partner, z) -> coordinates.  Issued ahead
+  // of the bulk prefetch below, whose tens of loads per thread it would otherwise queue behind
+  const double* r = blk_ + (long long)cn * 3 * ns_;
+  const int* idx = reinterpret_cast<const int*>(r + 2 * ns_);
+  int me = 0, pa = 0;
+  double mz = 1.0, mlnu = 0.0;
+  if (tid < ndim_) {
+    const int g = lo_ + j;
+    me = idx[g];
+    pa = idx[ns_ + g];
+    mz = r[g];
+    if (tid == 0) mlnu = r[ns_ + g];
+  }
+  const int stepbase = H.hbase[0];
+  // (the grids' logarithms ln e and lx come with the grid: nh_half_step_create insists)
   double nE_[NH_MAX_GRIDS], nE2_[NH_MAX_GRIDS], ngx_[NH_MAX_GRIDS], nlr_[NH_MAX_GRIDS],
       nln_[NH_MAX_GRIDS];
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
     nE_[g] = nE2_[g] = ngx_[g] = 1.0;
     nlr_[g] = nln_[g] = 0.0;
-    if (g < G.n && tid < G.nG[g]) {
-      const int nG = G.nG[g], i = tid;
+    if (g < H.ngrids && tid < H.nG[g]) {
+      const int nG = H.nG[g], i = tid;
       const bool last = i + 1 >= nG;
-      nE_[g] = G.e[g][i];
-      nE2_[g] = last ? nE_[g] : G.e[g][i + 1];
-      ngx_[g] = G.xg[g][i];
-      if (!last) nlr_[g] = G.lx[g] ? G.lx[g][i] : log(G.xg[g][i + 1] / ngx_[g]);
-      nln_[g] = G.lne[g] ? G.lne[g][i] : log(nE_[g]);
+      nE_[g] = H.e[g][i];
+      nE2_[g] = last ? nE_[g] : H.e[g][i + 1];
+      ngx_[g] = H.xg[g][i];
+      if (!last) nlr_[g] = H.lx[g][i];
+      nln_[g] = H.lne[g][i];
     }
   }
-  const int c = A.cursor[0];  // slice accepted last (-1: none yet in this block of moves)
-  const int cn = c + 1;       // slice proposed, evaluated and accepted here
-  const double* r = A.blk + (long long)cn * 3 * A.ns;
-  const int* idx = reinterpret_cast<const int*>(r + 2 * A.ns);
-  if (tid == 0) {
-    hi[HI_CNT] = 0;
-    hi[HI_NA] = 0;
-    hi[HI_NS] = 0;
-  }
-  // lx of every grid, the single-row tables, the synchrotron grid's powers -> LDS
-  for (int g = 0; g < G.n; ++g) {
-    const int nG = G.nG[g];
-    double* lxs = sm + D.o_lx[g];
-    for (int i = tid; i < nG - 1; i += T)
-      lxs[i] = G.lx[g] ? G.lx[g][i] : log(G.xg[g][i + 1] / G.xg[g][i]);
-  }
-  {
-    int ko = D.o_mkt;
-    for (int m = 0; m < A.nmom; ++m) {
-      const int nG = G.nG[A.mom[m].grid];
-      for (int i = tid; i < nG; i += T) {
-        sm[ko + i] = A.mom[m].Kt[i];
-        sm[ko + nG + i] = A.mom[m].dlnKt[i];
-      }
-      ko += 2 * nG;
-    }
-  }
-  if (has_syn) {
-    const int g = D.syn.grid, nG = G.nG[g];
-    const double* gam = G.xg[g];
-    for (int i = tid; i < nG; i += T) {
-      const double gi = gam[i];
-      const double v = 1.0 / (gi * gi);
-      sm[D.o_ig2 + i] = v;
-      sm[D.o_ig23 + i] = cbrt(v);
-      double d = 0.0;
-      if (i + 1 < nG) {
-        const double rr = gi / gam[i + 1];  // 1/g2^2 - 1/g1^2 without cancellation
-        d = v * (rr * rr - 1.0);
-      }
-      sm[D.o_dig2 + i] = d;
-    }
-  }
-  // ---- chain history of the ensemble step that the previous launch closed ---------------
-  // (hist->n counts the CLOSED steps -- the launch that accepts an odd slice increments it --
-  // and the row of the step closed last is n - 1: nh_hist_append writes the same row, so a
-  // row written by both is simply written twice)
-  if (A.hist && c >= 1 && (c & 1)) {
-    const long long rowh = A.hist->n - 1;
-    if (A.hist->coords && rowh < A.hist->cap) {
-      const long long N = 2LL * A.ns;
-      double* hc = A.hist->coords + rowh * N * A.ndim;
-      double* hl = A.hist->logp + rowh * N;
-      const int* idx2 = reinterpret_cast<const int*>(A.blk + (long long)(cn ^ 1) * 3 * A.ns +
-                                                     2 * A.ns);
-      // rows of this launch's own walkers (before their accept) and of the complementary
-      // half (nobody writes those); with fewer workgroups than walkers (sharded: the accept
-      // is a later launch) every workgroup takes several
-      for (int jj = j; jj < A.ns; jj += gridDim.x) {
-        for (int h = 0; h < 2; ++h) {
-          const int wr = h == 0 ? idx[jj] : idx2[jj];
-          for (int t = tid; t < A.ndim; t += T)
-            hc[(long long)wr * A.ndim + t] = A.coords[(long long)wr * A.ndim + t];
-          if (tid == 0) hl[wr] = A.logp[wr];
+  const bool lik_wave = wv == (nwv > 1 ? 1 : 0);
+  // ---- the emission tables -> this XCD's L2.  Every launch starts with cold L2s, and the
+  // workgroups of an XCD walk a table in the same order at the same pace: without this every
+  // trip of every work item is a first touch that waits for the Infinity Cache (measured 2.3 us
+  // per trip).  Workgroup j (on XCD j % 8) requests slice j / 8 of each table now, while the
+  // proposal's chain and the weights keep the workgroup busy for the next ~10 us.
+  hs_u32x4 pfv[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pfv[q] = hs_u32x4{0u, 0u, 0u, 0u};
+  if (wv >= 1) {
+    const unsigned nbx = (gridDim.x + 7u) >> 3, mex = (unsigned)j >> 3;
+    for (int t = 0; t < H.npf; ++t) {
+      const unsigned bytes = H.pfbytes[t];
+      const unsigned per = ((bytes + nbx - 1) / nbx + 15u) & ~15u;
+      const unsigned lo2 = mex * per, hi2 = min(bytes, lo2 + per);
+      const __amdgpu_buffer_rsrc_t rr =
+          __builtin_amdgcn_make_buffer_rsrc((void*)H.pfKD[t], 0, (int)bytes, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned off = lo2 + ((unsigned)q * (unsigned)(T - 64) + (unsigned)(tid - 64)) * 16u;
+        if (off < hi2) {
+          const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
+          pfv[q] ^= v;
         }
       }
     }
   }
+  // ... its third trip as soon as the second is back (the prefetch is still in flight)
+  double pcj = 0.0, psj = 0.0, pold = 0.0;
+  if (tid < ndim_) {
+    pcj = coords_[(long long)pa * ndim_ + tid];
+    psj = coords_[(long long)me * ndim_ + tid];
+    if (tid == 0) pold = H.logp[me];
+  }
+  if (tid == 0) {
+    hi[HI_CNT] = 0;
+    hi[HI_LIVE] = 0;
+    if (j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
+  }
+  // history of the step the previous launch closed: descriptor now, rows below
+  const bool want_hist = H.hist != nullptr && c >= 1 && (c & 1);
+  double* hcoords = nullptr;
+  double* hlogp = nullptr;
+  long long hcap = 0;
+  if (want_hist) {
+    hcoords = H.hist->coords;
+    hlogp = H.hist->logp;
+    hcap = H.hist->cap;
+  }
   HS_STAMP(1);
+  // ---- grids' own arrays -> LDS ------------------------------------------------------------
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
+    if (g < H.ngrids && tid + 1 < H.nG[g]) sm[H.o_lx[g] + tid] = nlr_[g];
+  }
+  for (int g = 0; g < H.ngrids; ++g) {  // grids longer than the workgroup
+    const int nG = H.nG[g];
+    for (int i = tid + T; i < nG - 1; i += T) sm[H.o_lx[g] + i] = H.lx[g][i];
+  }
+  // the single-row tables (We, Wp), the likelihood's data columns: loaded and parked in LDS
+  // by the waves that are NOT on the proposal's chain (a load-then-store loop waits a whole
+  // round trip; they have until the first barrier)
+  if (wv >= 1 || nwv == 1) {
+    const int t0 = nwv == 1 ? tid : tid - 64, TT = nwv == 1 ? T : T - 64;
+    int ko = H.o_mkt;
+    for (int m = 0; m < H.nmom; ++m) {
+      const int nG = H.nG[H.mgrid[m]];
+      for (int i = t0; i < nG; i += TT) {
+        sm[ko + i] = H.mKt[m][i];
+        sm[ko + nG + i] = H.mdK[m][i];
+      }
+      ko += 2 * nG;
+    }
+    double* lik = sm + H.o_lik;  // conv | flux | elo | ehi | ul, nE each
+    for (int k = TT - 1 - t0; k < H.nE; k += TT) {
+      lik[k] = H.conv[k];
+      lik[H.nE + k] = H.flux[k];
+      lik[2 * H.nE + k] = H.elo[k];
+      lik[3 * H.nE + k] = H.ehi[k];
+      lik[4 * H.nE + k] = (double)H.ul[k];
+    }
+  }
+  if (has_syn) {
+    const int g = H.syn_grid, nG = H.nG[g];
+    const double* gam = H.xg[g];
+    const double* lxg = H.lx[g];
+    for (int i = tid; i < nG; i += T) {
+      double gi = 1.0, lr = 0.0;
+      if (i < T) {  // this thread's own node of the synchrotron grid is in registers
+#pragma unroll
+        for (int q = 0; q < NH_MAX_GRIDS; ++q)
+          if (q == g) {
+            gi = ngx_[q];
+            lr = nlr_[q];
+          }
+      } else {
+        gi = gam[i];
+        lr = i + 1 < nG ? lxg[i] : 0.0;
+      }
+      const double v = 1.0 / (gi * gi);
+      sm[H.o_ig2 + i] = v;
+      sm[H.o_ig23 + i] = cbrt(v);
+      // 1/g2^2 - 1/g1^2 = (1/g1^2) (exp(-2 ln(g2/g1)) - 1), without cancellation
+      sm[H.o_dig2 + i] = i + 1 < nG ? v * expm1(-2.0 * lr) : 0.0;
+    }
+  }
+  // ---- chain history rows (the step closed by the previous launch; hist->n is not used:
+  // the row is the number of closed steps of this run - 1, what nh_hist_append is told too)
+  if (want_hist) {
+    const long long rowh = (long long)stepbase + (cn >> 1) - 1;
+    if (hcoords && rowh >= 0 && rowh < hcap) {
+      const long long N = 2LL * H.ns;
+      double* hc = hcoords + rowh * N * H.ndim;
+      double* hl = hlogp + rowh * N;
+      const int* idx2 = reinterpret_cast<const int*>(H.blk + (long long)(cn ^ 1) * 3 * H.ns +
+                                                     2 * H.ns);
+      // rows of this launch's own walkers (before their accept) and of the complementary
+      // half (nobody writes those); with fewer workgroups than walkers (sharded: the accept
+      // is a later launch) every workgroup takes several
+      for (int jj = j; jj < H.ns; jj += gridDim.x) {
+        for (int h = 0; h < 2; ++h) {
+          const int wr = h == 0 ? idx[jj] : idx2[jj];
+          for (int t = tid; t < H.ndim; t += T)
+            hc[(long long)wr * H.ndim + t] = H.coords[(long long)wr * H.ndim + t];
+          if (tid == 0) hl[wr] = H.logp[wr];
+        }
+      }
+    }
+  }
   // ---- 1. proposal ---------------------------------------------------------------------
-  if (tid < A.ndim) {
-    const int g = A.lo + j;
-    const double z = r[g];
-    const int me = idx[g], pa = idx[A.ns + g];
-    const double cj = A.coords[(long long)pa * A.ndim + tid];
-    const double sj = A.coords[(long long)me * A.ndim + tid];
-    const double q = cj - (cj - sj) * z;
-    A.qT[(long long)tid * A.nloc + j] = q;
+  if (tid < H.ndim) {
+    const double q = pcj - (pcj - psj) * mz;
+    H.qT[(long long)tid * H.nloc + j] = q;
     qs[tid] = q;
     if (tid == 0) {
-      A.factors[j] = (A.ndim - 1.0) * log(z);
-      accs[0] = z;
-      accs[1] = r[A.ns + g];
-      accs[2] = A.logp[me];
+      H.factors[j] = (H.ndim - 1.0) * log(mz);
+      accs[0] = mz;
+      accs[1] = mlnu;
+      accs[2] = pold;
       hi[HI_ME] = me;
       hi[HI_PA] = pa;
     }
   }
   __syncthreads();
   HS_STAMP(2);
+  {  // (the prefetched table bytes are not used; this keeps their loads in the program)
+    const hs_u32x4 pz = pfv[0] ^ pfv[1] ^ pfv[2];
+    if ((pz.x ^ pz.y ^ pz.z ^ pz.w) == 0x9e3779b9u && tid == 1023 && j < 0) hi[15] = 1;
+  }
   // ---- 2. parameter packs ----------------------------------------------------------------
-  if (tid < A.npk * NH_MAX_LAZY) {
+  if (tid < D.npk * NH_MAX_LAZY) {
     const int q = tid / NH_MAX_LAZY, col = tid % NH_MAX_LAZY;
-    if (col < A.pk[q].ncols) {
-      const nh_lazy& z = A.pk[q].cols[col];
+    if (col < D.pk[q].ncols) {
+      const nh_lazy& z = D.pk[q].cols[col];
       double v = z.a;
-      if (z.base) v = nh_lazy_apply(z, qs[(z.base - A.qT) / A.nloc]);
-      A.pk[q].out[(long long)j * A.pk[q].ld + col] = v;
-      if (A.pk[q].out == A.params) {
+      if (z.base) v = nh_lazy_apply(z, qs[(z.base - H.qT) / H.nloc]);
+      D.pk[q].out[(long long)j * D.pk[q].ld + col] = v;
+      if (D.pk[q].out == D.params) {
         row[col] = v;
         if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
       }
@@ -282,123 +424,139 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
   HS_STAMP(3);
   // ---- 3. particle weights on every grid (-> LDS); the synchrotron liveness search --------
   const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
+  double* spec = sm + H.o_spec;
+  double Bw = 0.0, qfac = 0.0;
+  if (has_syn) {
+    Bw = D.syn_bcol >= 0 ? row[D.syn_bcol] : D.synB[(long long)j * D.syn_ldB];
+    // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
+    qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
+  }
+  // liveness of every photon energy: first node that can contribute (exp(-x) == 0 in double
+  // beyond x = 746).  Tile t (64 energies) belongs to wave nwv-1-t (the waves at the back: the
+  // front ones carry the longest grids' weight nodes); each keeps its lanes' answers in
+  // registers and leaves the tile's count in LDS.  The live energies are compacted IN ORDER
+  // after the barrier (neighbouring lanes of a synchrotron work item then walk ranges of
+  // nearly the same length: compacted in arrival order the items ran 25 % longer).
+  int lv_i0 = 0, lv_k = -1;
+  double lv_q = 0.0, lv_E = 0.0;
+  bool lv_live = false;
+  int* tcnt = reinterpret_cast<int*>(sm + HS_O_INT) + 8;  // [<= 8] live energies per tile
+  const int syn_tiles = has_syn ? (H.syn_nE + 63) >> 6 : 0;
+  if (has_syn && nwv - 1 - wv < syn_tiles) {
+    const int nG = H.nG[H.syn_grid];
+    const double* ig2 = sm + H.o_ig2;
+    const int t = nwv - 1 - wv;
+    lv_k = t * 64 + lane;
+    lv_i0 = nG;
+    if (lv_k < H.syn_nE) {
+      lv_E = H.syn_E[lv_k];
+      lv_q = lv_E * qfac;
+      int lo = 0, hi2 = nG;  // first i with q*ig2[i] <= 746 (ig2 decreases with i)
+      while (lo < hi2) {
+        const int mid = (lo + hi2) >> 1;
+        if (lv_q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
+      }
+      lv_i0 = lo;
+    }
+    lv_live = lv_i0 < nG;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
+    if (lane == 0) tcnt[t] = __popcll(m);
+  }
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
-    if (g < G.n && tid < G.nG[g]) {
-      const int nG = G.nG[g], i = tid;
+    if (g < H.ngrids && tid < H.nG[g]) {
+      const int nG = H.nG[g], i = tid;
       const bool last = i + 1 >= nG;
       double nn, dsh;
-      pd_core(A.kind, p, nln_[g] - lg[0], nln_[g] - lg[1], lg[2] - lg[0], nE_[g] < p.eb,
+      pd_core(D.kind, p, nln_[g] - lg[0], nln_[g] - lg[1], lg[2] - lg[0], nE_[g] < p.eb,
               nE2_[g] < p.eb, nlr_[g], nn, dsh);
-      nn *= G.scale[g];
+      nn *= H.scale[g];
       const double wv_ = ngx_[g] * nn, dv = last ? 0.0 : nlr_[g] + dsh;
-      sm[D.o_w[g] + i] = wv_;
-      sm[D.o_d[g] + i] = dv;
+      sm[H.o_w[g] + i] = wv_;
+      sm[H.o_d[g] + i] = dv;
       if (D.write_weights) {
-        G.w[g][(long long)j * nG + i] = wv_;
-        G.dlw[g][(long long)j * nG + i] = dv;
+        D.w[g][(long long)j * nG + i] = wv_;
+        D.dlw[g][(long long)j * nG + i] = dv;
       }
     }
   }
-  for (int g = 0; g < G.n; ++g) {  // grids longer than the workgroup
-    const int nG = G.nG[g];
-    const double* e = G.e[g];
-    const double* xg = G.xg[g];
+  for (int g = 0; g < H.ngrids; ++g) {  // grids longer than the workgroup
+    const int nG = H.nG[g];
+    const double* e = H.e[g];
+    const double* xg = H.xg[g];
     for (int i = tid + T; i < nG; i += T) {
       const bool last = i + 1 >= nG;
       const double E = e[i];
       const double E2 = last ? E : e[i + 1];
       const double gx = xg[i];
       double lr = 0.0;
-      if (!last) lr = G.lx[g] ? G.lx[g][i] : log(xg[i + 1] / gx);
-      const double lnE = G.lne[g] ? G.lne[g][i] : log(E);
+      if (!last) lr = sm[H.o_lx[g] + i];
+      const double lnE = H.lne[g] ? H.lne[g][i] : log(E);
       double nn, dsh;
-      pd_core(A.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
+      pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
               dsh);
-      nn *= G.scale[g];
+      nn *= H.scale[g];
       const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
-      sm[D.o_w[g] + i] = wv_;
-      sm[D.o_d[g] + i] = dv;
+      sm[H.o_w[g] + i] = wv_;
+      sm[H.o_d[g] + i] = dv;
       if (D.write_weights) {
-        G.w[g][(long long)j * nG + i] = wv_;
-        G.dlw[g][(long long)j * nG + i] = dv;
-      }
-    }
-  }
-  double* spec = sm + D.o_spec;
-  double Bw = 0.0, qfac = 0.0;
-  if (has_syn) {
-    Bw = D.syn.bcol >= 0 ? row[D.syn.bcol] : D.syn.B[(long long)j * D.syn.ldB];
-    // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
-    qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
-    if (wv == nwv - 1) {
-      // liveness of every photon energy: first node that can contribute (exp(-x) == 0 in
-      // double beyond x = 746), compaction of the live ones, per-energy constants
-      const int nG = G.nG[D.syn.grid], nseg = nG - 1, nEs = D.syn.nE;
-      const double* ig2 = sm + D.o_ig2;
-      int* amap = reinterpret_cast<int*>(sm + D.o_amap);
-      int* ai0 = amap + nEs;
-      double* sq = sm + D.o_sq;  // q | cbrt(q) | CS1 per live energy
-      int base = 0;
-      long long live_nodes = 0;
-      for (int k0 = 0; k0 < nEs; k0 += 64) {
-        const int k = k0 + lane;
-        int i0 = nG;
-        double q = 0.0;
-        if (k < nEs) {
-          q = D.syn.E_eV[k] * qfac;
-          int lo = 0, hi2 = nG;
-          while (lo < hi2) {
-            const int mid = (lo + hi2) >> 1;
-            if (q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
-          }
-          i0 = lo;
-        }
-        const bool live = i0 < nG;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
-        if (live) {
-          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-          const int sb = max(i0 - 1, 0);
-          amap[pos] = k;
-          ai0[pos] = sb;
-          const double E_erg = D.syn.E_eV[k] * NH_ERG_PER_EV;
-          sq[pos] = q;
-          sq[nEs + pos] = cbrt(q);
-          // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
-          sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                              (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS * E_erg);
-        }
-        if (k < nEs && !live) spec[D.syn.spec_off + k] = 0.0;
-        int ln = live ? nseg - max(i0 - 1, 0) : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
-        live_nodes += __shfl(ln, 0, 64);
-        base += __popcll(m);
-      }
-      if (lane == 0) {
-        int Cd = 1, nS = 0;
-        if (base > 0) {
-          Cd = (int)((live_nodes / base + HS_SYN_NODES - 1) / HS_SYN_NODES);
-          Cd = min(max(Cd, 1), D.syn.cdmax);
-          nS = (base * Cd + 63) >> 6;
-        }
-        hi[HI_NA] = base;
-        hi[HI_CD] = Cd;
-        hi[HI_NS] = nS;
+        D.w[g][(long long)j * nG + i] = wv_;
+        D.dlw[g][(long long)j * nG + i] = dv;
       }
     }
   }
   __syncthreads();
   HS_STAMP(4);
-  // ---- 4. single-row reductions (We, Wp), one wave each ------------------------------------
-  if (wv < A.nmom) {
-    const nh_moment& m = A.mom[wv];
-    const int g = m.grid, nG = G.nG[g];
-    int ko = D.o_mkt;
-    for (int q = 0; q < wv; ++q) ko += 2 * G.nG[A.mom[q].grid];
-    const double* ws = sm + D.o_w[g];
-    const double* ds = sm + D.o_d[g];
-    const double* lxs = sm + D.o_lx[g];
+  // ordered compaction of the live energies + their constants, then chunks per live energy
+  // and the number of synchrotron work items (every thread computes the same)
+  int nA = 0, Cd = 1, nS = 0;
+  if (has_syn) {
+    const int nG = H.nG[H.syn_grid], nseg = nG - 1, nEs = H.syn_nE;
+    if (lv_k >= 0) {
+      int* amap = reinterpret_cast<int*>(sm + H.o_amap);
+      int* ai0 = amap + nEs;
+      double* sq = sm + H.o_sq;  // q | cbrt(q) | CS1 per live energy
+      const int t = nwv - 1 - wv;
+      int base = 0;
+      for (int q = 0; q < t; ++q) base += tcnt[q];
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
+      int ln = 0;
+      if (lv_live) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        const int sb = max(lv_i0 - 1, 0);
+        ln = nseg - sb;
+        amap[pos] = lv_k;
+        ai0[pos] = sb;
+        sq[pos] = lv_q;
+        sq[nEs + pos] = cbrt(lv_q);
+        // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
+        sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                            (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
+                             (lv_E * NH_ERG_PER_EV));
+      } else if (lv_k < nEs) {
+        spec[H.syn_spec_off + lv_k] = 0.0;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
+      if (lane == 0 && ln > 0) atomicAdd(&hi[HI_LIVE], ln);
+    }
+    for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
+    __syncthreads();
+    if (nA > 0) {
+      Cd = (hi[HI_LIVE] / nA + HS_SYN_NODES - 1) / HS_SYN_NODES;
+      Cd = min(max(Cd, 1), D.syn_cdmax);
+      nS = (nA * Cd + 63) >> 6;
+    }
+  }
+  // ---- 4. single-row reductions (We, Wp), one wave each (from the back) ------------------
+  if (nwv - 1 - wv < H.nmom) {
+    const int m = nwv - 1 - wv;
+    const int g = H.mgrid[m], nG = H.nG[g];
+    int ko = H.o_mkt;
+    for (int q = 0; q < m; ++q) ko += 2 * H.nG[H.mgrid[q]];
+    const double* ws = sm + H.o_w[g];
+    const double* ds = sm + H.o_d[g];
+    const double* lxs = sm + H.o_lx[g];
     double acc = 0.0;
     for (int sgm = lane; sgm < nG - 1; sgm += 64) {
       const double u1 = ws[sgm] * sm[ko + sgm];
@@ -407,15 +565,17 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
       acc += nh_seg_term(u1, u2, dl, lxs[sgm]);
     }
     acc = hs_wave_sum(acc);
-    if (lane == 0) m.out[j] = acc;
+    if (lane == 0) D.mom_out[m][j] = acc;
   }
   HS_STAMP(5);
   // ---- 5. work items: table reductions and synchrotron nodes, pulled from one counter ------
   {
-    const int nT = D.nT, nS = hi[HI_NS], nA = hi[HI_NA], Cd = hi[HI_CD];
+    const int nT = D.nT;
     const int both = 2 * min(nT, nS), total = nT + nS;
-    double* part_t = sm + D.o_part_t;
-    double* part_s = sm + D.o_part_s;
+    double* part_t = sm + H.o_part_t;
+    double* part_s = sm + H.o_part_s;
+    int dbg_nt = 0, dbg_ns = 0;
+    if (D.dbg && j == 0 && lane == 0) D.dbg[176 + wv] = (long long)wall_clock64();
     for (;;) {
       int it = 0;
       if (lane == 0) it = atomicAdd(&hi[HI_CNT], 1);
@@ -423,6 +583,15 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
       if (it >= total) break;
       bool is_tab;
       int ix;
+#if HS_ORDER == 1
+      is_tab = it < nT;
+      ix = is_tab ? it : it - nT;
+      (void)both;
+#elif HS_ORDER == 2
+      is_tab = it >= nS;
+      ix = is_tab ? it - nS : it;
+      (void)both;
+#else
       if (it < both) {
         is_tab = (it & 1) == 0;
         ix = it >> 1;
@@ -430,17 +599,29 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         is_tab = nT > nS;
         ix = it - (both >> 1);
       }
+#endif
+#ifdef HS_SKIP_TAB
+      if (is_tab) { part_t[ix * 64 + lane] = 0.0; continue; }
+#endif
+#ifdef HS_SKIP_SYN
+      if (!is_tab) { const int vt0 = ix * 64 + lane; if (vt0 / nA < Cd) part_s[(vt0 / nA) * H.syn_nE + vt0 % nA] = 0.0; continue; }
+#endif
+      if (is_tab) ++dbg_nt; else ++dbg_ns;
       if (is_tab) {
+        // (workgroups of one XCD start at different items: what one has fetched into the L2
+        // the others find there)
+        ix = (ix + (j >> 3) * 5) % nT;
         int t = 0;
         while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
         const hs_tab& tb = D.tab[t];
         const int loc = ix - tb.item0;
         const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
-        const int nG = G.nG[tb.grid];
+        const int tg = __builtin_amdgcn_readfirstlane(tb.grid);
+        const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
         const int s0 = chunk * D.seg, s1 = min(nG - 1, s0 + D.seg);
-        const double* ws = sm + D.o_w[tb.grid];
-        const double* ds = sm + D.o_d[tb.grid];
-        const double* lxs = sm + D.o_lx[tb.grid];
+        const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
+        const double* ds = sm + __builtin_amdgcn_readfirstlane(H.o_d[tg]);
+        const double* lxs = sm + __builtin_amdgcn_readfirstlane(H.o_lx[tg]);
         const double acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
                                      : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
         part_t[ix * 64 + lane] = acc;
@@ -449,16 +630,16 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         const int vt = ix * 64 + lane;
         const int a = vt % nA, ch = vt / nA;
         if (ch < Cd) {
-          const int g = D.syn.grid, nG = G.nG[g], nseg = nG - 1, nEs = D.syn.nE;
-          const int* amap = reinterpret_cast<const int*>(sm + D.o_amap);
+          const int g = H.syn_grid, nG = H.nG[g], nseg = nG - 1, nEs = H.syn_nE;
+          const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
           const int* ai0 = amap + nEs;
-          const double* ig2 = sm + D.o_ig2;
-          const double* dig2 = sm + D.o_dig2;
-          const double* ig23 = sm + D.o_ig23;
-          const double* wr = sm + D.o_w[g];
-          const double* dwr = sm + D.o_d[g];
-          const double* lxs = sm + D.o_lx[g];
-          const double* sq = sm + D.o_sq;
+          const double* ig2 = sm + H.o_ig2;
+          const double* dig2 = sm + H.o_dig2;
+          const double* ig23 = sm + H.o_ig23;
+          const double* wr = sm + H.o_w[g];
+          const double* dwr = sm + H.o_d[g];
+          const double* lxs = sm + H.o_lx[g];
+          const double* sq = sm + H.o_sq;
           const int sbeg = ai0[a];
           const int per = (nseg - sbeg + Cd - 1) / Cd;
           const int s0 = sbeg + ch * per;
@@ -492,6 +673,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         }
       }
     }
+    if (D.dbg && j == 0 && lane == 0) {
+      D.dbg[128 + wv] = (long long)wall_clock64();
+      D.dbg[144 + wv] = dbg_nt;
+      D.dbg[160 + wv] = dbg_ns;
+    }
   }
   HS_STAMP(6);
   __syncthreads();
@@ -504,31 +690,31 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         const int tile = k >> 6, ln = k & 63;
         double sum = 0.0;
         for (int cidx = 0; cidx < tb.chunks; ++cidx)
-          sum += sm[D.o_part_t + (tb.item0 + cidx * tb.tiles + tile) * 64 + ln];
+          sum += sm[H.o_part_t + (tb.item0 + cidx * tb.tiles + tile) * 64 + ln];
         if (tb.scale) sum *= tb.scale[k];
         spec[tb.spec_off + k] = sum;
         tb.out[(long long)j * tb.ldo + k] = sum;
       }
     }
     if (has_syn) {
-      const int nA = hi[HI_NA], Cd = hi[HI_CD], nEs = D.syn.nE;
-      const int* amap = reinterpret_cast<const int*>(sm + D.o_amap);
-      for (int a = tid; a < nA; a += T) {
+      const int nEs = H.syn_nE;
+      const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
+      for (int a = T - 1 - tid; a < nA; a += T) {  // (from the back: the tables took the front)
         double sum = 0.0;
-        for (int cidx = 0; cidx < Cd; ++cidx) sum += sm[D.o_part_s + cidx * nEs + a];
+        for (int cidx = 0; cidx < Cd; ++cidx) sum += sm[H.o_part_s + cidx * nEs + a];
         sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
-        spec[D.syn.spec_off + amap[a]] = sum;
+        spec[H.syn_spec_off + amap[a]] = sum;
       }
     }
   }
   __syncthreads();
-  if (has_syn)
-    for (int k = tid; k < D.syn.nE; k += T)
-      D.syn.out[(long long)j * D.syn.ldo + k] = spec[D.syn.spec_off + k];
   HS_STAMP(8);
+  if (has_syn)
+    for (int k = tid; k < H.syn_nE; k += T)
+      D.syn_out[(long long)j * D.syn_ldo + k] = spec[H.syn_spec_off + k];
   // ---- 7. likelihood + priors (core.py:64-121) and the accept, one wave ---------------------
-  if (wv == 0) {
-    const int nE = D.nE;
+  if (lik_wave) {
+    const int nE = H.nE;
     double prior = 0.0;
     const bool has_prior = D.lp || D.pri.n > 0;
     if (has_prior && lane == 0) {
@@ -537,10 +723,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         const nh_lazy& z = D.pri.t[t].x;
         double v = z.a;
         if (z.base) {
-          const long long d = z.base - A.qT;
+          const long long d = z.base - H.qT;
           // a term on one of this walker's proposed coordinates: taken from LDS
-          v = (d >= 0 && d < (long long)A.ndim * A.nloc && d % A.nloc == 0 && z.stride == 1)
-                  ? nh_lazy_apply(z, qs[d / A.nloc])
+          v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
+                  ? nh_lazy_apply(z, qs[d / H.nloc])
                   : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
         }
         const double p0 = D.pri.t[t].p0, p1 = D.pri.t[t].p1;
@@ -556,7 +742,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
     }
     double acc = 0.0;
     int nviol = 0, nul = 0;
-    for (int k = lane; k < nE; k += 64) {
+    auto column = [&](int k, double conv, double f, double elo, double ehi, int ul) {
       double m = 0.0;
       for (int q = 0; q < D.ncomp; ++q) {
         const double v = D.comp[q].off >= 0 ? spec[D.comp[q].off + k]
@@ -564,16 +750,20 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
         m += D.comp[q].scale * v;
       }
       if (D.model_out) D.model_out[(long long)j * nE + k] = m;
-      const double mc = m * D.conv[k];
-      const double f = D.flux[k];
-      if (D.ul[k]) {
+      const double mc = m * conv;
+      if (ul) {
         nul += 1;
         nviol += (mc > f) ? 1 : 0;
       } else {
         const double d = mc - f;
-        const double sg = (d > 0.0) ? D.ehi[k] : D.elo[k];
+        const double sg = (d > 0.0) ? ehi : elo;
         acc += -(d * d) / (2.0 * (sg * sg));
       }
+    };
+    {
+      const double* lik = sm + H.o_lik;
+      for (int k = lane; k < nE; k += 64)
+        column(k, lik[k], lik[nE + k], lik[2 * nE + k], lik[3 * nE + k], lik[4 * nE + k] != 0.0);
     }
     int cnt = nviol | (nul << 16);
 #pragma unroll
@@ -587,44 +777,58 @@ __global__ __launch_bounds__(1024) void k_half_step(const hs_dev* __restrict__ D
       nviol = cnt & 0xffff;
       nul = cnt >> 16;
       // quirk kept from core.py:89-92: cl is indexed by the violation count
-      if (nul > 0) acc += (double)nviol * log(1.0 - D.cl[nviol]);
+      if (nul > 0) acc += (double)nviol * log(1.0 - H.cl[nviol]);
       if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
       D.total[j] = acc;
     }
     if (D.do_accept) {  // emcee RedBlueMove.propose for this walker
       acc = __shfl(acc, 0, 64);
       const double z = accs[0];
-      const double d = (A.ndim - 1.0) * log(z) + acc - accs[2];
+      const double d = (H.ndim - 1.0) * log(z) + acc - accs[2];
       const bool ok = accs[1] < d;  // NaN compares false, as numpy
-      const int me = hi[HI_ME];
+      const int me2 = hi[HI_ME];
       if (ok)
-        for (int t = lane; t < A.ndim; t += 64)
-          const_cast<double*>(A.coords)[(long long)me * A.ndim + t] = qs[t];
+        for (int t = lane; t < H.ndim; t += 64)
+          const_cast<double*>(H.coords)[(long long)me2 * H.ndim + t] = qs[t];
       if (lane == 0) {
-        const int g = A.lo + j;
+        const int g = H.lo + j;
         if (ok) {
-          const_cast<double*>(A.logp)[me] = acc;
-          if (D.naccepted) D.naccepted[me] += 1;
+          const_cast<double*>(H.logp)[me2] = acc;
+          if (D.naccepted) D.naccepted[me2] += 1;
         }
         D.accepted[g] = ok ? 1 : 0;
-        if (D.sel) D.sel[g] = me;
+        if (D.sel) D.sel[g] = me2;
       }
     }
+    // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
+    if (lane == 0) atomicAdd(H.done, 1);
   }
   HS_STAMP(9);
-  // ---- 8. the last workgroup to finish moves the cursor on ---------------------------------
-  __syncthreads();
-  HS_STAMP(10);
-  if (tid == 0) {
-    __threadfence();
-    if (atomicAdd(A.done, 1) == (int)gridDim.x - 1) {
-      *A.done = 0;
-      A.cursor[0] = cn;
-      if (A.hist && (cn & 1) && A.hist->coords) A.hist->n += 1;  // this launch closed a step
-    }
-  }
-  HS_STAMP(11);
 }
+
+// KD[i] = {Kt[i], dlnKt[i]}: the layout the half-step kernel streams (one 16-byte load per node)
+__global__ void k_table_interleave(const double* __restrict__ Kt, const double* __restrict__ dlnKt,
+                                   long long n, double* __restrict__ KD) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    KD[2 * i] = Kt[i];
+    KD[2 * i + 1] = dlnKt[i];
+  }
+}
+
+extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dlnKt, long long n,
+                                   double* KD) {
+  NH_REQUIRE(c && Kt && dlnKt && KD && n >= 0, "bad argument");
+  if (n == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_TABLES);
+  hipLaunchKernelGGL(k_table_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     Kt, dlnKt, n, KD);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// word := value, stream-ordered (the slice bookkeeping of nh_half_step_begin_block)
+__global__ void k_set_word(int* p, int v) { *p = v; }
 
 // history row `row` := the CURRENT ensemble (after the last half-step of a block of moves, at
 // the end of a run, before anybody reads the chain: no later launch would have written it)
@@ -651,8 +855,8 @@ extern "C" int nh_hist_append(nh_ctx* c, const double* coords, const double* log
 
 extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out) {
   NH_REQUIRE(c && d && out, "NULL pointer");
-  NH_REQUIRE(d->coords && d->logp && d->blk && d->cursor && d->done && d->qT && d->factors &&
-                 d->params && d->total, "NULL pointer in the descriptor");
+  NH_REQUIRE(d->coords && d->logp && d->blk && d->cursor && d->qT && d->factors && d->params &&
+                 d->total, "NULL pointer in the descriptor");
   NH_REQUIRE(d->ns >= 1 && d->ndim >= 1 && d->ndim <= 64 && d->lo >= 0 && d->nloc >= 1 &&
                  d->lo + d->nloc <= d->ns, "bad proposal block");
   NH_REQUIRE(!d->do_accept || (d->lo == 0 && d->nloc == d->ns && d->accepted),
@@ -667,13 +871,15 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   NH_REQUIRE(d->conv && d->flux && d->err_lo && d->err_hi && d->ul && d->cl, "NULL data column");
   NH_REQUIRE(d->nterms >= 0 && d->nterms <= NH_MAX_PRIOR, "bad prior terms");
   static_assert(NH_HS_MAX_TAB == HS_MAX_TAB, "table count");
-  hs_dev H;
+  static_assert(sizeof(hs_hot) <= 1024, "the by-value kernel argument must stay small");
+  hs_hot H;
+  hs_dev C;
   memset(&H, 0, sizeof(H));
-  front_args& A = H.F;
-  A.coords = d->coords; A.logp = d->logp; A.blk = d->blk; A.cursor = d->cursor; A.done = d->done;
-  A.ns = d->ns; A.ndim = d->ndim; A.lo = d->lo; A.nloc = d->nloc; A.qT = d->qT;
-  A.factors = d->factors; A.hist = d->hist; A.npk = d->npacks; A.kind = d->kind;
-  A.params = d->params; A.nmom = d->nmoms;
+  memset(&C, 0, sizeof(C));
+  H.coords = d->coords; H.logp = d->logp; H.blk = d->blk; H.cursor = d->cursor;
+  H.qT = d->qT; H.factors = d->factors; H.hist = d->hist;
+  H.ns = d->ns; H.ndim = d->ndim; H.lo = d->lo; H.nloc = d->nloc;
+  C.npk = d->npacks; C.kind = d->kind; C.params = d->params;
   bool have_params = false;
   for (int q = 0; q < d->npacks; ++q) {
     const nh_pack& pk = d->packs[q];
@@ -689,45 +895,47 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
       NH_REQUIRE(pk.ncols >= 7, "the particle rows need 7 columns");
       have_params = true;
     }
-    A.pk[q] = pk;
+    C.pk[q] = pk;
   }
   NH_REQUIRE(have_params, "params must be the output of one of the packs");
-  pw_grids& G = A.G;
-  G.n = d->ngrids;
-  G.off[0] = 0;
+  H.ngrids = d->ngrids;
   int off = HS_O_FREE;
   for (int g = 0; g < d->ngrids; ++g) {
     const nh_grid& gr = d->grids[g];
     NH_REQUIRE(gr.e_eV && gr.xg && gr.nG >= 2 && (!d->write_weights || (gr.w && gr.dlw)),
                "bad grid descriptor");
-    G.e[g] = gr.e_eV; G.xg[g] = gr.xg; G.w[g] = gr.w; G.dlw[g] = gr.dlw;
-    G.lne[g] = gr.ln_e; G.lx[g] = gr.lx; G.scale[g] = gr.unit_scale; G.nG[g] = gr.nG;
-    G.off[g + 1] = G.off[g] + gr.nG;
-    A.mom_off[g] = -1;
+    NH_REQUIRE(gr.ln_e && gr.lx, "the half-step kernel needs the grids' ln_e and lx arrays");
+    H.e[g] = gr.e_eV; H.xg[g] = gr.xg; H.lne[g] = gr.ln_e; H.lx[g] = gr.lx;
+    H.scale[g] = gr.unit_scale; H.nG[g] = gr.nG;
+    C.w[g] = gr.w; C.dlw[g] = gr.dlw;
     H.o_w[g] = off; off += gr.nG;
     H.o_d[g] = off; off += gr.nG;
     H.o_lx[g] = off; off += gr.nG;
   }
   H.o_mkt = off;
+  H.nmom = d->nmoms;
   for (int m = 0; m < d->nmoms; ++m) {
     NH_REQUIRE(d->moms[m].grid >= 0 && d->moms[m].grid < d->ngrids && d->moms[m].Kt &&
                    d->moms[m].dlnKt && d->moms[m].out, "bad reduction");
-    A.mom[m] = d->moms[m];
+    H.mKt[m] = d->moms[m].Kt; H.mdK[m] = d->moms[m].dlnKt; H.mgrid[m] = d->moms[m].grid;
+    C.mom_out[m] = d->moms[m].out;
     off += 2 * d->grids[d->moms[m].grid].nG;
   }
-  H.accepted = d->accepted; H.naccepted = d->naccepted; H.sel = d->sel;
-  H.do_accept = d->do_accept; H.write_weights = d->write_weights;
+  C.accepted = d->accepted; C.naccepted = d->naccepted; C.sel = d->sel;
+  C.do_accept = d->do_accept; C.write_weights = d->write_weights;
   // ---- synchrotron ----
-  H.syn.grid = -1;
+  H.syn_grid = -1;
   int nspec = 0;
+  int syn_nE = 0;
   if (d->syn.grid >= 0) {
     const nh_hs_syn& s = d->syn;
     NH_REQUIRE(s.grid < d->ngrids && s.E_eV && s.out && s.nE >= 1 && s.ldo >= s.nE &&
                    (s.bcol >= 0 ? s.bcol < NH_PD_NPAR : (s.B != nullptr && s.ldB >= 1)),
                "bad synchrotron component");
     const int nG = d->grids[s.grid].nG;
-    H.syn.grid = s.grid; H.syn.E_eV = s.E_eV; H.syn.B = s.B; H.syn.out = s.out; H.syn.nE = s.nE;
-    H.syn.ldo = s.ldo; H.syn.bcol = s.bcol; H.syn.ldB = s.ldB;
+    NH_REQUIRE(s.nE <= 512, "at most 512 photon energies for the synchrotron component");
+    H.syn_grid = s.grid; H.syn_E = s.E_eV; H.syn_nE = syn_nE = s.nE;
+    C.synB = s.B; C.syn_out = s.out; C.syn_ldo = s.ldo; C.syn_bcol = s.bcol; C.syn_ldB = s.ldB;
     H.o_ig2 = off; off += nG;
     H.o_dig2 = off; off += nG;
     H.o_ig23 = off; off += nG;
@@ -735,34 +943,63 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     H.o_amap = off; off += s.nE + 1;  // 2 nE ints
     int cdmax = 32;
     while (cdmax > 1 && (size_t)cdmax * s.nE * 8 > 40 * 1024) cdmax >>= 1;
-    H.syn.cdmax = cdmax;
+    C.syn_cdmax = cdmax;
     H.o_part_s = off; off += cdmax * s.nE;
-    H.syn.spec_off = nspec;
+    H.syn_spec_off = nspec;
     nspec += s.nE;
   }
-  // ---- table reductions ----
-  H.ntab = d->ntab;
+  // workgroup size: small reductions are bound by the dependent round trips, not by lanes
+  int maxnG = 0;
+  for (int g = 0; g < d->ngrids; ++g) maxnG = d->grids[g].nG > maxnG ? d->grids[g].nG : maxnG;
+  long long work = 0;
+  for (int t = 0; t < d->ntab; ++t)
+    work += (long long)((d->tab[t].nK + 63) / 64) * 64 * d->grids[d->tab[t].grid].nG * 12;
+  if (d->syn.grid >= 0) work += (long long)d->syn.nE * d->grids[d->syn.grid].nG * 110 / 3;
+  int threads = work >= (1 << 20) ? 1024 : (work >= (1 << 18) ? 512 : 256);
+  if (threads < 1024 && maxnG > threads) threads = maxnG > 512 ? 1024 : 512;
+  if (const char* e = getenv("NH_HS_THREADS")) threads = atoi(e);
+  NH_REQUIRE(threads >= 128 && threads <= 1024 && threads % 64 == 0, "bad workgroup size");
+  if (d->syn.grid >= 0 && threads / 64 < (d->syn.nE + 63) / 64 + 2) threads = 1024;
+  NH_REQUIRE(threads / 64 > d->nmoms + 1, "more single-row reductions than waves");
+  // ---- table reductions: work items of `seg` segments x 64 columns ----
+  // With a synchrotron component the items interleave with its (issue-bound) items and 32
+  // segments keep the waves evenly loaded; without one, ONE round of equal items over the
+  // waves that are free from the start (not on a single-row reduction) ends soonest.
+  C.ntab = d->ntab;
   int seg = 32;
+  if (d->syn.grid < 0 && d->ntab > 0) {
+    int tiles = 0, maxseg = 0;
+    for (int t = 0; t < d->ntab; ++t) {
+      tiles += (d->tab[t].nK + 63) / 64;
+      const int nseg = d->grids[d->tab[t].grid].nG - 1;
+      maxseg = nseg > maxseg ? nseg : maxseg;
+    }
+    const int free_waves = threads / 64 - d->nmoms;
+    const int per_tile = free_waves / tiles > 1 ? free_waves / tiles : 1;
+    seg = (maxseg + per_tile - 1) / per_tile;
+    if (seg < 8) seg = 8;
+  }
   for (;;) {
     int nT = 0;
     for (int t = 0; t < d->ntab; ++t) {
       const int tiles = (d->tab[t].nK + 63) / 64;
-      const int nseg = d->grids[d->tab[t].grid < 0 ? 0 : d->tab[t].grid].nG - 1;
+      const int nseg = d->grids[d->tab[t].grid].nG - 1;
       nT += tiles * ((nseg + seg - 1) / seg);
     }
     if (nT <= 96) break;
     seg *= 2;
   }
-  H.seg = seg;
+  C.seg = seg;
   int nT = 0;
   for (int t = 0; t < d->ntab; ++t) {
     const nh_hs_table& tb = d->tab[t];
-    NH_REQUIRE(tb.grid >= 0 && tb.grid < d->ngrids && tb.Kt && tb.dlnKt && tb.out && tb.nK >= 1 &&
+    NH_REQUIRE(tb.grid >= 0 && tb.grid < d->ngrids && tb.KD && tb.out && tb.nK >= 1 &&
                    tb.ldo >= tb.nK, "bad table reduction");
     const int nG = d->grids[tb.grid].nG;
-    NH_REQUIRE((long long)nG * tb.nK < (1LL << 28), "table too large for 32-bit offsets");
-    hs_tab& o = H.tab[t];
-    o.Kt = tb.Kt; o.dlnKt = tb.dlnKt; o.scale = tb.scale; o.out = tb.out; o.grid = tb.grid;
+    NH_REQUIRE((long long)nG * tb.nK < (1LL << 27), "table too large for 32-bit offsets");
+    hs_tab& o = C.tab[t];
+    o.KD = tb.KD; o.scale = tb.scale;
+    H.pfKD[t] = tb.KD; H.pfbytes[t] = (unsigned)nG * (unsigned)tb.nK * 16u; o.out = tb.out; o.grid = tb.grid;
     o.nK = tb.nK; o.ldo = tb.ldo; o.nonneg = tb.nonnegative;
     o.tiles = (tb.nK + 63) / 64;
     o.chunks = (nG - 1 + seg - 1) / seg;
@@ -771,85 +1008,89 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     o.spec_off = nspec;
     nspec += tb.nK;
   }
-  H.nT = nT;
+  C.nT = nT;
+  H.npf = d->ntab;
   H.o_part_t = off; off += nT * 64;
   H.o_spec = off; off += nspec;
-  H.nspec = nspec;
+  H.o_lik = off; off += 5 * d->nE;
   // ---- likelihood: where does each component of the model live? ----
-  H.ncomp = d->ncomp; H.nE = d->nE;
+  C.ncomp = d->ncomp; H.nE = d->nE;
   for (int q = 0; q < d->ncomp; ++q) {
     const nh_comp& cp = d->comps[q];
     NH_REQUIRE(cp.ptr && cp.ld >= d->nE, "bad component");
-    hs_comp& o = H.comp[q];
+    hs_comp& o = C.comp[q];
     o.ptr = cp.ptr; o.ld = cp.ld; o.scale = cp.scale; o.off = -1;
     for (int t = 0; t < d->ntab && o.off < 0; ++t) {
       const long long dd = cp.ptr - d->tab[t].out;
       if (dd >= 0 && dd + d->nE <= d->tab[t].nK && cp.ld == d->tab[t].ldo)
-        o.off = H.tab[t].spec_off + (int)dd;
+        o.off = C.tab[t].spec_off + (int)dd;
     }
     if (o.off < 0 && d->syn.grid >= 0) {
       const long long dd = cp.ptr - d->syn.out;
-      if (dd >= 0 && dd + d->nE <= d->syn.nE && cp.ld == d->syn.ldo) o.off = H.syn.spec_off + (int)dd;
+      if (dd >= 0 && dd + d->nE <= syn_nE && cp.ld == d->syn.ldo) o.off = H.syn_spec_off + (int)dd;
     }
   }
   H.conv = d->conv; H.flux = d->flux; H.elo = d->err_lo; H.ehi = d->err_hi; H.ul = d->ul;
-  H.cl = d->cl; H.lp = d->lp; H.model_out = d->model_out; H.total = d->total;
-  H.pri.n = d->nterms;
-  for (int t = 0; t < d->nterms; ++t) H.pri.t[t] = d->terms[t];
-  H.lds_doubles = off;
+  H.cl = d->cl;
+  C.lp = d->lp; C.model_out = d->model_out; C.total = d->total;
+  C.pri.n = d->nterms;
+  for (int t = 0; t < d->nterms; ++t) C.pri.t[t] = d->terms[t];
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 150 * 1024, "the model's grids and tables do not fit in LDS");
-  // workgroup size: small reductions are bound by the dependent round trips, not by lanes
-  int maxnG = 0;
-  for (int g = 0; g < d->ngrids; ++g) maxnG = d->grids[g].nG > maxnG ? d->grids[g].nG : maxnG;
-  long long work = (long long)nT * seg * 64 * 12;
-  if (d->syn.grid >= 0) work += (long long)d->syn.nE * d->grids[d->syn.grid].nG * 110 / 3;
-  int threads = work >= (1 << 20) ? 1024 : (work >= (1 << 18) ? 512 : 256);
-  if (threads < 1024 && maxnG > threads) threads = maxnG > 512 ? 1024 : 512;
-  if (const char* e = getenv("NH_HS_THREADS")) threads = atoi(e);
-  NH_REQUIRE(threads >= 128 && threads <= 1024 && threads % 64 == 0, "bad workgroup size");
-  NH_REQUIRE(threads / 64 > d->nmoms, "more single-row reductions than waves");
-  H.threads = threads;
-  H.dbg = nullptr;
+  C.dbg = nullptr;
   if (const char* e = getenv("NH_HS_DEBUG"))
     if (atoi(e) != 0) {
-      NH_CHECK_HIP(hipMalloc(&H.dbg, 128 * sizeof(long long)));
-      NH_CHECK_HIP(hipMemset(H.dbg, 0, 128 * sizeof(long long)));
+      NH_CHECK_HIP(hipMalloc(&C.dbg, 256 * sizeof(long long)));
+      NH_CHECK_HIP(hipMemset(C.dbg, 0, 256 * sizeof(long long)));
     }
   nh_halfstep_plan* P = new nh_halfstep_plan();
-  P->dbg = H.dbg;
+  P->dbg = C.dbg;
   P->lds_bytes = lds;
   P->threads = threads;
   P->blocks = d->nloc;
+  P->dev = nullptr;
+  P->words = nullptr;
   hipError_t e = hipMalloc(&P->dev, sizeof(hs_dev));
-  if (e != hipSuccess) {
-    delete P;
-    return nh_set_error(NH_ENOMEM, "hipMalloc(descriptor): %s", hipGetErrorString(e));
-  }
-  e = hipMemcpy(P->dev, &H, sizeof(hs_dev), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(P->dev);
-    delete P;
-    return nh_set_error(NH_EHIP, "hipMemcpy(descriptor): %s", hipGetErrorString(e));
-  }
-  if (lds > 64 * 1024) {
+  if (e == hipSuccess) e = hipMalloc(&P->words, 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpy(P->dev, &C, sizeof(hs_dev), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(P->words, 0, 2 * sizeof(int));
+  if (e == hipSuccess && lds > 64 * 1024)
     e = hipFuncSetAttribute((const void*)k_half_step, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-    if (e != hipSuccess) {
-      (void)hipFree(P->dev);
-      delete P;
-      return nh_set_error(NH_EHIP, "hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e));
-    }
+  if (e != hipSuccess) {
+    if (P->dev) (void)hipFree(P->dev);
+    if (P->words) (void)hipFree(P->words);
+    if (P->dbg) (void)hipFree(P->dbg);
+    delete P;
+    return nh_set_error(NH_EHIP, "half-step plan: %s", hipGetErrorString(e));
   }
+  H.D = P->dev;
+  H.done = P->words;
+  H.hbase = P->words + 1;
+  P->hot = H;
   *out = P;
   return NH_OK;
 }
 
-extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P) {
+// A new block of moves has been uploaded to `blk`: the next launch proposes its slice
+// `first_slice` (0, unless the caller has already worked through the first slices of the block
+// by other means).  steps_before = ensemble steps of this run completed before this block of
+// moves (the history row of the block's first step).  Stream-ordered, no host synchronisation.
+extern "C" int nh_half_step_begin_block(nh_ctx* c, nh_halfstep_plan* P, int first_slice,
+                                        int steps_before) {
+  NH_REQUIRE(c && P && first_slice >= 0 && steps_before >= 0, "bad argument");
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, c->stream, P->words, first_slice * P->blocks);
+  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, c->stream, P->words + 1, steps_before);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   NH_REQUIRE(c && P && P->dev, "bad argument");
   nh_prof_scope ps(c, NH_K_HALFSTEP);
+  const hs_hot& H = P->hot;
   hipLaunchKernelGGL(k_half_step, dim3((unsigned)P->blocks), dim3(P->threads), P->lds_bytes,
-                     c->stream, (const hs_dev*)P->dev);
+                     c->stream, (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo, H);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -864,14 +1105,15 @@ extern "C" int nh_half_step_info(const nh_halfstep_plan* P, int* threads, int* b
 }
 
 // NH_HS_DEBUG=1: the phase stamps (100 MHz wall clock) of the first 8 workgroups of the
-// last launch, out[8][16]; zeros when the plan was created without NH_HS_DEBUG
+// last launch, out[8][16], then for workgroup 0 per wave: end of its work items [16], table
+// items taken [16], synchrotron items taken [16], start of its first item [16]
 extern "C" int nh_half_step_stamps(nh_ctx* c, const nh_halfstep_plan* P, long long* out) {
   NH_REQUIRE(c && P && out, "bad argument");
-  memset(out, 0, 128 * sizeof(long long));
+  memset(out, 0, 256 * sizeof(long long));
   if (!P->dbg) return NH_OK;
   int rc = nh_sync(c);
   if (rc) return rc;
-  NH_CHECK_HIP(hipMemcpy(out, P->dbg, 128 * sizeof(long long), hipMemcpyDeviceToHost));
+  NH_CHECK_HIP(hipMemcpy(out, P->dbg, 256 * sizeof(long long), hipMemcpyDeviceToHost));
   return NH_OK;
 }
 
@@ -880,6 +1122,7 @@ extern "C" int nh_half_step_destroy(nh_ctx* c, nh_halfstep_plan* P) {
   if (!P) return NH_OK;
   int rc = nh_sync(c);
   if (P->dev) (void)hipFree(P->dev);
+  if (P->words) (void)hipFree(P->words);
   if (P->dbg) (void)hipFree(P->dbg);
   delete P;
   return rc;

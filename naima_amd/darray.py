@@ -62,7 +62,7 @@ class nh_prior(C.Structure):
 
 class nh_hs_table(C.Structure):
     _fields_ = [("grid", C.c_int), ("nK", C.c_int), ("ldo", C.c_int), ("nonnegative", C.c_int),
-                ("Kt", C.c_void_p), ("dlnKt", C.c_void_p), ("scale", C.c_void_p),
+                ("KD", C.c_void_p), ("reserved", C.c_void_p), ("scale", C.c_void_p),
                 ("out", C.c_void_p)]
 
 
@@ -75,7 +75,7 @@ class nh_hs_syn(C.Structure):
 class nh_hs_desc(C.Structure):
     """include/naima_hip.h: the descriptor of nh_half_step_create"""
     _fields_ = [("coords", C.c_void_p), ("logp", C.c_void_p), ("blk", C.c_void_p),
-                ("cursor", C.c_void_p), ("done", C.c_void_p),
+                ("cursor", C.c_void_p), ("reserved", C.c_void_p),
                 ("ns", C.c_int), ("ndim", C.c_int), ("lo", C.c_int), ("nloc", C.c_int),
                 ("qT", C.c_void_p), ("factors", C.c_void_p), ("hist", C.c_void_p),
                 ("accepted", C.c_void_p), ("naccepted", C.c_void_p), ("sel", C.c_void_p),

@@ -100,6 +100,10 @@ class DeviceLoop:
         # (table reductions, a synchrotron component, the likelihood), the whole half-step is
         # ONE launch: proposal -> ... -> accept (NAIMA_AMD_MEGA=0 keeps the three launches)
         self.mega = False
+        # next slice of the current block of moves / history rows before that block: what a
+        # half-step plan created in the middle of a block has to be told
+        self._pos = dict(slice=0, steps=0, bake=False)
+        self.multi_graphs = {}
         self._plan = None
         self._front_args = None
         self.done = ctx.empty((1,), dtype=np.int32)
@@ -308,7 +312,7 @@ class DeviceLoop:
         if self.mega:
             plan["mega"] = True
             plan["front"] = dict(coords=self.coords.ptr, logp=self.logp.ptr, blk=self.blk.ptr,
-                                 cursor=self.cursor.ptr, done=self.done.ptr, qT=self.qT.ptr,
+                                 cursor=self.cursor.ptr, pos=self._pos, qT=self.qT.ptr,
                                  factors=self.factors.ptr, hist=self.histd.ptr,
                                  accepted=self.accepted.ptr, naccepted=self.nacc.ptr,
                                  sel=self.sel.ptr, ns=self.ns, ndim=self.ndim, lo=self.lo,
@@ -370,6 +374,7 @@ class DeviceLoop:
         self._part_evaluate()
         self._exchange()
         self._part_accept()
+        self._pos["slice"] += 1
 
     def _init_state(self, coords_host, logp_host):
         ctx, s = self.ctx, self.s
@@ -457,6 +462,9 @@ class DeviceLoop:
                 ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
                 if not self.mega:
                     self._front()  # slice 0 of the new block
+                elif self._plan["hs"] is not None:
+                    ctx.call("nh_half_step_begin_block", self._plan["hs"]["plan"], 0,
+                             block["n"] if dev_hist else 0)
             else:
                 ctx.call("nh_memset", self.cursor, 0, 4)
             mark = self._markers[self._nmark % len(self._markers)]
@@ -465,6 +473,7 @@ class DeviceLoop:
             self._inflight.append(mark)
             k = 0
             while k < K:
+                self._pos["slice"], self._pos["steps"] = 2 * k, (block["n"] - k) if dev_hist else 0
                 # several steps per graph launch when nothing has to happen on the host
                 # between them (history is kept by the kernel, nobody reads the states)
                 g = 1
@@ -472,10 +481,13 @@ class DeviceLoop:
                         yield_every >= self.GSTEPS and (block is None or dev_hist) and
                         not (block is not None and block["blobs"])):
                     g = self.GSTEPS
-                    if self.multi_graph is None:
-                        self.multi_graph = self._capture(
-                            lambda: [self._half_step_body() for _ in range(2 * self.GSTEPS)])
-                    ctx.graph_launch(self.multi_graph)
+                    # one launch per half-step: the slices are baked into the graph (the
+                    # proposal's chain of dependent reads is one trip shorter), so there is
+                    # one graph per starting step of the block of moves
+                    key = k if self.mega else 0
+                    if key not in self.multi_graphs:
+                        self.multi_graphs[key] = self.multi_graph = self._capture_steps(k, g)
+                    ctx.graph_launch(self.multi_graphs[key])
                 elif (self.split and self.graph2 is not None and self.fused and
                         yield_every >= 2 and (block is None or dev_hist) and
                         not (block is not None and block["blobs"])):
@@ -507,7 +519,8 @@ class DeviceLoop:
                     # NEXT launch of the same block of moves; nothing follows the last one of
                     # a block, and whoever is handed this state may read the chain
                     self._flush_pending()
-                    ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim, self.histd, -1)
+                    ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim, self.histd,
+                             block["n"] - 1)
                 yield DeviceState(self, rng)
         self._flush_pending()
 
@@ -526,6 +539,19 @@ class DeviceLoop:
         if self._pending:
             self.ctx.graph_launch(self.graph2)
             self._pending = False
+
+    def _capture_steps(self, k0, nsteps):
+        """hipGraph of ``nsteps`` ensemble steps starting at step k0 of a block of moves"""
+        def run():
+            for i in range(2 * nsteps):
+                self._pos["slice"] = 2 * k0 + i
+                self._half_step_body()
+
+        self._pos["bake"] = bool(self.mega)
+        try:
+            return self._capture(run)
+        finally:
+            self._pos["bake"] = False
 
     def _capture(self, fn):
         ctx = self.ctx

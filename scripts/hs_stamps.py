@@ -21,9 +21,10 @@ print(name, nw, "threads", hs["threads"], "blocks", hs["blocks"], "lds", hs["lds
 acc = []
 for rep in range(20):
     st = s.run_mcmc(st, 1, store=False)
-    out = np.zeros(128, dtype=np.int64)
+    out = np.zeros(256, dtype=np.int64)
     _lib._chk(_lib._lib.nh_half_step_stamps(ctx.h, hs["plan"], out.ctypes.data))
-    acc.append(out.reshape(8, 16)[:, :12].astype(float))
+    acc.append(out[:128].reshape(8, 16)[:, :12].astype(float))
+    last = out
 a = np.array(acc)  # [rep][block][phase]
 d = (a - a[:, :, :1]) / 100.0  # us since the block's start
 names = ["start", "prefetch issued", "proposal", "packs", "weights+live", "moments", "items done",
@@ -31,3 +32,7 @@ names = ["start", "prefetch issued", "proposal", "packs", "weights+live", "momen
 m = np.median(d, axis=0)
 for b in (0, 3, 7):
     print("block", b, " ".join("%s=%.2f" % (n, v) for n, v in zip(names, m[b])))
+t0 = last[0]
+print("block 0 per wave: item-phase start / end (us since block start), table items, syn items")
+for w in range(hs["threads"] // 64):
+    print("  wave %2d: %.2f -> %.2f  tab %d syn %d" % (w, (last[176 + w] - t0) / 100.0, (last[128 + w] - t0) / 100.0, last[144 + w], last[160 + w]))
