@@ -424,7 +424,8 @@ int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
 /* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the
  * first 8 workgroups of the last launch, out[8][16], followed by 4 x 16 per-wave figures of
- * workgroup 0 (256 values in all); all zero otherwise */
+ * workgroup 0, then start[1024] and end[1024] stamps of every workgroup (2304 values in all);
+ * all zero otherwise */
 int nh_half_step_stamps(nh_ctx* ctx, const nh_halfstep_plan* plan, long long* out);
 /* row `row` (-1: hist->n - 1) of the device-resident history := coords[N][ndim] / logp[N] */
 int nh_hist_append(nh_ctx* ctx, const double* coords, const double* logp, long long N, int ndim,

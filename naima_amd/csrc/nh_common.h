@@ -130,6 +130,14 @@ __device__ __forceinline__ double nh_rcp1(double x) {
   return fma(r, fma(-x, r, 1.0), r);
 }
 
+// 1/x seeded in single precision (v_cvt + v_rcp_f32 + v_cvt: 9 cycles against 18 for
+// v_rcp_f64, same 2^-23 seed) + one Newton step: 3e-14 relative.  |x| beyond the float
+// range gives 0 (the NH_DL_ZERO marker relies on it), |x| < 1e-38 is the caller's series.
+__device__ __forceinline__ double nh_rcp1f(double x) {
+  const double r = (double)__builtin_amdgcn_rcpf((float)x);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+
 // SIGNED = false promises u1, u2 >= 0 (non-negative table and amplitude): the
 // sign-change / NaN-ratio test of the log branch is then dead code
 template <bool SIGNED = true>
@@ -141,7 +149,7 @@ __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, d
   f = fma(f, dl, 1.0);
   const double ul = u1 * lx;
   const double ts = ul * f;
-  const double td = (u2 - u1) * lx * nh_rcp1(dl);
+  const double td = (u2 - u1) * lx * nh_rcp1f(dl);  // (discarded when |dl| < 2^-7)
   double t = (fabs(dl) < 0.0078125) ? ts : td;
   if (SIGNED) {
     // sign change or NaN ratio -> NaN b in the reference -> its log branch x1*y1*ln(x2/x1)
@@ -165,14 +173,6 @@ __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, d
 #define NH_SEG_SMALL_POS 0x1p-10
 #endif
 #define NH_DL_ZERO 1e300
-// 1/x seeded in single precision (v_cvt + v_rcp_f32 + v_cvt: 9 cycles against 18 for
-// v_rcp_f64, same 2^-23 seed) + one Newton step: 3e-14 relative.  |x| beyond the float
-// range gives 0 (the NH_DL_ZERO marker relies on it), |x| < 1e-38 is the caller's series.
-__device__ __forceinline__ double nh_rcp1f(double x) {
-  const double r = (double)__builtin_amdgcn_rcpf((float)x);
-  return fma(r, fma(-x, r, 1.0), r);
-}
-
 template <bool ZERO>
 __device__ __forceinline__ double nh_seg_pos(double u1, double u2, double dl, double lx) {
   double t = ((u2 - u1) * lx) * nh_rcp1f(dl);

@@ -43,6 +43,7 @@
 struct hs_tab {
   const double* KD; const double* scale; double* out;  // KD: interleaved {K, dlnK}, [nG][nK][2]
   int grid, nK, ldo, nonneg, spec_off, tiles, item0, chunks;
+  int sub, nKp;  // nK <= 32: sub = 64 / nKp sub-ranges of an item share a wave (nKp = 32, 16, ...)
 };
 
 struct hs_comp { const double* ptr; long long ld; double scale; int off; int pad; };
@@ -90,9 +91,10 @@ struct hs_hot {
   const double* syn_E;
   const double* conv; const double* flux; const double* elo; const double* ehi;
   const int* ul; const double* cl;
-  int nE, npf;
-  const double* pfKD[HS_MAX_TAB];   // the interleaved tables, for the L2 prefetch
-  unsigned pfbytes[HS_MAX_TAB];
+  int nE, ntab;
+  const double* tscale[HS_MAX_TAB];  // per-column factors of the table reductions (or NULL)
+  int tnK[HS_MAX_TAB], tspec[HS_MAX_TAB];
+  int o_scale, pad3;
 };
 
 struct nh_halfstep_plan {
@@ -105,15 +107,17 @@ struct nh_halfstep_plan {
 };
 
 // ints at the head of the LDS block (after qs/row/lg/acc)
-enum { HI_ME = 0, HI_PA, HI_NA, HI_CD, HI_NS, HI_CNT, HI_LIVE };
+enum { HI_ME = 0, HI_PA, HI_READY, HI_CD, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
 #define HS_O_ROW 64
 #define HS_O_LG 72
 #define HS_O_ACC 76   // z, lnU, old logp, (pad)
 #define HS_O_INT 80   // 16 ints
-#define HS_O_FREE 88
+#define HS_O_T64 88   // 2^(j/64), j < 64: the table of nh_exp_tab
+#define HS_O_FREE 152
 #define HS_STAMP(k)                                                                    \
   do {                                                                                  \
     if (D.dbg && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64();   \
+    if (D.dbg && tid == 0 && j < 1024) D.dbg[2304 + j * 16 + (k)] = (long long)wall_clock64(); \
   } while (0)
 
 __device__ __forceinline__ double hs_wave_sum(double v) {
@@ -197,6 +201,59 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
   return acc;
 }
 
+// The same for a table of at most 32 columns: a wave of 64 lanes would leave half of them (or
+// more) idle, and the loop is bound by instruction issue -- so `sub` = 64 / nKp sub-ranges of
+// the item's segments share the wave (lane = h nKp + k walks sub-range h of column k).  The
+// walker's w / dlw / lx reads are then per lane (LDS, `sub` distinct addresses per wave).
+template <bool SIGNED>
+__device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
+                                                       const double* ws, const double* ds,
+                                                       const double* lxs, int lane) {
+  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
+  const int nKp = __builtin_amdgcn_readfirstlane(t.nKp);
+  const int sub = __builtin_amdgcn_readfirstlane(t.sub);
+  const unsigned long long kd = (unsigned long long)t.KD;
+  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
+  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+  const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
+  const int k = lane & (nKp - 1), h = lane / nKp;
+  const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
+  const unsigned tbytes = (unsigned)nG * nK * 16u;
+  const __amdgpu_buffer_rsrc_t rKD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
+  const unsigned rowb = nK * 16u;
+  const int len = (s1 - s0 + sub - 1) / sub;     // segments per sub-range (wave-uniform)
+  const int sl = s0 + h * len;                   // this lane's first segment
+  const int se = min(s1, sl + len);              // ... and the end of its sub-range
+  unsigned ob = ((unsigned)sl * nK + kk) * 16u;  // (rows past the table read 0)
+  double acc = 0.0;
+  double K1, d1;
+  hs_buf_kd(rKD, ob, K1, d1);
+  double u1 = (sl < s1 ? ws[sl] : 0.0) * K1;
+  for (int q0 = 0; q0 < len; q0 += 8) {
+    double K2[8], dK[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int sg = sl + q0 + q;
+      const bool on = sg < se;
+      const int sc = on ? sg : s0;  // (a valid LDS address for the idle lanes)
+      const double u2 = ws[sc + 1] * K2[q];
+      const double dl = ds[sc] + d1;
+      const double term = SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[sc])
+                                 : nh_seg_pos<false>(u1, u2, dl, lxs[sc]);
+      acc += on ? term : 0.0;
+      u1 = u2;
+      d1 = dK[q];
+    }
+    ob += 8 * rowb;
+  }
+  // the sub-ranges of a column meet in its first lane group (fixed order: deterministic)
+  for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
+  return acc;
+}
+
 // The first arguments are what the proposal's chain of dependent reads starts from: scalar
 // kernel arguments can be preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count),
 // so the chain does not begin with a trip to the kernel-argument segment.
@@ -218,6 +275,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   int* hi = reinterpret_cast<int*>(sm + HS_O_INT);
   const bool has_syn = H.syn_grid >= 0;
   HS_STAMP(0);
+  if (D.dbg && tid == 0 && j < 1024) D.dbg[256 + j] = (long long)wall_clock64();
 
   // ---- 0. the first round trip: everything whose address is known at launch ---------------
   // which slice?  `done` counts the workgroups that have finished since the current block of
@@ -230,14 +288,20 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // of the bulk prefetch below, whose tens of loads per thread it would otherwise queue behind
   const double* r = blk_ + (long long)cn * 3 * ns_;
   const int* idx = reinterpret_cast<const int*>(r + 2 * ns_);
+  // A thread that evaluates a pack column (tid < 8 npacks) needs ONE proposed coordinate: it
+  // fetches that pair of coordinates itself, and its column's descriptor in the same trip as
+  // the slice -- no barrier and no LDS hop between the proposal and the packs.
+  const int npk8 = NH_MAX_PACK * NH_MAX_LAZY;
   int me = 0, pa = 0;
   double mz = 1.0, mlnu = 0.0;
-  if (tid < ndim_) {
+  nh_lazy pkz = {nullptr, 0, 0.0, 0.0, 0.0, 0, 0};
+  if (tid < max(ndim_, npk8)) {
     const int g = lo_ + j;
     me = idx[g];
     pa = idx[ns_ + g];
     mz = r[g];
     if (tid == 0) mlnu = r[ns_ + g];
+    if (tid < npk8) pkz = D.pk[tid / NH_MAX_LAZY].cols[tid % NH_MAX_LAZY];
   }
   const int stepbase = H.hbase[0];
   // (the grids' logarithms ln e and lx come with the grid: nh_half_step_create insists)
@@ -258,42 +322,24 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
   }
   const bool lik_wave = wv == (nwv > 1 ? 1 : 0);
-  // ---- the emission tables -> this XCD's L2.  Every launch starts with cold L2s, and the
-  // workgroups of an XCD walk a table in the same order at the same pace: without this every
-  // trip of every work item is a first touch that waits for the Infinity Cache (measured 2.3 us
-  // per trip).  Workgroup j (on XCD j % 8) requests slice j / 8 of each table now, while the
-  // proposal's chain and the weights keep the workgroup busy for the next ~10 us.
-  hs_u32x4 pfv[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) pfv[q] = hs_u32x4{0u, 0u, 0u, 0u};
-  if (wv >= 1) {
-    const unsigned nbx = (gridDim.x + 7u) >> 3, mex = (unsigned)j >> 3;
-    for (int t = 0; t < H.npf; ++t) {
-      const unsigned bytes = H.pfbytes[t];
-      const unsigned per = ((bytes + nbx - 1) / nbx + 15u) & ~15u;
-      const unsigned lo2 = mex * per, hi2 = min(bytes, lo2 + per);
-      const __amdgpu_buffer_rsrc_t rr =
-          __builtin_amdgcn_make_buffer_rsrc((void*)H.pfKD[t], 0, (int)bytes, 0x00020000);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const unsigned off = lo2 + ((unsigned)q * (unsigned)(T - 64) + (unsigned)(tid - 64)) * 16u;
-        if (off < hi2) {
-          const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
-          pfv[q] ^= v;
-        }
-      }
-    }
-  }
   // ... its third trip as soon as the second is back (the prefetch is still in flight)
-  double pcj = 0.0, psj = 0.0, pold = 0.0;
+  double pcj = 0.0, psj = 0.0, pold = 0.0, kcj = 0.0, ksj = 0.0;
   if (tid < ndim_) {
     pcj = coords_[(long long)pa * ndim_ + tid];
     psj = coords_[(long long)me * ndim_ + tid];
     if (tid == 0) pold = H.logp[me];
   }
+  int pkd = -1;  // the proposal coordinate this thread's pack column reads
+  if (tid < npk8 && pkz.base) {
+    pkd = (int)((pkz.base - H.qT) / H.nloc);
+    kcj = coords_[(long long)pa * ndim_ + pkd];
+    ksj = coords_[(long long)me * ndim_ + pkd];
+  }
   if (tid == 0) {
     hi[HI_CNT] = 0;
     hi[HI_LIVE] = 0;
+    hi[HI_READY] = 0;
+    hi[HI_NZ] = 0;
     if (j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
   }
   // history of the step the previous launch closed: descriptor now, rows below
@@ -308,6 +354,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   }
   HS_STAMP(1);
   // ---- grids' own arrays -> LDS ------------------------------------------------------------
+  if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
     if (g < H.ngrids && tid + 1 < H.nG[g]) sm[H.o_lx[g] + tid] = nlr_[g];
@@ -330,6 +377,9 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       }
       ko += 2 * nG;
     }
+    for (int t = 0; t < H.ntab; ++t)  // per-column factors of the reductions
+      for (int k = t0; k < H.tnK[t]; k += TT)
+        sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
     double* lik = sm + H.o_lik;  // conv | flux | elo | ehi | ul, nE each
     for (int k = TT - 1 - t0; k < H.nE; k += TT) {
       lik[k] = H.conv[k];
@@ -386,7 +436,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       }
     }
   }
-  // ---- 1. proposal ---------------------------------------------------------------------
+  // ---- 1. proposal + 2. parameter packs --------------------------------------------------
   if (tid < H.ndim) {
     const double q = pcj - (pcj - psj) * mz;
     H.qT[(long long)tid * H.nloc + j] = q;
@@ -400,19 +450,12 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       hi[HI_PA] = pa;
     }
   }
-  __syncthreads();
   HS_STAMP(2);
-  {  // (the prefetched table bytes are not used; this keeps their loads in the program)
-    const hs_u32x4 pz = pfv[0] ^ pfv[1] ^ pfv[2];
-    if ((pz.x ^ pz.y ^ pz.z ^ pz.w) == 0x9e3779b9u && tid == 1023 && j < 0) hi[15] = 1;
-  }
-  // ---- 2. parameter packs ----------------------------------------------------------------
   if (tid < D.npk * NH_MAX_LAZY) {
     const int q = tid / NH_MAX_LAZY, col = tid % NH_MAX_LAZY;
     if (col < D.pk[q].ncols) {
-      const nh_lazy& z = D.pk[q].cols[col];
-      double v = z.a;
-      if (z.base) v = nh_lazy_apply(z, qs[(z.base - H.qT) / H.nloc]);
+      double v = pkz.a;
+      if (pkd >= 0) v = nh_lazy_apply(pkz, kcj - (kcj - ksj) * mz);  // (the same q as qs[pkd])
       D.pk[q].out[(long long)j * D.pk[q].ld + col] = v;
       if (D.pk[q].out == D.params) {
         row[col] = v;
@@ -422,6 +465,40 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   }
   __syncthreads();
   HS_STAMP(3);
+  // ---- the priors (core.py:34-58, 99-101), now: a proposal the prior forbids is never accepted
+  // whatever its likelihood, so none of its integrals is evaluated (the reference evaluates
+  // the model and throws it away, core.py:103-119).  Besides the time saved on such walkers
+  // this keeps the launch time independent of how absurd they are: a negative B makes every
+  // (energy, gamma) node of the synchrotron integrand "live" -- 4x the work of a normal walker.
+  if (lik_wave && lane == 0) {
+    double prior = 0.0;
+    const bool has_prior = D.lp || D.pri.n > 0;
+    if (has_prior) {
+      prior = D.lp ? D.lp[j] : 0.0;
+      for (int t = 0; t < D.pri.n; ++t) {
+        const nh_lazy& z = D.pri.t[t].x;
+        double v = z.a;
+        if (z.base) {
+          const long long d = z.base - H.qT;
+          // a term on one of this walker's proposed coordinates: taken from LDS
+          v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
+                  ? nh_lazy_apply(z, qs[d / H.nloc])
+                  : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
+        }
+        const double p0 = D.pri.t[t].p0, p1 = D.pri.t[t].p1;
+        double rr;
+        switch (D.pri.t[t].kind) {
+          case NH_PRIOR_UNIFORM: rr = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
+          case NH_PRIOR_NORMAL: rr = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
+          case NH_PRIOR_LOGUNIFORM: rr = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
+          default: rr = v; break;
+        }
+        prior += rr;
+      }
+    }
+    accs[3] = prior;
+    hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
+  }
   // ---- 3. particle weights on every grid (-> LDS); the synchrotron liveness search --------
   const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
   double* spec = sm + H.o_spec;
@@ -460,8 +537,19 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
     lv_live = lv_i0 < nG;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
-    if (lane == 0) tcnt[t] = __popcll(m);
+    int ln = lv_live ? (nG - 1) - max(lv_i0 - 1, 0) : 0;  // segments this energy walks
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
+    if (lane == 0) {
+      tcnt[t] = __popcll(m);
+      if (ln > 0) atomicAdd(&hi[HI_LIVE], ln);
+    }
   }
+  // A grid on which EVERY weight is zero (a walker far off in parameter space: cutoff energy
+  // 10^-1000 TeV ...) contributes exact zeros to everything integrated over it (utils.py:347-348):
+  // its work items are skipped.  Such walkers are the ones that get stuck on the likelihood's
+  // zero-flux plateau; evaluated in full they cost 1.5x a normal walker and set the launch time.
+  int nzmask = 0;
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
     if (g < H.ngrids && tid < H.nG[g]) {
@@ -469,11 +557,12 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const bool last = i + 1 >= nG;
       double nn, dsh;
       pd_core(D.kind, p, nln_[g] - lg[0], nln_[g] - lg[1], lg[2] - lg[0], nE_[g] < p.eb,
-              nE2_[g] < p.eb, nlr_[g], nn, dsh);
+              nE2_[g] < p.eb, nlr_[g], nn, dsh, sm + HS_O_T64);
       nn *= H.scale[g];
       const double wv_ = ngx_[g] * nn, dv = last ? 0.0 : nlr_[g] + dsh;
       sm[H.o_w[g] + i] = wv_;
       sm[H.o_d[g] + i] = dv;
+      if (wv_ != 0.0) nzmask |= 1 << g;
       if (D.write_weights) {
         D.w[g][(long long)j * nG + i] = wv_;
         D.dlw[g][(long long)j * nG + i] = dv;
@@ -494,25 +583,46 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const double lnE = H.lne[g] ? H.lne[g][i] : log(E);
       double nn, dsh;
       pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
-              dsh);
+              dsh, sm + HS_O_T64);
       nn *= H.scale[g];
       const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
       sm[H.o_w[g] + i] = wv_;
       sm[H.o_d[g] + i] = dv;
+      if (wv_ != 0.0) nzmask |= 1 << g;
       if (D.write_weights) {
         D.w[g][(long long)j * nG + i] = wv_;
         D.dlw[g][(long long)j * nG + i] = dv;
       }
     }
   }
+  {
+    int any = nzmask;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
+    if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
+  }
   __syncthreads();
   HS_STAMP(4);
-  // ordered compaction of the live energies + their constants, then chunks per live energy
-  // and the number of synchrotron work items (every thread computes the same)
+  const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
+  // chunks per live energy and the number of synchrotron work items (every thread computes the
+  // same); the tile waves then compact the live energies IN ORDER and leave their constants
+  // in LDS -- nobody waits for that at a barrier: whoever pulls the first synchrotron item
+  // (the first pulls are table items) checks the ready count
   int nA = 0, Cd = 1, nS = 0;
   if (has_syn) {
-    const int nG = H.nG[H.syn_grid], nseg = nG - 1, nEs = H.syn_nE;
-    if (lv_k >= 0) {
+    const int nG = H.nG[H.syn_grid], nEs = H.syn_nE;
+    for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
+    const bool syn_zero = !(nz >> H.syn_grid & 1);  // nothing to integrate: every spectrum value is 0
+    if (nA > 0 && !syn_zero) {
+      Cd = (hi[HI_LIVE] / nA + HS_SYN_NODES - 1) / HS_SYN_NODES;
+      Cd = min(max(Cd, 1), D.syn_cdmax);
+      nS = (nA * Cd + 63) >> 6;
+    }
+    if (syn_zero) {
+      for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = 0.0;
+      nA = 0;
+    }
+    if (lv_k >= 0 && !syn_zero) {
       int* amap = reinterpret_cast<int*>(sm + H.o_amap);
       int* ai0 = amap + nEs;
       double* sq = sm + H.o_sq;  // q | cbrt(q) | CS1 per live energy
@@ -520,13 +630,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       int base = 0;
       for (int q = 0; q < t; ++q) base += tcnt[q];
       const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
-      int ln = 0;
       if (lv_live) {
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        const int sb = max(lv_i0 - 1, 0);
-        ln = nseg - sb;
         amap[pos] = lv_k;
-        ai0[pos] = sb;
+        ai0[pos] = max(lv_i0 - 1, 0);
         sq[pos] = lv_q;
         sq[nEs + pos] = cbrt(lv_q);
         // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
@@ -536,16 +643,9 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       } else if (lv_k < nEs) {
         spec[H.syn_spec_off + lv_k] = 0.0;
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
-      if (lane == 0 && ln > 0) atomicAdd(&hi[HI_LIVE], ln);
-    }
-    for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
-    __syncthreads();
-    if (nA > 0) {
-      Cd = (hi[HI_LIVE] / nA + HS_SYN_NODES - 1) / HS_SYN_NODES;
-      Cd = min(max(Cd, 1), D.syn_cdmax);
-      nS = (nA * Cd + 63) >> 6;
+      (void)nG;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&hi[HI_READY], 1);
     }
   }
   // ---- 4. single-row reductions (We, Wp), one wave each (from the back) ------------------
@@ -571,7 +671,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // ---- 5. work items: table reductions and synchrotron nodes, pulled from one counter ------
   {
     const int nT = D.nT;
-    const int both = 2 * min(nT, nS), total = nT + nS;
+    // pull order: a first round of table items (one per wave: the synchrotron constants are
+    // still being written), then the two kinds alternate, synchrotron (the longer items) first
+    const int F = min(nT, nwv);
+    const int both = 2 * min(nT - F, nS), total = nT + nS;
+    bool syn_ready = !has_syn;
     double* part_t = sm + H.o_part_t;
     double* part_s = sm + H.o_part_s;
     int dbg_nt = 0, dbg_ns = 0;
@@ -592,12 +696,15 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       ix = is_tab ? it - nS : it;
       (void)both;
 #else
-      if (it < both) {
-        is_tab = (it & 1) == 0;
-        ix = it >> 1;
+      if (it < F) {
+        is_tab = true;
+        ix = it;
+      } else if (it - F < both) {
+        is_tab = ((it - F) & 1) != 0;
+        ix = is_tab ? F + ((it - F) >> 1) : (it - F) >> 1;
       } else {
-        is_tab = nT > nS;
-        ix = it - (both >> 1);
+        is_tab = nT - F > nS;
+        ix = is_tab ? it - nS : it - nT;
       }
 #endif
 #ifdef HS_SKIP_TAB
@@ -622,11 +729,24 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
         const double* ds = sm + __builtin_amdgcn_readfirstlane(H.o_d[tg]);
         const double* lxs = sm + __builtin_amdgcn_readfirstlane(H.o_lx[tg]);
-        const double acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
-                                     : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
+        double acc;
+        if (!(nz >> tg & 1))
+          acc = 0.0;
+        else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
+          acc = tb.nonneg ? hs_table_item_packed<false>(tb, nG, s0, s1, ws, ds, lxs, lane)
+                          : hs_table_item_packed<true>(tb, nG, s0, s1, ws, ds, lxs, lane);
+        else
+          acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
+                          : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
         part_t[ix * 64 + lane] = acc;
       } else {
         // 64 (live energy, chunk) pairs of the synchrotron integrand
+        if (!syn_ready) {  // (wave-uniform) the tile waves' constants must have landed
+          while (__atomic_load_n(&hi[HI_READY], __ATOMIC_RELAXED) < syn_tiles)
+            __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          syn_ready = true;
+        }
         const int vt = ix * 64 + lane;
         const int a = vt % nA, ch = vt / nA;
         if (ch < Cd) {
@@ -640,6 +760,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           const double* dwr = sm + H.o_d[g];
           const double* lxs = sm + H.o_lx[g];
           const double* sq = sm + H.o_sq;
+          const double* T64 = sm + HS_O_T64;
           const int sbeg = ai0[a];
           const int per = (nseg - sbeg + Cd - 1) / Cd;
           const int s0 = sbeg + ch * per;
@@ -650,21 +771,23 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
             double u1 = 0.0, P1 = 1.0;
             {
               const double x = q * ig2[s0];
-              if (x <= 746.0) {
-                P1 = syn_P(cbq * ig23[s0]);
-                u1 = wr[s0] * (P1 * nh_exp_neg(x));  // gamma nelec dNdE / CS1, :335-338
+              const double w1 = wr[s0];
+              if (x <= 746.0 && w1 != 0.0) {  // (a zero weight makes the node an exact zero)
+                P1 = syn_P1(cbq * ig23[s0]);
+                u1 = w1 * (P1 * nh_exp_tab(-x, T64));  // gamma nelec dNdE / CS1, :335-338
               }
             }
             for (int s = s0; s < s1; ++s) {
               const double x = q * ig2[s + 1];
               double u2 = 0.0, P2 = 1.0;
-              if (x <= 746.0) {
-                P2 = syn_P(cbq * ig23[s + 1]);
-                u2 = wr[s + 1] * (P2 * nh_exp_neg(x));
+              const double w2 = wr[s + 1];
+              if (x <= 746.0 && w2 != 0.0) {
+                P2 = syn_P1(cbq * ig23[s + 1]);
+                u2 = w2 * (P2 * nh_exp_tab(-x, T64));
               }
               // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
-              const double dl = dwr[s] + syn_dlnP(P1, P2) - q * dig2[s];
-              acc += nh_seg_term<false>(u1, u2, dl, lxs[s]);
+              const double dl = dwr[s] + syn_dlnP1(P1, P2) - q * dig2[s];
+              acc += nh_seg_pos<true>(u1, u2, dl, lxs[s]);  // P(x) exp(-x) >= 0
               u1 = u2;
               P1 = P2;
             }
@@ -678,6 +801,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       D.dbg[144 + wv] = dbg_nt;
       D.dbg[160 + wv] = dbg_ns;
     }
+    if (D.dbg && j < 1024 && lane == 0) {
+      D.dbg[18688 + (j * 16 + wv) * 3] = (long long)wall_clock64();
+      D.dbg[18688 + (j * 16 + wv) * 3 + 1] = dbg_nt;
+      D.dbg[18688 + (j * 16 + wv) * 3 + 2] = dbg_ns | (nA << 8) | (Cd << 20);
+    }
   }
   HS_STAMP(6);
   __syncthreads();
@@ -688,10 +816,16 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const hs_tab& tb = D.tab[t];
       for (int k = tid; k < tb.nK; k += T) {
         const int tile = k >> 6, ln = k & 63;
+        const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
+        const int stride = tb.tiles * 64, chunks = tb.chunks;
         double sum = 0.0;
-        for (int cidx = 0; cidx < tb.chunks; ++cidx)
-          sum += sm[H.o_part_t + (tb.item0 + cidx * tb.tiles + tile) * 64 + ln];
-        if (tb.scale) sum *= tb.scale[k];
+        for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
+          sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        sum *= sm[H.o_scale + tb.spec_off + k];
         spec[tb.spec_off + k] = sum;
         tb.out[(long long)j * tb.ldo + k] = sum;
       }
@@ -700,8 +834,14 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const int nEs = H.syn_nE;
       const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
       for (int a = T - 1 - tid; a < nA; a += T) {  // (from the back: the tables took the front)
+        const double* pp = sm + H.o_part_s + a;
         double sum = 0.0;
-        for (int cidx = 0; cidx < Cd; ++cidx) sum += sm[H.o_part_s + cidx * nEs + a];
+        for (int c0 = 0; c0 < Cd; c0 += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
+          sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
         sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
         spec[H.syn_spec_off + amap[a]] = sum;
       }
@@ -715,31 +855,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // ---- 7. likelihood + priors (core.py:64-121) and the accept, one wave ---------------------
   if (lik_wave) {
     const int nE = H.nE;
-    double prior = 0.0;
     const bool has_prior = D.lp || D.pri.n > 0;
-    if (has_prior && lane == 0) {
-      prior = D.lp ? D.lp[j] : 0.0;
-      for (int t = 0; t < D.pri.n; ++t) {
-        const nh_lazy& z = D.pri.t[t].x;
-        double v = z.a;
-        if (z.base) {
-          const long long d = z.base - H.qT;
-          // a term on one of this walker's proposed coordinates: taken from LDS
-          v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
-                  ? nh_lazy_apply(z, qs[d / H.nloc])
-                  : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
-        }
-        const double p0 = D.pri.t[t].p0, p1 = D.pri.t[t].p1;
-        double rr;
-        switch (D.pri.t[t].kind) {
-          case NH_PRIOR_UNIFORM: rr = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
-          case NH_PRIOR_NORMAL: rr = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
-          case NH_PRIOR_LOGUNIFORM: rr = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
-          default: rr = v; break;
-        }
-        prior += rr;
-      }
-    }
+    const double prior = accs[3];  // (evaluated beside the weights, see above)
     double acc = 0.0;
     int nviol = 0, nul = 0;
     auto column = [&](int k, double conv, double f, double elo, double ehi, int ul) {
@@ -802,6 +919,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
     // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
     if (lane == 0) atomicAdd(H.done, 1);
+    if (D.dbg && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
   }
   HS_STAMP(9);
 }
@@ -999,20 +1117,29 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     NH_REQUIRE((long long)nG * tb.nK < (1LL << 27), "table too large for 32-bit offsets");
     hs_tab& o = C.tab[t];
     o.KD = tb.KD; o.scale = tb.scale;
-    H.pfKD[t] = tb.KD; H.pfbytes[t] = (unsigned)nG * (unsigned)tb.nK * 16u; o.out = tb.out; o.grid = tb.grid;
+    H.tscale[t] = tb.scale; H.tnK[t] = tb.nK; o.out = tb.out; o.grid = tb.grid;
     o.nK = tb.nK; o.ldo = tb.ldo; o.nonneg = tb.nonnegative;
     o.tiles = (tb.nK + 63) / 64;
+    o.nKp = 64;
+    o.sub = 1;
+    if (tb.nK <= 32) {
+      o.nKp = 32;
+      while (o.nKp / 2 >= tb.nK && o.nKp > 1) o.nKp /= 2;
+      o.sub = 64 / o.nKp;
+    }
     o.chunks = (nG - 1 + seg - 1) / seg;
     o.item0 = nT;
     nT += o.tiles * o.chunks;
     o.spec_off = nspec;
+    H.tspec[t] = nspec;
     nspec += tb.nK;
   }
   C.nT = nT;
-  H.npf = d->ntab;
   H.o_part_t = off; off += nT * 64;
   H.o_spec = off; off += nspec;
   H.o_lik = off; off += 5 * d->nE;
+  H.o_scale = off; off += nspec;
+  H.ntab = d->ntab;
   // ---- likelihood: where does each component of the model live? ----
   C.ncomp = d->ncomp; H.nE = d->nE;
   for (int q = 0; q < d->ncomp; ++q) {
@@ -1040,8 +1167,8 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   C.dbg = nullptr;
   if (const char* e = getenv("NH_HS_DEBUG"))
     if (atoi(e) != 0) {
-      NH_CHECK_HIP(hipMalloc(&C.dbg, 256 * sizeof(long long)));
-      NH_CHECK_HIP(hipMemset(C.dbg, 0, 256 * sizeof(long long)));
+      NH_CHECK_HIP(hipMalloc(&C.dbg, 67840 * sizeof(long long)));
+      NH_CHECK_HIP(hipMemset(C.dbg, 0, 67840 * sizeof(long long)));
     }
   nh_halfstep_plan* P = new nh_halfstep_plan();
   P->dbg = C.dbg;
@@ -1109,11 +1236,11 @@ extern "C" int nh_half_step_info(const nh_halfstep_plan* P, int* threads, int* b
 // items taken [16], synchrotron items taken [16], start of its first item [16]
 extern "C" int nh_half_step_stamps(nh_ctx* c, const nh_halfstep_plan* P, long long* out) {
   NH_REQUIRE(c && P && out, "bad argument");
-  memset(out, 0, 256 * sizeof(long long));
+  memset(out, 0, 67840 * sizeof(long long));
   if (!P->dbg) return NH_OK;
   int rc = nh_sync(c);
   if (rc) return rc;
-  NH_CHECK_HIP(hipMemcpy(out, P->dbg, 256 * sizeof(long long), hipMemcpyDeviceToHost));
+  NH_CHECK_HIP(hipMemcpy(out, P->dbg, 67840 * sizeof(long long), hipMemcpyDeviceToHost));
   return NH_OK;
 }
 

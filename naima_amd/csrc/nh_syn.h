@@ -87,3 +87,56 @@ __device__ __forceinline__ double syn_dlnP(double P1, double P2) {
   return 2.0 * s * a;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The same arithmetic on a diet, for the half-step kernel (issue-bound: every VALU slot of a
+// SIMD is taken, so instructions per node are what its time is made of).
+// ---------------------------------------------------------------------------------------
+// exp(x) for -1100 <= x <= 709 with a 64-entry table T64[j] = 2^(j/64) (in LDS):
+// x = (64 e + j) ln2/64 + r, |r| <= ln2/128 = 0.0054, exp(r) by a degree-5 polynomial
+// (next term r^6/720 = 3.5e-17): 15 VALU instructions and one LDS read against 19 + 13
+// s_nop for the degree-13 Horner form (the inline-asm FMAs with SGPR coefficients make the
+// assembler pad every one of them).  Gradual underflow through v_ldexp_f64.
+__device__ __forceinline__ double nh_exp_tab(double x, const double* __restrict__ T64) {
+  const double kf = rint(x * 92.33248261689366);    // 64 / ln 2
+  double r = fma(-kf, 0.010830424696223417, x);     // ln2/64: 36 leading bits ...
+  r = fma(-kf, 2.572804622327669e-14, r);           // ... and the rest
+  double p = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int k = (int)kf;
+  return ldexp(T64[k & 63] * p, k >> 6);
+}
+
+// P(x) of AKP10 Eq. D7 from cb = cbrt(x) with ONE reciprocal square root for both
+// 1/sqrt(1 + 3.4 cb^2) and 1/gt3:  P = 1.808 cb gt2 rsqrt(gt3^2 (1 + 3.4 cb^2))
+__device__ __forceinline__ double syn_P1(double cb) {
+  const double cb2 = cb * cb;
+  const double cb4 = cb2 * cb2;
+  const double t34 = fma(3.4, cb2, 1.0);
+  const double gt2 = fma(0.347, cb4, fma(2.210, cb2, 1.0));
+  const double gt3 = fma(0.217, cb4, fma(1.353, cb2, 1.0));
+  return ((1.808 * cb) * gt2) * nh_rsqrt((gt3 * gt3) * t34);
+}
+
+// ln(P2/P1) for neighbouring nodes: 2 atanh(s), s = (P2-P1)/(P2+P1).  Naima's default grids
+// (100 nodes per decade) have s^2 < 1e-4, where three terms are exact to 1.4e-13 relative
+// (5e-16 absolute); up to s^2 = 9e-4 five terms; coarser grids take the logarithm.
+__device__ __forceinline__ double syn_dlnP1(double P1, double P2) {
+  const double s = (P2 - P1) * nh_rcp1f(P2 + P1);
+  const double s2 = s * s;
+  if (__builtin_amdgcn_ballot_w64(s2 > 1e-4) != 0ull) {
+    asm volatile("" ::: "memory");  // keep the slower forms in the branch
+    if (__builtin_amdgcn_ballot_w64(s2 > 9e-4) != 0ull) return log(P2 / P1);
+    double a = fma(s2, 1.0 / 9.0, 1.0 / 7.0);
+    a = fma(a, s2, 0.2);
+    a = fma(a, s2, 1.0 / 3.0);
+    a = fma(a, s2, 1.0);
+    return 2.0 * s * a;
+  }
+  double a = fma(s2, 0.2, 1.0 / 3.0);
+  a = fma(a, s2, 1.0);
+  return (s + s) * a;
+}

@@ -252,3 +252,34 @@ def test_build_data_table_and_energy_edges():
         build_data_table(e, f)
     with pytest.raises(TypeError):
         build_data_table(e.value, f, flux_error=0.1 * f)
+
+
+def test_ctypes_mirrors_match_the_c_header(tmp_path):
+    """the ctypes Structures of naima_amd/darray.py have the sizes and field offsets a C
+    compiler gives the structs of include/naima_hip.h (a drifted mirror would hand the
+    library garbage without any error)"""
+    import ctypes as C
+    import subprocess
+
+    from naima_amd import darray as D
+    structs = ["nh_lazy", "nh_comp", "nh_grid", "nh_pack", "nh_moment", "nh_accept", "nh_prior",
+               "nh_hs_table", "nh_hs_syn", "nh_hs_desc"]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "naima_hip.h"', "int main(void) {"]
+    for name in structs:
+        cls = getattr(D, name)
+        lines.append('printf("%s %%zu", sizeof(%s));' % (name, name))
+        for f, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (name, f))
+        lines.append('printf("\\n");')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o",
+                           str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line in out:
+        parts = line.split()
+        cls = getattr(D, parts[0])
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(v) for v in parts[1:]] == want, parts[0]
