@@ -1,7 +1,9 @@
 """Results on disk with the layout of naima's ``save_run`` (analysis.py:366-471 of the
-reference: ``mcmc/{chain, log_prob, blobN, data}`` + attributes).  h5py is not installed
-on the target image, so the same keys go into a ``.npz``; ``read_run`` rebuilds a
-read-only result object with the attributes naima's post-processing reads."""
+reference: group ``mcmc`` with ``chain, log_prob, blobN, data`` + attributes).  With h5py
+the file IS the reference's HDF5 file (naima's own ``read_run`` reads it: checked when the
+golden schema is generated, tests/golden/gen_golden_run.py); h5py is not installed on the
+target image, where the same objects go into a ``.npz`` under the same names.  ``read_run``
+rebuilds a read-only result object with the attributes naima's post-processing reads."""
 import json
 
 import numpy as np
@@ -12,32 +14,146 @@ from .datatable import DataTable
 __all__ = ["save_run", "read_run", "save_results_table", "find_ML"]
 
 
+def _unit_string(unit):
+    """unit -> the string stored with a dataset, in astropy's spelling where the unit's name
+    is a plain product / quotient of named units: ``1 / (cm2 s TeV)``, ``erg / (cm2 s)`` --
+    factors by decreasing power, then alphabetically (case-insensitive), as
+    ``astropy.units.UnitBase.to_string()`` writes them.  Anything else is stored as named;
+    the reference reads either back with ``u.Quantity(..., unit=str)``."""
+    import re
+    if unit is None:
+        return ""
+    name = unit.name.strip()
+    m = re.fullmatch(r"([^/()]*?)\s*(?:/\s*\(?([^/()]*?)\)?)?", name)
+    tok = r"[A-Za-z]+\d*"
+    if not m:
+        return name
+    num, den = (m.group(1) or "").strip(), (m.group(2) or "").strip()
+    if num == "1":
+        num = ""
+    parts = []
+    for side in (num, den):
+        toks = side.split()
+        if any(not re.fullmatch(tok, t) for t in toks):
+            return name
+        split = [re.fullmatch(r"([A-Za-z]+)(\d*)", t).groups() for t in toks]
+        split.sort(key=lambda bp: (-int(bp[1] or 1), bp[0].lower()))
+        parts.append(" ".join(b + p for b, p in split))
+    num, den = parts
+    if not den:
+        return num
+    den = "(%s)" % den if " " in den else den
+    return "%s / %s" % (num or "1", den)
+
+
+def run_layout(sampler):
+    """What ``save_run`` writes, container-independent -- exactly the objects of the
+    reference's HDF5 file (analysis.py:366-471):
+
+      group ``mcmc``: attrs = run_info + ``acceptance_fraction`` + ``label<i>``
+        ``chain``     [nsteps][nwalkers][ndim]
+        ``log_prob``  [nsteps][nwalkers]
+        ``blob<i>``   blob i of every (step, walker), FLATTENED over steps x walkers
+                      (analysis.py:433-438), attr ``unit``
+        ``data``      the data table as a structured array (astropy ``write_table_hdf5``)
+        ``data.__table_column_meta__``  its YAML column / unit description, one line per row
+
+    Returns (attrs, datasets) with datasets[name] = (array, dataset attrs)."""
+    attrs = {}
+    for k, v in dict(getattr(sampler, "run_info", {})).items():
+        attrs[k] = v
+    attrs["acceptance_fraction"] = float(np.mean(sampler.acceptance_fraction))
+    for i, label in enumerate(sampler.labels):
+        attrs["label{0}".format(i)] = str(label)
+    ds = {"chain": (np.asarray(sampler.get_chain(), dtype=float), {}),
+          "log_prob": (np.asarray(sampler.get_log_prob(), dtype=float), {})}
+    blobs = sampler.get_blobs() or []
+    units = list(getattr(sampler, "blob_units", None) or [None] * len(blobs))
+    for j, b in enumerate(blobs):
+        b = np.asarray(b, dtype=float)
+        ds["blob{0}".format(j)] = (b.reshape((-1,) + b.shape[2:]), {"unit": _unit_string(units[j])})
+    data = getattr(sampler, "data", None)
+    if data is not None:
+        fields, lines, ser = [], ["datatype:"], {}
+        for k, v in data.items():
+            if isinstance(v, u.Quantity):
+                arr, un = np.asarray(v.value, dtype=float), _unit_string(v.unit)
+            else:
+                arr, un = np.asarray(v), None
+            if arr.dtype.kind == "i":
+                arr = arr.astype(np.int64)
+            fields.append((k, arr))
+            dt = {"f": "float64", "i": "int64", "b": "bool"}[arr.dtype.kind]
+            lines.append("- {{name: {0}, {1}datatype: {2}}}".format(
+                k, "unit: {0}, ".format(un) if un is not None else "", dt))
+            if un is not None:
+                ser[k] = un
+        n = len(fields[0][1])
+        table = np.zeros(n, dtype=[(k, a.dtype.str.replace("|b1", "?")) for k, a in fields])
+        for k, a in fields:
+            table[k] = a
+        # astropy's serialisation of the Quantity columns (alphabetical, one YAML anchor per
+        # distinct unit, in order of first appearance)
+        lines += ["meta: !!omap", "- __serialized_columns__:"]
+        anchors = {}
+        for k in sorted(ser):
+            un = ser[k]
+            lines += ["    {0}:".format(k), "      __class__: astropy.units.quantity.Quantity"]
+            if un in anchors:
+                lines.append("      unit: *{0}".format(anchors[un]))
+            else:
+                anchors[un] = "id{0:03d}".format(len(anchors) + 1)
+                lines.append("      unit: &{0} !astropy.units.Unit {{unit: {1}}}".format(anchors[un], un))
+            lines.append("      value: !astropy.table.SerializedColumn {{name: {0}}}".format(k))
+        ds["data"] = (table, {})
+        ds["data.__table_column_meta__"] = (np.array([x.encode() for x in lines]), {})
+    return attrs, ds
+
+
 def save_run(filename, sampler, compression=True, clobber=False):
     """Save the sampler chain, log-probabilities, blobs, data table, parameter labels and
-    run info to ``filename`` (``.npz`` appended if missing)."""
+    run info (analysis.py:366-471).  ``*.h5`` / ``*.hdf5``: the reference's HDF5 file,
+    object for object (needs h5py; naima's ``read_run`` reads it).  Anything else: the same
+    objects under the same names in a ``.npz`` (h5py is not installed on the target image)."""
     import os
+    attrs, ds = run_layout(sampler)
+    if filename.endswith((".h5", ".hdf5")):
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError("writing %s needs h5py; use a .npz file name for the same layout "
+                              "without it" % filename)
+        if os.path.exists(filename) and not clobber:
+            import warnings
+            warnings.warn("Not writing file because file exists and clobber is False")
+            return None
+        with h5py.File(filename, "w") as f:
+            g = f.create_group("mcmc")
+            for name, (arr, dattrs) in ds.items():
+                kw = {"compression": "gzip"} if compression and arr.ndim > 0 and arr.dtype.kind != "S" \
+                    else {}
+                d = g.create_dataset(name, data=arr, **kw)
+                for k, v in dattrs.items():
+                    d.attrs[k] = v
+            for k, v in attrs.items():
+                try:
+                    g.attrs[k] = v
+                except TypeError:
+                    g.attrs[k] = str(v)
+        return filename
     if not filename.endswith(".npz"):
         filename += ".npz"
     if os.path.exists(filename) and not clobber:
         raise OSError("{0} exists; pass clobber=True to overwrite".format(filename))
-    out = {"mcmc/chain": sampler.get_chain(), "mcmc/log_prob": sampler.get_log_prob()}
-    blobs = sampler.get_blobs() or []
-    units = list(getattr(sampler, "blob_units", None) or [None] * len(blobs))
-    for j, b in enumerate(blobs):
-        out["mcmc/blob%d" % j] = np.asarray(b)
-    meta = {"labels": list(sampler.labels), "run_info": dict(getattr(sampler, "run_info", {})),
-            "blob_units": [None if un is None else un.name for un in units],
-            "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
-            "data_units": {}}
-    data = getattr(sampler, "data", None)
-    if data is not None:
-        for k, v in data.items():
-            if isinstance(v, u.Quantity):
-                out["mcmc/data/" + k] = np.asarray(v.value)
-                meta["data_units"][k] = v.unit.name
-            else:
-                out["mcmc/data/" + k] = np.asarray(v)
-    out["meta"] = np.array(json.dumps(meta))
+    out = {}
+    dattrs = {}
+    for name, (arr, da) in ds.items():
+        out["mcmc/" + name] = arr
+        if da:
+            dattrs[name] = da
+    meta = {"attrs": {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in attrs.items()},
+            "dataset_attrs": dattrs}
+    out["mcmc.attrs"] = np.array(json.dumps(meta, default=str))
     (np.savez_compressed if compression else np.savez)(filename, **out)
     return filename
 
@@ -78,25 +194,57 @@ class _Result:
         return self._lp.T
 
 
-def read_run(filename):
-    """Read a run saved by ``save_run``."""
-    if not filename.endswith(".npz"):
-        filename += ".npz"
-    z = np.load(filename, allow_pickle=False)
-    meta = json.loads(str(z["meta"]))
-    blobs, j = [], 0
-    while "mcmc/blob%d" % j in z:
-        blobs.append(z["mcmc/blob%d" % j])
-        j += 1
+def _table_from(table, meta_lines):
+    """structured array + astropy column meta lines -> DataTable (units restored)"""
+    units = {}
+    for line in [x.decode() if isinstance(x, bytes) else str(x) for x in meta_lines]:
+        line = line.strip()
+        if line.startswith("- {name:") and "unit:" in line:
+            body = line[3:-1]
+            name = body.split("name:")[1].split(",")[0].strip()
+            units[name] = body.split("unit:")[1].rsplit(", datatype", 1)[0].strip()
     data = DataTable()
-    for key in z.files:
-        if key.startswith("mcmc/data/"):
-            name = key[len("mcmc/data/"):]
-            un = meta["data_units"].get(name)
-            data[name] = u.Quantity(z[key], u.Unit(un)) if un is not None else z[key]
-    units = [None if s is None else u.Unit(s) for s in meta["blob_units"]]
-    return _Result(z["mcmc/chain"], z["mcmc/log_prob"], blobs, units, data, meta["labels"],
-                   meta["run_info"], meta["acceptance_fraction"])
+    for name in table.dtype.names:
+        col = np.asarray(table[name])
+        data[name] = u.Quantity(col, u.Unit(units[name])) if name in units else col
+    return data
+
+
+def read_run(filename):
+    """Read a run saved by ``save_run`` (either container)."""
+    if filename.endswith((".h5", ".hdf5")):
+        import h5py
+        with h5py.File(filename, "r") as f:
+            g = f["mcmc"]
+            attrs = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in g.attrs.items()}
+            ds = {k: (np.array(g[k]), dict(g[k].attrs)) for k in g.keys()}
+    else:
+        if not filename.endswith(".npz"):
+            filename += ".npz"
+        z = np.load(filename, allow_pickle=False)
+        meta = json.loads(str(z["mcmc.attrs"]))
+        attrs = meta["attrs"]
+        ds = {k[len("mcmc/"):]: (z[k], meta["dataset_attrs"].get(k[len("mcmc/"):], {}))
+              for k in z.files if k.startswith("mcmc/")}
+    chain, log_prob = ds["chain"][0], ds["log_prob"][0]
+    nsteps, nwalkers = chain.shape[:2]
+    blobs, units, j = [], [], 0
+    while "blob%d" % j in ds:
+        arr, da = ds["blob%d" % j]
+        blobs.append(arr.reshape((nsteps, nwalkers) + arr.shape[1:]))
+        un = da.get("unit", "")
+        un = un.decode() if isinstance(un, bytes) else un
+        units.append(u.Unit(un) if un else None)
+        j += 1
+    data = _table_from(ds["data"][0], ds["data.__table_column_meta__"][0]) if "data" in ds else None
+    labels, i = [], 0
+    while "label%d" % i in attrs:
+        labels.append(attrs["label%d" % i])
+        i += 1
+    run_info = {k: v for k, v in attrs.items()
+                if not k.startswith("label") and k != "acceptance_fraction"}
+    return _Result(chain, log_prob, blobs, units, data, labels, run_info,
+                   attrs.get("acceptance_fraction"))
 
 
 def find_ML(sampler):

@@ -283,3 +283,44 @@ def test_ctypes_mirrors_match_the_c_header(tmp_path):
         cls = getattr(D, parts[0])
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(v) for v in parts[1:]] == want, parts[0]
+
+
+def test_validate_data_table_against_the_reference(golden):
+    """data ingest pinned by the reference: its validate_data_table (utils.py:38-213) over
+    its own table fixtures (tests/golden/data/*.dat are the reference's tests/data files,
+    data_tables.npz its outputs, gen_golden_data.py the script) -- every column of every
+    case: single tables with each energy-error spelling, upper limits + flux_ul, the cl
+    keyword, symmetric errors, an SED table; lists of tables in both orders with
+    sed = None / True / False (concatenation, unit conversion, energy sort, groups)"""
+    from naima_amd import datatable as DT
+    from naima_amd import units as u
+    z = golden("data_tables")
+    data_dir = os.path.join(ROOT, "tests", "golden", "data")
+    tables = {}
+    ncols = 0
+    for case in [str(c) for c in z["cases"]]:
+        kind, rest = case.split(":", 1)
+        if kind == "single":
+            tables[rest] = DT.read(os.path.join(data_dir, rest + ".dat"))
+            got = DT.validate_data_table(tables[rest])
+        else:
+            which, sed = rest.split(":sed=")
+            names = {"xray": "CrabNebula_Fake_Xray", "tev": "CrabNebula_HESS_ipac",
+                     "sed": "Fake_ipac_sed"}
+            lst = [DT.read(os.path.join(data_dir, names[k] + ".dat")) for k in which.split("+")]
+            got = DT.validate_data_table(lst, sed={"None": None, "True": True, "False": False}[sed])
+        cols = sorted(set(k.split("__")[1] for k in z.files if k.startswith(case + "__")))
+        assert set(cols) <= set(got.keys()), (case, set(cols) - set(got.keys()))
+        for col in cols:
+            want = z["%s__%s" % (case, col)]
+            key = "%s__%s__unit" % (case, col)
+            have = got[col]
+            if key in z.files:
+                have = have.to(u.Unit(str(z[key]))).value
+            have = np.asarray(have)
+            if want.dtype.kind in "bi":
+                assert np.array_equal(have.astype(want.dtype), want), (case, col)
+            else:
+                assert_allclose(have.astype(float), want, rtol=1e-13, atol=0, err_msg="%s %s" % (case, col))
+            ncols += 1
+    assert ncols >= 150  # (17 cases x 9 columns)
