@@ -363,6 +363,26 @@ int nh_stream_switch(nh_ctx* ctx, int side);
 int nh_stream_wait(nh_ctx* ctx, int waiter, int producer);
 int nh_stream_join(nh_ctx* ctx);
 
+/* ---- the general electron path: a particle grid PER WALKER --------------------------------
+ * Eemin / Eemax as per-walker values (fit parameters; the reference takes any keyword as
+ * per-call state, radiative.py:280, 430): walker w integrates over
+ *   gamma = logspace(log10(Eemin_w/mec2), log10(Eemax_w/mec2), max(10, int(nEed * decades)))
+ * (radiative.py:147-154), built with its weights in the workgroup's LDS; the emission kernel is
+ * evaluated at every (node, photon energy) -- no walker-independent table exists.
+ *   what = 0: Synchrotron._spectrum (radiative.py:282-342) with B_G per walker,
+ *             out[w*ldo + k] in 1/(s eV)
+ *   what = 1: InverseCompton on nseed thermal seed fields (radiative.py:547-607), seed s at
+ *             out[w*ldo + s*nE + k] = trapz_loglog(nelec sigma_s, gamma); the caller applies
+ *             uf * Eph / E (radiative.py:684-687); seed_theta[s] < 0: isotropic
+ * nmax: grid nodes the workgroup's LDS is sized for (4 nmax doubles); a walker that needs more
+ * gets NaN and *status (device int, zeroed by the caller) receives the largest count asked for. */
+int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NPAR]*/, int N,
+                        const nh_lazy* Eemin_eV /*host*/, const nh_lazy* Eemax_eV /*host*/,
+                        double nEed, int what, const nh_lazy* B_G /*host, what = 0*/,
+                        const double* seed_T_K /*host*/, const double* seed_theta /*host*/,
+                        int nseed, const double* E_eV, int nE, double* out, int ldo, int nmax,
+                        int* status /*device*/);
+
 /* ---- ONE launch per half-step ---------------------------------------------------------
  * nh_step_front + every table reduction of the model + its synchrotron component +
  * nh_lnprob (+ the accept of nh_lnprob_accept when do_accept) for the proposed walkers

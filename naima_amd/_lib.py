@@ -103,6 +103,8 @@ _SIGS = {
     "nh_half_step_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_half_step_stamps": [_dp, _dp, _dp],
+    "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
+                            _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _ll, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
 }
@@ -401,6 +403,28 @@ class Context:
         out = self.empty((N, 1))
         self.call("nh_integrate_tables", w, lw, N, nG, lx, Kt, dlnKt, 1, None, out, 1, 0, 1)
         return self._recorded("moments", key, out)
+
+    # -- the general path (a particle grid per walker) -------------------------------------
+    general_nmax = 2048  # grid nodes a workgroup's LDS is sized for (4 doubles each)
+
+    def general_status(self):
+        """device int the general kernel raises when a walker's grid exceeds general_nmax"""
+        if getattr(self, "_gen_status", None) is None:
+            self._gen_status = self.array(np.zeros(1, dtype=np.int32), dtype=np.int32)
+        return self._gen_status
+
+    def check_general(self):
+        """raise if a general-path launch since the last check met a grid longer than
+        general_nmax (those walkers were given NaN)"""
+        st = getattr(self, "_gen_status", None)
+        if st is None or self.capturing:
+            return
+        n = int(st.get()[0])
+        if n > self.general_nmax:
+            st.set(np.zeros(1, dtype=np.int32))
+            raise NaimaHipError("a walker's particle grid has %d nodes, more than the %d the "
+                                "general kernel's LDS is sized for: raise Context.general_nmax "
+                                "(at most ~4600) or lower nEed" % (n, self.general_nmax))
 
     # -- emission launches of a model evaluation ------------------------------------------
     # In the one-launch-per-half-step mode of the device loop (plan["mega"]) these are not

@@ -20,6 +20,8 @@
 #define NH_M_E_G 9.1093837015e-28
 #define NH_ALPHA_FS 0.0072973525693
 #define NH_MEC2_EV 510998.9499961643
+#define NH_MEC2_ERG_ 8.187105776823886e-07   /* m_e c^2 [erg] */
+#define NH_ERG_TO_EV_ 624150907446.0764      /* 1 erg in eV */
 #define NH_R0_CM 2.817940324670788e-13
 #define NH_ERG_PER_EV 1.602176634e-12
 #define NH_M_P_GEV 0.9382720881604903

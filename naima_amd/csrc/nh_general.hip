@@ -1,0 +1,195 @@
+// nh_general.hip -- the GENERAL electron path: every walker has its own particle grid.
+//
+// When Eemin / Eemax are fit parameters (the reference takes any keyword as per-call state,
+// radiative.py:280, 430) the grid of radiative.py:147-154
+//     gamma = logspace(log10(Eemin/mec2), log10(Eemax/mec2), max(10, int(nEed * decades)))
+// differs from walker to walker -- in its limits AND in its number of nodes -- so nothing
+// walker-independent can be tabulated: the emission kernel is evaluated at every (node,
+// photon energy) of every walker.  One workgroup per (walker, component): it builds the
+// walker's grid and weights in LDS (models.py eval + radiative.py:156-160), then integrates
+//     Synchrotron._spectrum                       (radiative.py:282-342), or
+//     InverseCompton on one thermal seed field    (radiative.py:547-607, 657-687)
+// with trapz_loglog (utils.py:285-355).  The parameters stay in HBM as lazy per-walker
+// scalars, so the device-resident step loop no longer falls back to the host for such models.
+#include "nh_ic.h"
+#include "nh_pdist.h"
+#include "nh_syn.h"
+
+struct gen_args {
+  int kind, N, what, nseed;
+  const double* rows;   // [N][NH_PD_NPAR] particle-distribution rows
+  nh_lazy emin, emax;   // per walker, eV
+  double nEed;
+  nh_lazy B;            // synchrotron: magnetic field [G]
+  double T[NH_MAX_COMP], theta[NH_MAX_COMP];  // IC: seed temperatures [K], angles (< 0: isotropic)
+  const double* E_eV; int nE;
+  double* out; int ldo;  // out[w*ldo + c*nE + k]
+  int nmax;              // LDS capacity in nodes
+  int* status;           // [1]: set to the largest node count asked for when it exceeds nmax
+};
+
+__device__ __forceinline__ double gen_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// term of one segment from the integrand at its two nodes: u = x y, dl = ln(u2/u1) formed as
+// ln(w2/w1) + ln(K2/K1) (log of a RATIO of neighbouring nodes: no cancellation)
+__device__ __forceinline__ double gen_term(double w1, double w2, double dlw, double K1, double K2,
+                                           double lx) {
+  const double u1 = w1 * K1, u2 = w2 * K2;
+  if (u1 == 0.0 || u2 == 0.0) return 0.0;  // utils.py:347-348
+  const double dl = dlw + log(K2 / K1);
+  return nh_seg_term<true>(u1, u2, dl, lx);
+}
+
+__global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
+  extern __shared__ double sm[];
+  double* gam = sm;               // [nmax]
+  double* wv = sm + A.nmax;       // w = gamma * n(gamma) [1/mec2 -> per unit gamma]
+  double* dw = sm + 2 * A.nmax;   // ln(w[i+1]/w[i])
+  double* lxs = sm + 3 * A.nmax;  // ln(gamma[i+1]/gamma[i])
+  double* part = sm + 4 * A.nmax;  // [4][64]
+  __shared__ int s_n;
+  __shared__ double s_l0, s_step, s_l1;
+  const int wi = blockIdx.x, comp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+  if (tid == 0) {
+    // radiative.py:147-154 (the limits in units of mec2; int() truncates)
+    const double gmin = nh_lazy_eval(A.emin, wi) / NH_MEC2_EV;
+    const double gmax = nh_lazy_eval(A.emax, wi) / NH_MEC2_EV;
+    const double l0 = log10(gmin), l1 = log10(gmax);
+    int n = (int)(A.nEed * (l1 - l0));
+    if (!(n >= 10)) n = 10;  // (also NaN limits)
+    if (n > A.nmax) {
+      atomicMax(A.status, n);
+      n = 0;
+    }
+    s_n = n;
+    s_l0 = l0;
+    s_l1 = l1;
+    s_step = n > 1 ? (l1 - l0) / (n - 1) : 0.0;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const double* pr = A.rows + (long long)wi * NH_PD_NPAR;
+  const pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  double* orow = A.out + (long long)wi * A.ldo + (long long)comp * A.nE;
+  if (n == 0) {  // grid too long for the workgroup's LDS: NaN, and the status word says so
+    for (int k = tid; k < A.nE; k += blockDim.x) orow[k] = NAN;
+    return;
+  }
+  // ---- the walker's grid: np.logspace = 10 ** (start + i step), last node exactly 10 ** stop
+  for (int i = tid; i < n; i += blockDim.x)
+    gam[i] = exp10(i + 1 < n ? s_l0 + i * s_step : s_l1);
+  __syncthreads();
+  // ---- weights (models.py eval on E = gamma mec2 in eV; nelec in 1/mec2: radiative.py:156-160)
+  for (int i = tid; i < n; i += blockDim.x) {
+    const bool last = i + 1 >= n;
+    const double g = gam[i], g2 = last ? g : gam[i + 1];
+    const double E = (g * NH_MEC2_ERG_) * NH_ERG_TO_EV_, E2 = (g2 * NH_MEC2_ERG_) * NH_ERG_TO_EV_;
+    const double lr = last ? 0.0 : log(g2 / g);
+    double nn, dsh;
+    pd_node(A.kind, p, E, E2, last ? 0.0 : log(E2 / E), nn, dsh);
+    nn *= NH_MEC2_EV;
+    wv[i] = g * nn;
+    dw[i] = last ? 0.0 : lr + dsh;
+    lxs[i] = lr;
+  }
+  __syncthreads();
+  const int nseg = n - 1;
+  const int per = (nseg + 3) / 4;
+  const int s0 = wvi * per, s1 = min(nseg, s0 + per);
+  if (A.what == 0) {
+    // ---- Synchrotron._spectrum -------------------------------------------------------
+    const double Bw = nh_lazy_eval(A.B, wi);
+    const double qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) /
+                        (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
+    for (int k0 = 0; k0 < A.nE; k0 += 64) {
+      const int k = k0 + lane;
+      double acc = 0.0;
+      if (k < A.nE && s0 < s1) {
+        const double q = A.E_eV[k] * qfac;
+        // Gtilde(x) = P(x) exp(-x); beyond x = 746 it is exactly 0 in double
+        auto G = [&](double g) {
+          const double x = q / (g * g);
+          return x <= 746.0 ? syn_P(cbrt(x)) * nh_exp_neg(x) : 0.0;
+        };
+        double K1 = G(gam[s0]);
+        for (int s = s0; s < s1; ++s) {
+          const double K2 = G(gam[s + 1]);
+          acc += gen_term(wv[s], wv[s + 1], dw[s], K1, K2, lxs[s]);
+          K1 = K2;
+        }
+      }
+      part[wvi * 64 + lane] = acc;
+      __syncthreads();
+      if (wvi == 0 && k < A.nE) {
+        const double E_erg = A.E_eV[k] * NH_ERG_PER_EV;
+        // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E), then 1/(s erg) -> 1/(s eV)
+        const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                           (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS * E_erg);
+        orow[k] = (part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]) * cs1 *
+                  NH_ERG_PER_EV;
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---- InverseCompton on thermal seed `comp` (the caller applies uf * Eph / E) --------
+    const double Tp = A.T[comp] * NH_K_TO_MEC2, th = A.theta[comp];
+    for (int k0 = 0; k0 < A.nE; k0 += 64) {
+      const int k = k0 + lane;
+      double acc = 0.0;
+      if (k < A.nE && s0 < s1) {
+        const double eg = A.E_eV[k] / NH_MEC2_EV;
+        double K1 = ic_planck_K(gam[s0], eg, Tp, th);
+        for (int s = s0; s < s1; ++s) {
+          const double K2 = ic_planck_K(gam[s + 1], eg, Tp, th);
+          acc += gen_term(wv[s], wv[s + 1], dw[s], K1, K2, lxs[s]);
+          K1 = K2;
+        }
+      }
+      part[wvi * 64 + lane] = acc;
+      __syncthreads();
+      if (wvi == 0 && k < A.nE)
+        orow[k] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int N,
+                                   const nh_lazy* Eemin_eV, const nh_lazy* Eemax_eV, double nEed,
+                                   int what, const nh_lazy* B_G, const double* seed_T,
+                                   const double* seed_theta, int nseed, const double* E_eV, int nE,
+                                   double* out, int ldo, int nmax, int* status) {
+  NH_REQUIRE(c && rows && Eemin_eV && Eemax_eV && E_eV && out && status, "NULL pointer");
+  NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
+  NH_REQUIRE(N >= 0 && nE >= 1 && nEed > 0 && nmax >= 10, "bad sizes");
+  NH_REQUIRE(what == 0 ? (B_G != nullptr) : (what == 1 && seed_T && seed_theta && nseed >= 1 &&
+                                             nseed <= NH_MAX_COMP), "bad component");
+  const int ncomp = what == 0 ? 1 : nseed;
+  NH_REQUIRE(ldo >= ncomp * nE, "ldo too small");
+  if (N == 0) return NH_OK;
+  gen_args A;
+  memset(&A, 0, sizeof(A));
+  A.kind = kind; A.N = N; A.what = what; A.nseed = ncomp; A.rows = rows;
+  A.emin = *Eemin_eV; A.emax = *Eemax_eV; A.nEed = nEed;
+  if (what == 0) A.B = *B_G;
+  for (int s = 0; s < ncomp && what == 1; ++s) {
+    NH_REQUIRE(seed_T[s] > 0.0, "seed temperature must be positive");
+    A.T[s] = seed_T[s];
+    A.theta[s] = seed_theta[s];
+  }
+  A.E_eV = E_eV; A.nE = nE; A.out = out; A.ldo = ldo; A.nmax = nmax; A.status = status;
+  const size_t lds = ((size_t)4 * nmax + 256) * sizeof(double);
+  NH_REQUIRE(lds <= 150 * 1024, "nmax does not fit in LDS (at most ~4700 nodes)");
+  if (lds > 64 * 1024)
+    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_general_electron,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  nh_prof_scope ps(c, what == 0 ? NH_K_SYNCHROTRON : NH_K_INTEGRATE);
+  hipLaunchKernelGGL(k_general_electron, dim3((unsigned)N, (unsigned)ncomp), dim3(256), lds,
+                     c->stream, A);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}

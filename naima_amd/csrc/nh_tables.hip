@@ -7,6 +7,7 @@
 // batched call builds them ONCE per call (n_E*n_x elements, microseconds) and
 // spends the per-walker work in the reduction.  Nothing is cached across calls.
 #include "nh_common.h"
+#include "nh_ic.h"
 
 #define NH_TAB_PROLOGUE                                                  \
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
@@ -37,46 +38,13 @@ static int table_dlog(nh_ctx* c, const double* Kt, int nG, int nE, int ld, doubl
   return NH_OK;
 }
 
-// ---------------------------------------------------------------------------
-// rows 6,7: Khangulyan+14 Eq. 14 / Eq. 11 (radiative.py:547-607, G12/G34 345-367)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double ic_g(double x, double al, double a, double be, double b) {
-  return 1.0 / (a * pow(x, al) / (1.0 + b * pow(x, be)) + 1.0);
-}
-__device__ __forceinline__ double ic_G34(double x, double al, double a, double be, double b,
-                                         double cc) {
-  double G = NH_PI26 * ((1.0 + cc * x) / (1.0 + NH_PI26 * cc * x)) * exp(-x);
-  return G * ic_g(x, al, a, be, b);
-}
-__device__ __forceinline__ double ic_G12(double x, double al, double a, double be, double b) {
-  double G = (NH_PI26 + x) * exp(-x);
-  return G * ic_g(x, al, a, be, b);
-}
-
+// rows 6,7: Khangulyan+14 Eq. 14 / Eq. 11: nh_ic.h
 __global__ __launch_bounds__(256) void k_table_ic_planck(const double* __restrict__ gam, int nG,
                                                           const double* __restrict__ E_eV,
                                                           int nE, double T_K, double theta,
                                                           double* __restrict__ Kt, int ld) {
   NH_TAB_PROLOGUE
-  const double Tp = T_K * NH_K_TO_MEC2;
-  const double g = gam[i];
-  const double eg = E_eV[k] / NH_MEC2_EV;
-  const double z = eg / g;
-  double cs;
-  if (theta < 0.0) {
-    double x = z / (1.0 - z) / (4.0 * g * Tp);
-    cs = z * z / (2.0 * (1.0 - z)) * ic_G34(x, 0.606, 0.443, 1.481, 0.540, 0.319) +
-         ic_G34(x, 0.461, 0.726, 1.457, 0.382, 6.620);
-  } else {
-    double tt = 2.0 * g * Tp * (1.0 - cos(theta));
-    double x = z / (1.0 - z) / tt;
-    cs = z * z / (2.0 * (1.0 - z)) * ic_G12(x, 0.857, 0.153, 1.840, 0.254) +
-         ic_G12(x, 0.691, 1.330, 1.668, 0.534);
-  }
-  double pref = (Tp / g) * (Tp / g);
-  pref *= NH_IC_PLANCK_NORM;
-  const bool ok = (eg < g) && (g > 1.0);
-  Kt[NH_TAB_AT] = ok ? pref * cs : 0.0;
+  Kt[NH_TAB_AT] = ic_planck_K(gam[i], E_eV[k] / NH_MEC2_EV, T_K * NH_K_TO_MEC2, theta);
 }
 
 extern "C" int nh_table_ic_planck(nh_ctx* c, const double* gam, int nG, const double* E_eV,

@@ -633,6 +633,7 @@ class DeviceLoop:
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""
         self._flush_pending()
+        self.ctx.check_general()  # (a per-walker grid longer than the general kernel's LDS)
         s = self.s
         for block in self.hist:
             n = block["n"]

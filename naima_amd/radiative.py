@@ -402,6 +402,67 @@ class BaseElectron(BaseRadiative):
         return self._gam_between(_scalar_energy("Eemin", self.Eemin),
                                  _scalar_energy("Eemax", self.Eemax), self.nEed)
 
+    # -- the general path on the device: Eemin / Eemax per walker -----------------------
+    def _general_limits(self):
+        """True when Eemin or Eemax is given per walker (host vector or device value) and
+        nEed is not: every walker then has its own grid (limits AND node count,
+        radiative.py:147-154) and the spectrum comes from nh_general_electron"""
+        if _per_walker(self.nEed):
+            return False
+        return _per_walker(self.Eemin) or _per_walker(self.Eemax)
+
+    def _general_supported(self):
+        return False
+
+    def _needs_walker_loop(self):
+        if self._general_limits() and self._general_supported():
+            others = [(n, v) for n, v in self._structural_values() if n not in ("Eemin", "Eemax")]
+            for n, v in others:
+                if _per_walker(v):
+                    return super()._needs_walker_loop()
+            return False
+        return super()._needs_walker_loop()
+
+    def _general_launch(self, what, E_eV, B=None, seeds=()):
+        """spectra [N][ncomp * nE] of nh_general_electron (device buffer)"""
+        import ctypes as C
+
+        from .darray import lazy_const
+        ctx = get_context()
+        pd = self.particle_distribution
+        if not hasattr(pd, "device_rows"):
+            raise NotImplementedError("per-walker Eemin / Eemax need a naima_amd.models "
+                                      "particle distribution with analytic parameters")
+        N = self.batch_size
+
+        def lazy_of(q, unit):
+            v = q.to(unit).value
+            if isinstance(v, DVec):
+                return v.lazy(), v
+            if np.ndim(v) > 0:
+                d = _as_dvec(ctx, v, N)
+                return d.lazy(), d
+            return lazy_const(float(v)), None
+
+        emin, k1 = lazy_of(self.Eemin, "eV")
+        emax, k2 = lazy_of(self.Eemax, "eV")
+        rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
+        nE = E_eV.size
+        ncomp = 1 if what == 0 else len(seeds)
+        out = ctx.empty((N, ncomp * nE))
+        status = ctx.general_status()
+        Bl, k3 = (lazy_of(B, "G") if what == 0 else (None, None))
+        T = (C.c_double * max(ncomp, 1))(*[float(s[0]) for s in seeds])
+        th = (C.c_double * max(ncomp, 1))(*[float(s[1]) for s in seeds])
+        ctx.call("nh_general_electron", PD_KIND[pd.kind], rows, N, C.addressof(emin),
+                 C.addressof(emax), float(self.nEed), what,
+                 C.addressof(Bl) if Bl is not None else None, T, th, ncomp, ctx.const(E_eV), nE,
+                 out, ncomp * nE, ctx.general_nmax, status)
+        del k1, k2, k3, rows
+        if not self.on_device:
+            ctx.check_general()
+        return ctx, N, out
+
     def _electron_weights(self, gam=None):
         gam = self._gam if gam is None else gam
         e_eV = (gam * MEC2_ERG) * ERG_TO_EV
@@ -440,7 +501,7 @@ class BaseElectron(BaseRadiative):
     @property
     def We(self):
         """Total energy in electrons used for the radiative calculation"""
-        if self._needs_walker_loop():
+        if BaseRadiative._needs_walker_loop(self):  # (per-walker limits: one walker at a time)
             return self._loop_walkers("We")
         return self._We_on(self._gam)
 
@@ -448,7 +509,7 @@ class BaseElectron(BaseRadiative):
         """Total energy in electrons between Eemin and Eemax (radiative.py:168-195)"""
         if Eemin is None and Eemax is None:
             return self.We
-        if self._needs_walker_loop():
+        if BaseRadiative._needs_walker_loop(self):
             return self._loop_walkers("compute_We", Eemin=Eemin, Eemax=Eemax)
         if Eemax is None:
             Eemax = self.Eemax
@@ -519,9 +580,15 @@ class Synchrotron(BaseElectron):
         return rider is not None and rider.ptr == Bv.ptr and rider.stride == Bv.stride \
             and (rider.a, rider.b, rider.c, rider.tf) == (Bv.a, Bv.b, Bv.c, Bv.tf)
 
+    def _general_supported(self):
+        return True
+
     def _spectrum(self, photon_energy):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
+        if self._general_limits():
+            ctx, N, out = self._general_launch(0, E_eV, B=self.B)
+            return self._result(ctx, out, N, E_eV.size, E)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         Bv = self.B.to("G").value
         ldB = 1
@@ -555,6 +622,51 @@ class InverseCompton(BaseElectron):
         self.nEed = 100
         self.param_names += ["seed_photon_fields"]
         self.__dict__.update(**kwargs)
+
+    def _general_supported(self):
+        """per-walker Eemin / Eemax on the device: thermal seed fields with walker-independent
+        temperature and angle (their energy density may still be per walker)"""
+        for seed in self.seed_photon_fields.values():
+            if seed["type"] != "thermal" or _per_walker(seed["T"]) or \
+                    (not seed["isotropic"] and _per_walker(seed["theta"])):
+                return False
+        return True
+
+    def _spectrum_general(self, E, E_eV):
+        """radiative.py:657-710 with a particle grid per walker (nh_general_electron): the
+        Khangulyan kernel at every (node, energy) of every walker, no shared table"""
+        nE = E_eV.size
+        names = list(self.seed_photon_fields)
+        seeds = []
+        for n in names:
+            sd = self.seed_photon_fields[n]
+            seeds.append((sd["T"].to("K").value,
+                          -1.0 if sd["isotropic"] else sd["theta"].to("rad").value))
+        ctx, N, out = self._general_launch(1, E_eV, seeds=seeds)
+        Eph = E_eV / MEC2_EV
+        dev = self.on_device
+        host = None if dev else out.get()
+        specs = []
+        for j, n in enumerate(names):
+            sd = self.seed_photon_fields[n]
+            T = sd["T"].to("K").value
+            uf = sd["u"].to("erg/cm3").value / (AR_CGS * T ** 4)  # radiative.py:684-687
+            colfac = Eph / E_eV
+            if dev:
+                m = DMat(ctx, [(out, out.ptr + 8 * j * nE, len(names) * nE, 1.0)], (N, nE)) * colfac
+                m = m * _as_dvec(ctx, uf, N) if _per_walker(sd["u"]) else m * float(uf)
+                specs.append(m)
+            else:
+                v = host[:, j * nE:(j + 1) * nE] * colfac
+                specs.append(v * np.broadcast_to(np.asarray(uf, dtype=float), (N,))[:, None])
+        if dev:
+            self.specic = [u.Quantity(m, _SPEC_UNIT) for m in specs]
+            total = specs[0]
+            for m in specs[1:]:
+                total = total + m
+            return u.Quantity(total, _SPEC_UNIT)
+        self.specic = [u.Quantity(self._finish(v, E), _SPEC_UNIT) for v in specs]
+        return u.Quantity(self._finish(np.sum(specs, axis=0), E), _SPEC_UNIT)
 
     def _structural_values(self):
         """grid parameters + the temperatures / angles of thermal seeds (their emission
@@ -715,6 +827,8 @@ class InverseCompton(BaseElectron):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         nE = E_eV.size
+        if self._general_limits():
+            return self._spectrum_general(E, E_eV)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         nG = gam.size
         Ed = ctx.const(E_eV)

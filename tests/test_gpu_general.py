@@ -110,15 +110,87 @@ def test_general_path_grid_limits_and_seed_temperature(na):
         assert_allclose(Wp[k].value, pk2.Wp.value, rtol=1e-14)
 
 
-def test_general_path_refuses_device_values(na):
+def test_general_path_device_values(na):
+    """Eemin / Eemax as device-resident per-walker values go through the general kernel (a
+    particle grid per walker) and agree with the same values given on the host; a seed
+    temperature per walker still has no device form"""
     from naima_amd._lib import get_context
     from naima_amd.darray import DPars
     u = na.u
     ctx = get_context()
-    P = DPars(ctx, ctx.array(np.array([[33.0, 33.2], [1.0, 5.0]])), 2, 2)
+    host = np.array([[33.0, 33.2, 32.9], [1.0, 5.0, 40.0], [0.3, 1.0, 2.0]])
+    P = DPars(ctx, ctx.array(host), 3, 3)
+    E = E_GAMMA * u.eV
+
+    def models(p):
+        pd = na.ExponentialCutoffPowerLaw(10 ** p[0] / u.eV, 10 * u.TeV, 2.4, 50 * u.TeV)
+        ic = na.InverseCompton(pd, seed_photon_fields=["CMB", ["star", 5000 * u.K, 1 * u.eV / u.cm ** 3,
+                                                                 60 * u.deg]],
+                               Eemin=p[1] * u.GeV, Eemax=p[2] * u.PeV)
+        sy = na.Synchrotron(pd, B=20 * u.uG, Eemin=p[1] * u.GeV, Eemax=p[2] * u.PeV)
+        return ic, sy
+
+    icd, syd = models(P)
+    ich, syh = models(host)
+    Ex = np.geomspace(1e2, 1e5, 9) * u.eV
+    assert_allclose(np.asarray(icd.flux(E, 1 * u.kpc).value), ich.flux(E, 1 * u.kpc).value, rtol=1e-13)
+    assert_allclose(np.asarray(syd.flux(Ex, 1 * u.kpc).value), syh.flux(Ex, 1 * u.kpc).value,
+                    rtol=1e-13, atol=1e-300)
     pd = na.ExponentialCutoffPowerLaw(10 ** P[0] / u.eV, 10 * u.TeV, 2.4, 50 * u.TeV)
     with pytest.raises(NotImplementedError):
-        na.InverseCompton(pd, Eemin=P[1] * u.GeV).flux(E_GAMMA * u.eV, 1 * u.kpc)
+        na.InverseCompton(pd, seed_photon_fields=[["FIR", P[1] * u.K, 0.5 * u.eV / u.cm ** 3]]
+                          ).flux(E, 1 * u.kpc)
+
+
+def test_general_kernel_against_oracle(na):
+    """nh_general_electron (grid, weights, Synchrotron and thermal-IC integrands of EVERY
+    walker built in its workgroup) against the oracle on each walker's own grid -- limits and
+    node counts differ from walker to walker -- and its overflow report"""
+    from naima_amd._lib import NaimaHipError, get_context
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(5)
+    N = 37
+    amp = 10 ** rng.normal(33, 0.2, N)
+    alpha = rng.uniform(1.8, 2.9, N)
+    ecut = rng.uniform(20, 200, N)
+    emin = 10 ** rng.uniform(-1, 2.5, N)       # GeV
+    emax = 10 ** rng.uniform(4.5, 6.2, N)      # GeV
+    B = rng.uniform(3, 80, N)
+    pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, ecut * u.TeV)
+    kw = dict(Eemin=emin * u.GeV, Eemax=emax * u.GeV, nEed=37)
+    Eg = np.geomspace(1e8, 3e13, 23)
+    Ex = np.geomspace(1.0, 1e5, 70)  # (two tiles of 64 energies)
+    ic = na.InverseCompton(pd, seed_photon_fields=["CMB", "NIR", ["star", 9000 * u.K, 2 * u.eV / u.cm ** 3,
+                                                                   130 * u.deg]], **kw)
+    f = ic.flux(Eg * u.eV, 0).value
+    per = [ic.flux(Eg * u.eV, 0, seed=j).value for j in range(3)]
+    fs = na.Synchrotron(pd, B=B * u.uG, **kw).flux(Ex * u.eV, 0).value
+    assert f.shape == (N, Eg.size) and fs.shape == (N, Ex.size)
+    nodes = set()
+    for i in range(N):
+        gam = O.electron_grid(emin[i] * 1e9, emax[i] * 1e9, 37)
+        nodes.add(gam.size)
+        opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13, alpha=alpha[i],
+                             e_cutoff=ecut[i] * 1e12, beta=1.0)
+        ne = O.nelec_on(opd, gam)
+        seeds = [O.thermal_seed("CMB"), O.thermal_seed("NIR"),
+                 dict(type="thermal", T=9000.0, u=2 * O.ERG_PER_EV, theta=np.deg2rad(130.0))]
+        tot, each = O.ic_spectrum(Eg, gam, ne, seeds)
+        assert_allclose(f[i], tot, rtol=1e-9, atol=tot.max() * 1e-200)
+        for j in range(3):
+            assert_allclose(per[j][i], each[j], rtol=1e-9, atol=tot.max() * 1e-200)
+        ref = O.synchrotron_spectrum(Ex, gam, ne, B[i] * 1e-6)
+        assert_allclose(fs[i], ref, rtol=1e-9, atol=ref.max() * 1e-200)
+    assert len(nodes) > 10  # (the walkers really have grids of different lengths)
+    ctx = get_context()
+    old = ctx.general_nmax
+    ctx.general_nmax = 64
+    try:
+        with pytest.raises(NaimaHipError, match="nodes"):
+            na.Synchrotron(pd, B=B * u.uG, **kw).flux(Ex * u.eV, 0)
+    finally:
+        ctx.general_nmax = old
 
 
 def test_table_model_particle_distribution(na, golden):
@@ -235,12 +307,16 @@ def test_prefit_batched_simplex(na, golden):
         float(np.asarray(na.lnprob(start, data, model, None)[0]))
 
 
-def test_device_sampler_falls_back_for_grid_shaping_parameters(na):
-    """a model whose fit parameters include Eemin cannot keep its parameters in HBM (every
-    walker has its own particle grid): device=True warns and samples with the host loop,
-    which evaluates such walkers through the general path"""
+def test_device_sampler_with_grid_limits_as_fit_parameters(na):
+    """a model whose fit parameters include Eemin (every walker has its own particle grid:
+    limits and node count) stays on the device -- no fall-back to the host loop, no warning
+    -- and the device-resident loop, the host-driven loop and the oracle agree"""
+    import warnings
+
     from bench import build_problem
     from naima_amd.sampler import EnsembleSampler
+    from oracle import naima_np as O
+    from oracle import workloads_np as WN
     u = na.u
     _, p0, raw, data, prior, labels = build_problem("cfg1", na)
 
@@ -256,17 +332,26 @@ def test_device_sampler_falls_back_for_grid_shaping_parameters(na):
     start = np.append(p0, 3.0)
     kw = dict(args=[data, model, pri], seed=2, naima_style=True, store_blobs=False)
     pos = start * (1 + 0.01 * np.random.default_rng(0).standard_normal((12, 4)))
-    with pytest.warns(UserWarning, match="host-driven loop"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         d = EnsembleSampler(12, 4, na.lnprob, device=True, **kw)
         sd = d.run_mcmc(pos, 3)
+        sd = d.run_mcmc(sd, 9)
+    assert d.device is True and d._dev is not None and d._dev.graph is not None
     h = EnsembleSampler(12, 4, na.lnprob, **kw)
-    sh = h.run_mcmc(pos, 3)
-    assert d.device is False
-    assert_allclose(sd.coords, sh.coords, rtol=1e-12)
-    assert np.all(np.isfinite(sd.log_prob))
-    # ... and the per-walker evaluation is the scalar one
-    one = na.lnprob(sd.coords[5], data, model, pri)
-    assert_allclose(np.asarray(sd.log_prob)[5], np.asarray(one[0]), rtol=1e-10)
+    sh = h.run_mcmc(pos, 12)
+    assert_allclose(sd.coords, sh.coords, rtol=1e-9)
+    assert_allclose(sd.log_prob, sh.log_prob, rtol=1e-7)
+    # ... and each walker's likelihood is the oracle's on ITS grid
+    E = WN.data_energy_eV(raw)
+    for i in (0, 5, 11):
+        c = np.asarray(sd.coords)[i]
+        gam = O.electron_grid(c[3] * 1e9, 1e9 * O.MEC2_EV, 100)
+        opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=c[0], e_0=10e12, alpha=c[1],
+                             e_cutoff=10 ** c[2] * 1e12, beta=1.0)
+        spec, _ = O.ic_spectrum(E, gam, O.nelec_on(opd, gam), [O.thermal_seed("CMB")])
+        ll = O.lnprobmodel(WN.to_data_repr(O.to_flux(spec, O.KPC_CM), raw), raw)
+        assert_allclose(np.asarray(sd.log_prob)[i], ll + float(np.asarray(pri(c))), rtol=1e-7)
 
 
 def test_device_sampler_falls_back_for_models_outside_naima_amd(na):
