@@ -64,7 +64,10 @@ FP64_VEC_PEAK_TF = 78.6    # vendor figure quoted in SURVEY.md 8d (256 CU x 128 
 def measured_traffic(name, symbol):
     """HBM-side bytes per launch of ``symbol`` from the committed TCC counter run
     (profiles/*_hbm_counters*.json: FETCH_SIZE and WRITE_SIZE collected in separate
-    rocprofv3 --pmc passes, KB per launch; see profiles/README.md).  None if absent."""
+    rocprofv3 --pmc passes, KB per launch; see profiles/README.md), with the gfx950
+    correction of MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced
+    reads (16 B per lane: the kernel's table stream) and is doubled; WRITE_SIZE is
+    uncalibrated and taken as reported.  None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_hbm_counters*.json" % name)))
     if not files:
@@ -74,7 +77,7 @@ def measured_traffic(name, symbol):
     w = [v for k, v in d.get("write", {}).items() if symbol in k]
     if not f:
         return None, None
-    return (max(f) + (max(w) if w else 0.0)) * 1024.0, os.path.basename(files[-1])
+    return (2.0 * max(f) + (max(w) if w else 0.0)) * 1024.0, os.path.basename(files[-1])
 
 
 def build_problem(name, na):
@@ -362,10 +365,11 @@ def main():
                      "event_pair_overhead_us": ev_us,
                      "algorithmic_bytes_per_launch": abytes,
                      "walkers_per_launch": walkers_per_launch,
-                     "note": "FP64-transcendental-bound path: the HBM fraction is << 1 % by "
+                     "note": "FP64-issue-bound path: the HBM fraction is << 1 % by "
                              "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
-                             "traffic = L2 memory-side bytes (mostly Infinity-Cache hits: each "
-                             "of the 8 XCD L2s pulls its own copy of the shared emission table)"},
+                             "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE): every "
+                             "launch starts with cold L2s, so each of the 8 XCDs pulls its own "
+                             "copy of the 1.1 MB emission table (Infinity-Cache hits)"},
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
         "acceptance_fraction": acc_frac,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -60,6 +61,13 @@ struct nh_ctx {
 int nh_scratch(nh_ctx* c, size_t bytes, void** out);
 
 int nh_set_error(int code, const char* fmt, ...);
+
+// tuning overrides (scripts/, experiments): read from the environment ONCE per process, not
+// on the launch path
+static inline int nh_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 #define NH_CHECK_HIP(expr)                                                              \
   do {                                                                                  \

@@ -695,7 +695,8 @@ extern "C" int nh_step_front(nh_ctx* c, const double* coords, const double* logp
   NH_REQUIRE(lds <= 60 * 1024, "reduction grids do not fit in LDS");
   nh_prof_scope ps(c, NH_K_PDIST);
   int threads = 1024;
-  if (const char* e = getenv("NH_FRONT_T")) threads = atoi(e);
+  static const int ov_threads = nh_env_int("NH_FRONT_T", 0);
+  if (ov_threads > 0) threads = ov_threads;
   hipLaunchKernelGGL(k_step_front, dim3((unsigned)nloc), dim3(threads), lds, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
@@ -903,7 +904,8 @@ __global__ __launch_bounds__(256) void k_integrate_rows(
 // carry twice the work of the others -- two half-range workgroups of 8 waves each spread
 // evenly instead
 extern "C" int nh_integrate_tables_nsplit(int N, int nG, int nK) {
-  if (const char* e = getenv("NH_INT_SPLIT")) return atoi(e);
+  static const int ov_split = nh_env_int("NH_INT_SPLIT", 0);
+  if (ov_split > 0) return ov_split;
   const long long ktiles = (nK + 63) / 64;
   if ((long long)N * nK * 4 < 4096 || nG < 66) return 1;
   const int W = (ktiles * N >= 8192) ? 4 : (ktiles * N >= 512 ? 2 : 1);
@@ -943,14 +945,16 @@ static int integrate_impl(nh_ctx* c, const double* w, const double* dlw, int N, 
   // 20.8 us, W = 2 17.0 us, W = 4 18.1 us -- halving the L2->L1 table traffic pays as
   // long as the launch keeps >= ~4 waves per SIMD.
   int W = ((long long)ktiles * N >= 8192) ? 4 : ((long long)ktiles * N >= 512 ? 2 : 1);
-  if (const char* e = getenv("NH_INT_W")) W = atoi(e);
+  static const int ov_W = nh_env_int("NH_INT_W", 0);
+  if (ov_W > 0) W = ov_W;
   const unsigned blocks = (unsigned)(ktiles * ((N + W - 1) / W) * nsplit);
   // split the abscissa so that the launch has >= ~4 waves per SIMD (1024 SIMDs)
   // (split launches use 8-wave workgroups: four fit on a CU, so 768 of them spread evenly)
   int C = 1;
   const int Cmax = nsplit > 1 ? 8 : 16;
   while (C < Cmax && (long long)blocks * C < 12288 && nseg / nsplit / (2 * C) >= 8) C *= 2;
-  if (const char* e = getenv("NH_INT_C")) C = atoi(e);
+  static const int ov_C = nh_env_int("NH_INT_C", 0);
+  if (ov_C > 0) C = ov_C;
   const size_t stg_bytes = 2 * (size_t)W * nG * sizeof(double);
   const bool stage = stg_bytes <= 48 * 1024;
   nh_lnprob_args none = {};

@@ -193,14 +193,16 @@ static int launch_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   // for tw = 64 / 32 / 22; C=8: 21.3 / 20.7 / 20.7) -- the kernel is bound by its total
   // instruction count, not by how the blocks are cut
   int tw = 64;
-  if (const char* e = getenv("NH_SYN_TW")) tw = atoi(e);
+  static const int ov_tw = nh_env_int("NH_SYN_TW", 0);
+  if (ov_tw > 0) tw = ov_tw;
   if (L) tw = 64;
   NH_REQUIRE(tw >= 1 && tw <= 64, "bad tile width");
   const int ktiles = (nE + tw - 1) / tw;
   NH_REQUIRE(!L || ktiles == 1, "the likelihood epilogue needs all energies in one tile");
   const unsigned blocks = (unsigned)(ktiles * N);
   if ((long long)blocks * C > 16384 && C > 4) C /= 2;  // plenty of waves: longer chunks
-  if (const char* e = getenv("NH_SYN_C")) C = atoi(e);
+  static const int ov_C = nh_env_int("NH_SYN_C", 0);
+  if (ov_C > 0) C = ov_C;
   size_t shm = (size_t)(3 * nG + SYN_MAXCH * 64) * sizeof(double);
   NH_REQUIRE(shm <= 150 * 1024, "electron grid too long for the LDS staging");
   nh_lnprob_args none = {};
