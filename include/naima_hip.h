@@ -411,6 +411,14 @@ typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
                  const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;
                  double* out /*[nloc][ldo]*/; } nh_hs_syn;
 #define NH_HS_MAX_TAB 4
+/* a blob the model function returns besides its flux (core.py:103-113; emcee keeps the blobs
+ * of the ACCEPTED position of every walker): kind 0 = the model spectrum itself (the sum of
+ * `comps`, nE values), kind 1 = lazy(result of single-row reduction `mom`) (We, Wp).  On
+ * accept the launch writes the row into cur[walker]; with the coordinates it appends the
+ * ensemble's rows to the history at *hist (a device word holding the history's base, 0: off). */
+typedef struct { int kind; int mom; int m; int pad; nh_lazy lazy;
+                 double* cur /*[N][m]*/; double* const* hist /*device*/; } nh_hs_blob;
+#define NH_HS_MAX_BLOB 4
 typedef struct {
   double* coords; double* logp; const double* blk;
   int* cursor; /* out: the slice of the launch, for nh_move_accept(advance = 0) after it */
@@ -431,6 +439,7 @@ typedef struct {
   const int* ul; const double* cl; const double* lp /* [nloc] or NULL */;
   nh_prior terms[NH_MAX_PRIOR]; int nterms;
   double* model_out /* [nloc][nE] or NULL */; double* total /* [nloc] */;
+  nh_hs_blob blobs[NH_HS_MAX_BLOB]; int nblobs; int pad2;
 } nh_hs_desc;
 typedef struct nh_halfstep_plan nh_halfstep_plan;
 int nh_half_step_create(nh_ctx* ctx, const nh_hs_desc* desc /*host*/, nh_halfstep_plan** out);
@@ -450,6 +459,8 @@ int nh_half_step_stamps(nh_ctx* ctx, const nh_halfstep_plan* plan, long long* ou
 /* row `row` (-1: hist->n - 1) of the device-resident history := coords[N][ndim] / logp[N] */
 int nh_hist_append(nh_ctx* ctx, const double* coords, const double* logp, long long N, int ndim,
                    const nh_hist* hist /*device*/, long long row);
+/* the same for the blobs a half-step plan keeps: row `row` of every blob history := cur */
+int nh_half_step_append_blobs(nh_ctx* ctx, const nh_halfstep_plan* plan, long long row);
 
 /* host-side generator of the move's random numbers: a worker thread fills a ring of
  * (page-locked) blocks ahead of the consumer, in exactly the slice layout above.  The

@@ -107,6 +107,7 @@ _SIGS = {
                             _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _ll, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
+    "nh_half_step_append_blobs": [_dp, _dp, _ll],
 }
 EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")
 
@@ -484,7 +485,7 @@ class Context:
             self.call("nh_synchrotron", *args)
         return out
 
-    def half_step(self, hook, comps, ncomp, nE, conv, dd, lpd, terms, nterms, total):
+    def half_step(self, hook, comps, ncomp, nE, conv, dd, lpd, terms, nterms, total, blobs=()):
         """the plan's nh_half_step launch: everything the recorded model evaluation asked
         for plus the likelihood of ``comps`` (created on first use, then checked and reused)"""
         import ctypes as C
@@ -558,6 +559,32 @@ class Context:
             d.terms[q] = terms[q]
         d.nterms = nterms
         d.model_out, d.total = None, total.ptr
+        # blobs the launch keeps itself (the device loop says where: hook["blobs"]); anything
+        # it cannot express leaves them to the separate staging / scatter launches
+        hook["blobs_in_kernel"] = False
+        blobs = [b for b in blobs if not isinstance(b, (float, int))]  # (lnprob's constant NaN)
+        dest = hook.get("blobs")
+        if dest and hook["mv"] is not None and len(dest) == len(blobs) <= 4:
+            from . import units as u
+            model_terms = [(int(comps[q].ptr), int(comps[q].ld), float(comps[q].scale))
+                           for q in range(ncomp)]
+            mouts = [mm[q].out for q in range(nmm)]
+            ent = []
+            for (cur, m, hist_word), b in zip(dest, blobs):
+                v = b.value if isinstance(b, u.Quantity) else b
+                if isinstance(v, D.DMat) and v.colfac is None and v.shape[1] == nE == m and \
+                        [(int(t[1]), int(t[2]), float(t[3])) for t in v.terms] == model_terms:
+                    ent.append(D.nh_hs_blob(0, 0, m, 0, D.lazy_const(1.0), cur, hist_word))
+                elif isinstance(v, D.DVec) and m == 1 and v.stride == 1 and v.ptr in mouts:
+                    ent.append(D.nh_hs_blob(1, mouts.index(v.ptr), 1, 0, v.lazy(), cur, hist_word))
+                else:
+                    ent = None
+                    break
+            if ent is not None:
+                for q, e in enumerate(ent):
+                    d.blobs[q] = e
+                d.nblobs = len(ent)
+                hook["blobs_in_kernel"] = True
         h = _dp()
         _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))
         thr, blk, lds = _i(), _i(), _ll()

@@ -141,7 +141,7 @@ class _DataOnDevice:
         return hit
 
 
-def lnprobmodel(model, data, lp=None):
+def lnprobmodel(model, data, lp=None, blobs=()):
     """Log-likelihood of ``model`` (Quantity, shape (n_E,) or (N, n_E)) given the data
     table: asymmetric Gaussian errors plus the upper-limit penalty (core.py:64-94).
     A device-resident model (``DMat``) gives a device-resident result."""
@@ -176,7 +176,8 @@ def lnprobmodel(model, data, lp=None):
         if hook is not None and plan is not None and plan["mega"] and plan["mode"] == "replay":
             # ONE launch for the whole half-step: proposal, packs, weights, We/Wp, every
             # spectrum of the model, this likelihood, the priors and the accept
-            ctx.half_step(hook, m.comps(), len(m.terms), nE, args[4], dd, lpd, terms, nterms, total)
+            ctx.half_step(hook, m.comps(), len(m.terms), nE, args[4], dd, lpd, terms, nterms, total,
+                          blobs=blobs)
             hook["used"] = True
             del lpd
             return DVec(ctx, total, total.ptr, N)
@@ -249,7 +250,7 @@ def _lnprob_device(pars, data, modelfunc, priorfunc):
     if not isinstance(model.value, DMat):
         raise TypeError("the model function returned a host array for device-resident "
                         "parameters; it must build its flux from naima_amd radiative models")
-    total = lnprobmodel(model, data, lp=lp)
+    total = lnprobmodel(model, data, lp=lp, blobs=blob)
     return (total, *blob)
 
 

@@ -48,10 +48,13 @@ struct hs_tab {
 
 struct hs_comp { const double* ptr; long long ld; double scale; int off; int pad; };
 
-// The descriptor's COLD part, in device memory: what a workgroup needs only after its
-// proposal is known (its loads hide behind the proposal's chain of dependent reads).
+// The descriptor.  All of it travels BY VALUE with the launch (hs_hot below), except the
+// parameter packs (1.6 KB), which stay in device memory: the threads that evaluate a pack
+// column fetch it in the same round trip as the slice of the move block.  (A first version
+// kept this block in device memory too: its first use -- the table descriptors at the head
+// of the work items, the prior terms -- then cost every wave a cold ~1.5 us round trip.)
 struct hs_dev {
-  nh_pack pk[NH_MAX_PACK];
+  const nh_pack* pk;  // [NH_MAX_PACK], device
   int npk, kind;
   const double* params;
   double* w[NH_MAX_GRIDS]; double* dlw[NH_MAX_GRIDS];
@@ -67,13 +70,15 @@ struct hs_dev {
   const double* lp;
   nh_prior_pack pri;
   double* model_out; double* total;
+  nh_hs_blob blob[NH_HS_MAX_BLOB];
+  int nblob, o_mrow;  // o_mrow: LDS offset of the model spectrum row + the moments' results
   long long* dbg;  // NH_HS_DEBUG=1: wall-clock stamps of the first 8 workgroups, [8][16]
 };
 
 // ... and its HOT part, passed by value: every pointer and size the first phases touch, so
 // that the kernel's first round trip to memory already fetches data, not descriptors.
 struct hs_hot {
-  const hs_dev* D;
+  hs_dev C;
   const double* coords; const double* logp; const double* blk;
   int* done; const int* hbase; int* cursor;
   double* qT; double* factors; const nh_hist* hist;
@@ -99,7 +104,7 @@ struct hs_hot {
 
 struct nh_halfstep_plan {
   hs_hot hot;
-  hs_dev* dev;       // device copy of the cold part
+  nh_pack* dev;      // device copy of the parameter packs
   int* words;        // device: done counter | hbase
   size_t lds_bytes;
   int threads, blocks;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
                                                     const double* coords_, int slice, int ns_,
                                                     int ndim_, int lo_, const hs_hot H) {
   extern __shared__ double sm[];
-  const hs_dev& D = *H.D;
+  const hs_dev& D = H.C;
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
   const int j = blockIdx.x;
@@ -432,6 +437,13 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           for (int t = tid; t < H.ndim; t += T)
             hc[(long long)wr * H.ndim + t] = H.coords[(long long)wr * H.ndim + t];
           if (tid == 0) hl[wr] = H.logp[wr];
+          for (int b = 0; b < D.nblob; ++b) {  // the blobs that belong to these positions
+            const nh_hs_blob& bl = D.blob[b];
+            double* hb = bl.hist ? *bl.hist : nullptr;
+            if (hb)
+              for (int t = tid; t < bl.m; t += T)
+                hb[(rowh * N + wr) * bl.m + t] = bl.cur[(long long)wr * bl.m + t];
+          }
         }
       }
     }
@@ -665,7 +677,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       acc += nh_seg_term(u1, u2, dl, lxs[sgm]);
     }
     acc = hs_wave_sum(acc);
-    if (lane == 0) D.mom_out[m][j] = acc;
+    if (lane == 0) {
+      D.mom_out[m][j] = acc;
+      sm[D.o_mrow + H.nE + m] = acc;
+    }
   }
   HS_STAMP(5);
   // ---- 5. work items: table reductions and synchrotron nodes, pulled from one counter ------
@@ -867,6 +882,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         m += D.comp[q].scale * v;
       }
       if (D.model_out) D.model_out[(long long)j * nE + k] = m;
+      if (D.nblob) sm[D.o_mrow + k] = m;
       const double mc = m * conv;
       if (ul) {
         nul += 1;
@@ -904,9 +920,18 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const double d = (H.ndim - 1.0) * log(z) + acc - accs[2];
       const bool ok = accs[1] < d;  // NaN compares false, as numpy
       const int me2 = hi[HI_ME];
-      if (ok)
+      if (ok) {
         for (int t = lane; t < H.ndim; t += 64)
           const_cast<double*>(H.coords)[(long long)me2 * H.ndim + t] = qs[t];
+        for (int b = 0; b < D.nblob; ++b) {  // the accepted position's blobs
+          const nh_hs_blob& bl = D.blob[b];
+          if (bl.kind == 0) {
+            for (int t = lane; t < bl.m; t += 64) bl.cur[(long long)me2 * bl.m + t] = sm[D.o_mrow + t];
+          } else if (lane == 0) {
+            bl.cur[me2] = nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom]);
+          }
+        }
+      }
       if (lane == 0) {
         const int g = H.lo + j;
         if (ok) {
@@ -922,6 +947,30 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     if (D.dbg && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
   }
   HS_STAMP(9);
+}
+
+// blob history row `row` := the current blobs of the whole ensemble
+__global__ void k_blob_hist_append(hs_hot H, long long row) {
+  const hs_dev& D = H.C;
+  const long long N = 2LL * H.ns;
+  for (int b = 0; b < D.nblob; ++b) {
+    const nh_hs_blob& bl = D.blob[b];
+    double* hb = bl.hist ? *bl.hist : nullptr;
+    if (!hb || row < 0) continue;
+    const long long n = N * bl.m;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x)
+      hb[row * n + t] = bl.cur[t];
+  }
+}
+
+extern "C" int nh_half_step_append_blobs(nh_ctx* c, const nh_halfstep_plan* P, long long row) {
+  NH_REQUIRE(c && P, "bad argument");
+  if (P->hot.C.nblob == 0) return NH_OK;
+  nh_prof_scope ps(c, NH_K_GLUE);
+  hipLaunchKernelGGL(k_blob_hist_append, dim3(64), dim3(256), 0, c->stream, P->hot, row);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
 }
 
 // KD[i] = {Kt[i], dlnKt[i]}: the layout the half-step kernel streams (one 16-byte load per node)
@@ -989,11 +1038,12 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   NH_REQUIRE(d->conv && d->flux && d->err_lo && d->err_hi && d->ul && d->cl, "NULL data column");
   NH_REQUIRE(d->nterms >= 0 && d->nterms <= NH_MAX_PRIOR, "bad prior terms");
   static_assert(NH_HS_MAX_TAB == HS_MAX_TAB, "table count");
-  static_assert(sizeof(hs_hot) <= 1024, "the by-value kernel argument must stay small");
+  static_assert(sizeof(hs_hot) <= 3800, "the by-value kernel argument must fit the 4 KB segment");
   hs_hot H;
-  hs_dev C;
   memset(&H, 0, sizeof(H));
-  memset(&C, 0, sizeof(C));
+  hs_dev& C = H.C;
+  nh_pack packs_host[NH_MAX_PACK];
+  memset(packs_host, 0, sizeof(packs_host));
   H.coords = d->coords; H.logp = d->logp; H.blk = d->blk; H.cursor = d->cursor;
   H.qT = d->qT; H.factors = d->factors; H.hist = d->hist;
   H.ns = d->ns; H.ndim = d->ndim; H.lo = d->lo; H.nloc = d->nloc;
@@ -1013,7 +1063,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
       NH_REQUIRE(pk.ncols >= 7, "the particle rows need 7 columns");
       have_params = true;
     }
-    C.pk[q] = pk;
+    packs_host[q] = pk;
   }
   NH_REQUIRE(have_params, "params must be the output of one of the packs");
   H.ngrids = d->ngrids;
@@ -1140,6 +1190,17 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   H.o_lik = off; off += 5 * d->nE;
   H.o_scale = off; off += nspec;
   H.ntab = d->ntab;
+  NH_REQUIRE(d->nblobs >= 0 && d->nblobs <= NH_HS_MAX_BLOB, "bad blob count");
+  C.nblob = d->nblobs;
+  C.o_mrow = off; off += d->nE + NH_MAX_MOMENT;
+  for (int b = 0; b < d->nblobs; ++b) {
+    const nh_hs_blob& bl = d->blobs[b];
+    NH_REQUIRE(d->do_accept, "blobs in the launch need the in-launch accept");
+    NH_REQUIRE(bl.cur && ((bl.kind == 0 && bl.m == d->nE) ||
+                          (bl.kind == 1 && bl.m == 1 && bl.mom >= 0 && bl.mom < d->nmoms)),
+               "bad blob");
+    C.blob[b] = bl;
+  }
   // ---- likelihood: where does each component of the model live? ----
   C.ncomp = d->ncomp; H.nE = d->nE;
   for (int q = 0; q < d->ncomp; ++q) {
@@ -1177,9 +1238,9 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   P->blocks = d->nloc;
   P->dev = nullptr;
   P->words = nullptr;
-  hipError_t e = hipMalloc(&P->dev, sizeof(hs_dev));
+  hipError_t e = hipMalloc(&P->dev, sizeof(packs_host));
   if (e == hipSuccess) e = hipMalloc(&P->words, 2 * sizeof(int));
-  if (e == hipSuccess) e = hipMemcpy(P->dev, &C, sizeof(hs_dev), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(P->words, 0, 2 * sizeof(int));
   if (e == hipSuccess && lds > 64 * 1024)
     e = hipFuncSetAttribute((const void*)k_half_step, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1191,7 +1252,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     delete P;
     return nh_set_error(NH_EHIP, "half-step plan: %s", hipGetErrorString(e));
   }
-  H.D = P->dev;
+  H.C.pk = P->dev;
   H.done = P->words;
   H.hbase = P->words + 1;
   P->hot = H;

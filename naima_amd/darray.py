@@ -72,6 +72,11 @@ class nh_hs_syn(C.Structure):
                 ("out", C.c_void_p)]
 
 
+class nh_hs_blob(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mom", C.c_int), ("m", C.c_int), ("pad", C.c_int),
+                ("lazy", nh_lazy), ("cur", C.c_void_p), ("hist", C.c_void_p)]
+
+
 class nh_hs_desc(C.Structure):
     """include/naima_hip.h: the descriptor of nh_half_step_create"""
     _fields_ = [("coords", C.c_void_p), ("logp", C.c_void_p), ("blk", C.c_void_p),
@@ -91,7 +96,8 @@ class nh_hs_desc(C.Structure):
                 ("err_hi", C.c_void_p), ("ul", C.c_void_p), ("cl", C.c_void_p),
                 ("lp", C.c_void_p),
                 ("terms", nh_prior * 16), ("nterms", C.c_int),
-                ("model_out", C.c_void_p), ("total", C.c_void_p)]
+                ("model_out", C.c_void_p), ("total", C.c_void_p),
+                ("blobs", nh_hs_blob * 4), ("nblobs", C.c_int), ("pad2", C.c_int)]
 
 
 def lazy_const(v):

@@ -112,6 +112,11 @@ class DeviceLoop:
         # nh_hist descriptor in HBM: the fused kernel appends the chain history itself
         self.histd = ctx.empty((4,), dtype=np.int64)
         ctx.call("nh_memset", self.histd, 0, self.histd.nbytes)
+        # ... and, in the one-launch mode, the blobs' histories (device words holding the base
+        # of each blob's history of the current call; 0: not kept)
+        self.blobhistd = ctx.empty((4,), dtype=np.int64)
+        ctx.call("nh_memset", self.blobhistd, 0, self.blobhistd.nbytes)
+        self.blobs_in_kernel = False
         self.cursor = ctx.empty((1,), dtype=np.int32)
         self.sel = ctx.empty((self.ns,), dtype=np.int32)
         self.qT = ctx.empty((self.ndim * self.nloc,))
@@ -209,6 +214,9 @@ class DeviceLoop:
         """copy the proposal's blobs into fixed staging buffers (only when kept)"""
         if not (self.s.store_blobs and self.cur_blobs):
             return
+        if self.mega and self._hook.get("blobs_in_kernel"):
+            self.blobs_in_kernel = True  # the half-step launch keeps the blobs itself
+            return
         if self.new_blobs is None:
             self.new_blobs = [self.ctx.empty((self.nloc, m)) for _, m, _, _ in self.cur_blobs]
             if self.sharded:  # every rank keeps every walker's blobs
@@ -229,7 +237,7 @@ class DeviceLoop:
         else:
             ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
                      self._newlp_ptr, self.ns, self.ndim, self.accepted, self.nacc, self.sel, 1)
-        if self.s.store_blobs and self.cur_blobs:
+        if self.s.store_blobs and self.cur_blobs and not self.blobs_in_kernel:
             if self.sharded:
                 for ab, (cur, m, _, _) in zip(self.all_blobs, self.cur_blobs):
                     ctx.call("nh_scatter_rows", cur, m, ab, m, self.sel, self.accepted, 0,
@@ -319,6 +327,9 @@ class DeviceLoop:
                                  nloc=self.nloc, front_args=self._front_args)
             if self._hook.get("total") is None:
                 self._hook["total"] = ctx.empty((self.nloc,))  # persistent: the plan points at it
+            if self.s.store_blobs and self.cur_blobs and not self.sharded:
+                self._hook["blobs"] = [(cur.ptr, m, self.blobhistd.ptr + 8 * i)
+                                       for i, (cur, m, _, _) in enumerate(self.cur_blobs)]
         # new slice protocol: cursor = the slice accepted last.  The two piecewise
         # half-steps (slices 0 and 1 of the first block) left it at 2.
         self.cursor.set(np.array([1], dtype=np.int32))
@@ -440,10 +451,14 @@ class DeviceLoop:
             self.hist.append(block)
         # chain history: appended on the device by nh_move_cycle when it is active for
         # the whole call, else one pair of copies per step
-        dev_hist = self.fused and block is not None
+        dev_hist = self.fused and block is not None and not (
+            self.mega and self._plan["hs"] is None)  # (the launch's plan does not exist yet)
         if self.fused:
             self.histd.set(np.array([block["coords"].ptr, block["logp"].ptr, 0, iterations]
                                     if dev_hist else [0, 0, 0, 0], dtype=np.int64))
+            words = [hb.ptr for hb in block["blobs"]] if dev_hist and self.blobs_in_kernel else []
+            self.blobhistd.set(np.array((words + [0, 0, 0, 0])[:4], dtype=np.int64))
+        blob_dev_hist = dev_hist and self.blobs_in_kernel  # the launches append the blobs too
         moves = s.moves(pinned=True)
         it = 0
         while it < iterations:
@@ -479,7 +494,7 @@ class DeviceLoop:
                 g = 1
                 if (self.step_graph is not None and self.fused and K - k >= self.GSTEPS and
                         yield_every >= self.GSTEPS and (block is None or dev_hist) and
-                        not (block is not None and block["blobs"])):
+                        not (block is not None and block["blobs"] and not blob_dev_hist)):
                     g = self.GSTEPS
                     # one launch per half-step: the slices are baked into the graph (the
                     # proposal's chain of dependent reads is one trip shorter), so there is
@@ -509,8 +524,9 @@ class DeviceLoop:
                         ctx.call("nh_copy", block["coords"].ptr + 8 * kk * N * self.ndim,
                                  self.coords, 8 * N * self.ndim)
                         ctx.call("nh_copy", block["logp"].ptr + 8 * kk * N, self.logp, 8 * N)
-                    for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
-                        ctx.call("nh_copy", hb.ptr + 8 * kk * N * m, cur, 8 * N * m)
+                    if not blob_dev_hist:
+                        for hb, (cur, m, _, _) in zip(block["blobs"], self.cur_blobs or []):
+                            ctx.call("nh_copy", hb.ptr + 8 * kk * N * m, cur, 8 * N * m)
                     block["n"] = kk + g
                 if yield_every < 2:
                     self._flush_pending()
@@ -521,6 +537,9 @@ class DeviceLoop:
                     self._flush_pending()
                     ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim, self.histd,
                              block["n"] - 1)
+                    if blob_dev_hist:
+                        ctx.call("nh_half_step_append_blobs", self._plan["hs"]["plan"],
+                                 block["n"] - 1)
                 yield DeviceState(self, rng)
         self._flush_pending()
 
