@@ -194,8 +194,11 @@ def main():
                     help="relative spread of the initial ensemble around p0 (naima: 10 %%, core.py:477-481)")
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="repeat the K-step timed region until this many seconds have been timed")
+    ap.add_argument("--no-blobs", action="store_true",
+                    help="the timed loop does not keep the blobs (emcee and the reference always do: "
+                         "(flux, We) per walker and step, core.py:450-457)")
     ap.add_argument("--no-blobs-run", action="store_true",
-                    help="skip the extra store_blobs=True measurement")
+                    help="skip the extra measurement with the opposite blob setting")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-chain", action="store_true",
                     help="do not keep the chain (emcee's store=False); default keeps it in HBM")
@@ -235,7 +238,8 @@ def main():
                                device=device, use_graph=graph)
 
     device = not args.host_loop
-    sampler = make_sampler(device, not args.no_graph)
+    keep_blobs = not args.no_blobs
+    sampler = make_sampler(device, not args.no_graph, blobs=keep_blobs)
     # naima's initial ensemble: a ball of 10 % of p0 around p0 (core.py:477-481)
     pos = p0 + args.ball * p0 * sampler._rng.normal(size=(nwalkers, p0.size))
     state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
@@ -279,11 +283,12 @@ def main():
     dt = float(np.median(times))
     final_coords = np.asarray(state.coords)
 
-    # ---- the same loop keeping blobs (the reference always stores (flux, We) per walker
-    # and step, core.py:450-457): reported in an extra key
+    # ---- the same loop with the other blob setting (the reference always stores (flux, We)
+    # per walker and step, core.py:450-457, and so does the timed loop above unless
+    # --no-blobs): reported in an extra key
     blobs_value = None
     if device and not args.no_blobs_run:
-        bs = make_sampler(device, not args.no_graph, blobs=True)
+        bs = make_sampler(device, not args.no_graph, blobs=not keep_blobs)
         bst = bs.run_mcmc(final_coords, 6, store=False)
         bt = []
         for _ in range(int(min(40, max(1, np.ceil(args.min_time / 2 / max(dt, 1e-6)))))):
@@ -296,7 +301,7 @@ def main():
     # ---- per-kernel HIP-event timing: hipGraph replay hides the launches from
     # events, so the SAME launch sequence is run eagerly (device loop, no graph)
     # with an event pair around every launch, for the same number of steps
-    prof_sampler = make_sampler(device, False)
+    prof_sampler = make_sampler(device, False, blobs=keep_blobs)
     pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
     ctx.sync()
     ctx.profile(True)
@@ -348,7 +353,8 @@ def main():
                            else "all-gather between two graphs per half-step")
             if device else "host loop",
             "chain": "discarded (store=False)" if args.no_chain else
-            "kept: every step's coords and log-prob appended in HBM by the step kernels"},
+            "kept: every step's coords, log-prob%s appended in HBM by the step kernels"
+            % (" and blobs" if keep_blobs else "")},
         "timing": {"regions": len(times), "steps_per_region": args.steps,
                    "statistic": "median region (every region: barrier + sync, K steps, sync + "
                                 "barrier, max over ranks)",
@@ -356,7 +362,9 @@ def main():
                    "value_first_region": nwalkers * args.steps / times[0],
                    "value_min": nwalkers * args.steps / max(times),
                    "value_max": nwalkers * args.steps / min(times)},
-        "value_store_blobs": blobs_value,
+        "blobs": ("kept: the model spectrum and We/Wp of every walker and step, in HBM"
+                  if keep_blobs else "not kept (--no-blobs)"),
+        ("value_without_blobs" if keep_blobs else "value_store_blobs"): blobs_value,
         "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,

@@ -281,6 +281,14 @@ int nh_move_accept(nh_ctx* ctx, double* coords, double* logp, const double* blk,
                    const double* newlp, int ns, int ndim, int* accepted, int* naccepted,
                    int* sel, int advance);
 
+/* nh_move_accept on gathered ROWS { lnprob | blob 0 | blob 1 ... } (width doubles each, row j
+ * = proposal j of the slice): the blobs of an accepted proposal go to cur[b][walker] (m[b]
+ * values each, consecutive in the row).  advance as nh_move_accept. */
+int nh_move_accept_rows(nh_ctx* ctx, double* coords, double* logp, const double* blk, int* cursor,
+                        const double* rows, int width, int ns, int ndim, int* accepted,
+                        int* naccepted, int* sel, int advance, int nblobs,
+                        double* const* cur /*host [nblobs]*/, const int* m /*host [nblobs]*/);
+
 /* ---- the two launches that bracket a model evaluation in the device step loop ------
  * Slice protocol of these two: cursor[0] = index of the slice whose proposals are being
  * evaluated (-1 right after a block upload).
@@ -439,7 +447,12 @@ typedef struct {
   const int* ul; const double* cl; const double* lp /* [nloc] or NULL */;
   nh_prior terms[NH_MAX_PRIOR]; int nterms;
   double* model_out /* [nloc][nE] or NULL */; double* total /* [nloc] */;
-  nh_hs_blob blobs[NH_HS_MAX_BLOB]; int nblobs; int pad2;
+  nh_hs_blob blobs[NH_HS_MAX_BLOB]; int nblobs;
+  /* do_accept = 0 (sharded loop) with blobs: total[] is an exchange buffer of rows of
+   * send_width doubles, row j = { lnprob | blob 0 | blob 1 ... } of walker j: ONE all-gather
+   * per half-step carries the log-probabilities and the blobs; nh_move_accept_rows takes the
+   * gathered rows.  0: total[] holds the log-probabilities only. */
+  int send_width;
 } nh_hs_desc;
 typedef struct nh_halfstep_plan nh_halfstep_plan;
 int nh_half_step_create(nh_ctx* ctx, const nh_hs_desc* desc /*host*/, nh_halfstep_plan** out);

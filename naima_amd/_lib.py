@@ -69,6 +69,7 @@ _SIGS = {
     "nh_lnprob": [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _i, _dp, _dp],
     "nh_move_propose": [_dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp],
     "nh_move_accept": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _i],
+    "nh_move_accept_rows": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp],
     "nh_step_front": [_dp, _dp, _dp, _dp, _dp, _dp, _i, _i, _i, _i, _dp, _dp, _dp, _i, _i, _dp, _dp,
                       _i, _dp, _i, _dp],
     "nh_pion_kelner06": [_dp, _i, _dp, _i, _dp, _i, _d, _i, _dp, _i, _dp, _dp],
@@ -564,7 +565,8 @@ class Context:
         hook["blobs_in_kernel"] = False
         blobs = [b for b in blobs if not isinstance(b, (float, int))]  # (lnprob's constant NaN)
         dest = hook.get("blobs")
-        if dest and hook["mv"] is not None and len(dest) == len(blobs) <= 4:
+        if dest and (hook["mv"] is not None or hook.get("send_width")) and \
+                len(dest) == len(blobs) <= 4:
             from . import units as u
             model_terms = [(int(comps[q].ptr), int(comps[q].ld), float(comps[q].scale))
                            for q in range(ncomp)]
@@ -584,6 +586,8 @@ class Context:
                 for q, e in enumerate(ent):
                     d.blobs[q] = e
                 d.nblobs = len(ent)
+                d.send_width = int(hook.get("send_width") or 0) if hook["mv"] is None else 0
+                hook["rows_active"] = d.send_width
                 hook["blobs_in_kernel"] = True
         h = _dp()
         _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))

@@ -159,6 +159,8 @@ def lnprobmodel(model, data, lp=None, blobs=()):
         # the sharded step loop wants the result in its all-gather send buffer
         total = hook["total"] if hook is not None and hook.get("total") is not None \
             else ctx.empty((N,))
+        if hook is not None and hook.get("total_rows") is not None:
+            total = hook["total_rows"]  # rows { lnprob | blobs }: see Context.half_step
         lpd = terms = None
         nterms = 0
         if isinstance(lp, LazyPrior):
@@ -180,7 +182,7 @@ def lnprobmodel(model, data, lp=None, blobs=()):
                           blobs=blobs)
             hook["used"] = True
             del lpd
-            return DVec(ctx, total, total.ptr, N)
+            return DVec(ctx, total, total.ptr, N, stride=int(hook.get("rows_active") or 1))
         if hook is not None:
             # device step loop: the stretch move's accept rides on this launch (single
             # rank; sharded, the accept has to wait for the all-gather: mv is None)

@@ -213,6 +213,72 @@ extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const dou
   return NH_OK;
 }
 
+struct accept_blobs { double* cur[4]; int m[4]; int n; };
+
+// the same on gathered rows { lnprob | blob 0 | blob 1 ... }: one workgroup per proposal
+__global__ void k_move_accept_rows(double* __restrict__ coords, double* __restrict__ logp,
+                                   const double* __restrict__ blk, int* __restrict__ cursor,
+                                   const double* __restrict__ rows, int width, int ns, int ndim,
+                                   int* __restrict__ accepted, int* __restrict__ naccepted,
+                                   int* __restrict__ sel, accept_blobs B) {
+  const move_slice m = move_get(blk, cursor, ns);
+  const int j = blockIdx.x;
+  const int me = m.idx[j], pa = m.idx[ns + j];
+  const double z = m.rnd[j];
+  const double* r = rows + (long long)j * width;
+  const double d = (ndim - 1.0) * log(z) + r[0] - logp[me];
+  const bool acc = m.rnd[ns + j] < d;  // NaN compares false, as numpy
+  __syncthreads();  // (everybody has read logp[me] before anybody writes it)
+  if (acc) {
+    for (int k = threadIdx.x; k < ndim; k += blockDim.x) {
+      const double cj = coords[(long long)pa * ndim + k];
+      const double sj = coords[(long long)me * ndim + k];
+      coords[(long long)me * ndim + k] = cj - (cj - sj) * z;
+    }
+    const double* rb = r + 1;
+    for (int b = 0; b < B.n; ++b) {
+      for (int t = threadIdx.x; t < B.m[b]; t += blockDim.x)
+        B.cur[b][(long long)me * B.m[b] + t] = rb[t];
+      rb += B.m[b];
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (acc) {
+      logp[me] = r[0];
+      if (naccepted) atomicAdd(&naccepted[me], 1);
+    }
+    accepted[j] = acc ? 1 : 0;
+    if (sel) sel[j] = me;
+  }
+}
+
+__global__ void k_cursor_advance(int* cursor) { cursor[0] += 1; }
+
+extern "C" int nh_move_accept_rows(nh_ctx* c, double* coords, double* logp, const double* blk,
+                                   int* cursor, const double* rows, int width, int ns, int ndim,
+                                   int* accepted, int* naccepted, int* sel, int advance,
+                                   int nblobs, double* const* cur, const int* m) {
+  NH_REQUIRE(c && coords && logp && blk && cursor && rows && accepted && ns >= 1 && ndim >= 1 &&
+                 width >= 1 && nblobs >= 0 && nblobs <= 4 && (nblobs == 0 || (cur && m)),
+             "bad argument");
+  accept_blobs B;
+  B.n = nblobs;
+  int wsum = 1;
+  for (int b = 0; b < nblobs; ++b) {
+    NH_REQUIRE(cur[b] && m[b] >= 1, "bad blob");
+    B.cur[b] = cur[b];
+    B.m[b] = m[b];
+    wsum += m[b];
+  }
+  NH_REQUIRE(width >= wsum, "rows narrower than 1 + the blobs' lengths");
+  nh_prof_scope ps(c, NH_K_GLUE);
+  hipLaunchKernelGGL(k_move_accept_rows, dim3((unsigned)ns), dim3(64), 0, c->stream, coords, logp,
+                     blk, cursor, rows, width, ns, ndim, accepted, naccepted, sel, B);
+  if (advance) hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, c->stream, cursor);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
 // blob bookkeeping: dst[idx[lo+j]][:] = src[j][:] where accepted[lo+j]
 __global__ void k_scatter_rows(double* __restrict__ dst, int ldd, const double* __restrict__ src,
                                int lds, const int* __restrict__ idx,

@@ -72,6 +72,7 @@ struct hs_dev {
   double* model_out; double* total;
   nh_hs_blob blob[NH_HS_MAX_BLOB];
   int nblob, o_mrow;  // o_mrow: LDS offset of the model spectrum row + the moments' results
+  int sendw, pad1;    // > 0: total[] holds rows { lnprob | blobs } of this width (sharded loop)
   long long* dbg;  // NH_HS_DEBUG=1: wall-clock stamps of the first 8 workgroups, [8][16]
 };
 
@@ -912,7 +913,19 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       // quirk kept from core.py:89-92: cl is indexed by the violation count
       if (nul > 0) acc += (double)nviol * log(1.0 - H.cl[nviol]);
       if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
-      D.total[j] = acc;
+      D.total[(long long)j * (D.sendw > 0 ? D.sendw : 1)] = acc;
+    }
+    if (D.sendw > 0) {  // sharded loop: the blobs travel with the log-probability
+      double* rowp = D.total + (long long)j * D.sendw + 1;
+      for (int b = 0; b < D.nblob; ++b) {
+        const nh_hs_blob& bl = D.blob[b];
+        if (bl.kind == 0) {
+          for (int t = lane; t < bl.m; t += 64) rowp[t] = sm[D.o_mrow + t];
+        } else if (lane == 0) {
+          rowp[0] = nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom]);
+        }
+        rowp += bl.m;
+      }
     }
     if (D.do_accept) {  // emcee RedBlueMove.propose for this walker
       acc = __shfl(acc, 0, 64);
@@ -1192,10 +1205,17 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   H.ntab = d->ntab;
   NH_REQUIRE(d->nblobs >= 0 && d->nblobs <= NH_HS_MAX_BLOB, "bad blob count");
   C.nblob = d->nblobs;
+  C.sendw = d->do_accept ? 0 : d->send_width;
+  if (C.sendw > 0) {
+    int wsum = 1;
+    for (int b = 0; b < d->nblobs; ++b) wsum += d->blobs[b].m;
+    NH_REQUIRE(C.sendw >= wsum, "send_width smaller than 1 + the blobs' lengths");
+  }
   C.o_mrow = off; off += d->nE + NH_MAX_MOMENT;
   for (int b = 0; b < d->nblobs; ++b) {
     const nh_hs_blob& bl = d->blobs[b];
-    NH_REQUIRE(d->do_accept, "blobs in the launch need the in-launch accept");
+    NH_REQUIRE(d->do_accept || d->send_width > 0,
+               "blobs in the launch need the in-launch accept or an exchange row");
     NH_REQUIRE(bl.cur && ((bl.kind == 0 && bl.m == d->nE) ||
                           (bl.kind == 1 && bl.m == 1 && bl.mom >= 0 && bl.mom < d->nmoms)),
                "bad blob");

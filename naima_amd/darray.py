@@ -97,7 +97,7 @@ class nh_hs_desc(C.Structure):
                 ("lp", C.c_void_p),
                 ("terms", nh_prior * 16), ("nterms", C.c_int),
                 ("model_out", C.c_void_p), ("total", C.c_void_p),
-                ("blobs", nh_hs_blob * 4), ("nblobs", C.c_int), ("pad2", C.c_int)]
+                ("blobs", nh_hs_blob * 4), ("nblobs", C.c_int), ("send_width", C.c_int)]
 
 
 def lazy_const(v):

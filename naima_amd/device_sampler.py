@@ -117,6 +117,7 @@ class DeviceLoop:
         self.blobhistd = ctx.empty((4,), dtype=np.int64)
         ctx.call("nh_memset", self.blobhistd, 0, self.blobhistd.nbytes)
         self.blobs_in_kernel = False
+        self.send_width = 0
         self.cursor = ctx.empty((1,), dtype=np.int32)
         self.sel = ctx.empty((self.ns,), dtype=np.int32)
         self.qT = ctx.empty((self.ndim * self.nloc,))
@@ -158,7 +159,8 @@ class DeviceLoop:
             self.ctx._in_eval = False
         self.s.n_lnprob_calls += 1
         self.s.n_walker_evals += n
-        total = res[0].dense()
+        rows = bool(self._hook and self._hook.get("rows_active")) and self.ctx._accept_hook is self._hook
+        total = res[0] if rows else res[0].dense()  # (rows: exchanged as they are)
         blobs = list(res[1:])
         # plain numbers among the blobs (lnprob's (model, nan) for a model that returns no
         # blob of its own, core.py:108-110) are the same for every walker and every step:
@@ -202,7 +204,9 @@ class DeviceLoop:
         if self.sharded:
             # fixed hand-over buffer so that the two graphs and the collective between
             # them always see the same addresses
-            if total.ptr != self.mylp.ptr:  # (the fused likelihood wrote it there itself)
+            if self._hook and self._hook.get("rows_active"):
+                pass  # rows { lnprob | blobs } are exchanged as the launch wrote them
+            elif total.ptr != self.mylp.ptr:  # (the fused likelihood wrote it there itself)
                 ctx.call("nh_copy", self.mylp, total.ptr, 8 * self.nloc)
             self._newlp_ptr = self.newlp.ptr
         else:
@@ -228,7 +232,15 @@ class DeviceLoop:
 
     def _part_accept(self):
         ctx = self.ctx
-        if self.fused:
+        if self.fused and self.sharded and self.blobs_in_kernel and self.send_width:
+            import ctypes as C
+            nb = len(self.cur_blobs)
+            cur = (C.c_void_p * nb)(*[c_.ptr for c_, _, _, _ in self.cur_blobs])
+            mm = (C.c_int * nb)(*[m for _, m, _, _ in self.cur_blobs])
+            ctx.call("nh_move_accept_rows", self.coords, self.logp, self.blk, self.cursor,
+                     self.recv_rows, self.send_width, self.ns, self.ndim, self.accepted, self.nacc,
+                     self.sel, 0, nb, cur, mm)
+        elif self.fused:
             if not (self._hook and self._hook["used"] and self._hook["mv"] is not None):
                 # sharded (the accept waits for the all-gather), or a foreign likelihood
                 ctx.call("nh_move_accept", self.coords, self.logp, self.blk, self.cursor,
@@ -327,9 +339,17 @@ class DeviceLoop:
                                  nloc=self.nloc, front_args=self._front_args)
             if self._hook.get("total") is None:
                 self._hook["total"] = ctx.empty((self.nloc,))  # persistent: the plan points at it
-            if self.s.store_blobs and self.cur_blobs and not self.sharded:
+            if self.s.store_blobs and self.cur_blobs:
                 self._hook["blobs"] = [(cur.ptr, m, self.blobhistd.ptr + 8 * i)
                                        for i, (cur, m, _, _) in enumerate(self.cur_blobs)]
+                if self.sharded:
+                    # the blobs travel with the log-probabilities: ONE all-gather of rows
+                    # { lnprob | blob 0 | blob 1 ... } per half-step
+                    self.send_width = 1 + sum(m for _, m, _, _ in self.cur_blobs)
+                    self._hook["send_width"] = self.send_width
+                    self.send_rows = ctx.empty((max(self.nloc, 1), self.send_width))
+                    self.recv_rows = ctx.empty((self.ns, self.send_width))
+                    self._hook["total_rows"] = self.send_rows
         # new slice protocol: cursor = the slice accepted last.  The two piecewise
         # half-steps (slices 0 and 1 of the first block) left it at 2.
         self.cursor.set(np.array([1], dtype=np.int32))
@@ -373,7 +393,10 @@ class DeviceLoop:
 
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
-        if self.sharded:
+        if self.sharded and self.blobs_in_kernel and self.send_width:
+            self.s.comm.allgather_device(self.ctx, self.send_rows.ptr, self.recv_rows,
+                                         self.nloc * self.send_width)
+        elif self.sharded:
             self.s.comm.allgather_device(self.ctx, self.mylp.ptr, self.newlp, self.nloc)
             if self.s.store_blobs and self.cur_blobs:
                 # blobs of the proposals follow their log-probabilities: the walker a rank

@@ -7,7 +7,7 @@ for w in cfg3 cfg5 cfg1 cfg2; do
 timeout 300 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu --ball 0.005 2> gpurun_out/r2/bench_$w.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print(d['config']['workload'][:5], d['value'], d['ms_per_step'], d['value_store_blobs'], d['kernels_us_per_launch'])
+print(d['config']['workload'][:5], d['value'], d['ms_per_step'], d.get('value_without_blobs', d.get('value_without_blobs', d.get('value_store_blobs'))), d['kernels_us_per_launch'])
 "
 tail -3 gpurun_out/r2/bench_$w.err
 done

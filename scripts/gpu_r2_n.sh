@@ -7,4 +7,4 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r2/bench_n1_drive
 python -c "
 import json
 d=json.load(open('gpurun_out/r2/bench_n1_driverlike.json'))
-print(d['value'], d['ms_per_step'], d['value_store_blobs'], d['timing'], d['roofline']['kernel'], d['roofline']['avg_launch_us'], d['fp64_valu']['kernels'], d['acceptance_fraction'], d['cpu_baseline'])"
+print(d['value'], d['ms_per_step'], d.get('value_without_blobs', d.get('value_without_blobs', d.get('value_store_blobs'))), d['timing'], d['roofline']['kernel'], d['roofline']['avg_launch_us'], d['fp64_valu']['kernels'], d['acceptance_fraction'], d['cpu_baseline'])"

@@ -43,7 +43,7 @@ import json, glob
 for f in sorted(glob.glob("gpurun_out/r2prof/bench_*.json")):
     try:
         d = json.load(open(f))
-        print(f.split('/')[-1], round(d['value']), d['ms_per_step'], d.get('value_store_blobs'), d['kernels_us_per_launch'])
+        print(f.split('/')[-1], round(d['value']), d['ms_per_step'], d.get('value_without_blobs', d.get('value_store_blobs')), d['kernels_us_per_launch'])
     except Exception as e:
         print(f, "ERR", e)
 PY
