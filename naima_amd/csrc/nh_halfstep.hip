@@ -100,7 +100,8 @@ struct hs_hot {
   int nE, ntab;
   const double* tscale[HS_MAX_TAB];  // per-column factors of the table reductions (or NULL)
   int tnK[HS_MAX_TAB], tspec[HS_MAX_TAB];
-  int o_scale, pad3;
+  int o_scale, o_synE;  // o_synE: the synchrotron component's photon energies in LDS
+  int o_pri, pad4;      // the prior terms, copied out of the kernel-argument segment
 };
 
 struct nh_halfstep_plan {
@@ -136,9 +137,11 @@ typedef unsigned int hs_u32x4 __attribute__((ext_vector_type(4)));
 // one 16-byte element {K[i][k], dlnK[i][k]} of the interleaved table
 __device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double& K,
                                           double& d) {
+  typedef double hs_f64x2 __attribute__((ext_vector_type(2)));
   const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-  K = __hiloint2double((int)v.y, (int)v.x);
-  d = __hiloint2double((int)v.w, (int)v.z);
+  const hs_f64x2 kd = __builtin_bit_cast(hs_f64x2, v);  // (register pairs as loaded: no moves)
+  K = kd.x;
+  d = kd.y;
 }
 
 // one table work item: columns [64 tile, 64 tile + 64) x segments [s0, s1) of table t for
@@ -148,11 +151,25 @@ __device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byt
 // walker per workgroup the rows stream from L2 once per walker and that rate is the bound:
 // 23 us of table items became XX).  Eight nodes per trip = eight kilobytes in flight per
 // wave (a double-buffered four-node version, half of that in flight, measured 25 % slower).
+typedef __attribute__((address_space(3))) const double hs_lds_cd;
+// LDS byte address of a pointer into the workgroup's shared block, parked in a VECTOR register:
+// the walker's w / dlw / lx reads of a table item are wave-uniform, the compiler keeps such an
+// address in SGPRs and re-materialises it with a v_mov before EVERY ds_read (3 of the 15 VALU
+// instructions of a segment); from a VGPR base the reads of a trip are immediate offsets.
+__device__ __forceinline__ unsigned hs_lds_addr(const double* p) {
+  unsigned a = (unsigned)(unsigned long long)(hs_lds_cd*)p;
+  asm volatile("" : "+v"(a));
+  return a;
+}
+__device__ __forceinline__ double hs_lds_at(unsigned base, int idx) {
+  return *(hs_lds_cd*)(unsigned long long)(base + 8u * (unsigned)idx);
+}
+
 template <bool SIGNED>
 __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
                                                 const double* ws, const double* ds,
                                                 const double* lxs, int lane) {
-  // the table's address and width come out of the descriptor in memory: the compiler cannot
+  // the table's address and width come out of the descriptor: the compiler cannot
   // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
   // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
   // the 25 the loop then costs) -- say so once per work item instead
@@ -168,10 +185,11 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
       __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
   const unsigned rowb = nK * 16u;
   unsigned ob = ((unsigned)s0 * nK + kk) * 16u;
+  unsigned aw = hs_lds_addr(ws + s0), ad = hs_lds_addr(ds + s0), al = hs_lds_addr(lxs + s0);
   double acc = 0.0;
   double K1, d1;  // node s: its K and the log-ratio of the segment that starts there
   hs_buf_kd(rKD, ob, K1, d1);
-  double u1 = ws[s0] * K1;
+  double u1 = hs_lds_at(aw, 0) * K1;
   int s = s0;
   for (; s + 8 <= s1; s += 8) {
     double K2[8], dK[8];
@@ -179,14 +197,17 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
     for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const double u2 = ws[s + q + 1] * K2[q];
-      const double dl = ds[s + q] + d1;
-      acc += SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[s + q])
-                    : nh_seg_pos<false>(u1, u2, dl, lxs[s + q]);
+      const double u2 = hs_lds_at(aw, q + 1) * K2[q];
+      const double dl = hs_lds_at(ad, q) + d1;
+      acc += SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
+                    : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
       u1 = u2;
       d1 = dK[q];
     }
     ob += 8 * rowb;
+    aw += 64u;
+    ad += 64u;
+    al += 64u;
   }
   if (s < s1) {  // tail: the remaining (< 8) nodes in one trip; rows past the table read 0
     double K2[7], dK[7];
@@ -195,10 +216,10 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       if (s + q < s1) {
-        const double u2 = ws[s + q + 1] * K2[q];
-        const double dl = ds[s + q] + d1;
-        acc += SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[s + q])
-                      : nh_seg_pos<false>(u1, u2, dl, lxs[s + q]);
+        const double u2 = hs_lds_at(aw, q + 1) * K2[q];
+        const double dl = hs_lds_at(ad, q) + d1;
+        acc += SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
+                      : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
         u1 = u2;
         d1 = dK[q];
       }
@@ -235,25 +256,38 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   double acc = 0.0;
   double K1, d1;
   hs_buf_kd(rKD, ob, K1, d1);
+  // Four nodes per trip, the NEXT trip's loads issued before the current one is consumed: a
+  // narrow table means few work items -- one per wave, all waves in step -- so nothing else
+  // hides the round trip, and a trip's arithmetic (the signed segment form, four waves per
+  // SIMD) takes about as long as the trip itself.
+  double K2[4], dK[4], K2n[4], dKn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
   double u1 = (sl < s1 ? ws[sl] : 0.0) * K1;
-  for (int q0 = 0; q0 < len; q0 += 8) {
-    double K2[8], dK[8];
+  for (int q0 = 0; q0 < len; q0 += 4) {
+    ob += 4 * rowb;
+    if (q0 + 4 < len) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
+      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2n[q], dKn[q]);
+    }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const int sg = sl + q0 + q;
       const bool on = sg < se;
       const int sc = on ? sg : s0;  // (a valid LDS address for the idle lanes)
       const double u2 = ws[sc + 1] * K2[q];
       const double dl = ds[sc] + d1;
-      const double term = SIGNED ? nh_seg_term<true>(u1, u2, dl, lxs[sc])
+      const double term = SIGNED ? nh_seg_signed(u1, u2, dl, lxs[sc])
                                  : nh_seg_pos<false>(u1, u2, dl, lxs[sc]);
       acc += on ? term : 0.0;
       u1 = u2;
       d1 = dK[q];
     }
-    ob += 8 * rowb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      K2[q] = K2n[q];
+      dK[q] = dKn[q];
+    }
   }
   // the sub-ranges of a column meet in its first lane group (fixed order: deterministic)
   for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -383,6 +417,15 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       }
       ko += 2 * nG;
     }
+    {  // the prior terms: read one after the other out of the (cold) kernel-argument segment by
+       // the one lane that sums them they cost a 1.5 us round trip EACH (measured: the
+       // likelihood wave reached the next barrier 3 us after everybody else)
+      const double* src = reinterpret_cast<const double*>(&D.pri);
+      for (int t = t0; t < (int)(sizeof(nh_prior_pack) / sizeof(double)); t += TT)
+        sm[H.o_pri + t] = src[t];
+    }
+    if (has_syn)  // (first touched by the liveness search: a cold trip on the critical path)
+      for (int k = t0; k < H.syn_nE; k += TT) sm[H.o_synE + k] = H.syn_E[k];
     for (int t = 0; t < H.ntab; ++t)  // per-column factors of the reductions
       for (int k = t0; k < H.tnK[t]; k += TT)
         sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
@@ -483,34 +526,38 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // the model and throws it away, core.py:103-119).  Besides the time saved on such walkers
   // this keeps the launch time independent of how absurd they are: a negative B makes every
   // (energy, gamma) node of the synchrotron integrand "live" -- 4x the work of a normal walker.
-  if (lik_wave && lane == 0) {
-    double prior = 0.0;
-    const bool has_prior = D.lp || D.pri.n > 0;
-    if (has_prior) {
-      prior = D.lp ? D.lp[j] : 0.0;
-      for (int t = 0; t < D.pri.n; ++t) {
-        const nh_lazy& z = D.pri.t[t].x;
-        double v = z.a;
-        if (z.base) {
-          const long long d = z.base - H.qT;
-          // a term on one of this walker's proposed coordinates: taken from LDS
-          v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
-                  ? nh_lazy_apply(z, qs[d / H.nloc])
-                  : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
-        }
-        const double p0 = D.pri.t[t].p0, p1 = D.pri.t[t].p1;
-        double rr;
-        switch (D.pri.t[t].kind) {
-          case NH_PRIOR_UNIFORM: rr = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
-          case NH_PRIOR_NORMAL: rr = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
-          case NH_PRIOR_LOGUNIFORM: rr = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
-          default: rr = v; break;
-        }
-        prior += rr;
+  if (lik_wave) {
+    const nh_prior_pack& PR = *reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri);
+    const int npri = PR.n;
+    const bool has_prior = D.lp || npri > 0;
+    double term = 0.0;
+    if (lane < npri) {  // one term per lane
+      const nh_prior& pt = PR.t[lane];
+      const nh_lazy z = pt.x;
+      double v = z.a;
+      if (z.base) {
+        const long long d = z.base - H.qT;
+        // a term on one of this walker's proposed coordinates: taken from LDS
+        v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
+                ? nh_lazy_apply(z, qs[d / H.nloc])
+                : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
+      }
+      const double p0 = pt.p0, p1 = pt.p1;
+      switch (pt.kind) {
+        case NH_PRIOR_UNIFORM: term = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
+        case NH_PRIOR_NORMAL: term = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
+        case NH_PRIOR_LOGUNIFORM: term = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
+        default: term = v; break;
       }
     }
-    accs[3] = prior;
-    hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
+    // (summed in term order, as the separate kernels do: lane 0 adds them up)
+    double prior = 0.0;
+    for (int t = 0; t < npri; ++t) prior += __shfl(term, t, 64);
+    if (D.lp) prior += D.lp[j];
+    if (lane == 0) {
+      accs[3] = prior;
+      hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
+    }
   }
   // ---- 3. particle weights on every grid (-> LDS); the synchrotron liveness search --------
   const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
@@ -539,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     lv_k = t * 64 + lane;
     lv_i0 = nG;
     if (lv_k < H.syn_nE) {
-      lv_E = H.syn_E[lv_k];
+      lv_E = sm[H.o_synE + lv_k];
       lv_q = lv_E * qfac;
       int lo = 0, hi2 = nG;  // first i with q*ig2[i] <= 746 (ig2 decreases with i)
       while (lo < hi2) {
@@ -614,6 +661,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
     if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
   }
+  if (D.dbg && j == 0 && lane == 0) D.dbg[192 + wv] = (long long)wall_clock64();
   __syncthreads();
   HS_STAMP(4);
   const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
@@ -871,7 +919,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // ---- 7. likelihood + priors (core.py:64-121) and the accept, one wave ---------------------
   if (lik_wave) {
     const int nE = H.nE;
-    const bool has_prior = D.lp || D.pri.n > 0;
+    const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
     const double prior = accs[3];  // (evaluated beside the weights, see above)
     double acc = 0.0;
     int nviol = 0, nul = 0;
@@ -1202,6 +1250,8 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   H.o_spec = off; off += nspec;
   H.o_lik = off; off += 5 * d->nE;
   H.o_scale = off; off += nspec;
+  H.o_synE = off; off += syn_nE;
+  H.o_pri = off; off += (int)(sizeof(nh_prior_pack) / sizeof(double)) + 1;
   H.ntab = d->ntab;
   NH_REQUIRE(d->nblobs >= 0 && d->nblobs <= NH_HS_MAX_BLOB, "bad blob count");
   C.nblob = d->nblobs;
