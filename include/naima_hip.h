@@ -408,12 +408,15 @@ int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NP
  * (writing a row twice is harmless).  The descriptor is copied once (nh_half_step_create);
  * a launch takes no other argument, so it can be captured into a hipGraph and replayed. */
 /* KD: the emission table of nh_integrate_tables in the interleaved layout the kernel streams,
- * KD[(i*nK + k)*2 + {0,1}] = {Kt[i][k], dlnKt[i][k]} (nh_table_interleave) */
+ * KD[(i*nK + k)*2 + {0,1}] = {Kt[i][k], dlnKt[i][k]} (nh_table_interleave).  Where column k
+ * changes sign between nodes i and i+1 the second entry is NaN: that segment takes the
+ * reference's log branch (NaN exponent b, utils.py:336-345) -- decided once per table, the
+ * sign pattern does not depend on the walker. */
 typedef struct { int grid; int nK; int ldo; int nonnegative;
                  const double* KD; const double* reserved; const double* scale /*[nK] or NULL*/;
                  double* out /*[nloc][ldo]*/; } nh_hs_table;
-int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt, long long n,
-                        double* KD /*[2n]*/);
+int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt, int nG, int nK,
+                        double* KD /*[2 nG nK]*/);
 typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
                  int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB; int pad;
                  const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;

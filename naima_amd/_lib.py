@@ -106,7 +106,7 @@ _SIGS = {
     "nh_half_step_stamps": [_dp, _dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
                             _dp],
-    "nh_table_interleave": [_dp, _dp, _dp, _ll, _dp],
+    "nh_table_interleave": [_dp, _dp, _dp, _i, _i, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
     "nh_half_step_append_blobs": [_dp, _dp, _ll],
 }
@@ -534,9 +534,9 @@ class Context:
             if ent["kind"] == "tab":
                 _, w, lw, N, nG, lx, Kt, dKt, nK, sc, nonneg = k
 
-                def interleaved(Kt=Kt, dKt=dKt, n=nG * nK):
-                    kd = self.empty((2 * n,))
-                    self.call("nh_table_interleave", Kt, dKt, n, kd)
+                def interleaved(Kt=Kt, dKt=dKt, nG=nG, nK=nK):
+                    kd = self.empty((2 * nG * nK,))
+                    self.call("nh_table_interleave", Kt, dKt, nG, nK, kd)
                     return kd
 
                 kd = self.table(("kd", Kt, dKt, nG * nK), interleaved)

@@ -183,24 +183,26 @@ __device__ __forceinline__ double nh_seg_term(double u1, double u2, double dl, d
 #define NH_SEG_SMALL_POS 0x1p-10
 #endif
 #define NH_DL_ZERO 1e300
-// nh_seg_term<true> with its rare cases behind ONE wave-uniform branch: the series (|dl| <
-// 2^-7), the reference's log branch for a sign change / NaN ratio.  For signed tables whose
-// sign changes cluster (the FITPACK ringing of the pi0 look-up table sits in the corners of
-// the (Ep, Egamma) plane) most waves take the short path: (u2-u1) lx / dl and the zero test.
+// nh_seg_term<true> for the interleaved tables of the half-step kernel: the series (|dl| <
+// 2^-10, rare: the segment at the peak of u) behind a wave-uniform branch, the reference's log
+// branch for a sign change selected by dl = NaN.  The FITPACK ringing of the pi0 look-up table
+// changes sign in a fifth of its segments: testing the signs of u1, u2 per segment and
+// branching on "any lane" took the long way in nearly every trip.
 __device__ __forceinline__ double nh_seg_signed(double u1, double u2, double dl, double lx) {
   double t = ((u2 - u1) * lx) * nh_rcp1f(dl);
-  const bool small = fabs(dl) < 0.0078125;
-  const bool logb = ((__double2hiint(u1) ^ __double2hiint(u2)) < 0) || !(dl == dl);
-  if (__builtin_amdgcn_ballot_w64(small || logb) != 0) {
+  const bool small = fabs(dl) < NH_SEG_SMALL_POS;  // (false for NaN)
+  if (__builtin_amdgcn_ballot_w64(small) != 0) {
     asm volatile("" ::: "memory");  // keep this a branch: the compiler would if-convert it
     double f = fma(dl, 8.333333333333333e-03, 4.166666666666666e-02);
     f = fma(f, dl, 1.666666666666667e-01);
     f = fma(f, dl, 0.5);
     f = fma(f, dl, 1.0);
-    const double ul = u1 * lx;
-    t = small ? ul * f : t;
-    t = logb ? ul : t;
+    t = small ? (u1 * lx) * f : t;
   }
+  // sign change of the integrand: the interleaved table carries it as dl = NaN (the sign
+  // pattern of a table is walker-independent, nh_table_interleave) -> NaN b in the reference
+  // -> its log branch x1 y1 ln(x2/x1); a NaN weight ratio takes the same way, as there
+  t = (dl == dl) ? t : u1 * lx;
   return (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
 }
 

@@ -253,41 +253,53 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   const int sl = s0 + h * len;                   // this lane's first segment
   const int se = min(s1, sl + len);              // ... and the end of its sub-range
   unsigned ob = ((unsigned)sl * nK + kk) * 16u;  // (rows past the table read 0)
+  // per-lane LDS bases: the reads of a trip are immediate offsets from them.  Lanes whose
+  // sub-range is shorter than `len` read on past its end (another array of the block, or
+  // nothing: LDS reads out of range return 0) and discard the term.
+  unsigned aw = hs_lds_addr(ws + sl), ad = hs_lds_addr(ds + sl), al = hs_lds_addr(lxs + sl);
   double acc = 0.0;
   double K1, d1;
   hs_buf_kd(rKD, ob, K1, d1);
   // Four nodes per trip, the NEXT trip's loads issued before the current one is consumed: a
   // narrow table means few work items -- one per wave, all waves in step -- so nothing else
-  // hides the round trip, and a trip's arithmetic (the signed segment form, four waves per
-  // SIMD) takes about as long as the trip itself.
-  double K2[4], dK[4], K2n[4], dKn[4];
+  // hides the round trip.  Two trips per loop iteration: the two register sets swap roles by
+  // name instead of being copied (eight 64-bit moves per trip otherwise).
+  double KA[4], dA[4], KB[4], dB[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
-  double u1 = (sl < s1 ? ws[sl] : 0.0) * K1;
-  for (int q0 = 0; q0 < len; q0 += 4) {
-    ob += 4 * rowb;
-    if (q0 + 4 < len) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2n[q], dKn[q]);
-    }
+  for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+  double u1 = hs_lds_at(aw, 0) * K1;
+  const int owed = se - sl;  // segments of this lane's sub-range (<= 0: idle from the start)
+  int done = 0;              // (wave-uniform: lives in an SGPR)
+  auto trip = [&](const double (&K2)[4], const double (&dK)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int sg = sl + q0 + q;
-      const bool on = sg < se;
-      const int sc = on ? sg : s0;  // (a valid LDS address for the idle lanes)
-      const double u2 = ws[sc + 1] * K2[q];
-      const double dl = ds[sc] + d1;
-      const double term = SIGNED ? nh_seg_signed(u1, u2, dl, lxs[sc])
-                                 : nh_seg_pos<false>(u1, u2, dl, lxs[sc]);
-      acc += on ? term : 0.0;
+      const double u2 = hs_lds_at(aw, q + 1) * K2[q];
+      const double dl = hs_lds_at(ad, q) + d1;
+      const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
+                                 : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
+      acc += done + q < owed ? term : 0.0;
       u1 = u2;
       d1 = dK[q];
     }
+    done += 4;
+    aw += 32u;
+    ad += 32u;
+    al += 32u;
+  };
+  for (int q0 = 0; q0 < len; q0 += 8) {
+    ob += 4 * rowb;
+    if (q0 + 4 < len) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      K2[q] = K2n[q];
-      dK[q] = dKn[q];
+      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KB[q], dB[q]);
     }
+    trip(KA, dA);
+    if (q0 + 4 >= len) break;
+    ob += 4 * rowb;
+    if (q0 + 8 < len) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+    }
+    trip(KB, dB);
   }
   // the sub-ranges of a column meet in its first lane group (fixed order: deterministic)
   for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -335,13 +347,21 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   int me = 0, pa = 0;
   double mz = 1.0, mlnu = 0.0;
   nh_lazy pkz = {nullptr, 0, 0.0, 0.0, 0.0, 0, 0};
+  int pk_nc = 0, pk_ld = 0;  // this thread's pack: its shape and output, in the same trip
+  double* pk_out = nullptr;
   if (tid < max(ndim_, npk8)) {
     const int g = lo_ + j;
     me = idx[g];
     pa = idx[ns_ + g];
     mz = r[g];
     if (tid == 0) mlnu = r[ns_ + g];
-    if (tid < npk8) pkz = D.pk[tid / NH_MAX_LAZY].cols[tid % NH_MAX_LAZY];
+    if (tid < npk8 && tid < D.npk * NH_MAX_LAZY) {
+      const nh_pack& P = D.pk[tid / NH_MAX_LAZY];
+      pkz = P.cols[tid % NH_MAX_LAZY];
+      pk_nc = P.ncols;
+      pk_ld = P.ld;
+      pk_out = P.out;
+    }
   }
   const int stepbase = H.hbase[0];
   // (the grids' logarithms ln e and lx come with the grid: nh_half_step_create insists)
@@ -508,12 +528,12 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   }
   HS_STAMP(2);
   if (tid < D.npk * NH_MAX_LAZY) {
-    const int q = tid / NH_MAX_LAZY, col = tid % NH_MAX_LAZY;
-    if (col < D.pk[q].ncols) {
+    const int col = tid % NH_MAX_LAZY;
+    if (col < pk_nc) {
       double v = pkz.a;
       if (pkd >= 0) v = nh_lazy_apply(pkz, kcj - (kcj - ksj) * mz);  // (the same q as qs[pkd])
-      D.pk[q].out[(long long)j * D.pk[q].ld + col] = v;
-      if (D.pk[q].out == D.params) {
+      pk_out[(long long)j * pk_ld + col] = v;
+      if (pk_out == D.params) {
         row[col] = v;
         if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
       }
@@ -1034,23 +1054,35 @@ extern "C" int nh_half_step_append_blobs(nh_ctx* c, const nh_halfstep_plan* P, l
   return NH_OK;
 }
 
-// KD[i] = {Kt[i], dlnKt[i]}: the layout the half-step kernel streams (one 16-byte load per node)
+// KD[i][k] = {Kt[i][k], dlnKt[i][k]}: the layout the half-step kernel streams (one 16-byte load
+// per node).  Where the table changes sign between nodes i and i+1 the log-ratio is stored as
+// NaN: the reference's b = log10(y2/y1)/log10(x2/x1) is NaN there and the segment takes its log
+// branch (utils.py:336-345); the sign pattern belongs to the table, not to the walker (the
+// weights multiply both nodes by numbers of one sign), so it is settled here, once.
 __global__ void k_table_interleave(const double* __restrict__ Kt, const double* __restrict__ dlnKt,
-                                   long long n, double* __restrict__ KD) {
+                                   int nG, int nK, double* __restrict__ KD) {
+  const long long n = (long long)nG * nK;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    KD[2 * i] = Kt[i];
-    KD[2 * i + 1] = dlnKt[i];
+    const double k1 = Kt[i];
+    double d = dlnKt[i];
+    if (i + nK < n) {
+      const double k2 = Kt[i + nK];
+      if (k1 != 0.0 && k2 != 0.0 && ((__double2hiint(k1) ^ __double2hiint(k2)) < 0)) d = NAN;
+    }
+    KD[2 * i] = k1;
+    KD[2 * i + 1] = d;
   }
 }
 
-extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dlnKt, long long n,
-                                   double* KD) {
-  NH_REQUIRE(c && Kt && dlnKt && KD && n >= 0, "bad argument");
+extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dlnKt, int nG,
+                                   int nK, double* KD) {
+  NH_REQUIRE(c && Kt && dlnKt && KD && nG >= 0 && nK >= 0, "bad argument");
+  const long long n = (long long)nG * nK;
   if (n == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_TABLES);
   hipLaunchKernelGGL(k_table_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                     Kt, dlnKt, n, KD);
+                     Kt, dlnKt, nG, nK, KD);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

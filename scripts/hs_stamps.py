@@ -13,9 +13,10 @@ nw = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ball = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
 burn = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+graph = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False
 model, p0, raw, data, prior, labels = build_problem(name, na)
 s = EnsembleSampler(nw, p0.size, na.lnprob, args=[data, model, prior], seed=seed, naima_style=True,
-                    store_blobs=False, device=True, use_graph=False)
+                    store_blobs=False, device=True, use_graph=graph)
 pos = p0 + ball * p0 * s._rng.normal(size=(nw, p0.size))
 st = s.run_mcmc(pos, burn, store=False)
 ctx.sync()
