@@ -381,13 +381,15 @@ int nh_stream_join(nh_ctx* ctx);
  *             out[w*ldo + k] in 1/(s eV)
  *   what = 1: InverseCompton on nseed thermal seed fields (radiative.py:547-607), seed s at
  *             out[w*ldo + s*nE + k] = trapz_loglog(nelec sigma_s, gamma); the caller applies
- *             uf * Eph / E (radiative.py:684-687); seed_theta[s] < 0: isotropic
+ *             uf * Eph / E (radiative.py:684-687); seed_theta[s] < 0: isotropic.  T and theta
+ *             are lazy scalars: a seed temperature / angle may itself be a fit parameter (a
+ *             walker with T <= 0 gets the NaN the reference's arithmetic gives)
  * nmax: grid nodes the workgroup's LDS is sized for (4 nmax doubles); a walker that needs more
  * gets NaN and *status (device int, zeroed by the caller) receives the largest count asked for. */
 int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NPAR]*/, int N,
                         const nh_lazy* Eemin_eV /*host*/, const nh_lazy* Eemax_eV /*host*/,
                         double nEed, int what, const nh_lazy* B_G /*host, what = 0*/,
-                        const double* seed_T_K /*host*/, const double* seed_theta /*host*/,
+                        const nh_lazy* seed_T_K /*host*/, const nh_lazy* seed_theta /*host*/,
                         int nseed, const double* E_eV, int nE, double* out, int ldo, int nmax,
                         int* status /*device*/);
 

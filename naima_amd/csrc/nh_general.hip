@@ -9,8 +9,10 @@
 // walker's grid and weights in LDS (models.py eval + radiative.py:156-160), then integrates
 //     Synchrotron._spectrum                       (radiative.py:282-342), or
 //     InverseCompton on one thermal seed field    (radiative.py:547-607, 657-687)
-// with trapz_loglog (utils.py:285-355).  The parameters stay in HBM as lazy per-walker
-// scalars, so the device-resident step loop no longer falls back to the host for such models.
+// with trapz_loglog (utils.py:285-355).  The same holds when a seed field's temperature or
+// angle is a fit parameter (the Khangulyan kernel then differs per walker even on a shared
+// grid): T and theta are lazy per-walker scalars too.  The parameters stay in HBM, so the
+// device-resident step loop no longer falls back to the host for such models.
 #include "nh_ic.h"
 #include "nh_pdist.h"
 #include "nh_syn.h"
@@ -21,7 +23,7 @@ struct gen_args {
   nh_lazy emin, emax;   // per walker, eV
   double nEed;
   nh_lazy B;            // synchrotron: magnetic field [G]
-  double T[NH_MAX_COMP], theta[NH_MAX_COMP];  // IC: seed temperatures [K], angles (< 0: isotropic)
+  nh_lazy T[NH_MAX_COMP], theta[NH_MAX_COMP];  // IC: seed temperatures [K], angles [rad] (< 0: isotropic)
   const double* E_eV; int nE;
   double* out; int ldo;  // out[w*ldo + c*nE + k]
   int nmax;              // LDS capacity in nodes
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
     }
   } else {
     // ---- InverseCompton on thermal seed `comp` (the caller applies uf * Eph / E) --------
-    const double Tp = A.T[comp] * NH_K_TO_MEC2, th = A.theta[comp];
+    const double Tp = nh_lazy_eval(A.T[comp], wi) * NH_K_TO_MEC2;
+    const double th = nh_lazy_eval(A.theta[comp], wi);
     for (int k0 = 0; k0 < A.nE; k0 += 64) {
       const int k = k0 + lane;
       double acc = 0.0;
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
 
 extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int N,
                                    const nh_lazy* Eemin_eV, const nh_lazy* Eemax_eV, double nEed,
-                                   int what, const nh_lazy* B_G, const double* seed_T,
-                                   const double* seed_theta, int nseed, const double* E_eV, int nE,
+                                   int what, const nh_lazy* B_G, const nh_lazy* seed_T,
+                                   const nh_lazy* seed_theta, int nseed, const double* E_eV, int nE,
                                    double* out, int ldo, int nmax, int* status) {
   NH_REQUIRE(c && rows && Eemin_eV && Eemax_eV && E_eV && out && status, "NULL pointer");
   NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
@@ -177,7 +180,7 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
   A.emin = *Eemin_eV; A.emax = *Eemax_eV; A.nEed = nEed;
   if (what == 0) A.B = *B_G;
   for (int s = 0; s < ncomp && what == 1; ++s) {
-    NH_REQUIRE(seed_T[s] > 0.0, "seed temperature must be positive");
+    NH_REQUIRE(seed_T[s].base || seed_T[s].a > 0.0, "seed temperature must be positive");
     A.T[s] = seed_T[s];
     A.theta[s] = seed_theta[s];
   }

@@ -414,9 +414,16 @@ class BaseElectron(BaseRadiative):
     def _general_supported(self):
         return False
 
+    def _general_needed(self):
+        """True when the spectrum has to come from nh_general_electron (no table to share)"""
+        return self._general_limits()
+
+    _general_names = ("Eemin", "Eemax")
+
     def _needs_walker_loop(self):
-        if self._general_limits() and self._general_supported():
-            others = [(n, v) for n, v in self._structural_values() if n not in ("Eemin", "Eemax")]
+        if self._general_needed() and self._general_supported():
+            others = [(n, v) for n, v in self._structural_values()
+                      if n not in self._general_names and not n.endswith(("-T", "-theta"))]
             for n, v in others:
                 if _per_walker(v):
                     return super()._needs_walker_loop()
@@ -452,13 +459,23 @@ class BaseElectron(BaseRadiative):
         out = ctx.empty((N, ncomp * nE))
         status = ctx.general_status()
         Bl, k3 = (lazy_of(B, "G") if what == 0 else (None, None))
-        T = (C.c_double * max(ncomp, 1))(*[float(s[0]) for s in seeds])
-        th = (C.c_double * max(ncomp, 1))(*[float(s[1]) for s in seeds])
+        from .darray import nh_lazy
+        T = (nh_lazy * max(ncomp, 1))()
+        th = (nh_lazy * max(ncomp, 1))()
+        keep = []
+        for j, (Tq, thq) in enumerate(seeds):
+            T[j], k = lazy_of(Tq, "K")
+            keep.append(k)
+            if thq is None:
+                th[j] = lazy_const(-1.0)
+            else:
+                th[j], k = lazy_of(thq, "rad")
+                keep.append(k)
         ctx.call("nh_general_electron", PD_KIND[pd.kind], rows, N, C.addressof(emin),
                  C.addressof(emax), float(self.nEed), what,
                  C.addressof(Bl) if Bl is not None else None, T, th, ncomp, ctx.const(E_eV), nE,
                  out, ncomp * nE, ctx.general_nmax, status)
-        del k1, k2, k3, rows
+        del k1, k2, k3, rows, keep
         if not self.on_device:
             ctx.check_general()
         return ctx, N, out
@@ -624,13 +641,24 @@ class InverseCompton(BaseElectron):
         self.__dict__.update(**kwargs)
 
     def _general_supported(self):
-        """per-walker Eemin / Eemax on the device: thermal seed fields with walker-independent
-        temperature and angle (their energy density may still be per walker)"""
+        """the general path on the device: thermal seed fields only (their temperature, angle
+        and energy density may all be per walker)"""
+        return all(seed["type"] == "thermal" for seed in self.seed_photon_fields.values())
+
+    def _seed_shape_per_walker(self):
+        """a thermal seed whose temperature or angle is given per walker: its Khangulyan kernel
+        differs from walker to walker, no table can be shared (radiative.py:547-607)"""
         for seed in self.seed_photon_fields.values():
-            if seed["type"] != "thermal" or _per_walker(seed["T"]) or \
-                    (not seed["isotropic"] and _per_walker(seed["theta"])):
-                return False
-        return True
+            if seed["type"] == "thermal" and (_per_walker(seed["T"]) or (
+                    not seed["isotropic"] and _per_walker(seed["theta"]))):
+                return True
+        return False
+
+    def _general_needed(self):
+        if _per_walker(self.nEed):
+            return False
+        return self._general_limits() or (self._seed_shape_per_walker()
+                                          and self._general_supported())
 
     def _spectrum_general(self, E, E_eV):
         """radiative.py:657-710 with a particle grid per walker (nh_general_electron): the
@@ -640,8 +668,7 @@ class InverseCompton(BaseElectron):
         seeds = []
         for n in names:
             sd = self.seed_photon_fields[n]
-            seeds.append((sd["T"].to("K").value,
-                          -1.0 if sd["isotropic"] else sd["theta"].to("rad").value))
+            seeds.append((sd["T"], None if sd["isotropic"] else sd["theta"]))
         ctx, N, out = self._general_launch(1, E_eV, seeds=seeds)
         Eph = E_eV / MEC2_EV
         dev = self.on_device
@@ -654,7 +681,8 @@ class InverseCompton(BaseElectron):
             colfac = Eph / E_eV
             if dev:
                 m = DMat(ctx, [(out, out.ptr + 8 * j * nE, len(names) * nE, 1.0)], (N, nE)) * colfac
-                m = m * _as_dvec(ctx, uf, N) if _per_walker(sd["u"]) else m * float(uf)
+                m = m * _as_dvec(ctx, uf, N) if (_per_walker(sd["u"]) or _per_walker(sd["T"])) \
+                    else m * float(uf)
                 specs.append(m)
             else:
                 v = host[:, j * nE:(j + 1) * nE] * colfac
@@ -827,7 +855,7 @@ class InverseCompton(BaseElectron):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         nE = E_eV.size
-        if self._general_limits():
+        if self._general_needed():
             return self._spectrum_general(E, E_eV)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         nG = gam.size
