@@ -76,6 +76,10 @@ int nh_free(nh_ctx* ctx, void* dev);
 int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes);
 int nh_download(nh_ctx* ctx, void* host_dst, const void* dev_src, long long bytes);
 int nh_memset(nh_ctx* ctx, void* dev, int byte, long long bytes);
+/* dev[0..n) := values[0..n), n <= 8 64-bit words carried as kernel arguments: stream-ordered
+ * like nh_upload, without the staging copy an upload from pageable memory costs (the
+ * descriptors a run of the sampler re-points: where its chain history goes) */
+int nh_set_words(nh_ctx* ctx, void* dev, const long long* values /*host*/, int n);
 int nh_sync(nh_ctx* ctx);
 /* pinned host staging + markers: nh_upload from a pinned buffer is truly asynchronous, so
  * the host can prepare half-step h+1 while the device runs h; a marker recorded after the

@@ -108,6 +108,7 @@ _SIGS = {
                             _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _i, _i, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
+    "nh_set_words": [_dp, _dp, _dp, _i],
     "nh_half_step_append_blobs": [_dp, _dp, _ll],
 }
 EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")

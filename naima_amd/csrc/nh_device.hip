@@ -254,6 +254,22 @@ __global__ void k_move_accept_rows(double* __restrict__ coords, double* __restri
 
 __global__ void k_cursor_advance(int* cursor) { cursor[0] += 1; }
 
+// up to eight 64-bit words := values that travel as kernel arguments (stream-ordered; no
+// host staging buffer, unlike an upload from pageable memory)
+struct nh_words8 { long long v[8]; };
+__global__ void k_set_words(long long* dst, nh_words8 w, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = w.v[threadIdx.x];
+}
+
+extern "C" int nh_set_words(nh_ctx* c, void* dev, const long long* values, int n) {
+  NH_REQUIRE(c && dev && values && n >= 1 && n <= 8, "bad argument");
+  nh_words8 w;
+  for (int i = 0; i < 8; ++i) w.v[i] = i < n ? values[i] : 0;
+  hipLaunchKernelGGL(k_set_words, dim3(1), dim3(8), 0, c->stream, static_cast<long long*>(dev), w, n);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
 extern "C" int nh_move_accept_rows(nh_ctx* c, double* coords, double* logp, const double* blk,
                                    int* cursor, const double* rows, int width, int ns, int ndim,
                                    int* accepted, int* naccepted, int* sel, int advance,

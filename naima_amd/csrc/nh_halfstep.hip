@@ -1089,6 +1089,10 @@ extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dl
 
 // word := value, stream-ordered (the slice bookkeeping of nh_half_step_begin_block)
 __global__ void k_set_word(int* p, int v) { *p = v; }
+__global__ void k_set_word2(int* p, int v0, int v1) {
+  p[0] = v0;
+  p[1] = v1;
+}
 
 // history row `row` := the CURRENT ensemble (after the last half-step of a block of moves, at
 // the end of a run, before anybody reads the chain: no later launch would have written it)
@@ -1369,8 +1373,8 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
 extern "C" int nh_half_step_begin_block(nh_ctx* c, nh_halfstep_plan* P, int first_slice,
                                         int steps_before) {
   NH_REQUIRE(c && P && first_slice >= 0 && steps_before >= 0, "bad argument");
-  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, c->stream, P->words, first_slice * P->blocks);
-  hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, c->stream, P->words + 1, steps_before);
+  hipLaunchKernelGGL(k_set_word2, dim3(1), dim3(1), 0, c->stream, P->words,
+                     first_slice * P->blocks, steps_before);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

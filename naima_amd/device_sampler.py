@@ -16,6 +16,7 @@ pieces (grids, emission tables, data columns) are evaluated during a warm-up pas
 land in the context's caches, and are therefore not part of the graph.  After
 capture no Python model code runs inside the loop.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -110,12 +111,13 @@ class DeviceLoop:
         ctx.call("nh_memset", self.done, 0, 4)
         self._hook = None
         # nh_hist descriptor in HBM: the fused kernel appends the chain history itself
-        self.histd = ctx.empty((4,), dtype=np.int64)
+        # ... followed, in the one-launch mode, by the blobs' histories (device words holding
+        # the base of each blob's history of the current call; 0: not kept).  Eight words in
+        # one buffer: a call of sample() re-points all of them with ONE small launch
+        # (nh_set_words) instead of two staged uploads
+        self.histd = ctx.empty((8,), dtype=np.int64)
         ctx.call("nh_memset", self.histd, 0, self.histd.nbytes)
-        # ... and, in the one-launch mode, the blobs' histories (device words holding the base
-        # of each blob's history of the current call; 0: not kept)
-        self.blobhistd = ctx.empty((4,), dtype=np.int64)
-        ctx.call("nh_memset", self.blobhistd, 0, self.blobhistd.nbytes)
+        self.blobhist_ptr = self.histd.ptr + 32
         self.blobs_in_kernel = False
         self.send_width = 0
         self.cursor = ctx.empty((1,), dtype=np.int32)
@@ -340,7 +342,7 @@ class DeviceLoop:
             if self._hook.get("total") is None:
                 self._hook["total"] = ctx.empty((self.nloc,))  # persistent: the plan points at it
             if self.s.store_blobs and self.cur_blobs:
-                self._hook["blobs"] = [(cur.ptr, m, self.blobhistd.ptr + 8 * i)
+                self._hook["blobs"] = [(cur.ptr, m, self.blobhist_ptr + 8 * i)
                                        for i, (cur, m, _, _) in enumerate(self.cur_blobs)]
                 if self.sharded:
                     # the blobs travel with the log-probabilities: ONE all-gather of rows
@@ -477,10 +479,12 @@ class DeviceLoop:
         dev_hist = self.fused and block is not None and not (
             self.mega and self._plan["hs"] is None)  # (the launch's plan does not exist yet)
         if self.fused:
-            self.histd.set(np.array([block["coords"].ptr, block["logp"].ptr, 0, iterations]
-                                    if dev_hist else [0, 0, 0, 0], dtype=np.int64))
-            words = [hb.ptr for hb in block["blobs"]] if dev_hist and self.blobs_in_kernel else []
-            self.blobhistd.set(np.array((words + [0, 0, 0, 0])[:4], dtype=np.int64))
+            words = [block["coords"].ptr, block["logp"].ptr, 0, iterations] if dev_hist \
+                else [0, 0, 0, 0]
+            if dev_hist and self.blobs_in_kernel:
+                words = words + [hb.ptr for hb in block["blobs"]]
+            words = (words + [0, 0, 0, 0])[:8]
+            ctx.call("nh_set_words", self.histd, (C.c_longlong * 8)(*words), 8)
         blob_dev_hist = dev_hist and self.blobs_in_kernel  # the launches append the blobs too
         moves = s.moves(pinned=True)
         it = 0
@@ -515,14 +519,16 @@ class DeviceLoop:
                 # several steps per graph launch when nothing has to happen on the host
                 # between them (history is kept by the kernel, nobody reads the states)
                 g = 1
-                if (self.step_graph is not None and self.fused and K - k >= self.GSTEPS and
-                        yield_every >= self.GSTEPS and (block is None or dev_hist) and
+                gmax = min(self.GSTEPS, K - k) if self.mega else self.GSTEPS
+                if (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and
+                        yield_every >= gmax and (block is None or dev_hist) and
                         not (block is not None and block["blobs"] and not blob_dev_hist)):
-                    g = self.GSTEPS
+                    g = gmax
                     # one launch per half-step: the slices are baked into the graph (the
                     # proposal's chain of dependent reads is one trip shorter), so there is
-                    # one graph per starting step of the block of moves
-                    key = k if self.mega else 0
+                    # one graph per (starting step of the block of moves, number of steps):
+                    # the tail of a block shorter than GSTEPS is a graph of its own
+                    key = (k, g) if self.mega else 0
                     if key not in self.multi_graphs:
                         self.multi_graphs[key] = self.multi_graph = self._capture_steps(k, g)
                     ctx.graph_launch(self.multi_graphs[key])
@@ -553,10 +559,11 @@ class DeviceLoop:
                     block["n"] = kk + g
                 if yield_every < 2:
                     self._flush_pending()
-                if self.mega and dev_hist:
+                if self.mega and dev_hist and (k >= K or yield_every <= iterations):
                     # one launch per half-step: the row of a closed step is written by the
                     # NEXT launch of the same block of moves; nothing follows the last one of
-                    # a block, and whoever is handed this state may read the chain
+                    # a block, and whoever is handed this state may read the chain (nobody
+                    # does between the graphs of one run_mcmc call: yield_every > iterations)
                     self._flush_pending()
                     ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim, self.histd,
                              block["n"] - 1)
