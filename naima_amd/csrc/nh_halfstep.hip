@@ -78,7 +78,23 @@ struct hs_dev {
 
 // ... and its HOT part, passed by value: every pointer and size the first phases touch, so
 // that the kernel's first round trip to memory already fetches data, not descriptors.
+// The kernel's first scalar round trip: every pointer and size its second (vector) trip
+// needs, contiguous at the head of the argument block so that a few wide scalar loads and ONE
+// wait fetch it.  pkd: byte t = the proposal coordinate pack thread t reads (0xFF: a constant).
+struct hs_first {
+  const nh_pack* pk; const int* hbase; const double* logp; const nh_hist* hist;
+  int npk8, ngrids, nloc, ppk;  // ppk: the pack whose output is the particle rows
+  int nG[NH_MAX_GRIDS];
+  const double* e[NH_MAX_GRIDS]; const double* xg[NH_MAX_GRIDS];
+  const double* lne[NH_MAX_GRIDS]; const double* lx[NH_MAX_GRIDS];
+  unsigned pkd[8];
+  double* qT; double* factors;
+  const double* syn_c;  // [3][syn_nG]: 1/gamma^2 | its cube root | 1/g2^2 - 1/g1^2 (or NULL)
+  int syn_nG, pad;
+};
+
 struct hs_hot {
+  hs_first F;
   hs_dev C;
   const double* coords; const double* logp; const double* blk;
   int* done; const int* hbase; int* cursor;
@@ -108,6 +124,7 @@ struct nh_halfstep_plan {
   hs_hot hot;
   nh_pack* dev;      // device copy of the parameter packs
   int* words;        // device: done counter | hbase
+  double* syn_c;     // device: the synchrotron grid's constants (k_syn_consts), or NULL
   size_t lds_bytes;
   int threads, blocks;
   long long* dbg;
@@ -123,8 +140,8 @@ enum { HI_ME = 0, HI_PA, HI_READY, HI_CD, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
 #define HS_O_FREE 152
 #define HS_STAMP(k)                                                                    \
   do {                                                                                  \
-    if (D.dbg && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64();   \
-    if (D.dbg && tid == 0 && j < 1024) D.dbg[2304 + j * 16 + (k)] = (long long)wall_clock64(); \
+    if (dbg_on && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64();   \
+    if (dbg_on && tid == 0 && j < 1024) D.dbg[2304 + j * 16 + (k)] = (long long)wall_clock64(); \
   } while (0)
 
 __device__ __forceinline__ double hs_wave_sum(double v) {
@@ -310,11 +327,40 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
 // kernel arguments can be preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count),
 // so the chain does not begin with a trip to the kernel-argument segment.
 // slice >= 0: the slice of the block of moves this launch works on (baked into a captured
-// graph); slice < 0: derived from the plan's own launch counter.
+// graph); slice < 0: derived from the plan's own launch counter.  flags: bit 0 = debug stamps.
+//
+// The head of the kernel is TWO round trips, written so that the compiler cannot make it more
+// (the first version interleaved scalar loads of the 2.9 KB argument block, their waits and
+// vector loads as the source happened to use them: seven dependent waits, 2.3 us before the
+// first coordinate was asked for):
+//   trip 1 (scalar):  the slice's (walker, partner, z, ln U) and hs_first, the block of every
+//                     pointer and size the second trip needs -- one wait;
+//   trip 2 (vector):  the coordinates (first in the queue: loads return in order), the pack
+//                     descriptors, the grids' arrays -- all issued before anything is used.
+// (input-only: the value has to BE there, and what follows keeps using the very value that
+// was loaded -- a pointer that went through the asm as an in/out integer would come back without
+// its address space and be dereferenced with flat loads)
+typedef int hs_i16 __attribute__((ext_vector_type(16)));
+typedef int hs_i8 __attribute__((ext_vector_type(8)));
+typedef int hs_i2 __attribute__((ext_vector_type(2)));
+typedef int hs_i4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ const T __attribute__((address_space(1))) * hs_gptr(int lo, int hi) {
+  return (const T __attribute__((address_space(1)))*)(((unsigned long long)(unsigned)hi << 32) |
+                                                      (unsigned)lo);
+}
+#define HS_KERNARG_H 48
+static_assert(offsetof(hs_hot, F) == 0, "hs_first leads the argument block");
+static_assert(sizeof(hs_hot) + HS_KERNARG_H <= 0xc80, "the warm-up loads cover the argument block");
+static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
+                  offsetof(hs_first, syn_c) == 240 && offsetof(hs_first, nG) == 48 &&
+                  offsetof(hs_first, e) == 64 && offsetof(hs_first, lne) == 128 &&
+                  offsetof(hs_first, pkd) == 192, "hs_first: the layout the first trip reads");
 __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done_,
                                                     const double* __restrict__ blk_,
                                                     const double* coords_, int slice, int ns_,
-                                                    int ndim_, int lo_, const hs_hot H) {
+                                                    int ndim_, int lo_, int flags_,
+                                                    const hs_hot H) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
@@ -325,94 +371,283 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   double* lg = sm + HS_O_LG;
   double* accs = sm + HS_O_ACC;
   int* hi = reinterpret_cast<int*>(sm + HS_O_INT);
-  const bool has_syn = H.syn_grid >= 0;
+  const bool dbg_on = (flags_ & 1) != 0;
   HS_STAMP(0);
-  if (D.dbg && tid == 0 && j < 1024) D.dbg[256 + j] = (long long)wall_clock64();
+  if (dbg_on && tid == 0 && j < 1024) D.dbg[256 + j] = (long long)wall_clock64();
 
-  // ---- 0. the first round trip: everything whose address is known at launch ---------------
+  // ---- trip 1 ------------------------------------------------------------------------------
   // which slice?  `done` counts the workgroups that have finished since the current block of
   // moves was uploaded (every one adds 1 on its way out, nh_half_step_begin_block zeroes it):
   // launches completed = done / grid size, whatever this launch's own early finishers have
   // already added.  hbase = ensemble steps of the run completed before this block of moves.
   const int cn = slice >= 0 ? slice : done_[0] / (int)gridDim.x;  // the slice worked on here
   const int c = cn - 1;  // slice accepted by the previous launch
-  // ---- the proposal's chain FIRST: slice -> (me, partner, z) -> coordinates.  Issued ahead
-  // of the bulk prefetch below, whose tens of loads per thread it would otherwise queue behind
   const double* r = blk_ + (long long)cn * 3 * ns_;
   const int* idx = reinterpret_cast<const int*>(r + 2 * ns_);
-  // A thread that evaluates a pack column (tid < 8 npacks) needs ONE proposed coordinate: it
-  // fetches that pair of coordinates itself, and its column's descriptor in the same trip as
-  // the slice -- no barrier and no LDS hop between the proposal and the packs.
-  const int npk8 = NH_MAX_PACK * NH_MAX_LAZY;
-  int me = 0, pa = 0;
-  double mz = 1.0, mlnu = 0.0;
-  nh_lazy pkz = {nullptr, 0, 0.0, 0.0, 0.0, 0, 0};
-  int pk_nc = 0, pk_ld = 0;  // this thread's pack: its shape and output, in the same trip
-  double* pk_out = nullptr;
-  if (tid < max(ndim_, npk8)) {
-    const int g = lo_ + j;
-    me = idx[g];
-    pa = idx[ns_ + g];
-    mz = r[g];
-    if (tid == 0) mlnu = r[ns_ + g];
-    if (tid < npk8 && tid < D.npk * NH_MAX_LAZY) {
-      const nh_pack& P = D.pk[tid / NH_MAX_LAZY];
-      pkz = P.cols[tid % NH_MAX_LAZY];
-      pk_nc = P.ncols;
-      pk_ld = P.ld;
-      pk_out = P.out;
-    }
+  // ONE batch of scalar loads and ONE wait, spelled out: left to itself the compiler fetches
+  // each field of the argument block where it is first used, with a wait each time.
+  int me, pa;
+  double mz, mlnu;
+  hs_i16 fa, fb, fc, fd;
+  {
+    const int g = lo_ + j;  // (wave-uniform addresses)
+    hs_i2 zb, ub;
+    // hs_first sits at the head of H, H after the eight scalar arguments (44 bytes, aligned to
+    // 8).  Not &H.F: taking the address of a by-value argument makes the compiler copy all of
+    // it to scratch first.
+    const char* kbase = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const char* kfirst = kbase + HS_KERNARG_H;
+    int w0, w1, w2, w3;  // (nobody reads these)
+    asm volatile(
+        "s_load_dword %[me], %[pme], 0x0\n\t"
+        "s_load_dword %[pa], %[ppa], 0x0\n\t"
+        "s_load_dwordx2 %[zb], %[pz], 0x0\n\t"
+        "s_load_dwordx2 %[ub], %[pu], 0x0\n\t"
+        "s_load_dwordx16 %[fa], %[kf], 0x0\n\t"
+        "s_load_dwordx16 %[fb], %[kf], 0x40\n\t"
+        "s_load_dwordx16 %[fc], %[kf], 0x80\n\t"
+        "s_load_dwordx16 %[fd], %[kf], 0xc0\n\t"
+        // ... and one word of every other 64-byte line of the argument block (2.9 KB): the
+        // scalar cache starts every launch cold, and the fields the later phases read -- each
+        // where it is first needed, each with a wait -- would cost a miss per line and wave
+        "s_load_dword %[w0], %[ka], 0x140\n\t"
+        "s_load_dword %[w1], %[ka], 0x180\n\t"
+        "s_load_dword %[w2], %[ka], 0x1c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x200\n\t"
+        "s_load_dword %[w0], %[ka], 0x240\n\t"
+        "s_load_dword %[w1], %[ka], 0x280\n\t"
+        "s_load_dword %[w2], %[ka], 0x2c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x300\n\t"
+        "s_load_dword %[w0], %[ka], 0x340\n\t"
+        "s_load_dword %[w1], %[ka], 0x380\n\t"
+        "s_load_dword %[w2], %[ka], 0x3c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x400\n\t"
+        "s_load_dword %[w0], %[ka], 0x440\n\t"
+        "s_load_dword %[w1], %[ka], 0x480\n\t"
+        "s_load_dword %[w2], %[ka], 0x4c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x500\n\t"
+        "s_load_dword %[w0], %[ka], 0x540\n\t"
+        "s_load_dword %[w1], %[ka], 0x580\n\t"
+        "s_load_dword %[w2], %[ka], 0x5c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x600\n\t"
+        "s_load_dword %[w0], %[ka], 0x640\n\t"
+        "s_load_dword %[w1], %[ka], 0x680\n\t"
+        "s_load_dword %[w2], %[ka], 0x6c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x700\n\t"
+        "s_load_dword %[w0], %[ka], 0x740\n\t"
+        "s_load_dword %[w1], %[ka], 0x780\n\t"
+        "s_load_dword %[w2], %[ka], 0x7c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x800\n\t"
+        "s_load_dword %[w0], %[ka], 0x840\n\t"
+        "s_load_dword %[w1], %[ka], 0x880\n\t"
+        "s_load_dword %[w2], %[ka], 0x8c0\n\t"
+        "s_load_dword %[w3], %[ka], 0x900\n\t"
+        "s_load_dword %[w0], %[ka], 0x940\n\t"
+        "s_load_dword %[w1], %[ka], 0x980\n\t"
+        "s_load_dword %[w2], %[ka], 0x9c0\n\t"
+        "s_load_dword %[w3], %[ka], 0xa00\n\t"
+        "s_load_dword %[w0], %[ka], 0xa40\n\t"
+        "s_load_dword %[w1], %[ka], 0xa80\n\t"
+        "s_load_dword %[w2], %[ka], 0xac0\n\t"
+        "s_load_dword %[w3], %[ka], 0xb00\n\t"
+        "s_load_dword %[w0], %[ka], 0xb40\n\t"
+        "s_load_dword %[w1], %[ka], 0xb80\n\t"
+        "s_load_dword %[w2], %[ka], 0xbc0\n\t"
+        "s_load_dword %[w3], %[ka], 0xc00\n\t"
+        "s_load_dword %[w0], %[ka], 0xc40\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [me] "=&s"(me), [pa] "=&s"(pa), [zb] "=&s"(zb), [ub] "=&s"(ub), [fa] "=&s"(fa),
+          [fb] "=&s"(fb), [fc] "=&s"(fc), [fd] "=&s"(fd), [w0] "=&s"(w0),
+          [w1] "=&s"(w1), [w2] "=&s"(w2), [w3] "=&s"(w3)
+        : [pme] "s"(idx + g), [ppa] "s"(idx + ns_ + g), [pz] "s"(r + g), [pu] "s"(r + ns_ + g),
+          [kf] "s"(kfirst), [ka] "s"(kbase));
+    mz = __hiloint2double(zb.y, zb.x);
+    mlnu = __hiloint2double(ub.y, ub.x);
   }
-  const int stepbase = H.hbase[0];
-  // (the grids' logarithms ln e and lx come with the grid: nh_half_step_create insists)
+  struct {
+    const nh_pack __attribute__((address_space(1))) * pk;
+    const int __attribute__((address_space(1))) * hbase;
+    const double __attribute__((address_space(1))) * logp;
+    const nh_hist __attribute__((address_space(1))) * hist;
+    int npk8, ngrids, nloc, ppk;
+    double __attribute__((address_space(1))) * qT;
+    double __attribute__((address_space(1))) * factors;
+    const double __attribute__((address_space(1))) * syn_c;
+    int syn_nG;
+    int nG[NH_MAX_GRIDS];
+    const double __attribute__((address_space(1))) * e[NH_MAX_GRIDS];
+    const double __attribute__((address_space(1))) * xg[NH_MAX_GRIDS];
+    const double __attribute__((address_space(1))) * lne[NH_MAX_GRIDS];
+    const double __attribute__((address_space(1))) * lx[NH_MAX_GRIDS];
+    unsigned pkd[8];
+  } F;
+  F.pk = hs_gptr<nh_pack>(fa[0], fa[1]);
+  F.hbase = hs_gptr<int>(fa[2], fa[3]);
+  F.logp = hs_gptr<double>(fa[4], fa[5]);
+  F.hist = hs_gptr<nh_hist>(fa[6], fa[7]);
+  F.npk8 = fa[8]; F.ngrids = fa[9]; F.nloc = fa[10]; F.ppk = fa[11];
+  F.qT = (double __attribute__((address_space(1)))*)hs_gptr<double>(fd[8], fd[9]);
+  F.factors = (double __attribute__((address_space(1)))*)hs_gptr<double>(fd[10], fd[11]);
+  F.syn_c = hs_gptr<double>(fd[12], fd[13]);
+  F.syn_nG = fd[14];
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
+    F.nG[g] = fa[12 + g];
+    F.e[g] = hs_gptr<double>(fb[2 * g], fb[2 * g + 1]);
+    F.xg[g] = hs_gptr<double>(fb[8 + 2 * g], fb[9 + 2 * g]);
+    F.lne[g] = hs_gptr<double>(fc[2 * g], fc[2 * g + 1]);
+    F.lx[g] = hs_gptr<double>(fc[8 + 2 * g], fc[9 + 2 * g]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) F.pkd[q] = (unsigned)fd[q];
+  HS_STAMP(1);
+  // ---- trip 2: everything is asked for before anything is used ------------------------------
+  // the proposal's coordinates first
+  // (no initial values: a merge of "0" and "what the load brings" at the end of each of these
+  // conditionals would be a register copy -- and the wait for the load right here)
+  double pcj, psj, pold, kcj, ksj;
+  if (tid < ndim_) {
+    pcj = coords_[(long long)pa * ndim_ + tid];
+    psj = coords_[(long long)me * ndim_ + tid];
+    if (tid == 0) pold = F.logp[me];
+  }
+  // A thread that evaluates a pack column (tid < 8 npacks) needs ONE proposed coordinate (which
+  // one is walker-independent: a byte of F.pkd): it fetches that pair of coordinates itself,
+  // and its column's descriptor in the same trip -- no barrier and no LDS hop between the
+  // proposal and the packs.
+  nh_lazy pkz;
+  int pk_nc, pk_ld, pkd = -1;
+  double* pk_out;
+  if (tid < F.npk8) {
+    unsigned word = F.pkd[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) word = (tid >> 2) == q ? F.pkd[q] : word;
+    const int b = (int)((word >> (8 * (tid & 3))) & 0xFFu);
+    if (b != 0xFF) {
+      pkd = b;
+      kcj = coords_[(long long)pa * ndim_ + pkd];
+      ksj = coords_[(long long)me * ndim_ + pkd];
+    }
+    typedef const long long __attribute__((address_space(1))) * gw_t;
+    static_assert(sizeof(nh_lazy) == 48 && offsetof(nh_pack, ncols) == 384 &&
+                      offsetof(nh_pack, out) == 392, "nh_pack layout");
+    const gw_t P = (gw_t)(F.pk + tid / NH_MAX_LAZY);
+    const gw_t w = P + (tid % NH_MAX_LAZY) * 6;  // this thread's column (an nh_lazy)
+    pkz.base = (const double*)w[0];  // (never dereferenced: pkd says which coordinate)
+    pkz.stride = w[1];
+    pkz.a = __longlong_as_double(w[2]);
+    pkz.b = __longlong_as_double(w[3]);
+    pkz.c = __longlong_as_double(w[4]);
+    pkz.tf = (int)w[5];
+    pkz.pad = 0;
+    const long long shape = P[48];  // ncols | ld
+    pk_nc = (int)shape;
+    pk_ld = (int)(shape >> 32);
+    pk_out = (double*)P[49];
+  }
+  // the grids' own arrays: this thread's node of every grid (clamped neighbour indices:
+  // nothing is selected before all loads are out)
   double nE_[NH_MAX_GRIDS], nE2_[NH_MAX_GRIDS], ngx_[NH_MAX_GRIDS], nlr_[NH_MAX_GRIDS],
       nln_[NH_MAX_GRIDS];
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
     nE_[g] = nE2_[g] = ngx_[g] = 1.0;
     nlr_[g] = nln_[g] = 0.0;
-    if (g < H.ngrids && tid < H.nG[g]) {
-      const int nG = H.nG[g], i = tid;
-      const bool last = i + 1 >= nG;
-      nE_[g] = H.e[g][i];
-      nE2_[g] = last ? nE_[g] : H.e[g][i + 1];
-      ngx_[g] = H.xg[g][i];
-      if (!last) nlr_[g] = H.lx[g][i];
-      nln_[g] = H.lne[g][i];
+    if (g < F.ngrids && tid < F.nG[g]) {  // (waves past the end of a grid issue nothing: the
+                                            // loads of this trip are bound by the L1's 64 B/clk)
+      const int nG = F.nG[g];
+      const int i0 = tid, i1 = min(tid + 1, nG - 1), il = min(tid, nG - 2);
+      nE_[g] = F.e[g][i0];
+      nE2_[g] = F.e[g][i1];
+      ngx_[g] = F.xg[g][i0];
+      nlr_[g] = F.lx[g][il];
+      nln_[g] = F.lne[g][i0];
     }
   }
+  // the synchrotron grid's walker-independent constants (made once, nh_half_step_create)
+  double sc0 = 0.0, sc1 = 0.0, sc2 = 0.0;
+  if (tid < F.syn_nG) {
+    sc0 = F.syn_c[tid];
+    sc1 = F.syn_c[F.syn_nG + tid];
+    sc2 = F.syn_c[2 * F.syn_nG + tid];
+  }
+  const bool has_syn = H.syn_grid >= 0;
+  // what the waves off the proposal's chain park in LDS (below): asked for in this same trip
+  const bool fill_wave = wv >= 1 || nwv == 1;
+  const int t0 = nwv == 1 ? tid : tid - 64, TT = nwv == 1 ? T : T - 64;
+  const int npri = (int)(sizeof(nh_prior_pack) / sizeof(double));
+  const double* psrc = reinterpret_cast<const double*>(&D.pri);
+  const int kl = TT - 1 - t0;  // (the likelihood columns from the back)
+  double vsc[HS_MAX_TAB], vpri, vse, vl[4];
+  int vul;
+  if (fill_wave) {
+    if (t0 < npri) vpri = psrc[t0];
+    if (has_syn && t0 < H.syn_nE) vse = H.syn_E[t0];
+#pragma unroll
+    for (int t = 0; t < HS_MAX_TAB; ++t)
+      if (t < H.ntab && t0 < H.tnK[t]) vsc[t] = H.tscale[t] ? H.tscale[t][t0] : 1.0;
+    if (kl < H.nE) {
+      vl[0] = H.conv[kl];
+      vl[1] = H.flux[kl];
+      vl[2] = H.elo[kl];
+      vl[3] = H.ehi[kl];
+      vul = H.ul[kl];
+    }
+  }
+  // history of the step the previous launch closed: its descriptor (the last wave writes it)
+  const bool want_hist = F.hist != nullptr && c >= 1 && (c & 1);
+  const bool hist_wave = wv == nwv - 1;
+  double* hcoords = nullptr;
+  double* hlogp = nullptr;
+  long long hcap = 0;
+  int stepbase = 0;
+  if (want_hist && hist_wave) {
+    hcoords = F.hist->coords;
+    hlogp = F.hist->logp;
+    hcap = F.hist->cap;
+    stepbase = F.hbase[0];
+  }
   const bool lik_wave = wv == (nwv > 1 ? 1 : 0);
-  // ... its third trip as soon as the second is back (the prefetch is still in flight)
-  double pcj = 0.0, psj = 0.0, pold = 0.0, kcj = 0.0, ksj = 0.0;
-  if (tid < ndim_) {
-    pcj = coords_[(long long)pa * ndim_ + tid];
-    psj = coords_[(long long)me * ndim_ + tid];
-    if (tid == 0) pold = H.logp[me];
-  }
-  int pkd = -1;  // the proposal coordinate this thread's pack column reads
-  if (tid < npk8 && pkz.base) {
-    pkd = (int)((pkz.base - H.qT) / H.nloc);
-    kcj = coords_[(long long)pa * ndim_ + pkd];
-    ksj = coords_[(long long)me * ndim_ + pkd];
-  }
   if (tid == 0) {
     hi[HI_CNT] = 0;
     hi[HI_LIVE] = 0;
     hi[HI_READY] = 0;
     hi[HI_NZ] = 0;
-    if (j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
   }
-  // history of the step the previous launch closed: descriptor now, rows below
-  const bool want_hist = H.hist != nullptr && c >= 1 && (c & 1);
-  double* hcoords = nullptr;
-  double* hlogp = nullptr;
-  long long hcap = 0;
-  if (want_hist) {
-    hcoords = H.hist->coords;
-    hlogp = H.hist->logp;
-    hcap = H.hist->cap;
+  // ---- 1. proposal + 2. parameter packs (the first consumers of trip 2) -----------------------
+  if (tid < ndim_) {
+    const double q = pcj - (pcj - psj) * mz;
+    F.qT[(long long)tid * F.nloc + j] = q;
+    qs[tid] = q;
+    if (tid == 0) {
+      F.factors[j] = (ndim_ - 1.0) * log(mz);
+      accs[0] = mz;
+      accs[1] = mlnu;
+      accs[2] = pold;
+      hi[HI_ME] = me;
+      hi[HI_PA] = pa;
+    }
   }
-  HS_STAMP(1);
+  HS_STAMP(2);
+  if (tid < F.npk8) {
+    const int col = tid % NH_MAX_LAZY;
+    if (col < pk_nc) {
+      double v = pkz.a;
+      if (pkd >= 0) v = nh_lazy_apply(pkz, kcj - (kcj - ksj) * mz);  // (the same q as qs[pkd])
+      int ld = pk_ld;
+      asm volatile("" : "+v"(ld));  // (its sign extension would be hoisted to the load: a wait)
+      pk_out[(long long)j * ld + col] = v;
+      if (tid / NH_MAX_LAZY == F.ppk) {  // the particle rows: also into LDS
+        row[col] = v;
+        if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
+      }
+    }
+  }
+  // (the `last` node of a grid has no segment to its right)
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g)
+    if (g < F.ngrids && tid + 1 >= F.nG[g]) nlr_[g] = 0.0;
+  if (dbg_on && j == 0 && lane == 0) D.dbg[224 + wv] = (long long)wall_clock64();
   // ---- grids' own arrays -> LDS ------------------------------------------------------------
   if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
 #pragma unroll
@@ -423,34 +658,35 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     const int nG = H.nG[g];
     for (int i = tid + T; i < nG - 1; i += T) sm[H.o_lx[g] + i] = H.lx[g][i];
   }
-  // the single-row tables (We, Wp), the likelihood's data columns: loaded and parked in LDS
-  // by the waves that are NOT on the proposal's chain (a load-then-store loop waits a whole
-  // round trip; they have until the first barrier)
-  if (wv >= 1 || nwv == 1) {
-    const int t0 = nwv == 1 ? tid : tid - 64, TT = nwv == 1 ? T : T - 64;
-    int ko = H.o_mkt;
-    for (int m = 0; m < H.nmom; ++m) {
-      const int nG = H.nG[H.mgrid[m]];
-      for (int i = t0; i < nG; i += TT) {
-        sm[ko + i] = H.mKt[m][i];
-        sm[ko + nG + i] = H.mdK[m][i];
+  // the single-row tables (We, Wp), the likelihood's data columns, the prior terms ...: loaded
+  // and parked in LDS by the waves that are NOT on the proposal's chain.  Every load of a
+  // thread's first element of each array is issued before the first store (written as
+  // load-then-store loops, one after the other, this cost the waves five round trips in a row
+  // and the workgroup's first barrier waited for them 2.4 us after the proposal was ready).
+  if (fill_wave) {
+    // ---- ... and now the stores
+    if (t0 < npri) sm[H.o_pri + t0] = vpri;
+    for (int t = t0 + TT; t < npri; t += TT) sm[H.o_pri + t] = psrc[t];
+    if (has_syn) {
+      if (t0 < H.syn_nE) sm[H.o_synE + t0] = vse;
+      for (int k = t0 + TT; k < H.syn_nE; k += TT) sm[H.o_synE + k] = H.syn_E[k];
+    }
+#pragma unroll
+    for (int t = 0; t < HS_MAX_TAB; ++t)  // per-column factors of the reductions
+      if (t < H.ntab) {
+        if (t0 < H.tnK[t]) sm[H.o_scale + H.tspec[t] + t0] = vsc[t];
+        for (int k = t0 + TT; k < H.tnK[t]; k += TT)
+          sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
       }
-      ko += 2 * nG;
-    }
-    {  // the prior terms: read one after the other out of the (cold) kernel-argument segment by
-       // the one lane that sums them they cost a 1.5 us round trip EACH (measured: the
-       // likelihood wave reached the next barrier 3 us after everybody else)
-      const double* src = reinterpret_cast<const double*>(&D.pri);
-      for (int t = t0; t < (int)(sizeof(nh_prior_pack) / sizeof(double)); t += TT)
-        sm[H.o_pri + t] = src[t];
-    }
-    if (has_syn)  // (first touched by the liveness search: a cold trip on the critical path)
-      for (int k = t0; k < H.syn_nE; k += TT) sm[H.o_synE + k] = H.syn_E[k];
-    for (int t = 0; t < H.ntab; ++t)  // per-column factors of the reductions
-      for (int k = t0; k < H.tnK[t]; k += TT)
-        sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
     double* lik = sm + H.o_lik;  // conv | flux | elo | ehi | ul, nE each
-    for (int k = TT - 1 - t0; k < H.nE; k += TT) {
+    if (kl < H.nE) {
+      lik[kl] = vl[0];
+      lik[H.nE + kl] = vl[1];
+      lik[2 * H.nE + kl] = vl[2];
+      lik[3 * H.nE + kl] = vl[3];
+      lik[4 * H.nE + kl] = (double)vul;
+    }
+    for (int k = kl + TT; k < H.nE; k += TT) {
       lik[k] = H.conv[k];
       lik[H.nE + k] = H.flux[k];
       lik[2 * H.nE + k] = H.elo[k];
@@ -458,33 +694,20 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       lik[4 * H.nE + k] = (double)H.ul[k];
     }
   }
-  if (has_syn) {
-    const int g = H.syn_grid, nG = H.nG[g];
-    const double* gam = H.xg[g];
-    const double* lxg = H.lx[g];
-    for (int i = tid; i < nG; i += T) {
-      double gi = 1.0, lr = 0.0;
-      if (i < T) {  // this thread's own node of the synchrotron grid is in registers
-#pragma unroll
-        for (int q = 0; q < NH_MAX_GRIDS; ++q)
-          if (q == g) {
-            gi = ngx_[q];
-            lr = nlr_[q];
-          }
-      } else {
-        gi = gam[i];
-        lr = i + 1 < nG ? lxg[i] : 0.0;
-      }
-      const double v = 1.0 / (gi * gi);
-      sm[H.o_ig2 + i] = v;
-      sm[H.o_ig23 + i] = cbrt(v);
-      // 1/g2^2 - 1/g1^2 = (1/g1^2) (exp(-2 ln(g2/g1)) - 1), without cancellation
-      sm[H.o_dig2 + i] = i + 1 < nG ? v * expm1(-2.0 * lr) : 0.0;
-    }
+  if (tid < F.syn_nG) {
+    sm[H.o_ig2 + tid] = sc0;
+    sm[H.o_ig23 + tid] = sc1;
+    sm[H.o_dig2 + tid] = sc2;
+  }
+  for (int i = tid + T; i < F.syn_nG; i += T) {  // a grid longer than the workgroup
+    sm[H.o_ig2 + i] = F.syn_c[i];
+    sm[H.o_ig23 + i] = F.syn_c[F.syn_nG + i];
+    sm[H.o_dig2 + i] = F.syn_c[2 * F.syn_nG + i];
   }
   // ---- chain history rows (the step closed by the previous launch; hist->n is not used:
-  // the row is the number of closed steps of this run - 1, what nh_hist_append is told too)
-  if (want_hist) {
+  // the row is the number of closed steps of this run - 1, what nh_hist_append is told too).
+  // One wave's work, and not one of the proposal's chain.
+  if (want_hist && hist_wave) {
     const long long rowh = (long long)stepbase + (cn >> 1) - 1;
     if (hcoords && rowh >= 0 && rowh < hcap) {
       const long long N = 2LL * H.ns;
@@ -498,49 +721,37 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       for (int jj = j; jj < H.ns; jj += gridDim.x) {
         for (int h = 0; h < 2; ++h) {
           const int wr = h == 0 ? idx[jj] : idx2[jj];
-          for (int t = tid; t < H.ndim; t += T)
+          for (int t = lane; t < H.ndim; t += 64)
             hc[(long long)wr * H.ndim + t] = H.coords[(long long)wr * H.ndim + t];
-          if (tid == 0) hl[wr] = H.logp[wr];
+          if (lane == 0) hl[wr] = H.logp[wr];
           for (int b = 0; b < D.nblob; ++b) {  // the blobs that belong to these positions
             const nh_hs_blob& bl = D.blob[b];
             double* hb = bl.hist ? *bl.hist : nullptr;
             if (hb)
-              for (int t = tid; t < bl.m; t += T)
+              for (int t = lane; t < bl.m; t += 64)
                 hb[(rowh * N + wr) * bl.m + t] = bl.cur[(long long)wr * bl.m + t];
           }
         }
       }
     }
   }
-  // ---- 1. proposal + 2. parameter packs --------------------------------------------------
-  if (tid < H.ndim) {
-    const double q = pcj - (pcj - psj) * mz;
-    H.qT[(long long)tid * H.nloc + j] = q;
-    qs[tid] = q;
-    if (tid == 0) {
-      H.factors[j] = (H.ndim - 1.0) * log(mz);
-      accs[0] = mz;
-      accs[1] = mlnu;
-      accs[2] = pold;
-      hi[HI_ME] = me;
-      hi[HI_PA] = pa;
-    }
-  }
-  HS_STAMP(2);
-  if (tid < D.npk * NH_MAX_LAZY) {
-    const int col = tid % NH_MAX_LAZY;
-    if (col < pk_nc) {
-      double v = pkz.a;
-      if (pkd >= 0) v = nh_lazy_apply(pkz, kcj - (kcj - ksj) * mz);  // (the same q as qs[pkd])
-      pk_out[(long long)j * pk_ld + col] = v;
-      if (pk_out == D.params) {
-        row[col] = v;
-        if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
-      }
-    }
-  }
+  if (dbg_on && j == 0 && lane == 0) D.dbg[208 + wv] = (long long)wall_clock64();
   __syncthreads();
   HS_STAMP(3);
+  if (tid == 0 && j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
+  // the single-row tables (We, Wp) -> LDS, by the threads at the BACK of the workgroup: they
+  // have no node of any grid to evaluate below, and nobody reads these before the next barrier
+  {
+    int ko = H.o_mkt;
+    for (int m = 0; m < H.nmom; ++m) {
+      const int nG = H.nG[H.mgrid[m]];
+      for (int i = T - 1 - tid; i < nG; i += T) {
+        sm[ko + i] = H.mKt[m][i];
+        sm[ko + nG + i] = H.mdK[m][i];
+      }
+      ko += 2 * nG;
+    }
+  }
   // ---- the priors (core.py:34-58, 99-101), now: a proposal the prior forbids is never accepted
   // whatever its likelihood, so none of its integrals is evaluated (the reference evaluates
   // the model and throws it away, core.py:103-119).  Besides the time saved on such walkers
@@ -681,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
     if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
   }
-  if (D.dbg && j == 0 && lane == 0) D.dbg[192 + wv] = (long long)wall_clock64();
+  if (dbg_on && j == 0 && lane == 0) D.dbg[192 + wv] = (long long)wall_clock64();
   __syncthreads();
   HS_STAMP(4);
   const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
@@ -763,7 +974,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     double* part_t = sm + H.o_part_t;
     double* part_s = sm + H.o_part_s;
     int dbg_nt = 0, dbg_ns = 0;
-    if (D.dbg && j == 0 && lane == 0) D.dbg[176 + wv] = (long long)wall_clock64();
+    if (dbg_on && j == 0 && lane == 0) D.dbg[176 + wv] = (long long)wall_clock64();
     for (;;) {
       int it = 0;
       if (lane == 0) it = atomicAdd(&hi[HI_CNT], 1);
@@ -880,12 +1091,12 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         }
       }
     }
-    if (D.dbg && j == 0 && lane == 0) {
+    if (dbg_on && j == 0 && lane == 0) {
       D.dbg[128 + wv] = (long long)wall_clock64();
       D.dbg[144 + wv] = dbg_nt;
       D.dbg[160 + wv] = dbg_ns;
     }
-    if (D.dbg && j < 1024 && lane == 0) {
+    if (dbg_on && j < 1024 && lane == 0) {
       D.dbg[18688 + (j * 16 + wv) * 3] = (long long)wall_clock64();
       D.dbg[18688 + (j * 16 + wv) * 3 + 1] = dbg_nt;
       D.dbg[18688 + (j * 16 + wv) * 3 + 2] = dbg_ns | (nA << 8) | (Cd << 20);
@@ -1025,7 +1236,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
     // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
     if (lane == 0) atomicAdd(H.done, 1);
-    if (D.dbg && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
+    if (dbg_on && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
   }
   HS_STAMP(9);
 }
@@ -1085,6 +1296,21 @@ extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dl
                      Kt, dlnKt, nG, nK, KD);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
+}
+
+// the synchrotron grid's constants: 1/gamma^2, its cube root (x^(1/3) = q^(1/3) ig23), and
+// 1/g2^2 - 1/g1^2 = (1/g1^2) (exp(-2 ln(g2/g1)) - 1) without cancellation -- the same for every
+// walker and every launch: computed once per plan (the kernel used to spend 1.3 us of every
+// launch on them, all SIMDs busy, before its first barrier)
+__global__ void k_syn_consts(const double* __restrict__ gam, const double* __restrict__ lx, int nG,
+                             double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nG) return;
+  const double gi = gam[i];
+  const double v = 1.0 / (gi * gi);
+  out[i] = v;
+  out[nG + i] = cbrt(v);
+  out[2 * nG + i] = i + 1 < nG ? v * expm1(-2.0 * lx[i]) : 0.0;
 }
 
 // word := value, stream-ordered (the slice bookkeeping of nh_half_step_begin_block)
@@ -1163,6 +1389,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     packs_host[q] = pk;
   }
   NH_REQUIRE(have_params, "params must be the output of one of the packs");
+  NH_REQUIRE(d->ndim < 255, "at most 254 fit parameters");
   H.ngrids = d->ngrids;
   int off = HS_O_FREE;
   for (int g = 0; g < d->ngrids; ++g) {
@@ -1344,7 +1571,17 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   P->blocks = d->nloc;
   P->dev = nullptr;
   P->words = nullptr;
+  P->syn_c = nullptr;
   hipError_t e = hipMalloc(&P->dev, sizeof(packs_host));
+  if (e == hipSuccess && H.syn_grid >= 0) {
+    const int nGs = H.nG[H.syn_grid];
+    e = hipMalloc(&P->syn_c, 3 * (size_t)nGs * sizeof(double));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_syn_consts, dim3((unsigned)((nGs + 255) / 256)), dim3(256), 0, c->stream,
+                         H.xg[H.syn_grid], H.lx[H.syn_grid], nGs, P->syn_c);
+      e = hipGetLastError();
+    }
+  }
   if (e == hipSuccess) e = hipMalloc(&P->words, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(P->words, 0, 2 * sizeof(int));
@@ -1354,6 +1591,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   if (e != hipSuccess) {
     if (P->dev) (void)hipFree(P->dev);
     if (P->words) (void)hipFree(P->words);
+    if (P->syn_c) (void)hipFree(P->syn_c);
     if (P->dbg) (void)hipFree(P->dbg);
     delete P;
     return nh_set_error(NH_EHIP, "half-step plan: %s", hipGetErrorString(e));
@@ -1361,6 +1599,30 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   H.C.pk = P->dev;
   H.done = P->words;
   H.hbase = P->words + 1;
+  {  // the first scalar trip's block (hs_first)
+    hs_first& F = H.F;
+    memset(&F, 0, sizeof(F));
+    F.pk = P->dev; F.hbase = H.hbase; F.logp = H.logp; F.hist = H.hist;
+    F.npk8 = d->npacks * NH_MAX_LAZY; F.ngrids = H.ngrids; F.nloc = H.nloc;
+    F.qT = H.qT; F.factors = H.factors;
+    F.syn_c = P->syn_c; F.syn_nG = H.syn_grid >= 0 ? H.nG[H.syn_grid] : 0;
+    F.ppk = -1;
+    for (int q = 0; q < d->npacks; ++q)
+      if (packs_host[q].out == d->params) F.ppk = q;
+    for (int g = 0; g < H.ngrids; ++g) {
+      F.nG[g] = H.nG[g];
+      F.e[g] = H.e[g]; F.xg[g] = H.xg[g]; F.lne[g] = H.lne[g]; F.lx[g] = H.lx[g];
+    }
+    for (int t = 0; t < 32; ++t) {
+      unsigned b = 0xFFu;
+      const int q = t / NH_MAX_LAZY, col = t % NH_MAX_LAZY;
+      if (q < d->npacks && col < packs_host[q].ncols && packs_host[q].cols[col].base) {
+        const long long off = packs_host[q].cols[col].base - H.qT;
+        b = (unsigned)(off / H.nloc);  // (a proposal coordinate: checked above)
+      }
+      F.pkd[t >> 2] |= b << (8 * (t & 3));
+    }
+  }
   P->hot = H;
   *out = P;
   return NH_OK;
@@ -1384,7 +1646,8 @@ extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   nh_prof_scope ps(c, NH_K_HALFSTEP);
   const hs_hot& H = P->hot;
   hipLaunchKernelGGL(k_half_step, dim3((unsigned)P->blocks), dim3(P->threads), P->lds_bytes,
-                     c->stream, (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo, H);
+                     c->stream, (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
+                     P->dbg ? 1 : 0, H);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -1416,6 +1679,7 @@ extern "C" int nh_half_step_destroy(nh_ctx* c, nh_halfstep_plan* P) {
   if (!P) return NH_OK;
   int rc = nh_sync(c);
   if (P->dev) (void)hipFree(P->dev);
+  if (P->syn_c) (void)hipFree(P->syn_c);
   if (P->words) (void)hipFree(P->words);
   if (P->dbg) (void)hipFree(P->dbg);
   delete P;

@@ -42,6 +42,8 @@ for w in range(hs["threads"] // 64):
     print("  wave %2d: %.2f -> %.2f  tab %d syn %d" % (w, (last[176 + w] - t0) / 100.0, (last[128 + w] - t0) / 100.0, last[144 + w], last[160 + w]))
 print("block 0: each wave's arrival at the barrier that ends the weights phase (us):",
       [round((last[192 + w] - t0) / 100.0, 2) for w in range(hs["threads"] // 64)])
+print("block 0: each wave before its LDS fills / at the FIRST barrier (us):",
+      [(round((last[224 + w] - t0) / 100.0, 2), round((last[208 + w] - t0) / 100.0, 2)) for w in range(hs["threads"] // 64)])
 nb = hs["blocks"]
 st_, en_ = last[256:256 + nb].astype(float), last[1280:1280 + nb].astype(float)
 dur = (en_ - st_) / 100.0
