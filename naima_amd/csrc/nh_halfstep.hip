@@ -90,7 +90,8 @@ struct hs_first {
   unsigned pkd[8];
   double* qT; double* factors;
   const double* syn_c;  // [3][syn_nG]: 1/gamma^2 | its cube root | 1/g2^2 - 1/g1^2 (or NULL)
-  int syn_nG, pad;
+  int syn_nG;
+  int broken;  // the particle distribution has a break energy (the only use of the grids' E)
 };
 
 struct hs_hot {
@@ -397,19 +398,14 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     // it to scratch first.
     const char* kbase = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
     const char* kfirst = kbase + HS_KERNARG_H;
-    int w0, w1, w2, w3;  // (nobody reads these)
-    asm volatile(
-        "s_load_dword %[me], %[pme], 0x0\n\t"
-        "s_load_dword %[pa], %[ppa], 0x0\n\t"
-        "s_load_dwordx2 %[zb], %[pz], 0x0\n\t"
-        "s_load_dwordx2 %[ub], %[pu], 0x0\n\t"
-        "s_load_dwordx16 %[fa], %[kf], 0x0\n\t"
-        "s_load_dwordx16 %[fb], %[kf], 0x40\n\t"
-        "s_load_dwordx16 %[fc], %[kf], 0x80\n\t"
-        "s_load_dwordx16 %[fd], %[kf], 0xc0\n\t"
-        // ... and one word of every other 64-byte line of the argument block (2.9 KB): the
-        // scalar cache starts every launch cold, and the fields the later phases read -- each
-        // where it is first needed, each with a wait -- would cost a miss per line and wave
+    // One word of every other 64-byte line of the argument block (2.9 KB), by ONE wave of the
+    // workgroup: the scalar cache starts every launch cold, and the fields the later phases
+    // read -- each where it is first needed, each with a wait -- would cost a miss per line
+    // and wave.  (The loads land in registers nobody reads; the wait of the batch below
+    // covers them.)
+    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (wv == nwv - 1) {
+      asm volatile(
         "s_load_dword %[w0], %[ka], 0x140\n\t"
         "s_load_dword %[w1], %[ka], 0x180\n\t"
         "s_load_dword %[w2], %[ka], 0x1c0\n\t"
@@ -455,12 +451,26 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         "s_load_dword %[w2], %[ka], 0xbc0\n\t"
         "s_load_dword %[w3], %[ka], 0xc00\n\t"
         "s_load_dword %[w0], %[ka], 0xc40\n\t"
+          : [w0] "+s"(w0), [w1] "+s"(w1), [w2] "+s"(w2), [w3] "+s"(w3)
+          : [ka] "s"(kbase));
+    }
+    asm volatile(
+        "s_load_dword %[me], %[pme], 0x0\n\t"
+        "s_load_dword %[pa], %[ppa], 0x0\n\t"
+        "s_load_dwordx2 %[zb], %[pz], 0x0\n\t"
+        "s_load_dwordx2 %[ub], %[pu], 0x0\n\t"
+        "s_load_dwordx16 %[fa], %[kf], 0x0\n\t"
+        "s_load_dwordx16 %[fb], %[kf], 0x40\n\t"
+        "s_load_dwordx16 %[fc], %[kf], 0x80\n\t"
+        "s_load_dwordx16 %[fd], %[kf], 0xc0\n\t"
         "s_waitcnt lgkmcnt(0)"
         : [me] "=&s"(me), [pa] "=&s"(pa), [zb] "=&s"(zb), [ub] "=&s"(ub), [fa] "=&s"(fa),
-          [fb] "=&s"(fb), [fc] "=&s"(fc), [fd] "=&s"(fd), [w0] "=&s"(w0),
-          [w1] "=&s"(w1), [w2] "=&s"(w2), [w3] "=&s"(w3)
+          [fb] "=&s"(fb), [fc] "=&s"(fc), [fd] "=&s"(fd)
         : [pme] "s"(idx + g), [ppa] "s"(idx + ns_ + g), [pz] "s"(r + g), [pu] "s"(r + ns_ + g),
-          [kf] "s"(kfirst), [ka] "s"(kbase));
+          [kf] "s"(kfirst));
+    // (w0..w3 stay reserved until here: a register handed to somebody else while one of the
+    // warm-up loads is still on its way would be overwritten when it lands)
+    asm volatile("" ::"s"(w0), "s"(w1), "s"(w2), "s"(w3));
     mz = __hiloint2double(zb.y, zb.x);
     mlnu = __hiloint2double(ub.y, ub.x);
   }
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     double __attribute__((address_space(1))) * qT;
     double __attribute__((address_space(1))) * factors;
     const double __attribute__((address_space(1))) * syn_c;
-    int syn_nG;
+    int syn_nG, broken;
     int nG[NH_MAX_GRIDS];
     const double __attribute__((address_space(1))) * e[NH_MAX_GRIDS];
     const double __attribute__((address_space(1))) * xg[NH_MAX_GRIDS];
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   F.factors = (double __attribute__((address_space(1)))*)hs_gptr<double>(fd[10], fd[11]);
   F.syn_c = hs_gptr<double>(fd[12], fd[13]);
   F.syn_nG = fd[14];
+  F.broken = fd[15];
 #pragma unroll
   for (int g = 0; g < NH_MAX_GRIDS; ++g) {
     F.nG[g] = fa[12 + g];
@@ -545,23 +556,65 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     pk_ld = (int)(shape >> 32);
     pk_out = (double*)P[49];
   }
-  // the grids' own arrays: this thread's node of every grid (clamped neighbour indices:
-  // nothing is selected before all loads are out)
-  double nE_[NH_MAX_GRIDS], nE2_[NH_MAX_GRIDS], ngx_[NH_MAX_GRIDS], nlr_[NH_MAX_GRIDS],
-      nln_[NH_MAX_GRIDS];
+  // the grids' own arrays.  The nodes of all grids are dealt to the waves in units of 64
+  // (unit u = 64 consecutive nodes of ONE grid: which grid is wave-uniform, its arrays are
+  // scalar pointers); wave w holds units w and w + nwv in registers.  (One node of EVERY grid
+  // per thread, the first layout, gave the front waves three nodes and the back ones none:
+  // seven passes of the weights on one SIMD against four on another.)
+  int ub[NH_MAX_GRIDS + 1];  // first unit of each grid
+  ub[0] = 0;
 #pragma unroll
-  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
-    nE_[g] = nE2_[g] = ngx_[g] = 1.0;
-    nlr_[g] = nln_[g] = 0.0;
-    if (g < F.ngrids && tid < F.nG[g]) {  // (waves past the end of a grid issue nothing: the
-                                            // loads of this trip are bound by the L1's 64 B/clk)
-      const int nG = F.nG[g];
-      const int i0 = tid, i1 = min(tid + 1, nG - 1), il = min(tid, nG - 2);
-      nE_[g] = F.e[g][i0];
-      nE2_[g] = F.e[g][i1];
-      ngx_[g] = F.xg[g][i0];
-      nlr_[g] = F.lx[g][il];
-      nln_[g] = F.lne[g][i0];
+  for (int g = 0; g < NH_MAX_GRIDS; ++g)
+    ub[g + 1] = ub[g] + (g < F.ngrids ? (F.nG[g] + 63) >> 6 : 0);
+  const int nunits = ub[NH_MAX_GRIDS];
+  // ... to the waves that have nothing else to do before the second barrier: not the
+  // likelihood wave (it evaluates the priors), not the tile waves at the back (the liveness
+  // search of the synchrotron energies) -- with a unit on top they were the last to arrive
+  const int tiles_ = H.syn_grid >= 0 ? (H.syn_nE + 63) >> 6 : 0;
+  int nwork = nwv - 1 - tiles_, rank = wv == 0 ? 0 : wv - 1;
+  bool worker = wv != 1 && wv < nwv - tiles_;
+  if (nwork < 1) {  // (a workgroup of one or two waves: everybody)
+    nwork = nwv;
+    rank = wv;
+    worker = true;
+  }
+  int ug[2], ui[2];  // slot -> grid (wave-uniform; -1: none), node of this lane
+  double nE_[2], nE2_[2], ngx_[2], nlr_[2], nln_[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int u = rank + sl * nwork;
+    int g = -1;
+#pragma unroll
+    for (int q = 0; q < NH_MAX_GRIDS; ++q)
+      if (worker && u >= ub[q] && u < ub[q + 1]) g = q;
+    ug[sl] = g;
+    ui[sl] = 0;
+    nE_[sl] = nE2_[sl] = ngx_[sl] = 1.0;
+    nlr_[sl] = nln_[sl] = 0.0;
+    if (g >= 0) {
+      int nG = 0, u0 = 0;
+      const double __attribute__((address_space(1)))* pe = nullptr;
+      const double __attribute__((address_space(1)))* px = nullptr;
+      const double __attribute__((address_space(1)))* pl = nullptr;
+      const double __attribute__((address_space(1)))* pn = nullptr;
+#pragma unroll
+      for (int q = 0; q < NH_MAX_GRIDS; ++q)
+        if (g == q) {
+          nG = F.nG[q]; u0 = ub[q];
+          pe = F.e[q]; px = F.xg[q]; pl = F.lx[q]; pn = F.lne[q];
+        }
+      const int i = (u - u0) * 64 + lane;
+      ui[sl] = i;
+      if (i < nG) {  // (clamped neighbour indices: nothing is selected before all loads are out)
+        const int i1 = min(i + 1, nG - 1), il = min(i, nG - 2);
+        if (F.broken) {  // (E itself is only compared with the break energy)
+          nE_[sl] = pe[i];
+          nE2_[sl] = pe[i1];
+        }
+        ngx_[sl] = px[i];
+        nlr_[sl] = pl[il];
+        nln_[sl] = pn[i];
+      }
     }
   }
   // the synchrotron grid's walker-independent constants (made once, nh_half_step_create)
@@ -643,20 +696,21 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       }
     }
   }
-  // (the `last` node of a grid has no segment to its right)
-#pragma unroll
-  for (int g = 0; g < NH_MAX_GRIDS; ++g)
-    if (g < F.ngrids && tid + 1 >= F.nG[g]) nlr_[g] = 0.0;
   if (dbg_on && j == 0 && lane == 0) D.dbg[224 + wv] = (long long)wall_clock64();
   // ---- grids' own arrays -> LDS ------------------------------------------------------------
   if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
 #pragma unroll
-  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
-    if (g < H.ngrids && tid + 1 < H.nG[g]) sm[H.o_lx[g] + tid] = nlr_[g];
-  }
-  for (int g = 0; g < H.ngrids; ++g) {  // grids longer than the workgroup
-    const int nG = H.nG[g];
-    for (int i = tid + T; i < nG - 1; i += T) sm[H.o_lx[g] + i] = H.lx[g][i];
+  for (int sl = 0; sl < 2; ++sl)
+    if (ug[sl] >= 0) {
+      const int g = ug[sl], i = ui[sl], nG = H.nG[g];
+      if (i + 1 >= nG) nlr_[sl] = 0.0;  // (the last node of a grid has no segment to its right)
+      if (i + 1 < nG) sm[H.o_lx[g] + i] = nlr_[sl];
+    }
+  for (int u = worker ? rank + 2 * nwork : nunits; u < nunits; u += nwork) {  // the rest: from memory
+    int g = 0;
+    while (u >= ub[g + 1]) ++g;
+    const int i = (u - ub[g]) * 64 + lane;
+    if (i + 1 < H.nG[g]) sm[H.o_lx[g] + i] = H.lx[g][i];
   }
   // the single-row tables (We, Wp), the likelihood's data columns, the prior terms ...: loaded
   // and parked in LDS by the waves that are NOT on the proposal's chain.  Every load of a
@@ -739,13 +793,15 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   __syncthreads();
   HS_STAMP(3);
   if (tid == 0 && j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
-  // the single-row tables (We, Wp) -> LDS, by the threads at the BACK of the workgroup: they
-  // have no node of any grid to evaluate below, and nobody reads these before the next barrier
+  // the single-row tables (We, Wp) -> LDS, by the waves at the back of the workgroup that are
+  // not tile waves (those search the synchrotron energies' live ranges now): they hold at most
+  // one unit of nodes below, and nobody reads these before the next barrier
   {
+    const int Tb = (nwv - tiles_ > 0 ? nwv - tiles_ : nwv) * 64;
     int ko = H.o_mkt;
     for (int m = 0; m < H.nmom; ++m) {
       const int nG = H.nG[H.mgrid[m]];
-      for (int i = T - 1 - tid; i < nG; i += T) {
+      for (int i = Tb - 1 - tid; i >= 0 && i < nG; i += Tb) {
         sm[ko + i] = H.mKt[m][i];
         sm[ko + nG + i] = H.mdK[m][i];
       }
@@ -809,7 +865,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   double lv_q = 0.0, lv_E = 0.0;
   bool lv_live = false;
   int* tcnt = reinterpret_cast<int*>(sm + HS_O_INT) + 8;  // [<= 8] live energies per tile
-  const int syn_tiles = has_syn ? (H.syn_nE + 63) >> 6 : 0;
+  const int syn_tiles = tiles_;
   if (has_syn && nwv - 1 - wv < syn_tiles) {
     const int nG = H.nG[H.syn_grid];
     const double* ig2 = sm + H.o_ig2;
@@ -842,36 +898,37 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // zero-flux plateau; evaluated in full they cost 1.5x a normal walker and set the launch time.
   int nzmask = 0;
 #pragma unroll
-  for (int g = 0; g < NH_MAX_GRIDS; ++g) {
-    if (g < H.ngrids && tid < H.nG[g]) {
-      const int nG = H.nG[g], i = tid;
-      const bool last = i + 1 >= nG;
-      double nn, dsh;
-      pd_core(D.kind, p, nln_[g] - lg[0], nln_[g] - lg[1], lg[2] - lg[0], nE_[g] < p.eb,
-              nE2_[g] < p.eb, nlr_[g], nn, dsh, sm + HS_O_T64);
-      nn *= H.scale[g];
-      const double wv_ = ngx_[g] * nn, dv = last ? 0.0 : nlr_[g] + dsh;
-      sm[H.o_w[g] + i] = wv_;
-      sm[H.o_d[g] + i] = dv;
-      if (wv_ != 0.0) nzmask |= 1 << g;
-      if (D.write_weights) {
-        D.w[g][(long long)j * nG + i] = wv_;
-        D.dlw[g][(long long)j * nG + i] = dv;
+  for (int sl = 0; sl < 2; ++sl)
+    if (ug[sl] >= 0) {  // (wave-uniform)
+      const int g = ug[sl], i = ui[sl], nG = H.nG[g];
+      if (i < nG) {
+        const bool last = i + 1 >= nG;
+        double nn, dsh;
+        pd_core(D.kind, p, nln_[sl] - lg[0], nln_[sl] - lg[1], lg[2] - lg[0], nE_[sl] < p.eb,
+                nE2_[sl] < p.eb, nlr_[sl], nn, dsh, sm + HS_O_T64);
+        nn *= H.scale[g];
+        const double wv_ = ngx_[sl] * nn, dv = last ? 0.0 : nlr_[sl] + dsh;
+        sm[H.o_w[g] + i] = wv_;
+        sm[H.o_d[g] + i] = dv;
+        if (wv_ != 0.0) nzmask |= 1 << g;
+        if (D.write_weights) {
+          D.w[g][(long long)j * nG + i] = wv_;
+          D.dlw[g][(long long)j * nG + i] = dv;
+        }
       }
     }
-  }
-  for (int g = 0; g < H.ngrids; ++g) {  // grids longer than the workgroup
-    const int nG = H.nG[g];
-    const double* e = H.e[g];
-    const double* xg = H.xg[g];
-    for (int i = tid + T; i < nG; i += T) {
+  for (int u = worker ? rank + 2 * nwork : nunits; u < nunits; u += nwork) {  // the rest: from memory
+    int g = 0;
+    while (u >= ub[g + 1]) ++g;
+    const int nG = H.nG[g], i = (u - ub[g]) * 64 + lane;
+    if (i < nG) {
       const bool last = i + 1 >= nG;
-      const double E = e[i];
-      const double E2 = last ? E : e[i + 1];
-      const double gx = xg[i];
+      const double E = H.e[g][i];
+      const double E2 = last ? E : H.e[g][i + 1];
+      const double gx = H.xg[g][i];
       double lr = 0.0;
-      if (!last) lr = sm[H.o_lx[g] + i];
-      const double lnE = H.lne[g] ? H.lne[g][i] : log(E);
+      if (!last) lr = H.lx[g][i];
+      const double lnE = H.lne[g][i];
       double nn, dsh;
       pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
               dsh, sm + HS_O_T64);
@@ -1606,6 +1663,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     F.npk8 = d->npacks * NH_MAX_LAZY; F.ngrids = H.ngrids; F.nloc = H.nloc;
     F.qT = H.qT; F.factors = H.factors;
     F.syn_c = P->syn_c; F.syn_nG = H.syn_grid >= 0 ? H.nG[H.syn_grid] : 0;
+    F.broken = (d->kind == NH_PD_BROKENPL || d->kind == NH_PD_ECBPL) ? 1 : 0;
     F.ppk = -1;
     for (int q = 0; q < d->npacks; ++q)
       if (packs_host[q].out == d->params) F.ppk = q;
