@@ -109,3 +109,33 @@ def test_device_loop_equals_oracle_driven_sampler(na, cfg):
     assert_allclose(st.coords, c, rtol=1e-8)
     assert_allclose(st.log_prob, l, rtol=1e-6)
     assert_allclose(s.get_chain()[-1], c, rtol=1e-8)
+
+
+def test_one_launch_half_step_with_more_grid_nodes_than_register_units(na):
+    """a particle grid of 1800 nodes: the waves hold two units of 64 nodes each in registers,
+    the rest of the grid is evaluated from memory -- the one-launch half-step must still be
+    the path taken, and agree with the host-driven loop"""
+    from bench import build_problem
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    _, p0, raw, data, prior = _problem(na, "cfg2", {})
+
+    def model(pars, data):
+        pd = na.ExponentialCutoffPowerLaw(10 ** pars[0] / u.eV, 10 * u.TeV, pars[1],
+                                          10 ** pars[2] * u.TeV)
+        syn = na.Synchrotron(pd, B=pars[3] * u.uG, Eemin=1 * u.GeV, Eemax=1 * u.PeV, nEed=300)
+        return syn.sed(data, distance=1 * u.kpc)
+
+    nw, nd = 24, p0.size
+    kw = dict(args=[data, model, prior], seed=7, naima_style=True, store_blobs=False)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(2).standard_normal((nw, nd)))
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    sh, sd = h.run_mcmc(pos, 3), d.run_mcmc(pos, 3)
+    sh, sd = h.run_mcmc(sh, 9), d.run_mcmc(sd, 9)
+    dev = d._dev
+    assert dev is not None and dev.mega and dev._plan["hs"] is not None  # ONE launch per half-step
+    assert dev._plan["hs"]["threads"] == 1024
+    assert_allclose(sd.coords, sh.coords, rtol=1e-8)
+    assert_allclose(sd.log_prob, sh.log_prob, rtol=1e-6)
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
