@@ -271,12 +271,22 @@ def main():
         comm.barrier()
         return comm.max(time.perf_counter() - t0), st
 
+    # (rehearsals of the region, untimed: the graphs a K-step call replays -- the tail of a
+    # block of moves is a graph of its own -- are captured here, not inside a timed region)
+    # (a K-step call takes its moves from 32-step blocks: where a call starts within a block
+    # repeats after 32 / gcd(32, K) calls, and with it the set of graphs)
+    import math
+    rehearsed = 0
+    for _ in range(min(16, 32 // math.gcd(32, max(1, args.steps)))):
+        _, state = timed_region(sampler, state)
+        sampler.reset()
+        rehearsed += args.steps
     first, state = timed_region(sampler, state)
     acc_frac = float(np.mean(sampler.acceptance_fraction))
     sampler.reset()  # (the chain of a region is dropped before the next one)
     times = [first]
-    nrep = int(min(400, max(0, np.ceil((args.min_time - first) / max(first, 1e-6)))))
-    for _ in range(nrep):
+    # every region's time is already the max over ranks: all ranks take the same decisions
+    while sum(times) < args.min_time and len(times) < 400:
         dt_i, state = timed_region(sampler, state)
         times.append(dt_i)
         sampler.reset()
@@ -347,7 +357,7 @@ def main():
             "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
             "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
             "initial_ball": args.ball,
-            "device": info["name"], "untimed_spinup_steps": spinup,
+            "device": info["name"], "untimed_spinup_steps": spinup + rehearsed,
             "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
                            "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
                            else "all-gather between two graphs per half-step")
