@@ -1120,28 +1120,42 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           const double q = sq[a], cbq = sq[nEs + a];
           double acc = 0.0;
           if (s0 < s1) {
-            double u1 = 0.0, P1 = 1.0;
-            {
-              const double x = q * ig2[s0];
-              const double w1 = wr[s0];
-              if (x <= 746.0 && w1 != 0.0) {  // (a zero weight makes the node an exact zero)
-                P1 = syn_P1(cbq * ig23[s0]);
-                u1 = w1 * (P1 * nh_exp_tab(-x, T64));  // gamma nelec dNdE / CS1, :335-338
-              }
-            }
-            for (int s = s0; s < s1; ++s) {
-              const double x = q * ig2[s + 1];
-              double u2 = 0.0, P2 = 1.0;
-              const double w2 = wr[s + 1];
-              if (x <= 746.0 && w2 != 0.0) {
-                P2 = syn_P1(cbq * ig23[s + 1]);
-                u2 = w2 * (P2 * nh_exp_tab(-x, T64));
-              }
+            // One node: gamma nelec dNdE / CS1 (radiative.py:335-338) and P.  No branch: a dead
+            // node (x > 746: exp(-x) == 0 in double; a zero weight: an exact zero) is computed
+            // like any other and zeroed by a select -- inside the live range the liveness search
+            // left, that is the first node at most -- so that TWO nodes per trip are one
+            // straight block the scheduler can interleave.  (One node per trip, behind a branch,
+            // is a dependent chain of ~70 FP64 instructions: a wave alone took 21 cycles per
+            // instruction, four waves per SIMD kept it 40 % busy.)
+            auto node = [&](int sn, double& u, double& P) {
+              const double x = q * ig2[sn];
+              const double w = wr[sn];
+              const bool on = x <= 746.0 && w != 0.0;  // (NaN: off, as before)
+              const double Pv = syn_P1(cbq * ig23[sn]);
+              const double ev = nh_exp_tab(-fmin(x, 800.0), T64);
+              u = on ? w * (Pv * ev) : 0.0;
+              P = on ? Pv : 1.0;
+            };
+            double u1, P1;
+            node(s0, u1, P1);
+            int s = s0;
+            for (; s + 2 <= s1; s += 2) {
+              double uA, PA, uB, PB;
+              node(s + 1, uA, PA);
+              node(s + 2, uB, PB);
               // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
-              const double dl = dwr[s] + syn_dlnP1(P1, P2) - q * dig2[s];
-              acc += nh_seg_pos<true>(u1, u2, dl, lxs[s]);  // P(x) exp(-x) >= 0
-              u1 = u2;
-              P1 = P2;
+              const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
+              const double dlB = dwr[s + 1] + syn_dlnP1(PA, PB) - q * dig2[s + 1];
+              acc += nh_seg_pos<true>(u1, uA, dlA, lxs[s]);  // P(x) exp(-x) >= 0
+              acc += nh_seg_pos<true>(uA, uB, dlB, lxs[s + 1]);
+              u1 = uB;
+              P1 = PB;
+            }
+            if (s < s1) {
+              double uA, PA;
+              node(s + 1, uA, PA);
+              const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
+              acc += nh_seg_pos<true>(u1, uA, dlA, lxs[s]);
             }
           }
           part_s[ch * nEs + a] = acc * sq[2 * nEs + a];  // linear in u: CS1 once per thread
