@@ -50,6 +50,8 @@ KERNEL_FLOP_EQ = {
     "cfg2": {"synchrotron": 179 * 300 * 50.0},
     "cfg1": {"integrate_tables": 28 * 570 * 30.0},
     "cfg5": {"integrate_tables": 28 * 600 * 30.0},
+    # (seed energy, photon energy, gamma) nodes of the SSC seed integral, 45 eq. each
+    "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * 45.0},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
 KERNEL_SYMBOL = {"half_step": "k_half_step", "integrate_tables": "k_integrate_tables",
@@ -102,9 +104,32 @@ def executed_flop_eq(name, raw, coords):
     only the (energy, gamma) nodes with x = E/Ec(gamma, B) <= 746 (nh_synchrotron.hip: the
     liveness search), which depends on each walker's B"""
     out = dict(KERNEL_FLOP_EQ.get(name, {}))
+    from naima_amd import constants as K
+    if name == "cfg4":
+        # the SSC seed integral: a segment of the seed axis is integrated only where the
+        # Aharonian-Atoyan kernel is non-zero at one of its ends (radiative.py:628-636: the
+        # windows q <= 1, q >= 1/(4 gamma^2)); elsewhere the kernel evaluates fic and moves on
+        l0, l1 = np.log10(1e8 / K.MEC2_EV), np.log10(5e16 / K.MEC2_EV)
+        gam = np.logspace(l0, l1, max(10, int(100 * (l1 - l0))))
+        eps = np.logspace(-7, 9, 100) / K.MEC2_EV
+        Eg = np.asarray(raw["energy"], dtype=float) * {"eV": 1.0, "keV": 1e3, "MeV": 1e6,
+                                                       "GeV": 1e9, "TeV": 1e12}[raw["energy_unit"]] / K.MEC2_EV
+        w = Eg[:, None] / gam[None, :]
+        ok = (w < 1.0) & (w > 0.0)
+        with np.errstate(all="ignore"):
+            c1 = np.where(ok, w / (4.0 * gam[None, :] * (1.0 - w)), np.nan)
+        qmin = 1.0 / (4.0 * gam[None, :] ** 2)
+        live, prev = 0, None
+        for e0 in eps:
+            q = c1 / e0
+            on = ok & (q < 1.0) & (q > qmin)  # (fic is 0 AT q = 1 and half-weighted at qmin)
+            if prev is not None:
+                live += int((on | prev).sum())
+            prev = on
+        out["ic_seed_walkers"] = live * 45.0
+        return out
     if "synchrotron" not in out:
         return out
-    from naima_amd import constants as K
     # (Eemin, Eemax, nEed) of the workload's Synchrotron grid and the index of B [uG]
     lo, hi, per, iB = {"cfg2": (1e9, 1e15, 50, 3), "cfg3": (1e9, 1e9 * K.MEC2_EV, 100, 3)}[name]
     l0, l1 = np.log10(lo / K.MEC2_EV), np.log10(hi / K.MEC2_EV)
@@ -414,7 +439,10 @@ def main():
                                           "EXECUTED nodes only: the synchrotron kernel skips "
                                           "every (energy, gamma) node with E/Ec > 746 "
                                           "(exp(-x) == 0 in double) -- counted on the host "
-                                          "from the final ensemble's B, mean over walkers"}
+                                          "from the final ensemble's B, mean over walkers; "
+                                          "the SSC seed kernel (cfg4) is credited with the "
+                                          "seed-axis segments inside the Aharonian-Atoyan "
+                                          "kernel's windows, 45 eq. each"}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out), flush=True)
