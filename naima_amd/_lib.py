@@ -5,6 +5,7 @@ compute call raises.  Importing this module does not load the library, so the
 host-side pieces (units, data ingest, sampler bookkeeping) import on any box.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -20,6 +21,7 @@ PD_KIND = {"PowerLaw": 0, "ExponentialCutoffPowerLaw": 1, "BrokenPowerLaw": 2,
 PP_MODEL = {"Geant4": 0, "Pythia8": 1, "SIBYLL": 2, "QGSJET": 3}
 
 _dp = C.c_void_p
+_ITEMSIZE = {np.float64: 8, np.int64: 8, np.int32: 4, np.float32: 4, np.uint8: 1}
 _i = C.c_int
 _d = C.c_double
 _ll = C.c_longlong
@@ -189,7 +191,7 @@ class DeviceArray:
     __slots__ = ("ctx", "ptr", "shape", "dtype", "nbytes", "_cap", "stream", "anchor",
                  "graph_owned", "pending", "__weakref__")
 
-    def __init__(self, ctx, ptr, shape, dtype, cap):
+    def __init__(self, ctx, ptr, shape, dtype, cap, nbytes=None):
         self.ctx, self.ptr, self.shape, self.dtype, self._cap = ctx, ptr, tuple(shape), dtype, cap
         self.stream = ctx.cur_stream  # the stream whose work produces this buffer
         self.anchor = None
@@ -198,7 +200,9 @@ class DeviceArray:
         self.graph_owned = bool(ctx.capturing)
         # a deferred launch that will fill this buffer (see Context.defer)
         self.pending = None
-        self.nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        self.nbytes = nbytes if nbytes is not None else \
+            math.prod(int(x) for x in shape) * _ITEMSIZE.get(dtype, 0) or \
+            int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
 
     @property
     def size(self):
@@ -281,8 +285,12 @@ class Context:
         return b
 
     def empty(self, shape, dtype=np.float64):
-        shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        # (on the sampler's per-call path: no numpy reductions for the product of three ints)
+        shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
+        isz = _ITEMSIZE.get(dtype)
+        if isz is None:
+            isz = np.dtype(dtype).itemsize
+        nbytes = math.prod(shape) * isz
         cap = self._bucket(nbytes)
         # during a capture, buffers released earlier in the SAME capture may be reused
         # (graph order is stream order); nothing else may ever alias them
@@ -295,7 +303,7 @@ class Context:
             p = _dp()
             _chk(_lib.nh_alloc(self.h, cap, C.byref(p)))
             ptr = p.value
-        return DeviceArray(self, ptr, shape, dtype, cap)
+        return DeviceArray(self, ptr, shape, dtype, cap, nbytes)
 
     def _release(self, ptr, cap, graph_owned=False):
         if graph_owned:

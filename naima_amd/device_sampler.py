@@ -501,18 +501,20 @@ class DeviceLoop:
             addr, K = moves.take(min(self.KSTEPS, iterations - it))
             ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
             if self.fused:
-                ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
-                if not self.mega:
-                    self._front()  # slice 0 of the new block
-                elif self._plan["hs"] is not None:
+                if self.mega and self._plan["hs"] is not None:
+                    # (the one-launch kernel writes the cursor itself, every launch)
                     ctx.call("nh_half_step_begin_block", self._plan["hs"]["plan"], 0,
                              block["n"] if dev_hist else 0)
+                else:
+                    ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
+                    if not self.mega:
+                        self._front()  # slice 0 of the new block
             else:
                 ctx.call("nh_memset", self.cursor, 0, 4)
             mark = self._markers[self._nmark % len(self._markers)]
             self._nmark += 1
-            ctx.call("nh_marker_record", mark)
-            self._inflight.append(mark)
+            mark_pending = True  # recorded behind the block's first launch: the host gets
+            self._inflight.append(mark)  # that one out first (any later point is as good)
             k = 0
             while k < K:
                 self._pos["slice"], self._pos["steps"] = 2 * k, (block["n"] - k) if dev_hist else 0
@@ -544,6 +546,9 @@ class DeviceLoop:
                 else:
                     self._flush_pending()
                     self._run_step()
+                if mark_pending:
+                    ctx.call("nh_marker_record", mark)
+                    mark_pending = False
                 k += g
                 it += g
                 s.iteration += g
