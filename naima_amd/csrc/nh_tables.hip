@@ -8,6 +8,7 @@
 // spends the per-walker work in the reduction.  Nothing is cached across calls.
 #include "nh_common.h"
 #include "nh_ic.h"
+#include "nh_syn.h"
 
 #define NH_TAB_PROLOGUE                                                  \
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
@@ -132,66 +133,137 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
 // seed densities n_w(eps0_s) (pre-scaled) and log-ratios are wave-uniform scalars.
 // The gamma range is additionally split over gridDim.y; the partial sums are reduced
 // deterministically by k_ssc_finish.
+//
+// The kernel is bound by instruction issue (5 waves per SIMD, no memory traffic to speak
+// of), so the seed-axis step is written for its instruction count -- 136 VALU instructions
+// for the 8 walkers of a wave against ~400 in the first version, whose ISA showed where they
+// went: a double-double library log per node (110), two scalar loads WITH their wait and ten
+// address instructions per walker, exec-mask branches for the window's Heaviside factors:
+//   * the walkers' densities and log-ratios are transposed by k_ssc_prep to [group][s][W]:
+//     two 64-byte scalar loads per seed node fetch them for all W walkers of the wave;
+//   * the log-ratios are divided by ln(eps_{s+1}/eps_s) there, so that a segment term is
+//     (u2 - u1) / dl' -- no multiplication by lx per walker (dl' = dl / lx; the series
+//     threshold |dl| < 2^-10 becomes |dl'| < 2^-10 / lx, a scalar per seed node);
+//   * ln fic by ssc_log (fdlibm's degree-7 atanh form, 30 instructions, <= 2 ulp: the
+//     difference of the logarithms of neighbouring nodes is O(1));
+//   * the window as ONE product (1 - q)(q - qmin) > 0 (qmin < 1: never both negative), the
+//     reference's value 0.5 at an edge behind a wave-uniform branch nobody takes.
 // ---------------------------------------------------------------------------
+#define SSC_W 8
+#define SSC_REC 24  // doubles per (group, seed node) record
+// Everything a wave needs at seed node s, as ONE record behind ONE pointer (three wide scalar
+// loads at fixed offsets; separate arrays cost four address computations per node and the
+// scalar registers to hold them):
+//   [0, W)    n_w(eps0_s) of the group's W walkers, 1/(mec2 cm3)       (radiative.py:639)
+//   [W, 2W)   ln(n_w(eps0_s)/n_w(eps0_{s-1})) / lx of the segment that ENDS at s
+//   [16, 20)  lx = ln(eps0_s/eps0_{s-1}), 1/lx, 2^-10/lx (series threshold in units of
+//             dl' = dl/lx), 0       -- record 0: 1/eps0_0, 2 ln eps0_0 in [16], [17]
+//   [20, 22)  1/eps0_{s+1}, 2 ln eps0_{s+1} (in mec2): the NEXT node's fic operands
 __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restrict__ sd, int N,
-                           int ns, double* __restrict__ e0, double* __restrict__ lxs,
-                           double* __restrict__ ie0, double* __restrict__ le0,
-                           double* __restrict__ sdm, double* __restrict__ dlnd) {
-  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < ns) {
-    const double e = se[idx] / NH_MEC2_EV;
-    e0[idx] = e;
-    ie0[idx] = 1.0 / e;
-    le0[idx] = log(e);
-    if (idx + 1 < ns) lxs[idx] = log(se[idx + 1] / se[idx]);
+                           int ns, double* __restrict__ rec) {
+  static_assert(2 * SSC_W == 16 && SSC_REC == 24, "record layout");
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int groups = (N + SSC_W - 1) / SSC_W;
+  if (idx >= (long long)groups * ns * SSC_REC) return;
+  const int slot = (int)(idx % SSC_REC);
+  const int s = (int)((idx / SSC_REC) % ns);
+  const int grp = (int)(idx / ((long long)SSC_REC * ns));
+  double v = 0.0;
+  if (slot < 2 * SSC_W) {
+    const long long w = min(grp * SSC_W + (slot & (SSC_W - 1)), N - 1);
+    const double b = sd[w * ns + s];
+    if (slot < SSC_W) {
+      v = b * NH_MEC2_EV;
+    } else if (s > 0) {  // a zero node ends the power-law segment: marked as in the tables
+      const double a = sd[w * ns + s - 1];
+      v = (a == 0.0 || b == 0.0) ? NH_DL_ZERO : log(fabs(b / a)) / log(se[s] / se[s - 1]);
+    }
+  } else if (slot < 20) {
+    if (s > 0) {
+      const double lx = log(se[s] / se[s - 1]);
+      v = slot == 16 ? lx : slot == 17 ? 1.0 / lx : slot == 18 ? NH_SEG_SMALL_POS / lx : 0.0;
+    } else if (slot == 16) {
+      v = NH_MEC2_EV / se[0];
+    } else if (slot == 17) {
+      v = 2.0 * log(se[0] / NH_MEC2_EV);
+    }
+  } else if (s + 1 < ns) {
+    const double e = se[s + 1] / NH_MEC2_EV;
+    v = slot == 20 ? 1.0 / e : slot == 21 ? 2.0 * log(e) : 0.0;
   }
-  if (idx >= (long long)N * ns) return;
-  int s = (int)(idx % ns);
-  double d = sd[idx] * NH_MEC2_EV;  // 1/(eV cm3) -> 1/(mec2 cm3), radiative.py:639
-  sdm[idx] = d;
-  double dl = 0.0;
-  if (s + 1 < ns) {  // a zero node ends the power-law segment: marked as in the tables
-    const double a = sd[idx], b = sd[idx + 1];
-    dl = (a == 0.0 || b == 0.0) ? NH_DL_ZERO : log(fabs(b / a));
-  }
-  dlnd[idx] = dl;
+  rec[idx] = v;
 }
 
 // fic of Eq. 22 along the seed axis for fixed (gamma, E_gamma): with w = E_gamma/gamma,
 //   q = w / (4 eps0 gamma (1 - w)) = c1 / eps0,   b q = w / (1 - w) =: B  (no eps0 in it),
-//   fic = 2 q ln q + (1 + 2 q)(1 - q) + (B^2 / (2 (1 + B))) (1 - q),   ln q = ln c1 - ln eps0,
-// so one seed node costs a dozen FMAs: the divisions and the logarithm of ic_fic_windowed
-// are taken once per (gamma, E_gamma).  Windows and the NaN -> 0 rule as there.
-struct ssc_gk { double c1, lnc1, hB, qmin; bool valid; };
+//   fic = 2 q ln q + (1 + 2 q)(1 - q) + (B^2 / (2 (1 + B))) (1 - q)
+//       = q (2 ln c1 - 2 ln eps0) + (1 - q)(2 q + 1 + hB),
+// so one seed node costs six instructions: the divisions and the logarithm of
+// ic_fic_windowed are taken once per (gamma, E_gamma).  Windows and the NaN -> 0 rule as there.
+struct ssc_gk { double c1, lnc1x2, ohB, hB, qmin; bool valid; };
 
 __device__ __forceinline__ ssc_gk ssc_setup(double g, double eg) {
   ssc_gk r;
   const double wq = eg / g, omw = 1.0 - wq;
   r.valid = omw > 0.0 && wq > 0.0;  // else q <= 0 or infinite: log(q) NaN -> 0 (radiative.py:636)
   r.c1 = wq / (4.0 * g * omw);
-  r.lnc1 = r.valid ? log(r.c1) : 0.0;
+  r.lnc1x2 = r.valid ? 2.0 * log(r.c1) : 0.0;
   const double B = wq / omw;
   r.hB = 0.5 * (B * B) / (1.0 + B);
+  r.ohB = 1.0 + r.hB;
   r.qmin = 1.0 / (4.0 * (g * g));
   return r;
 }
 
-__device__ __forceinline__ double ssc_fic(const ssc_gk& r, double ie0, double le0) {
+// (ie0 = 1 / eps0, le0x2 = 2 ln eps0)
+__device__ __forceinline__ double ssc_fic(const ssc_gk& r, double ie0, double le0x2) {
   const double q = r.c1 * ie0;
   const double omq = 1.0 - q;
-  const double f = 2.0 * q * (r.lnc1 - le0) + fma(2.0, q, 1.0) * omq + r.hB * omq;
-  const double win = nh_heaviside(omq) * nh_heaviside(q - r.qmin);
-  return r.valid ? f * win : 0.0;
+  const double f = fma(omq, fma(2.0, q, r.ohB), q * (r.lnc1x2 - le0x2));
+  // heaviside(1 - q) heaviside(q - qmin), radiative.py:633-634: both factors 1 inside the
+  // window; they cannot both be negative (qmin <= 1/4), so inside <=> their product > 0
+  const double p = omq * (q - r.qmin);
+  double fw = (r.valid && p > 0.0) ? f : 0.0;
+  if (__builtin_amdgcn_ballot_w64(p == 0.0) != 0ull) {  // on an edge: heaviside(0) = 0.5
+    asm volatile("" ::: "memory");
+    const double win = nh_heaviside(omq) * nh_heaviside(q - r.qmin);
+    fw = r.valid ? f * win : 0.0;
+  }
+  return fw;
 }
 
+// ln x for a normal x > 0: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1)/(m + 1),
+// ln m = 2 s + s R(s^2) with fdlibm's degree-7 R (|error| < 2^-58 before rounding); ~2 ulp.
+// The library's log carries a double-double through all of it for the last half ulp: 110
+// instructions against 30.
+__device__ __forceinline__ double ssc_log(double x, double L0, double L1, double L2, double L3,
+                                          double L4, double L5, double L6) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double s = (m - 1.0) * nh_rcp2f(m + 1.0);
+  const double z = s * s;
+  double R = fma(z, L0, L1);
+  R = fma(R, z, L2);
+  R = fma(R, z, L3);
+  R = fma(R, z, L4);
+  R = fma(R, z, L5);
+  R = fma(R, z, L6);
+  const double lnm = fma(s, R * z, s + s);
+  const double ef = (double)e;
+  return fma(ef, 6.93147180369123816490e-01, fma(ef, 1.90821492927058770002e-10, lnm));
+}
+
+typedef double ssc_d4 __attribute__((ext_vector_type(4)));
 template <int C, int W>
 __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, const double* __restrict__ ie0,
-    const double* __restrict__ le0, const double* __restrict__ lxs,
-    const double* __restrict__ sdm, const double* __restrict__ dlnd, int ns,
+    const double* __restrict__ E_eV, int nE, const double* __restrict__ rec, int ns,
     double* __restrict__ partial) {
+  static_assert(W == SSC_W, "k_ssc_prep transposes for groups of SSC_W walkers");
   __shared__ double part[C][W][64];
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,13 +279,20 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
   const int per = (nseg + nch - 1) / nch;
   const int s0 = (blockIdx.y * C + ch) * per;
   const int s1 = min(nseg, s0 + per);
-  unsigned row[W], srow[W];
+  const double* __restrict__ rg = rec + (size_t)grp * ns * SSC_REC;  // this group's records
+  // the coefficients of ssc_log in scalar registers: v_fma_f64 takes them as they are (from
+  // vector registers the compiler copies each one into the destination of a v_fmac first)
+  double L0 = 1.479819860511658591e-01, L1 = 1.531383769920937332e-01;
+  double L2 = 1.818357216161805012e-01, L3 = 2.222219843214978396e-01;
+  double L4 = 2.857142874366239149e-01, L5 = 3.999999999940941908e-01;
+  double L6 = 6.666666666666735130e-01;
+  asm volatile("" : "+s"(L0), "+s"(L1), "+s"(L2), "+s"(L3), "+s"(L4), "+s"(L5), "+s"(L6));
+#define SSC_LOG(x) ssc_log(x, L0, L1, L2, L3, L4, L5, L6)
+  unsigned row[W];
   double acc[W], Kp[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    const unsigned wj = (unsigned)min(w0 + j, N - 1);
-    row[j] = wj * (unsigned)nG;
-    srow[j] = wj * (unsigned)ns;
+    row[j] = (unsigned)min(w0 + j, N - 1) * (unsigned)nG;
     acc[j] = 0.0;
     Kp[j] = 0.0;
   }
@@ -222,25 +301,53 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     // inner reduction over the seed spectrum for W walkers at once
     double in[W], u1[W];
     const ssc_gk gk = ssc_setup(g, eg);
-    double f1 = ssc_fic(gk, ie0[0], le0[0]);
-    double lf1 = log(fabs(f1));  // seed nodes are ~0.16 decades apart: ln f2 - ln f1 is O(1),
-                                 // the difference of logarithms loses nothing here
+    double f1 = ssc_fic(gk, rg[16], rg[17]);
+    // (the logarithm on every lane, a zero patched afterwards: behind a select the compiler
+    // puts it in a branch of its own, and the scalar loads of the step behind that branch)
+    double lf1 = SSC_LOG(fabs(f1)) + (f1 == 0.0 ? -INFINITY : 0.0);
 #pragma unroll
-    for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * sdm[srow[j]]; }
+    for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * rg[j]; }
+    const double* rp = rg;
+    double ie = rp[20], le = rp[21];  // the fic operands, one step ahead
     for (int s = 1; s < ns; ++s) {
-      const double f2 = ssc_fic(gk, ie0[s], le0[s]);
+      rp += SSC_REC;
+      const double ien = rp[20], len = rp[21];
+      const double f2 = ssc_fic(gk, ie, le);
+      ie = ien;
+      le = len;
       // both zero for a whole wave (outside every lane's window): nothing to add
       if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
-        const double lf2 = log(fabs(f2));
-        // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
-        // segment contributes (u2 - u1) lx 0 = 0 (utils.py:347-348) without a test per walker
-        const double dlf = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO);
-        lf1 = lf2;
-        const double lxv = lxs[s - 1];
+        double sd8[W], dl8[W];
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          const double u2 = f2 * sdm[srow[j] + s];
-          in[j] += nh_seg_pos<false>(u1[j], u2, dlf + dlnd[srow[j] + s - 1], lxv);
+          sd8[j] = rp[j];
+          dl8[j] = rp[W + j];
+        }
+        const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 16);  // (one load, one wait)
+        const double lxv = Lv.x, ilx = Lv.y, thr = Lv.z;
+        const double lf2 = SSC_LOG(fabs(f2)) + (f2 == 0.0 ? -INFINITY : 0.0);
+        // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
+        // segment contributes (u2 - u1) 0 = 0 (utils.py:347-348) without a test per walker
+        const double dlf = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx;
+        lf1 = lf2;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const double uo = u1[j], io = in[j];
+          const double u2 = f2 * sd8[j];
+          const double dl = dlf + dl8[j];
+          double t = fma(u2 - uo, nh_rcp1f(dl), io);
+          // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos
+          const bool small = fabs(dl) < thr;
+          if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
+            asm volatile("" ::: "memory");  // keep this a branch
+            const double d = dl * lxv;
+            double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
+            f = fma(f, d, 1.666666666666667e-01);
+            f = fma(f, d, 0.5);
+            f = fma(f, d, 1.0);
+            t = small ? fma(uo * lxv, f, io) : t;
+          }
+          in[j] = t;
           u1[j] = u2;
         }
       } else {
@@ -255,7 +362,7 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     for (int j = 0; j < W; ++j) {
       const double Kv = in[j] * pref;
       if (i > s0) {  // outer segment (i-1, i) of trapz_loglog(nelec*gamint, gam), :684
-        const double dl = dlw[row[j] + i - 1] + log(fabs(Kv / Kp[j]));
+        const double dl = dlw[row[j] + i - 1] + SSC_LOG(fabs(Kv * nh_rcp(Kp[j])));
         acc[j] += nh_seg_term(w[row[j] + i - 1] * Kp[j], w[row[j] + i] * Kv, dl, lx[i - 1]);
       }
       Kp[j] = Kv;
@@ -298,7 +405,7 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)N * ns < (1LL << 31),
              "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
-  constexpr int C = 8, W = 8;
+  constexpr int C = 8, W = SSC_W;
   const int ktiles = (nE + 63) / 64;
   const int groups = (N + W - 1) / W;
   const int nseg = nG - 1;
@@ -307,23 +414,18 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   while (nsuper < 16 && (long long)ktiles * groups * nsuper * C < 4096 &&
          nseg / ((nsuper * 2) * C) >= 4)
     nsuper *= 2;
-  const size_t nd = (size_t)N * ns;
-  const size_t need = (4 * (size_t)ns + 2 * nd + (size_t)nsuper * N * nE) * sizeof(double);
+  const size_t nd = (size_t)groups * ns * SSC_REC;
+  const size_t need = (nd + SSC_REC + (size_t)nsuper * N * nE) * sizeof(double);
   void* sc = nullptr;
   int rc = nh_scratch(c, need, &sc);
   if (rc) return rc;
-  double* e0 = static_cast<double*>(sc);
-  double* lxs = e0 + ns;
-  double* ie0 = lxs + ns;
-  double* le0 = ie0 + ns;
-  double* sdm = le0 + ns;
-  double* dlnd = sdm + nd;
-  double* partial = dlnd + nd;
+  double* rec = static_cast<double*>(sc);
+  double* partial = rec + nd + SSC_REC;
   nh_prof_scope ps(c, NH_K_SSC);
   hipLaunchKernelGGL(k_ssc_prep, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream,
-                     seed_E, seed_dens, N, ns, e0, lxs, ie0, le0, sdm, dlnd);
+                     seed_E, seed_dens, N, ns, rec);
   hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(ktiles * groups, nsuper), dim3(64 * C), 0,
-                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, ie0, le0, lxs, sdm, dlnd, ns, partial);
+                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, rec, ns, partial);
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                      partial, nsuper, N, nE, E_eV, out, ldo);
