@@ -9,6 +9,7 @@
 #include "nh_common.h"
 #include "nh_ic.h"
 #include "nh_syn.h"
+#include "nh_lnprob.h"
 
 #define NH_TAB_PROLOGUE                                                  \
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      \
@@ -257,28 +258,35 @@ __device__ __forceinline__ double ssc_log(double x, double L0, double L1, double
 }
 
 typedef double ssc_d4 __attribute__((ext_vector_type(4)));
+// Mapping: one wave = ONE photon energy x 64 consecutive nodes of the gamma grid (63
+// segments; the tiles overlap by one node) x W walkers.  The first version put 64 photon
+// energies on the lanes: a tile of cfg4's 261 energies spans five decades, so the kernel's
+// window in eps0 (its lower edge moves with E/gamma^2) differed from lane to lane and a wave
+// walked the union -- 65 % of the lane-slots it paid for were inside their window (counted on
+// the host for cfg4's grids).  64 neighbouring gamma nodes span 0.64 decades: 93 %.  The
+// outer trapz_loglog over gamma (radiative.py:684) then runs ACROSS the lanes: each lane
+// fetches its right neighbour's inner integral with one shuffle, the 63 segment terms meet
+// in a wave sum; the tiles' partial sums are added by k_ssc_finish in a fixed order.
+#define SSC_TILE 63  // segments of the gamma grid per wave
 template <int C, int W>
 __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
-    const double* __restrict__ E_eV, int nE, const double* __restrict__ rec, int ns,
+    const double* __restrict__ E_eV, int nE, const double* __restrict__ rec, int ns, int ntile,
     double* __restrict__ partial) {
   static_assert(W == SSC_W, "k_ssc_prep transposes for groups of SSC_W walkers");
-  __shared__ double part[C][W][64];
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ktiles = (nE + 63) >> 6;
-  const int tile = blockIdx.x % ktiles, grp = blockIdx.x / ktiles;
-  const int k = tile * 64 + lane;
-  const bool kvalid = k < nE;
-  const double eg = E_eV[kvalid ? k : nE - 1] / NH_MEC2_EV;
+  const int tile = blockIdx.x % ntile, grp = blockIdx.x / ntile;
+  const int k = blockIdx.y * C + ch;  // this wave's photon energy (wave-uniform)
+  if (k >= nE) return;
+  const double eg = E_eV[k] / NH_MEC2_EV;
   const int w0 = grp * W;
-  // this block's share of the segments: gridDim.y super-chunks, C chunks each
-  const int nseg = nG - 1;
-  const int nch = gridDim.y * C;
-  const int per = (nseg + nch - 1) / nch;
-  const int s0 = (blockIdx.y * C + ch) * per;
-  const int s1 = min(nseg, s0 + per);
+  const int i = tile * SSC_TILE + lane;  // this lane's node
+  const bool node = i < nG;
+  const bool seg = lane < SSC_TILE && i + 1 < nG;  // ... and the segment that starts there
+  const int ic = node ? i : nG - 1;
+  const double g = gam[ic];
   const double* __restrict__ rg = rec + (size_t)grp * ns * SSC_REC;  // this group's records
   // the coefficients of ssc_log in scalar registers: v_fma_f64 takes them as they are (from
   // vector registers the compiler copies each one into the destination of a v_fmac first)
@@ -288,100 +296,81 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
   double L6 = 6.666666666666735130e-01;
   asm volatile("" : "+s"(L0), "+s"(L1), "+s"(L2), "+s"(L3), "+s"(L4), "+s"(L5), "+s"(L6));
 #define SSC_LOG(x) ssc_log(x, L0, L1, L2, L3, L4, L5, L6)
-  unsigned row[W];
-  double acc[W], Kp[W];
+  // inner reduction over the seed spectrum for W walkers at once
+  double in[W], u1[W];
+  ssc_gk gk = ssc_setup(g, eg);
+  gk.valid = gk.valid && node;
+  double f1 = ssc_fic(gk, rg[16], rg[17]);
+  // (the logarithm on every lane, a zero patched afterwards: behind a select the compiler
+  // puts it in a branch of its own, and the scalar loads of the step behind that branch)
+  double lf1 = SSC_LOG(fabs(f1)) + (f1 == 0.0 ? -INFINITY : 0.0);
+#pragma unroll
+  for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * rg[j]; }
+  const double* rp = rg;
+  double ie = rp[20], le = rp[21];  // the fic operands, one step ahead
+  for (int s = 1; s < ns; ++s) {
+    rp += SSC_REC;
+    const double ien = rp[20], len = rp[21];
+    const double f2 = ssc_fic(gk, ie, le);
+    ie = ien;
+    le = len;
+    // both zero for a whole wave (outside every lane's window): nothing to add
+    if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
+      double sd8[W], dl8[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        sd8[j] = rp[j];
+        dl8[j] = rp[W + j];
+      }
+      const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 16);  // (one load, one wait)
+      const double lxv = Lv.x, ilx = Lv.y, thr = Lv.z;
+      const double lf2 = SSC_LOG(fabs(f2)) + (f2 == 0.0 ? -INFINITY : 0.0);
+      // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
+      // segment contributes (u2 - u1) 0 = 0 (utils.py:347-348) without a test per walker
+      const double dlf = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx;
+      lf1 = lf2;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const double uo = u1[j], io = in[j];
+        const double u2 = f2 * sd8[j];
+        const double dl = dlf + dl8[j];
+        double t = fma(u2 - uo, nh_rcp1f(dl), io);
+        // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos
+        const bool small = fabs(dl) < thr;
+        if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
+          asm volatile("" ::: "memory");  // keep this a branch
+          const double d = dl * lxv;
+          double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
+          f = fma(f, d, 1.666666666666667e-01);
+          f = fma(f, d, 0.5);
+          f = fma(f, d, 1.0);
+          t = small ? fma(uo * lxv, f, io) : t;
+        }
+        in[j] = t;
+        u1[j] = u2;
+      }
+    } else {
+      lf1 = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < W; ++j) u1[j] = 0.0;
+    }
+    f1 = f2;
+  }
+  // outer segments (i, i+1) of trapz_loglog(nelec*gamint, gam), radiative.py:684: across lanes
+  const double pref = (3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g);  // radiative.py:650-653
+  const double lxi = lx[seg ? i : 0];
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    row[j] = (unsigned)min(w0 + j, N - 1) * (unsigned)nG;
-    acc[j] = 0.0;
-    Kp[j] = 0.0;
+    const size_t row = (size_t)min(w0 + j, N - 1) * (size_t)nG;
+    const double Kv = in[j] * pref;
+    const double Kn = __shfl_down(Kv, 1, 64);
+    const double wi = w[row + ic], wn = w[row + (seg ? i + 1 : ic)];
+    const double dl = dlw[row + (seg ? i : 0)] + SSC_LOG(fabs(Kn * nh_rcp(Kv)));
+    double t = nh_seg_term(wi * Kv, wn * Kn, dl, lxi);
+    t = nh_wave_sum(seg ? t : 0.0);
+    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + (w0 + j)) * nE + k] = t;
   }
-  for (int i = s0; i <= s1 && s0 < s1; ++i) {  // nodes s0..s1 of the chunk
-    const double g = gam[i];
-    // inner reduction over the seed spectrum for W walkers at once
-    double in[W], u1[W];
-    const ssc_gk gk = ssc_setup(g, eg);
-    double f1 = ssc_fic(gk, rg[16], rg[17]);
-    // (the logarithm on every lane, a zero patched afterwards: behind a select the compiler
-    // puts it in a branch of its own, and the scalar loads of the step behind that branch)
-    double lf1 = SSC_LOG(fabs(f1)) + (f1 == 0.0 ? -INFINITY : 0.0);
-#pragma unroll
-    for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * rg[j]; }
-    const double* rp = rg;
-    double ie = rp[20], le = rp[21];  // the fic operands, one step ahead
-    for (int s = 1; s < ns; ++s) {
-      rp += SSC_REC;
-      const double ien = rp[20], len = rp[21];
-      const double f2 = ssc_fic(gk, ie, le);
-      ie = ien;
-      le = len;
-      // both zero for a whole wave (outside every lane's window): nothing to add
-      if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
-        double sd8[W], dl8[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          sd8[j] = rp[j];
-          dl8[j] = rp[W + j];
-        }
-        const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 16);  // (one load, one wait)
-        const double lxv = Lv.x, ilx = Lv.y, thr = Lv.z;
-        const double lf2 = SSC_LOG(fabs(f2)) + (f2 == 0.0 ? -INFINITY : 0.0);
-        // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
-        // segment contributes (u2 - u1) 0 = 0 (utils.py:347-348) without a test per walker
-        const double dlf = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx;
-        lf1 = lf2;
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          const double uo = u1[j], io = in[j];
-          const double u2 = f2 * sd8[j];
-          const double dl = dlf + dl8[j];
-          double t = fma(u2 - uo, nh_rcp1f(dl), io);
-          // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos
-          const bool small = fabs(dl) < thr;
-          if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
-            asm volatile("" ::: "memory");  // keep this a branch
-            const double d = dl * lxv;
-            double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
-            f = fma(f, d, 1.666666666666667e-01);
-            f = fma(f, d, 0.5);
-            f = fma(f, d, 1.0);
-            t = small ? fma(uo * lxv, f, io) : t;
-          }
-          in[j] = t;
-          u1[j] = u2;
-        }
-      } else {
-        lf1 = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < W; ++j) u1[j] = 0.0;
-      }
-      f1 = f2;
-    }
-    const double pref = (3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g);  // radiative.py:650-653
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const double Kv = in[j] * pref;
-      if (i > s0) {  // outer segment (i-1, i) of trapz_loglog(nelec*gamint, gam), :684
-        const double dl = dlw[row[j] + i - 1] + SSC_LOG(fabs(Kv * nh_rcp(Kp[j])));
-        acc[j] += nh_seg_term(w[row[j] + i - 1] * Kp[j], w[row[j] + i] * Kv, dl, lx[i - 1]);
-      }
-      Kp[j] = Kv;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < W; ++j) part[ch][j][lane] = acc[j];
-  __syncthreads();
-  if (ch == 0 && kvalid) {
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      if (w0 + j < N) {
-        double sum = 0.0;
-#pragma unroll
-        for (int c2 = 0; c2 < C; ++c2) sum += part[c2][j][lane];
-        partial[((long long)blockIdx.y * N + (w0 + j)) * nE + k] = sum;
-      }
-    }
-  }
+#undef SSC_LOG
 }
 
 __global__ void k_ssc_finish(const double* __restrict__ partial, int nsuper, int N, int nE,
@@ -406,14 +395,8 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
              "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
   constexpr int C = 8, W = SSC_W;
-  const int ktiles = (nE + 63) / 64;
   const int groups = (N + W - 1) / W;
-  const int nseg = nG - 1;
-  // super-chunks over gamma so that the launch has ~4 waves per SIMD
-  int nsuper = 1;
-  while (nsuper < 16 && (long long)ktiles * groups * nsuper * C < 4096 &&
-         nseg / ((nsuper * 2) * C) >= 4)
-    nsuper *= 2;
+  const int nsuper = (nG - 1 + SSC_TILE - 1) / SSC_TILE;  // tiles of the gamma grid
   const size_t nd = (size_t)groups * ns * SSC_REC;
   const size_t need = (nd + SSC_REC + (size_t)nsuper * N * nE) * sizeof(double);
   void* sc = nullptr;
@@ -424,8 +407,9 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   nh_prof_scope ps(c, NH_K_SSC);
   hipLaunchKernelGGL(k_ssc_prep, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream,
                      seed_E, seed_dens, N, ns, rec);
-  hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(ktiles * groups, nsuper), dim3(64 * C), 0,
-                     c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, rec, ns, partial);
+  hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(groups * nsuper, (nE + C - 1) / C),
+                     dim3(64 * C), 0, c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, rec, ns, nsuper,
+                     partial);
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                      partial, nsuper, N, nE, E_eV, out, ldo);
