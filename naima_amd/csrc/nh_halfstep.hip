@@ -74,6 +74,11 @@ struct hs_dev {
   int nblob, o_mrow;  // o_mrow: LDS offset of the model spectrum row + the moments' results
   int sendw, pad1;    // > 0: total[] holds rows { lnprob | blobs } of this width (sharded loop)
   long long* dbg;  // NH_HS_DEBUG=1: wall-clock stamps of the first 8 workgroups, [8][16]
+  // gridDim.y = K > 1 workgroups share a walker (launches of fewer walkers than the chip has
+  // CUs): their partial spectra meet in xspec[walker][K][nspec], the last to arrive (tick) sums
+  // them in a fixed order and carries on to the likelihood
+  double* xspec; int* tick;
+  int nspec, syn_nodes;  // syn_nodes: synchrotron nodes per thread and work item
 };
 
 // ... and its HOT part, passed by value: every pointer and size the first phases touch, so
@@ -126,13 +131,15 @@ struct nh_halfstep_plan {
   nh_pack* dev;      // device copy of the parameter packs
   int* words;        // device: done counter | hbase
   double* syn_c;     // device: the synchrotron grid's constants (k_syn_consts), or NULL
+  double* xspec;     // device: the partial spectra of a split launch, or NULL
+  int* tick;         // device: arrival counters of a split launch, or NULL
   size_t lds_bytes;
-  int threads, blocks;
+  int threads, blocks, split;  // split = K workgroups per walker (gridDim.y)
   long long* dbg;
 };
 
 // ints at the head of the LDS block (after qs/row/lg/acc)
-enum { HI_ME = 0, HI_PA, HI_READY, HI_CD, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
+enum { HI_ME = 0, HI_PA, HI_READY, HI_TICK, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
 #define HS_O_ROW 64
 #define HS_O_LG 72
 #define HS_O_ACC 76   // z, lnU, old logp, (pad)
@@ -367,6 +374,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
   const int j = blockIdx.x;
+  // K workgroups per walker (a launch of fewer walkers than the chip has CUs): each does the
+  // whole prologue and its share of the work items; blocks (j, part) sit on one XCD whenever
+  // the number of walkers is a multiple of 8 (linear block id = part gridDim.x + j)
+  const int K = gridDim.y, part = blockIdx.y;
   double* qs = sm;
   double* row = sm + HS_O_ROW;
   double* lg = sm + HS_O_LG;
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // moves was uploaded (every one adds 1 on its way out, nh_half_step_begin_block zeroes it):
   // launches completed = done / grid size, whatever this launch's own early finishers have
   // already added.  hbase = ensemble steps of the run completed before this block of moves.
-  const int cn = slice >= 0 ? slice : done_[0] / (int)gridDim.x;  // the slice worked on here
+  const int cn = slice >= 0 ? slice : done_[0] / (int)(gridDim.x * gridDim.y);  // the slice worked on here
   const int c = cn - 1;  // slice accepted by the previous launch
   const double* r = blk_ + (long long)cn * 3 * ns_;
   const int* idx = reinterpret_cast<const int*>(r + 2 * ns_);
@@ -648,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
   }
   // history of the step the previous launch closed: its descriptor (the last wave writes it)
-  const bool want_hist = F.hist != nullptr && c >= 1 && (c & 1);
+  const bool want_hist = F.hist != nullptr && c >= 1 && (c & 1) && part == 0;
   const bool hist_wave = wv == nwv - 1;
   double* hcoords = nullptr;
   double* hlogp = nullptr;
@@ -793,6 +804,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   __syncthreads();
   HS_STAMP(3);
   if (tid == 0 && j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
+  if (K > 1) {  // the work items of the other workgroups of this walker: their slots count as 0
+    for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
+    if (H.syn_grid >= 0)
+      for (int t = tid; t < D.syn_cdmax * H.syn_nE; t += T) sm[H.o_part_s + t] = 0.0;
+  }
   // the single-row tables (We, Wp) -> LDS, by the waves at the back of the workgroup that are
   // not tile waves (those search the synchrotron energies' live ranges now): they hold at most
   // one unit of nodes below, and nobody reads these before the next barrier
@@ -963,7 +979,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
     const bool syn_zero = !(nz >> H.syn_grid & 1);  // nothing to integrate: every spectrum value is 0
     if (nA > 0 && !syn_zero) {
-      Cd = (hi[HI_LIVE] / nA + HS_SYN_NODES - 1) / HS_SYN_NODES;
+      Cd = (hi[HI_LIVE] / nA + D.syn_nodes - 1) / D.syn_nodes;
       Cd = min(max(Cd, 1), D.syn_cdmax);
       nS = (nA * Cd + 63) >> 6;
     }
@@ -1036,6 +1052,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       int it = 0;
       if (lane == 0) it = atomicAdd(&hi[HI_CNT], 1);
       it = __builtin_amdgcn_readfirstlane(it);
+      if (K > 1) {  // this workgroup's share: one of every K items, rotating (the two kinds
+        if (it * K >= total) break;  // alternate: a fixed residue would take one kind only)
+        it = it * K + ((part + it) & (K - 1));
+        if (it >= total) continue;
+      }
       if (it >= total) break;
       bool is_tab;
       int ix;
@@ -1193,7 +1214,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         }
         sum *= sm[H.o_scale + tb.spec_off + k];
         spec[tb.spec_off + k] = sum;
-        tb.out[(long long)j * tb.ldo + k] = sum;
+        if (K == 1) tb.out[(long long)j * tb.ldo + k] = sum;
       }
     }
     if (has_syn) {
@@ -1215,6 +1236,42 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   }
   __syncthreads();
   HS_STAMP(8);
+  if (K > 1) {
+    // ---- 6b. the K workgroups of this walker meet: partial spectra out (write-through), one
+    // ticket each; whoever draws the last one sums all K partials in the order of their index
+    // (the result does not depend on who arrived when) and carries on.  Nobody waits.
+    // (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores, drained, before the ticket;
+    // sc1 loads behind it.  Nobody has read these lines earlier in this launch.)
+    unsigned long long* xs = reinterpret_cast<unsigned long long*>(D.xspec) +
+                             ((long long)j * K + part) * D.nspec;
+    for (int k = tid; k < D.nspec; k += T)
+      __hip_atomic_store(xs + k, (unsigned long long)__double_as_longlong(spec[k]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      hi[HI_TICK] = __hip_atomic_fetch_add(D.tick + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (hi[HI_TICK] != K - 1) {  // (the whole workgroup)
+      if (tid == 0) atomicAdd(H.done, 1);
+      return;
+    }
+    if (tid == 0) D.tick[j] = 0;  // for the next launch
+    const unsigned long long* xa = reinterpret_cast<const unsigned long long*>(D.xspec) +
+                                   (long long)j * K * D.nspec;
+    for (int k = tid; k < D.nspec; k += T) {
+      double sum = 0.0;
+      for (int q = 0; q < K; ++q)
+        sum += __longlong_as_double((long long)__hip_atomic_load(
+            xa + (long long)q * D.nspec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      spec[k] = sum;
+    }
+    __syncthreads();
+    for (int t = 0; t < D.ntab; ++t) {
+      const hs_tab& tb = D.tab[t];
+      for (int k = tid; k < tb.nK; k += T) tb.out[(long long)j * tb.ldo + k] = spec[tb.spec_off + k];
+    }
+  }
   if (has_syn)
     for (int k = tid; k < H.syn_nE; k += T)
       D.syn_out[(long long)j * D.syn_ldo + k] = spec[H.syn_spec_off + k];
@@ -1414,7 +1471,8 @@ extern "C" int nh_hist_append(nh_ctx* c, const double* coords, const double* log
   return NH_OK;
 }
 
-extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out) {
+static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int kmax,
+                     bool* lds_overflow) {
   NH_REQUIRE(c && d && out, "NULL pointer");
   NH_REQUIRE(d->coords && d->logp && d->blk && d->cursor && d->qT && d->factors && d->params &&
                  d->total, "NULL pointer in the descriptor");
@@ -1524,12 +1582,30 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   NH_REQUIRE(threads >= 128 && threads <= 1024 && threads % 64 == 0, "bad workgroup size");
   if (d->syn.grid >= 0 && threads / 64 < (d->syn.nE + 63) / 64 + 2) threads = 1024;
   NH_REQUIRE(threads / 64 > d->nmoms + 1, "more single-row reductions than waves");
+  // ---- a launch of fewer walkers than the chip has CUs: K workgroups per walker ----
+  // (each repeats the prologue -- on CUs that would otherwise idle -- and takes every K-th
+  // work item; the items are cut finer so that every wave of every workgroup still gets some)
+  int split = 1;
+  {
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    int devid = 0;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    // (worth it where the work items are most of a launch: measured on cfg2 / cfg3 at 128
+    // walkers per launch 42.3 -> 32.7 us and 33.8 -> 28.0 us; the hand-off costs ~3.5 us, which
+    // the table-only models cfg1 / cfg5 -- 7 us of items in a 17 us launch -- do not get back)
+    if (work >= (1 << 20))
+      while (split * 2 <= kmax && (long long)d->nloc * split * 2 <= ncu) split *= 2;
+  }
   // ---- table reductions: work items of `seg` segments x 64 columns ----
   // With a synchrotron component the items interleave with its (issue-bound) items and 32
   // segments keep the waves evenly loaded; without one, ONE round of equal items over the
   // waves that are free from the start (not on a single-row reduction) ends soonest.
   C.ntab = d->ntab;
-  int seg = 32;
+  int seg = split >= 4 ? 8 : (split == 2 ? 16 : 32);
+  C.syn_nodes = HS_SYN_NODES / split > 3 ? HS_SYN_NODES / split : 3;
   if (d->syn.grid < 0 && d->ntab > 0) {
     int tiles = 0, maxseg = 0;
     for (int t = 0; t < d->ntab; ++t) {
@@ -1537,7 +1613,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
       const int nseg = d->grids[d->tab[t].grid].nG - 1;
       maxseg = nseg > maxseg ? nseg : maxseg;
     }
-    const int free_waves = threads / 64 - d->nmoms;
+    const int free_waves = (threads / 64 - d->nmoms) * split;
     const int per_tile = free_waves / tiles > 1 ? free_waves / tiles : 1;
     seg = (maxseg + per_tile - 1) / per_tile;
     if (seg < 8) seg = 8;
@@ -1549,7 +1625,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
       const int nseg = d->grids[d->tab[t].grid].nG - 1;
       nT += tiles * ((nseg + seg - 1) / seg);
     }
-    if (nT <= 96) break;
+    if (nT <= (split > 1 ? 160 : 96)) break;
     seg *= 2;
   }
   C.seg = seg;
@@ -1582,6 +1658,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   C.nT = nT;
   H.o_part_t = off; off += nT * 64;
   H.o_spec = off; off += nspec;
+  C.nspec = nspec;
   H.o_lik = off; off += 5 * d->nE;
   H.o_scale = off; off += nspec;
   H.o_synE = off; off += syn_nE;
@@ -1628,6 +1705,7 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   C.pri.n = d->nterms;
   for (int t = 0; t < d->nterms; ++t) C.pri.t[t] = d->terms[t];
   const size_t lds = (size_t)off * sizeof(double);
+  if (lds > 150 * 1024) *lds_overflow = true;
   NH_REQUIRE(lds <= 150 * 1024, "the model's grids and tables do not fit in LDS");
   C.dbg = nullptr;
   if (const char* e = getenv("NH_HS_DEBUG"))
@@ -1640,9 +1718,12 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   P->lds_bytes = lds;
   P->threads = threads;
   P->blocks = d->nloc;
+  P->split = split;
   P->dev = nullptr;
   P->words = nullptr;
   P->syn_c = nullptr;
+  P->xspec = nullptr;
+  P->tick = nullptr;
   hipError_t e = hipMalloc(&P->dev, sizeof(packs_host));
   if (e == hipSuccess && H.syn_grid >= 0) {
     const int nGs = H.nG[H.syn_grid];
@@ -1652,6 +1733,11 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
                          H.xg[H.syn_grid], H.lx[H.syn_grid], nGs, P->syn_c);
       e = hipGetLastError();
     }
+  }
+  if (e == hipSuccess && split > 1) {
+    e = hipMalloc(&P->xspec, (size_t)d->nloc * split * nspec * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&P->tick, (size_t)d->nloc * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(P->tick, 0, (size_t)d->nloc * sizeof(int));
   }
   if (e == hipSuccess) e = hipMalloc(&P->words, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
@@ -1663,11 +1749,15 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
     if (P->dev) (void)hipFree(P->dev);
     if (P->words) (void)hipFree(P->words);
     if (P->syn_c) (void)hipFree(P->syn_c);
+    if (P->xspec) (void)hipFree(P->xspec);
+    if (P->tick) (void)hipFree(P->tick);
     if (P->dbg) (void)hipFree(P->dbg);
     delete P;
     return nh_set_error(NH_EHIP, "half-step plan: %s", hipGetErrorString(e));
   }
   H.C.pk = P->dev;
+  H.C.xspec = P->xspec;
+  H.C.tick = P->tick;
   H.done = P->words;
   H.hbase = P->words + 1;
   {  // the first scalar trip's block (hs_first)
@@ -1700,6 +1790,19 @@ extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_p
   return NH_OK;
 }
 
+// (a split launch cuts the work items finer and needs more LDS for their partial sums: where
+// that does not fit, fewer workgroups per walker)
+extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out) {
+  int kmax = 8;
+  if (const char* e = getenv("NH_HS_SPLIT")) kmax = atoi(e) > 0 ? atoi(e) : 1;
+  for (;;) {
+    bool lds_overflow = false;
+    const int rc = hs_create(c, d, out, kmax, &lds_overflow);
+    if (rc == NH_OK || !lds_overflow || kmax <= 1) return rc;
+    kmax >>= 1;
+  }
+}
+
 // A new block of moves has been uploaded to `blk`: the next launch proposes its slice
 // `first_slice` (0, unless the caller has already worked through the first slices of the block
 // by other means).  steps_before = ensemble steps of this run completed before this block of
@@ -1708,7 +1811,7 @@ extern "C" int nh_half_step_begin_block(nh_ctx* c, nh_halfstep_plan* P, int firs
                                         int steps_before) {
   NH_REQUIRE(c && P && first_slice >= 0 && steps_before >= 0, "bad argument");
   hipLaunchKernelGGL(k_set_word2, dim3(1), dim3(1), 0, c->stream, P->words,
-                     first_slice * P->blocks, steps_before);
+                     first_slice * P->blocks * P->split, steps_before);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -1717,7 +1820,7 @@ extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   NH_REQUIRE(c && P && P->dev, "bad argument");
   nh_prof_scope ps(c, NH_K_HALFSTEP);
   const hs_hot& H = P->hot;
-  hipLaunchKernelGGL(k_half_step, dim3((unsigned)P->blocks), dim3(P->threads), P->lds_bytes,
+  hipLaunchKernelGGL(k_half_step, dim3((unsigned)P->blocks, (unsigned)P->split), dim3(P->threads), P->lds_bytes,
                      c->stream, (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
                      P->dbg ? 1 : 0, H);
   NH_CHECK_HIP(hipGetLastError());
@@ -1752,6 +1855,8 @@ extern "C" int nh_half_step_destroy(nh_ctx* c, nh_halfstep_plan* P) {
   int rc = nh_sync(c);
   if (P->dev) (void)hipFree(P->dev);
   if (P->syn_c) (void)hipFree(P->syn_c);
+  if (P->xspec) (void)hipFree(P->xspec);
+  if (P->tick) (void)hipFree(P->tick);
   if (P->words) (void)hipFree(P->words);
   if (P->dbg) (void)hipFree(P->dbg);
   delete P;
