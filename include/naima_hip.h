@@ -472,6 +472,12 @@ int nh_half_step_begin_block(nh_ctx* ctx, nh_halfstep_plan* plan, int first_slic
 int nh_half_step_launch(nh_ctx* ctx, nh_halfstep_plan* plan, int slice);
 int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
                       long long* lds_bytes);
+/* workgroups per walker of the plan's launches: 1, or K = 2, 4, 8 where a launch holds fewer
+ * walkers than the device has compute units and the model's work items are most of a launch
+ * (each of the K workgroups repeats the prologue and takes every K-th work item; the last to
+ * arrive sums the partial spectra in index order and evaluates the likelihood: the results do
+ * not depend on arrival order).  NH_HS_SPLIT=<K> in the environment caps K (1: never split). */
+int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
 /* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the
  * first 8 workgroups of the last launch, out[8][16], followed by 4 x 16 per-wave figures of

@@ -104,6 +104,7 @@ _SIGS = {
     "nh_half_step_begin_block": [_dp, _dp, _i, _i],
     "nh_half_step_launch": [_dp, _dp, _i],
     "nh_half_step_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
+    "nh_half_step_split": [_dp, C.POINTER(_i)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_half_step_stamps": [_dp, _dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
@@ -602,8 +603,10 @@ class Context:
         _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))
         thr, blk, lds = _i(), _i(), _ll()
         _chk(_lib.nh_half_step_info(h, C.byref(thr), C.byref(blk), C.byref(lds)))
+        spl = _i()
+        _chk(_lib.nh_half_step_split(h, C.byref(spl)))
         plan["hs"] = dict(key=key, plan=h, keep=(conv, lpd, total, dd), threads=thr.value,
-                          blocks=blk.value, lds_bytes=lds.value)
+                          blocks=blk.value, lds_bytes=lds.value, split=spl.value)
         # where the step loop stands in the current block of moves
         self.call("nh_half_step_begin_block", h, f["pos"]["slice"], f["pos"]["steps"])
         self.call("nh_half_step_launch", h, -1)

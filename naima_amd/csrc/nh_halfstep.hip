@@ -1836,6 +1836,12 @@ extern "C" int nh_half_step_info(const nh_halfstep_plan* P, int* threads, int* b
   return NH_OK;
 }
 
+extern "C" int nh_half_step_split(const nh_halfstep_plan* P, int* split) {
+  NH_REQUIRE(P && split, "bad argument");
+  *split = P->split;
+  return NH_OK;
+}
+
 // NH_HS_DEBUG=1: the phase stamps (100 MHz wall clock) of the first 8 workgroups of the
 // last launch, out[8][16], then for workgroup 0 per wave: end of its work items [16], table
 // items taken [16], synchrotron items taken [16], start of its first item [16]

@@ -139,3 +139,48 @@ def test_one_launch_half_step_with_more_grid_nodes_than_register_units(na):
     assert_allclose(sd.coords, sh.coords, rtol=1e-8)
     assert_allclose(sd.log_prob, sh.log_prob, rtol=1e-6)
     assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+
+
+@pytest.mark.parametrize("cfg,nw,steps", [("cfg3", 256, 150), ("cfg2", 256, 150), ("cfg3", 24, 60)],
+                         ids=["cfg3-256", "cfg2-256", "cfg3-24"])
+def test_split_launch_equals_unsplit_launch(na, monkeypatch, cfg, nw, steps):
+    """A launch of fewer walkers than the chip has compute units gives K workgroups to every
+    walker; their partial spectra meet through device memory inside the launch (write-through
+    stores, an arrival ticket, the last arriver sums in index order).  Tens of thousands of
+    such hand-offs, blobs kept, against the same loop with one workgroup per walker
+    (NH_HS_SPLIT=1) and against the host-driven loop: a stale or torn partial would show as a
+    wrong spectrum (the blobs), a wrong log-probability and, from there on, another chain."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, cfg, {})
+    nd = p0.size
+    kw = dict(args=[data, model, prior], seed=23, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.01 * np.random.default_rng(8).standard_normal((nw, nd)))
+    runs = {}
+    for k in ("1", "8"):
+        monkeypatch.setenv("NH_HS_SPLIT", k)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        st = d.run_mcmc(pos, 2)
+        st = d.run_mcmc(st, steps - 2)
+        hs = d._dev._plan["hs"]
+        assert hs is not None and d._dev.mega
+        runs[k] = (hs["split"], st, d.get_chain(), d.get_log_prob(), d.get_blobs(),
+                   d.acceptance_fraction)
+    assert runs["1"][0] == 1
+    assert runs["8"][0] == (2 if nw == 256 else 8)  # (nw/2 walkers per launch, 256 CUs)
+    (_, s1, c1, l1, b1, a1), (_, s8, c8, l8, b8, a8) = runs["1"], runs["8"]
+    assert_allclose(c8, c1, rtol=1e-8)
+    assert_allclose(l8, l1, rtol=1e-6)
+    assert_allclose(a8, a1)
+    for x, y in zip(b8, b1):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
+                        atol=1e-300, equal_nan=True)
+    # twice the same split run: the sum of the partials does not depend on who arrived last
+    monkeypatch.setenv("NH_HS_SPLIT", "8")
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    st = d.run_mcmc(pos, 2)
+    st = d.run_mcmc(st, steps - 2)
+    assert np.array_equal(d.get_chain(), c8) and np.array_equal(d.get_log_prob(), l8)
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    sh = h.run_mcmc(pos, 2)
+    sh = h.run_mcmc(sh, 38)
+    assert_allclose(c8[:40], h.get_chain(), rtol=1e-8)
