@@ -50,10 +50,10 @@ KERNEL_FLOP_EQ = {
     "cfg2": {"synchrotron": 179 * 300 * 50.0},
     "cfg1": {"integrate_tables": 28 * 570 * 30.0},
     "cfg5": {"integrate_tables": 28 * 600 * 30.0},
-    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 36 eq. each: per
-    # walker a reciprocal (20) + mul, add, sub, cmp, three fma (10); its share (1/8: a wave
-    # serves 8 walkers) of the Aharonian-Atoyan kernel (12) and its logarithm (20 + 24) = 7
-    "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * 36.0},
+    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 34 eq. each: per
+    # walker a reciprocal (20) + mul, add, sub, cmp, three fma (10); its share (1/16: a wave
+    # serves 16 walkers) of the Aharonian-Atoyan kernel (12) and its logarithm (20 + 24) = 4
+    "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * 34.0},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
 KERNEL_SYMBOL = {"half_step": "k_half_step", "integrate_tables": "k_integrate_tables",
@@ -128,7 +128,7 @@ def executed_flop_eq(name, raw, coords):
             if prev is not None:
                 live += int((on | prev).sum())
             prev = on
-        out["ic_seed_walkers"] = live * 36.0
+        out["ic_seed_walkers"] = live * 34.0
         return out
     if "synchrotron" not in out:
         return out
@@ -444,7 +444,7 @@ def main():
                                           "from the final ensemble's B, mean over walkers; "
                                           "the SSC seed kernel (cfg4) is credited with the "
                                           "seed-axis segments inside the Aharonian-Atoyan "
-                                          "kernel's windows, 36 eq. each"}
+                                          "kernel's windows, 34 eq. each"}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out), flush=True)

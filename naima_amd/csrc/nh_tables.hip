@@ -135,13 +135,14 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
 // The gamma range is additionally split over gridDim.y; the partial sums are reduced
 // deterministically by k_ssc_finish.
 //
-// The kernel is bound by instruction issue (5 waves per SIMD, no memory traffic to speak
-// of), so the seed-axis step is written for its instruction count -- 136 VALU instructions
-// for the 8 walkers of a wave against ~400 in the first version, whose ISA showed where they
-// went: a double-double library log per node (110), two scalar loads WITH their wait and ten
-// address instructions per walker, exec-mask branches for the window's Heaviside factors:
+// The kernel is bound by instruction issue (no memory traffic to speak of), so the seed-axis
+// step is written for its instruction count -- ~57 VALU instructions per node + 10 per
+// walker against ~400 for 8 walkers in the first version, whose ISA showed where they went: a
+// double-double library log per node (110), two scalar loads WITH their wait and ten address
+// instructions per walker, exec-mask branches for the window's Heaviside factors:
 //   * the walkers' densities and log-ratios are transposed by k_ssc_prep to [group][s][W]:
-//     two 64-byte scalar loads per seed node fetch them for all W walkers of the wave;
+//     two 64-byte scalar loads per seed node fetch them for eight walkers of the wave (W = 16:
+//     the second eight's are on their way while the first eight are worked on);
 //   * the log-ratios are divided by ln(eps_{s+1}/eps_s) there, so that a segment term is
 //     (u2 - u1) / dl' -- no multiplication by lx per walker (dl' = dl / lx; the series
 //     threshold |dl| < 2^-10 becomes |dl'| < 2^-10 / lx, a scalar per seed node);
@@ -150,25 +151,26 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
 //   * the window as ONE product (1 - q)(q - qmin) > 0 (qmin < 1: never both negative), the
 //     reference's value 0.5 at an edge behind a wave-uniform branch nobody takes.
 // ---------------------------------------------------------------------------
-#define SSC_W 8
-#define SSC_REC 24  // doubles per (group, seed node) record
+#define SSC_REC(W) (2 * (W) + 8)  // doubles per (group, seed node) record; W walkers per group
 // Everything a wave needs at seed node s, as ONE record behind ONE pointer (three wide scalar
 // loads at fixed offsets; separate arrays cost four address computations per node and the
 // scalar registers to hold them):
 //   [0, W)    n_w(eps0_s) of the group's W walkers, 1/(mec2 cm3)       (radiative.py:639)
 //   [W, 2W)   ln(n_w(eps0_s)/n_w(eps0_{s-1})) / lx of the segment that ENDS at s
-//   [16, 20)  lx = ln(eps0_s/eps0_{s-1}), 1/lx, 2^-10/lx (series threshold in units of
-//             dl' = dl/lx), 0       -- record 0: 1/eps0_0, 2 ln eps0_0 in [16], [17]
-//   [20, 22)  1/eps0_{s+1}, 2 ln eps0_{s+1} (in mec2): the NEXT node's fic operands
+//   [2W, 2W+4)  lx = ln(eps0_s/eps0_{s-1}), 1/lx, 2^-10/lx (series threshold in units of
+//               dl' = dl/lx), 0     -- record 0: 1/eps0_0, 2 ln eps0_0 in the first two
+//   [2W+4, 2W+6)  1/eps0_{s+1}, 2 ln eps0_{s+1} (in mec2): the NEXT node's fic operands
+template <int SSC_W>
 __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restrict__ sd, int N,
                            int ns, double* __restrict__ rec) {
-  static_assert(2 * SSC_W == 16 && SSC_REC == 24, "record layout");
+  constexpr int REC = SSC_REC(SSC_W);
+  static_assert((SSC_W & (SSC_W - 1)) == 0 && REC % 4 == 0, "record layout");
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int groups = (N + SSC_W - 1) / SSC_W;
-  if (idx >= (long long)groups * ns * SSC_REC) return;
-  const int slot = (int)(idx % SSC_REC);
-  const int s = (int)((idx / SSC_REC) % ns);
-  const int grp = (int)(idx / ((long long)SSC_REC * ns));
+  if (idx >= (long long)groups * ns * REC) return;
+  const int slot = (int)(idx % REC);
+  const int s = (int)((idx / REC) % ns);
+  const int grp = (int)(idx / ((long long)REC * ns));
   double v = 0.0;
   if (slot < 2 * SSC_W) {
     const long long w = min(grp * SSC_W + (slot & (SSC_W - 1)), N - 1);
@@ -179,18 +181,20 @@ __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restri
       const double a = sd[w * ns + s - 1];
       v = (a == 0.0 || b == 0.0) ? NH_DL_ZERO : log(fabs(b / a)) / log(se[s] / se[s - 1]);
     }
-  } else if (slot < 20) {
+  } else if (slot < 2 * SSC_W + 4) {
+    const int q = slot - 2 * SSC_W;
     if (s > 0) {
       const double lx = log(se[s] / se[s - 1]);
-      v = slot == 16 ? lx : slot == 17 ? 1.0 / lx : slot == 18 ? NH_SEG_SMALL_POS / lx : 0.0;
-    } else if (slot == 16) {
+      v = q == 0 ? lx : q == 1 ? 1.0 / lx : q == 2 ? NH_SEG_SMALL_POS / lx : 0.0;
+    } else if (q == 0) {
       v = NH_MEC2_EV / se[0];
-    } else if (slot == 17) {
+    } else if (q == 1) {
       v = 2.0 * log(se[0] / NH_MEC2_EV);
     }
   } else if (s + 1 < ns) {
+    const int q = slot - 2 * SSC_W - 4;
     const double e = se[s + 1] / NH_MEC2_EV;
-    v = slot == 20 ? 1.0 / e : slot == 21 ? 2.0 * log(e) : 0.0;
+    v = q == 0 ? 1.0 / e : q == 1 ? 2.0 * log(e) : 0.0;
   }
   rec[idx] = v;
 }
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
     const double* __restrict__ E_eV, int nE, const double* __restrict__ rec, int ns, int ntile,
     double* __restrict__ partial) {
-  static_assert(W == SSC_W, "k_ssc_prep transposes for groups of SSC_W walkers");
+  constexpr int REC = SSC_REC(W);
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x % ntile, grp = blockIdx.x / ntile;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
   const bool seg = lane < SSC_TILE && i + 1 < nG;  // ... and the segment that starts there
   const int ic = node ? i : nG - 1;
   const double g = gam[ic];
-  const double* __restrict__ rg = rec + (size_t)grp * ns * SSC_REC;  // this group's records
+  const double* __restrict__ rg = rec + (size_t)grp * ns * REC;  // this group's records
   // the coefficients of ssc_log in scalar registers: v_fma_f64 takes them as they are (from
   // vector registers the compiler copies each one into the destination of a v_fmac first)
   double L0 = 1.479819860511658591e-01, L1 = 1.531383769920937332e-01;
@@ -300,17 +304,17 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
   double in[W], u1[W];
   ssc_gk gk = ssc_setup(g, eg);
   gk.valid = gk.valid && node;
-  double f1 = ssc_fic(gk, rg[16], rg[17]);
+  double f1 = ssc_fic(gk, rg[2 * W], rg[2 * W + 1]);
   // (the logarithm on every lane, a zero patched afterwards: behind a select the compiler
   // puts it in a branch of its own, and the scalar loads of the step behind that branch)
   double lf1 = SSC_LOG(fabs(f1)) + (f1 == 0.0 ? -INFINITY : 0.0);
 #pragma unroll
   for (int j = 0; j < W; ++j) { in[j] = 0.0; u1[j] = f1 * rg[j]; }
   const double* rp = rg;
-  double ie = rp[20], le = rp[21];  // the fic operands, one step ahead
+  double ie = rp[2 * W + 4], le = rp[2 * W + 5];  // the fic operands, one step ahead
   for (int s = 1; s < ns; ++s) {
-    rp += SSC_REC;
-    const double ien = rp[20], len = rp[21];
+    rp += REC;
+    const double ien = rp[2 * W + 4], len = rp[2 * W + 5];
     const double f2 = ssc_fic(gk, ie, le);
     ie = ien;
     le = len;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
         sd8[j] = rp[j];
         dl8[j] = rp[W + j];
       }
-      const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 16);  // (one load, one wait)
+      const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 2 * W);  // (one load, one wait)
       const double lxv = Lv.x, ilx = Lv.y, thr = Lv.z;
       const double lf2 = SSC_LOG(fabs(f2)) + (f2 == 0.0 ? -INFINITY : 0.0);
       // +-inf / NaN where a node is zero -> +-1e300: the reciprocal underflows to 0 and the
@@ -394,22 +398,30 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)N * ns < (1LL << 31),
              "arrays too large for 32-bit element offsets");
   if (N == 0) return NH_OK;
-  constexpr int C = 8, W = SSC_W;
+  // W walkers share a wave's kernel evaluations: 16 where there are that many (the second
+  // eight walkers' scalars are fetched while the first eight are worked on), else 8
+  constexpr int C = 8;
+  const int W = N > 8 ? 16 : 8;
   const int groups = (N + W - 1) / W;
   const int nsuper = (nG - 1 + SSC_TILE - 1) / SSC_TILE;  // tiles of the gamma grid
-  const size_t nd = (size_t)groups * ns * SSC_REC;
-  const size_t need = (nd + SSC_REC + (size_t)nsuper * N * nE) * sizeof(double);
+  const size_t nd = (size_t)groups * ns * SSC_REC(W);
+  const size_t need = (nd + SSC_REC(W) + (size_t)nsuper * N * nE) * sizeof(double);
   void* sc = nullptr;
   int rc = nh_scratch(c, need, &sc);
   if (rc) return rc;
   double* rec = static_cast<double*>(sc);
-  double* partial = rec + nd + SSC_REC;
+  double* partial = rec + nd + SSC_REC(W);
   nh_prof_scope ps(c, NH_K_SSC);
-  hipLaunchKernelGGL(k_ssc_prep, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream,
-                     seed_E, seed_dens, N, ns, rec);
-  hipLaunchKernelGGL((k_ic_seed_walkers<C, W>), dim3(groups * nsuper, (nE + C - 1) / C),
-                     dim3(64 * C), 0, c->stream, w, dlw, N, gam, lx, nG, E_eV, nE, rec, ns, nsuper,
-                     partial);
+  const dim3 gp((unsigned)((nd + 255) / 256)), gk(groups * nsuper, (nE + C - 1) / C);
+  if (W == 16) {
+    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL((k_ic_seed_walkers<C, 16>), gk, dim3(64 * C), 0, c->stream, w, dlw, N, gam,
+                       lx, nG, E_eV, nE, rec, ns, nsuper, partial);
+  } else {
+    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL((k_ic_seed_walkers<C, 8>), gk, dim3(64 * C), 0, c->stream, w, dlw, N, gam,
+                       lx, nG, E_eV, nE, rec, ns, nsuper, partial);
+  }
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                      partial, nsuper, N, nE, E_eV, out, ldo);
