@@ -10,11 +10,13 @@
 // OCML cbrt/sqrt/div/exp/log):
 //   cbrt(x)     = cbrt(q) * gamma_i^(-2/3): one cube root per THREAD, the grid part
 //                 is tabulated in LDS together with 1/gamma^2 and its difference;
-//   1/sqrt, 1/y = single-precision v_rsq/v_rcp seed + two Newton steps (well-scaled operands);
-//   exp(-x)     = Cody-Waite reduction + degree-13 Taylor (three-address FMAs, coefficients
-//                 in scalar registers) + v_ldexp_f64;
-//   ln(P2/P1)   = 2 atanh(s), s = (P2-P1)/(P2+P1), 5-term series (adjacent nodes
-//                 differ by a few per cent), log() only on coarse grids.
+//   P(x)        = ONE reciprocal square root (single-precision v_rsq seed + two Newton steps)
+//                 for 1/sqrt(1 + 3.4 cb^2) and 1/gt3 together (nh_syn.h: syn_P1);
+//   exp(-x)     = 64-entry 2^(j/64) table in LDS + degree-5 polynomial + v_ldexp_f64;
+//   ln(P2/P1)   = 2 atanh(s), s = (P2-P1)/(P2+P1), 3-term series on naima's default grid
+//                 density, 5 terms up to s^2 = 9e-4, log() only on coarser grids.
+// (the node arithmetic of the half-step kernel, nh_halfstep.hip; round 1's degree-13 Horner
+// exp and separate rsqrt + reciprocal cost ~115 instructions per node, this ~75)
 #include "nh_lnprob.h"
 #include "nh_syn.h"
 #include <cstdlib>
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
   __shared__ int ai0[64];    //                       -> its first segment that can contribute
   __shared__ int s_nA;
   __shared__ double synv[64];  // EPI: this walker's spectrum, by energy index
+  __shared__ double T64[64];   // 2^(j/64): the table of nh_exp_tab
   constexpr int T = 64 * C;
   const int tid = threadIdx.x;
   // EPI: the LAST wave (the first one is on the critical path of the liveness search)
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     dig2[i] = d;
   }
   if (tid == 0) s_nA = 0;
+  if (tid >= T - 64) T64[tid - (T - 64)] = exp2((double)(tid - (T - 64)) * 0.015625);
   __syncthreads();
 
   // a tile = tw (<= 64) photon energies, INTERLEAVED over the ktiles tiles (energy
@@ -140,26 +144,40 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     const double* wr = w + (long long)wi * nG;
     const double* dwr = dlw + (long long)wi * nG;
     if (s0 < s1) {
-      double u1 = 0.0, P1 = 1.0;
-      {
-        const double x = q * ig2[s0];
-        if (x <= 746.0) {
-          P1 = syn_P(cbq * ig23[s0]);
-          u1 = wr[s0] * (P1 * nh_exp_neg(x));  // gamma nelec dNdE / CS1, :335-338
-        }
-      }
-      for (int s = s0; s < s1; ++s) {
-        const double x = q * ig2[s + 1];
-        double u2 = 0.0, P2 = 1.0;
-        if (x <= 746.0) {
-          P2 = syn_P(cbq * ig23[s + 1]);
-          u2 = wr[s + 1] * (P2 * nh_exp_neg(x));
-        }
+      // The node arithmetic of the half-step kernel (nh_syn.h: table-driven exp, one reciprocal
+      // square root for P, 3-term atanh for ln(P2/P1) on naima's default grid density, the
+      // non-negative segment form): ~75 instructions per node against ~115.  No branch: a dead
+      // node (x > 746: exp(-x) == 0 in double; a zero weight) is computed like any other and
+      // zeroed by a select, two nodes per trip are one straight block.
+      auto node = [&](int sn, double& u, double& P) {
+        const double x = q * ig2[sn];
+        const double wn = wr[sn];
+        const bool on = x <= 746.0 && wn != 0.0;  // (NaN: off)
+        const double Pv = syn_P1(cbq * ig23[sn]);
+        const double ev = nh_exp_tab(-fmin(x, 800.0), T64);
+        u = on ? wn * (Pv * ev) : 0.0;  // gamma nelec dNdE / CS1, :335-338
+        P = on ? Pv : 1.0;
+      };
+      double u1, P1;
+      node(s0, u1, P1);
+      int s = s0;
+      for (; s + 2 <= s1; s += 2) {
+        double uA, PA, uB, PB;
+        node(s + 1, uA, PA);
+        node(s + 2, uB, PB);
         // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
-        const double dl = dwr[s] + syn_dlnP(P1, P2) - q * dig2[s];
-        acc += nh_seg_term<false>(u1, u2, dl, lx[s]);  // P(x) exp(-x) > 0: one sign
-        u1 = u2;
-        P1 = P2;
+        const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
+        const double dlB = dwr[s + 1] + syn_dlnP1(PA, PB) - q * dig2[s + 1];
+        acc += nh_seg_pos<true>(u1, uA, dlA, lx[s]);  // P(x) exp(-x) >= 0: one sign
+        acc += nh_seg_pos<true>(uA, uB, dlB, lx[s + 1]);
+        u1 = uB;
+        P1 = PB;
+      }
+      if (s < s1) {
+        double uA, PA;
+        node(s + 1, uA, PA);
+        const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
+        acc += nh_seg_pos<true>(u1, uA, dlA, lx[s]);
       }
     }
     part[ch * 64 + a] = acc * cs1;  // the terms are linear in u: CS1 once per thread

@@ -2,6 +2,8 @@
 # (separate passes), SQ counters, the per-phase stamps, bench lines of every workload, shard table
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+(time timeout 1500 python -m pytest tests -m gpu -x -q) > gpurun_out/r2_gputest.log 2>&1
+tail -4 gpurun_out/r2_gputest.log
 O=gpurun_out/r2prof
 rm -rf $O; mkdir -p $O
 CMD="python bench.py --steps 20 --warmup 5 --no-cpu --no-blobs-run"
@@ -30,12 +32,18 @@ for k, v in res.items():
     if 'half_step' in k:
         print(k, json.dumps({c: round(x, 1) for c, x in v.items() if not c.startswith("launches")}))
 PY
+# cfg4 (Crab Syn+SSC): per-kernel totals of its three-launch loop + the SSC seed kernel
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o cfg4stats -- python bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run > $O/cfg4_bench_under_rocprof.json 2> $O/err_cfg4stats.log
+head -8 $O/cfg4stats_kernel_stats.csv | cut -c1-200
 head -12 $O/stats_kernel_stats.csv | cut -c1-200
 cut -c1-600 $O/bench_under_rocprof.json
 # un-profiled bench lines
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1_default.json 2> $O/err_bench.log
 for w in cfg1 cfg2 cfg5; do timeout 600 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu > $O/bench_$w.json 2>> $O/err_bench.log; done
 timeout 600 python bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run > $O/bench_cfg4.json 2>> $O/err_bench.log
+timeout 600 python bench.py --workload cfg3 --walkers 256 --steps 200 --warmup 20 --no-cpu > $O/bench_cfg3_w256_split.json 2>> $O/err_bench.log
+NH_HS_SPLIT=1 timeout 600 python bench.py --workload cfg3 --walkers 256 --steps 200 --warmup 20 --no-cpu > $O/bench_cfg3_w256_nosplit.json 2>> $O/err_bench.log
+NH_HS_SPLIT=1 timeout 600 python bench.py --workload cfg2 --steps 200 --warmup 20 --no-cpu > $O/bench_cfg2_nosplit.json 2>> $O/err_bench.log
 timeout 600 python bench.py --workload cfg5 --scaling strong --walkers-total 2048 --steps 100 --warmup 10 --no-cpu --no-blobs-run > $O/bench_cfg5_strong2048_n1.json 2>> $O/err_bench.log
 timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu --ball 0.005 > $O/bench_cfg3_ball0005.json 2>> $O/err_bench.log
 python - <<'PY'
