@@ -834,3 +834,44 @@ def test_edge_shapes_against_oracle(na):
     check(N=257, nE=70, Eemin_eV=1e10, Eemax_eV=1e13, nEed=1000, Elo=1e-2, Ehi=1e12, B0=50.0)  # 3000 nodes
     check(N=5, nE=7, Eemin_eV=1e9, Eemax_eV=1e14, nEed=30, Elo=1e12, Ehi=1e14, B0=3.0)  # synchrotron all dead
     check(N=64, nE=130, Eemin_eV=1e8, Eemax_eV=5e16, nEed=10, Elo=1e-5, Ehi=1e13, B0=100.0)  # coarse grid
+
+
+def test_ssc_seed_edge_shapes_against_oracle(na):
+    """nh_ic_seed_walkers (a seed density per walker, radiative.py:609-655 + 684) at the shapes
+    its mapping cares about: 1 / 9 / 17 / 33 walkers (groups of 8 and of 16, padded groups), a
+    seed spectrum of two nodes, seed nodes with ZERO density (the trapz_loglog zero rule,
+    utils.py:347-348) at the ends and in the middle, a particle grid shorter than a wave's 64
+    nodes and one that needs several gamma tiles, one photon energy"""
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(3)
+
+    def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=()):
+        E = np.geomspace(1e3, 3e13, nE) if nE > 1 else np.array([2e9])
+        se = np.geomspace(1e-6, 1e4, ns)
+        base = 1e3 * (se / 1e-2) ** -1.4 * np.exp(-se / 2e3)
+        sd = base[None, :] * 10 ** (0.3 * rng.standard_normal((N, ns)))
+        for z in zeros:
+            sd[:, z] = 0.0
+        if zeros and N > 2:
+            sd[1, ns // 3] = 0.0  # ... and a zero that only one walker has
+        amp = 10 ** (33 + 0.05 * rng.standard_normal(N))
+        alpha = 2.3 + 0.1 * rng.standard_normal(N)
+        pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, 30 * u.TeV)
+        seed = ["ssc", se * u.eV, u.Quantity(sd, u.Unit("1/(eV cm3)"))]
+        ic = na.InverseCompton(pd, seed_photon_fields=[seed], Eemin=Eemin_eV * u.eV,
+                               Eemax=Eemax_eV * u.eV, nEed=nEed)
+        got = np.asarray(ic.flux(E * u.eV if nE > 1 else E[0] * u.eV, 0).value).reshape(N, nE)
+        gam = O.electron_grid(Eemin_eV, Eemax_eV, nEed)
+        for i in sorted(set([0, 1 % N, N // 2, N - 1])):
+            opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13,
+                                 alpha=alpha[i], e_cutoff=30e12, beta=1.0)
+            ne = O.nelec_on(opd, gam)
+            ref = O.ic_seed_spectrum(E, gam, ne, dict(type="array", energy=se, density=sd[i]))
+            assert_allclose(got[i], ref, rtol=RT, atol=np.abs(ref).max() * 1e-200)
+
+    check(N=1, ns=12, nE=9, Eemin_eV=1e9, Eemax_eV=1e14, nEed=20)
+    check(N=9, ns=2, nE=5, Eemin_eV=1e9, Eemax_eV=1e13, nEed=10)        # two seed nodes, 40 nodes
+    check(N=17, ns=30, nE=70, Eemin_eV=1e8, Eemax_eV=1e15, nEed=40, zeros=(0, 29, 11))  # 280 nodes
+    check(N=33, ns=25, nE=1, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, zeros=(5,))  # 17 -> 10 nodes
+    check(N=8, ns=40, nE=66, Eemin_eV=1e10, Eemax_eV=1e13, nEed=100)      # 300 nodes, 5 tiles
