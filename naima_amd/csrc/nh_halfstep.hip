@@ -1606,6 +1606,8 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   C.ntab = d->ntab;
   int seg = split >= 4 ? 8 : (split == 2 ? 16 : 32);
   C.syn_nodes = HS_SYN_NODES / split > 3 ? HS_SYN_NODES / split : 3;
+  if (const char* e = getenv("NH_HS_SEG")) seg = atoi(e) >= 4 ? atoi(e) : seg;  // (tuning experiments)
+  if (const char* e = getenv("NH_HS_SYN_NODES")) C.syn_nodes = atoi(e) >= 1 ? atoi(e) : C.syn_nodes;
   if (d->syn.grid < 0 && d->ntab > 0) {
     int tiles = 0, maxseg = 0;
     for (int t = 0; t < d->ntab; ++t) {

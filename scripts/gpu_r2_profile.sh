@@ -7,7 +7,7 @@ tail -4 gpurun_out/r2_gputest.log
 O=gpurun_out/r2prof
 rm -rf $O; mkdir -p $O
 CMD="python bench.py --steps 20 --warmup 5 --no-cpu --no-blobs-run"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- $CMD > $O/bench_under_rocprof.json 2> $O/err_stats.log
+bash scripts/gpu_r2_stats.sh
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O -o fetch -- $CMD > /dev/null 2> $O/err_fetch.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O -o write -- $CMD > /dev/null 2> $O/err_write.log
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O -o tcc -- $CMD > /dev/null 2> $O/err_tcc.log
