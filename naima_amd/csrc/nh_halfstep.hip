@@ -900,7 +900,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
     lv_live = lv_i0 < nG;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
-    int ln = lv_live ? (nG - 1) - max(lv_i0 - 1, 0) : 0;  // segments this energy walks
+    int ln = lv_live ? (nG - 1) - lv_i0 : 0;  // segments this energy walks
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
     if (lane == 0) {
@@ -998,7 +998,9 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       if (lv_live) {
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
         amap[pos] = lv_k;
-        ai0[pos] = max(lv_i0 - 1, 0);
+        // from the first LIVE node on: the segment to its left has a zero node and contributes
+        // an exact 0 (utils.py:347-348) -- no dead node inside a range, no zero test per segment
+        ai0[pos] = lv_i0;
         sq[pos] = lv_q;
         sq[nEs + pos] = cbrt(lv_q);
         // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
@@ -1141,21 +1143,17 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           const double q = sq[a], cbq = sq[nEs + a];
           double acc = 0.0;
           if (s0 < s1) {
-            // One node: gamma nelec dNdE / CS1 (radiative.py:335-338) and P.  No branch: a dead
-            // node (x > 746: exp(-x) == 0 in double; a zero weight: an exact zero) is computed
-            // like any other and zeroed by a select -- inside the live range the liveness search
-            // left, that is the first node at most -- so that TWO nodes per trip are one
-            // straight block the scheduler can interleave.  (One node per trip, behind a branch,
-            // is a dependent chain of ~70 FP64 instructions: a wave alone took 21 cycles per
-            // instruction, four waves per SIMD kept it 40 % busy.)
+            // One node: gamma nelec dNdE / CS1 (radiative.py:335-338) and P.  No branch and no
+            // select: every node of the range is live (x <= 746, the liveness search), a zero
+            // weight gives u = 0 by itself (P is finite), so TWO nodes per trip are one straight
+            // block the scheduler can interleave.  (One node per trip, behind a branch, is a
+            // dependent chain of ~70 FP64 instructions: a wave alone took 21 cycles per
+            // instruction, four waves per SIMD kept it 40 % busy.)  A weight that has underflowed
+            // to 0 ends the integrand like a table's zero entry does (nh_seg_pos<false>).
             auto node = [&](int sn, double& u, double& P) {
               const double x = q * ig2[sn];
-              const double w = wr[sn];
-              const bool on = x <= 746.0 && w != 0.0;  // (NaN: off, as before)
-              const double Pv = syn_P1(cbq * ig23[sn]);
-              const double ev = nh_exp_tab(-fmin(x, 800.0), T64);
-              u = on ? w * (Pv * ev) : 0.0;
-              P = on ? Pv : 1.0;
+              P = syn_P1(cbq * ig23[sn]);
+              u = wr[sn] * (P * nh_exp_tab(-fmin(x, 800.0), T64));
             };
             double u1, P1;
             node(s0, u1, P1);
@@ -1167,8 +1165,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
               // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
               const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
               const double dlB = dwr[s + 1] + syn_dlnP1(PA, PB) - q * dig2[s + 1];
-              acc += nh_seg_pos<true>(u1, uA, dlA, lxs[s]);  // P(x) exp(-x) >= 0
-              acc += nh_seg_pos<true>(uA, uB, dlB, lxs[s + 1]);
+              acc += nh_seg_pos<false>(u1, uA, dlA, lxs[s]);  // P(x) exp(-x) >= 0
+              acc += nh_seg_pos<false>(uA, uB, dlB, lxs[s + 1]);
               u1 = uB;
               P1 = PB;
             }
@@ -1176,7 +1174,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
               double uA, PA;
               node(s + 1, uA, PA);
               const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
-              acc += nh_seg_pos<true>(u1, uA, dlA, lxs[s]);
+              acc += nh_seg_pos<false>(u1, uA, dlA, lxs[s]);
             }
           }
           part_s[ch * nEs + a] = acc * sq[2 * nEs + a];  // linear in u: CS1 once per thread
