@@ -417,12 +417,16 @@ int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NP
  * KD[(i*nK + k)*2 + {0,1}] = {Kt[i][k], dlnKt[i][k]} (nh_table_interleave).  Where column k
  * changes sign between nodes i and i+1 the second entry is NaN: that segment takes the
  * reference's log branch (NaN exponent b, utils.py:336-345) -- decided once per table, the
- * sign pattern does not depend on the walker. */
+ * sign pattern does not depend on the walker.  A table declared `nonnegative` to the half-step
+ * plan is built WITH lx = ln(x[i+1]/x[i]) of its grid: its second entries are dlnKt / lx (the
+ * kernel then integrates a segment as (u2 - u1) / (dl / lx), utils.py:336-339 without the
+ * multiplication); other tables with lx = NULL. */
 typedef struct { int grid; int nK; int ldo; int nonnegative;
                  const double* KD; const double* reserved; const double* scale /*[nK] or NULL*/;
                  double* out /*[nloc][ldo]*/; } nh_hs_table;
-int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt, int nG, int nK,
-                        double* KD /*[2 nG nK]*/);
+int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt,
+                        const double* lx /*[nG-1] device, or NULL*/, int nG, int nK,
+                        double* KD);
 typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
                  int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB; int pad;
                  const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;

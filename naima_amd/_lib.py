@@ -109,7 +109,7 @@ _SIGS = {
     "nh_half_step_stamps": [_dp, _dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
                             _dp],
-    "nh_table_interleave": [_dp, _dp, _dp, _i, _i, _dp],
+    "nh_table_interleave": [_dp, _dp, _dp, _dp, _i, _i, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
     "nh_set_words": [_dp, _dp, _dp, _i],
     "nh_half_step_append_blobs": [_dp, _dp, _ll],
@@ -544,13 +544,14 @@ class Context:
             if ent["kind"] == "tab":
                 _, w, lw, N, nG, lx, Kt, dKt, nK, sc, nonneg = k
 
-                def interleaved(Kt=Kt, dKt=dKt, nG=nG, nK=nK):
+                def interleaved(Kt=Kt, dKt=dKt, nG=nG, nK=nK, lx=lx, nonneg=nonneg):
                     kd = self.empty((2 * nG * nK,))
-                    self.call("nh_table_interleave", Kt, dKt, nG, nK, kd)
+                    # (a non-negative table carries its log-ratios in units of lx)
+                    self.call("nh_table_interleave", Kt, dKt, lx if nonneg else None, nG, nK, kd)
                     return kd
 
-                kd = self.table(("kd", Kt, dKt, nG * nK), interleaved)
-                self._pinned.add(("kd", Kt, dKt, nG * nK))  # the plan points into it
+                kd = self.table(("kd", Kt, dKt, nG * nK, bool(nonneg)), interleaved)
+                self._pinned.add(("kd", Kt, dKt, nG * nK, bool(nonneg)))  # the plan points into it
                 d.tab[nt] = D.nh_hs_table(wgrid[w], nK, nK, nonneg, kd.ptr, None, sc or None,
                                           ent["out"].ptr)
                 nt += 1

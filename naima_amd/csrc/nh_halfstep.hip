@@ -111,6 +111,8 @@ struct hs_hot {
   double scale[NH_MAX_GRIDS];
   int nG[NH_MAX_GRIDS];
   int o_w[NH_MAX_GRIDS], o_d[NH_MAX_GRIDS], o_lx[NH_MAX_GRIDS];
+  // grids that a non-negative table is reduced over: dlw / lx and 2^-10 / lx per node (-1: none)
+  int o_dp[NH_MAX_GRIDS], o_th[NH_MAX_GRIDS];
   int ngrids, nmom;
   const double* mKt[NH_MAX_MOMENT]; const double* mdK[NH_MAX_MOMENT];
   int mgrid[NH_MAX_MOMENT];
@@ -190,6 +192,29 @@ __device__ __forceinline__ double hs_lds_at(unsigned base, int idx) {
   return *(hs_lds_cd*)(unsigned long long)(base + 8u * (unsigned)idx);
 }
 
+// One segment of a NON-NEGATIVE table on pre-divided log-ratios: the table carries
+// dlnK / lx (nh_table_interleave with lx), the walker dlw / lx, so that
+//   (u2 - u1) lx / dl = (u2 - u1) / dl',   dl' = dl / lx
+// -- no multiplication by lx, and the term joins the sum in the reciprocal's last FMA: 10
+// instructions per segment against 12.  |dl| < 2^-10 <=> |dl'| < th = 2^-10 / lx (per segment, in
+// LDS where lx was); the series (rare, wave-uniform branch) takes lx = 2^-10 / th.
+__device__ __forceinline__ double hs_seg_pre(double acc, double u1, double u2, double dlp,
+                                             double th) {
+  double a2 = fma(u2 - u1, nh_rcp1f(dlp), acc);
+  const bool small = fabs(dlp) < th;
+  if (__builtin_amdgcn_ballot_w64(small) != 0) {
+    asm volatile("" ::: "memory");  // keep this a branch: the compiler would if-convert it
+    const double lx = NH_SEG_SMALL_POS * nh_rcp(th);
+    const double d = dlp * lx;
+    double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
+    f = fma(f, d, 1.666666666666667e-01);
+    f = fma(f, d, 0.5);
+    f = fma(f, d, 1.0);
+    a2 = small ? fma(u1 * lx, f, acc) : a2;
+  }
+  return a2;
+}
+
 template <bool SIGNED>
 __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
                                                 const double* ws, const double* ds,
@@ -224,8 +249,8 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
     for (int q = 0; q < 8; ++q) {
       const double u2 = hs_lds_at(aw, q + 1) * K2[q];
       const double dl = hs_lds_at(ad, q) + d1;
-      acc += SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
-                    : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
+      if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(al, q));
+      else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(al, q));
       u1 = u2;
       d1 = dK[q];
     }
@@ -243,8 +268,8 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
       if (s + q < s1) {
         const double u2 = hs_lds_at(aw, q + 1) * K2[q];
         const double dl = hs_lds_at(ad, q) + d1;
-        acc += SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
-                      : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
+        if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(al, q));
+        else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(al, q));
         u1 = u2;
         d1 = dK[q];
       }
@@ -301,7 +326,7 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
       const double u2 = hs_lds_at(aw, q + 1) * K2[q];
       const double dl = hs_lds_at(ad, q) + d1;
       const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
-                                 : nh_seg_pos<false>(u1, u2, dl, hs_lds_at(al, q));
+                                 : hs_seg_pre(0.0, u1, u2, dl, hs_lds_at(al, q));
       acc += done + q < owed ? term : 0.0;
       u1 = u2;
       d1 = dK[q];
@@ -359,7 +384,7 @@ __device__ __forceinline__ const T __attribute__((address_space(1))) * hs_gptr(i
 }
 #define HS_KERNARG_H 48
 static_assert(offsetof(hs_hot, F) == 0, "hs_first leads the argument block");
-static_assert(sizeof(hs_hot) + HS_KERNARG_H <= 0xc80, "the warm-up loads cover the argument block");
+static_assert(sizeof(hs_hot) + HS_KERNARG_H <= 0xcc0, "the warm-up loads cover the argument block");
 static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
                   offsetof(hs_first, syn_c) == 240 && offsetof(hs_first, nG) == 48 &&
                   offsetof(hs_first, e) == 64 && offsetof(hs_first, lne) == 128 &&
@@ -462,6 +487,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         "s_load_dword %[w2], %[ka], 0xbc0\n\t"
         "s_load_dword %[w3], %[ka], 0xc00\n\t"
         "s_load_dword %[w0], %[ka], 0xc40\n\t"
+        "s_load_dword %[w1], %[ka], 0xc80\n\t"
           : [w0] "+s"(w0), [w1] "+s"(w1), [w2] "+s"(w2), [w3] "+s"(w3)
           : [ka] "s"(kbase));
     }
@@ -926,6 +952,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         const double wv_ = ngx_[sl] * nn, dv = last ? 0.0 : nlr_[sl] + dsh;
         sm[H.o_w[g] + i] = wv_;
         sm[H.o_d[g] + i] = dv;
+        if (H.o_dp[g] >= 0) {  // (wave-uniform) what the non-negative table items read
+          const double il = last ? 0.0 : nh_rcp(nlr_[sl]);
+          sm[H.o_dp[g] + i] = dv * il;
+          sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+        }
         if (wv_ != 0.0) nzmask |= 1 << g;
         if (D.write_weights) {
           D.w[g][(long long)j * nG + i] = wv_;
@@ -952,6 +983,11 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
       sm[H.o_w[g] + i] = wv_;
       sm[H.o_d[g] + i] = dv;
+      if (H.o_dp[g] >= 0) {
+        const double il = last ? 0.0 : nh_rcp(lr);
+        sm[H.o_dp[g] + i] = dv * il;
+        sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+      }
       if (wv_ != 0.0) nzmask |= 1 << g;
       if (D.write_weights) {
         D.w[g][(long long)j * nG + i] = wv_;
@@ -1102,8 +1138,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
         const int s0 = chunk * D.seg, s1 = min(nG - 1, s0 + D.seg);
         const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
-        const double* ds = sm + __builtin_amdgcn_readfirstlane(H.o_d[tg]);
-        const double* lxs = sm + __builtin_amdgcn_readfirstlane(H.o_lx[tg]);
+        // (a non-negative table: the pre-divided log-ratios and the series thresholds)
+        const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
+        const double* ds = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_dp[tg] : H.o_d[tg]);
+        const double* lxs = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_th[tg] : H.o_lx[tg]);
         double acc;
         if (!(nz >> tg & 1))
           acc = 0.0;
@@ -1397,7 +1435,8 @@ extern "C" int nh_half_step_append_blobs(nh_ctx* c, const nh_halfstep_plan* P, l
 // branch (utils.py:336-345); the sign pattern belongs to the table, not to the walker (the
 // weights multiply both nodes by numbers of one sign), so it is settled here, once.
 __global__ void k_table_interleave(const double* __restrict__ Kt, const double* __restrict__ dlnKt,
-                                   int nG, int nK, double* __restrict__ KD) {
+                                   const double* __restrict__ lx, int nG, int nK,
+                                   double* __restrict__ KD) {
   const long long n = (long long)nG * nK;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -1406,20 +1445,23 @@ __global__ void k_table_interleave(const double* __restrict__ Kt, const double* 
     if (i + nK < n) {
       const double k2 = Kt[i + nK];
       if (k1 != 0.0 && k2 != 0.0 && ((__double2hiint(k1) ^ __double2hiint(k2)) < 0)) d = NAN;
+      // a non-negative table: log-ratios in units of the segment's lx (hs_seg_pre); the zero
+      // marker NH_DL_ZERO stays what it is (its reciprocal has to underflow to 0)
+      if (lx && d < NH_DL_ZERO) d /= lx[i / nK];
     }
     KD[2 * i] = k1;
     KD[2 * i + 1] = d;
   }
 }
 
-extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dlnKt, int nG,
-                                   int nK, double* KD) {
+extern "C" int nh_table_interleave(nh_ctx* c, const double* Kt, const double* dlnKt,
+                                   const double* lx, int nG, int nK, double* KD) {
   NH_REQUIRE(c && Kt && dlnKt && KD && nG >= 0 && nK >= 0, "bad argument");
   const long long n = (long long)nG * nK;
   if (n == 0) return NH_OK;
   nh_prof_scope ps(c, NH_K_TABLES);
   hipLaunchKernelGGL(k_table_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                     Kt, dlnKt, nG, nK, KD);
+                     Kt, dlnKt, lx, nG, nK, KD);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -1470,7 +1512,7 @@ extern "C" int nh_hist_append(nh_ctx* c, const double* coords, const double* log
 }
 
 static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int kmax,
-                     bool* lds_overflow) {
+                     int segscale, bool* lds_overflow) {
   NH_REQUIRE(c && d && out, "NULL pointer");
   NH_REQUIRE(d->coords && d->logp && d->blk && d->cursor && d->qT && d->factors && d->params &&
                  d->total, "NULL pointer in the descriptor");
@@ -1530,6 +1572,13 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     H.o_w[g] = off; off += gr.nG;
     H.o_d[g] = off; off += gr.nG;
     H.o_lx[g] = off; off += gr.nG;
+    H.o_dp[g] = H.o_th[g] = -1;
+    for (int t = 0; t < d->ntab; ++t)
+      if (d->tab[t].grid == g && d->tab[t].nonnegative) {
+        H.o_dp[g] = off; off += gr.nG;
+        H.o_th[g] = off; off += gr.nG;
+        break;
+      }
   }
   H.o_mkt = off;
   H.nmom = d->nmoms;
@@ -1603,6 +1652,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   // waves that are free from the start (not on a single-row reduction) ends soonest.
   C.ntab = d->ntab;
   int seg = split >= 4 ? 8 : (split == 2 ? 16 : 32);
+  if (split > 1) seg *= segscale;  // (coarser items: fewer partial sums in LDS)
   C.syn_nodes = HS_SYN_NODES / split > 3 ? HS_SYN_NODES / split : 3;
   if (const char* e = getenv("NH_HS_SEG")) seg = atoi(e) >= 4 ? atoi(e) : seg;  // (tuning experiments)
   if (const char* e = getenv("NH_HS_SYN_NODES")) C.syn_nodes = atoi(e) >= 1 ? atoi(e) : C.syn_nodes;
@@ -1795,11 +1845,13 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
 extern "C" int nh_half_step_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out) {
   int kmax = 8;
   if (const char* e = getenv("NH_HS_SPLIT")) kmax = atoi(e) > 0 ? atoi(e) : 1;
-  for (;;) {
-    bool lds_overflow = false;
-    const int rc = hs_create(c, d, out, kmax, &lds_overflow);
-    if (rc == NH_OK || !lds_overflow || kmax <= 1) return rc;
-    kmax >>= 1;
+  for (;; kmax >>= 1) {
+    for (int segscale = 1; segscale <= 4; segscale *= 2) {  // coarser items before fewer workgroups
+      bool lds_overflow = false;
+      const int rc = hs_create(c, d, out, kmax, segscale, &lds_overflow);
+      if (rc == NH_OK || !lds_overflow) return rc;
+      if (kmax <= 1) return rc;
+    }
   }
 }
 
