@@ -202,8 +202,10 @@ __device__ __forceinline__ double nh_seg_signed(double u1, double u2, double dl,
   // sign change of the integrand: the interleaved table carries it as dl = NaN (the sign
   // pattern of a table is walker-independent, nh_table_interleave) -> NaN b in the reference
   // -> its log branch x1 y1 ln(x2/x1); a NaN weight ratio takes the same way, as there
-  t = (dl == dl) ? t : u1 * lx;
-  return (u1 == 0.0 || u2 == 0.0) ? 0.0 : t;
+  // A zero node (utils.py:347-348) needs no test of its own: a zero TABLE entry is marked by
+  // dl >= NH_DL_ZERO (k_table_dlog; never NaN), whose reciprocal underflows to 0, as in
+  // nh_seg_pos<false>; a weight that has underflowed to 0 ends the integrand the same way.
+  return (dl == dl) ? t : u1 * lx;
 }
 
 template <bool ZERO>
