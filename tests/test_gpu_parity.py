@@ -875,3 +875,55 @@ def test_ssc_seed_edge_shapes_against_oracle(na):
     check(N=17, ns=30, nE=70, Eemin_eV=1e8, Eemax_eV=1e15, nEed=40, zeros=(0, 29, 11))  # 280 nodes
     check(N=33, ns=25, nE=1, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, zeros=(5,))  # 17 -> 10 nodes
     check(N=8, ns=40, nE=66, Eemin_eV=1e10, Eemax_eV=1e13, nEed=100)      # 300 nodes, 5 tiles
+
+
+def test_abi_table_interleave(na):
+    """nh_table_interleave: {K, dlnK} pairs; a sign change between two non-zero nodes -> NaN (the
+    NaN exponent of utils.py:336-345); with the grid's lx the log-ratios come in units of
+    ln(x2/x1) (b + 1 of utils.py:336-339 itself), the zero marker and the NaN untouched"""
+    from naima_amd._lib import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(4)
+    nG, nK = 37, 5
+    K = 10 ** rng.uniform(-30, 3, (nG, nK))
+    K[:, 1] *= np.where(rng.random(nG) < 0.3, -1.0, 1.0)   # a column that changes sign
+    K[[0, 7, 8, 36], 2] = 0.0                              # zero nodes
+    x = np.geomspace(3.0, 2e9, nG) * (1 + 0.01 * rng.random(nG)).cumprod()
+    lxh = np.log(x[1:] / x[:-1])
+    with np.errstate(all="ignore"):
+        dK = np.zeros_like(K)
+        dK[:-1] = np.log(np.abs(K[1:] / K[:-1]))
+    zero = np.zeros_like(K, dtype=bool)
+    zero[:-1] = (K[:-1] == 0) | (K[1:] == 0)
+    dK[zero] = 1e300                                        # k_table_dlog's marker
+    flip = np.zeros_like(zero)
+    flip[:-1] = (K[:-1] * K[1:] < 0)
+    Kd, dKd = ctx.array(K), ctx.array(dK)
+    lx = ctx.array(lxh)
+    for with_lx in (False, True):
+        kd = ctx.empty((2 * nG * nK,))
+        ctx.call("nh_table_interleave", Kd, dKd, lx if with_lx else None, nG, nK, kd)
+        got = kd.get().reshape(nG, nK, 2)
+        assert np.array_equal(got[..., 0], K)
+        d = got[..., 1]
+        assert np.all(np.isnan(d[flip])) and not np.any(np.isnan(d[~flip]))
+        assert np.all(d[zero] == 1e300)
+        want = dK.copy()
+        if with_lx:
+            want[:-1] /= lxh[:, None]
+        ok = ~flip & ~zero
+        ok[-1] = False  # (the last row has no segment)
+        assert_allclose(d[ok], want[ok], rtol=2e-16)
+
+
+def test_synchrotron_grid_too_long_for_lds_is_an_error(na):
+    """k_synchrotron stages three grid arrays in LDS (150 KB: 5034 nodes); a longer particle grid
+    must come back as a NaimaHipError that says so, not as a launch failure or a wrong answer"""
+    from naima_amd._lib import NaimaHipError
+    u = na.u
+    pd = na.ExponentialCutoffPowerLaw(1e33 / u.eV, 10 * u.TeV, 2.3, 30 * u.TeV)
+    syn = na.Synchrotron(pd, B=10 * u.uG, Eemin=1 * u.GeV, Eemax=1 * u.PeV, nEed=1000)  # 6000 nodes
+    with pytest.raises(NaimaHipError, match="LDS"):
+        syn.flux(np.geomspace(1e-3, 1e4, 5) * u.eV, 0)
+    ok = na.Synchrotron(pd, B=10 * u.uG, Eemin=1 * u.GeV, Eemax=1 * u.PeV, nEed=800)  # 4800 nodes
+    assert np.all(np.isfinite(ok.flux(np.geomspace(1e-3, 1e4, 5) * u.eV, 0).value))
