@@ -282,7 +282,10 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
 // more) idle, and the loop is bound by instruction issue -- so `sub` = 64 / nKp sub-ranges of
 // the item's segments share the wave (lane = h nKp + k walks sub-range h of column k).  The
 // walker's w / dlw / lx reads are then per lane (LDS, `sub` distinct addresses per wave).
-template <bool SIGNED>
+// PK nodes per trip: 4 in the general instance of the kernel (123 VGPRs), 6 where there is no
+// synchrotron component (99 VGPRs without them): a narrow table's items are bound by the round
+// trips of their loads, half as many rows again in flight per trip (8 spills)
+template <bool SIGNED, int PK>
 __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
                                                        const double* ws, const double* ds,
                                                        const double* lxs, int lane) {
@@ -310,19 +313,19 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   double acc = 0.0;
   double K1, d1;
   hs_buf_kd(rKD, ob, K1, d1);
-  // Four nodes per trip, the NEXT trip's loads issued before the current one is consumed: a
+  // PK nodes per trip, the NEXT trip's loads issued before the current one is consumed: a
   // narrow table means few work items -- one per wave, all waves in step -- so nothing else
   // hides the round trip.  Two trips per loop iteration: the two register sets swap roles by
   // name instead of being copied (eight 64-bit moves per trip otherwise).
-  double KA[4], dA[4], KB[4], dB[4];
+  double KA[PK], dA[PK], KB[PK], dB[PK];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+  for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
   double u1 = hs_lds_at(aw, 0) * K1;
   const int owed = se - sl;  // segments of this lane's sub-range (<= 0: idle from the start)
   int done = 0;              // (wave-uniform: lives in an SGPR)
-  auto trip = [&](const double (&K2)[4], const double (&dK)[4]) {
+  auto trip = [&](const double (&K2)[PK], const double (&dK)[PK]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PK; ++q) {
       const double u2 = hs_lds_at(aw, q + 1) * K2[q];
       const double dl = hs_lds_at(ad, q) + d1;
       const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
@@ -331,23 +334,23 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
       u1 = u2;
       d1 = dK[q];
     }
-    done += 4;
-    aw += 32u;
-    ad += 32u;
-    al += 32u;
+    done += PK;
+    aw += 8u * PK;
+    ad += 8u * PK;
+    al += 8u * PK;
   };
-  for (int q0 = 0; q0 < len; q0 += 8) {
-    ob += 4 * rowb;
-    if (q0 + 4 < len) {
+  for (int q0 = 0; q0 < len; q0 += 2 * PK) {
+    ob += PK * rowb;
+    if (q0 + PK < len) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KB[q], dB[q]);
+      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KB[q], dB[q]);
     }
     trip(KA, dA);
-    if (q0 + 4 >= len) break;
-    ob += 4 * rowb;
-    if (q0 + 8 < len) {
+    if (q0 + PK >= len) break;
+    ob += PK * rowb;
+    if (q0 + 2 * PK < len) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
     }
     trip(KB, dB);
   }
@@ -389,6 +392,9 @@ static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
                   offsetof(hs_first, syn_c) == 240 && offsetof(hs_first, nG) == 48 &&
                   offsetof(hs_first, e) == 64 && offsetof(hs_first, lne) == 128 &&
                   offsetof(hs_first, pkd) == 192, "hs_first: the layout the first trip reads");
+// SYN = false: the instance for models without a synchrotron component (table-only: cfg1,
+// cfg5) -- the synchrotron items' registers are not there to be allocated around
+template <bool SYN>
 __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done_,
                                                     const double* __restrict__ blk_,
                                                     const double* coords_, int slice, int ns_,
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   // ... to the waves that have nothing else to do before the second barrier: not the
   // likelihood wave (it evaluates the priors), not the tile waves at the back (the liveness
   // search of the synchrotron energies) -- with a unit on top they were the last to arrive
-  const int tiles_ = H.syn_grid >= 0 ? (H.syn_nE + 63) >> 6 : 0;
+  const int tiles_ = SYN && H.syn_grid >= 0 ? (H.syn_nE + 63) >> 6 : 0;
   int nwork = nwv - 1 - tiles_, rank = wv == 0 ? 0 : wv - 1;
   bool worker = wv != 1 && wv < nwv - tiles_;
   if (nwork < 1) {  // (a workgroup of one or two waves: everybody)
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     sc1 = F.syn_c[F.syn_nG + tid];
     sc2 = F.syn_c[2 * F.syn_nG + tid];
   }
-  const bool has_syn = H.syn_grid >= 0;
+  const bool has_syn = SYN && H.syn_grid >= 0;
   // what the waves off the proposal's chain park in LDS (below): asked for in this same trip
   const bool fill_wave = wv >= 1 || nwv == 1;
   const int t0 = nwv == 1 ? tid : tid - 64, TT = nwv == 1 ? T : T - 64;
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   if (tid == 0 && j == 0) H.cursor[0] = cn;  // for launches that follow the older slice protocol
   if (K > 1) {  // the work items of the other workgroups of this walker: their slots count as 0
     for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
-    if (H.syn_grid >= 0)
+    if (SYN && H.syn_grid >= 0)
       for (int t = tid; t < D.syn_cdmax * H.syn_nE; t += T) sm[H.o_part_s + t] = 0.0;
   }
   // the single-row tables (We, Wp) -> LDS, by the waves at the back of the workgroup that are
@@ -1146,13 +1152,13 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         if (!(nz >> tg & 1))
           acc = 0.0;
         else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
-          acc = tb.nonneg ? hs_table_item_packed<false>(tb, nG, s0, s1, ws, ds, lxs, lane)
-                          : hs_table_item_packed<true>(tb, nG, s0, s1, ws, ds, lxs, lane);
+          acc = tb.nonneg ? hs_table_item_packed<false, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane)
+                          : hs_table_item_packed<true, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane);
         else
           acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
                           : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
         part_t[ix * 64 + lane] = acc;
-      } else {
+      } else if (SYN) {
         // 64 (live energy, chunk) pairs of the synchrotron integrand
         if (!syn_ready) {  // (wave-uniform) the tile waves' constants must have landed
           while (__atomic_load_n(&hi[HI_READY], __ATOMIC_RELAXED) < syn_tiles)
@@ -1793,8 +1799,11 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(P->words, 0, 2 * sizeof(int));
   if (e == hipSuccess && lds > 64 * 1024)
-    e = hipFuncSetAttribute((const void*)k_half_step, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+    e = H.syn_grid >= 0
+            ? hipFuncSetAttribute((const void*)k_half_step<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute((const void*)k_half_step<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
     if (P->dev) (void)hipFree(P->dev);
     if (P->words) (void)hipFree(P->words);
@@ -1872,9 +1881,15 @@ extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   NH_REQUIRE(c && P && P->dev, "bad argument");
   nh_prof_scope ps(c, NH_K_HALFSTEP);
   const hs_hot& H = P->hot;
-  hipLaunchKernelGGL(k_half_step, dim3((unsigned)P->blocks, (unsigned)P->split), dim3(P->threads), P->lds_bytes,
-                     c->stream, (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
-                     P->dbg ? 1 : 0, H);
+  const dim3 grid((unsigned)P->blocks, (unsigned)P->split);
+  if (H.syn_grid >= 0)
+    hipLaunchKernelGGL(k_half_step<true>, grid, dim3(P->threads), P->lds_bytes, c->stream,
+                       (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
+                       P->dbg ? 1 : 0, H);
+  else
+    hipLaunchKernelGGL(k_half_step<false>, grid, dim3(P->threads), P->lds_bytes, c->stream,
+                       (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
+                       P->dbg ? 1 : 0, H);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
