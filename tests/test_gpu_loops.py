@@ -184,3 +184,51 @@ def test_split_launch_equals_unsplit_launch(na, monkeypatch, cfg, nw, steps):
     sh = h.run_mcmc(pos, 2)
     sh = h.run_mcmc(sh, 38)
     assert_allclose(c8[:40], h.get_chain(), rtol=1e-8)
+
+
+def test_split_launch_of_the_table_only_instance(na, monkeypatch):
+    """A model without a synchrotron component runs k_half_step<false>; with 200 photon
+    energies its table items are most of a launch, so a small ensemble gives every walker
+    several workgroups there too: device loop (split) == device loop (unsplit) == host loop,
+    for the pi0 look-up table (signed segments, unpacked 64-column tiles)"""
+    from naima_amd import workloads as W
+    from naima_amd.datatable import make_data
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    model = W.WORKLOADS["cfg5"]["model"](na)
+    p0 = np.asarray(W.WORKLOADS["cfg5"]["p0"], dtype=float)
+    E = np.geomspace(0.05, 300.0, 200)
+
+    def flux_at(E_TeV):
+        out = model(p0, {"energy": E_TeV * u.TeV})[0]
+        return out.to("1/(s cm2 TeV)").value
+
+    true = flux_at(E)
+    rng = np.random.default_rng(12)
+    raw = dict(energy=E, energy_unit="TeV", flux=true * (1 + 0.1 * rng.standard_normal(E.size)),
+               flux_error_lo=0.1 * true, flux_error_hi=0.1 * true,
+               ul=np.zeros(E.size, dtype=bool), cl=np.full(E.size, 0.9), flux_unit="1/(cm2 s TeV)")
+    data = make_data(raw)
+    nw, nd, steps = 24, p0.size, 40
+    kw = dict(args=[data, model, None], seed=3, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(6).standard_normal((nw, nd)))
+    runs = {}
+    for k in ("1", "8"):
+        monkeypatch.setenv("NH_HS_SPLIT", k)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        st = d.run_mcmc(pos, 2)
+        st = d.run_mcmc(st, steps - 2)
+        hs = d._dev._plan["hs"]
+        assert hs is not None and d._dev.mega
+        runs[k] = (hs["split"], d.get_chain(), d.get_log_prob(), d.get_blobs())
+    assert runs["1"][0] == 1 and runs["8"][0] > 1
+    assert_allclose(runs["8"][1], runs["1"][1], rtol=1e-8)
+    assert_allclose(runs["8"][2], runs["1"][2], rtol=1e-6)
+    for x, y in zip(runs["8"][3], runs["1"][3]):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
+                        atol=1e-300)
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    sh = h.run_mcmc(pos, 2)
+    sh = h.run_mcmc(sh, steps - 2)
+    assert_allclose(runs["8"][1], h.get_chain(), rtol=1e-8)
+    assert_allclose(runs["8"][2], h.get_log_prob(), rtol=1e-6)
