@@ -828,7 +828,9 @@ class _Branch:
                 c._forked = True
                 self.active = True
             return self
-        if c.multistream and c.cur_stream == -1:
+        # (not while a step graph is being captured: hipStreamEndCapture died on cfg4's graph
+        # with forked side streams -- ROCm 7.2 -- and the fork never paid inside a graph)
+        if c.multistream and c.cur_stream == -1 and not getattr(c, "capturing", False):
             side = c._next_side
             c._next_side = (side + 1) % 4
             _chk(_lib.nh_stream_fork(c.h, side))
