@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     if (live) {
       const int pos = __popcll(m & ((1ull << tid) - 1ull));
       amap[pos] = k;
-      ai0[pos] = max(i0 - 1, 0);
+      ai0[pos] = i0;  // (from the first LIVE node on: the segment to its left contributes an exact 0)
     }
     if (tid == 0) s_nA = __popcll(m);
     if (k < nE && !live) out[(long long)wi * ldo + k] = 0.0;
@@ -146,17 +146,16 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
     if (s0 < s1) {
       // The node arithmetic of the half-step kernel (nh_syn.h: table-driven exp, one reciprocal
       // square root for P, 3-term atanh for ln(P2/P1) on naima's default grid density, the
-      // non-negative segment form): ~75 instructions per node against ~115.  No branch: a dead
-      // node (x > 746: exp(-x) == 0 in double; a zero weight) is computed like any other and
-      // zeroed by a select, two nodes per trip are one straight block.
+      // non-negative segment form): ~69 instructions per node against ~115.  No branch and no
+      // select: a range starts at its first live node (x <= 746), so no node of it is dead; a
+      // zero weight gives u = 0 by itself; two nodes per trip are one straight block.
       auto node = [&](int sn, double& u, double& P) {
         const double x = q * ig2[sn];
         const double wn = wr[sn];
-        const bool on = x <= 746.0 && wn != 0.0;  // (NaN: off)
         const double Pv = syn_P1(cbq * ig23[sn]);
         const double ev = nh_exp_tab(-fmin(x, 800.0), T64);
-        u = on ? wn * (Pv * ev) : 0.0;  // gamma nelec dNdE / CS1, :335-338
-        P = on ? Pv : 1.0;
+        u = wn * (Pv * ev);  // gamma nelec dNdE / CS1, :335-338 (every node of the range is live)
+        P = Pv;
       };
       double u1, P1;
       node(s0, u1, P1);
@@ -168,8 +167,8 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
         const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
         const double dlB = dwr[s + 1] + syn_dlnP1(PA, PB) - q * dig2[s + 1];
-        acc += nh_seg_pos<true>(u1, uA, dlA, lx[s]);  // P(x) exp(-x) >= 0: one sign
-        acc += nh_seg_pos<true>(uA, uB, dlB, lx[s + 1]);
+        acc += nh_seg_pos<false>(u1, uA, dlA, lx[s]);  // P(x) exp(-x) >= 0: one sign
+        acc += nh_seg_pos<false>(uA, uB, dlB, lx[s + 1]);
         u1 = uB;
         P1 = PB;
       }
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         double uA, PA;
         node(s + 1, uA, PA);
         const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
-        acc += nh_seg_pos<true>(u1, uA, dlA, lx[s]);
+        acc += nh_seg_pos<false>(u1, uA, dlA, lx[s]);
       }
     }
     part[ch * 64 + a] = acc * cs1;  // the terms are linear in u: CS1 once per thread
