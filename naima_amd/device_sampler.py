@@ -88,7 +88,8 @@ class DeviceLoop:
         # the random numbers of up to KSTEPS ensemble steps travel as ONE block; a device
         # cursor selects the current half-step's slice (advanced by the accept kernel)
         self.KSTEPS = 32
-        self.GSTEPS = 8   # ensemble steps per hipGraph launch when the host has nothing to do
+        # ensemble steps per hipGraph launch when the host has nothing to do
+        self.GSTEPS = max(1, int(os.environ.get("NAIMA_AMD_GSTEPS", "8")))
         self.multi_graph = None
         # one spare slice: the fused move kernel proposes the half-step AFTER the one it
         # accepts, so the last one of a block reads (and discards) slice 2*KSTEPS
