@@ -515,6 +515,10 @@ int nh_graph_destroy(nh_ctx* ctx, void* graph_exec);
 
 /* ---- multi-GPU: one all-gather per half-step -------------- */
 #define NH_UNIQUE_ID_BYTES 128
+/* NH_OK when librccl could be loaded and every entry point resolved (no communicator is made).
+ * Every rank asks this first and the answers are min-reduced over the control plane, so that no
+ * rank enters the blocking ncclCommInitRank while another one never will. */
+int nh_comm_available(void);
 int nh_comm_unique_id(char* id_out /*[NH_UNIQUE_ID_BYTES]*/);
 int nh_comm_init(nh_ctx* ctx, int rank, int nranks, const char* id);
 int nh_comm_destroy(nh_ctx* ctx);

@@ -96,6 +96,7 @@ _SIGS = {
     "nh_graph_end": [_dp, C.POINTER(_dp)],
     "nh_graph_launch": [_dp, _dp],
     "nh_graph_destroy": [_dp, _dp],
+    "nh_comm_available": [],
     "nh_comm_unique_id": [C.c_char_p],
     "nh_comm_init": [_dp, _i, _i, C.c_char_p],
     "nh_comm_destroy": [_dp],
@@ -123,6 +124,26 @@ class NaimaHipError(RuntimeError):
     pass
 
 
+def under_rocprofiler():
+    """True when this process was started under rocprofv3 / a rocprofiler-sdk tool"""
+    return bool(os.environ.get("ROCPROFILER_LIBRARY_CTOR") or os.environ.get("ROCP_TOOL_LIBRARIES")
+                or "rocprofiler-sdk" in os.environ.get("LD_PRELOAD", ""))
+
+
+def _profiler_workaround():
+    """rocprofv3 (ROCm 7.2) + hipGraph replay: with rocprofiler-sdk's queue interception active,
+    the HIP runtime's replay of a graph from PRE-BUILT AQL packets ("graph packet capture", its
+    default) dies inside hipGraphLaunch after a few hundred replays of the step graphs -- a
+    SIGSEGV in the runtime's packet copy, or "AQL packet is malformed" / a hung queue -- for
+    graphs of sixteen kernel nodes with 3 KB by-value arguments.  The same graphs, binary and
+    command run through under the profiler when the runtime dispatches the nodes one by one
+    (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), and always when no profiler is attached (round 3:
+    profiles/README.md has the four runs).  Set here, before the HIP runtime reads its flags,
+    and only when a profiler is attached; an explicit setting of the user wins."""
+    if under_rocprofiler():
+        os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
 def load():
     """dlopen libnaima_hip.so; raises (loudly) when it has not been built."""
     global _lib
@@ -132,6 +153,7 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or naima_amd/csrc/build.sh.  naima_amd has no CPU fallback." % LIB_PATH)
+    _profiler_workaround()
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)

@@ -67,6 +67,11 @@ static int rccl_load() {
       return nh_set_error(NH_ECOMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
   } while (0)
 
+// librccl loaded and every symbol resolved?  No communicator, no collective: what every rank
+// checks (and agrees on over the control plane) BEFORE anybody enters ncclCommInitRank, which
+// blocks until all ranks have called it
+extern "C" int nh_comm_available(void) { return rccl_load(); }
+
 extern "C" int nh_comm_unique_id(char* id_out) {
   NH_REQUIRE(id_out, "id_out is NULL");
   int rc = rccl_load();

@@ -18,6 +18,18 @@ int nh_set_error(int code, const char* fmt, ...) {
 extern "C" const char* nh_last_error(void) { return g_err; }
 extern "C" int nh_version(void) { return 100; }
 
+// rocprofv3 (ROCm 7.2) + hipGraph replay from pre-built AQL packets dies inside hipGraphLaunch
+// on this library's step graphs (sixteen kernel nodes, 3 KB by-value arguments); node-by-node
+// replay does not (profiles/README.md, round 3).  Best effort for hosts that load the library
+// without naima_amd/_lib.py (which does the same before the HIP runtime is loaded at all): only
+// under a profiler, never over an explicit setting.
+__attribute__((constructor(101))) static void nh_profiler_workaround() {
+  const char* pre = getenv("LD_PRELOAD");
+  if (getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCP_TOOL_LIBRARIES") ||
+      (pre && strstr(pre, "rocprofiler-sdk")))
+    setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0", 0);
+}
+
 extern "C" int nh_create(int device, nh_ctx** out) {
   NH_REQUIRE(out != nullptr, "out is NULL");
   int ndev = 0;

@@ -388,6 +388,7 @@ __device__ __forceinline__ const T __attribute__((address_space(1))) * hs_gptr(i
 #define HS_KERNARG_H 48
 static_assert(offsetof(hs_hot, F) == 0, "hs_first leads the argument block");
 static_assert(sizeof(hs_hot) + HS_KERNARG_H <= 0xcc0, "the warm-up loads cover the argument block");
+static_assert(sizeof(hs_hot) + HS_KERNARG_H >= 0xc84, "the last warm-up load (0xc80) stays inside the argument block");
 static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
                   offsetof(hs_first, syn_c) == 240 && offsetof(hs_first, nG) == 48 &&
                   offsetof(hs_first, e) == 64 && offsetof(hs_first, lne) == 128 &&
@@ -1565,6 +1566,13 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   }
   NH_REQUIRE(have_params, "params must be the output of one of the packs");
   NH_REQUIRE(d->ndim < 255, "at most 254 fit parameters");
+  for (int t = 0; t < d->ntab; ++t) {  // (checked before anything indexes grids[] with it)
+    const nh_hs_table& tb = d->tab[t];
+    NH_REQUIRE(tb.grid >= 0 && tb.grid < d->ngrids && tb.KD && tb.out && tb.nK >= 1 &&
+                   tb.ldo >= tb.nK, "bad table reduction");
+  }
+  if (getenv("NH_HS_TEST_REJECT"))  // (test hook: a plan this function turns down)
+    return nh_set_error(NH_EINVAL, "half-step plan rejected (NH_HS_TEST_REJECT)");
   H.ngrids = d->ngrids;
   int off = HS_O_FREE;
   for (int g = 0; g < d->ngrids; ++g) {
@@ -1688,8 +1696,6 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   int nT = 0;
   for (int t = 0; t < d->ntab; ++t) {
     const nh_hs_table& tb = d->tab[t];
-    NH_REQUIRE(tb.grid >= 0 && tb.grid < d->ngrids && tb.KD && tb.out && tb.nK >= 1 &&
-                   tb.ldo >= tb.nK, "bad table reduction");
     const int nG = d->grids[tb.grid].nG;
     NH_REQUIRE((long long)nG * tb.nK < (1LL << 27), "table too large for 32-bit offsets");
     hs_tab& o = C.tab[t];

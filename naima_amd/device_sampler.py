@@ -56,6 +56,26 @@ class DeviceState:
         return iter((self.coords, self.log_prob, self.random_state))
 
 
+def _release_loop(ctx, res):
+    """finalizer of a DeviceLoop: its graph executables, then the half-step plan they launch
+    (device packs, counters, partial-spectra buffers, the host descriptor)"""
+    if ctx.h is None:
+        return  # the context went first and took the device allocations with it
+    try:
+        ctx.sync()
+        for g in res["graphs"]:
+            _lib._lib.nh_graph_destroy(ctx.h, g)
+        for plan in res["plans"]:
+            hs = plan.get("hs") if plan else None
+            if hs is not None and hs.get("plan") is not None:
+                _lib._lib.nh_half_step_destroy(ctx.h, hs["plan"])
+                hs["plan"] = None
+                plan["hs"] = None
+    except Exception:
+        pass
+    res["graphs"], res["plans"] = [], []
+
+
 class DeviceLoop:
     def __init__(self, sampler):
         if not sampler.naima_style:
@@ -146,6 +166,10 @@ class DeviceLoop:
         self.hist = []             # pending device history blocks
         self.warm = 0
         self._have_state = False
+        # what this loop owns on the device besides pooled buffers: released when it goes
+        import weakref
+        self._res = dict(graphs=[], plans=[])
+        self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
     def reset(self):
@@ -322,6 +346,7 @@ class DeviceLoop:
         plan["mode"] = "replay"
         ctx.pin_caches()
         self._plan = plan
+        self._res["plans"].append(plan)
         self._front_args = (pk, len(packs), kind, rows_ptr, gd, len(grids), mm, len(moments))
         if not self.sharded:
             self._hook = dict(N=self.nloc, used=False, total=None,
@@ -618,7 +643,9 @@ class DeviceLoop:
         except Exception:
             ctx.graph_abort()
             raise
-        return ctx.graph_end()
+        g = ctx.graph_end()
+        self._res["graphs"].append(g)
+        return g
 
     def _run_step(self):
         """one ensemble step = two half-steps.  Single GPU: after the eager warm-up and
@@ -642,7 +669,7 @@ class DeviceLoop:
         if self.mega and self._plan["hs"] is None:
             # the first one-launch half-step creates the kernel's descriptor (device
             # allocation + upload): not inside a stream capture
-            self._half_step_body()
+            self._first_one_launch_half_step()
             self._half_step_body()
             return
 
@@ -652,6 +679,28 @@ class DeviceLoop:
 
         self.step_graph = self.graph = self._capture(two)
         ctx.graph_launch(self.step_graph)
+
+    def _first_one_launch_half_step(self):
+        """the half-step that creates the one-launch plan.  _can_be_one_launch is an estimate
+        made from the recorded launches; nh_half_step_create has the last word (exact LDS
+        layout, its admission rules).  If it turns the plan down, nothing has been launched
+        yet for this half-step: the loop drops to the three-launch fused sequence for good."""
+        try:
+            self._half_step_body()
+        except _lib.NaimaHipError:
+            if self._plan.get("hs") is not None:
+                raise  # the plan exists: this was a real failure of a launch
+            import warnings
+            warnings.warn("nh_half_step_create turned the one-launch plan down (%s); the device "
+                          "loop keeps the three-launch half-step"
+                          % _lib._lib.nh_last_error().decode())
+            self.mega = False
+            self._plan["mega"] = False
+            self.blobs_in_kernel = False
+            self._hook.pop("blobs", None)
+            self._hook.pop("blobs_in_kernel", None)
+            self._front()  # proposal + packs + weights of this slice, as a launch of its own
+            self._half_step_body()
 
     def _run_half_step(self):
         """eager warm-up (fills the static caches), then capture, then replay.  One
@@ -672,8 +721,11 @@ class DeviceLoop:
                 self._record_half_step()
             self.warm += 1
             return
-        if not s.use_graph or (self.mega and self._plan["hs"] is None):
-            self._half_step_body()  # (a first one-launch half-step: never inside a capture)
+        if self.mega and self._plan["hs"] is None:
+            self._first_one_launch_half_step()  # (never inside a capture)
+            return
+        if not s.use_graph:
+            self._half_step_body()
             return
         if not multi:
             self.graph = self._capture(self._half_step_body)

@@ -82,8 +82,13 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
+_MAX_MSG = 64 << 20  # nothing on the control plane comes near this (ids, scalars, staged rows)
+
+
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_MSG:
+        raise ConnectionError("control-plane message of %d bytes refused (cap %d)" % (n, _MAX_MSG))
     return _recv_exact(sock, n)
 
 
@@ -101,8 +106,11 @@ class SocketGroup:
         self.rank, self.size, self.timeout = int(rank), int(size), float(timeout)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
-        ident = "%s:%d:%d:%s:%s" % (addr, base, self.size,
-                                    os.environ.get("TORCHELASTIC_RUN_ID", ""), salt)
+        # (NAIMA_AMD_GROUP_SECRET: a value only the launcher's processes know, for hosts where
+        # the rendezvous variables alone -- all public -- are not credential enough)
+        ident = "%s:%d:%d:%s:%s:%s" % (addr, base, self.size,
+                                       os.environ.get("TORCHELASTIC_RUN_ID", ""), salt,
+                                       os.environ.get("NAIMA_AMD_GROUP_SECRET", ""))
         self.token = hashlib.sha256(ident.encode()).digest()[:16]
         self.peers = {}     # rank 0: rank -> socket
         self.sock = None    # other ranks: the socket to rank 0
@@ -118,11 +126,25 @@ class SocketGroup:
 
     def _serve(self, addr, ports):
         srv = None
+        # the hub listens on the interface the ranks are told to connect to (MASTER_ADDR),
+        # not on every interface of the host; a name that does not resolve to a local address
+        # (some launchers pass the node's public name) falls back to all interfaces
+        bind_addr = "0.0.0.0"
+        try:
+            cand = socket.gethostbyname(addr)
+            probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                probe.bind((cand, 0))
+                bind_addr = cand
+            finally:
+                probe.close()
+        except OSError:
+            pass
         for p in ports:
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind(("0.0.0.0", p))
+                s.bind((bind_addr, p))
             except OSError:
                 s.close()
                 continue
@@ -212,14 +234,21 @@ class SocketGroup:
         return max(vals) if op == "max" else min(vals)
 
     def free_port(self):
-        """a TCP port that is free on rank 0 right now, agreed by every rank"""
-        p = b""
+        """a TCP port that is free on rank 0 right now, agreed by every rank.  Rank 0 keeps
+        the probing socket (SO_REUSEADDR, never listening) open until every rank holds the
+        number, so nothing else on the host is handed the port in between; whoever binds it
+        next with SO_REUSEADDR -- the hub of the group that asked -- succeeds."""
+        p, s = b"", None
         if self.rank == 0:
             s = socket.socket()
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             s.bind(("", 0))
             p = struct.pack("<i", s.getsockname()[1])
-            s.close()
-        return struct.unpack("<i", self.bcast(p))[0]
+        try:
+            return struct.unpack("<i", self.bcast(p))[0]
+        finally:
+            if s is not None:
+                s.close()
 
     def close(self):
         for c in list(self.peers.values()) + [self.sock, self._srv]:
@@ -277,8 +306,10 @@ class HostComm:
 class RcclComm:
     """RCCL all-gather through the C ABI (nh_comm_allgather) on device buffers.  Building
     one is a collective over ``group``: every rank takes the same branch at every step,
-    so a rank that cannot load librccl (or a hub that cannot make the unique id) makes ALL
-    ranks raise ``RcclUnavailable`` together instead of leaving the others waiting."""
+    so a rank that cannot load librccl (checked and agreed BEFORE the blocking
+    ncclCommInitRank) or a hub that cannot make the unique id makes ALL ranks raise
+    ``RcclUnavailable`` together instead of leaving the others waiting; a control-plane
+    time-out or a lost peer during construction is reported the same way."""
 
     def __init__(self, ctx=None, group=None):
         import ctypes as C
@@ -294,27 +325,40 @@ class RcclComm:
             del os.environ["NCCL_DEBUG"]
         buf = C.create_string_buffer(128)
         err = ""
-        # 1. rank 0 makes the id (this is also where librccl gets loaded); ALWAYS broadcasts:
-        #    the id, or an empty message that says "no RCCL here"
-        if self.rank == 0:
-            try:
-                _lib._chk(lib.nh_comm_unique_id(buf))
-                msg = buf.raw
-            except Exception as e:  # librccl missing / ncclGetUniqueId refused
-                msg, err = b"", str(e)
-        else:
-            msg = b""
-        uid = self.group.bcast(msg)
-        if len(uid) != 128:
-            raise RcclUnavailable("rank 0 could not create an RCCL unique id %s" % err)
-        # 2. the communicator; whoever fails says so before anybody uses it
-        ok = 1.0
         try:
-            _lib._chk(lib.nh_comm_init(self.ctx.h, self.rank, self.size, uid))
-        except Exception as e:
-            ok, err = 0.0, str(e)
-        if self.group.reduce_scalar(ok, "min") != 1.0:
-            raise RcclUnavailable("ncclCommInitRank failed on some rank %s" % err)
+            # 0. can EVERY rank load librccl and resolve its entry points?  Agreed before anybody
+            #    enters ncclCommInitRank: that call blocks until all ranks have made it, so a
+            #    rank that fails earlier would leave the others inside it
+            have = 1.0
+            if lib.nh_comm_available() != 0:
+                have, err = 0.0, lib.nh_last_error().decode()
+            if self.group.reduce_scalar(have, "min") != 1.0:
+                raise RcclUnavailable("librccl cannot be loaded on some rank %s" % err)
+            # 1. rank 0 makes the id; ALWAYS broadcasts: the id, or an empty message that says
+            #    "no id"
+            if self.rank == 0:
+                try:
+                    _lib._chk(lib.nh_comm_unique_id(buf))
+                    msg = buf.raw
+                except Exception as e:  # ncclGetUniqueId refused
+                    msg, err = b"", str(e)
+            else:
+                msg = b""
+            uid = self.group.bcast(msg)
+            if len(uid) != 128:
+                raise RcclUnavailable("rank 0 could not create an RCCL unique id %s" % err)
+            # 2. the communicator; whoever fails says so before anybody uses it
+            ok = 1.0
+            try:
+                _lib._chk(lib.nh_comm_init(self.ctx.h, self.rank, self.size, uid))
+            except Exception as e:
+                ok, err = 0.0, str(e)
+            if self.group.reduce_scalar(ok, "min") != 1.0:
+                raise RcclUnavailable("ncclCommInitRank failed on some rank %s" % err)
+        except (socket.timeout, ConnectionError, OSError) as e:
+            # a peer died or never answered: the same fallback as "no RCCL" (the host-staged
+            # path will say so itself if the control plane is really gone)
+            raise RcclUnavailable("control plane failed while building the communicator: %r" % (e,))
         self._send = self._recv = None
         self._graph_ok = None
 

@@ -252,13 +252,18 @@ HAND = {
     "cfg3": [("norm below its prior", 0, -0.03), ("index above its prior", 1, 2.4),
              ("index below its prior", 1, -0.8), ("negative B (below its prior)", 3, -0.4),
              ("beta below its prior", 4, 0.05), ("beta above its prior", 4, 6.0),
-             ("cut-off 1e-403 TeV: every weight underflows", 2, -240.0)],
+             ("cut-off 10 keV: every weight underflows", 2, -8.0 / np.log10(48.0))],
     #   cfg2 prior: p0 >= 0 only
     "cfg2": [("norm below its prior", 0, -0.03),
-             ("cut-off 1e-403 TeV: every weight underflows", 2, -240.0)],
+             ("cut-off 10 keV: every weight underflows", 2, -8.0 / np.log10(48.0))],
     #   cfg5: no prior; log10(cut-off / TeV) is p4 = 2
-    "cfg5": [("cut-off 1e-400 TeV: every weight underflows", 4, -200.0)],
+    "cfg5": [("cut-off 10 keV: every weight underflows", 4, -4.0)],
 }
+# (The cut-off sits five decades below the particle grids -- exp(-(E/E_c)^beta) underflows at
+# every node -- but not absurdly far: a stretch move that uses such a walker as the partner
+# lands at 10^(+11) TeV, still a number.  From 10^-403 TeV the same move proposes 10^+403 TeV
+# = inf, which the reference refuses with "e_cutoff value is NaN or Inf" (extern/validator.py)
+# and emcee passes on: the run dies there, and so does the host-driven loop here.)
 
 
 def _bench_ball(name, p0, nw):
@@ -408,3 +413,28 @@ def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na):
     fin = np.isfinite(l)
     assert_allclose(got[fin], l[fin], rtol=1e-6)
     assert_allclose(st.coords, c, rtol=1e-8)
+
+
+def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkeypatch):
+    """the device loop's own estimate says "one launch", nh_half_step_create says no (test
+    hook NH_HS_TEST_REJECT): the sampler warns once, keeps the three-launch fused half-step
+    and still agrees with the host-driven loop"""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg3", {})
+    nw, nd = 24, p0.size
+    kw = dict(args=[data, model, prior], seed=13, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(4).standard_normal((nw, nd)))
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    sh = h.run_mcmc(pos, 3)
+    sh = h.run_mcmc(sh, 11)
+    monkeypatch.setenv("NH_HS_TEST_REJECT", "1")
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    with pytest.warns(UserWarning, match="turned the one-launch plan down"):
+        sd = d.run_mcmc(pos, 3)
+    sd = d.run_mcmc(sd, 11)
+    assert d._dev is not None and d._dev.fused and not d._dev.mega
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+    assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)
+    for x, y in zip(d.get_blobs(), h.get_blobs()):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
+                        atol=1e-300, equal_nan=True)
