@@ -483,6 +483,43 @@ int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
  * not depend on arrival order).  NH_HS_SPLIT=<K> in the environment caps K (1: never split). */
 int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
+
+/* ---- a whole block of moves in ONE launch: the half-step kernel with resident workgroups ----
+ * Replaces the sequence of nh_half_step_launch calls for slices [slice0, slice0 + nslices) of
+ * the block of moves in `blk` (whole ensemble steps: slice0 and nslices even, at most 32 steps)
+ * -- emcee's EnsembleSampler.sample loop over StretchMove / RedBlueMove.propose around
+ * core.py:97-121 (reference call sites core.py:128, 450-457).  The workgroups stay resident
+ * for the whole launch; the ensemble-wide barrier between half-steps becomes a per-walker
+ * hand-off: a walker of slice h + 1 waits only for its own and its partner's record of the
+ * previous slices (data-tagged 8-byte granules written write-through by the workgroup that
+ * moved the walker; see nh_persist.hip).  Everything walker-independent (grid nodes, table
+ * of exponentials, data columns, priors) is loaded into LDS once per launch.
+ * Needs a plan with do_accept = 1, one workgroup per walker, lo = 0, nloc = ns, ndim <= 15, no
+ * separately evaluated prior (lp == NULL) and every likelihood component produced inside the
+ * launch; nh_half_step_run_create says no otherwise (the caller keeps launching per half-step).
+ * The launch reads coords / logp as they are and leaves them at the state after the last
+ * slice; naccepted is advanced; the spectra / weights / parameter-row outputs of the plan's
+ * descriptor are NOT written.  Chain history: hist_coords [cap][N][ndim], hist_logp [cap][N]
+ * and hist_blobs[b] [cap][N][m_b] (device; hist_coords NULL: none kept) receive rows hist_row0,
+ * hist_row0 + 1, ... for the steps of the launch; the blobs' current values (blobs[].cur) end at
+ * the last step's.  A launch whose workgroups cannot all be resident would wait for ever: the
+ * grid is sized by the occupancy query, every wait is bounded, and a time-out aborts the
+ * launch and latches an error that nh_half_step_run_status reports (0 = every launch so far
+ * found its records). */
+typedef struct nh_halfstep_run nh_halfstep_run;
+int nh_half_step_run_create(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run** out);
+int nh_half_step_run(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run* run, int slice0,
+                     int nslices, double* hist_coords, double* hist_logp,
+                     double* const* hist_blobs /*host array of device pointers, or NULL*/,
+                     long long hist_row0, long long hist_cap);
+int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
+int nh_half_step_run_info(const nh_halfstep_run* run, int* grid, int* threads,
+                          long long* lds_bytes);
+/* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
+ * (workgroup, slice handled): start | records in | packs done | weights done | own items
+ * done | all items done | spectra summed | record published */
+int nh_half_step_run_stamps(nh_ctx* ctx, const nh_halfstep_run* run, long long* out);
+int nh_half_step_run_destroy(nh_ctx* ctx, nh_halfstep_run* run);
 /* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the
  * first 8 workgroups of the last launch, out[8][16], followed by 4 x 16 per-wave figures of
  * workgroup 0, then start[1024] and end[1024] stamps of every workgroup (2304 values in all);

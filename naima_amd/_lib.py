@@ -108,6 +108,12 @@ _SIGS = {
     "nh_half_step_split": [_dp, C.POINTER(_i)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_half_step_stamps": [_dp, _dp, _dp],
+    "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
+    "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],
+    "nh_half_step_run_status": [_dp, _dp, C.POINTER(_i)],
+    "nh_half_step_run_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
+    "nh_half_step_run_stamps": [_dp, _dp, _dp],
+    "nh_half_step_run_destroy": [_dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
                             _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _dp, _i, _i, _dp],

@@ -28,336 +28,7 @@
 // (before its own accept) and, for the complementary half, by the workgroup with the same
 // index (nobody writes those rows).  The kernel boundary is the ensemble-wide barrier
 // between half-steps.
-#include "nh_front.h"
-#include "nh_lnprob.h"
-#include "nh_syn.h"
-
-#define HS_MAX_TAB 4
-#ifndef HS_SYN_NODES
-#define HS_SYN_NODES 10  // synchrotron nodes per thread and work item (besides the start node)
-#endif
-#ifndef HS_ORDER
-#define HS_ORDER 0  // work items: 0 = tables and synchrotron alternate, 1 = tables first, 2 = synchrotron first
-#endif
-
-struct hs_tab {
-  const double* KD; const double* scale; double* out;  // KD: interleaved {K, dlnK}, [nG][nK][2]
-  int grid, nK, ldo, nonneg, spec_off, tiles, item0, chunks;
-  int sub, nKp;  // nK <= 32: sub = 64 / nKp sub-ranges of an item share a wave (nKp = 32, 16, ...)
-};
-
-struct hs_comp { const double* ptr; long long ld; double scale; int off; int pad; };
-
-// The descriptor.  All of it travels BY VALUE with the launch (hs_hot below), except the
-// parameter packs (1.6 KB), which stay in device memory: the threads that evaluate a pack
-// column fetch it in the same round trip as the slice of the move block.  (A first version
-// kept this block in device memory too: its first use -- the table descriptors at the head
-// of the work items, the prior terms -- then cost every wave a cold ~1.5 us round trip.)
-struct hs_dev {
-  const nh_pack* pk;  // [NH_MAX_PACK], device
-  int npk, kind;
-  const double* params;
-  double* w[NH_MAX_GRIDS]; double* dlw[NH_MAX_GRIDS];
-  double* mom_out[NH_MAX_MOMENT];
-  int* accepted; int* naccepted; int* sel;
-  int do_accept, write_weights;
-  hs_tab tab[HS_MAX_TAB];
-  int ntab, nT, seg;  // table items in total; segments per item
-  const double* synB; double* syn_out;
-  int syn_ldo, syn_bcol, syn_ldB, syn_cdmax;
-  hs_comp comp[NH_MAX_COMP];
-  int ncomp, pad0;
-  const double* lp;
-  nh_prior_pack pri;
-  double* model_out; double* total;
-  nh_hs_blob blob[NH_HS_MAX_BLOB];
-  int nblob, o_mrow;  // o_mrow: LDS offset of the model spectrum row + the moments' results
-  int sendw, pad1;    // > 0: total[] holds rows { lnprob | blobs } of this width (sharded loop)
-  long long* dbg;  // NH_HS_DEBUG=1: wall-clock stamps of the first 8 workgroups, [8][16]
-  // gridDim.y = K > 1 workgroups share a walker (launches of fewer walkers than the chip has
-  // CUs): their partial spectra meet in xspec[walker][K][nspec], the last to arrive (tick) sums
-  // them in a fixed order and carries on to the likelihood
-  double* xspec; int* tick;
-  int nspec, syn_nodes;  // syn_nodes: synchrotron nodes per thread and work item
-};
-
-// ... and its HOT part, passed by value: every pointer and size the first phases touch, so
-// that the kernel's first round trip to memory already fetches data, not descriptors.
-// The kernel's first scalar round trip: every pointer and size its second (vector) trip
-// needs, contiguous at the head of the argument block so that a few wide scalar loads and ONE
-// wait fetch it.  pkd: byte t = the proposal coordinate pack thread t reads (0xFF: a constant).
-struct hs_first {
-  const nh_pack* pk; const int* hbase; const double* logp; const nh_hist* hist;
-  int npk8, ngrids, nloc, ppk;  // ppk: the pack whose output is the particle rows
-  int nG[NH_MAX_GRIDS];
-  const double* e[NH_MAX_GRIDS]; const double* xg[NH_MAX_GRIDS];
-  const double* lne[NH_MAX_GRIDS]; const double* lx[NH_MAX_GRIDS];
-  unsigned pkd[8];
-  double* qT; double* factors;
-  const double* syn_c;  // [3][syn_nG]: 1/gamma^2 | its cube root | 1/g2^2 - 1/g1^2 (or NULL)
-  int syn_nG;
-  int broken;  // the particle distribution has a break energy (the only use of the grids' E)
-};
-
-struct hs_hot {
-  hs_first F;
-  hs_dev C;
-  const double* coords; const double* logp; const double* blk;
-  int* done; const int* hbase; int* cursor;
-  double* qT; double* factors; const nh_hist* hist;
-  int ns, ndim, lo, nloc;
-  const double* e[NH_MAX_GRIDS]; const double* xg[NH_MAX_GRIDS];
-  const double* lne[NH_MAX_GRIDS]; const double* lx[NH_MAX_GRIDS];
-  double scale[NH_MAX_GRIDS];
-  int nG[NH_MAX_GRIDS];
-  int o_w[NH_MAX_GRIDS], o_d[NH_MAX_GRIDS], o_lx[NH_MAX_GRIDS];
-  // grids that a non-negative table is reduced over: dlw / lx and 2^-10 / lx per node (-1: none)
-  int o_dp[NH_MAX_GRIDS], o_th[NH_MAX_GRIDS];
-  int ngrids, nmom;
-  const double* mKt[NH_MAX_MOMENT]; const double* mdK[NH_MAX_MOMENT];
-  int mgrid[NH_MAX_MOMENT];
-  int o_mkt, o_part_t, o_spec, o_lik;
-  int syn_grid, syn_nE, syn_spec_off, o_ig2, o_dig2, o_ig23, o_sq, o_amap, o_part_s, pad1;
-  const double* syn_E;
-  const double* conv; const double* flux; const double* elo; const double* ehi;
-  const int* ul; const double* cl;
-  int nE, ntab;
-  const double* tscale[HS_MAX_TAB];  // per-column factors of the table reductions (or NULL)
-  int tnK[HS_MAX_TAB], tspec[HS_MAX_TAB];
-  int o_scale, o_synE;  // o_synE: the synchrotron component's photon energies in LDS
-  int o_pri, pad4;      // the prior terms, copied out of the kernel-argument segment
-};
-
-struct nh_halfstep_plan {
-  hs_hot hot;
-  nh_pack* dev;      // device copy of the parameter packs
-  int* words;        // device: done counter | hbase
-  double* syn_c;     // device: the synchrotron grid's constants (k_syn_consts), or NULL
-  double* xspec;     // device: the partial spectra of a split launch, or NULL
-  int* tick;         // device: arrival counters of a split launch, or NULL
-  size_t lds_bytes;
-  int threads, blocks, split;  // split = K workgroups per walker (gridDim.y)
-  long long* dbg;
-};
-
-// ints at the head of the LDS block (after qs/row/lg/acc)
-enum { HI_ME = 0, HI_PA, HI_READY, HI_TICK, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
-#define HS_O_ROW 64
-#define HS_O_LG 72
-#define HS_O_ACC 76   // z, lnU, old logp, (pad)
-#define HS_O_INT 80   // 16 ints
-#define HS_O_T64 88   // 2^(j/64), j < 64: the table of nh_exp_tab
-#define HS_O_FREE 152
-#define HS_STAMP(k)                                                                    \
-  do {                                                                                  \
-    if (dbg_on && tid == 0 && j < 8) D.dbg[j * 16 + (k)] = (long long)wall_clock64();   \
-    if (dbg_on && tid == 0 && j < 1024) D.dbg[2304 + j * 16 + (k)] = (long long)wall_clock64(); \
-  } while (0)
-
-__device__ __forceinline__ double hs_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-typedef unsigned int hs_u32x4 __attribute__((ext_vector_type(4)));
-// one 16-byte element {K[i][k], dlnK[i][k]} of the interleaved table
-__device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double& K,
-                                          double& d) {
-  typedef double hs_f64x2 __attribute__((ext_vector_type(2)));
-  const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
-  const hs_f64x2 kd = __builtin_bit_cast(hs_f64x2, v);  // (register pairs as loaded: no moves)
-  K = kd.x;
-  d = kd.y;
-}
-
-// one table work item: columns [64 tile, 64 tile + 64) x segments [s0, s1) of table t for
-// this workgroup's walker, whose w / dlw / lx live in LDS (wave-uniform reads).  The table
-// is the interleaved copy KD[i][k] = {K, dlnK}: ONE 16-byte load per lane and node instead of
-// two 8-byte ones (8-byte accesses reach 0.54-0.70 of the L2 rate of 16-byte ones; with one
-// walker per workgroup the rows stream from L2 once per walker and that rate is the bound:
-// 23 us of table items became XX).  Eight nodes per trip = eight kilobytes in flight per
-// wave (a double-buffered four-node version, half of that in flight, measured 25 % slower).
-typedef __attribute__((address_space(3))) const double hs_lds_cd;
-// LDS byte address of a pointer into the workgroup's shared block, parked in a VECTOR register:
-// the walker's w / dlw / lx reads of a table item are wave-uniform, the compiler keeps such an
-// address in SGPRs and re-materialises it with a v_mov before EVERY ds_read (3 of the 15 VALU
-// instructions of a segment); from a VGPR base the reads of a trip are immediate offsets.
-__device__ __forceinline__ unsigned hs_lds_addr(const double* p) {
-  unsigned a = (unsigned)(unsigned long long)(hs_lds_cd*)p;
-  asm volatile("" : "+v"(a));
-  return a;
-}
-__device__ __forceinline__ double hs_lds_at(unsigned base, int idx) {
-  return *(hs_lds_cd*)(unsigned long long)(base + 8u * (unsigned)idx);
-}
-
-// One segment of a NON-NEGATIVE table on pre-divided log-ratios: the table carries
-// dlnK / lx (nh_table_interleave with lx), the walker dlw / lx, so that
-//   (u2 - u1) lx / dl = (u2 - u1) / dl',   dl' = dl / lx
-// -- no multiplication by lx, and the term joins the sum in the reciprocal's last FMA: 10
-// instructions per segment against 12.  |dl| < 2^-10 <=> |dl'| < th = 2^-10 / lx (per segment, in
-// LDS where lx was); the series (rare, wave-uniform branch) takes lx = 2^-10 / th.
-__device__ __forceinline__ double hs_seg_pre(double acc, double u1, double u2, double dlp,
-                                             double th) {
-  double a2 = fma(u2 - u1, nh_rcp1f(dlp), acc);
-  const bool small = fabs(dlp) < th;
-  if (__builtin_amdgcn_ballot_w64(small) != 0) {
-    asm volatile("" ::: "memory");  // keep this a branch: the compiler would if-convert it
-    const double lx = NH_SEG_SMALL_POS * nh_rcp(th);
-    const double d = dlp * lx;
-    double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
-    f = fma(f, d, 1.666666666666667e-01);
-    f = fma(f, d, 0.5);
-    f = fma(f, d, 1.0);
-    a2 = small ? fma(u1 * lx, f, acc) : a2;
-  }
-  return a2;
-}
-
-template <bool SIGNED>
-__device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
-                                                const double* ws, const double* ds,
-                                                const double* lxs, int lane) {
-  // the table's address and width come out of the descriptor: the compiler cannot
-  // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
-  // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
-  // the 25 the loop then costs) -- say so once per work item instead
-  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
-  const unsigned long long kd = (unsigned long long)t.KD;
-  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
-  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
-  const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
-  const int k = tile * 64 + lane;
-  const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
-  const unsigned tbytes = (unsigned)nG * nK * 16u;
-  const __amdgpu_buffer_rsrc_t rKD =
-      __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
-  const unsigned rowb = nK * 16u;
-  unsigned ob = ((unsigned)s0 * nK + kk) * 16u;
-  unsigned aw = hs_lds_addr(ws + s0), ad = hs_lds_addr(ds + s0), al = hs_lds_addr(lxs + s0);
-  double acc = 0.0;
-  double K1, d1;  // node s: its K and the log-ratio of the segment that starts there
-  hs_buf_kd(rKD, ob, K1, d1);
-  double u1 = hs_lds_at(aw, 0) * K1;
-  int s = s0;
-  for (; s + 8 <= s1; s += 8) {
-    double K2[8], dK[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double u2 = hs_lds_at(aw, q + 1) * K2[q];
-      const double dl = hs_lds_at(ad, q) + d1;
-      if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(al, q));
-      else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(al, q));
-      u1 = u2;
-      d1 = dK[q];
-    }
-    ob += 8 * rowb;
-    aw += 64u;
-    ad += 64u;
-    al += 64u;
-  }
-  if (s < s1) {  // tail: the remaining (< 8) nodes in one trip; rows past the table read 0
-    double K2[7], dK[7];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
-#pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      if (s + q < s1) {
-        const double u2 = hs_lds_at(aw, q + 1) * K2[q];
-        const double dl = hs_lds_at(ad, q) + d1;
-        if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(al, q));
-        else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(al, q));
-        u1 = u2;
-        d1 = dK[q];
-      }
-    }
-  }
-  return acc;
-}
-
-// The same for a table of at most 32 columns: a wave of 64 lanes would leave half of them (or
-// more) idle, and the loop is bound by instruction issue -- so `sub` = 64 / nKp sub-ranges of
-// the item's segments share the wave (lane = h nKp + k walks sub-range h of column k).  The
-// walker's w / dlw / lx reads are then per lane (LDS, `sub` distinct addresses per wave).
-// PK nodes per trip: 4 in the general instance of the kernel (123 VGPRs), 6 where there is no
-// synchrotron component (99 VGPRs without them): a narrow table's items are bound by the round
-// trips of their loads, half as many rows again in flight per trip (8 spills)
-template <bool SIGNED, int PK>
-__device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
-                                                       const double* ws, const double* ds,
-                                                       const double* lxs, int lane) {
-  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
-  const int nKp = __builtin_amdgcn_readfirstlane(t.nKp);
-  const int sub = __builtin_amdgcn_readfirstlane(t.sub);
-  const unsigned long long kd = (unsigned long long)t.KD;
-  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
-  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
-  const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
-  const int k = lane & (nKp - 1), h = lane / nKp;
-  const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
-  const unsigned tbytes = (unsigned)nG * nK * 16u;
-  const __amdgpu_buffer_rsrc_t rKD =
-      __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
-  const unsigned rowb = nK * 16u;
-  const int len = (s1 - s0 + sub - 1) / sub;     // segments per sub-range (wave-uniform)
-  const int sl = s0 + h * len;                   // this lane's first segment
-  const int se = min(s1, sl + len);              // ... and the end of its sub-range
-  unsigned ob = ((unsigned)sl * nK + kk) * 16u;  // (rows past the table read 0)
-  // per-lane LDS bases: the reads of a trip are immediate offsets from them.  Lanes whose
-  // sub-range is shorter than `len` read on past its end (another array of the block, or
-  // nothing: LDS reads out of range return 0) and discard the term.
-  unsigned aw = hs_lds_addr(ws + sl), ad = hs_lds_addr(ds + sl), al = hs_lds_addr(lxs + sl);
-  double acc = 0.0;
-  double K1, d1;
-  hs_buf_kd(rKD, ob, K1, d1);
-  // PK nodes per trip, the NEXT trip's loads issued before the current one is consumed: a
-  // narrow table means few work items -- one per wave, all waves in step -- so nothing else
-  // hides the round trip.  Two trips per loop iteration: the two register sets swap roles by
-  // name instead of being copied (eight 64-bit moves per trip otherwise).
-  double KA[PK], dA[PK], KB[PK], dB[PK];
-#pragma unroll
-  for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
-  double u1 = hs_lds_at(aw, 0) * K1;
-  const int owed = se - sl;  // segments of this lane's sub-range (<= 0: idle from the start)
-  int done = 0;              // (wave-uniform: lives in an SGPR)
-  auto trip = [&](const double (&K2)[PK], const double (&dK)[PK]) {
-#pragma unroll
-    for (int q = 0; q < PK; ++q) {
-      const double u2 = hs_lds_at(aw, q + 1) * K2[q];
-      const double dl = hs_lds_at(ad, q) + d1;
-      const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(al, q))
-                                 : hs_seg_pre(0.0, u1, u2, dl, hs_lds_at(al, q));
-      acc += done + q < owed ? term : 0.0;
-      u1 = u2;
-      d1 = dK[q];
-    }
-    done += PK;
-    aw += 8u * PK;
-    ad += 8u * PK;
-    al += 8u * PK;
-  };
-  for (int q0 = 0; q0 < len; q0 += 2 * PK) {
-    ob += PK * rowb;
-    if (q0 + PK < len) {
-#pragma unroll
-      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KB[q], dB[q]);
-    }
-    trip(KA, dA);
-    if (q0 + PK >= len) break;
-    ob += PK * rowb;
-    if (q0 + 2 * PK < len) {
-#pragma unroll
-      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
-    }
-    trip(KB, dB);
-  }
-  // the sub-ranges of a column meet in its first lane group (fixed order: deterministic)
-  for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
-  return acc;
-}
+#include "nh_hs.h"
 
 // The first arguments are what the proposal's chain of dependent reads starts from: scalar
 // kernel arguments can be preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count),
@@ -1167,62 +838,12 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           syn_ready = true;
         }
-        const int vt = ix * 64 + lane;
-        const int a = vt % nA, ch = vt / nA;
-        if (ch < Cd) {
-          const int g = H.syn_grid, nG = H.nG[g], nseg = nG - 1, nEs = H.syn_nE;
-          const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
-          const int* ai0 = amap + nEs;
-          const double* ig2 = sm + H.o_ig2;
-          const double* dig2 = sm + H.o_dig2;
-          const double* ig23 = sm + H.o_ig23;
-          const double* wr = sm + H.o_w[g];
-          const double* dwr = sm + H.o_d[g];
-          const double* lxs = sm + H.o_lx[g];
-          const double* sq = sm + H.o_sq;
-          const double* T64 = sm + HS_O_T64;
-          const int sbeg = ai0[a];
-          const int per = (nseg - sbeg + Cd - 1) / Cd;
-          const int s0 = sbeg + ch * per;
-          const int s1 = min(nseg, s0 + per);
-          const double q = sq[a], cbq = sq[nEs + a];
-          double acc = 0.0;
-          if (s0 < s1) {
-            // One node: gamma nelec dNdE / CS1 (radiative.py:335-338) and P.  No branch and no
-            // select: every node of the range is live (x <= 746, the liveness search), a zero
-            // weight gives u = 0 by itself (P is finite), so TWO nodes per trip are one straight
-            // block the scheduler can interleave.  (One node per trip, behind a branch, is a
-            // dependent chain of ~70 FP64 instructions: a wave alone took 21 cycles per
-            // instruction, four waves per SIMD kept it 40 % busy.)  A weight that has underflowed
-            // to 0 ends the integrand like a table's zero entry does (nh_seg_pos<false>).
-            auto node = [&](int sn, double& u, double& P) {
-              const double x = q * ig2[sn];
-              P = syn_P1(cbq * ig23[sn]);
-              u = wr[sn] * (P * nh_exp_tab(-fmin(x, 800.0), T64));
-            };
-            double u1, P1;
-            node(s0, u1, P1);
-            int s = s0;
-            for (; s + 2 <= s1; s += 2) {
-              double uA, PA, uB, PB;
-              node(s + 1, uA, PA);
-              node(s + 2, uB, PB);
-              // ln|u2/u1| = ln(w2/w1) + ln(P2/P1) - (x2 - x1); unused when a node is 0
-              const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
-              const double dlB = dwr[s + 1] + syn_dlnP1(PA, PB) - q * dig2[s + 1];
-              acc += nh_seg_pos<false>(u1, uA, dlA, lxs[s]);  // P(x) exp(-x) >= 0
-              acc += nh_seg_pos<false>(uA, uB, dlB, lxs[s + 1]);
-              u1 = uB;
-              P1 = PB;
-            }
-            if (s < s1) {
-              double uA, PA;
-              node(s + 1, uA, PA);
-              const double dlA = dwr[s] + syn_dlnP1(P1, PA) - q * dig2[s];
-              acc += nh_seg_pos<false>(u1, uA, dlA, lxs[s]);
-            }
-          }
-          part_s[ch * nEs + a] = acc * sq[2 * nEs + a];  // linear in u: CS1 once per thread
+        {
+          const int g = H.syn_grid, nEs = H.syn_nE;
+          const hs_syn_lds L = {reinterpret_cast<const int*>(sm + H.o_amap), sm + H.o_ig2,
+                                sm + H.o_dig2, sm + H.o_ig23, sm + H.o_w[g], sm + H.o_d[g],
+                                sm + H.o_lx[g], sm + H.o_sq, sm + HS_O_T64};
+          hs_syn_item(ix, lane, nA, Cd, H.nG[g], nEs, L, part_s);
         }
       }
     }

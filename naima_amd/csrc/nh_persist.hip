@@ -1,0 +1,904 @@
+// nh_persist.hip -- a whole block of moves in ONE launch: the half-step kernel with its
+// workgroups resident, walkers handed from half-step to half-step by per-walker records
+// instead of by the kernel boundary.
+//
+// Why.  k_half_step (nh_halfstep.hip) carries one walker from the stretch-move proposal to
+// the accept in one launch, and the launch boundary is the ensemble-wide barrier between
+// half-steps (emcee RedBlueMove: the second half moves against the first half's NEW
+// positions; reference call sites core.py:128, 450-457).  But a walker of half-step h + 1
+// needs exactly TWO records -- its own and its partner's -- not the whole launch.  Paying
+// the boundary meant, per half-step of cfg3 (256 workgroups, round-2 phase stamps): 1.45 us
+// of boundary, two cold round trips (argument block, grids' arrays: 2.5 us) and 2 us of LDS
+// refills before the first useful instruction, the SLOWEST of 256 workgroups (35.1 us against
+// a median of 33.2) setting the pace of all, every XCD's L2 cold again (each pulled its own
+// copy of the 1.1 MB emission table from the Infinity Cache: 80x the algorithmic traffic).
+//
+// Here gridDim.x workgroups (all co-resident: one per CU at 1024 threads) loop over the
+// slices of the block of moves.  What does not depend on the walker is fetched ONCE per
+// launch and stays in LDS: the grids' nodes, ln E and segment widths, the synchrotron grid's
+// constants, the exp table, the likelihood's data columns, the prior terms, the parameter
+// packs' descriptors.  The ensemble lives in a ring of rows, row k = the state after step
+// k - 1 of the launch, one record per walker: 2 (ndim + 1) granules of 8 bytes
+// { 32 bits of payload | 32-bit tag }, tag = (launch sequence number, row).  A granule is one
+// naturally aligned 8-byte write-through (sc1) store, so whoever reads it sees all of it or
+// none of it, and a stale or not-yet-written granule is RECOGNISED by its tag, never consumed
+// (MI355X_MICROARCH.md, hand-off price list: data-tagged granules, ~1 us producer to
+// consumer, no fence).  Every record is written once per launch, by the workgroup that moved
+// the walker in that step; a consumer polls the 2 x 2 (ndim + 1) granules it needs with sc1
+// loads from one wave.  There is no other synchronisation: dependencies point strictly
+// backwards in (slice, walker) order and every workgroup works through its walkers in that
+// order, so the launch cannot deadlock as long as all workgroups are resident (the host sizes
+// the grid by the occupancy query); every poll loop is bounded and a time-out aborts the
+// whole launch with a status word instead of hanging the device.
+//
+// Inside a workgroup wave 0 runs ahead: as soon as the spectra of slice h are summed it polls
+// for the records of slice h + 1, proposes and evaluates the parameter packs, while wave 1
+// finishes slice h (likelihood, accept, publish, history).  The small per-walker block of LDS
+// (proposal, particle row, counters) is double-buffered for that overlap.
+//
+// Outputs: the ring (its last row is converted back to the flat coords / logp arrays by
+// k_run_epilogue), the chain history rows (each entry written once, by the walker's mover),
+// the accept flags accw[step][walker], blobs of ACCEPTED proposals (history row, or the
+// current-blob array when no history is kept); k_run_epilogue fills the blob rows of rejected
+// proposals forward from the previous step and adds the accept flags to the acceptance
+// counters.
+#include "nh_hs.h"
+
+#define HS_RUN_MAX_STEPS 32  // steps per launch (one block of moves); ring rows = this + 1
+#define HS_RUN_ERR_TIMEOUT 1
+#define HS_RUN_ERR_PEER 2
+
+struct hs_run {
+  unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
+  int* status;               // device word: 0, or HS_RUN_ERR_* of the first workgroup that gave up
+  int* accw;                 // [HS_RUN_MAX_STEPS][N]: 1 where the step's proposal was accepted
+  double* hcoords; double* hlogp;  // chain history of this call (or NULL) ...
+  double* hblob[NH_HS_MAX_BLOB];   // ... and the blobs' (or NULL)
+  long long hrow0, hcap;     // history row of the launch's first step; rows the history holds
+  long long* dbg;            // NH_HS_DEBUG: [256][64][8] wall-clock stamps, or NULL
+  int slice0, nslices;       // slices [slice0, slice0 + nslices) of the block of moves; slice0 even
+  unsigned seq;              // launch sequence number (tags)
+  int gr, N;                 // granules per record (a multiple of 16: one record = whole lines)
+  int o_gx[NH_MAX_GRIDS], o_lne[NH_MAX_GRIDS], o_ge[NH_MAX_GRIDS];  // LDS: grid nodes, ln E, E
+  int o_pk, o_small1, o_olds;  // LDS: pack descriptors, the second small block, old coordinates
+  int spin_limit, pad;
+};
+
+static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
+
+__device__ __forceinline__ unsigned long long hs_ld_sc1(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hs_st_sc1(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned hs_tag(unsigned seq, int row) {
+  return (seq << 8) | (unsigned)(row + 1);  // (never 0: a zeroed ring matches nothing)
+}
+// granule L of the record of the doubles v[0 .. n): L = 2 d + {0: low, 1: high word}
+__device__ __forceinline__ unsigned long long hs_granule(double v, int L, unsigned tag) {
+  const unsigned w = (L & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+  return ((unsigned long long)tag << 32) | w;
+}
+
+#define HSR_STAMP(k)                                                                   \
+  do {                                                                                  \
+    if (R.dbg && tid == 0 && blockIdx.x < 256 && it < 64)                               \
+      R.dbg[((long long)blockIdx.x * 64 + it) * 8 + (k)] = (long long)wall_clock64();   \
+  } while (0)
+
+template <bool SYN>
+__global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs_run R) {
+  extern __shared__ double sm[];
+  const hs_dev& D = H.C;
+  const int T = blockDim.x, tid0 = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6), nwv = T >> 6;
+  int tid = tid0, lane = tid0 & 63;
+  const int ns = H.ns, ndim = H.ndim, N = R.N;
+  const bool has_syn = SYN && H.syn_grid >= 0;
+  const bool broken = H.F.broken != 0;
+  const int GRn = 2 * (ndim + 1);  // granules of a record that carry data (<= 32)
+  const bool lik_wave = wv == (nwv > 1 ? 1 : 0);
+  const int npk8 = H.F.npk8;
+
+  // =========================== once per launch ==============================================
+  if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
+  for (int g = 0; g < H.ngrids; ++g) {
+    const int nG = H.nG[g];
+    for (int i = tid; i < nG; i += T) {
+      sm[H.o_lx[g] + i] = i + 1 < nG ? H.lx[g][i] : 0.0;
+      sm[R.o_gx[g] + i] = H.xg[g][i];
+      sm[R.o_lne[g] + i] = H.lne[g][i];
+      if (broken) sm[R.o_ge[g] + i] = H.e[g][i];
+    }
+  }
+  {
+    const int npri = (int)(sizeof(nh_prior_pack) / sizeof(double));
+    const double* psrc = reinterpret_cast<const double*>(&D.pri);
+    for (int t = tid; t < npri; t += T) sm[H.o_pri + t] = psrc[t];
+    if (has_syn) {
+      for (int k = tid; k < H.syn_nE; k += T) sm[H.o_synE + k] = H.syn_E[k];
+      const int nGs = H.F.syn_nG;
+      for (int i = tid; i < nGs; i += T) {
+        sm[H.o_ig2 + i] = H.F.syn_c[i];
+        sm[H.o_ig23 + i] = H.F.syn_c[nGs + i];
+        sm[H.o_dig2 + i] = H.F.syn_c[2 * nGs + i];
+      }
+    }
+    for (int t = 0; t < H.ntab; ++t)
+      for (int k = tid; k < H.tnK[t]; k += T)
+        sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
+    double* lik = sm + H.o_lik;  // conv | flux | elo | ehi | ul, nE each
+    for (int k = tid; k < H.nE; k += T) {
+      lik[k] = H.conv[k];
+      lik[H.nE + k] = H.flux[k];
+      lik[2 * H.nE + k] = H.elo[k];
+      lik[3 * H.nE + k] = H.ehi[k];
+      lik[4 * H.nE + k] = (double)H.ul[k];
+    }
+    int ko = H.o_mkt;
+    for (int m = 0; m < H.nmom; ++m) {  // the single-row tables (We, Wp)
+      const int nG = H.nG[H.mgrid[m]];
+      for (int i = tid; i < nG; i += T) {
+        sm[ko + i] = H.mKt[m][i];
+        sm[ko + nG + i] = H.mdK[m][i];
+      }
+      ko += 2 * nG;
+    }
+    // the parameter packs' columns, one per thread of wave 0: a | b | c | tf, ncols | ld | out
+    if (tid < npk8) {
+      const nh_pack& P = D.pk[tid / NH_MAX_LAZY];
+      const nh_lazy& z = P.cols[tid % NH_MAX_LAZY];
+      double* o = sm + R.o_pk + tid * 6;
+      o[0] = z.a;
+      o[1] = z.b;
+      o[2] = z.c;
+      reinterpret_cast<int*>(o + 3)[0] = z.tf;
+      reinterpret_cast<int*>(o + 3)[1] = P.ncols;
+      reinterpret_cast<long long*>(o + 4)[0] = (long long)P.ld;
+      reinterpret_cast<double**>(o + 5)[0] = P.out;
+    }
+  }
+  // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or
+  // by the host: the kernel boundary has made it visible).  Walker w by workgroup w mod grid.
+  if (wv == 0) {
+    const unsigned tag0 = hs_tag(R.seq, 0);
+    for (int w = blockIdx.x; w < N; w += gridDim.x) {
+      if (lane < GRn) {
+        const int d = lane >> 1;
+        const double v = d < ndim ? H.coords[(long long)w * ndim + d] : H.logp[w];
+        hs_st_sc1(R.ring + (long long)w * R.gr + lane, hs_granule(v, lane, tag0));
+      }
+    }
+  }
+  __syncthreads();
+
+  // which grid does unit u (64 consecutive nodes of one grid) belong to
+  int ub[NH_MAX_GRIDS + 1];
+  ub[0] = 0;
+#pragma unroll
+  for (int g = 0; g < NH_MAX_GRIDS; ++g)
+    ub[g + 1] = ub[g] + (g < H.ngrids ? (H.nG[g] + 63) >> 6 : 0);
+  const int nunits = ub[NH_MAX_GRIDS];
+  const int tiles_ = has_syn ? (H.syn_nE + 63) >> 6 : 0;
+  // the weights' nodes go to the waves that have nothing else to do before the second
+  // barrier: not the likelihood wave (priors), not the tile waves (liveness search)
+  int nwork = nwv - 1 - tiles_, rank = wv == 0 ? 0 : wv - 1;
+  bool worker = wv != 1 && wv < nwv - tiles_;
+  if (nwork < 1) {
+    nwork = nwv;
+    rank = wv;
+    worker = true;
+  }
+
+  // =========================== the slices ====================================================
+  int it = 0;
+  for (int s = 0; s < R.nslices; ++s) {
+    const int h = R.slice0 + s, tl = s >> 1, half = s & 1;  // tl: step of the launch
+    const double* r = H.blk + (long long)h * 3 * ns;
+    const int* idx = reinterpret_cast<const int*>(r + 2 * ns);
+    for (int j = blockIdx.x; j < H.nloc; j += gridDim.x, ++it) {
+      // (the thread index is made opaque once per slice: everything derived from it -- LDS
+      // addresses, lane roles of every phase -- would otherwise be hoisted out of the slice loop
+      // and kept in registers across all phases: 190 registers of spill)
+      tid = tid0;
+      asm volatile("" : "+v"(tid));
+      lane = tid & 63;
+      const int par = it & 1;
+      double* qs = par ? sm + R.o_small1 : sm;
+      double* row = qs + HS_O_ROW;
+      double* lg = qs + HS_O_LG;
+      double* accs = qs + HS_O_ACC;
+      int* hi = reinterpret_cast<int*>(qs + HS_O_INT);
+      double* olds = sm + R.o_olds + par * 64;
+      HSR_STAMP(0);
+      // ---- A. wave 0: the two records, the proposal, the parameter packs ---------------------
+      if (wv == 0) {
+        const int g = H.lo + j;
+        const int me = idx[g], pa = idx[ns + g];
+        const double mz = r[g], mlnu = r[ns + g];
+        if (lane == 0) {
+          hi[HI_CNT] = 0;
+          hi[HI_LIVE] = 0;
+          hi[HI_READY] = 0;
+          hi[HI_NZ] = 0;
+          hi[HI_TICK] = 0;  // (here: the abort flag of this slice)
+        }
+        // lanes 0 .. GRn-1: my own record in row tl (the state after the previous step);
+        // lanes 32 .. 32+GRn-1: the partner's -- row tl for the first half of a step, row
+        // tl + 1 for the second (the partner has moved in the first half of THIS step)
+        const bool mine = lane < GRn, theirs = lane >= 32 && lane - 32 < GRn;
+        const int prow = tl + half;
+        const unsigned long long* src =
+            R.ring + ((long long)(lane < 32 ? tl : prow) * N + (lane < 32 ? me : pa)) * R.gr +
+            (lane & 31);
+        const unsigned want = hs_tag(R.seq, lane < 32 ? tl : prow);
+        unsigned long long v = 0;
+        bool ok = !(mine || theirs);
+        int spins = 0, bad = 0;
+        for (;;) {
+          if (!ok) {
+            v = hs_ld_sc1(src);
+            ok = (unsigned)(v >> 32) == want;
+          }
+          if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+          ++spins;
+          if ((spins & 255) == 0) {  // somebody else has given up: so do we
+            int st = 0;
+            if (lane == 0)
+              st = (int)__hip_atomic_load(R.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st = __builtin_amdgcn_readfirstlane(st);
+            if (st != 0) { bad = HS_RUN_ERR_PEER; break; }
+          }
+          if (spins > R.spin_limit) { bad = HS_RUN_ERR_TIMEOUT; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) {
+          if (lane == 0) {
+            hi[HI_TICK] = bad;
+            if (bad == HS_RUN_ERR_TIMEOUT)
+              __hip_atomic_store(R.status, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const unsigned pl = (unsigned)v;
+        const int d2 = (2 * lane) & 31;
+        const unsigned mlo = (unsigned)__shfl((int)pl, d2, 64);
+        const unsigned mhi = (unsigned)__shfl((int)pl, d2 + 1, 64);
+        const unsigned plo = (unsigned)__shfl((int)pl, 32 + d2, 64);
+        const unsigned phi = (unsigned)__shfl((int)pl, 33 + d2, 64);
+        const double sme = __hiloint2double((int)mhi, (int)mlo);
+        const double spa = __hiloint2double((int)phi, (int)plo);
+        const double q = spa - (spa - sme) * mz;  // emcee StretchMove.get_proposal
+        if (lane < ndim) {
+          qs[lane] = q;
+          olds[lane] = sme;
+        }
+        if (lane == ndim) accs[2] = sme;  // the old log-probability rides behind the coordinates
+        if (lane == 0) {
+          accs[0] = mz;
+          accs[1] = mlnu;
+          hi[HI_ME] = me;
+          hi[HI_PA] = pa;
+        }
+        HSR_STAMP(1);
+        // the packs: thread t < 8 npacks evaluates column t % 8 of pack t / 8 from ONE proposed
+        // coordinate (which one is walker-independent: a byte of pkd), taken by a shuffle
+        int pkd = -1;
+        if (lane < npk8) {
+          const unsigned word = H.F.pkd[lane >> 2];
+          const int b = (int)((word >> (8 * (lane & 3))) & 0xFFu);
+          if (b != 0xFF) pkd = b;
+        }
+        const double qv = __shfl(q, pkd < 0 ? 0 : pkd, 64);
+        if (lane < npk8) {
+          const double* o = sm + R.o_pk + lane * 6;
+          nh_lazy z;
+          z.base = nullptr;
+          z.stride = 1;
+          z.a = o[0];
+          z.b = o[1];
+          z.c = o[2];
+          z.tf = reinterpret_cast<const int*>(o + 3)[0];
+          z.pad = 0;
+          const int nc = reinterpret_cast<const int*>(o + 3)[1];
+          const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
+          double* out = reinterpret_cast<double* const*>(o + 5)[0];
+          const int col = lane % NH_MAX_LAZY;
+          if (col < nc) {
+            double val = z.a;
+            if (pkd >= 0) val = nh_lazy_apply(z, qv);
+            out[(long long)j * ld + col] = val;
+            if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
+              row[col] = val;
+              if (col == 1 || col == 3 || col == 5) lg[col >> 1] = val > 0.0 ? log(val) : 0.0;
+            }
+          }
+        }
+      }
+      __syncthreads();  // ---------------------------------------------------------------- #1
+      HSR_STAMP(2);
+      if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
+      // ---- B. priors (core.py:34-58, 99-101): a proposal the prior forbids is never accepted,
+      // so none of its integrals is evaluated (the reference evaluates and discards,
+      // core.py:103-119)
+      if (lik_wave) {
+        const nh_prior_pack& PR = *reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri);
+        const int npri = PR.n;
+        const bool has_prior = D.lp || npri > 0;
+        double term = 0.0;
+        if (lane < npri) {
+          const nh_prior& pt = PR.t[lane];
+          const nh_lazy z = pt.x;
+          double v = z.a;
+          if (z.base) {
+            const long long d = z.base - H.qT;
+            v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
+                    ? nh_lazy_apply(z, qs[d / H.nloc])
+                    : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
+          }
+          const double p0 = pt.p0, p1 = pt.p1;
+          switch (pt.kind) {
+            case NH_PRIOR_UNIFORM: term = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
+            case NH_PRIOR_NORMAL: term = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
+            case NH_PRIOR_LOGUNIFORM: term = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
+            default: term = v; break;
+          }
+        }
+        double prior = 0.0;
+        for (int t = 0; t < npri; ++t) prior += __shfl(term, t, 64);
+        if (D.lp) prior += D.lp[j];
+        if (lane == 0) {
+          accs[3] = prior;
+          hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
+        }
+      }
+      // ---- particle weights on every grid (-> LDS); the synchrotron liveness search ----------
+      const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
+      double* spec = sm + H.o_spec;
+      double Bw = 0.0, qfac = 0.0;
+      if (has_syn) {
+        Bw = D.syn_bcol >= 0 ? row[D.syn_bcol] : D.synB[(long long)j * D.syn_ldB];
+        // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
+        qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
+      }
+      int lv_i0 = 0, lv_k = -1;
+      double lv_q = 0.0, lv_E = 0.0;
+      bool lv_live = false;
+      int* tcnt = hi + 8;  // [<= 8] live energies per tile
+      const int syn_tiles = tiles_;
+      if (has_syn && nwv - 1 - wv < syn_tiles) {
+        const int nG = H.nG[H.syn_grid];
+        const double* ig2 = sm + H.o_ig2;
+        const int t = nwv - 1 - wv;
+        lv_k = t * 64 + lane;
+        lv_i0 = nG;
+        if (lv_k < H.syn_nE) {
+          lv_E = sm[H.o_synE + lv_k];
+          lv_q = lv_E * qfac;
+          int lo = 0, hi2 = nG;  // first i with q*ig2[i] <= 746 (ig2 decreases with i)
+          while (lo < hi2) {
+            const int mid = (lo + hi2) >> 1;
+            if (lv_q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
+          }
+          lv_i0 = lo;
+        }
+        lv_live = lv_i0 < nG;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
+        int ln = lv_live ? (nG - 1) - lv_i0 : 0;  // segments this energy walks
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
+        if (lane == 0) {
+          tcnt[t] = __popcll(m);
+          if (ln > 0) atomicAdd(&hi[HI_LIVE], ln);
+        }
+      }
+      int nzmask = 0;
+      for (int u = worker ? rank : nunits; u < nunits; u += nwork) {
+        int g = 0;
+        while (u >= ub[g + 1]) ++g;
+        const int nG = H.nG[g], i = (u - ub[g]) * 64 + lane;
+        if (i < nG) {
+          const bool last = i + 1 >= nG;
+          const double lr = sm[H.o_lx[g] + i];  // (0 at the last node)
+          const double lnE = sm[R.o_lne[g] + i];
+          const double gx = sm[R.o_gx[g] + i];
+          bool b1 = false, b2 = false;
+          if (broken) {
+            const double E = sm[R.o_ge[g] + i];
+            const double E2 = last ? E : sm[R.o_ge[g] + i + 1];
+            b1 = E < p.eb;
+            b2 = E2 < p.eb;
+          }
+          double nn, dsh;
+          pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], b1, b2, lr, nn, dsh,
+                  sm + HS_O_T64);
+          nn *= H.scale[g];
+          const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
+          sm[H.o_w[g] + i] = wv_;
+          sm[H.o_d[g] + i] = dv;
+          if (H.o_dp[g] >= 0) {  // what the non-negative table items read
+            const double il = last ? 0.0 : nh_rcp(lr);
+            sm[H.o_dp[g] + i] = dv * il;
+            sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+          }
+          if (wv_ != 0.0) nzmask |= 1 << g;
+        }
+      }
+      {
+        int any = nzmask;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
+        if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
+      }
+      __syncthreads();  // ---------------------------------------------------------------- #2
+      HSR_STAMP(3);
+      const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
+      int nA = 0, Cd = 1, nS = 0;
+      if (has_syn) {
+        const int nEs = H.syn_nE;
+        for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
+        const bool syn_zero = !(nz >> H.syn_grid & 1);
+        if (nA > 0 && !syn_zero) {
+          Cd = (hi[HI_LIVE] / nA + D.syn_nodes - 1) / D.syn_nodes;
+          Cd = min(max(Cd, 1), D.syn_cdmax);
+          nS = (nA * Cd + 63) >> 6;
+        }
+        if (syn_zero) {
+          for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = 0.0;
+          nA = 0;
+        }
+        if (lv_k >= 0 && !syn_zero) {
+          int* amap = reinterpret_cast<int*>(sm + H.o_amap);
+          int* ai0 = amap + nEs;
+          double* sq = sm + H.o_sq;  // q | cbrt(q) | CS1 per live energy
+          const int t = nwv - 1 - wv;
+          int base = 0;
+          for (int q = 0; q < t; ++q) base += tcnt[q];
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
+          if (lv_live) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            amap[pos] = lv_k;
+            ai0[pos] = lv_i0;
+            sq[pos] = lv_q;
+            sq[nEs + pos] = cbrt(lv_q);
+            // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
+            sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                                (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
+                                 (lv_E * NH_ERG_PER_EV));
+          } else if (lv_k < nEs) {
+            spec[H.syn_spec_off + lv_k] = 0.0;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) atomicAdd(&hi[HI_READY], 1);
+        }
+      }
+      // ---- single-row reductions (We, Wp), one wave each (from the back) ----------------------
+      if (nwv - 1 - wv < H.nmom) {
+        const int m = nwv - 1 - wv;
+        const int g = H.mgrid[m], nG = H.nG[g];
+        int ko = H.o_mkt;
+        for (int q = 0; q < m; ++q) ko += 2 * H.nG[H.mgrid[q]];
+        const double* ws = sm + H.o_w[g];
+        const double* ds = sm + H.o_d[g];
+        const double* lxs = sm + H.o_lx[g];
+        double acc = 0.0;
+        for (int sgm = lane; sgm < nG - 1; sgm += 64) {
+          const double u1 = ws[sgm] * sm[ko + sgm];
+          const double u2 = ws[sgm + 1] * sm[ko + sgm + 1];
+          const double dl = ds[sgm] + sm[ko + nG + sgm];
+          acc += nh_seg_term(u1, u2, dl, lxs[sgm]);
+        }
+        acc = hs_wave_sum(acc);
+        if (lane == 0) sm[D.o_mrow + H.nE + m] = acc;
+      }
+      // ---- C. work items: table reductions and synchrotron nodes, pulled from one counter -----
+      {
+        const int nT = D.nT;
+        const int F0 = min(nT, nwv);
+        const int both = 2 * min(nT - F0, nS), total = nT + nS;
+        bool syn_ready = !has_syn;
+        double* part_t = sm + H.o_part_t;
+        double* part_s = sm + H.o_part_s;
+        for (;;) {
+          int item = 0;
+          if (lane == 0) item = atomicAdd(&hi[HI_CNT], 1);
+          item = __builtin_amdgcn_readfirstlane(item);
+          if (item >= total) break;
+          bool is_tab;
+          int ix;
+          if (item < F0) {
+            is_tab = true;
+            ix = item;
+          } else if (item - F0 < both) {
+            is_tab = ((item - F0) & 1) != 0;
+            ix = is_tab ? F0 + ((item - F0) >> 1) : (item - F0) >> 1;
+          } else {
+            is_tab = nT - F0 > nS;
+            ix = is_tab ? item - nS : item - nT;
+          }
+          if (is_tab) {
+            int t = 0;
+            while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
+            const hs_tab& tb = D.tab[t];
+            const int loc = ix - tb.item0;
+            const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
+            const int tg = __builtin_amdgcn_readfirstlane(tb.grid);
+            const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
+            const int s0 = chunk * D.seg, s1 = min(nG - 1, s0 + D.seg);
+            const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
+            const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
+            const double* ds = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_dp[tg] : H.o_d[tg]);
+            const double* lxs = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_th[tg] : H.o_lx[tg]);
+            double acc;
+            if (!(nz >> tg & 1))
+              acc = 0.0;
+            else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
+              acc = tb.nonneg ? hs_table_item_packed<false, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane)
+                              : hs_table_item_packed<true, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane);
+            else
+              acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
+                              : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
+            part_t[ix * 64 + lane] = acc;
+          } else if (SYN) {
+            if (!syn_ready) {  // (wave-uniform) the tile waves' constants must have landed
+              while (__atomic_load_n(&hi[HI_READY], __ATOMIC_RELAXED) < syn_tiles)
+                __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              syn_ready = true;
+            }
+            const int g = H.syn_grid, nEs = H.syn_nE;
+            const hs_syn_lds L = {reinterpret_cast<const int*>(sm + H.o_amap), sm + H.o_ig2,
+                                  sm + H.o_dig2, sm + H.o_ig23, sm + H.o_w[g], sm + H.o_d[g],
+                                  sm + H.o_lx[g], sm + H.o_sq, sm + HS_O_T64};
+            hs_syn_item(ix, lane, nA, Cd, H.nG[g], nEs, L, part_s);
+          }
+        }
+      }
+      HSR_STAMP(4);
+      __syncthreads();  // ---------------------------------------------------------------- #3
+      HSR_STAMP(5);
+      // ---- the walker's spectra meet in LDS ---------------------------------------------------
+      for (int t = 0; t < D.ntab; ++t) {
+        const hs_tab& tb = D.tab[t];
+        for (int k = tid; k < tb.nK; k += T) {
+          const int tile = k >> 6, ln = k & 63;
+          const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
+          const int stride = tb.tiles * 64, chunks = tb.chunks;
+          double sum = 0.0;
+          for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          }
+          sum *= sm[H.o_scale + tb.spec_off + k];
+          spec[tb.spec_off + k] = sum;
+        }
+      }
+      if (has_syn) {
+        const int nEs = H.syn_nE;
+        const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
+        for (int a = T - 1 - tid; a < nA; a += T) {  // (from the back: the tables took the front)
+          const double* pp = sm + H.o_part_s + a;
+          double sum = 0.0;
+          for (int c0 = 0; c0 < Cd; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          }
+          sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
+          spec[H.syn_spec_off + amap[a]] = sum;
+        }
+      }
+      __syncthreads();  // ---------------------------------------------------------------- #4
+      HSR_STAMP(6);
+      // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
+      // wave 0 is already polling for the next slice ------------------------------------------
+      if (lik_wave) {
+        const int nE = H.nE;
+        const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
+        const double prior = accs[3];
+        double acc = 0.0;
+        int nviol = 0, nul = 0;
+        const double* lik = sm + H.o_lik;
+        for (int k = lane; k < nE; k += 64) {
+          double m = 0.0;
+          for (int q = 0; q < D.ncomp; ++q) {
+            const double v = D.comp[q].off >= 0 ? spec[D.comp[q].off + k]
+                                                : D.comp[q].ptr[(long long)j * D.comp[q].ld + k];
+            m += D.comp[q].scale * v;
+          }
+          if (D.nblob) sm[D.o_mrow + k] = m;
+          const double mc = m * lik[k];
+          const double f = lik[nE + k];
+          if (lik[4 * nE + k] != 0.0) {
+            nul += 1;
+            nviol += (mc > f) ? 1 : 0;
+          } else {
+            const double d = mc - f;
+            const double sg = (d > 0.0) ? lik[3 * nE + k] : lik[2 * nE + k];
+            acc += -(d * d) / (2.0 * (sg * sg));
+          }
+        }
+        int cnt = nviol | (nul << 16);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double a2 = __shfl_down(acc, off, 64);
+          const int c2 = __shfl_down(cnt, off, 64);
+          acc += a2;
+          cnt += c2;
+        }
+        if (lane == 0) {
+          nviol = cnt & 0xffff;
+          nul = cnt >> 16;
+          // quirk kept from core.py:89-92: cl is indexed by the violation count
+          if (nul > 0) acc += (double)nviol * log(1.0 - H.cl[nviol]);
+          if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
+        }
+        acc = __shfl(acc, 0, 64);
+        // emcee RedBlueMove.propose for this walker
+        const double z = accs[0], oldlp = accs[2];
+        const double dd = (ndim - 1.0) * log(z) + acc - oldlp;
+        const bool ok = accs[1] < dd;  // NaN compares false, as numpy
+        const int me2 = hi[HI_ME];
+        // the record of the state after this step: row tl + 1
+        double val = 0.0;
+        if (lane < GRn) {
+          const int d = lane >> 1;
+          val = d < ndim ? (ok ? qs[d] : olds[d]) : (ok ? acc : oldlp);
+          hs_st_sc1(R.ring + ((long long)(tl + 1) * N + me2) * R.gr + lane,
+                    hs_granule(val, lane, hs_tag(R.seq, tl + 1)));
+        }
+        HSR_STAMP(7);
+        // chain history: this walker's entry of the step's row (nobody else writes it)
+        const long long hrow = R.hrow0 + tl;
+        const bool hist = R.hcoords != nullptr && hrow < R.hcap;
+        if (hist) {
+          if (lane < ndim) R.hcoords[(hrow * N + me2) * ndim + lane] = ok ? qs[lane] : olds[lane];
+          if (lane == 0) R.hlogp[hrow * N + me2] = ok ? acc : oldlp;
+        }
+        if (lane == 0) R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
+        if (ok) {  // the accepted position's blobs
+          for (int b = 0; b < D.nblob; ++b) {
+            const nh_hs_blob& bl = D.blob[b];
+            double* hb = hist ? R.hblob[b] : nullptr;
+            if (hb) {  // (its row of the history; k_run_epilogue fills the rejected ones)
+              double* dst = hb + (hrow * N + me2) * bl.m;
+              if (bl.kind == 0) {
+                for (int t = lane; t < bl.m; t += 64) dst[t] = sm[D.o_mrow + t];
+              } else if (lane == 0) {
+                dst[0] = nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom]);
+              }
+            } else {  // no history: the current-blob array itself.  Several workgroups write a
+              // walker's row in the course of a launch: write-through, so that the LAST
+              // write is the one memory keeps (dirty lines of different L2s have no order)
+              unsigned long long* dst = reinterpret_cast<unsigned long long*>(bl.cur + (long long)me2 * bl.m);
+              if (bl.kind == 0) {
+                for (int t = lane; t < bl.m; t += 64)
+                  hs_st_sc1(dst + t, (unsigned long long)__double_as_longlong(sm[D.o_mrow + t]));
+              } else if (lane == 0) {
+                hs_st_sc1(dst, (unsigned long long)__double_as_longlong(
+                                   nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom])));
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// After a launch of k_half_step_run: the flat coords / logp arrays := the ring's last row; the
+// acceptance counters += the accept flags; blob history rows of rejected proposals := the
+// previous step's (emcee keeps the blobs of the position a walker is AT), the current blobs :=
+// the last row.  One thread per (walker, element).
+__global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
+  const hs_dev& D = H.C;
+  const int N = R.N, ndim = H.ndim;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gsz = (long long)gridDim.x * blockDim.x;
+  for (long long e = gid; e < (long long)N * (ndim + 1); e += gsz) {
+    const int w = (int)(e / (ndim + 1)), d = (int)(e % (ndim + 1));
+    const unsigned long long* rec = R.ring + ((long long)nsteps * N + w) * R.gr + 2 * d;
+    const unsigned long long lo = rec[0], hiw = rec[1];
+    const double v = __hiloint2double((int)(unsigned)hiw, (int)(unsigned)lo);
+    if (d < ndim) const_cast<double*>(H.coords)[(long long)w * ndim + d] = v;
+    else const_cast<double*>(H.logp)[w] = v;
+  }
+  if (D.naccepted)
+    for (long long w = gid; w < N; w += gsz) {
+      int a = 0;
+      for (int t = 0; t < nsteps; ++t) a += R.accw[(long long)t * N + w];
+      D.naccepted[w] += a;
+    }
+  const bool hist = R.hcoords != nullptr;
+  for (int b = 0; b < D.nblob; ++b) {
+    const nh_hs_blob& bl = D.blob[b];
+    double* hb = hist ? R.hblob[b] : nullptr;
+    if (!hb) continue;
+    for (long long e = gid; e < (long long)N * bl.m; e += gsz) {
+      const int w = (int)(e / bl.m);
+      double prev = bl.cur[e];
+      for (int t = 0; t < nsteps; ++t) {
+        const long long hrow = R.hrow0 + t;
+        if (hrow >= R.hcap) break;
+        double* cell = hb + hrow * (long long)N * bl.m + e;
+        if (R.accw[(long long)t * N + w]) prev = *cell;
+        else *cell = prev;
+      }
+      bl.cur[e] = prev;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct nh_halfstep_run {
+  hs_run R;
+  unsigned long long* ring;
+  int* status;
+  int* accw;
+  long long* dbg;
+  size_t lds_bytes;
+  int grid, threads;
+  unsigned seq;
+};
+
+extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run** out) {
+  NH_REQUIRE(c && P && out, "bad argument");
+  const hs_hot& H = P->hot;
+  NH_REQUIRE(H.C.do_accept && P->split == 1, "the resident loop needs the in-launch accept and one workgroup per walker");
+  NH_REQUIRE(H.ndim <= 15, "at most 15 fit parameters in a record (32 granules per wave half)");
+  NH_REQUIRE(H.lo == 0 && H.nloc == H.ns, "the resident loop moves whole half-ensembles");
+  NH_REQUIRE(H.C.lp == nullptr, "a prior evaluated by a launch of its own cannot ride in the resident loop");
+  for (int q = 0; q < H.C.ncomp; ++q)
+    NH_REQUIRE(H.C.comp[q].off >= 0, "every component of the model must be produced inside the launch");
+  hs_run R;
+  memset(&R, 0, sizeof(R));
+  R.N = 2 * H.ns;
+  R.gr = ((2 * (H.ndim + 1) + 15) / 16) * 16;
+  // LDS: the plan's layout, then what stays resident on top of it
+  int off = (int)(P->lds_bytes / sizeof(double));
+  for (int g = 0; g < H.ngrids; ++g) {
+    R.o_gx[g] = off; off += H.nG[g];
+    R.o_lne[g] = off; off += H.nG[g];
+    R.o_ge[g] = off;
+    if (H.F.broken) off += H.nG[g];
+  }
+  R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * 6;
+  R.o_small1 = off; off += HS_O_T64;
+  R.o_olds = off; off += 128;
+  const size_t lds = (size_t)off * sizeof(double);
+  NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
+  const void* fn = H.syn_grid >= 0 ? (const void*)k_half_step_run<true> : (const void*)k_half_step_run<false>;
+  if (lds > 64 * 1024)
+    NH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // every workgroup of the launch has to be resident (they wait for each other's records)
+  int per_cu = 0, ncu = 0, devid = 0;
+  NH_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, P->threads, lds));
+  NH_CHECK_HIP(hipGetDevice(&devid));
+  NH_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid));
+  NH_REQUIRE(per_cu >= 1 && ncu >= 1, "the resident kernel does not fit a compute unit");
+  if (per_cu > 1) per_cu -= 1;  // (MI355X_MICROARCH.md: the query can be one block per CU high)
+  long long cap = (long long)per_cu * ncu;
+  if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  nh_halfstep_run* Q = new nh_halfstep_run();
+  Q->R = R;
+  Q->lds_bytes = lds;
+  Q->threads = P->threads;
+  Q->grid = (int)(H.nloc < cap ? H.nloc : cap);
+  Q->seq = 1;
+  Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
+  const size_t ring_bytes = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr * sizeof(unsigned long long);
+  hipError_t e = hipMalloc(&Q->ring, ring_bytes);
+  if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
+  if (e == hipSuccess) e = hipMalloc(&Q->status, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(Q->status, 0, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(Q->accw, 0, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
+  if (e == hipSuccess)
+    if (const char* dv = getenv("NH_HS_DEBUG"))
+      if (atoi(dv) != 0) {
+        e = hipMalloc(&Q->dbg, 256 * 64 * 8 * sizeof(long long));
+        if (e == hipSuccess) e = hipMemset(Q->dbg, 0, 256 * 64 * 8 * sizeof(long long));
+      }
+  if (e != hipSuccess) {
+    if (Q->ring) (void)hipFree(Q->ring);
+    if (Q->status) (void)hipFree(Q->status);
+    if (Q->accw) (void)hipFree(Q->accw);
+    if (Q->dbg) (void)hipFree(Q->dbg);
+    delete Q;
+    return nh_set_error(NH_EHIP, "resident half-step loop: %s", hipGetErrorString(e));
+  }
+  Q->R.ring = Q->ring; Q->R.status = Q->status; Q->R.accw = Q->accw; Q->R.dbg = Q->dbg;
+  Q->R.spin_limit = 1 << 22;  // ~1 s of polling: a record that has not come by then never will
+  if (const char* sl = getenv("NH_RUN_SPIN_LIMIT")) Q->R.spin_limit = atoi(sl) > 0 ? atoi(sl) : Q->R.spin_limit;
+  *out = Q;
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run* Q, int slice0,
+                                int nslices, double* hist_coords, double* hist_logp,
+                                double* const* hist_blobs /*host, nblob pointers, or NULL*/,
+                                long long hist_row0, long long hist_cap) {
+  NH_REQUIRE(c && P && Q, "bad argument");
+  NH_REQUIRE(slice0 >= 0 && (slice0 & 1) == 0 && nslices >= 2 && (nslices & 1) == 0 &&
+                 nslices <= 2 * HS_RUN_MAX_STEPS, "whole ensemble steps, at most one block of moves");
+  const hs_hot& H = P->hot;
+  NH_REQUIRE(hist_coords == nullptr || (hist_logp && hist_row0 >= 0 && hist_row0 + nslices / 2 <= hist_cap),
+             "the chain history must hold every step of the launch");
+  hs_run R = Q->R;
+  R.slice0 = slice0;
+  R.nslices = nslices;
+  R.seq = Q->seq++ & 0xFFFFFFu;
+  if (R.seq == 0) R.seq = Q->seq++ & 0xFFFFFFu;
+  R.hcoords = hist_coords;
+  R.hlogp = hist_logp;
+  R.hrow0 = hist_row0;
+  R.hcap = hist_cap;
+  for (int b = 0; b < NH_HS_MAX_BLOB; ++b)
+    R.hblob[b] = (hist_coords && hist_blobs && b < H.C.nblob) ? hist_blobs[b] : nullptr;
+  {
+    nh_prof_scope ps(c, NH_K_HALFSTEP);
+    if (H.syn_grid >= 0)
+      hipLaunchKernelGGL(k_half_step_run<true>, dim3(Q->grid), dim3(Q->threads), Q->lds_bytes,
+                         c->stream, H, R);
+    else
+      hipLaunchKernelGGL(k_half_step_run<false>, dim3(Q->grid), dim3(Q->threads), Q->lds_bytes,
+                         c->stream, H, R);
+    NH_CHECK_HIP(hipGetLastError());
+  }
+  {
+    nh_prof_scope ps(c, NH_K_GLUE);
+    const long long work = (long long)R.N * (H.nE + H.ndim + 2);
+    const int blocks = (int)((work + 255) / 256 < 1024 ? (work + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_run_epilogue, dim3(blocks), dim3(256), 0, c->stream, H, R, nslices / 2);
+    NH_CHECK_HIP(hipGetLastError());
+  }
+  return NH_OK;
+}
+
+// 0 while every launch so far found its records; else the code of the first failure (the
+// ensemble is then undefined from that launch on).  Synchronises the stream.
+extern "C" int nh_half_step_run_status(nh_ctx* c, nh_halfstep_run* Q, int* status) {
+  NH_REQUIRE(c && Q && status, "bad argument");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipMemcpy(status, Q->status, sizeof(int), hipMemcpyDeviceToHost));
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_info(const nh_halfstep_run* Q, int* grid, int* threads,
+                                     long long* lds_bytes) {
+  NH_REQUIRE(Q, "bad argument");
+  if (grid) *grid = Q->grid;
+  if (threads) *threads = Q->threads;
+  if (lds_bytes) *lds_bytes = (long long)Q->lds_bytes;
+  return NH_OK;
+}
+
+// NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch's workgroups,
+// per (workgroup, iteration): 0 start of the slice, 1 records in, 2 first barrier (packs
+// done), 3 weights done, 4 this thread's items done, 5 all items done, 6 spectra summed,
+// 7 record published
+extern "C" int nh_half_step_run_stamps(nh_ctx* c, const nh_halfstep_run* Q, long long* out) {
+  NH_REQUIRE(c && Q && out, "bad argument");
+  memset(out, 0, 256 * 64 * 8 * sizeof(long long));
+  if (!Q->dbg) return NH_OK;
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipMemcpy(out, Q->dbg, 256 * 64 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
+  NH_REQUIRE(c, "ctx is NULL");
+  if (!Q) return NH_OK;
+  int rc = nh_sync(c);
+  if (Q->ring) (void)hipFree(Q->ring);
+  if (Q->status) (void)hipFree(Q->status);
+  if (Q->accw) (void)hipFree(Q->accw);
+  if (Q->dbg) (void)hipFree(Q->dbg);
+  delete Q;
+  return rc;
+}

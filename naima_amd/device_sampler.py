@@ -38,6 +38,7 @@ class DeviceState:
     def coords(self):
         if self._c is None:
             self._loop._flush_pending()
+            self._loop.check_resident()
             self._c = self._loop.coords.get().reshape(self._loop.N, self._loop.ndim)
         return self._c
 
@@ -45,6 +46,7 @@ class DeviceState:
     def log_prob(self):
         if self._l is None:
             self._loop._flush_pending()
+            self._loop.check_resident()
             self._l = self._loop.logp.get()
         return self._l
 
@@ -65,6 +67,9 @@ def _release_loop(ctx, res):
         ctx.sync()
         for g in res["graphs"]:
             _lib._lib.nh_graph_destroy(ctx.h, g)
+        for r in res.get("runs", []):
+            _lib._lib.nh_half_step_run_destroy(ctx.h, r)
+        res["runs"] = []
         for plan in res["plans"]:
             hs = plan.get("hs") if plan else None
             if hs is not None and hs.get("plan") is not None:
@@ -168,7 +173,12 @@ class DeviceLoop:
         self._have_state = False
         # what this loop owns on the device besides pooled buffers: released when it goes
         import weakref
-        self._res = dict(graphs=[], plans=[])
+        self._res = dict(graphs=[], plans=[], runs=[])
+        # the resident loop (nh_half_step_run: a whole block of moves per launch, walkers handed
+        # from half-step to half-step by per-walker records): None = not tried yet, False = this
+        # plan / configuration cannot (or NAIMA_AMD_RESIDENT=0), else the handle
+        self._run = None if os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0" else False
+        self.resident_launches = 0
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
@@ -548,7 +558,14 @@ class DeviceLoop:
                 # between them (history is kept by the kernel, nobody reads the states)
                 g = 1
                 gmax = min(self.GSTEPS, K - k) if self.mega else self.GSTEPS
-                if (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and
+                resident = False
+                if (self._resident_ok() and yield_every >= K - k and (block is None or dev_hist)
+                        and not (block is not None and block["blobs"] and not blob_dev_hist)):
+                    # the rest of this block of moves in ONE launch of resident workgroups
+                    g = K - k
+                    self._run_resident(2 * k, 2 * g, block if dev_hist else None)
+                    resident = True
+                elif (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and
                         yield_every >= gmax and (block is None or dev_hist) and
                         not (block is not None and block["blobs"] and not blob_dev_hist)):
                     g = gmax
@@ -590,7 +607,7 @@ class DeviceLoop:
                     block["n"] = kk + g
                 if yield_every < 2:
                     self._flush_pending()
-                if self.mega and dev_hist and (k >= K or yield_every <= iterations):
+                if self.mega and dev_hist and not resident and (k >= K or yield_every <= iterations):
                     # one launch per half-step: the row of a closed step is written by the
                     # NEXT launch of the same block of moves; nothing follows the last one of
                     # a block, and whoever is handed this state may read the chain (nobody
@@ -603,6 +620,58 @@ class DeviceLoop:
                                  block["n"] - 1)
                 yield DeviceState(self, rng)
         self._flush_pending()
+
+    # ------------------------------------------------------------- resident loop
+    def _resident_ok(self):
+        """can the rest of a block of moves run as ONE launch (nh_half_step_run)?  Needs the
+        one-launch plan, a single rank, one workgroup per walker, blobs (if kept) kept by the
+        launch; the library has the last word (LDS, occupancy, the plan's shape)"""
+        if self._run is False or not self.mega or self.sharded or not self.s.use_graph:
+            return False
+        hs = self._plan["hs"] if self._plan else None
+        if hs is None or hs["split"] != 1:
+            return False
+        if self.s.store_blobs and self.cur_blobs and not self.blobs_in_kernel:
+            return False
+        if self._run is None:
+            h = _lib._dp()
+            if _lib._lib.nh_half_step_run_create(self.ctx.h, hs["plan"], C.byref(h)) != 0:
+                self._run = False
+                self.resident_reason = _lib._lib.nh_last_error().decode()
+                return False
+            self._run = h
+            self._res["runs"].append(h)
+            g, t, l = _lib._i(), _lib._i(), _lib._ll()
+            _lib._chk(_lib._lib.nh_half_step_run_info(h, C.byref(g), C.byref(t), C.byref(l)))
+            self.resident_info = dict(grid=g.value, threads=t.value, lds_bytes=l.value)
+        return True
+
+    def _run_resident(self, slice0, nslices, block):
+        ctx, hs = self.ctx, self._plan["hs"]
+        hc = hl = None
+        hb, row0, cap = None, 0, 0
+        if block is not None:
+            hc, hl = block["coords"].ptr, block["logp"].ptr
+            row0, cap = block["n"], block["coords"].shape[0]
+            if block["blobs"]:
+                hb = (C.c_void_p * 4)(*([b.ptr for b in block["blobs"]] + [None] * 4)[:4])
+        ctx.call("nh_half_step_run", hs["plan"], self._run, slice0, nslices, hc, hl, hb, row0, cap)
+        self.resident_launches += 1
+        self.s.n_lnprob_calls += nslices
+        self.s.n_walker_evals += nslices * self.nloc
+
+    def check_resident(self):
+        """raise if a launch of the resident loop gave up waiting for a walker's record (its
+        workgroups were not all resident: another process on the GPU, a profiler that
+        serialises workgroups); the ensemble is undefined from that launch on"""
+        if self._run:
+            st = _lib._i()
+            _lib._chk(_lib._lib.nh_half_step_run_status(self.ctx.h, self._run, C.byref(st)))
+            if st.value != 0:
+                raise _lib.NaimaHipError(
+                    "the resident half-step loop timed out waiting for a walker's record (status "
+                    "%d): its workgroups were not all resident.  Run with NAIMA_AMD_RESIDENT=0"
+                    % st.value)
 
     def _run_half_step_merged(self):
         ctx = self.ctx
@@ -740,6 +809,7 @@ class DeviceLoop:
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""
         self._flush_pending()
+        self.check_resident()
         self.ctx.check_general()  # (a per-walker grid longer than the general kernel's LDS)
         s = self.s
         for block in self.hist:

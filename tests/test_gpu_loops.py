@@ -438,3 +438,51 @@ def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkey
     for x, y in zip(d.get_blobs(), h.get_blobs()):
         assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
                         atol=1e-300, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,nw,mkw", [("cfg3", 512, {}), ("cfg5", 256, {}), ("cfg1", 32, {}),
+                                         ("cfg5", 256, {"useLUT": False})],
+                         ids=["cfg3-512", "cfg5-256", "cfg1-32", "cfg5-analytic-256"])
+def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
+    """nh_half_step_run -- a whole block of moves in ONE launch, walkers handed from half-step
+    to half-step through per-walker records (write-through granules with tags) instead of
+    through the kernel boundary -- against the same kernel arithmetic launched once per
+    half-step (NAIMA_AMD_RESIDENT=0), from the benchmark's ball (uneven load: degenerate
+    walkers finish early, so consumers do wait for records): chain, log-probability, blobs
+    and acceptance of 100 steps (four blocks of moves, a 4-step tail)"""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, name, mkw)
+    nd = p0.size
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True)
+    rng = np.random.default_rng(BENCH_SEED)
+    pos = p0 + 0.1 * p0 * rng.normal(size=(nw, nd))
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", mode)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        with np.errstate(all="ignore"):
+            st = d.run_mcmc(pos, 4)
+            st = d.run_mcmc(st, 96)
+            st2 = d.run_mcmc(st, 7, store=False)  # (no history: blobs go to the current array)
+        assert d._dev.mega and d._dev._plan["hs"] is not None
+        assert (d._dev.resident_launches > 0) == (mode == "1"), getattr(d._dev, "resident_reason", "")
+        runs[mode] = (d.get_chain(), d.get_log_prob(), d.get_blobs(), d.acceptance_fraction,
+                      np.array(st2.coords), np.array(st2.log_prob),
+                      [np.array(b) for b in (st2.blobs or [])])
+    a, b = runs["0"], runs["1"]
+    assert a[0].shape == (100, nw, nd)
+    assert_allclose(b[0], a[0], rtol=1e-10)
+    assert np.array_equal(np.isinf(b[1]), np.isinf(a[1]))
+    fin = np.isfinite(a[1])
+    assert_allclose(b[1][fin], a[1][fin], rtol=1e-9)
+    for x, y in zip(b[2], a[2]):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10,
+                        atol=1e-300, equal_nan=True)
+    assert_allclose(b[3], a[3])
+    assert_allclose(b[4], a[4], rtol=1e-10)
+    fin = np.isfinite(a[5])
+    assert_allclose(b[5][fin], a[5][fin], rtol=1e-9)
+    for x, y in zip(b[6], a[6]):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10,
+                        atol=1e-300, equal_nan=True)
+    print("%s: resident == per-launch; bit-identical chain: %s" % (name, np.array_equal(a[0], b[0])))
