@@ -285,6 +285,7 @@ class Context:
         self._accept_hook = None
         self._cap_pool = {}
         self._retained = []
+        self._release_later = []  # device loops collected during a stream capture
         self._deferred = []
         self._pinned = set()
         self._pinned_ptrs = set()
@@ -761,7 +762,16 @@ class Context:
         self._cap_pool = {}
         g = _dp()
         _chk(_lib.nh_graph_end(self.h, C.byref(g)))
+        self._release_deferred()
         return g
+
+    def _release_deferred(self):
+        """device loops that were collected while a capture was in progress"""
+        if self._release_later:
+            from .device_sampler import _release_loop
+            later, self._release_later = self._release_later, []
+            for res in later:
+                _release_loop(self, res)
 
     def graph_abort(self):
         if self.capturing:
@@ -773,6 +783,7 @@ class Context:
             _lib.nh_graph_end(self.h, C.byref(g))
             if g:
                 _lib.nh_graph_destroy(self.h, g)
+            self._release_deferred()
 
     def graph_launch(self, g):
         _chk(_lib.nh_graph_launch(self.h, g))

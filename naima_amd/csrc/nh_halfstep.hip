@@ -1260,21 +1260,33 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   if (d->syn.grid >= 0) work += (long long)d->syn.nE * d->grids[d->syn.grid].nG * 110 / 3;
   int threads = work >= (1 << 20) ? 1024 : (work >= (1 << 18) ? 512 : 256);
   if (threads < 1024 && maxnG > threads) threads = maxnG > 512 ? 1024 : 512;
+  int ncu = 256;
+  {
+    hipDeviceProp_t prop;
+    int devid = 0;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+  }
+  // A table-only model's launch is half prologue and tail (dependent round trips, single-wave
+  // phases: 9 of cfg5's 16 us) with the CU's other waves idle.  When a launch holds more
+  // walkers than the chip has CUs, smaller workgroups put several walkers on a CU at once and
+  // one walker's prologue runs beside another's items: cfg5 at 1024 walkers per launch 66.8 us
+  // (1024 threads, four rounds) -> 51.6 (512) -> 37.0 (256 threads, four workgroups per CU).
+  // Launches of at most one walker per CU keep the large workgroup (256 walkers: 15.6 us at
+  // 1024 threads, 16.7 at 512, 24.5 at 256).
+  if (d->syn.grid < 0)
+    while (threads > 256 && (long long)d->nloc * threads > 1024LL * ncu) threads >>= 1;
   if (const char* e = getenv("NH_HS_THREADS")) threads = atoi(e);
   NH_REQUIRE(threads >= 128 && threads <= 1024 && threads % 64 == 0, "bad workgroup size");
   if (d->syn.grid >= 0 && threads / 64 < (d->syn.nE + 63) / 64 + 2) threads = 1024;
+  while (threads < 1024 && threads / 64 <= d->nmoms + 1) threads <<= 1;  // (a wave per single-row reduction)
   NH_REQUIRE(threads / 64 > d->nmoms + 1, "more single-row reductions than waves");
   // ---- a launch of fewer walkers than the chip has CUs: K workgroups per walker ----
   // (each repeats the prologue -- on CUs that would otherwise idle -- and takes every K-th
   // work item; the items are cut finer so that every wave of every workgroup still gets some)
   int split = 1;
   {
-    int ncu = 256;
-    hipDeviceProp_t prop;
-    int devid = 0;
-    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
     // (worth it where the work items are most of a launch: measured on cfg2 / cfg3 at 128
     // walkers per launch 42.3 -> 32.7 us and 33.8 -> 28.0 us; the hand-off costs ~3.5 us, which
     // the table-only models cfg1 / cfg5 -- 7 us of items in a 17 us launch -- do not get back)

@@ -779,7 +779,9 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   NH_CHECK_HIP(hipGetDevice(&devid));
   NH_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid));
   NH_REQUIRE(per_cu >= 1 && ncu >= 1, "the resident kernel does not fit a compute unit");
-  if (per_cu > 1) per_cu -= 1;  // (MI355X_MICROARCH.md: the query can be one block per CU high)
+  // (MI355X_MICROARCH.md: the query can be one block per CU high where the SGPR file is what
+  // limits residency -- 6 waves per SIMD at this kernel's ~110 SGPRs; its 128 VGPRs allow 4,
+  // so registers or LDS bind first and the query is exact.  The bounded waits are the net.)
   long long cap = (long long)per_cu * ncu;
   if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
   nh_halfstep_run* Q = new nh_halfstep_run();

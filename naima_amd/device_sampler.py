@@ -63,6 +63,11 @@ def _release_loop(ctx, res):
     (device packs, counters, partial-spectra buffers, the host descriptor)"""
     if ctx.h is None:
         return  # the context went first and took the device allocations with it
+    if ctx.capturing:
+        # (the collector may run this in the middle of ANOTHER loop's stream capture, which a
+        # synchronisation would invalidate: the context releases it after the capture)
+        ctx._release_later.append(res)
+        return
     try:
         ctx.sync()
         for g in res["graphs"]:
@@ -563,6 +568,14 @@ class DeviceLoop:
                         and not (block is not None and block["blobs"] and not blob_dev_hist)):
                     # the rest of this block of moves in ONE launch of resident workgroups
                     g = K - k
+                    if k > 0 and dev_hist:
+                        # the per-launch kernel leaves the history row of a closed step to the
+                        # NEXT launch of the block: there is none, the resident loop takes over
+                        ctx.call("nh_hist_append", self.coords, self.logp, N, self.ndim,
+                                 self.histd, block["n"] - 1)
+                        if blob_dev_hist:
+                            ctx.call("nh_half_step_append_blobs", self._plan["hs"]["plan"],
+                                     block["n"] - 1)
                     self._run_resident(2 * k, 2 * g, block if dev_hist else None)
                     resident = True
                 elif (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and

@@ -486,3 +486,27 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
         assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10,
                         atol=1e-300, equal_nan=True)
     print("%s: resident == per-launch; bit-identical chain: %s" % (name, np.array_equal(a[0], b[0])))
+
+
+def test_table_only_model_with_more_walkers_than_compute_units(na):
+    """cfg5 at BASELINE's 2048 walkers on one GPU: 1024 walkers per half-step, four per compute
+    unit -- the plan picks 256-thread workgroups (several walkers share a CU, one's prologue
+    beside another's items) and every workgroup of the resident loop handles several walkers per
+    slice: device loop == host-driven loop"""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg5", {})
+    nw, nd = 2048, p0.size
+    kw = dict(args=[data, model, prior], seed=41, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.01 * np.random.default_rng(3).standard_normal((nw, nd)))
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    sh, sd = h.run_mcmc(pos, 3), d.run_mcmc(pos, 3)
+    sh, sd = h.run_mcmc(sh, 37), d.run_mcmc(sd, 37)
+    dev = d._dev
+    assert dev.mega and dev._plan["hs"] is not None and dev._plan["hs"]["threads"] == 256
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+    assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)
+    assert_allclose(d.acceptance_fraction, h.acceptance_fraction)
+    for x, y in zip(d.get_blobs(), h.get_blobs()):
+        assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
+                        atol=1e-300)
