@@ -814,7 +814,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
         const int tg = __builtin_amdgcn_readfirstlane(tb.grid);
         const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
-        const int s0 = chunk * D.seg, s1 = min(nG - 1, s0 + D.seg);
+        int s0, s1;
+        hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
         const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
         // (a non-negative table: the pre-divided log-ratios and the series thresholds)
         const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       for (int k = tid; k < tb.nK; k += T) {
         const int tile = k >> 6, ln = k & 63;
         const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
-        const int stride = tb.tiles * 64, chunks = tb.chunks;
+        const int stride = tb.tiles * 64, chunks = HS_CHUNKS(tb.chunks);
         double sum = 0.0;
         for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
           double v[8];
@@ -1315,14 +1316,27 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     seg = (maxseg + per_tile - 1) / per_tile;
     if (seg < 8) seg = 8;
   }
+  // NH_HS_GRADE=1: the last third of a table's segments in chunks of half the length
+  const bool grade = nh_env_int("NH_HS_GRADE", 0) != 0 && d->syn.grid >= 0;
+  auto chunking = [&](int nseg, int sg, int& nfull, int& seg2) {
+    nfull = (nseg + sg - 1) / sg;
+    seg2 = sg;
+    if (grade && sg >= 8) {
+      nfull = (2 * nseg / 3) / sg;
+      seg2 = sg / 2;
+    }
+    const int rest = nseg - nfull * sg;
+    return nfull + (rest > 0 ? (rest + seg2 - 1) / seg2 : 0);
+  };
   for (;;) {
     int nT = 0;
     for (int t = 0; t < d->ntab; ++t) {
       const int tiles = (d->tab[t].nK + 63) / 64;
       const int nseg = d->grids[d->tab[t].grid].nG - 1;
-      nT += tiles * ((nseg + seg - 1) / seg);
+      int nf, s2;
+      nT += tiles * chunking(nseg, seg, nf, s2);
     }
-    if (nT <= (split > 1 ? 160 : 96)) break;
+    if (nT <= (split > 1 ? 160 : (grade ? 128 : 96))) break;
     seg *= 2;
   }
   C.seg = seg;
@@ -1343,9 +1357,12 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
       while (o.nKp / 2 >= tb.nK && o.nKp > 1) o.nKp /= 2;
       o.sub = 64 / o.nKp;
     }
-    o.chunks = (nG - 1 + seg - 1) / seg;
+    int nfull = 0, seg2 = 0;
+    const int nchunks = chunking(nG - 1, seg, nfull, seg2);
+    NH_REQUIRE(nchunks < 256 && nfull < 256 && seg2 < 32768, "table cut into too many chunks");
+    o.chunks = nchunks | (nfull << 8) | (seg2 << 16);
     o.item0 = nT;
-    nT += o.tiles * o.chunks;
+    nT += o.tiles * nchunks;
     o.spec_off = nspec;
     H.tspec[t] = nspec;
     nspec += tb.nK;

@@ -19,7 +19,21 @@ struct hs_tab {
   const double* KD; const double* scale; double* out;  // KD: interleaved {K, dlnK}, [nG][nK][2]
   int grid, nK, ldo, nonneg, spec_off, tiles, item0, chunks;
   int sub, nKp;  // nK <= 32: sub = 64 / nKp sub-ranges of an item share a wave (nKp = 32, 16, ...)
+  // `chunks` packs three numbers: chunks | nfull << 8 | seg2 << 16.  Chunks [0, nfull) hold `seg`
+  // segments each, the rest seg2 (<= seg): the items pulled last decide how far apart the waves
+  // reach the barrier, so they are the short ones.  (Packed into the existing word: a wider
+  // struct made the compiler copy the whole by-value descriptor to scratch in k_half_step.)
 };
+#define HS_CHUNKS(pk) ((pk) & 0xff)
+
+// segments [s0, s1) of chunk `chunk` of a table over a grid of nseg segments
+__device__ __forceinline__ void hs_chunk_range(int packed_chunks, int chunk, int seg, int nseg,
+                                               int& s0, int& s1) {
+  const int nf = (packed_chunks >> 8) & 0xff, s2 = packed_chunks >> 16;  // (wave-uniform)
+  const int over = max(chunk - nf, 0);
+  s0 = (chunk - over) * seg + over * s2;
+  s1 = min(nseg, s0 + (over > 0 ? s2 : seg));
+}
 
 struct hs_comp { const double* ptr; long long ld; double scale; int off; int pad; };
 

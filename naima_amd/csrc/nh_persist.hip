@@ -81,6 +81,47 @@ __device__ __forceinline__ unsigned long long hs_granule(double v, int L, unsign
   return ((unsigned long long)tag << 32) | w;
 }
 
+// The library-math phases of a slice (parameter packs: exp10 / log ...; particle weights:
+// exp, expm1; the likelihood's log) run ONCE per slice and thread, but their polynomial
+// coefficients are loop invariants of the slice loop: inlined, the compiler parks ~70 of them
+// in registers across the whole loop and spills them (190 dwords of scratch, reloaded on the
+// serial path of every slice).  As real calls they are materialised where they are used.
+__device__ __attribute__((noinline)) double hsr_lazy_apply(double a, double b, double c, int tf,
+                                                           double raw) {
+  nh_lazy z;
+  z.base = nullptr; z.stride = 1; z.a = a; z.b = b; z.c = c; z.tf = tf; z.pad = 0;
+  return nh_lazy_apply(z, raw);
+}
+__device__ __attribute__((noinline)) double hsr_log(double x) { return log(x); }
+__device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x); }
+struct hsr_node { double n, dsh; };
+struct hsr_node2 { double n0, dsh0, n1, dsh1; };
+__device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, double al, double be,
+                                                          double a2, double lxx, double lxc,
+                                                          double lkb, int b12, double lr,
+                                                          const double* T64) {
+  pd_par p;
+  p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
+  hsr_node r;
+  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64);
+  return r;
+}
+
+// two nodes of (possibly) different grids in one go: the two dependent chains of ~100
+// instructions interleave -- a wave that holds two units of nodes is not twice as late
+__device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, double al,
+                                                            double be, double a2, double lkb,
+                                                            double lxx0, double lxc0, int b0,
+                                                            double lr0, double lxx1, double lxc1,
+                                                            int b1, double lr1, const double* T64) {
+  pd_par p;
+  p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
+  hsr_node2 r;
+  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64);
+  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64);
+  return r;
+}
+
 #define HSR_STAMP(k)                                                                   \
   do {                                                                                  \
     if (R.dbg && tid == 0 && blockIdx.x < 256 && it < 64)                               \
@@ -306,11 +347,11 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           const int col = lane % NH_MAX_LAZY;
           if (col < nc) {
             double val = z.a;
-            if (pkd >= 0) val = nh_lazy_apply(z, qv);
+            if (pkd >= 0) val = hsr_lazy_apply(z.a, z.b, z.c, z.tf, qv);
             out[(long long)j * ld + col] = val;
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
-              if (col == 1 || col == 3 || col == 5) lg[col >> 1] = val > 0.0 ? log(val) : 0.0;
+              if (col == 1 || col == 3 || col == 5) lg[col >> 1] = val > 0.0 ? hsr_log(val) : 0.0;
             }
           }
         }
@@ -332,9 +373,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           double v = z.a;
           if (z.base) {
             const long long d = z.base - H.qT;
-            v = (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1)
-                    ? nh_lazy_apply(z, qs[d / H.nloc])
-                    : nh_lazy_apply(z, z.base[(long long)j * z.stride]);
+            // a term on one of this walker's proposed coordinates: taken from LDS
+            const bool mine = d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1;
+            const double raw = mine ? qs[d / H.nloc] : z.base[(long long)j * z.stride];
+            v = hsr_lazy_apply(z.a, z.b, z.c, z.tf, raw);
           }
           const double p0 = pt.p0, p1 = pt.p1;
           switch (pt.kind) {
@@ -393,36 +435,62 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         }
       }
       int nzmask = 0;
-      for (int u = worker ? rank : nunits; u < nunits; u += nwork) {
-        int g = 0;
-        while (u >= ub[g + 1]) ++g;
-        const int nG = H.nG[g], i = (u - ub[g]) * 64 + lane;
-        if (i < nG) {
-          const bool last = i + 1 >= nG;
-          const double lr = sm[H.o_lx[g] + i];  // (0 at the last node)
-          const double lnE = sm[R.o_lne[g] + i];
-          const double gx = sm[R.o_gx[g] + i];
-          bool b1 = false, b2 = false;
-          if (broken) {
-            const double E = sm[R.o_ge[g] + i];
-            const double E2 = last ? E : sm[R.o_ge[g] + i + 1];
-            b1 = E < p.eb;
-            b2 = E2 < p.eb;
+      for (int u = worker ? rank : nunits; u < nunits; u += 2 * nwork) {
+        // this wave's units u and u + nwork (if any), node `lane` of each
+        int gq[2], iq[2], bq[2] = {0, 0};
+        double lrq[2] = {0.0, 0.0}, lneq[2] = {0.0, 0.0}, gxq[2] = {0.0, 0.0};
+        bool onq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int uu = u + q * nwork;
+          int g = 0;
+          while (uu < nunits && uu >= ub[g + 1]) ++g;
+          gq[q] = g;
+          const int nG = H.nG[g], i = (uu - ub[g]) * 64 + lane;
+          iq[q] = i;
+          onq[q] = uu < nunits && i < nG;
+          if (onq[q]) {
+            const bool last = i + 1 >= nG;
+            lrq[q] = sm[H.o_lx[g] + i];  // (0 at the last node)
+            lneq[q] = sm[R.o_lne[g] + i];
+            gxq[q] = sm[R.o_gx[g] + i];
+            if (broken) {
+              const double E = sm[R.o_ge[g] + i];
+              const double E2 = last ? E : sm[R.o_ge[g] + i + 1];
+              bq[q] = (E < p.eb ? 1 : 0) | (E2 < p.eb ? 2 : 0);
+            }
           }
-          double nn, dsh;
-          pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], b1, b2, lr, nn, dsh,
-                  sm + HS_O_T64);
-          nn *= H.scale[g];
-          const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
-          sm[H.o_w[g] + i] = wv_;
-          sm[H.o_d[g] + i] = dv;
-          if (H.o_dp[g] >= 0) {  // what the non-negative table items read
-            const double il = last ? 0.0 : nh_rcp(lr);
-            sm[H.o_dp[g] + i] = dv * il;
-            sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
-          }
-          if (wv_ != 0.0) nzmask |= 1 << g;
         }
+        const bool two = u + nwork < nunits;  // (wave-uniform)
+        double nnq[2], dshq[2];
+        if (two) {
+          const hsr_node2 nd = hsr_pd_core2(D.kind, p.A, p.al, p.be, p.a2, lg[2] - lg[0],
+                                            lneq[0] - lg[0], lneq[0] - lg[1], bq[0], lrq[0],
+                                            lneq[1] - lg[0], lneq[1] - lg[1], bq[1], lrq[1],
+                                            sm + HS_O_T64);
+          nnq[0] = nd.n0; dshq[0] = nd.dsh0; nnq[1] = nd.n1; dshq[1] = nd.dsh1;
+        } else {
+          const hsr_node nd = hsr_pd_core(D.kind, p.A, p.al, p.be, p.a2, lneq[0] - lg[0],
+                                          lneq[0] - lg[1], lg[2] - lg[0], bq[0], lrq[0],
+                                          sm + HS_O_T64);
+          nnq[0] = nd.n; dshq[0] = nd.dsh; nnq[1] = 0.0; dshq[1] = 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (onq[q]) {
+            const int g = gq[q], i = iq[q];
+            const bool last = i + 1 >= H.nG[g];
+            const double nn = nnq[q] * H.scale[g];
+            const double wv_ = gxq[q] * nn, dv = last ? 0.0 : lrq[q] + dshq[q];
+            sm[H.o_w[g] + i] = wv_;
+            sm[H.o_d[g] + i] = dv;
+            if (H.o_dp[g] >= 0) {  // what the non-negative table items read
+              const double il = last ? 0.0 : nh_rcp(lrq[q]);
+              sm[H.o_dp[g] + i] = dv * il;
+              sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+            }
+            if (wv_ != 0.0) nzmask |= 1 << g;
+          }
       }
       {
         int any = nzmask;
@@ -460,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             amap[pos] = lv_k;
             ai0[pos] = lv_i0;
             sq[pos] = lv_q;
-            sq[nEs + pos] = cbrt(lv_q);
+            sq[nEs + pos] = hsr_cbrt(lv_q);
             // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
             sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
                                 (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
@@ -524,7 +592,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
             const int tg = __builtin_amdgcn_readfirstlane(tb.grid);
             const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
-            const int s0 = chunk * D.seg, s1 = min(nG - 1, s0 + D.seg);
+            int s0, s1;
+            hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
             const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
             const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
             const double* ds = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_dp[tg] : H.o_d[tg]);
@@ -557,45 +626,46 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       HSR_STAMP(4);
       __syncthreads();  // ---------------------------------------------------------------- #3
       HSR_STAMP(5);
-      // ---- the walker's spectra meet in LDS ---------------------------------------------------
-      for (int t = 0; t < D.ntab; ++t) {
-        const hs_tab& tb = D.tab[t];
-        for (int k = tid; k < tb.nK; k += T) {
-          const int tile = k >> 6, ln = k & 63;
-          const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
-          const int stride = tb.tiles * 64, chunks = tb.chunks;
-          double sum = 0.0;
-          for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
-            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          }
-          sum *= sm[H.o_scale + tb.spec_off + k];
-          spec[tb.spec_off + k] = sum;
-        }
-      }
-      if (has_syn) {
-        const int nEs = H.syn_nE;
-        const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
-        for (int a = T - 1 - tid; a < nA; a += T) {  // (from the back: the tables took the front)
-          const double* pp = sm + H.o_part_s + a;
-          double sum = 0.0;
-          for (int c0 = 0; c0 < Cd; c0 += 8) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
-            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          }
-          sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
-          spec[H.syn_spec_off + amap[a]] = sum;
-        }
-      }
-      __syncthreads();  // ---------------------------------------------------------------- #4
-      HSR_STAMP(6);
-      // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
-      // wave 0 is already polling for the next slice ------------------------------------------
+      // ---- D. the walker's spectra are summed, the likelihood + priors (core.py:64-121), the
+      // accept and the record: ONE wave; wave 0 is already polling for the next slice, the
+      // others wait at its first barrier (nothing they could write before it is read here) ----
       if (lik_wave) {
+        for (int t = 0; t < D.ntab; ++t) {
+          const hs_tab& tb = D.tab[t];
+          for (int k = lane; k < tb.nK; k += 64) {
+            const int tile = k >> 6, ln = k & 63;
+            const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
+            const int stride = tb.tiles * 64, chunks = HS_CHUNKS(tb.chunks);
+            double sum = 0.0;
+            for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
+              double v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
+              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            sum *= sm[H.o_scale + tb.spec_off + k];
+            spec[tb.spec_off + k] = sum;
+          }
+        }
+        if (has_syn) {
+          const int nEs = H.syn_nE;
+          const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
+          for (int a = lane; a < nA; a += 64) {
+            const double* pp = sm + H.o_part_s + a;
+            double sum = 0.0;
+            for (int c0 = 0; c0 < Cd; c0 += 8) {
+              double v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
+              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
+            spec[H.syn_spec_off + amap[a]] = sum;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own LDS writes, in order)
+        if (R.dbg && lane == 0 && blockIdx.x < 256 && it < 64)
+          R.dbg[((long long)blockIdx.x * 64 + it) * 8 + 6] = (long long)wall_clock64();
         const int nE = H.nE;
         const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
         const double prior = accs[3];
@@ -633,13 +703,13 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           nviol = cnt & 0xffff;
           nul = cnt >> 16;
           // quirk kept from core.py:89-92: cl is indexed by the violation count
-          if (nul > 0) acc += (double)nviol * log(1.0 - H.cl[nviol]);
+          if (nul > 0) acc += (double)nviol * hsr_log(1.0 - H.cl[nviol]);
           if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
         }
         acc = __shfl(acc, 0, 64);
         // emcee RedBlueMove.propose for this walker
         const double z = accs[0], oldlp = accs[2];
-        const double dd = (ndim - 1.0) * log(z) + acc - oldlp;
+        const double dd = (ndim - 1.0) * hsr_log(z) + acc - oldlp;
         const bool ok = accs[1] < dd;  // NaN compares false, as numpy
         const int me2 = hi[HI_ME];
         // the record of the state after this step: row tl + 1
@@ -650,7 +720,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           hs_st_sc1(R.ring + ((long long)(tl + 1) * N + me2) * R.gr + lane,
                     hs_granule(val, lane, hs_tag(R.seq, tl + 1)));
         }
-        HSR_STAMP(7);
+        if (R.dbg && lane == 0 && blockIdx.x < 256 && it < 64)
+          R.dbg[((long long)blockIdx.x * 64 + it) * 8 + 7] = (long long)wall_clock64();
         // chain history: this walker's entry of the step's row (nobody else writes it)
         const long long hrow = R.hrow0 + tl;
         const bool hist = R.hcoords != nullptr && hrow < R.hcap;
