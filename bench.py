@@ -56,7 +56,7 @@ KERNEL_FLOP_EQ = {
     "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * 34.0},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
-KERNEL_SYMBOL = {"half_step": "k_half_step", "integrate_tables": "k_integrate_tables",
+KERNEL_SYMBOL = {"half_step": "k_half_step",  # (k_half_step_run when the loop is resident) "integrate_tables": "k_integrate_tables",
                  "synchrotron": "k_synchrotron",
                  "particle_weights": "k_step_front (proposal+packs+weights+We)", "lnprob": "k_lnprobmodel",
                  "integrate_rows": "k_integrate_rows", "ic_seed_walkers": "k_ic_seed_walkers",
@@ -338,14 +338,31 @@ def main():
     # ---- per-kernel HIP-event timing: hipGraph replay hides the launches from
     # events, so the SAME launch sequence is run eagerly (device loop, no graph)
     # with an event pair around every launch, for the same number of steps
-    prof_sampler = make_sampler(device, False, blobs=keep_blobs)
-    pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
-    ctx.sync()
-    ctx.profile(True)
-    ctx.profile_read(reset=True)
-    prof_sampler.run_mcmc(pstate, max(args.steps, 50), store=False)
-    prof = ctx.profile_read(reset=True)
-    ctx.profile(False)
+    # ... unless the loop IS eager launches: the resident loop (nh_half_step_run) is one launch
+    # per block of moves, no graph -- then the timed sampler itself is bracketed, with regions of
+    # the same K steps as the timed ones
+    resident = device and getattr(sampler._dev, "resident_launches", 0) > 0
+    prof_steps = max(args.steps, 50)
+    if resident:
+        ctx.sync()
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        pstate, prof_steps = state, 0
+        while prof_steps < 50:
+            pstate = sampler.run_mcmc(pstate, args.steps, store=not args.no_chain)
+            sampler.reset()
+            prof_steps += args.steps
+        prof = ctx.profile_read(reset=True)
+        ctx.profile(False)
+    else:
+        prof_sampler = make_sampler(device, False, blobs=keep_blobs)
+        pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
+        ctx.sync()
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        prof_sampler.run_mcmc(pstate, prof_steps, store=False)
+        prof = ctx.profile_read(reset=True)
+        ctx.profile(False)
     ev_us = ctx.profile_overhead_us()  # what an event pair adds to every launch
 
     if rank != 0:
@@ -373,6 +390,8 @@ def main():
               key=lambda k: launch_us(k) * prof[k]["launches"])
     avg_s = launch_us(dom) * 1e-6
     walkers_per_launch = per_gpu / 2.0  # one half-ensemble shard per launch
+    if resident:  # one launch = every half-step of a K-step region: walker-steps per launch
+        walkers_per_launch = per_gpu * prof_steps / float(prof[dom]["launches"])
     abytes = ALGO[name]["bytes"] * walkers_per_launch
     achieved = abytes / avg_s / 1e9
     traffic, traffic_src = measured_traffic(name, KERNEL_SYMBOL.get(dom, dom).split("/")[0])
@@ -410,7 +429,9 @@ def main():
         "blobs": ("kept: the model spectrum and We/Wp of every walker and step, in HBM"
                   if keep_blobs else "not kept (--no-blobs)"),
         ("value_without_blobs" if keep_blobs else "value_store_blobs"): blobs_value,
-        "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom, dom), "achieved": achieved,
+        "roofline": {"bound": "hbm",
+                     "kernel": ("k_half_step_run" if resident and dom == "half_step"
+                                else KERNEL_SYMBOL.get(dom, dom)), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_us": avg_s * 1e6,
@@ -418,6 +439,7 @@ def main():
                      "event_pair_overhead_us": ev_us, "event_correction": ev_note,
                      "algorithmic_bytes_per_launch": abytes,
                      "walkers_per_launch": walkers_per_launch,
+                     "us_per_half_step": (avg_s * 1e6 / (walkers_per_launch / (per_gpu / 2.0))),
                      "note": "FP64-issue-bound path: the HBM fraction is << 1 % by "
                              "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
                              "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE): every "
@@ -426,8 +448,10 @@ def main():
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
         "acceptance_fraction": acc_frac,
-        "loop": ("host" if not device else ("device+hipGraph" if sampler._dev.graph is not None
-                                            else "device")),
+        "loop": ("host" if not device else
+                 "device, resident workgroups: one launch of k_half_step_run per block of moves "
+                 "(<= 32 steps), walkers handed over by tagged records" if resident else
+                 ("device+hipGraph" if sampler._dev.graph is not None else "device")),
     }
     fp = {}
     executed = executed_flop_eq(name, raw, final_coords)

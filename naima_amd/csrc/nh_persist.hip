@@ -61,7 +61,8 @@ struct hs_run {
   int gr, N;                 // granules per record (a multiple of 16: one record = whole lines)
   int o_gx[NH_MAX_GRIDS], o_lne[NH_MAX_GRIDS], o_ge[NH_MAX_GRIDS];  // LDS: grid nodes, ln E, E
   int o_pk, o_small1, o_olds;  // LDS: pack descriptors, the second small block, old coordinates
-  int spin_limit, pad;
+  int o_lcl;                   // LDS: ln(1 - cl[n]), n <= nE
+  int spin_limit, order;       // order: 0 = table and synchrotron items alternate, 2 = synchrotron first
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -170,6 +171,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       for (int k = tid; k < H.tnK[t]; k += T)
         sm[H.o_scale + H.tspec[t] + k] = H.tscale[t] ? H.tscale[t][k] : 1.0;
     double* lik = sm + H.o_lik;  // conv | flux | elo | ehi | ul, nE each
+    // (ln(1 - cl[n]) for every violation count the likelihood can meet, core.py:89-92)
+    for (int k = tid; k <= H.nE; k += T) sm[R.o_lcl + k] = k < H.nE ? log(1.0 - H.cl[k]) : 0.0;
     for (int k = tid; k < H.nE; k += T) {
       lik[k] = H.conv[k];
       lik[H.nE + k] = H.flux[k];
@@ -224,12 +227,19 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
   const int tiles_ = has_syn ? (H.syn_nE + 63) >> 6 : 0;
   // the weights' nodes go to the waves that have nothing else to do before the second
   // barrier: not the likelihood wave (priors), not the tile waves (liveness search)
-  int nwork = nwv - 1 - tiles_, rank = wv == 0 ? 0 : wv - 1;
-  bool worker = wv != 1 && wv < nwv - tiles_;
-  if (nwork < 1) {
-    nwork = nwv;
+  // ... first; the tile waves and the likelihood wave take a unit after their own duty (19 units
+  // of cfg3 over 13 waves left six of them with two)
+  int nfree = nwv - 1 - tiles_;
+  int nwork = nwv, rank;
+  const bool worker = true;
+  if (nfree < 1 || nwv == 1) {
     rank = wv;
-    worker = true;
+  } else if (wv == 1) {
+    rank = nwv - 1;                       // the likelihood wave: last
+  } else if (wv >= nwv - tiles_) {
+    rank = nfree + (wv - (nwv - tiles_));  // tile waves: behind the free ones
+  } else {
+    rank = wv == 0 ? 0 : wv - 1;
   }
 
   // =========================== the slices ====================================================
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         if (lane == 0) {
           accs[3] = prior;
           hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
+          lg[3] = (ndim - 1.0) * hsr_log(accs[0]);  // (the accept's z term: off the slice's tail)
         }
       }
       // ---- particle weights on every grid (-> LDS); the synchrotron liveness search ----------
@@ -574,7 +585,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           if (item >= total) break;
           bool is_tab;
           int ix;
-          if (item < F0) {
+          if (R.order == 2) {
+            is_tab = item >= nS;
+            ix = is_tab ? item - nS : item;
+          } else if (item < F0) {
             is_tab = true;
             ix = item;
           } else if (item - F0 < both) {
@@ -626,46 +640,46 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       HSR_STAMP(4);
       __syncthreads();  // ---------------------------------------------------------------- #3
       HSR_STAMP(5);
-      // ---- D. the walker's spectra are summed, the likelihood + priors (core.py:64-121), the
-      // accept and the record: ONE wave; wave 0 is already polling for the next slice, the
-      // others wait at its first barrier (nothing they could write before it is read here) ----
+      // ---- the walker's spectra meet in LDS (every thread its column: one wave alone took 1.9 us
+      // over it, 16 waves and a barrier 0.9) ------------------------------------------------
+      for (int t = 0; t < D.ntab; ++t) {
+        const hs_tab& tb = D.tab[t];
+        for (int k = tid; k < tb.nK; k += T) {
+          const int tile = k >> 6, ln = k & 63;
+          const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
+          const int stride = tb.tiles * 64, chunks = HS_CHUNKS(tb.chunks);
+          double sum = 0.0;
+          for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          }
+          sum *= sm[H.o_scale + tb.spec_off + k];
+          spec[tb.spec_off + k] = sum;
+        }
+      }
+      if (has_syn) {
+        const int nEs = H.syn_nE;
+        const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
+        for (int a = T - 1 - tid; a < nA; a += T) {  // (from the back: the tables took the front)
+          const double* pp = sm + H.o_part_s + a;
+          double sum = 0.0;
+          for (int c0 = 0; c0 < Cd; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          }
+          sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
+          spec[H.syn_spec_off + amap[a]] = sum;
+        }
+      }
+      __syncthreads();  // ---------------------------------------------------------------- #4
+      HSR_STAMP(6);
+      // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
+      // wave 0 is already polling for the next slice and the others wait at its first barrier ----
       if (lik_wave) {
-        for (int t = 0; t < D.ntab; ++t) {
-          const hs_tab& tb = D.tab[t];
-          for (int k = lane; k < tb.nK; k += 64) {
-            const int tile = k >> 6, ln = k & 63;
-            const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
-            const int stride = tb.tiles * 64, chunks = HS_CHUNKS(tb.chunks);
-            double sum = 0.0;
-            for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
-              double v[8];
-#pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
-              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
-            sum *= sm[H.o_scale + tb.spec_off + k];
-            spec[tb.spec_off + k] = sum;
-          }
-        }
-        if (has_syn) {
-          const int nEs = H.syn_nE;
-          const int* amap = reinterpret_cast<const int*>(sm + H.o_amap);
-          for (int a = lane; a < nA; a += 64) {
-            const double* pp = sm + H.o_part_s + a;
-            double sum = 0.0;
-            for (int c0 = 0; c0 < Cd; c0 += 8) {
-              double v[8];
-#pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] = c0 + q < Cd ? pp[(c0 + q) * nEs] : 0.0;
-              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
-            sum *= NH_ERG_PER_EV;  // 1/(s erg) -> 1/(s eV), :340
-            spec[H.syn_spec_off + amap[a]] = sum;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own LDS writes, in order)
-        if (R.dbg && lane == 0 && blockIdx.x < 256 && it < 64)
-          R.dbg[((long long)blockIdx.x * 64 + it) * 8 + 6] = (long long)wall_clock64();
         const int nE = H.nE;
         const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
         const double prior = accs[3];
@@ -703,13 +717,13 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           nviol = cnt & 0xffff;
           nul = cnt >> 16;
           // quirk kept from core.py:89-92: cl is indexed by the violation count
-          if (nul > 0) acc += (double)nviol * hsr_log(1.0 - H.cl[nviol]);
+          if (nul > 0) acc += (double)nviol * (nviol <= nE ? sm[R.o_lcl + nviol] : hsr_log(1.0 - H.cl[nviol]));
           if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
         }
         acc = __shfl(acc, 0, 64);
         // emcee RedBlueMove.propose for this walker
-        const double z = accs[0], oldlp = accs[2];
-        const double dd = (ndim - 1.0) * hsr_log(z) + acc - oldlp;
+        const double oldlp = accs[2];
+        const double dd = lg[3] + acc - oldlp;
         const bool ok = accs[1] < dd;  // NaN compares false, as numpy
         const int me2 = hi[HI_ME];
         // the record of the state after this step: row tl + 1
@@ -839,6 +853,8 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * 6;
   R.o_small1 = off; off += HS_O_T64;
   R.o_olds = off; off += 128;
+  R.o_lcl = off; off += H.nE + 1;
+  R.order = nh_env_int("NH_RUN_ORDER", 0);
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
   const void* fn = H.syn_grid >= 0 ? (const void*)k_half_step_run<true> : (const void*)k_half_step_run<false>;

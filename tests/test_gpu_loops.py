@@ -253,17 +253,18 @@ HAND = {
              ("index below its prior", 1, -0.8), ("negative B (below its prior)", 3, -0.4),
              ("beta below its prior", 4, 0.05), ("beta above its prior", 4, 6.0),
              ("cut-off 10 keV: every weight underflows", 2, -8.0 / np.log10(48.0))],
-    #   cfg2 prior: p0 >= 0 only
-    "cfg2": [("norm below its prior", 0, -0.03),
-             ("cut-off 10 keV: every weight underflows", 2, -8.0 / np.log10(48.0))],
-    #   cfg5: no prior; log10(cut-off / TeV) is p4 = 2
-    "cfg5": [("cut-off 10 keV: every weight underflows", 4, -4.0)],
+    #   cfg2 prior: p0 >= 0 only; cfg5: none.  No zero-weight walker for these two: a walker on
+    #   the zero-flux plateau has the same likelihood wherever it goes, nothing but a prior holds
+    #   it, and within ~15 steps the stretch move walks it to |log10(cut-off)| > 308 -- 10**x is
+    #   then inf, which the reference refuses ("e_cutoff value is NaN or Inf",
+    #   extern/validator.py) and emcee passes on: the reference's run dies there, the host-driven
+    #   loop here raises the same error.  cfg3's priors keep its plateau walker in range.
+    "cfg2": [("norm below its prior", 0, -0.03)],
+    "cfg5": [],
 }
 # (The cut-off sits five decades below the particle grids -- exp(-(E/E_c)^beta) underflows at
 # every node -- but not absurdly far: a stretch move that uses such a walker as the partner
-# lands at 10^(+11) TeV, still a number.  From 10^-403 TeV the same move proposes 10^+403 TeV
-# = inf, which the reference refuses with "e_cutoff value is NaN or Inf" (extern/validator.py)
-# and emcee passes on: the run dies there, and so does the host-driven loop here.)
+# lands at 10^(+11) TeV, still a number.)
 
 
 def _bench_ball(name, p0, nw):
@@ -369,7 +370,8 @@ def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw):
              int(np.isinf(lh[-1]).sum())))
     if prior is not None:
         assert ndead > 0, "no proposal was forbidden by the prior: HI_DEAD not exercised"
-    assert nzero > 0, "no proposal had a grid of zero weights: that short-cut not exercised"
+    if name == "cfg3":
+        assert nzero > 0, "no proposal had a grid of zero weights: that short-cut not exercised"
 
 
 def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na):
