@@ -62,7 +62,10 @@ struct hs_run {
   int o_gx[NH_MAX_GRIDS], o_lne[NH_MAX_GRIDS], o_ge[NH_MAX_GRIDS];  // LDS: grid nodes, ln E, E
   int o_pk, o_small1, o_olds;  // LDS: pack descriptors, the second small block, old coordinates
   int o_lcl;                   // LDS: ln(1 - cl[n]), n <= nE
-  int spin_limit, order;       // order: 0 = table and synchrotron items alternate, 2 = synchrotron first
+  // order: 2 = synchrotron items (twice as long as table items) first, then the tables -- the
+  // items pulled last decide how far apart the waves reach the barrier (cfg3: 18.9 -> 18.6 us of
+  // items + wait); 0 = the two kinds alternate as in k_half_step
+  int spin_limit, order;
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -227,19 +230,14 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
   const int tiles_ = has_syn ? (H.syn_nE + 63) >> 6 : 0;
   // the weights' nodes go to the waves that have nothing else to do before the second
   // barrier: not the likelihood wave (priors), not the tile waves (liveness search)
-  // ... first; the tile waves and the likelihood wave take a unit after their own duty (19 units
-  // of cfg3 over 13 waves left six of them with two)
-  int nfree = nwv - 1 - tiles_;
-  int nwork = nwv, rank;
-  const bool worker = true;
-  if (nfree < 1 || nwv == 1) {
+  // (tried: a unit for the tile waves and the likelihood wave after their own duty -- the
+  // likelihood wave, priors and a logarithm first, then became the last to arrive: 3.1 -> 3.7 us)
+  int nwork = nwv - 1 - tiles_, rank = wv == 0 ? 0 : wv - 1;
+  bool worker = wv != 1 && wv < nwv - tiles_;
+  if (nwork < 1) {
+    nwork = nwv;
     rank = wv;
-  } else if (wv == 1) {
-    rank = nwv - 1;                       // the likelihood wave: last
-  } else if (wv >= nwv - tiles_) {
-    rank = nfree + (wv - (nwv - tiles_));  // tile waves: behind the free ones
-  } else {
-    rank = wv == 0 ? 0 : wv - 1;
+    worker = true;
   }
 
   // =========================== the slices ====================================================
@@ -854,7 +852,7 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   R.o_small1 = off; off += HS_O_T64;
   R.o_olds = off; off += 128;
   R.o_lcl = off; off += H.nE + 1;
-  R.order = nh_env_int("NH_RUN_ORDER", 0);
+  R.order = nh_env_int("NH_RUN_ORDER", 2);
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
   const void* fn = H.syn_grid >= 0 ? (const void*)k_half_step_run<true> : (const void*)k_half_step_run<false>;

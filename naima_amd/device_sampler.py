@@ -519,7 +519,12 @@ class DeviceLoop:
         # the whole call, else one pair of copies per step
         dev_hist = self.fused and block is not None and not (
             self.mega and self._plan["hs"] is None)  # (the launch's plan does not exist yet)
-        if self.fused:
+        blob_hist_ok = not (block is not None and block["blobs"] and not (dev_hist and self.blobs_in_kernel))
+        # the whole call as launches of the resident loop, one per block of moves: nothing of the
+        # per-launch kernel's bookkeeping (history descriptor words, slice counter) is needed
+        fast = (self._resident_ok() and yield_every >= iterations and (block is None or dev_hist)
+                and blob_hist_ok)
+        if self.fused and not fast:
             words = [block["coords"].ptr, block["logp"].ptr, 0, iterations] if dev_hist \
                 else [0, 0, 0, 0]
             if dev_hist and self.blobs_in_kernel:
@@ -529,6 +534,27 @@ class DeviceLoop:
         blob_dev_hist = dev_hist and self.blobs_in_kernel  # the launches append the blobs too
         moves = s.moves(pinned=True)
         it = 0
+        while fast and it < iterations:
+            # up to KSTEPS steps per launch; the generator hands its stream out in pieces that end
+            # at its own block boundaries: they land side by side in `blk` and run as ONE launch
+            want, have = min(self.KSTEPS, iterations - it), 0
+            while have < want:
+                while len(self._inflight) >= 2:  # (nh_moves_take's contract, see below)
+                    ctx.call("nh_marker_wait", self._inflight.pop(0))
+                addr, got = moves.take(want - have)
+                ctx.call("nh_upload", self.blk.ptr + 8 * 2 * have * 3 * ns, addr,
+                         8 * 2 * got * 3 * ns)
+                mark = self._markers[self._nmark % len(self._markers)]
+                self._nmark += 1
+                ctx.call("nh_marker_record", mark)
+                self._inflight.append(mark)
+                have += got
+            self._run_resident(0, 2 * want, block)
+            it += want
+            s.iteration += want
+            if block is not None:
+                block["n"] += want
+            yield DeviceState(self, rng)
         while it < iterations:
             self._flush_pending()  # (merged sharded mode) the block's last accept
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the

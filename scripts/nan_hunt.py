@@ -35,8 +35,8 @@ props = T._replay_proposals(pos, ch, S, P, Z)
 allp = np.concatenate([pos, props])
 badc = ~np.isfinite(ch).all(axis=2)
 print("non-finite chain entries: %d (step, walker) pairs; first: %s" % (badc.sum(), np.argwhere(badc)[:5].tolist()))
-big = np.abs(allp) > 1e3
-print("rows of the evaluation set with |coordinate| > 1e3 or non-finite: %d" % (big | ~np.isfinite(allp)).any(axis=1).sum())
+big = np.abs(allp) > 300.0
+print("rows of the evaluation set with |coordinate| > 300 or non-finite: %d" % (big | ~np.isfinite(allp)).any(axis=1).sum())
 keep = np.isfinite(allp).all(axis=1) & ~big.any(axis=1)
 for i in np.flatnonzero(~keep)[:5]:
     print("   dropped row %d (step %d): %s" % (i, (i - len(pos)) // nw if i >= len(pos) else -1, allp[i]))
