@@ -262,7 +262,7 @@ def main():
     def make_sampler(device, graph, blobs=False):
         return EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
                                seed=20260929, comm=comm, naima_style=True, store_blobs=blobs,
-                               device=device, use_graph=graph)
+                               device=device, use_graph=graph, nan_policy="reject")
 
     device = not args.host_loop
     keep_blobs = not args.no_blobs
@@ -448,6 +448,9 @@ def main():
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
         "acceptance_fraction": acc_frac,
+        # (emcee stops at the first NaN log-probability; far-off walkers of the 10 % ball of the
+        # weakly constrained workloads -- cfg2, cfg5 -- do produce them: rejected and counted)
+        "nan_proposals_rejected": int(sampler.nan_proposals),
         "loop": ("host" if not device else
                  "device, resident workgroups: one launch of k_half_step_run per block of moves "
                  "(<= 32 steps), walkers handed over by tagged records" if resident else

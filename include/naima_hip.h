@@ -482,6 +482,11 @@ int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
  * arrive sums the partial spectra in index order and evaluates the likelihood: the results do
  * not depend on arrival order).  NH_HS_SPLIT=<K> in the environment caps K (1: never split). */
 int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
+/* proposals whose log-probability was NaN since the plan was created (or the last reset):
+ * emcee raises ValueError("Probability function returned NaN") on the first one
+ * (EnsembleSampler.compute_log_prob; reference call site core.py:128), a launch rejects the
+ * proposal and counts it here for the caller to act on.  Synchronises the stream. */
+int nh_half_step_nan_count(nh_ctx* ctx, nh_halfstep_plan* plan, int reset, int* count);
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
 
 /* ---- a whole block of moves in ONE launch: the half-step kernel with resident workgroups ----

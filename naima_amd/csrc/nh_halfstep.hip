@@ -1025,6 +1025,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         }
         D.accepted[g] = ok ? 1 : 0;
         if (D.sel) D.sel[g] = me2;
+        // emcee raises "Probability function returned NaN" here; the launch cannot, it counts
+        if (acc != acc) atomicAdd(const_cast<int*>(H.hbase) + 1, 1);
       }
     }
     // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
@@ -1451,9 +1453,9 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     if (e == hipSuccess) e = hipMalloc(&P->tick, (size_t)d->nloc * sizeof(int));
     if (e == hipSuccess) e = hipMemset(P->tick, 0, (size_t)d->nloc * sizeof(int));
   }
-  if (e == hipSuccess) e = hipMalloc(&P->words, 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&P->words, 4 * sizeof(int));  // done | hbase | NaN proposals | -
   if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(P->words, 0, 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(P->words, 0, 4 * sizeof(int));
   if (e == hipSuccess && lds > 64 * 1024)
     e = H.syn_grid >= 0
             ? hipFuncSetAttribute((const void*)k_half_step<true>,
@@ -1575,6 +1577,19 @@ extern "C" int nh_half_step_stamps(nh_ctx* c, const nh_halfstep_plan* P, long lo
   int rc = nh_sync(c);
   if (rc) return rc;
   NH_CHECK_HIP(hipMemcpy(out, P->dbg, 67840 * sizeof(long long), hipMemcpyDeviceToHost));
+  return NH_OK;
+}
+
+// proposals whose log-probability came out NaN since the plan was made (or since the last
+// reset): emcee's EnsembleSampler.compute_log_prob raises ValueError("Probability function
+// returned NaN") on the first one; a launch rejects the proposal (NaN compares false) and counts.
+// Synchronises the stream.
+extern "C" int nh_half_step_nan_count(nh_ctx* c, nh_halfstep_plan* P, int reset, int* count) {
+  NH_REQUIRE(c && P && count, "bad argument");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipMemcpy(count, P->words + 2, sizeof(int), hipMemcpyDeviceToHost));
+  if (reset && *count) NH_CHECK_HIP(hipMemset(P->words + 2, 0, sizeof(int)));
   return NH_OK;
 }
 

@@ -741,7 +741,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           if (lane < ndim) R.hcoords[(hrow * N + me2) * ndim + lane] = ok ? qs[lane] : olds[lane];
           if (lane == 0) R.hlogp[hrow * N + me2] = ok ? acc : oldlp;
         }
-        if (lane == 0) R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
+        if (lane == 0) {
+          R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
+          if (acc != acc) atomicAdd(const_cast<int*>(H.hbase) + 1, 1);  // (see nh_half_step_nan_count)
+        }
         if (ok) {  // the accepted position's blobs
           for (int b = 0; b < D.nblob; ++b) {
             const nh_hs_blob& bl = D.blob[b];
@@ -802,14 +805,23 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
     if (!hb) continue;
     for (long long e = gid; e < (long long)N * bl.m; e += gsz) {
       const int w = (int)(e / bl.m);
+      // (every load of the column is issued before the first is used: walked one step at a time
+      // the fill was a chain of 2 x nsteps dependent round trips, 24 us for 20 steps)
+      double cell[HS_RUN_MAX_STEPS];
+      unsigned acc = 0;
+#pragma unroll
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t)
+        if (t < nsteps) {
+          cell[t] = hb[(R.hrow0 + t) * (long long)N * bl.m + e];
+          acc |= R.accw[(long long)t * N + w] ? 1u << t : 0u;
+        }
       double prev = bl.cur[e];
-      for (int t = 0; t < nsteps; ++t) {
-        const long long hrow = R.hrow0 + t;
-        if (hrow >= R.hcap) break;
-        double* cell = hb + hrow * (long long)N * bl.m + e;
-        if (R.accw[(long long)t * N + w]) prev = *cell;
-        else *cell = prev;
-      }
+#pragma unroll
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t)
+        if (t < nsteps) {
+          if (acc >> t & 1) prev = cell[t];
+          else hb[(R.hrow0 + t) * (long long)N * bl.m + e] = prev;
+        }
       bl.cur[e] = prev;
     }
   }

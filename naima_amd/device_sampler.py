@@ -39,6 +39,7 @@ class DeviceState:
         if self._c is None:
             self._loop._flush_pending()
             self._loop.check_resident()
+            self._loop.check_nan()
             self._c = self._loop.coords.get().reshape(self._loop.N, self._loop.ndim)
         return self._c
 
@@ -47,6 +48,7 @@ class DeviceState:
         if self._l is None:
             self._loop._flush_pending()
             self._loop.check_resident()
+            self._loop.check_nan()
             self._l = self._loop.logp.get()
         return self._l
 
@@ -699,6 +701,21 @@ class DeviceLoop:
         self.s.n_lnprob_calls += nslices
         self.s.n_walker_evals += nslices * self.nloc
 
+    def check_nan(self):
+        """NaN log-probabilities the launches met since the last look (one-launch plans count
+        them on the device): counted, or raised as emcee does, by the sampler's nan_policy"""
+        hs = self._plan["hs"] if self._plan else None
+        if hs is None or hs.get("plan") is None:
+            return
+        n = _lib._i()
+        _lib._chk(_lib._lib.nh_half_step_nan_count(self.ctx.h, hs["plan"], 1, C.byref(n)))
+        if n.value:
+            self.s.nan_proposals += n.value
+            if self.s.nan_policy == "raise":
+                raise ValueError("Probability function returned NaN (%d proposals of the device "
+                                 "loop; emcee stops at the first one -- pass nan_policy='reject' "
+                                 "to treat them as rejected proposals)" % n.value)
+
     def check_resident(self):
         """raise if a launch of the resident loop gave up waiting for a walker's record (its
         workgroups were not all resident: another process on the GPU, a profiler that
@@ -849,6 +866,7 @@ class DeviceLoop:
         """bring the pending chain history and acceptance counters to the host"""
         self._flush_pending()
         self.check_resident()
+        self.check_nan()
         self.ctx.check_general()  # (a per-walker grid longer than the general kernel's LDS)
         s = self.s
         for block in self.hist:

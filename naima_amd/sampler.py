@@ -57,7 +57,8 @@ class EnsembleSampler:
     """
 
     def __init__(self, nwalkers, ndim, log_prob_fn, args=(), a=2.0, seed=None, comm=None,
-                 naima_style=False, store_blobs=True, device=False, use_graph=True):
+                 naima_style=False, store_blobs=True, device=False, use_graph=True,
+                 nan_policy="raise"):
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError("need an even number of walkers, at least twice the dimension")
         self.nwalkers, self.ndim, self.a = int(nwalkers), int(ndim), float(a)
@@ -70,6 +71,15 @@ class EnsembleSampler:
         self._moves = None
         self.naima_style = naima_style
         self.store_blobs = store_blobs
+        # a proposal whose log-probability is NaN: "raise" is emcee's behaviour (ValueError
+        # "Probability function returned NaN", EnsembleSampler.compute_log_prob) -- the host loop
+        # raises on the spot, the device loop (whose launches cannot) when the run's results
+        # next reach the host; "reject" treats the proposal as one that is never accepted and
+        # counts it in ``nan_proposals``
+        if nan_policy not in ("raise", "reject"):
+            raise ValueError("nan_policy must be 'raise' or 'reject'")
+        self.nan_policy = nan_policy
+        self.nan_proposals = 0
         # device=True: ensemble, proposals, log-probabilities and blobs live in HBM; the
         # launch sequence of one half-step (propose -> model -> likelihood -> accept)
         # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)
@@ -163,7 +173,10 @@ class EnsembleSampler:
             lnp_local, blobs = np.asarray(res, dtype=float), []
         lnp_local = np.broadcast_to(lnp_local, (hi - lo,)).astype(float)
         if np.any(np.isnan(lnp_local)):
-            raise ValueError("Probability function returned NaN")
+            if self.nan_policy == "raise":
+                raise ValueError("Probability function returned NaN")
+            self.nan_proposals += int(np.isnan(lnp_local).sum())
+            lnp_local = np.where(np.isnan(lnp_local), -np.inf, lnp_local)
         if self.comm.size > 1:
             m = max(shard_counts(n, self.comm.size))
             pad = np.full((m,), -np.inf)

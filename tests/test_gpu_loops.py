@@ -334,7 +334,13 @@ def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw):
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior = _problem(na, name, {})
     nd = p0.size
-    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True)
+    # (cfg2 and cfg5 have next to no prior: walkers the ball throws far off wander on, and within
+    # ~30 steps one of them proposes parameters for which the reference's own arithmetic gives a
+    # NaN log-probability -- the oracle agrees -- where emcee raises ValueError and the run is
+    # over, here as there (test_nan_log_probability_is_emcees_error).  To compare all 70 steps
+    # both loops run with nan_policy="reject": such a proposal is never accepted, and counted.)
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True,
+              nan_policy="reject")
     pos = _bench_ball(name, p0, nw)
     calls = (2, 68)  # 70 steps: three blocks of moves, several multi-step graphs
     h = EnsembleSampler(nw, nd, na.lnprob, **kw)
@@ -364,10 +370,12 @@ def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw):
     assert props.shape == (sum(calls) * nw, nd)
     with np.errstate(all="ignore"):
         ndead, nzero = _count_shortcuts(na, model, prior, data, props)
+    d.get_chain()  # (flush: the device loop's NaN count reaches the host)
     print("%s: %d proposals, %d forbidden by the prior, %d with a grid of zero weights; "
-          "%d walkers end at lnp < -1000, %d at -inf"
+          "%d walkers end at lnp < -1000, %d at -inf; NaN proposals rejected: host %d, device %d"
           % (name, len(props), ndead, nzero, int((lh[-1] < -1000).sum()),
-             int(np.isinf(lh[-1]).sum())))
+             int(np.isinf(lh[-1]).sum()), h.nan_proposals, d.nan_proposals))
+    assert d.nan_proposals == h.nan_proposals
     if prior is not None:
         assert ndead > 0, "no proposal was forbidden by the prior: HI_DEAD not exercised"
     if name == "cfg3":
@@ -512,3 +520,25 @@ def test_table_only_model_with_more_walkers_than_compute_units(na):
     for x, y in zip(d.get_blobs(), h.get_blobs()):
         assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-8,
                         atol=1e-300)
+
+
+def test_nan_log_probability_is_emcees_error(na):
+    """a proposal whose log-probability is NaN ends an emcee run with ValueError("Probability
+    function returned NaN") (EnsembleSampler.compute_log_prob; the reference just lets it
+    through, core.py:128): the host-driven loop raises on the spot, the device loop -- whose
+    launches cannot -- when the run's results next reach the host.  cfg2 from the benchmark's
+    ball meets its first such proposal (a negative magnetic field the prior does not forbid)
+    within ~30 steps."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg2", {})
+    nw, nd = 256, p0.size
+    pos = _bench_ball("cfg2", p0, nw)
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=False)
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    with pytest.raises(ValueError, match="returned NaN"), np.errstate(all="ignore"):
+        h.run_mcmc(pos, 70)
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    with pytest.raises(ValueError, match="returned NaN"), np.errstate(all="ignore"):
+        st = d.run_mcmc(pos, 2)
+        st = d.run_mcmc(st, 68)
+        st.coords
