@@ -1026,11 +1026,14 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         D.accepted[g] = ok ? 1 : 0;
         if (D.sel) D.sel[g] = me2;
         // emcee raises "Probability function returned NaN" here; the launch cannot, it counts
-        if (acc != acc) atomicAdd(const_cast<int*>(H.hbase) + 1, 1);
       }
     }
     // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
-    if (lane == 0) atomicAdd(H.done, 1);
+    if (lane == 0) {
+      atomicAdd(H.done, 1);
+      // emcee raises "Probability function returned NaN" here; the launch cannot, it counts
+      if (acc != acc) atomicAdd(H.done + 2, 1);
+    }
     if (dbg_on && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
   }
   HS_STAMP(9);

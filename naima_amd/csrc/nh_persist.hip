@@ -743,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         }
         if (lane == 0) {
           R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
-          if (acc != acc) atomicAdd(const_cast<int*>(H.hbase) + 1, 1);  // (see nh_half_step_nan_count)
+          if (acc != acc) atomicAdd(H.done + 2, 1);  // (see nh_half_step_nan_count)
         }
         if (ok) {  // the accepted position's blobs
           for (int b = 0; b < D.nblob; ++b) {
@@ -794,8 +794,12 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   }
   if (D.naccepted)
     for (long long w = gid; w < N; w += gsz) {
+      int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
+#pragma unroll
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = t < nsteps ? R.accw[(long long)t * N + w] : 0;
       int a = 0;
-      for (int t = 0; t < nsteps; ++t) a += R.accw[(long long)t * N + w];
+#pragma unroll
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += f[t];
       D.naccepted[w] += a;
     }
   const bool hist = R.hcoords != nullptr;
@@ -881,6 +885,11 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   // so registers or LDS bind first and the query is exact.  The bounded waits are the net.)
   long long cap = (long long)per_cu * ncu;
   if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  // More walkers per half-step than resident workgroups: a workgroup would take several walkers
+  // per slice, one after the other -- and the resident layout's extra LDS (grid nodes, ln E, E)
+  // halves the workgroups a CU holds: cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s
+  // resident (two 256-thread workgroups per CU) against 24.2 M launched per half-step (four).
+  NH_REQUIRE(H.nloc <= cap, "more walkers per half-step than resident workgroups");
   nh_halfstep_run* Q = new nh_halfstep_run();
   Q->R = R;
   Q->lds_bytes = lds;

@@ -324,3 +324,26 @@ def test_validate_data_table_against_the_reference(golden):
                 assert_allclose(have.astype(float), want, rtol=1e-13, atol=0, err_msg="%s %s" % (case, col))
             ncols += 1
     assert ncols >= 150  # (17 cases x 9 columns)
+
+
+def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
+    """k_half_step takes its 3 KB descriptor by value; small edits (one more dynamic field read,
+    an atomic in the wrong block) have twice made the compiler copy all of it to scratch memory
+    -- 6x slower launches, and nothing but ScratchSize in the resource report shows it.  The
+    resident kernel's only scratch is the frames of its out-of-line math calls."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "naima_amd", "csrc")
+    want = {"nh_halfstep.hip": ("k_half_step", 0), "nh_persist.hip": ("k_half_step_run", 256)}
+    for f, (sym, limit) in want.items():
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
+                              "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                              "-Rpass-analysis=kernel-resource-usage", os.path.join(src, f),
+                              "-o", os.devnull], capture_output=True, text=True).stderr
+        blocks = re.split(r"remark: Function Name: ", out)[1:]
+        sizes = {b.split()[0]: int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+                 for b in blocks}
+        mine = {k: v for k, v in sizes.items() if sym + "IL" in k}
+        assert len(mine) == 2, sizes
+        for k, v in mine.items():
+            assert v <= limit, "%s uses %d bytes of scratch per lane" % (k, v)
