@@ -74,6 +74,13 @@ int nh_device_info(nh_ctx* ctx, char* name, int name_len, int* compute_units,
 int nh_alloc(nh_ctx* ctx, long long bytes, void** dev_out);
 int nh_free(nh_ctx* ctx, void* dev);
 int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes);
+/* host -> device on a copy stream of its own: not ordered behind the main stream's work and not
+ * waited for by nh_sync (the NEXT block of stretch-move random numbers goes up while the current
+ * block's launch runs; emcee draws them inside the step, StretchMove.get_proposal).  `marker` is
+ * recorded behind the copy; nh_stream_wait_marker orders the main stream behind it. */
+int nh_upload_ahead(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes,
+                    void* marker);
+int nh_stream_wait_marker(nh_ctx* ctx, void* marker);
 int nh_download(nh_ctx* ctx, void* host_dst, const void* dev_src, long long bytes);
 int nh_memset(nh_ctx* ctx, void* dev, int byte, long long bytes);
 /* dev[0..n) := values[0..n), n <= 8 64-bit words carried as kernel arguments: stream-ordered

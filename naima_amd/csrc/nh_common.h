@@ -55,6 +55,7 @@ struct nh_ctx {
   void* rccl_lib;  // dlopen handle
   void* scratch;   // library-owned device scratch (grown outside graph capture)
   size_t scratch_bytes;
+  hipStream_t copy_stream;  // uploads that run AHEAD of the main stream (nh_upload_ahead), or NULL
 };
 
 // device scratch of at least `bytes`; contents are only valid within one entry point

@@ -44,6 +44,7 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   c->rccl_lib = nullptr;
   c->scratch = nullptr;
   c->scratch_bytes = 0;
+  c->copy_stream = nullptr;
   memset(c->acc_ms, 0, sizeof(c->acc_ms));
   memset(c->acc_n, 0, sizeof(c->acc_n));
   NH_CHECK_HIP(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
@@ -71,6 +72,10 @@ extern "C" int nh_destroy(nh_ctx* c) {
     (void)hipEventDestroy(c->ev_side[i]);
   }
   (void)hipEventDestroy(c->ev_fork);
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
   if (c->scratch) (void)hipFree(c->scratch);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& e : c->pool) (void)hipEventDestroy(e);
@@ -139,6 +144,28 @@ extern "C" int nh_upload(nh_ctx* c, void* dst, const void* src, long long bytes)
   // pageable source: hipMemcpyAsync stages it before returning, so the host
   // buffer may be reused immediately; ordering on the stream is preserved
   NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  return NH_OK;
+}
+
+// Host -> device on a stream of its own, NOT ordered behind what the main stream is doing
+// (and not waited for by nh_sync): the upload of the NEXT block of stretch-move random numbers
+// while the current block's launch runs.  `marker` (nh_marker_create) is recorded behind the
+// copy; nh_stream_wait_marker makes the main stream wait for it before the first launch that
+// reads the data.  The caller keeps `dst` disjoint from anything queued or running.
+extern "C" int nh_upload_ahead(nh_ctx* c, void* dst, const void* src, long long bytes,
+                               void* marker) {
+  NH_REQUIRE(c && dst && src && bytes >= 0 && marker, "bad argument");
+  if (!c->copy_stream)
+    NH_CHECK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
+  NH_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(marker), c->copy_stream));
+  return NH_OK;
+}
+
+// everything launched on the context's stream from here on waits for `marker`
+extern "C" int nh_stream_wait_marker(nh_ctx* c, void* marker) {
+  NH_REQUIRE(c && marker, "bad argument");
+  NH_CHECK_HIP(hipStreamWaitEvent(c->stream, reinterpret_cast<hipEvent_t>(marker), 0));
   return NH_OK;
 }
 

@@ -796,10 +796,10 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
     for (long long w = gid; w < N; w += gsz) {
       int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
 #pragma unroll
-      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = t < nsteps ? R.accw[(long long)t * N + w] : 0;
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = R.accw[(long long)(t < nsteps ? t : nsteps - 1) * N + w];
       int a = 0;
 #pragma unroll
-      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += f[t];
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += t < nsteps ? f[t] : 0;
       D.naccepted[w] += a;
     }
   const bool hist = R.hcoords != nullptr;
@@ -812,14 +812,19 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
       // (every load of the column is issued before the first is used: walked one step at a time
       // the fill was a chain of 2 x nsteps dependent round trips, 24 us for 20 steps)
       double cell[HS_RUN_MAX_STEPS];
-      unsigned acc = 0;
+      int fl[HS_RUN_MAX_STEPS];
 #pragma unroll
-      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t)
-        if (t < nsteps) {
-          cell[t] = hb[(R.hrow0 + t) * (long long)N * bl.m + e];
-          acc |= R.accw[(long long)t * N + w] ? 1u << t : 0u;
-        }
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) {
+        // (straight-line, every address valid: steps past the launch's re-read its last one.
+        // Behind a condition per step the compiler waited for each load before the next.)
+        const long long tt = t < nsteps ? t : nsteps - 1;
+        cell[t] = hb[(R.hrow0 + tt) * (long long)N * bl.m + e];
+        fl[t] = R.accw[tt * N + w];
+      }
       double prev = bl.cur[e];
+      unsigned acc = 0;  // (first use of any load: after the last one has been issued)
+#pragma unroll
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) acc |= (t < nsteps && fl[t]) ? 1u << t : 0u;
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t)
         if (t < nsteps) {

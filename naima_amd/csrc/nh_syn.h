@@ -124,12 +124,17 @@ __device__ __forceinline__ double syn_P1(double cb) {
 // ln(P2/P1) for neighbouring nodes: 2 atanh(s), s = (P2-P1)/(P2+P1).  Naima's default grids
 // (100 nodes per decade) have s^2 < 1e-4, where three terms are exact to 1.4e-13 relative
 // (5e-16 absolute); up to s^2 = 9e-4 five terms; coarser grids take the logarithm.
+// (out of line: the library logarithm and the IEEE division are ~150 instructions that would sit
+// in the middle of the hot loop's instruction stream, for grids coarser than naima ever uses)
+__device__ __attribute__((noinline)) double syn_log_ratio(double P1, double P2) {
+  return log(P2 / P1);
+}
 __device__ __forceinline__ double syn_dlnP1(double P1, double P2) {
   const double s = (P2 - P1) * nh_rcp1f(P2 + P1);
   const double s2 = s * s;
   if (__builtin_amdgcn_ballot_w64(s2 > 1e-4) != 0ull) {
     asm volatile("" ::: "memory");  // keep the slower forms in the branch
-    if (__builtin_amdgcn_ballot_w64(s2 > 9e-4) != 0ull) return log(P2 / P1);
+    if (__builtin_amdgcn_ballot_w64(s2 > 9e-4) != 0ull) return syn_log_ratio(P1, P2);
     double a = fma(s2, 1.0 / 9.0, 1.0 / 7.0);
     a = fma(a, s2, 0.2);
     a = fma(a, s2, 1.0 / 3.0);

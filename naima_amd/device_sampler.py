@@ -125,8 +125,13 @@ class DeviceLoop:
         self.multi_graph = None
         # one spare slice: the fused move kernel proposes the half-step AFTER the one it
         # accepts, so the last one of a block reads (and discards) slice 2*KSTEPS
-        self.blk = ctx.empty((2 * self.KSTEPS + 1, 3 * self.ns))
+        # (room for MOVES_CAP steps: the resident loop keeps the move stream's next steps on the
+        # device ahead of time -- uploaded on a copy stream while the current launch runs)
+        self.MOVES_CAP = 4 * self.KSTEPS
+        self.blk = ctx.empty((2 * self.MOVES_CAP + 1, 3 * self.ns))
         ctx.call("nh_memset", self.blk, 0, self.blk.nbytes)
+        self._mv = dict(have=0, used=0, ahead=None)  # steps on the device / consumed / last ahead marker
+        self._blk_tmp = None
         # nh_step_front mode: set after a recording evaluation when the model's parameter
         # packs read the proposal buffer and it asks for ONE particle-weights launch
         self.fused = False
@@ -536,22 +541,26 @@ class DeviceLoop:
         blob_dev_hist = dev_hist and self.blobs_in_kernel  # the launches append the blobs too
         moves = s.moves(pinned=True)
         it = 0
+        mv = self._mv
         while fast and it < iterations:
-            # up to KSTEPS steps per launch; the generator hands its stream out in pieces that end
-            # at its own block boundaries: they land side by side in `blk` and run as ONE launch
-            want, have = min(self.KSTEPS, iterations - it), 0
-            while have < want:
-                while len(self._inflight) >= 2:  # (nh_moves_take's contract, see below)
-                    ctx.call("nh_marker_wait", self._inflight.pop(0))
-                addr, got = moves.take(want - have)
-                ctx.call("nh_upload", self.blk.ptr + 8 * 2 * have * 3 * ns, addr,
-                         8 * 2 * got * 3 * ns)
-                mark = self._markers[self._nmark % len(self._markers)]
-                self._nmark += 1
-                ctx.call("nh_marker_record", mark)
-                self._inflight.append(mark)
-                have += got
-            self._run_resident(0, 2 * want, block)
+            # up to KSTEPS steps per launch.  The moves are a function of the seed only, so the
+            # stream's next steps are already on the device (uploaded ahead, below) unless this
+            # is the first call; the generator hands its stream out in pieces that end at its
+            # own block boundaries: they land side by side in `blk` and run as ONE launch
+            want = min(self.KSTEPS, iterations - it)
+            if mv["have"] - mv["used"] < want:
+                need = want - (mv["have"] - mv["used"])
+                if mv["have"] + need > self.MOVES_CAP:
+                    self._moves_to_front()
+                self._moves_append(moves, need, ahead=False)
+            if mv["ahead"] is not None:  # the launch waits for the copy stream's last upload
+                ctx.call("nh_stream_wait_marker", mv["ahead"])
+                mv["ahead"] = None
+            self._run_resident(2 * mv["used"], 2 * want, block)
+            mv["used"] += want
+            if mv["have"] - mv["used"] < self.KSTEPS and \
+                    mv["have"] + self.KSTEPS <= self.MOVES_CAP:
+                self._moves_append(moves, self.KSTEPS, ahead=True)
             it += want
             s.iteration += want
             if block is not None:
@@ -567,8 +576,15 @@ class DeviceLoop:
             # has to be complete -- wait on the marker recorded after it
             while len(self._inflight) >= 2:
                 ctx.call("nh_marker_wait", self._inflight.pop(0))
-            addr, K = moves.take(min(self.KSTEPS, iterations - it))
-            ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
+            if mv["have"] > mv["used"]:
+                # steps of the move stream the resident loop uploaded ahead and did not use: they
+                # come first (to the front of `blk`, where this loop expects its block)
+                K = min(mv["have"] - mv["used"], self.KSTEPS, iterations - it)
+                self._moves_to_front(K)
+            else:
+                mv["have"] = mv["used"] = 0
+                addr, K = moves.take(min(self.KSTEPS, iterations - it))
+                ctx.call("nh_upload", self.blk, addr, 8 * 2 * K * 3 * ns)
             if self.fused:
                 if self.mega and self._plan["hs"] is not None:
                     # (the one-launch kernel writes the cursor itself, every launch)
@@ -661,6 +677,53 @@ class DeviceLoop:
                                  block["n"] - 1)
                 yield DeviceState(self, rng)
         self._flush_pending()
+
+    # ------------------------------------------------------------- the move stream on the device
+    def _moves_append(self, moves, n, ahead):
+        """the next n steps of the move stream (fewer if the generator's piece ends earlier and
+        `ahead`) behind the ones `blk` holds; ahead: on the copy stream, beside the running
+        launch (nh_upload_ahead), else on the main stream"""
+        ctx, mv, sb = self.ctx, self._mv, 8 * 2 * 3 * self.ns
+        done = 0
+        while done < n:
+            # nh_moves_take's contract: only the copy of the MOST RECENT take may still be
+            # queued when the next one is taken
+            while len(self._inflight) >= 2:
+                ctx.call("nh_marker_wait", self._inflight.pop(0))
+            addr, got = moves.take(n - done)
+            mark = self._markers[self._nmark % len(self._markers)]
+            self._nmark += 1
+            dst = self.blk.ptr + sb * mv["have"]
+            if ahead:
+                ctx.call("nh_upload_ahead", dst, addr, sb * got, mark)
+                mv["ahead"] = mark
+            else:
+                ctx.call("nh_upload", dst, addr, sb * got)
+                ctx.call("nh_marker_record", mark)
+            self._inflight.append(mark)
+            mv["have"] += got
+            done += got
+
+    def _moves_to_front(self, k=None):
+        """the unused steps `blk` holds (the first k of them) move to its front, in stream order
+        behind whatever still reads the block; with k the loop that follows consumes them"""
+        ctx, mv, sb = self.ctx, self._mv, 8 * 2 * 3 * self.ns
+        avail = mv["have"] - mv["used"]
+        n = avail if k is None else k
+        if mv["ahead"] is not None:
+            ctx.call("nh_stream_wait_marker", mv["ahead"])
+            mv["ahead"] = None
+        if n > 0 and mv["used"] > 0:
+            if self._blk_tmp is None:
+                self._blk_tmp = ctx.empty((2 * self.MOVES_CAP, 3 * self.ns))
+            ctx.call("nh_copy", self._blk_tmp, self.blk.ptr + sb * mv["used"], sb * n)
+            ctx.call("nh_copy", self.blk, self._blk_tmp, sb * n)
+        if k is None:
+            mv["have"], mv["used"] = avail, 0
+        else:
+            mv["used"] += k  # (what is left stays where it is, behind the part now at the front)
+            if mv["used"] == mv["have"]:
+                mv["have"] = mv["used"] = 0
 
     # ------------------------------------------------------------- resident loop
     def _resident_ok(self):
