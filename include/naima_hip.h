@@ -529,7 +529,8 @@ int nh_half_step_run_info(const nh_halfstep_run* run, int* grid, int* threads,
                           long long* lds_bytes);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
  * (workgroup, slice handled): start | records in | packs done | weights done | own items
- * done | all items done | spectra summed | record published */
+ * done | all items done | spectra summed | record published; then [64][4][16]: for workgroup
+ * 0, per slice handled, when each of its waves reached barrier 1 | 2 | 3 (| unused) */
 int nh_half_step_run_stamps(nh_ctx* ctx, const nh_halfstep_run* run, long long* out);
 int nh_half_step_run_destroy(nh_ctx* ctx, nh_halfstep_run* run);
 /* diagnostics (plans created under NH_HS_DEBUG=1): per-phase 100 MHz wall-clock stamps of the

@@ -126,6 +126,12 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
   return r;
 }
 
+// workgroup 0 only: when does each WAVE reach barrier 1 / 2 / 3 and finish its last item
+#define HSR_WSTAMP(k)                                                                  \
+  do {                                                                                  \
+    if (R.dbg && lane == 0 && blockIdx.x == 0 && it < 64)                               \
+      R.dbg[256 * 64 * 8 + (it * 4 + (k)) * 16 + wv] = (long long)wall_clock64();       \
+  } while (0)
 #define HSR_STAMP(k)                                                                   \
   do {                                                                                  \
     if (R.dbg && tid == 0 && blockIdx.x < 256 && it < 64)                               \
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           }
         }
       }
+      HSR_WSTAMP(0);
       __syncthreads();  // ---------------------------------------------------------------- #1
       HSR_STAMP(2);
       if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
         if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
       }
+      HSR_WSTAMP(1);
       __syncthreads();  // ---------------------------------------------------------------- #2
       HSR_STAMP(3);
       const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
@@ -636,6 +644,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         }
       }
       HSR_STAMP(4);
+      HSR_WSTAMP(2);
       __syncthreads();  // ---------------------------------------------------------------- #3
       HSR_STAMP(5);
       // ---- the walker's spectra meet in LDS (every thread its column: one wave alone took 1.9 us
@@ -912,8 +921,8 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   if (e == hipSuccess)
     if (const char* dv = getenv("NH_HS_DEBUG"))
       if (atoi(dv) != 0) {
-        e = hipMalloc(&Q->dbg, 256 * 64 * 8 * sizeof(long long));
-        if (e == hipSuccess) e = hipMemset(Q->dbg, 0, 256 * 64 * 8 * sizeof(long long));
+        e = hipMalloc(&Q->dbg, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
+        if (e == hipSuccess) e = hipMemset(Q->dbg, 0, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
       }
   if (e != hipSuccess) {
     if (Q->ring) (void)hipFree(Q->ring);
@@ -996,11 +1005,11 @@ extern "C" int nh_half_step_run_info(const nh_halfstep_run* Q, int* grid, int* t
 // 7 record published
 extern "C" int nh_half_step_run_stamps(nh_ctx* c, const nh_halfstep_run* Q, long long* out) {
   NH_REQUIRE(c && Q && out, "bad argument");
-  memset(out, 0, 256 * 64 * 8 * sizeof(long long));
+  memset(out, 0, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
   if (!Q->dbg) return NH_OK;
   int rc = nh_sync(c);
   if (rc) return rc;
-  NH_CHECK_HIP(hipMemcpy(out, Q->dbg, 256 * 64 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  NH_CHECK_HIP(hipMemcpy(out, Q->dbg, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long), hipMemcpyDeviceToHost));
   return NH_OK;
 }
 

@@ -1,42 +1,52 @@
-"""gpurun_out/r2prof (scripts/gpu_r2_profile.sh on the GPU box) -> profiles/r02_* (tracked)"""
+"""gpurun_out/<tag>prof (scripts/gpu_profile.sh on the GPU box) -> profiles/<tag>_* (tracked)
+
+    python scripts/collect_profiles.py [tag, default r03]
+"""
+import glob
 import json
 import os
 import shutil
+import sys
 
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-S, D = os.path.join(R, "gpurun_out", "r2prof"), os.path.join(R, "profiles")
-COPY = {
-    "bench_n1_default.json": "r02_bench_n1_default.json",
-    "bench_under_rocprof.json": "r02_cfg3_bench_under_rocprof.json",
-    "stats_kernel_stats.csv": "r02_cfg3_kernel_stats.csv",
-    "stats_command.txt": "r02_cfg3_kernel_stats_command.txt",
-    "counters_per_launch.json": "r02_cfg3_counters_per_launch.json",
-    "stamps_cfg3.txt": "r02_cfg3_half_step_phase_stamps.txt",
-    "stamps_cfg5.txt": "r02_cfg5_half_step_phase_stamps.txt",
-    "shard_table.json": "r02_shard_table.json",
-    "cfg4stats_kernel_stats.csv": "r02_cfg4_kernel_stats.csv",
-    "cfg4_bench_under_rocprof.json": "r02_cfg4_bench_under_rocprof.json",
-    "bench_cfg1.json": "r02_bench_cfg1.json", "bench_cfg2.json": "r02_bench_cfg2.json",
-    "bench_cfg2_nosplit.json": "r02_bench_cfg2_nosplit.json",
-    "bench_cfg4.json": "r02_bench_cfg4.json", "bench_cfg5.json": "r02_bench_cfg5.json",
-    "bench_cfg3_ball0005.json": "r02_bench_cfg3_ball0005.json",
-    "bench_cfg3_w256_split.json": "r02_bench_cfg3_w256_split.json",
-    "bench_cfg3_w256_nosplit.json": "r02_bench_cfg3_w256_nosplit.json",
-    "bench_cfg5_strong2048_n1.json": "r02_bench_cfg5_strong2048_n1.json",
-}
+S, D = os.path.join(R, "gpurun_out", TAG + "prof"), os.path.join(R, "profiles")
+COPY = {"bench_n1_default.json": "bench_n1_default.json",
+        "bench_n1_per_launch_kernel.json": "bench_n1_per_launch_kernel.json",
+        "bench_cfg5_per_launch_kernel.json": "bench_cfg5_per_launch_kernel.json",
+        "cfg3_stats_command.txt": "cfg3_kernel_stats_command.txt",
+        "stamps_cfg3.txt": "cfg3_resident_loop_phase_stamps.txt",
+        "stamps_cfg5.txt": "cfg5_resident_loop_phase_stamps.txt",
+        "bench_cfg3_w256.json": "bench_cfg3_w256.json",
+        "bench_cfg5_strong2048_n1.json": "bench_cfg5_strong2048_n1.json"}
+for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+    COPY["%s_stats_kernel_stats.csv" % w] = "%s_kernel_stats.csv" % w
+    COPY["%s_stats_bench.json" % w] = "%s_bench_under_rocprof.json" % w
+    if w != "cfg3":
+        COPY["bench_%s.json" % w] = "bench_%s.json" % w
+for w in ("cfg3", "cfg5"):
+    COPY["%s_counters_per_launch.json" % w] = "%s_counters_per_launch.json" % w
 for a, b in COPY.items():
-    if os.path.exists(os.path.join(S, a)) and os.path.getsize(os.path.join(S, a)) > 0:
-        shutil.copyfile(os.path.join(S, a), os.path.join(D, b))
+    src = os.path.join(S, a)
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copyfile(src, os.path.join(D, "%s_%s" % (TAG, b)))
     else:
         print("missing:", a)
-# TCC traffic of the half-step kernel in the layout bench.py reads (KB per launch)
-c = json.load(open(os.path.join(S, "counters_per_launch.json")))
-old = json.load(open(os.path.join(D, "r02_cfg3_hbm_counters.json")))
-out = {"_note": old["_note"], "fetch": {}, "write": {}, "tcc_hit": {}, "tcc_miss": {}}
-for k, v in c.items():
-    for src, dst in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("TCC_HIT_sum", "tcc_hit"),
-                     ("TCC_MISS_sum", "tcc_miss")):
-        if src in v:
-            out[dst][k] = v[src]
-json.dump(out, open(os.path.join(D, "r02_cfg3_hbm_counters.json"), "w"), indent=1)
-print("k_half_step fetch KB", out["fetch"].get("k_half_step"), "write KB", out["write"].get("k_half_step"))
+# fabric-side traffic of the half-step kernels in the layout bench.py reads (KB per launch)
+for w in ("cfg3", "cfg5"):
+    f = os.path.join(S, "%s_counters_per_launch.json" % w)
+    if not os.path.exists(f):
+        continue
+    c = json.load(open(f))
+    out = {"_note": "rocprofv3 --kernel-trace --pmc, one counter group per pass (scripts/gpu_profile.sh); "
+                    "FETCH_SIZE / WRITE_SIZE in KB per launch as reported: bench.py doubles FETCH_SIZE "
+                    "(gfx950 reports half the bytes of 16-byte-per-lane reads, MI355X_MICROARCH.md)",
+           "fetch": {}, "write": {}, "tcc_hit": {}, "tcc_miss": {}, "launches": {}}
+    for k, v in c.items():
+        for src, dst in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("TCC_HIT_sum", "tcc_hit"),
+                         ("TCC_MISS_sum", "tcc_miss")):
+            if src in v:
+                out[dst][k] = v[src]
+                out["launches"][k] = v.get("launches_" + src)
+    json.dump(out, open(os.path.join(D, "%s_%s_hbm_counters.json" % (TAG, w)), "w"), indent=1)
+    print(w, {k: v for k, v in out["fetch"].items() if "half_step" in k}, {k: v for k, v in out["write"].items() if "half_step" in k})

@@ -30,8 +30,10 @@ st = s.run_mcmc(st, 400, store=False)
 st = s.run_mcmc(st, 32, store=True)  # the launch whose stamps are read: 64 slices
 dev = s._dev
 assert dev._run, getattr(dev, "resident_reason", "resident loop not taken")
-buf = np.zeros((256, 64, 8), dtype=np.int64)
-_lib._chk(_lib._lib.nh_half_step_run_stamps(ctx.h, dev._run, buf.ctypes.data_as(C.c_void_p)))
+raw = np.zeros((256 * 64 * 8 + 64 * 4 * 16,), dtype=np.int64)
+_lib._chk(_lib._lib.nh_half_step_run_stamps(ctx.h, dev._run, raw.ctypes.data_as(C.c_void_p)))
+buf = raw[:256 * 64 * 8].reshape(256, 64, 8)
+wst = raw[256 * 64 * 8:].reshape(64, 4, 16).astype(float) / 100.0
 print(name, nw, "walkers;", dev.resident_info)
 G = min(256, dev.resident_info["grid"])
 t = buf[:G].astype(float) / 100.0  # us
@@ -51,3 +53,9 @@ print("56 slices of a workgroup: median %.1f us = %.2f us per slice; launch star
       % (np.median(tot), np.median(tot) / 56, t[:, 0, 0].max() - t[:, 0, 0].min()))
 wait = d[:, :, 0]
 print("waiting for records: mean %.2f us, fraction of slices > 2 us: %.3f" % (wait.mean(), (wait > 2).mean()))
+
+# workgroup 0: arrival of each wave at the barriers, relative to the slice's start (us), slices 8..40
+t0 = t[0, :, 0]
+for k, nm in enumerate(["barrier 1", "barrier 2", "barrier 3"]):
+    rel = np.array([wst[i, k, :] - t0[i] for i in range(8, 40)])
+    print("workgroup 0, waves reach %s at (median over 32 slices), us: %s" % (nm, " ".join("%5.1f" % v for v in np.median(rel, axis=0))))
