@@ -77,8 +77,9 @@ def measured_traffic(name, symbol):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    f = [v for k, v in d.get("fetch", {}).items() if symbol in k]
-    w = [v for k, v in d.get("write", {}).items() if symbol in k]
+    same = lambda k: symbol in k and ("_run" in k) == ("_run" in symbol)  # noqa: E731
+    f = [v for k, v in d.get("fetch", {}).items() if same(k)]
+    w = [v for k, v in d.get("write", {}).items() if same(k)]
     if not f:
         return None, None
     return (2.0 * max(f) + (max(w) if w else 0.0)) * 1024.0, os.path.basename(files[-1])
@@ -313,7 +314,7 @@ def main():
     sampler.reset()  # (the chain of a region is dropped before the next one)
     times = [first]
     # every region's time is already the max over ranks: all ranks take the same decisions
-    while sum(times) < args.min_time and len(times) < 400:
+    while sum(times) < args.min_time and len(times) < 1000:
         dt_i, state = timed_region(sampler, state)
         times.append(dt_i)
         sampler.reset()
@@ -394,7 +395,9 @@ def main():
         walkers_per_launch = per_gpu * prof_steps / float(prof[dom]["launches"])
     abytes = ALGO[name]["bytes"] * walkers_per_launch
     achieved = abytes / avg_s / 1e9
-    traffic, traffic_src = measured_traffic(name, KERNEL_SYMBOL.get(dom, dom).split("/")[0])
+    dom_symbol = ("k_half_step_run" if resident and dom == "half_step"
+                  else KERNEL_SYMBOL.get(dom, dom).split("/")[0].split(" ")[0])
+    traffic, traffic_src = measured_traffic(name, dom_symbol)
     out = {
         "metric": "walker-steps/sec (ensemble lnprob evals/s)",
         "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
@@ -430,7 +433,8 @@ def main():
                   if keep_blobs else "not kept (--no-blobs)"),
         ("value_without_blobs" if keep_blobs else "value_store_blobs"): blobs_value,
         "roofline": {"bound": "hbm",
-                     "kernel": ("k_half_step_run" if resident and dom == "half_step"
+                     "kernel": ("k_half_step_run (nh_half_step_run: one launch per block of moves)"
+                                if resident and dom == "half_step"
                                 else KERNEL_SYMBOL.get(dom, dom)), "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
@@ -442,9 +446,16 @@ def main():
                      "us_per_half_step": (avg_s * 1e6 / (walkers_per_launch / (per_gpu / 2.0))),
                      "note": "FP64-issue-bound path: the HBM fraction is << 1 % by "
                              "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
+                             "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE) per launch "
+                             "of the profiled driver command (a resident launch = every half-step "
+                             "of a 20-step region: the tables stay in the L2s, what is left is the "
+                             "chain history, the kept blobs and the write-through records)"
+                             if resident else
+                             "FP64-issue-bound path: the HBM fraction is << 1 % by "
+                             "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
                              "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE): every "
                              "launch starts with cold L2s, so each of the 8 XCDs pulls its own "
-                             "copy of the 1.1 MB emission table (Infinity-Cache hits)"},
+                             "copy of the emission table (Infinity-Cache hits)"},
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
         "acceptance_fraction": acc_frac,

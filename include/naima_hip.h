@@ -395,14 +395,23 @@ int nh_stream_join(nh_ctx* ctx);
  *             uf * Eph / E (radiative.py:684-687); seed_theta[s] < 0: isotropic.  T and theta
  *             are lazy scalars: a seed temperature / angle may itself be a fit parameter (a
  *             walker with T <= 0 gets the NaN the reference's arithmetic gives)
+ *   what = 2: We = trapz_loglog(gamma nelec, gamma mec2) over the walker's grid, erg
+ *             (radiative.py:162-195: We, compute_We with per-walker limits); out[w*ldo]
+ * The limits arrive in the unit the caller's Quantity carries, with that unit's value in erg
+ * beside them: the kernel forms gamma_min = (Eemin / mec2[erg]) * unit_erg exactly as the host
+ * path does (what astropy reduces Eemin / mec2 to), so both paths take log10 of the same double.
+ * nEed is a lazy scalar too (nodes per decade per walker).
  * nmax: grid nodes the workgroup's LDS is sized for (4 nmax doubles); a walker that needs more
- * gets NaN and *status (device int, zeroed by the caller) receives the largest count asked for. */
+ * gets NaN and status[0] (device ints, zeroed by the caller) receives the largest count asked
+ * for.  status[1] counts evaluations whose nEed * decades lay within 1e-9 of an integer: there
+ * int() may differ between this log10 and numpy's in the last place -- reported, not silent. */
 int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NPAR]*/, int N,
-                        const nh_lazy* Eemin_eV /*host*/, const nh_lazy* Eemax_eV /*host*/,
-                        double nEed, int what, const nh_lazy* B_G /*host, what = 0*/,
+                        const nh_lazy* Eemin /*host*/, double Eemin_unit_erg,
+                        const nh_lazy* Eemax /*host*/, double Eemax_unit_erg,
+                        const nh_lazy* nEed /*host*/, int what, const nh_lazy* B_G /*host, what = 0*/,
                         const nh_lazy* seed_T_K /*host*/, const nh_lazy* seed_theta /*host*/,
                         int nseed, const double* E_eV, int nE, double* out, int ldo, int nmax,
-                        int* status /*device*/);
+                        int* status /*device, 2 ints*/);
 
 /* ---- ONE launch per half-step ---------------------------------------------------------
  * nh_step_front + every table reduction of the model + its synchrotron component +

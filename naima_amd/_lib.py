@@ -117,8 +117,8 @@ _SIGS = {
     "nh_half_step_run_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_run_stamps": [_dp, _dp, _dp],
     "nh_half_step_run_destroy": [_dp, _dp],
-    "nh_general_electron": [_dp, _i, _dp, _i, _dp, _dp, _d, _i, _dp, _dp, _dp, _i, _dp, _i, _dp, _i, _i,
-                            _dp],
+    "nh_general_electron": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _i, _dp, _dp, _dp, _i, _dp, _i,
+                            _dp, _i, _i, _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _dp, _i, _i, _dp],
     "nh_hist_append": [_dp, _dp, _dp, _ll, _i, _dp, _ll],
     "nh_set_words": [_dp, _dp, _dp, _i],
@@ -452,20 +452,32 @@ class Context:
     general_nmax = 2048  # grid nodes a workgroup's LDS is sized for (4 doubles each)
 
     def general_status(self):
-        """device int the general kernel raises when a walker's grid exceeds general_nmax"""
+        """device ints of the general kernel: [0] the largest node count asked for when a walker's
+        grid exceeds general_nmax, [1] evaluations whose node count sat on an int() boundary"""
         if getattr(self, "_gen_status", None) is None:
-            self._gen_status = self.array(np.zeros(1, dtype=np.int32), dtype=np.int32)
+            self._gen_status = self.array(np.zeros(2, dtype=np.int32), dtype=np.int32)
         return self._gen_status
+
+    general_boundary_hits = 0  # evaluations of the general kernel that sat on an int() boundary
 
     def check_general(self):
         """raise if a general-path launch since the last check met a grid longer than
-        general_nmax (those walkers were given NaN)"""
+        general_nmax (those walkers were given NaN); warn if a walker's node count
+        int(nEed * decades) was decided within rounding of an integer (the device's log10 and
+        numpy's may then disagree on it in the last place)"""
         st = getattr(self, "_gen_status", None)
         if st is None or self.capturing:
             return
-        n = int(st.get()[0])
+        n, amb = (int(v) for v in st.get())
+        if n or amb:
+            st.set(np.zeros(2, dtype=np.int32))
+        if amb:
+            import warnings
+            self.general_boundary_hits += amb
+            warnings.warn("%d evaluation(s) of a per-walker particle grid had nEed * decades within "
+                          "1e-9 of an integer: int() of it (radiative.py:152-154) may differ between "
+                          "the device's log10 and numpy's there" % amb, RuntimeWarning)
         if n > self.general_nmax:
-            st.set(np.zeros(1, dtype=np.int32))
             raise NaimaHipError("a walker's particle grid has %d nodes, more than the %d the "
                                 "general kernel's LDS is sized for: raise Context.general_nmax "
                                 "(at most ~4600) or lower nEed" % (n, self.general_nmax))

@@ -20,14 +20,16 @@
 struct gen_args {
   int kind, N, what, nseed;
   const double* rows;   // [N][NH_PD_NPAR] particle-distribution rows
-  nh_lazy emin, emax;   // per walker, eV
-  double nEed;
+  nh_lazy emin, emax;   // per walker, in the unit the caller's Quantity carries ...
+  double emin_erg, emax_erg;  // ... and that unit in erg (astropy's own factor)
+  nh_lazy nEed;         // nodes per decade, per walker
   nh_lazy B;            // synchrotron: magnetic field [G]
   nh_lazy T[NH_MAX_COMP], theta[NH_MAX_COMP];  // IC: seed temperatures [K], angles [rad] (< 0: isotropic)
   const double* E_eV; int nE;
   double* out; int ldo;  // out[w*ldo + c*nE + k]
   int nmax;              // LDS capacity in nodes
-  int* status;           // [1]: set to the largest node count asked for when it exceeds nmax
+  int* status;           // [0]: the largest node count asked for when it exceeds nmax;
+                         // [1]: evaluations whose node count sat on an int() boundary
 };
 
 __device__ __forceinline__ double gen_wave_sum(double v) {
@@ -57,12 +59,19 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
   __shared__ double s_l0, s_step, s_l1;
   const int wi = blockIdx.x, comp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
   if (tid == 0) {
-    // radiative.py:147-154 (the limits in units of mec2; int() truncates)
-    const double gmin = nh_lazy_eval(A.emin, wi) / NH_MEC2_EV;
-    const double gmax = nh_lazy_eval(A.emax, wi) / NH_MEC2_EV;
+    // radiative.py:147-154 (the limits in units of mec2; int() truncates).  The reference's
+    // expression, operation for operation: (value / mec2[erg]) * (the unit in erg) -- what
+    // astropy reduces Eemin / mec2 to -- so that the limits are the host path's bit for bit.
+    const double gmin = (nh_lazy_eval(A.emin, wi) / NH_MEC2_ERG_) * A.emin_erg;
+    const double gmax = (nh_lazy_eval(A.emax, wi) / NH_MEC2_ERG_) * A.emax_erg;
     const double l0 = log10(gmin), l1 = log10(gmax);
-    int n = (int)(A.nEed * (l1 - l0));
+    const double v = nh_lazy_eval(A.nEed, wi) * (l1 - l0);
+    int n = (int)v;
     if (!(n >= 10)) n = 10;  // (also NaN limits)
+    // int() of a float: numpy's log10 and this one may differ in the last place, which decides
+    // the count only when v sits within rounding (~1e-13) of an integer.  Such evaluations are
+    // counted -- the caller is told (Context.check_general) -- never silently different.
+    if (v >= 10.0 && fabs(v - rint(v)) < 1e-9) atomicAdd(A.status + 1, 1);
     if (n > A.nmax) {
       atomicMax(A.status, n);
       n = 0;
@@ -102,6 +111,20 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
   const int nseg = n - 1;
   const int per = (nseg + 3) / 4;
   const int s0 = wvi * per, s1 = min(nseg, s0 + per);
+  if (A.what == 2) {
+    // ---- We = trapz_loglog(gamma nelec, gamma mec2) over the walker's own grid, erg --------
+    // (radiative.py:162-195: u = x y = (gamma mec2)(gamma nelec); ln(K2/K1) = ln(g2/g1))
+    double acc = 0.0;
+    for (int sg = tid; sg < nseg; sg += blockDim.x) {
+      const double u1 = wv[sg] * (gam[sg] * NH_MEC2_ERG_), u2 = wv[sg + 1] * (gam[sg + 1] * NH_MEC2_ERG_);
+      acc += (u1 == 0.0 || u2 == 0.0) ? 0.0 : nh_seg_term<true>(u1, u2, dw[sg] + lxs[sg], lxs[sg]);
+    }
+    acc = gen_wave_sum(acc);
+    if (lane == 0) part[wvi] = acc;
+    __syncthreads();
+    if (tid == 0) orow[0] = (part[0] + part[1]) + (part[2] + part[3]);
+    return;
+  }
   if (A.what == 0) {
     // ---- Synchrotron._spectrum -------------------------------------------------------
     const double Bw = nh_lazy_eval(A.B, wi);
@@ -162,22 +185,29 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
 }
 
 extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int N,
-                                   const nh_lazy* Eemin_eV, const nh_lazy* Eemax_eV, double nEed,
-                                   int what, const nh_lazy* B_G, const nh_lazy* seed_T,
-                                   const nh_lazy* seed_theta, int nseed, const double* E_eV, int nE,
-                                   double* out, int ldo, int nmax, int* status) {
-  NH_REQUIRE(c && rows && Eemin_eV && Eemax_eV && E_eV && out && status, "NULL pointer");
+                                   const nh_lazy* Eemin, double Eemin_unit_erg,
+                                   const nh_lazy* Eemax, double Eemax_unit_erg,
+                                   const nh_lazy* nEed, int what, const nh_lazy* B_G,
+                                   const nh_lazy* seed_T, const nh_lazy* seed_theta, int nseed,
+                                   const double* E_eV, int nE, double* out, int ldo, int nmax,
+                                   int* status) {
+  NH_REQUIRE(c && rows && Eemin && Eemax && nEed && out && status, "NULL pointer");
   NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
-  NH_REQUIRE(N >= 0 && nE >= 1 && nEed > 0 && nmax >= 10, "bad sizes");
-  NH_REQUIRE(what == 0 ? (B_G != nullptr) : (what == 1 && seed_T && seed_theta && nseed >= 1 &&
-                                             nseed <= NH_MAX_COMP), "bad component");
-  const int ncomp = what == 0 ? 1 : nseed;
+  NH_REQUIRE(N >= 0 && nmax >= 10 && Eemin_unit_erg > 0 && Eemax_unit_erg > 0, "bad sizes");
+  NH_REQUIRE(what == 2 || (E_eV && nE >= 1), "photon energies missing");
+  NH_REQUIRE(nEed->base || nEed->a > 0.0, "nEed must be positive");
+  NH_REQUIRE(what == 0 ? (B_G != nullptr)
+                       : (what == 2 || (what == 1 && seed_T && seed_theta && nseed >= 1 &&
+                                        nseed <= NH_MAX_COMP)), "bad component");
+  if (what == 2) nE = 1;
+  const int ncomp = what == 1 ? nseed : 1;
   NH_REQUIRE(ldo >= ncomp * nE, "ldo too small");
   if (N == 0) return NH_OK;
   gen_args A;
   memset(&A, 0, sizeof(A));
   A.kind = kind; A.N = N; A.what = what; A.nseed = ncomp; A.rows = rows;
-  A.emin = *Eemin_eV; A.emax = *Eemax_eV; A.nEed = nEed;
+  A.emin = *Eemin; A.emax = *Eemax; A.nEed = *nEed;
+  A.emin_erg = Eemin_unit_erg; A.emax_erg = Eemax_unit_erg;
   if (what == 0) A.B = *B_G;
   for (int s = 0; s < ncomp && what == 1; ++s) {
     NH_REQUIRE(seed_T[s].base || seed_T[s].a > 0.0, "seed temperature must be positive");
@@ -191,6 +221,7 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
     NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_general_electron,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   nh_prof_scope ps(c, what == 0 ? NH_K_SYNCHROTRON : NH_K_INTEGRATE);
+  // (what == 2 reads no photon energies: any valid pointer)
   hipLaunchKernelGGL(k_general_electron, dim3((unsigned)N, (unsigned)ncomp), dim3(256), lds,
                      c->stream, A);
   NH_CHECK_HIP(hipGetLastError());

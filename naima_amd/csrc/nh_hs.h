@@ -164,8 +164,7 @@ __device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byt
 // this workgroup's walker, whose w / dlw / lx live in LDS (wave-uniform reads).  The table
 // is the interleaved copy KD[i][k] = {K, dlnK}: ONE 16-byte load per lane and node instead of
 // two 8-byte ones (8-byte accesses reach 0.54-0.70 of the L2 rate of 16-byte ones; with one
-// walker per workgroup the rows stream from L2 once per walker and that rate is the bound:
-// 23 us of table items became XX).  Eight nodes per trip = eight kilobytes in flight per
+// walker per workgroup the rows stream from L2 once per walker).  Eight nodes per trip = eight kilobytes in flight per
 // wave (a double-buffered four-node version, half of that in flight, measured 25 % slower).
 typedef __attribute__((address_space(3))) const double hs_lds_cd;
 // LDS byte address of a pointer into the workgroup's shared block, parked in a VECTOR register:

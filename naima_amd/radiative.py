@@ -404,12 +404,10 @@ class BaseElectron(BaseRadiative):
 
     # -- the general path on the device: Eemin / Eemax per walker -----------------------
     def _general_limits(self):
-        """True when Eemin or Eemax is given per walker (host vector or device value) and
-        nEed is not: every walker then has its own grid (limits AND node count,
-        radiative.py:147-154) and the spectrum comes from nh_general_electron"""
-        if _per_walker(self.nEed):
-            return False
-        return _per_walker(self.Eemin) or _per_walker(self.Eemax)
+        """True when Eemin, Eemax or nEed is given per walker (host vector or device value):
+        every walker then has its own grid (limits AND node count, radiative.py:147-154) and
+        the spectrum comes from nh_general_electron"""
+        return _per_walker(self.Eemin) or _per_walker(self.Eemax) or _per_walker(self.nEed)
 
     def _general_supported(self):
         return False
@@ -418,7 +416,7 @@ class BaseElectron(BaseRadiative):
         """True when the spectrum has to come from nh_general_electron (no table to share)"""
         return self._general_limits()
 
-    _general_names = ("Eemin", "Eemax")
+    _general_names = ("Eemin", "Eemax", "nEed")
 
     def _needs_walker_loop(self):
         if self._general_needed() and self._general_supported():
@@ -430,8 +428,9 @@ class BaseElectron(BaseRadiative):
             return False
         return super()._needs_walker_loop()
 
-    def _general_launch(self, what, E_eV, B=None, seeds=()):
-        """spectra [N][ncomp * nE] of nh_general_electron (device buffer)"""
+    def _general_launch(self, what, E_eV, B=None, seeds=(), Eemin=None, Eemax=None):
+        """spectra [N][ncomp * nE] of nh_general_electron (device buffer); what = 2: We over
+        each walker's grid between Eemin and Eemax (default: the object's own limits), [N][1]"""
         import ctypes as C
 
         from .darray import lazy_const
@@ -451,11 +450,23 @@ class BaseElectron(BaseRadiative):
                 return d.lazy(), d
             return lazy_const(float(v)), None
 
-        emin, k1 = lazy_of(self.Eemin, "eV")
-        emax, k2 = lazy_of(self.Eemax, "eV")
+        # the limits travel in their own unit, with that unit in erg beside them: the kernel forms
+        # (value / mec2[erg]) * unit_erg exactly as _gam_between does
+        qmin = self.Eemin if Eemin is None else Eemin
+        qmax = self.Eemax if Eemax is None else Eemax
+        emin, k1 = lazy_of(qmin, qmin.unit)
+        emax, k2 = lazy_of(qmax, qmax.unit)
+        nv = self.nEed.value if isinstance(self.nEed, u.Quantity) else self.nEed
+        if isinstance(nv, DVec):
+            ned, k4 = nv.lazy(), nv
+        elif np.ndim(nv) > 0:
+            k4 = _as_dvec(ctx, np.asarray(nv, dtype=float), N)
+            ned = k4.lazy()
+        else:
+            ned, k4 = lazy_const(float(nv)), None
         rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
-        nE = E_eV.size
-        ncomp = 1 if what == 0 else len(seeds)
+        nE = 1 if what == 2 else E_eV.size
+        ncomp = len(seeds) if what == 1 else 1
         out = ctx.empty((N, ncomp * nE))
         status = ctx.general_status()
         Bl, k3 = (lazy_of(B, "G") if what == 0 else (None, None))
@@ -472,10 +483,11 @@ class BaseElectron(BaseRadiative):
                 th[j], k = lazy_of(thq, "rad")
                 keep.append(k)
         ctx.call("nh_general_electron", PD_KIND[pd.kind], rows, N, C.addressof(emin),
-                 C.addressof(emax), float(self.nEed), what,
-                 C.addressof(Bl) if Bl is not None else None, T, th, ncomp, ctx.const(E_eV), nE,
-                 out, ncomp * nE, ctx.general_nmax, status)
-        del k1, k2, k3, rows, keep
+                 float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
+                 C.addressof(ned), what, C.addressof(Bl) if Bl is not None else None, T, th, ncomp,
+                 ctx.const(E_eV) if what != 2 else None, nE, out, ncomp * nE, ctx.general_nmax,
+                 status)
+        del k1, k2, k3, k4, rows, keep
         if not self.on_device:
             ctx.check_general()
         return ctx, N, out
@@ -515,10 +527,33 @@ class BaseElectron(BaseRadiative):
         We = out.get()[:, 0]
         return u.Quantity(We if self.is_batched else We[0], u.erg)
 
+    def _We_general(self, Eemin=None, Eemax=None):
+        """We over every walker's own grid (limits / nEed per walker) by nh_general_electron"""
+        ctx, N, out = self._general_launch(2, None, Eemin=Eemin, Eemax=Eemax)
+        if self.on_device:
+            return u.Quantity(DVec(ctx, out, out.ptr, N), u.erg)
+        We = out.get()[:, 0]
+        return u.Quantity(We if self.is_batched else We[0], u.erg)
+
+    def _We_per_walker(self, Eemin=None, Eemax=None):
+        """True when We has to be integrated over a grid per walker and the device can do it"""
+        per = self._general_limits() or any(q is not None and _per_walker(q) for q in (Eemin, Eemax))
+        if not per or not hasattr(self.particle_distribution, "device_rows"):
+            return False
+        for q in (Eemin, Eemax):  # (a per-walker argument has to match the object's own batch)
+            v = q.value if isinstance(q, u.Quantity) else q
+            if q is not None and np.ndim(v) > 0 and not (self.is_batched and len(v) == self.batch_size):
+                return False
+        others = [(n, v) for n, v in self._structural_values()
+                  if n not in self._general_names and not n.endswith(("-T", "-theta", "-u"))]
+        return not any(_per_walker(v) for n, v in others)
+
     @property
     def We(self):
         """Total energy in electrons used for the radiative calculation"""
-        if BaseRadiative._needs_walker_loop(self):  # (per-walker limits: one walker at a time)
+        if self._We_per_walker():
+            return self._We_general()
+        if BaseRadiative._needs_walker_loop(self):  # (other per-walker structure: one at a time)
             return self._loop_walkers("We")
         return self._We_on(self._gam)
 
@@ -526,6 +561,12 @@ class BaseElectron(BaseRadiative):
         """Total energy in electrons between Eemin and Eemax (radiative.py:168-195)"""
         if Eemin is None and Eemax is None:
             return self.We
+        if self._We_per_walker(Eemin, Eemax):
+            lo = self.Eemin if Eemin is None else validate_scalar_or_batch(
+                "Eemin", Eemin, physical_type="energy")
+            hi = self.Eemax if Eemax is None else validate_scalar_or_batch(
+                "Eemax", Eemax, physical_type="energy")
+            return self._We_general(lo, hi)
         if BaseRadiative._needs_walker_loop(self):
             return self._loop_walkers("compute_We", Eemin=Eemin, Eemax=Eemax)
         if Eemax is None:
