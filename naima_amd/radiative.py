@@ -535,45 +535,40 @@ class BaseElectron(BaseRadiative):
         We = out.get()[:, 0]
         return u.Quantity(We if self.is_batched else We[0], u.erg)
 
-    def _We_per_walker(self, Eemin=None, Eemax=None):
-        """True when We has to be integrated over a grid per walker and the device can do it"""
-        per = self._general_limits() or any(q is not None and _per_walker(q) for q in (Eemin, Eemax))
-        if not per or not hasattr(self.particle_distribution, "device_rows"):
+    def _We_general_ok(self, lo, hi):
+        """the device can integrate We over a grid per walker (limits lo, hi, self.nEed)"""
+        if not hasattr(self.particle_distribution, "device_rows"):
             return False
-        for q in (Eemin, Eemax):  # (a per-walker argument has to match the object's own batch)
+        for q in (lo, hi, self.nEed):  # (a per-walker value has to match the object's own batch)
             v = q.value if isinstance(q, u.Quantity) else q
-            if q is not None and np.ndim(v) > 0 and not (self.is_batched and len(v) == self.batch_size):
+            if not isinstance(v, DVec) and np.ndim(v) > 0 and \
+                    not (self.is_batched and len(v) == self.batch_size):
                 return False
-        others = [(n, v) for n, v in self._structural_values()
-                  if n not in self._general_names and not n.endswith(("-T", "-theta", "-u"))]
-        return not any(_per_walker(v) for n, v in others)
+        return True
+
+    def _We_between(self, lo, hi, what, **kw):
+        if _per_walker(lo) or _per_walker(hi) or _per_walker(self.nEed):
+            if self._We_general_ok(lo, hi):
+                return self._We_general(lo, hi)
+            return self._loop_walkers(what, **kw)  # (one walker at a time: host values only)
+        return self._We_on(self._gam_between(_scalar_energy("Eemin", lo),
+                                             _scalar_energy("Eemax", hi), self.nEed))
 
     @property
     def We(self):
         """Total energy in electrons used for the radiative calculation"""
-        if self._We_per_walker():
-            return self._We_general()
-        if BaseRadiative._needs_walker_loop(self):  # (other per-walker structure: one at a time)
-            return self._loop_walkers("We")
-        return self._We_on(self._gam)
+        return self._We_between(self.Eemin, self.Eemax, "We")
 
     def compute_We(self, Eemin=None, Eemax=None):
-        """Total energy in electrons between Eemin and Eemax (radiative.py:168-195)"""
+        """Total energy in electrons between Eemin and Eemax (radiative.py:168-195).  The grid
+        follows the limits in force: per walker only where THEY are (radiative.py:147-154)"""
         if Eemin is None and Eemax is None:
             return self.We
-        if self._We_per_walker(Eemin, Eemax):
-            lo = self.Eemin if Eemin is None else validate_scalar_or_batch(
-                "Eemin", Eemin, physical_type="energy")
-            hi = self.Eemax if Eemax is None else validate_scalar_or_batch(
-                "Eemax", Eemax, physical_type="energy")
-            return self._We_general(lo, hi)
-        if BaseRadiative._needs_walker_loop(self):
-            return self._loop_walkers("compute_We", Eemin=Eemin, Eemax=Eemax)
-        if Eemax is None:
-            Eemax = self.Eemax
-        if Eemin is None:
-            Eemin = self.Eemin
-        return self._We_on(self._gam_between(Eemin, Eemax, self.nEed))
+        lo = self.Eemin if Eemin is None else validate_scalar_or_batch(
+            "Eemin", Eemin, physical_type="energy")
+        hi = self.Eemax if Eemax is None else validate_scalar_or_batch(
+            "Eemax", Eemax, physical_type="energy")
+        return self._We_between(lo, hi, "compute_We", Eemin=Eemin, Eemax=Eemax)
 
     def set_We(self, We, Eemin=None, Eemax=None, amplitude_name=None):
         """Normalize the particle distribution so that the electron energy between
