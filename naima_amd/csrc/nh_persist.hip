@@ -56,6 +56,11 @@ struct hs_run {
   double* hblob[NH_HS_MAX_BLOB];   // ... and the blobs' (or NULL)
   long long hrow0, hcap;     // history row of the launch's first step; rows the history holds
   long long* dbg;            // NH_HS_DEBUG: [256][64][8] wall-clock stamps, or NULL
+  // gridDim.y = K > 1 workgroups share a walker (a half-step of fewer walkers than CUs, as in
+  // k_half_step): partial spectra of slice s at xspec[s][walker][K][nspec], arrival tickets at
+  // tick[s][walker] (zeroed before the launch) -- per slice, because nothing stops one of a
+  // walker's workgroups from running slices ahead of another
+  double* xspec; int* tick;
   int slice0, nslices;       // slices [slice0, slice0 + nslices) of the block of moves; slice0 even
   unsigned seq;              // launch sequence number (tags)
   int gr, N;                 // granules per record (a multiple of 16: one record = whole lines)
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
   const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6), nwv = T >> 6;
   int tid = tid0, lane = tid0 & 63;
   const int ns = H.ns, ndim = H.ndim, N = R.N;
+  const int K = gridDim.y, part = blockIdx.y;
   const bool has_syn = SYN && H.syn_grid >= 0;
   const bool broken = H.F.broken != 0;
   const int GRn = 2 * (ndim + 1);  // granules of a record that carry data (<= 32)
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
   // by the host: the kernel boundary has made it visible).  Walker w by workgroup w mod grid.
   if (wv == 0) {
     const unsigned tag0 = hs_tag(R.seq, 0);
-    for (int w = blockIdx.x; w < N; w += gridDim.x) {
+    for (int w = blockIdx.y * gridDim.x + blockIdx.x; w < N; w += gridDim.x * gridDim.y) {
       if (lane < GRn) {
         const int d = lane >> 1;
         const double v = d < ndim ? H.coords[(long long)w * ndim + d] : H.logp[w];
@@ -374,6 +380,11 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       __syncthreads();  // ---------------------------------------------------------------- #1
       HSR_STAMP(2);
       if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
+      if (K > 1) {  // the work items of the walker's other workgroups: their slots count as 0
+        for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
+        if (has_syn)
+          for (int t = tid; t < D.syn_cdmax * H.syn_nE; t += T) sm[H.o_part_s + t] = 0.0;
+      }
       // ---- B. priors (core.py:34-58, 99-101): a proposal the prior forbids is never accepted,
       // so none of its integrals is evaluated (the reference evaluates and discards,
       // core.py:103-119)
@@ -588,6 +599,11 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           int item = 0;
           if (lane == 0) item = atomicAdd(&hi[HI_CNT], 1);
           item = __builtin_amdgcn_readfirstlane(item);
+          if (K > 1) {  // this workgroup's share: one of every K items, rotating
+            if (item * K >= total) break;
+            item = item * K + ((part + item) & (K - 1));
+            if (item >= total) continue;
+          }
           if (item >= total) break;
           bool is_tab;
           int ix;
@@ -683,6 +699,33 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         }
       }
       __syncthreads();  // ---------------------------------------------------------------- #4
+      if (K > 1) {
+        // the K workgroups of this walker meet: partial spectra out (write-through), one ticket
+        // each; whoever draws the last one sums all K partials in the order of their index (the
+        // result does not depend on who arrived when) and carries on; the others go to their
+        // next slice.  (sc1 stores, drained, before the ticket; sc1 loads behind it.)
+        const long long cell = (long long)s * H.nloc + j;
+        unsigned long long* xs = reinterpret_cast<unsigned long long*>(R.xspec) +
+                                 (cell * K + part) * D.nspec;
+        for (int k = tid; k < D.nspec; k += T)
+          hs_st_sc1(xs + k, (unsigned long long)__double_as_longlong(spec[k]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+          hi[HI_LIVE] = __hip_atomic_fetch_add(R.tick + cell, 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (hi[HI_LIVE] != K - 1) continue;  // (the whole workgroup; HI_LIVE is free by now)
+        const unsigned long long* xa = reinterpret_cast<const unsigned long long*>(R.xspec) +
+                                       cell * K * D.nspec;
+        for (int k = tid; k < D.nspec; k += T) {
+          double sum = 0.0;
+          for (int q = 0; q < K; ++q)
+            sum += __longlong_as_double((long long)hs_ld_sc1(xa + (long long)q * D.nspec + k));
+          spec[k] = sum;
+        }
+        __syncthreads();
+      }
       HSR_STAMP(6);
       // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
       // wave 0 is already polling for the next slice and the others wait at its first barrier ----
@@ -852,6 +895,9 @@ struct nh_halfstep_run {
   int* status;
   int* accw;
   long long* dbg;
+  double* xspec;
+  int* tick;
+  int split;
   size_t lds_bytes;
   int grid, threads;
   unsigned seq;
@@ -860,7 +906,7 @@ struct nh_halfstep_run {
 extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run** out) {
   NH_REQUIRE(c && P && out, "bad argument");
   const hs_hot& H = P->hot;
-  NH_REQUIRE(H.C.do_accept && P->split == 1, "the resident loop needs the in-launch accept and one workgroup per walker");
+  NH_REQUIRE(H.C.do_accept, "the resident loop needs the in-launch accept");
   NH_REQUIRE(H.ndim <= 15, "at most 15 fit parameters in a record (32 granules per wave half)");
   NH_REQUIRE(H.lo == 0 && H.nloc == H.ns, "the resident loop moves whole half-ensembles");
   NH_REQUIRE(H.C.lp == nullptr, "a prior evaluated by a launch of its own cannot ride in the resident loop");
@@ -903,7 +949,7 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   // per slice, one after the other -- and the resident layout's extra LDS (grid nodes, ln E, E)
   // halves the workgroups a CU holds: cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s
   // resident (two 256-thread workgroups per CU) against 24.2 M launched per half-step (four).
-  NH_REQUIRE(H.nloc <= cap, "more walkers per half-step than resident workgroups");
+  NH_REQUIRE((long long)H.nloc * P->split <= cap, "more walkers per half-step than resident workgroups");
   nh_halfstep_run* Q = new nh_halfstep_run();
   Q->R = R;
   Q->lds_bytes = lds;
@@ -911,6 +957,7 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   Q->grid = (int)(H.nloc < cap ? H.nloc : cap);
   Q->seq = 1;
   Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
+  Q->xspec = nullptr; Q->tick = nullptr; Q->split = P->split;
   const size_t ring_bytes = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr * sizeof(unsigned long long);
   hipError_t e = hipMalloc(&Q->ring, ring_bytes);
   if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
@@ -918,6 +965,10 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   if (e == hipSuccess) e = hipMemset(Q->status, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
   if (e == hipSuccess) e = hipMemset(Q->accw, 0, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
+  if (e == hipSuccess && P->split > 1) {
+    e = hipMalloc(&Q->xspec, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * P->split * H.C.nspec * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&Q->tick, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * sizeof(int));
+  }
   if (e == hipSuccess)
     if (const char* dv = getenv("NH_HS_DEBUG"))
       if (atoi(dv) != 0) {
@@ -929,10 +980,13 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
     if (Q->status) (void)hipFree(Q->status);
     if (Q->accw) (void)hipFree(Q->accw);
     if (Q->dbg) (void)hipFree(Q->dbg);
+    if (Q->xspec) (void)hipFree(Q->xspec);
+    if (Q->tick) (void)hipFree(Q->tick);
     delete Q;
     return nh_set_error(NH_EHIP, "resident half-step loop: %s", hipGetErrorString(e));
   }
   Q->R.ring = Q->ring; Q->R.status = Q->status; Q->R.accw = Q->accw; Q->R.dbg = Q->dbg;
+  Q->R.xspec = Q->xspec; Q->R.tick = Q->tick;
   Q->R.spin_limit = 1 << 22;  // ~1 s of polling: a record that has not come by then never will
   if (const char* sl = getenv("NH_RUN_SPIN_LIMIT")) Q->R.spin_limit = atoi(sl) > 0 ? atoi(sl) : Q->R.spin_limit;
   *out = Q;
@@ -960,13 +1014,16 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.hcap = hist_cap;
   for (int b = 0; b < NH_HS_MAX_BLOB; ++b)
     R.hblob[b] = (hist_coords && hist_blobs && b < H.C.nblob) ? hist_blobs[b] : nullptr;
+  if (Q->tick)  // (the arrival tickets of this launch's slices)
+    NH_CHECK_HIP(hipMemsetAsync(Q->tick, 0, (size_t)nslices * H.nloc * sizeof(int), c->stream));
   {
     nh_prof_scope ps(c, NH_K_HALFSTEP);
+    const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
     if (H.syn_grid >= 0)
-      hipLaunchKernelGGL(k_half_step_run<true>, dim3(Q->grid), dim3(Q->threads), Q->lds_bytes,
+      hipLaunchKernelGGL(k_half_step_run<true>, grid, dim3(Q->threads), Q->lds_bytes,
                          c->stream, H, R);
     else
-      hipLaunchKernelGGL(k_half_step_run<false>, dim3(Q->grid), dim3(Q->threads), Q->lds_bytes,
+      hipLaunchKernelGGL(k_half_step_run<false>, grid, dim3(Q->threads), Q->lds_bytes,
                          c->stream, H, R);
     NH_CHECK_HIP(hipGetLastError());
   }
@@ -1021,6 +1078,8 @@ extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
   if (Q->status) (void)hipFree(Q->status);
   if (Q->accw) (void)hipFree(Q->accw);
   if (Q->dbg) (void)hipFree(Q->dbg);
+  if (Q->xspec) (void)hipFree(Q->xspec);
+  if (Q->tick) (void)hipFree(Q->tick);
   delete Q;
   return rc;
 }

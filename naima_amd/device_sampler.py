@@ -728,12 +728,12 @@ class DeviceLoop:
     # ------------------------------------------------------------- resident loop
     def _resident_ok(self):
         """can the rest of a block of moves run as ONE launch (nh_half_step_run)?  Needs the
-        one-launch plan, a single rank, one workgroup per walker, blobs (if kept) kept by the
-        launch; the library has the last word (LDS, occupancy, the plan's shape)"""
+        one-launch plan, a single rank, blobs (if kept) kept by the launch; the library has
+        the last word (LDS, occupancy, the plan's shape)"""
         if self._run is False or not self.mega or self.sharded or not self.s.use_graph:
             return False
         hs = self._plan["hs"] if self._plan else None
-        if hs is None or hs["split"] != 1:
+        if hs is None:
             return False
         if self.s.store_blobs and self.cur_blobs and not self.blobs_in_kernel:
             return False

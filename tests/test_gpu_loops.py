@@ -471,8 +471,10 @@ def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkey
 
 
 @pytest.mark.parametrize("name,nw,mkw", [("cfg3", 512, {}), ("cfg5", 256, {}), ("cfg1", 32, {}),
-                                         ("cfg5", 256, {"useLUT": False})],
-                         ids=["cfg3-512", "cfg5-256", "cfg1-32", "cfg5-analytic-256"])
+                                         ("cfg5", 256, {"useLUT": False}), ("cfg2", 256, {}),
+                                         ("cfg3", 256, {}), ("cfg3", 48, {})],
+                         ids=["cfg3-512", "cfg5-256", "cfg1-32", "cfg5-analytic-256", "cfg2-256-two-per-walker",
+                              "cfg3-256-two-per-walker", "cfg3-48-eight-per-walker"])
 def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
     """nh_half_step_run -- a whole block of moves in ONE launch, walkers handed from half-step
     to half-step through per-walker records (write-through granules with tags) instead of
