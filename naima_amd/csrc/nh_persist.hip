@@ -164,9 +164,11 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
     const int nG = H.nG[g];
     for (int i = tid; i < nG; i += T) {
       sm[H.o_lx[g] + i] = i + 1 < nG ? H.lx[g][i] : 0.0;
-      sm[R.o_gx[g] + i] = H.xg[g][i];
-      sm[R.o_lne[g] + i] = H.lne[g][i];
-      if (broken) sm[R.o_ge[g] + i] = H.e[g][i];
+      if (R.o_gx[0] >= 0) {  // (small workgroups leave the nodes in L2: LDS decides how many fit a CU)
+        sm[R.o_gx[g] + i] = H.xg[g][i];
+        sm[R.o_lne[g] + i] = H.lne[g][i];
+        if (broken) sm[R.o_ge[g] + i] = H.e[g][i];
+      }
     }
   }
   {
@@ -479,11 +481,12 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           if (onq[q]) {
             const bool last = i + 1 >= nG;
             lrq[q] = sm[H.o_lx[g] + i];  // (0 at the last node)
-            lneq[q] = sm[R.o_lne[g] + i];
-            gxq[q] = sm[R.o_gx[g] + i];
+            const bool in_lds = R.o_gx[0] >= 0;  // (wave-uniform)
+            lneq[q] = in_lds ? sm[R.o_lne[g] + i] : H.lne[g][i];
+            gxq[q] = in_lds ? sm[R.o_gx[g] + i] : H.xg[g][i];
             if (broken) {
-              const double E = sm[R.o_ge[g] + i];
-              const double E2 = last ? E : sm[R.o_ge[g] + i + 1];
+              const double E = in_lds ? sm[R.o_ge[g] + i] : H.e[g][i];
+              const double E2 = last ? E : (in_lds ? sm[R.o_ge[g] + i + 1] : H.e[g][i + 1]);
               bq[q] = (E < p.eb ? 1 : 0) | (E2 < p.eb ? 2 : 0);
             }
           }
@@ -918,7 +921,13 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   R.gr = ((2 * (H.ndim + 1) + 15) / 16) * 16;
   // LDS: the plan's layout, then what stays resident on top of it
   int off = (int)(P->lds_bytes / sizeof(double));
-  for (int g = 0; g < H.ngrids; ++g) {
+  // Workgroups of 1024 threads own their CU: the grids' nodes, ln E (and E where the particle
+  // distribution has a break) stay in LDS for the whole launch.  Smaller workgroups (a half-step
+  // of more walkers than CUs, k_half_step item 14) share a CU, and LDS decides how many fit:
+  // they read the nodes from L2 every slice, as k_half_step does, while a neighbour computes.
+  const bool grids_in_lds = P->threads >= 1024 && nh_env_int("NH_RUN_GRIDS_IN_LDS", 1) != 0;
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) R.o_gx[g] = R.o_lne[g] = R.o_ge[g] = -1;
+  for (int g = 0; g < H.ngrids && grids_in_lds; ++g) {
     R.o_gx[g] = off; off += H.nG[g];
     R.o_lne[g] = off; off += H.nG[g];
     R.o_ge[g] = off;
@@ -946,9 +955,8 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   long long cap = (long long)per_cu * ncu;
   if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
   // More walkers per half-step than resident workgroups: a workgroup would take several walkers
-  // per slice, one after the other -- and the resident layout's extra LDS (grid nodes, ln E, E)
-  // halves the workgroups a CU holds: cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s
-  // resident (two 256-thread workgroups per CU) against 24.2 M launched per half-step (four).
+  // per slice, one after the other (cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s
+  // that way, two 256-thread workgroups per CU, against 24.2 M launched per half-step, four).
   NH_REQUIRE((long long)H.nloc * P->split <= cap, "more walkers per half-step than resident workgroups");
   nh_halfstep_run* Q = new nh_halfstep_run();
   Q->R = R;
