@@ -565,3 +565,30 @@ def test_nan_log_probability_is_emcees_error(na):
         st = d.run_mcmc(pos, 2)
         st = d.run_mcmc(st, 68)
         st.coords
+
+
+def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
+    """every wait of the resident loop is bounded: with a poll limit of ONE (NH_RUN_SPIN_LIMIT=1)
+    the first walker whose record is not there yet makes its workgroup latch an error and leave,
+    every other workgroup follows, the launch ends, and the sampler raises when the results
+    reach the host -- the device is not left spinning"""
+    from naima_amd._lib import NaimaHipError
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg3", {})
+    nw, nd = 512, p0.size
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
+    monkeypatch.setenv("NH_RUN_SPIN_LIMIT", "1")
+    d = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
+                        store_blobs=False, device=True)
+    st = d.run_mcmc(pos, 4)
+    with pytest.raises(NaimaHipError, match="timed out"):
+        st = d.run_mcmc(st, 40)
+        st.coords
+    assert d._dev.resident_launches > 0
+    # the context is still usable: a fresh sampler with the default limit runs
+    monkeypatch.delenv("NH_RUN_SPIN_LIMIT")
+    d2 = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
+                         store_blobs=False, device=True)
+    st = d2.run_mcmc(pos, 4)
+    st = d2.run_mcmc(st, 40)
+    assert np.all(np.isfinite(st.coords)) and d2._dev.resident_launches > 0
