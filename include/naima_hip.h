@@ -77,9 +77,11 @@ int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes)
 /* host -> device on a copy stream of its own: not ordered behind the main stream's work and not
  * waited for by nh_sync (the NEXT block of stretch-move random numbers goes up while the current
  * block's launch runs; emcee draws them inside the step, StretchMove.get_proposal).  `marker` is
- * recorded behind the copy; nh_stream_wait_marker orders the main stream behind it. */
+ * recorded behind the copy; nh_stream_wait_marker orders the main stream behind it.  `after`
+ * orders the copy itself behind a point of the main stream: the destination may still be read
+ * by launches queued before that point (a ring of blocks that wraps). */
 int nh_upload_ahead(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes,
-                    void* marker);
+                    void* marker, void* after /* marker on the main stream the copy waits for, or NULL */);
 int nh_stream_wait_marker(nh_ctx* ctx, void* marker);
 int nh_download(nh_ctx* ctx, void* host_dst, const void* dev_src, long long bytes);
 int nh_memset(nh_ctx* ctx, void* dev, int byte, long long bytes);

@@ -35,7 +35,7 @@ _SIGS = {
     "nh_free": [_dp, _dp],
     "nh_upload": [_dp, _dp, _dp, _ll],
     "nh_download": [_dp, _dp, _dp, _ll],
-    "nh_upload_ahead": [_dp, _dp, _dp, _ll, _dp],
+    "nh_upload_ahead": [_dp, _dp, _dp, _ll, _dp, _dp],
     "nh_stream_wait_marker": [_dp, _dp],
     "nh_memset": [_dp, _dp, _i, _ll],
     "nh_sync": [_dp],

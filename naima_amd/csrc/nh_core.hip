@@ -151,12 +151,16 @@ extern "C" int nh_upload(nh_ctx* c, void* dst, const void* src, long long bytes)
 // (and not waited for by nh_sync): the upload of the NEXT block of stretch-move random numbers
 // while the current block's launch runs.  `marker` (nh_marker_create) is recorded behind the
 // copy; nh_stream_wait_marker makes the main stream wait for it before the first launch that
-// reads the data.  The caller keeps `dst` disjoint from anything queued or running.
+// reads the data.  The caller keeps `dst` disjoint from what the launches behind `after` read.
 extern "C" int nh_upload_ahead(nh_ctx* c, void* dst, const void* src, long long bytes,
-                               void* marker) {
+                               void* marker, void* after) {
   NH_REQUIRE(c && dst && src && bytes >= 0 && marker, "bad argument");
   if (!c->copy_stream)
     NH_CHECK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  // `after` (a marker recorded on the main stream, or NULL): the copy may not start before it --
+  // the last launch that could still be reading the bytes about to be overwritten
+  if (after)
+    NH_CHECK_HIP(hipStreamWaitEvent(c->copy_stream, reinterpret_cast<hipEvent_t>(after), 0));
   NH_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
   NH_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(marker), c->copy_stream));
   return NH_OK;

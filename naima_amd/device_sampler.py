@@ -130,7 +130,10 @@ class DeviceLoop:
         self.MOVES_CAP = 4 * self.KSTEPS
         self.blk = ctx.empty((2 * self.MOVES_CAP + 1, 3 * self.ns))
         ctx.call("nh_memset", self.blk, 0, self.blk.nbytes)
-        self._mv = dict(have=0, used=0, ahead=None)  # steps on the device / consumed / last ahead marker
+        # steps on the device / consumed / last ahead marker / markers behind the last two launches
+        self._mv = dict(have=0, used=0, ahead=None, prev=None, last=None)
+        self._launch_marks = [ctx.marker() for _ in range(3)]
+        self._nlaunch = 0
         self._blk_tmp = None
         # nh_step_front mode: set after a recording evaluation when the model's parameter
         # packs read the proposal buffer and it asks for ONE particle-weights launch
@@ -558,6 +561,14 @@ class DeviceLoop:
                 mv["ahead"] = None
             self._run_resident(2 * mv["used"], 2 * want, block)
             mv["used"] += want
+            # a marker behind this launch: `blk` is a ring, and the host runs launches ahead of
+            # the device -- an upload on the copy stream may overlap THIS launch (whose steps lie
+            # below `have`), but must wait for every earlier one, which may still be reading the
+            # very bytes it is about to overwrite once the ring has wrapped
+            mv["prev"] = mv["last"]
+            mv["last"] = self._launch_marks[self._nlaunch % 3]
+            self._nlaunch += 1
+            ctx.call("nh_marker_record", mv["last"])
             if mv["have"] - mv["used"] < self.KSTEPS and \
                     mv["have"] + self.KSTEPS <= self.MOVES_CAP:
                 self._moves_append(moves, self.KSTEPS, ahead=True)
@@ -566,6 +577,8 @@ class DeviceLoop:
             if block is not None:
                 block["n"] += want
             yield DeviceState(self, rng)
+        if it < iterations:
+            mv["prev"] = mv["last"] = None  # (the per-launch loop takes over: see _moves_append)
         while it < iterations:
             self._flush_pending()  # (merged sharded mode) the block's last accept
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the
@@ -695,7 +708,10 @@ class DeviceLoop:
             self._nmark += 1
             dst = self.blk.ptr + sb * mv["have"]
             if ahead:
-                ctx.call("nh_upload_ahead", dst, addr, sb * got, mark)
+                # (the first ahead-upload of a loop waits for the launch just queued: whatever
+                # ran before it -- the per-launch loop's graphs read `blk` too -- is then done)
+                ctx.call("nh_upload_ahead", dst, addr, sb * got, mark,
+                         mv["prev"] if mv["prev"] is not None else mv["last"])
                 mv["ahead"] = mark
             else:
                 ctx.call("nh_upload", dst, addr, sb * got)

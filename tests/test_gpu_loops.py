@@ -592,3 +592,27 @@ def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
     st = d2.run_mcmc(pos, 4)
     st = d2.run_mcmc(st, 40)
     assert np.all(np.isfinite(st.coords)) and d2._dev.resident_launches > 0
+
+
+def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
+    """one run_mcmc call of 330 steps: eleven launches queued back to back, the device block of
+    moves (a ring of 128 steps, refilled on a copy stream while launches run) wraps twice --
+    against the per-launch loop, which uploads every block in stream order.  A refill that
+    overtook a launch still reading the old bytes would change the chain from there on."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg5", {})
+    nw, nd = 256, p0.size
+    pos = p0 * (1 + 0.01 * np.random.default_rng(2).standard_normal((nw, nd)))
+    kw = dict(args=[data, model, prior], seed=77, naima_style=True, store_blobs=False,
+              nan_policy="reject")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", mode)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        st = d.run_mcmc(pos, 4)
+        st = d.run_mcmc(st, 330)
+        st = d.run_mcmc(st, 50)
+        out[mode] = (d.get_chain(), d.get_log_prob(), d._dev.resident_launches)
+    assert out["0"][2] == 0 and out["1"][2] >= 13
+    assert np.array_equal(out["1"][0], out["0"][0])
+    assert np.array_equal(out["1"][1], out["0"][1])
