@@ -415,6 +415,26 @@ int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NP
                         int nseed, const double* E_eV, int nE, double* out, int ldo, int nmax,
                         int* status /*device, 2 ints*/);
 
+/* The same for protons: Epmin / Epmax / nEpd per walker (radiative.py:1002-1055, 1495-1536).
+ * Walker w integrates over Ep = logspace(log10 Epmin_w, log10 Epmax_w, max(10, int(nEpd_w *
+ * decades))) GeV, decades = log10(Epmax / Epmin) (count_mode 0: the spectrum's grid,
+ * radiative.py:1002-1009) or log10 Epmax - log10 Epmin (count_mode 1: compute_Wp's,
+ * :1047-1053); the limits arrive in the caller's unit with that unit in GeV beside them.
+ *   what = 0: out[w*ldo + k] = trapz_loglog(dsigma/dE(Ep, E_k) J, Ep), the Kafexhiu+14 cross
+ *             section evaluated at every (node, energy) (hiE: NH_PP_*, nuc: nuclear enhancement);
+ *             the caller applies nh c (radiative.py:1530-1536)
+ *   what = 1: the same with the look-up table's FITPACK spline (tx, ty, cf as for
+ *             nh_table_pion_lut) evaluated at every (node, energy)
+ *   what = 2: out[w*ldo] = Wp = trapz_loglog(Ep J, Ep), GeV
+ * nmax / status as for nh_general_electron. */
+int nh_general_proton(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NPAR]*/, int N,
+                      const nh_lazy* Epmin /*host*/, double Epmin_unit_GeV,
+                      const nh_lazy* Epmax /*host*/, double Epmax_unit_GeV,
+                      const nh_lazy* nEpd /*host*/, int count_mode, int what, int hiE, int nuc,
+                      const double* tx, int ntx, const double* ty, int nty, const double* cf,
+                      const double* E_eV, int nE, double* out, int ldo, int nmax,
+                      int* status /*device, 2 ints*/);
+
 /* ---- ONE launch per half-step ---------------------------------------------------------
  * nh_step_front + every table reduction of the model + its synchrotron component +
  * nh_lnprob (+ the accept of nh_lnprob_accept when do_accept) for the proposed walkers

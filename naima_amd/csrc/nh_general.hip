@@ -15,6 +15,7 @@
 // device-resident step loop no longer falls back to the host for such models.
 #include "nh_ic.h"
 #include "nh_pdist.h"
+#include "nh_pion.h"
 #include "nh_syn.h"
 
 struct gen_args {
@@ -224,6 +225,161 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
   // (what == 2 reads no photon energies: any valid pointer)
   hipLaunchKernelGGL(k_general_electron, dim3((unsigned)N, (unsigned)ncomp), dim3(256), lds,
                      c->stream, A);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The GENERAL proton path: Epmin / Epmax / nEpd per walker (radiative.py:1002-1055, 1495-1536).
+// One workgroup per walker builds the walker's proton grid
+//     Ep = logspace(log10 Epmin, log10 Epmax, max(10, int(nEpd * log10(Epmax / Epmin))))   [GeV]
+// (the spectrum's grid, radiative.py:1002-1009: the count from the logarithm of the RATIO; Wp
+// between explicit limits, :1047-1053, from the DIFFERENCE of the logarithms -- `count_mode`)
+// and its weights Ep J(Ep) in LDS, then integrates
+//   what = 0: the Kafexhiu+14 cross section evaluated at every (node, photon energy)
+//   what = 1: the look-up table's FITPACK spline at every (node, photon energy)
+//   what = 2: Wp = trapz_loglog(Ep J, Ep), GeV
+// with trapz_loglog (negative spline values and sign changes as utils.py:336-348 treats them).
+// ---------------------------------------------------------------------------------------------
+struct genp_args {
+  int kind, N, what, count_mode;
+  const double* rows;
+  nh_lazy emin, emax;        // in the caller's unit ...
+  double emin_GeV, emax_GeV; // ... and that unit in GeV (astropy's factor)
+  nh_lazy nEpd;
+  const double* E_eV; int nE;
+  double* out; int ldo;
+  int nmax; int* status;
+  pp_model M, G4; int nuc;
+  const double* tx; const double* ty; const double* cf; int ntx, nty;
+};
+
+__global__ __launch_bounds__(256) void k_general_proton(genp_args A) {
+  extern __shared__ double sm[];
+  double* Ep = sm;                // [nmax]
+  double* wv = sm + A.nmax;       // Ep * J(Ep)
+  double* dw = sm + 2 * A.nmax;   // ln(w[i+1]/w[i])
+  double* lxs = sm + 3 * A.nmax;  // ln(Ep[i+1]/Ep[i])
+  double* part = sm + 4 * A.nmax; // [4][64]
+  __shared__ int s_n;
+  __shared__ double s_l0, s_step, s_l1;
+  const int wi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+  if (tid == 0) {
+    const double lo = nh_lazy_eval(A.emin, wi) * A.emin_GeV;
+    const double hi = nh_lazy_eval(A.emax, wi) * A.emax_GeV;
+    const double l0 = log10(lo), l1 = log10(hi);
+    const double dec = A.count_mode == 0 ? log10(hi / lo) : (l1 - l0);
+    const double v = nh_lazy_eval(A.nEpd, wi) * dec;
+    int n = (int)v;
+    if (!(n >= 10)) n = 10;
+    if (v >= 10.0 && fabs(v - rint(v)) < 1e-9) atomicAdd(A.status + 1, 1);  // (see k_general_electron)
+    if (n > A.nmax) {
+      atomicMax(A.status, n);
+      n = 0;
+    }
+    s_n = n;
+    s_l0 = l0;
+    s_l1 = l1;
+    s_step = n > 1 ? (l1 - l0) / (n - 1) : 0.0;
+  }
+  __syncthreads();
+  const int n = s_n;
+  const double* pr = A.rows + (long long)wi * NH_PD_NPAR;
+  const pd_par p = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6]};
+  double* orow = A.out + (long long)wi * A.ldo;
+  const int nout = A.what == 2 ? 1 : A.nE;
+  if (n == 0) {
+    for (int k = tid; k < nout; k += blockDim.x) orow[k] = NAN;
+    return;
+  }
+  for (int i = tid; i < n; i += blockDim.x)
+    Ep[i] = exp10(i + 1 < n ? s_l0 + i * s_step : s_l1);
+  __syncthreads();
+  // weights: J = n(Ep [eV]) per eV -> per GeV (radiative.py:1011-1015)
+  for (int i = tid; i < n; i += blockDim.x) {
+    const bool last = i + 1 >= n;
+    const double e1 = Ep[i], e2 = last ? e1 : Ep[i + 1];
+    const double E = e1 * 1e9, E2 = e2 * 1e9;
+    const double lr = last ? 0.0 : log(e2 / e1);
+    double nn, dsh;
+    pd_node(A.kind, p, E, E2, last ? 0.0 : log(E2 / E), nn, dsh);
+    nn *= 1e9;
+    wv[i] = e1 * nn;
+    dw[i] = last ? 0.0 : lr + dsh;
+    lxs[i] = lr;
+  }
+  __syncthreads();
+  const int nseg = n - 1;
+  if (A.what == 2) {
+    double acc = 0.0;
+    for (int sg = tid; sg < nseg; sg += blockDim.x) {
+      const double u1 = wv[sg] * Ep[sg], u2 = wv[sg + 1] * Ep[sg + 1];
+      acc += (u1 == 0.0 || u2 == 0.0) ? 0.0 : nh_seg_term<true>(u1, u2, dw[sg] + lxs[sg], lxs[sg]);
+    }
+    acc = gen_wave_sum(acc);
+    if (lane == 0) part[wvi] = acc;
+    __syncthreads();
+    if (tid == 0) orow[0] = (part[0] + part[1]) + (part[2] + part[3]);
+    return;
+  }
+  const int per = (nseg + 3) / 4;
+  const int s0 = wvi * per, s1 = min(nseg, s0 + per);
+  for (int k0 = 0; k0 < A.nE; k0 += 64) {
+    const int k = k0 + lane;
+    double acc = 0.0;
+    if (k < A.nE && s0 < s1) {
+      const double Eg = A.E_eV[k] * 1e-9;
+      auto K = [&](double ep) {
+        return A.what == 0 ? pp_diffsigma(ep, Eg, A.M, A.G4.a, A.nuc)
+                           : pp_lut_value(ep, Eg, A.tx, A.ntx, A.ty, A.nty, A.cf);
+      };
+      double K1 = K(Ep[s0]);
+      for (int s = s0; s < s1; ++s) {
+        const double K2 = K(Ep[s + 1]);
+        acc += gen_term(wv[s], wv[s + 1], dw[s], K1, K2, lxs[s]);
+        K1 = K2;
+      }
+    }
+    part[wvi * 64 + lane] = acc;
+    __syncthreads();
+    if (wvi == 0 && k < A.nE)
+      orow[k] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    __syncthreads();
+  }
+}
+
+extern "C" int nh_general_proton(nh_ctx* c, int kind, const double* rows, int N,
+                                 const nh_lazy* Epmin, double Epmin_unit_GeV,
+                                 const nh_lazy* Epmax, double Epmax_unit_GeV,
+                                 const nh_lazy* nEpd, int count_mode, int what, int hiE, int nuc,
+                                 const double* tx, int ntx, const double* ty, int nty,
+                                 const double* cf, const double* E_eV, int nE, double* out,
+                                 int ldo, int nmax, int* status) {
+  NH_REQUIRE(c && rows && Epmin && Epmax && nEpd && out && status, "NULL pointer");
+  NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
+  NH_REQUIRE(N >= 0 && nmax >= 10 && Epmin_unit_GeV > 0 && Epmax_unit_GeV > 0, "bad sizes");
+  NH_REQUIRE(what >= 0 && what <= 2 && (count_mode == 0 || count_mode == 1), "bad mode");
+  NH_REQUIRE(what == 2 || (E_eV && nE >= 1 && ldo >= nE), "photon energies missing");
+  NH_REQUIRE(what != 0 || (hiE >= NH_PP_GEANT4 && hiE <= NH_PP_QGSJET), "unknown hiEmodel");
+  NH_REQUIRE(what != 1 || (tx && ty && cf && ntx >= 8 && nty >= 8), "spline missing");
+  NH_REQUIRE(nEpd->base || nEpd->a > 0.0, "nEpd must be positive");
+  if (N == 0) return NH_OK;
+  genp_args A;
+  memset(&A, 0, sizeof(A));
+  A.kind = kind; A.N = N; A.what = what; A.count_mode = count_mode; A.rows = rows;
+  A.emin = *Epmin; A.emax = *Epmax; A.emin_GeV = Epmin_unit_GeV; A.emax_GeV = Epmax_unit_GeV;
+  A.nEpd = *nEpd;
+  A.E_eV = E_eV; A.nE = what == 2 ? 1 : nE; A.out = out; A.ldo = ldo; A.nmax = nmax; A.status = status;
+  if (what == 0) { A.M = pp_get_model(hiE); A.G4 = pp_get_model(NH_PP_GEANT4); A.nuc = nuc; }
+  A.tx = tx; A.ty = ty; A.cf = cf; A.ntx = ntx; A.nty = nty;
+  const size_t lds = ((size_t)4 * nmax + 256) * sizeof(double);
+  NH_REQUIRE(lds <= 150 * 1024, "nmax does not fit in LDS (at most ~4700 nodes)");
+  if (lds > 64 * 1024)
+    NH_CHECK_HIP(hipFuncSetAttribute((const void*)k_general_proton,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  nh_prof_scope ps(c, NH_K_INTEGRATE);
+  hipLaunchKernelGGL(k_general_proton, dim3((unsigned)N), dim3(256), lds, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

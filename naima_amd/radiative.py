@@ -1096,6 +1096,80 @@ class BaseProton(BaseRadiative):
         return np.logspace(np.log10(lo), np.log10(hi),
                            max(10, int(self.nEpd * (np.log10(hi / lo)))))
 
+    # -- the general path on the device: Epmin / Epmax / nEpd per walker -------------------
+    def _general_limits(self):
+        """True when Epmin, Epmax or nEpd is given per walker: every walker then has its own
+        proton grid (radiative.py:1002-1009) and nh_general_proton integrates over it"""
+        return _per_walker(self.Epmin) or _per_walker(self.Epmax) or _per_walker(self.nEpd)
+
+    def _general_ok(self, *values):
+        if not hasattr(self.particle_distribution, "device_rows"):
+            return False
+        for q in values:  # (a per-walker value has to match the object's own batch)
+            v = q.value if isinstance(q, u.Quantity) else q
+            if not isinstance(v, DVec) and np.ndim(v) > 0 and \
+                    not (self.is_batched and len(v) == self.batch_size):
+                return False
+        return True
+
+    def _needs_walker_loop(self):
+        if self._general_limits() and self._general_ok(self.Epmin, self.Epmax, self.nEpd):
+            others = [v for n, v in self._structural_values()
+                      if n not in ("Epmin", "Epmax", "nEpd")]
+            if not any(_per_walker(v) for v in others):
+                return False
+        return super()._needs_walker_loop()
+
+    def _general_proton(self, what, E_eV, lo, hi, count_mode, hiE=0, nuc=0, lut=None):
+        """nh_general_proton over every walker's own grid between lo and hi: spectra [N][nE]
+        (what 0: analytic cross section, 1: look-up table) or Wp [N][1] in GeV (what 2)"""
+        import ctypes as C
+
+        from .darray import lazy_const
+        ctx = get_context()
+        pd = self.particle_distribution
+        N = self.batch_size
+
+        def lazy_of(v):
+            v = v.value if isinstance(v, u.Quantity) else v
+            if isinstance(v, DVec):
+                return v.lazy(), v
+            if np.ndim(v) > 0:
+                d = _as_dvec(ctx, np.asarray(v, dtype=float), N)
+                return d.lazy(), d
+            return lazy_const(float(v)), None
+
+        def gev_factor(q):
+            f = ASTROPY_TO_GEV.get(q.unit.name)
+            return float(q.unit.to("GeV") if f is None else f)
+
+        emin, k1 = lazy_of(lo)
+        emax, k2 = lazy_of(hi)
+        ned, k3 = lazy_of(self.nEpd)
+        rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
+        nE = 1 if what == 2 else E_eV.size
+        out = ctx.empty((N, nE))
+        tx = ty = cf = None
+        ntx = nty = 0
+        if lut is not None:
+            tx, ty, cf = (ctx.const(a) for a in lut)
+            ntx, nty = int(lut[0].size), int(lut[1].size)
+        ctx.call("nh_general_proton", PD_KIND[pd.kind], rows, N, C.addressof(emin), gev_factor(lo),
+                 C.addressof(emax), gev_factor(hi), C.addressof(ned), count_mode, what, hiE, nuc,
+                 tx, ntx, ty, nty, cf, ctx.const(E_eV) if what != 2 else None, nE, out, nE,
+                 ctx.general_nmax, ctx.general_status())
+        del k1, k2, k3, rows
+        if not self.on_device:
+            ctx.check_general()
+        return ctx, N, out
+
+    def _Wp_general(self, lo, hi, count_mode):
+        ctx, N, out = self._general_proton(2, None, lo, hi, count_mode)
+        if self.on_device:
+            return u.Quantity(DVec(ctx, out, out.ptr, N), u.GeV).to("erg")
+        Wp = out.get()[:, 0]
+        return u.Quantity(Wp if self.is_batched else Wp[0], u.GeV).to("erg")
+
     def _proton_weights(self, Ep=None):
         Ep = self._Ep if Ep is None else Ep
         return self._weights(Ep, Ep * 1e9, 1e9) + (Ep,)
@@ -1131,20 +1205,26 @@ class BaseProton(BaseRadiative):
     @property
     def Wp(self):
         """Total energy in protons"""
+        if self._general_limits() and not self._needs_walker_loop():
+            return self._Wp_general(self.Epmin, self.Epmax, 0)
         if self._needs_walker_loop():
             return self._loop_walkers("Wp")
         return self._Wp_on(self._Ep)
 
     def compute_Wp(self, Epmin=None, Epmax=None):
-        """Total energy in protons between Epmin and Epmax (radiative.py:1023-1055)"""
+        """Total energy in protons between Epmin and Epmax (radiative.py:1023-1055).  The grid
+        follows the limits in force: per walker only where THEY are"""
         if Epmin is None and Epmax is None:
             return self.Wp
-        if self._needs_walker_loop():
+        lo = self.Epmin if Epmin is None else validate_scalar_or_batch(
+            "Epmin", Epmin, physical_type="energy")
+        hi = self.Epmax if Epmax is None else validate_scalar_or_batch(
+            "Epmax", Epmax, physical_type="energy")
+        if _per_walker(lo) or _per_walker(hi) or _per_walker(self.nEpd):
+            if self._general_ok(lo, hi, self.nEpd):
+                return self._Wp_general(lo, hi, 1)
             return self._loop_walkers("compute_Wp", Epmin=Epmin, Epmax=Epmax)
-        if Epmax is None:
-            Epmax = self.Epmax
-        if Epmin is None:
-            Epmin = self.Epmin
+        Epmin, Epmax = lo, hi
         l0 = np.log10(_to_GeV(Epmin))
         l1 = np.log10(_to_GeV(Epmax))
         return self._Wp_on(np.logspace(l0, l1, max(10, int(self.nEpd * (l1 - l0)))))
@@ -1222,6 +1302,8 @@ class PionDecay(BaseProton):
         nE = E_eV.size
         if self.hiEmodel not in PP_MODEL:
             raise KeyError(self.hiEmodel)
+        if self._general_limits():
+            return self._spectrum_general(E, E_eV)
         ctx, N, w, lw, xd, lx, Ep = self._proton_weights()
         nG = Ep.size
         Ed = ctx.const(E_eV)
@@ -1255,6 +1337,28 @@ class PionDecay(BaseProton):
             self.specpp = self._result(ctx, out, N, nE, E, rows=fac)
         else:
             self.specpp = self._result(ctx, out, N, nE, E, scale=fac)
+        return self.specpp
+
+    def _spectrum_general(self, E, E_eV):
+        """radiative.py:1495-1536 with a proton grid per walker (nh_general_proton): no table
+        can be shared, the cross section (or the look-up table's spline) is evaluated at every
+        (node, photon energy) of every walker"""
+        use_lut = bool(self.useLUT)
+        if use_lut and not os.path.exists(self._lut_file()):
+            import warnings
+            warnings.warn("LUT {0} not found, reverting to useLUT = False".format(
+                os.path.basename(self._lut_file())))
+            self.useLUT = use_lut = False
+        ctx, N, out = self._general_proton(
+            1 if use_lut else 0, E_eV, self.Epmin, self.Epmax, 0, hiE=PP_MODEL[self.hiEmodel],
+            nuc=int(bool(self.nuclear_enhancement)),
+            lut=_lut_spline(self._lut_file()) if use_lut else None)
+        nh = self.nh.to("1/cm3").value
+        fac = (nh * C_CGS) * 1e-9  # 1/(s GeV) -> 1/(s eV), radiative.py:1534-1536
+        if _per_walker(self.nh):
+            self.specpp = self._result(ctx, out, N, E_eV.size, E, rows=fac)
+        else:
+            self.specpp = self._result(ctx, out, N, E_eV.size, E, scale=fac)
         return self.specpp
 
     def _own_batch_sizes(self):

@@ -108,9 +108,11 @@ def test_general_path_grid_limits_and_seed_temperature(na):
                             nEed=[40, 50, 60][k])
         # (limits AND node density per walker: the general kernel again, against the table path)
         assert_allclose(fs[k].value, sk.flux(Ex, 2 * u.kpc).value, rtol=1e-10, atol=1e-300)
+        # (proton limits per walker: nh_general_proton -- the look-up table's spline at every
+        # node of every walker's own grid -- against the single walker's table path)
         pk2 = na.PionDecay(pk, Epmin=[2.0, 5.0, 10.0][k] * u.GeV)
-        assert_allclose(fp[k].value, pk2.flux(E, 2 * u.kpc).value, rtol=1e-14, atol=1e-300)
-        assert_allclose(Wp[k].value, pk2.Wp.value, rtol=1e-14)
+        assert_allclose(fp[k].value, pk2.flux(E, 2 * u.kpc).value, rtol=1e-9, atol=1e-300)
+        assert_allclose(Wp[k].value, pk2.Wp.value, rtol=1e-10)
 
 
 def test_general_path_device_values(na):
@@ -591,3 +593,46 @@ def test_general_kernel_on_an_int_boundary_and_per_walker_density(na):
         assert_allclose(f[i], tot, rtol=1e-9, atol=tot.max() * 1e-200)
         g2 = O.electron_grid(Wlo[i] * 1e9, 510e12, ned[i])
         assert_allclose(W[i], O.electron_energy_content(opd, g2), rtol=1e-9)
+
+
+def test_general_proton_kernel_against_oracle(na):
+    """nh_general_proton: Epmin, Epmax AND nEpd per walker (radiative.py:1002-1055, 1495-1536) --
+    the analytic Kafexhiu+14 cross section and the look-up table's spline evaluated on every
+    walker's own proton grid -- and Wp / compute_Wp between per-walker limits, against the oracle
+    on each walker's grid"""
+    from oracle import naima_np as O
+    from oracle import workloads_np as WN
+    u = na.u
+    rng = np.random.default_rng(11)
+    N = 13
+    amp = 10 ** rng.normal(46, 0.3, N)
+    a1, a2 = rng.uniform(1.6, 2.2, N), rng.uniform(2.3, 3.0, N)
+    eb, ec = rng.uniform(0.5, 5.0, N), rng.uniform(50, 500, N)
+    epmin = rng.uniform(1.3, 30.0, N)            # GeV
+    epmax = 10 ** rng.uniform(5.0, 7.0, N)       # GeV
+    ned = rng.integers(30, 120, N).astype(float)
+    pd = na.ExponentialCutoffBrokenPowerLaw(amp / u.TeV, 1 * u.TeV, eb * u.TeV, a1, a2, ec * u.TeV)
+    Eg = np.geomspace(3e8, 1e14, 19)
+    kw = dict(Epmin=epmin * u.GeV, Epmax=epmax * u.GeV, nEpd=ned)
+    f_an = na.PionDecay(pd, nh=2 / u.cm ** 3, useLUT=False, **kw).flux(Eg * u.eV, 0).value
+    pl = na.PionDecay(pd, nh=2 / u.cm ** 3, **kw)
+    f_lut = pl.flux(Eg * u.eV, 0).value
+    Wp = pl.Wp.to("erg").value
+    wlo = rng.uniform(100.0, 3000.0, N)
+    Wp2 = pl.compute_Wp(Epmin=wlo * u.GeV).to("erg").value
+    assert f_an.shape == f_lut.shape == (N, Eg.size) and Wp.shape == Wp2.shape == (N,)
+    lut = WN.get_lut()
+    for i in range(N):
+        Ep = O.proton_grid(epmin[i], epmax[i], ned[i])
+        opd = O.ParticleDist("ExponentialCutoffBrokenPowerLaw", amplitude=amp[i] * 1e-12, e_0=1e12,
+                             e_break=eb[i] * 1e12, alpha_1=a1[i], alpha_2=a2[i],
+                             e_cutoff=ec[i] * 1e12, beta=1.0)
+        J = O.J_on(opd, Ep)
+        ref = O.pion_spectrum(Eg, Ep, J, 2.0)
+        assert_allclose(f_an[i], ref, rtol=1e-9, atol=np.abs(ref).max() * 1e-200)
+        refl = O.pion_spectrum(Eg, Ep, J, 2.0, diffsigma=lut)
+        assert_allclose(f_lut[i], refl, rtol=1e-7, atol=np.abs(refl).max() * 1e-12)
+        assert_allclose(Wp[i], O.proton_energy_content(opd, Ep), rtol=1e-9)
+        l0, l1 = np.log10(wlo[i]), np.log10(epmax[i])
+        Ep2 = np.logspace(l0, l1, max(10, int(ned[i] * (l1 - l0))))
+        assert_allclose(Wp2[i], O.proton_energy_content(opd, Ep2), rtol=1e-9)

@@ -371,7 +371,7 @@ def test_device_sampler_matches_host_sampler(na, golden, use_graph):
     assert_allclose(bd[0], bh[0], rtol=1e-9, atol=1e-300)
     assert_allclose(bd[1], bh[1], rtol=1e-9)
     if use_graph:
-        assert d._dev.graph is not None
+        assert d._dev.graph is not None or d._dev.resident_launches > 0
     # continuing from the device state does not re-upload or re-evaluate
     sd2 = d.run_mcmc(sd, 3)
     sh2 = h.run_mcmc(sh, 3)
@@ -708,11 +708,13 @@ def test_abi_last_producer_epilogues(na):
     same(s1, s2)
 
 
-def test_device_loop_front_kernel_history_and_multistep_graph(na, golden):
-    """store_blobs=False: the loop runs on nh_step_front / nh_lnprob_accept, keeps the
-    chain history on the device across block boundaries (32 steps) and replays eight
-    steps per graph launch; the chain equals the host loop's"""
+def test_device_loop_front_kernel_history_and_multistep_graph(na, golden, monkeypatch):
+    """store_blobs=False, the per-launch loop (NAIMA_AMD_RESIDENT=0: what a sharded run and
+    plans the resident loop declines use): one k_half_step launch per half-step, the chain
+    history kept on the device across block boundaries (32 steps), eight steps replayed per
+    graph launch; the chain equals the host loop's"""
     from naima_amd.sampler import EnsembleSampler
+    monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0")
     model, data, prior, p0 = _cfg_problem(na, golden, "cfg3")
     kw = dict(args=[data, model, prior], seed=7, naima_style=True, store_blobs=False)
     h = EnsembleSampler(32, 5, na.lnprob, **kw)
@@ -723,7 +725,7 @@ def test_device_loop_front_kernel_history_and_multistep_graph(na, golden):
     assert d._dev.fused
     sh = h.run_mcmc(sh, 45)
     sd = d.run_mcmc(sd, 45)
-    assert d._dev.multi_graph is not None
+    assert d._dev.multi_graph is not None and d._dev.resident_launches == 0
     assert d.get_chain().shape == (48, 32, 5)
     assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
     assert_allclose(d.get_log_prob(), h.get_log_prob(), rtol=1e-6)
