@@ -14,6 +14,8 @@ S, D = os.path.join(R, "gpurun_out", TAG + "prof"), os.path.join(R, "profiles")
 COPY = {"bench_n1_default.json": "bench_n1_default.json",
         "bench_n1_per_launch_kernel.json": "bench_n1_per_launch_kernel.json",
         "bench_cfg5_per_launch_kernel.json": "bench_cfg5_per_launch_kernel.json",
+        "bench_cfg2_per_launch_kernel.json": "bench_cfg2_per_launch_kernel.json",
+        "bench_cfg5_strong2048_n1_per_launch_kernel.json": "bench_cfg5_strong2048_n1_per_launch_kernel.json",
         "cfg3_stats_command.txt": "cfg3_kernel_stats_command.txt",
         "stamps_cfg3.txt": "cfg3_resident_loop_phase_stamps.txt",
         "stamps_cfg5.txt": "cfg5_resident_loop_phase_stamps.txt",

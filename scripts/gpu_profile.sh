@@ -56,6 +56,8 @@ timeout 600 python bench.py --workload cfg3 --walkers 256 --steps 20 --warmup 5 
 timeout 600 python bench.py --workload cfg5 --scaling strong --walkers-total 2048 --steps 100 --warmup 10 --no-cpu --no-blobs-run > $O/bench_cfg5_strong2048_n1.json 2>> $O/err_bench.log
 NAIMA_AMD_RESIDENT=0 timeout 600 python $DRV --no-cpu > $O/bench_n1_per_launch_kernel.json 2>> $O/err_bench.log
 NAIMA_AMD_RESIDENT=0 timeout 600 python bench.py --workload cfg5 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg5_per_launch_kernel.json 2>> $O/err_bench.log
+NAIMA_AMD_RESIDENT=0 timeout 600 python bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg2_per_launch_kernel.json 2>> $O/err_bench.log
+NAIMA_AMD_RESIDENT=0 timeout 600 python bench.py --workload cfg5 --scaling strong --walkers-total 2048 --steps 100 --warmup 10 --no-cpu --no-blobs-run > $O/bench_cfg5_strong2048_n1_per_launch_kernel.json 2>> $O/err_bench.log
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$O/bench_*.json")):
