@@ -198,6 +198,19 @@ int nh_ic_seed_walkers(nh_ctx* ctx, const double* w, const double* dlw, int N,
                        const double* E_eV, int nE, const double* seed_E_eV,
                        const double* seed_dens /*[N][ns]*/, int ns, double* out, int ldo);
 
+/* The same with the Aharonian-Atoyan kernel of radiative.py:620-637 tabulated: it depends on
+ * (seed energy, gamma, photon energy) only, so a sampler builds it once -- nh_ssc_table fills
+ * `table` (nh_ssc_table_bytes bytes of device memory: cfg4's grids 374 MB) -- and every step
+ * runs the walkers' part alone.  Same result as nh_ic_seed_walkers. */
+long long nh_ssc_table_bytes(int nG, int nE, int ns);
+int nh_ssc_table(nh_ctx* ctx, const double* gam, int nG, const double* E_eV, int nE,
+                 const double* seed_E_eV, int ns, void* table);
+int nh_ic_seed_walkers_tab(nh_ctx* ctx, const double* w, const double* dlw, int N,
+                           const double* gam, const double* lx, int nG,
+                           const double* E_eV, int nE, const double* seed_E_eV,
+                           const double* seed_dens /*[N][ns]*/, int ns, const void* table,
+                           double* out, int ldo);
+
 /* ---- row 10: radiative.py:838-989 Bremsstrahlung ------------------------- */
 /* two tables: sigma_ee (rel/non-rel, 873-928) and sigma_ep = sigma_1 (838-849),
  * both in cm2/eV. */

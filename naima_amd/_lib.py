@@ -54,6 +54,9 @@ _SIGS = {
     "nh_table_ic_planck": [_dp, _dp, _i, _dp, _i, _d, _d, _dp, _dp, _i],
     "nh_table_ic_seed": [_dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _i],
     "nh_ic_seed_walkers": [_dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _i],
+    "nh_ssc_table": [_dp, _dp, _i, _dp, _i, _dp, _i, _dp],
+    "nh_ic_seed_walkers_tab": [_dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _i, _dp, _dp, _i, _dp, _dp,
+                               _i],
     "nh_table_brems": [_dp, _dp, _i, _dp, _i, _dp, _dp, _dp, _dp, _i],
     "nh_table_pion_analytic": [_dp, _dp, _i, _dp, _i, _i, _i, _dp, _dp, _i],
     "nh_table_pion_lut": [_dp, _dp, _i, _dp, _i, _dp, _i, _dp, _i, _dp, _dp, _dp, _i],
@@ -126,7 +129,7 @@ _SIGS = {
     "nh_set_words": [_dp, _dp, _dp, _i],
     "nh_half_step_append_blobs": [_dp, _dp, _ll],
 }
-EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version")
+EXPORTS = tuple(_SIGS) + ("nh_last_error", "nh_version", "nh_ssc_table_bytes")
 
 _lib = None
 
@@ -173,6 +176,8 @@ def load():
     lib.nh_last_error.restype = C.c_char_p
     lib.nh_last_error.argtypes = []
     lib.nh_version.restype = _i
+    lib.nh_ssc_table_bytes.restype = _ll
+    lib.nh_ssc_table_bytes.argtypes = [_i, _i, _i]
     _lib = lib
     return lib
 
@@ -298,6 +303,7 @@ class Context:
         self._nanchor = 0
         self.side_small = os.environ.get("NAIMA_AMD_SIDE_SMALL", "0") != "0"
         self._tables = {}
+        self._big_tables = {}
         self.capturing = False
         # side streams (nh_stream_fork/join): -1 = main
         self.cur_stream = -1
@@ -764,6 +770,35 @@ class Context:
                 self._tables = {k: v for k, v in self._tables.items() if k in self._pinned}
             hit = build()
             self._tables[key] = hit
+        return hit
+
+    def ssc_table(self, gd, nG, Ed, nE, sed, ns):
+        """the tabulated SSC kernel of nh_ic_seed_walkers_tab for these three grids (cached; the
+        big tables share NAIMA_AMD_TABLE_GB of HBM, default 16: the oldest ones no plan points
+        into make room).  None when it does not fit: the caller evaluates the kernel per step."""
+        if os.environ.get("NAIMA_AMD_SSC_TABLE", "1") == "0":
+            return None
+        key = ("ssc", gd.ptr, Ed.ptr, sed.ptr, nG, nE, ns)
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit
+        nbytes = int(_lib.nh_ssc_table_bytes(nG, nE, ns))
+        budget = float(os.environ.get("NAIMA_AMD_TABLE_GB", "16")) * 2.0 ** 30
+        if nbytes <= 0 or nbytes > budget or self.capturing:
+            return None
+        big = self._big_tables = {k: v for k, v in self._big_tables.items() if k in self._tables}
+        for k in list(big):
+            if sum(big.values()) + nbytes <= budget:
+                break
+            if k not in self._pinned:
+                self._tables.pop(k, None)
+                del big[k]
+        if sum(big.values()) + nbytes > budget:
+            return None
+        hit = self.empty(((nbytes + 7) // 8,))
+        _chk(_lib.nh_ssc_table(self.h, gd.ptr, nG, Ed.ptr, nE, sed.ptr, ns, hit.ptr))
+        self._tables[key] = hit
+        big[key] = nbytes
         return hit
 
     # -- hipGraph capture -----------------------------------------------------

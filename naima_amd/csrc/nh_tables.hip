@@ -378,6 +378,161 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
 #undef SSC_LOG
 }
 
+// ---------------------------------------------------------------------------
+// The same reduction with the kernel TABULATED.  fic(eps0_s, gamma_i, E_k), its logarithmic
+// slope along the seed axis and the window of seed nodes in which it is non-zero depend on
+// the three grids only -- not on the walker, not on the step -- and 288 GB of HBM hold them
+// for any fit: n_E x n_gamma x n_s x 16 bytes (cfg4: 261 x 14 tiles x 100 x 1 KB = 374 MB),
+// built once per sampler by k_ssc_table with the very instruction sequence k_ic_seed_walkers
+// runs per step (ssc_fic, ssc_log: the two kernels give the same bits).  The per-step kernel
+// then is the walkers' arithmetic alone: per seed node ONE 16-byte load per lane (a wave reads
+// 1 KB contiguous; the C waves of a workgroup are C walker groups at the same (E, gamma tile),
+// so one of them misses and the others hit the CU's L1) instead of ~80 instructions of kernel
+// + logarithm, and the loop runs over the tile's window [s_lo, s_hi) instead of testing every
+// node for it (45 % of cfg4's (gamma, E, s) triples are outside).
+//   table = int2 win[n_E * ntile] (padded to 256 B) | double2 F[n_E * ntile][n_s][64]:
+//   F[..][s][lane] = { fic at seed node s,  ln(fic_s / fic_{s-1}) / ln(eps_s / eps_{s-1}) }
+// ---------------------------------------------------------------------------
+typedef double ssc_d2 __attribute__((ext_vector_type(2)));
+
+static inline size_t ssc_table_win_bytes(int nE, int ntile) {
+  return (((size_t)nE * ntile * sizeof(int2)) + 255) & ~(size_t)255;
+}
+
+__global__ __launch_bounds__(512) void k_ssc_table(const double* __restrict__ gam, int nG,
+                                                   const double* __restrict__ E_eV, int nE,
+                                                   const double* __restrict__ se, int ns,
+                                                   int ntile, ssc_d2* __restrict__ F,
+                                                   int2* __restrict__ win) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x;
+  const int k = blockIdx.y * 8 + (threadIdx.x >> 6);
+  if (k >= nE) return;
+  const double eg = E_eV[k] / NH_MEC2_EV;
+  const int i = tile * SSC_TILE + lane;
+  const bool node = i < nG;
+  const double g = gam[node ? i : nG - 1];
+  const double L0 = 1.479819860511658591e-01, L1 = 1.531383769920937332e-01;
+  const double L2 = 1.818357216161805012e-01, L3 = 2.222219843214978396e-01;
+  const double L4 = 2.857142874366239149e-01, L5 = 3.999999999940941908e-01;
+  const double L6 = 6.666666666666735130e-01;
+  ssc_gk gk = ssc_setup(g, eg);
+  gk.valid = gk.valid && node;
+  ssc_d2* __restrict__ Fp = F + ((size_t)(k * ntile + tile) * ns) * 64 + lane;
+  // (the operands as k_ssc_prep writes them for k_ic_seed_walkers)
+  double f1 = ssc_fic(gk, NH_MEC2_EV / se[0], 2.0 * log(se[0] / NH_MEC2_EV));
+  double lf1 = ssc_log(fabs(f1), L0, L1, L2, L3, L4, L5, L6) + (f1 == 0.0 ? -INFINITY : 0.0);
+  ssc_d2 e0 = {f1, 0.0};
+  Fp[0] = e0;
+  int s_lo = ns, s_hi = 0;
+  for (int s = 1; s < ns; ++s) {
+    const double e = se[s] / NH_MEC2_EV;
+    const double f2 = ssc_fic(gk, 1.0 / e, 2.0 * log(e));
+    const double lf2 = ssc_log(fabs(f2), L0, L1, L2, L3, L4, L5, L6) + (f2 == 0.0 ? -INFINITY : 0.0);
+    const double ilx = 1.0 / log(se[s] / se[s - 1]);
+    ssc_d2 v = {f2, fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx};
+    Fp[(size_t)s * 64] = v;
+    if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
+      s_lo = min(s_lo, s);
+      s_hi = s + 1;
+    }
+    f1 = f2;
+    lf1 = lf2;
+  }
+  if (lane == 0) win[k * ntile + tile] = make_int2(s_lo, s_hi);
+}
+
+// blockIdx.x -> (tile of (E, gamma), chunk of C walker groups): consecutive workgroups go to
+// different XCDs, so the chunks of one tile sit 8 apart -- one XCD's L2 serves all of them
+template <int C, int W>
+__global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
+    const double* __restrict__ w, const double* __restrict__ dlw, int N,
+    const double* __restrict__ gam, const double* __restrict__ lx, int nG, int nE,
+    const double* __restrict__ rec, int ns, int ntile, int groups, int ngchunk,
+    const ssc_d2* __restrict__ F, const int2* __restrict__ win, double* __restrict__ partial) {
+  constexpr int REC = SSC_REC(W);
+  const int lane = threadIdx.x & 63;
+  const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
+  const int tk = (by / ngchunk) * 8 + bx;
+  const int grp = (by % ngchunk) * C + ch;
+  if (tk >= nE * ntile || grp >= groups) return;
+  const int k = tk / ntile, tile = tk - k * ntile;
+  const int w0 = grp * W;
+  const int i = tile * SSC_TILE + lane;  // this lane's node
+  const bool node = i < nG;
+  const bool seg = lane < SSC_TILE && i + 1 < nG;  // ... and the segment that starts there
+  const int ic = node ? i : nG - 1;
+  const double g = gam[ic];
+  const int2 wn = win[tk];
+  const int s_lo = __builtin_amdgcn_readfirstlane(wn.x);
+  const int s_hi = __builtin_amdgcn_readfirstlane(wn.y);
+  double in[W], u1[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) in[j] = 0.0;
+  if (s_lo < s_hi) {
+    const ssc_d2* __restrict__ Fp = F + (size_t)tk * ns * 64 + lane;
+    const double* rp = rec + ((size_t)grp * ns + (s_lo - 1)) * REC;
+    const double f0 = Fp[(size_t)(s_lo - 1) * 64].x;
+#pragma unroll
+    for (int j = 0; j < W; ++j) u1[j] = f0 * rp[j];
+    ssc_d2 nx = Fp[(size_t)s_lo * 64];
+    for (int s = s_lo; s < s_hi; ++s) {
+      rp += REC;
+      const ssc_d2 cur = nx;
+      nx = Fp[(size_t)min(s + 1, ns - 1) * 64];  // one node ahead
+      double sd8[W], dl8[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        sd8[j] = rp[j];
+        dl8[j] = rp[W + j];
+      }
+      const ssc_d4 Lv = *reinterpret_cast<const ssc_d4*>(rp + 2 * W);
+      const double lxv = Lv.x, thr = Lv.z;
+      const double f2 = cur.x, dlf = cur.y;
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const double uo = u1[j], io = in[j];
+        const double u2 = f2 * sd8[j];
+        const double dl = dlf + dl8[j];
+        double t = fma(u2 - uo, nh_rcp1f(dl), io);
+        // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos
+        const bool small = fabs(dl) < thr;
+        if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
+          asm volatile("" ::: "memory");  // keep this a branch
+          const double d = dl * lxv;
+          double f = fma(d, 8.333333333333333e-03, 4.166666666666666e-02);
+          f = fma(f, d, 1.666666666666667e-01);
+          f = fma(f, d, 0.5);
+          f = fma(f, d, 1.0);
+          t = small ? fma(uo * lxv, f, io) : t;
+        }
+        in[j] = t;
+        u1[j] = u2;
+      }
+    }
+  }
+  double L0 = 1.479819860511658591e-01, L1 = 1.531383769920937332e-01;
+  double L2 = 1.818357216161805012e-01, L3 = 2.222219843214978396e-01;
+  double L4 = 2.857142874366239149e-01, L5 = 3.999999999940941908e-01;
+  double L6 = 6.666666666666735130e-01;
+  // outer segments (i, i+1) of trapz_loglog(nelec*gamint, gam), radiative.py:684: across lanes
+  const double pref = (3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g);  // radiative.py:650-653
+  const double lxi = lx[seg ? i : 0];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const size_t row = (size_t)min(w0 + j, N - 1) * (size_t)nG;
+    const double Kv = in[j] * pref;
+    const double Kn = __shfl_down(Kv, 1, 64);
+    const double wi = w[row + ic], wnx = w[row + (seg ? i + 1 : ic)];
+    const double dl = dlw[row + (seg ? i : 0)] +
+                      ssc_log(fabs(Kn * nh_rcp(Kv)), L0, L1, L2, L3, L4, L5, L6);
+    double t = nh_seg_term(wi * Kv, wnx * Kn, dl, lxi);
+    t = nh_wave_sum(seg ? t : 0.0);
+    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + (w0 + j)) * nE + k] = t;
+  }
+}
+
 __global__ void k_ssc_finish(const double* __restrict__ partial, int nsuper, int N, int nE,
                              const double* __restrict__ E_eV, double* __restrict__ out, int ldo) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,6 +581,74 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
                      partial, nsuper, N, nE, E_eV, out, ldo);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+extern "C" long long nh_ssc_table_bytes(int nG, int nE, int ns) {
+  if (nG < 2 || nE < 1 || ns < 2) return 0;
+  const int ntile = (nG - 1 + SSC_TILE - 1) / SSC_TILE;
+  return (long long)(ssc_table_win_bytes(nE, ntile) +
+                     (size_t)nE * ntile * ns * 64 * sizeof(ssc_d2));
+}
+
+extern "C" int nh_ssc_table(nh_ctx* c, const double* gam, int nG, const double* E_eV, int nE,
+                            const double* seed_E, int ns, void* table) {
+  NH_REQUIRE(c && gam && E_eV && seed_E && table, "NULL pointer");
+  NH_REQUIRE(nG >= 2 && nE >= 1 && ns >= 2, "bad sizes");
+  const int ntile = (nG - 1 + SSC_TILE - 1) / SSC_TILE;
+  nh_prof_scope ps(c, NH_K_TABLES);
+  int2* win = static_cast<int2*>(table);
+  ssc_d2* F = reinterpret_cast<ssc_d2*>(static_cast<char*>(table) + ssc_table_win_bytes(nE, ntile));
+  hipLaunchKernelGGL(k_ssc_table, dim3(ntile, (nE + 7) / 8), dim3(512), 0, c->stream, gam, nG,
+                     E_eV, nE, seed_E, ns, ntile, F, win);
+  NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+extern "C" int nh_ic_seed_walkers_tab(nh_ctx* c, const double* w, const double* dlw, int N,
+                                      const double* gam, const double* lx, int nG,
+                                      const double* E_eV, int nE, const double* seed_E,
+                                      const double* seed_dens, int ns, const void* table,
+                                      double* out, int ldo) {
+  NH_REQUIRE(c && w && dlw && gam && lx && E_eV && seed_E && seed_dens && table && out,
+             "NULL pointer");
+  NH_REQUIRE(N >= 0 && nG >= 2 && nE >= 1 && ns >= 2 && ldo >= nE, "bad sizes");
+  NH_REQUIRE((long long)N * nG < (1LL << 31) && (long long)N * ns < (1LL << 31),
+             "arrays too large for 32-bit element offsets");
+  if (N == 0) return NH_OK;
+  constexpr int C = 8;
+  const int W = N > 8 ? 16 : 8;
+  const int groups = (N + W - 1) / W;
+  const int ngchunk = (groups + C - 1) / C;
+  const int ntile = (nG - 1 + SSC_TILE - 1) / SSC_TILE;
+  NH_REQUIRE((long long)nE * ntile < (1LL << 27), "too many (energy, tile) pairs");
+  const size_t nd = (size_t)groups * ns * SSC_REC(W);
+  const size_t need = (nd + SSC_REC(W) + (size_t)ntile * N * nE) * sizeof(double);
+  void* sc = nullptr;
+  int rc = nh_scratch(c, need, &sc);
+  if (rc) return rc;
+  double* rec = static_cast<double*>(sc);
+  double* partial = rec + nd + SSC_REC(W);
+  const int2* win = static_cast<const int2*>(table);
+  const ssc_d2* F = reinterpret_cast<const ssc_d2*>(static_cast<const char*>(table) +
+                                                    ssc_table_win_bytes(nE, ntile));
+  nh_prof_scope ps(c, NH_K_SSC);
+  const dim3 gp((unsigned)((nd + 255) / 256));
+  const unsigned tk8 = (unsigned)((nE * ntile + 7) / 8);
+  const dim3 gk(tk8 * ngchunk * 8);
+  if (W == 16) {
+    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 16>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, partial);
+  } else {
+    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 8>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, partial);
+  }
+  long long tot = (long long)N * nE;
+  hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                     partial, ntile, N, nE, E_eV, out, ldo);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

@@ -948,8 +948,16 @@ class InverseCompton(BaseElectron):
                 sd_buf = ctx.array(np.broadcast_to(sdv, (N, se.size)))
                 sd_ptr = sd_buf.ptr
             out = ctx.empty((N, nE))
-            ctx.call("nh_ic_seed_walkers", w, lw, N, gd, lx, nG, Ed, nE, ctx.const(se),
-                     sd_ptr, int(se.size), out, nE)
+            sed, ns = ctx.const(se), int(se.size)
+            # the Aharonian-Atoyan kernel on (seed energy, gamma, photon energy) does not depend
+            # on the walker: tabulated once per set of grids when HBM has room for it
+            tab = ctx.ssc_table(gd, nG, Ed, nE, sed, ns) if ns >= 2 else None
+            if tab is not None:
+                ctx.call("nh_ic_seed_walkers_tab", w, lw, N, gd, lx, nG, Ed, nE, sed, sd_ptr, ns,
+                         tab, out, nE)
+            else:
+                ctx.call("nh_ic_seed_walkers", w, lw, N, gd, lx, nG, Ed, nE, sed, sd_ptr, ns,
+                         out, nE)
             del sd_buf
             specs[name] = DMat.from_buffer(ctx, out, N, nE) if dev else out.get()
         if dev:

@@ -838,15 +838,23 @@ def test_edge_shapes_against_oracle(na):
     check(N=64, nE=130, Eemin_eV=1e8, Eemax_eV=5e16, nEed=10, Elo=1e-5, Ehi=1e13, B0=100.0)  # coarse grid
 
 
-def test_ssc_seed_edge_shapes_against_oracle(na):
-    """nh_ic_seed_walkers (a seed density per walker, radiative.py:609-655 + 684) at the shapes
-    its mapping cares about: 1 / 9 / 17 / 33 walkers (groups of 8 and of 16, padded groups), a
+@pytest.mark.parametrize("tabulated", ["1", "0"])
+def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
+    """nh_ic_seed_walkers_tab (the kernel tabulated once per set of grids: what a fit runs) and
+    nh_ic_seed_walkers (the kernel evaluated per call: when the table does not fit) -- a seed
+    density per walker, radiative.py:609-655 + 684 -- at the shapes
+    their mapping cares about: 1 / 9 / 17 / 33 walkers (groups of 8 and of 16, padded groups), a
     seed spectrum of two nodes, seed nodes with ZERO density (the trapz_loglog zero rule,
     utils.py:347-348) at the ends and in the middle, a particle grid shorter than a wave's 64
     nodes and one that needs several gamma tiles, one photon energy"""
     from oracle import naima_np as O
+    from naima_amd._lib import get_context
+    monkeypatch.setenv("NAIMA_AMD_SSC_TABLE", tabulated)
     u = na.u
     rng = np.random.default_rng(3)
+    ctx, seen = get_context(), []
+    orig = ctx.call
+    monkeypatch.setattr(ctx, "call", lambda name, *a: (seen.append(name), orig(name, *a))[1])
 
     def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=()):
         E = np.geomspace(1e3, 3e13, nE) if nE > 1 else np.array([2e9])
@@ -877,6 +885,36 @@ def test_ssc_seed_edge_shapes_against_oracle(na):
     check(N=17, ns=30, nE=70, Eemin_eV=1e8, Eemax_eV=1e15, nEed=40, zeros=(0, 29, 11))  # 280 nodes
     check(N=33, ns=25, nE=1, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, zeros=(5,))  # 17 -> 10 nodes
     check(N=8, ns=40, nE=66, Eemin_eV=1e10, Eemax_eV=1e13, nEed=100)      # 300 nodes, 5 tiles
+    check(N=150, ns=33, nE=19, Eemin_eV=1e9, Eemax_eV=1e14, nEed=30, zeros=(2,))  # 10 groups: two chunks
+    assert ("nh_ic_seed_walkers_tab" in seen) == (tabulated == "1")
+    assert ("nh_ic_seed_walkers" in seen) == (tabulated == "0")
+
+
+def test_ssc_tabulated_kernel_against_the_evaluated_one(na, monkeypatch):
+    """k_ssc_table restates what k_ic_seed_walkers evaluates per step: the two entry points
+    agree to rounding (cfg4-like grids, 40 walkers; zero seed nodes)"""
+    u = na.u
+    rng = np.random.default_rng(8)
+    N, ns, nE = 40, 100, 37
+    E = np.geomspace(1e-5, 1e14, nE)
+    se = np.geomspace(1e-7, 1e9, ns)
+    sd = 1e3 * (se / 1e-2) ** -1.6 * np.exp(-se / 1e5) * 10 ** (0.2 * rng.standard_normal((N, ns)))
+    sd[:, 0] = 0.0
+    sd[3, 50] = 0.0
+    amp = 10 ** (33 + 0.05 * rng.standard_normal(N))
+    out = {}
+    for tab in ("1", "0"):
+        monkeypatch.setenv("NAIMA_AMD_SSC_TABLE", tab)
+        pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, 2.4, 300 * u.TeV)
+        ic = na.InverseCompton(pd, seed_photon_fields=[
+            ["ssc", se * u.eV, u.Quantity(sd, u.Unit("1/(eV cm3)"))]],
+            Eemin=1e8 * u.eV, Eemax=1e15 * u.eV, nEed=60)
+        out[tab] = np.asarray(ic.flux(E * u.eV, 0).value)
+    assert np.isfinite(out["1"]).all() and (out["1"] > 0).any()
+    rel = np.abs(out["1"] - out["0"]) / np.abs(out["0"]).max(axis=1, keepdims=True)
+    print("tabulated vs evaluated: max |diff| / max|row| = %.3g, identical %d of %d" %
+          (rel.max(), (out["1"] == out["0"]).sum(), out["0"].size))
+    assert_allclose(out["1"], out["0"], rtol=1e-13, atol=0)
 
 
 def test_abi_table_interleave(na):
