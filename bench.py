@@ -45,15 +45,17 @@ ALGO = {
 }
 # flop-equivalents per launch-walker of the two hot kernels (op-count convention of
 # a node of Synchrotron 50 eq., a segment of a table reduction 30 eq.)
+SSC_SEG_EQ = 34.0 if os.environ.get("NAIMA_AMD_SSC_TABLE", "1") == "0" else 30.0
 KERNEL_FLOP_EQ = {
     "cfg3": {"synchrotron": 64 * 570 * 50.0, "integrate_tables": 64 * 3 * 370 * 30.0},
     "cfg2": {"synchrotron": 179 * 300 * 50.0},
     "cfg1": {"integrate_tables": 28 * 570 * 30.0},
     "cfg5": {"integrate_tables": 28 * 600 * 30.0},
-    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 34 eq. each: per
-    # walker a reciprocal (20) + mul, add, sub, cmp, three fma (10); its share (1/16: a wave
-    # serves 16 walkers) of the Aharonian-Atoyan kernel (12) and its logarithm (20 + 24) = 4
-    "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * 34.0},
+    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 30 eq. each: per
+    # walker a reciprocal (20) + mul, add, sub, cmp, three fma (10).  (The Aharonian-Atoyan
+    # kernel and its logarithm come from the table built once per sampler; evaluated per step
+    # -- NAIMA_AMD_SSC_TABLE=0 -- a walker's 1/16 share of them is another 4.)
+    "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * SSC_SEG_EQ},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
 KERNEL_SYMBOL = {"half_step": "k_half_step",  # (k_half_step_run when the loop is resident) "integrate_tables": "k_integrate_tables",
@@ -129,7 +131,7 @@ def executed_flop_eq(name, raw, coords):
             if prev is not None:
                 live += int((on | prev).sum())
             prev = on
-        out["ic_seed_walkers"] = live * 34.0
+        out["ic_seed_walkers"] = live * SSC_SEG_EQ
         return out
     if "synchrotron" not in out:
         return out
@@ -490,7 +492,9 @@ def main():
                                           "from the final ensemble's B, mean over walkers; "
                                           "the SSC seed kernel (cfg4) is credited with the "
                                           "seed-axis segments inside the Aharonian-Atoyan "
-                                          "kernel's windows, 34 eq. each"}
+                                          "kernel's windows, %g eq. each (the reciprocal's "
+                                          "20 are five instructions on this chip: an op-count "
+                                          "convention, not pipe utilisation)" % SSC_SEG_EQ}
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out), flush=True)

@@ -210,6 +210,15 @@ static int launch_synchrotron(nh_ctx* c, const double* w, const double* dlw, con
   // for tw = 64 / 32 / 22; C=8: 21.3 / 20.7 / 20.7) -- the kernel is bound by its total
   // instruction count, not by how the blocks are cut
   int tw = 64;
+  // ... for one tile per walker.  Several tiles per walker (cfg4: 261 data + 100 seed
+  // energies, 128 walkers) go faster as 512-thread workgroups of ~33 energies, two per CU, one's
+  // set-up and reduction beside the other's nodes: 63.0 -> 53.3 us mean of cfg4's two launches
+  // (C, tw = 8, 44: 58.3; 8, 22: 57.4; 16, 33: 61.6; 4, 64: 84.4)
+  if (nE > 64 && !L) {
+    C = min(C, 8);
+    const int kt = (nE + 32) / 33;
+    tw = (nE + kt - 1) / kt;
+  }
   static const int ov_tw = nh_env_int("NH_SYN_TW", 0);
   if (ov_tw > 0) tw = ov_tw;
   if (L) tw = 64;

@@ -7,6 +7,8 @@
 // batched call builds them ONCE per call (n_E*n_x elements, microseconds) and
 // spends the per-walker work in the reduction.  Nothing is cached across calls.
 #include "nh_common.h"
+#include <algorithm>
+#include <vector>
 #include "nh_ic.h"
 #include "nh_pion.h"
 #include "nh_syn.h"
@@ -390,13 +392,17 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
 // so one of them misses and the others hit the CU's L1) instead of ~80 instructions of kernel
 // + logarithm, and the loop runs over the tile's window [s_lo, s_hi) instead of testing every
 // node for it (45 % of cfg4's (gamma, E, s) triples are outside).
-//   table = int2 win[n_E * ntile] (padded to 256 B) | double2 F[n_E * ntile][n_s][64]:
+//   table = int2 win[n_E * ntile] | int order[n_E * ntile] (padded to 256 B) |
+//           double2 F[n_E * ntile][n_s][64]:
 //   F[..][s][lane] = { fic at seed node s,  ln(fic_s / fic_{s-1}) / ln(eps_s / eps_{s-1}) }
+//   order = the (E, gamma tile) pairs by decreasing window length: a workgroup's time is
+//   proportional to it (0 ... n_s - 1 segments), and the longest ones dispatched first leave
+//   the short ones to fill the end of the launch
 // ---------------------------------------------------------------------------
 typedef double ssc_d2 __attribute__((ext_vector_type(2)));
 
-static inline size_t ssc_table_win_bytes(int nE, int ntile) {
-  return (((size_t)nE * ntile * sizeof(int2)) + 255) & ~(size_t)255;
+static inline size_t ssc_table_win_bytes(int nE, int ntile) {  // win + order
+  return (((size_t)nE * ntile * (sizeof(int2) + sizeof(int))) + 255) & ~(size_t)255;
 }
 
 __global__ __launch_bounds__(512) void k_ssc_table(const double* __restrict__ gam, int nG,
@@ -449,14 +455,16 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG, int nE,
     const double* __restrict__ rec, int ns, int ntile, int groups, int ngchunk,
-    const ssc_d2* __restrict__ F, const int2* __restrict__ win, double* __restrict__ partial) {
+    const ssc_d2* __restrict__ F, const int2* __restrict__ win, const int* __restrict__ order,
+    double* __restrict__ partial) {
   constexpr int REC = SSC_REC(W);
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
-  const int tk = (by / ngchunk) * 8 + bx;
+  const int slot = (by / ngchunk) * 8 + bx;
   const int grp = (by % ngchunk) * C + ch;
-  if (tk >= nE * ntile || grp >= groups) return;
+  if (slot >= nE * ntile || grp >= groups) return;
+  const int tk = __builtin_amdgcn_readfirstlane(order[slot]);
   const int k = tk / ntile, tile = tk - k * ntile;
   const int w0 = grp * W;
   const int i = tile * SSC_TILE + lane;  // this lane's node
@@ -603,6 +611,20 @@ extern "C" int nh_ssc_table(nh_ctx* c, const double* gam, int nG, const double* 
   hipLaunchKernelGGL(k_ssc_table, dim3(ntile, (nE + 7) / 8), dim3(512), 0, c->stream, gam, nG,
                      E_eV, nE, seed_E, ns, ntile, F, win);
   NH_CHECK_HIP(hipGetLastError());
+  // longest windows first (once per table: a round trip through the host is fine here)
+  const int ntk = nE * ntile;
+  std::vector<int2> hw((size_t)ntk);
+  NH_CHECK_HIP(hipMemcpyAsync(hw.data(), win, (size_t)ntk * sizeof(int2), hipMemcpyDeviceToHost,
+                              c->stream));
+  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
+  std::vector<int> ord((size_t)ntk);
+  for (int t = 0; t < ntk; ++t) ord[(size_t)t] = t;
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+    return hw[(size_t)a].y - hw[(size_t)a].x > hw[(size_t)b].y - hw[(size_t)b].x;
+  });
+  NH_CHECK_HIP(hipMemcpyAsync(win + ntk, ord.data(), (size_t)ntk * sizeof(int),
+                              hipMemcpyHostToDevice, c->stream));
+  NH_CHECK_HIP(hipStreamSynchronize(c->stream));
   return NH_OK;
 }
 
@@ -631,6 +653,7 @@ extern "C" int nh_ic_seed_walkers_tab(nh_ctx* c, const double* w, const double* 
   double* rec = static_cast<double*>(sc);
   double* partial = rec + nd + SSC_REC(W);
   const int2* win = static_cast<const int2*>(table);
+  const int* order = reinterpret_cast<const int*>(win + (size_t)nE * ntile);
   const ssc_d2* F = reinterpret_cast<const ssc_d2*>(static_cast<const char*>(table) +
                                                     ssc_table_win_bytes(nE, ntile));
   nh_prof_scope ps(c, NH_K_SSC);
@@ -640,11 +663,11 @@ extern "C" int nh_ic_seed_walkers_tab(nh_ctx* c, const double* w, const double* 
   if (W == 16) {
     hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 16>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
-                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, partial);
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, partial);
   } else {
     hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 8>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
-                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, partial);
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, partial);
   }
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,

@@ -104,6 +104,27 @@ def test_abi_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) == set(declared)
 
 
+def test_ssc_table_size_is_what_the_layout_says():
+    """nh_ssc_table_bytes (host arithmetic only): window + dispatch order per (energy, gamma
+    tile), padded to 256 bytes, then 64 lanes x 16 bytes per (energy, tile, seed node) -- the
+    gamma grid in tiles of 63 segments; cfg4's grids 374 MB; degenerate sizes give 0"""
+    from naima_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.nh_ssc_table_bytes.restype = ctypes.c_longlong
+    lib.nh_ssc_table_bytes.argtypes = [ctypes.c_int] * 3
+
+    def expect(nG, nE, ns):
+        ntile = (nG - 1 + 62) // 63
+        head = (nE * ntile * 12 + 255) // 256 * 256
+        return head + nE * ntile * ns * 64 * 16
+
+    for nG, nE, ns in [(869, 261, 100), (64, 1, 2), (65, 3, 7), (2, 5, 9), (3000, 70, 30)]:
+        assert lib.nh_ssc_table_bytes(nG, nE, ns) == expect(nG, nE, ns)
+    assert lib.nh_ssc_table_bytes(869, 261, 100) == 374_213_632
+    assert lib.nh_ssc_table_bytes(1, 5, 9) == 0 and lib.nh_ssc_table_bytes(10, 0, 9) == 0
+    assert lib.nh_ssc_table_bytes(10, 5, 1) == 0
+
+
 def test_no_cpu_fallback():
     """without a GPU every compute path must raise, never silently fall back"""
     from naima_amd import _lib
