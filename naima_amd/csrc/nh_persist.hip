@@ -71,6 +71,11 @@ struct hs_run {
   // items pulled last decide how far apart the waves reach the barrier (cfg3: 18.9 -> 18.6 us of
   // items + wait); 0 = the two kinds alternate as in k_half_step
   int spin_limit, order;
+  // synchrotron nodes per thread and work item.  The plan's 10 suit a launch per half-step and
+  // workgroups that share a walker; one resident workgroup per walker runs fastest on items
+  // three times that long (cfg3, us per 40 half-steps: 1 015 at 10, 981 at 16, 975 at 24, 959
+  // at 30 and at 40; two workgroups per walker -- cfg2 -- 901 at 5, 885 at 10, 914 at 16)
+  int syn_nodes, pad_;
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
         const bool syn_zero = !(nz >> H.syn_grid & 1);
         if (nA > 0 && !syn_zero) {
-          Cd = (hi[HI_LIVE] / nA + D.syn_nodes - 1) / D.syn_nodes;
+          Cd = (hi[HI_LIVE] / nA + R.syn_nodes - 1) / R.syn_nodes;
           Cd = min(max(Cd, 1), D.syn_cdmax);
           nS = (nA * Cd + 63) >> 6;
         }
@@ -938,6 +943,11 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   R.o_olds = off; off += 128;
   R.o_lcl = off; off += H.nE + 1;
   R.order = nh_env_int("NH_RUN_ORDER", 2);
+  R.syn_nodes = H.C.syn_nodes;
+  if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = 32;
+  if (P->split == 2 && R.syn_nodes < 10) R.syn_nodes = 10;  // (cfg2: 901 -> 885 us; 914 at 16)
+  R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
+  NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
   const void* fn = H.syn_grid >= 0 ? (const void*)k_half_step_run<true> : (const void*)k_half_step_run<false>;

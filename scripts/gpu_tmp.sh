@@ -1,10 +1,18 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/syn; rm -rf $O; mkdir -p $O
-for v in "16 64" "8 64" "8 44" "8 33" "16 44" "16 33" "4 64" "8 22"; do set -- $v
-NH_SYN_C=$1 NH_SYN_TW=$2 timeout 300 python bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run --min-time 0.2 > $O/b_$1_$2.json 2> $O/b_$1_$2.err
+O=gpurun_out/sweep; rm -rf $O; mkdir -p $O
+run() { tag=$1; shift; wl=$1; shift
+env "$@" timeout 300 python bench.py $wl --steps 20 --warmup 5 --no-cpu --min-time 0.4 > $O/$tag.json 2> $O/$tag.err
 python - <<PY
 import json
-d=json.load(open('$O/b_$1_$2.json'))
-print('$1 $2', round(d['value']), d['kernels_us_per_launch'])
+try:
+    d=json.load(open('$O/$tag.json')); print('$tag', round(d['value']), round(d['value_without_blobs']), d['kernels_us_per_launch'].get('k_half_step'))
+except Exception as e: print('$tag ERR', e)
 PY
-done
+}
+run base "--workload cfg3" A=1
+run hs24 "--workload cfg3" NH_HS_SYN_NODES=24
+run run10 "--workload cfg3" NH_RUN_SYN_NODES=10
+run run30 "--workload cfg3" NH_RUN_SYN_NODES=30
+run run40 "--workload cfg3" NH_RUN_SYN_NODES=40
+run hs40 "--workload cfg3" NH_HS_SYN_NODES=40
+run base2 "--workload cfg3" A=1
