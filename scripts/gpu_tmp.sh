@@ -1,20 +1,18 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/sweep; rm -rf $O; mkdir -p $O
-run() { tag=$1; shift
-env "$@" timeout 300 python bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run --min-time 0.2 > $O/$tag.json 2> $O/$tag.err
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/icache; rm -rf $O; mkdir -p $O
+for w in cfg3 cfg5; do
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE --output-format csv -d $O -o ${w}_sqd -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --workload $w --no-cpu --no-blobs-run --min-time 0.1 > $O/${w}_bench.json 2> $O/err_$w.log ); echo "$w exit $?"
+done
 python - <<PY
-import json
-try:
-    d=json.load(open('$O/$tag.json')); print('$tag', round(d['value']), d['kernels_us_per_launch'])
-except Exception as e: print('$tag ERR', e)
+import csv, collections, glob
+for f in sorted(glob.glob("$O/*_counter_collection.csv")):
+    rows = list(csv.DictReader(open(f)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
+    for r in rows:
+        k = r['Kernel_Name'].split('(')[0]
+        agg[k][r['Counter_Name']] += float(r['Counter_Value']); n[k][r['Counter_Name']] += 1
+    for k in agg:
+        if 'half_step' in k or 'epilogue' in k:
+            print(f.split('/')[-1][:8], k, {c: round(agg[k][c]/n[k][c]) for c in agg[k]}, dict(n[k]))
 PY
-}
-run base A=1
-run W1 NH_INT_W=1
-run W4 NH_INT_W=4
-run C8 NH_INT_C=8
-run W1C8 NH_INT_W=1 NH_INT_C=8
-run W4C8 NH_INT_W=4 NH_INT_C=8
-run S2 NH_INT_SPLIT=2
-run W1S2 NH_INT_W=1 NH_INT_SPLIT=2
-run W4C4 NH_INT_W=4 NH_INT_C=4
