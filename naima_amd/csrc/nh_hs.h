@@ -391,7 +391,7 @@ __device__ __forceinline__ void hs_syn_item(int ix, int lane, int nA, int Cd, in
       auto node = [&](int sn, double& u, double& P) {
         const double x = q * ig2[sn];
         P = syn_P1(cbq * ig23[sn]);
-        u = wr[sn] * (P * nh_exp_tab(-fmin(x, 800.0), T64));
+        u = wr[sn] * (P * nh_exp_tab(-x, T64));  // (x <= 746: the range starts at the first live node)
       };
       double u1, P1;
       node(s0, u1, P1);

@@ -112,13 +112,19 @@ __device__ __forceinline__ double nh_exp_tab(double x, const double* __restrict_
 
 // P(x) of AKP10 Eq. D7 from cb = cbrt(x) with ONE reciprocal square root for both
 // 1/sqrt(1 + 3.4 cb^2) and 1/gt3:  P = 1.808 cb gt2 rsqrt(gt3^2 (1 + 3.4 cb^2))
+// (ONE Newton step on the single-precision seed: 1.5 e0^2 = 2e-14 relative on P, next to the
+// 1.4e-13 of the three-term ln(P2/P1) below -- three instructions of a node's 73)
+__device__ __forceinline__ double nh_rsqrt1(double a) {
+  const double y = (double)__builtin_amdgcn_rsqf((float)a);
+  return y * fma(-(0.5 * a) * y, y, 1.5);
+}
 __device__ __forceinline__ double syn_P1(double cb) {
   const double cb2 = cb * cb;
   const double cb4 = cb2 * cb2;
   const double t34 = fma(3.4, cb2, 1.0);
   const double gt2 = fma(0.347, cb4, fma(2.210, cb2, 1.0));
   const double gt3 = fma(0.217, cb4, fma(1.353, cb2, 1.0));
-  return ((1.808 * cb) * gt2) * nh_rsqrt((gt3 * gt3) * t34);
+  return ((1.808 * cb) * gt2) * nh_rsqrt1((gt3 * gt3) * t34);
 }
 
 // ln(P2/P1) for neighbouring nodes: 2 atanh(s), s = (P2-P1)/(P2+P1).  Naima's default grids

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * C) void k_synchrotron(
         const double x = q * ig2[sn];
         const double wn = wr[sn];
         const double Pv = syn_P1(cbq * ig23[sn]);
-        const double ev = nh_exp_tab(-fmin(x, 800.0), T64);
+        const double ev = nh_exp_tab(-x, T64);  // (x <= 746 from the first live node on)
         u = wn * (Pv * ev);  // gamma nelec dNdE / CS1, :335-338 (every node of the range is live)
         P = Pv;
       };
