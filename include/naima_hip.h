@@ -569,6 +569,37 @@ int nh_half_step_run(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run* run, 
                      double* const* hist_blobs /*host array of device pointers, or NULL*/,
                      long long hist_row0, long long hist_cap);
 int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
+/* ---- the resident loop over an ensemble SHARED by the GPUs of a node (2 .. 8 ranks, one process
+ * per GPU).  Replaces, for walkers sharded as in the per-launch loop (rank r proposes positions
+ * [lo, lo + nloc) of every half-step; the reference's analogue is Pool(threads) over a fixed
+ * ensemble, core.py:446-457), the all-gather between the launches of a half-step: a mover stores
+ * its walker's record into EVERY rank's ring (system-scope stores; xGMI for the others), consumers
+ * poll their local ring as on one GPU.  No collective and no launch per half-step.
+ *   create_shared: plan with lo / nloc = this rank's block (do_accept not needed), rings in
+ *                  fine-grained device memory;
+ *   export / attach: the 64-byte hipIpc handle of a rank's rings, to be carried to every other
+ *                  rank by the caller's control plane and attached there (all before the first run);
+ *   probe:         `rounds` tagged exchanges with every peer inside ONE launch -- status 0 only if
+ *                  stores another GPU makes while the kernel runs reach its polling loads (call on
+ *                  every rank at the same time; bounded like every wait of the loop);
+ *   hist_flags:    where nh_half_step_run keeps who-moved-what of the following launches,
+ *                  [hist_cap][N] ints preset to -1 by the caller: 0 / 1 = this rank moved the
+ *                  walker in that step and rejected / accepted (history rows and blobs are written
+ *                  by the mover only, on its own GPU; blob rows of rejected moves are NOT filled);
+ *   counters:      nacc_own[N] (moves this rank accepted; the plan's naccepted is not touched) and
+ *                  curstamp[N] (-1, or the step count at which this rank last accepted a move of
+ *                  the walker: whoever holds the largest stamp holds the walker's current blobs in
+ *                  its blobs[].cur); reset bit 0 / 1 clears the first / second afterwards.
+ * After a shared launch coords / logp hold the whole ensemble on every rank. */
+int nh_half_step_run_create_shared(nh_ctx* ctx, nh_halfstep_plan* plan, int rank, int nrank,
+                                   nh_halfstep_run** out);
+int nh_half_step_run_export(nh_ctx* ctx, nh_halfstep_run* run, void* handle64);
+int nh_half_step_run_attach(nh_ctx* ctx, nh_halfstep_run* run, int peer, const void* handle64);
+int nh_half_step_run_probe(nh_ctx* ctx, nh_halfstep_run* run, int rounds, int* status,
+                           double* us_per_round);
+int nh_half_step_run_hist_flags(nh_halfstep_run* run, int* flags);
+int nh_half_step_run_counters(nh_ctx* ctx, nh_halfstep_run* run, int* nacc_own, int* curstamp,
+                              int reset);
 int nh_half_step_run_info(const nh_halfstep_run* run, int* grid, int* threads,
                           long long* lds_bytes);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per

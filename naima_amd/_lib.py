@@ -117,6 +117,12 @@ _SIGS = {
     "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],
     "nh_half_step_run_status": [_dp, _dp, C.POINTER(_i)],
+    "nh_half_step_run_create_shared": [_dp, _dp, _i, _i, C.POINTER(_dp)],
+    "nh_half_step_run_export": [_dp, _dp, _dp],
+    "nh_half_step_run_attach": [_dp, _dp, _i, _dp],
+    "nh_half_step_run_probe": [_dp, _dp, _i, C.POINTER(_i), C.POINTER(C.c_double)],
+    "nh_half_step_run_hist_flags": [_dp, _dp],
+    "nh_half_step_run_counters": [_dp, _dp, _dp, _dp, _i],
     "nh_half_step_run_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_run_stamps": [_dp, _dp, _dp],
     "nh_half_step_run_destroy": [_dp, _dp],

@@ -47,6 +47,9 @@
 #define HS_RUN_MAX_STEPS 32  // steps per launch (one block of moves); ring rows = this + 1
 #define HS_RUN_ERR_TIMEOUT 1
 #define HS_RUN_ERR_PEER 2
+#define HS_RUN_ERR_LAST_ROW 3  // (epilogue of a shared ensemble: a rank's last records never came)
+#define HS_RUN_MAX_RANKS 8     // GPUs of one node that may share an ensemble
+#define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
 
 struct hs_run {
   unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
@@ -76,6 +79,15 @@ struct hs_run {
   // three times that long (cfg3, us per 40 half-steps: 1 015 at 10, 981 at 16, 975 at 24, 959
   // at 30 and at 40; two workgroups per walker -- cfg2 -- 901 at 5, 885 at 10, 914 at 16)
   int syn_nodes, pad_;
+  // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
+  // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
+  // (peer[rank] == ring); a mover stores its walker's record into every one of them
+  int nrank, rank;
+  unsigned long long* peer[HS_RUN_MAX_RANKS];
+  int* nacc_own;   // acceptance counters of the moves THIS rank made (the plan's are replicated)
+  int* hacc;       // with a history: [hcap][N] -1 | 0 | 1 = not moved by this rank | rejected | accepted
+  int* curstamp;   // with blobs: [N] stamp of the last move this rank accepted for the walker
+  int stamp0, pad2_;  // stamp of the launch's first step (counts the steps of all launches)
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -85,6 +97,13 @@ __device__ __forceinline__ unsigned long long hs_ld_sc1(const unsigned long long
 }
 __device__ __forceinline__ void hs_st_sc1(unsigned long long* p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// system scope (sc0 sc1): records that another GPU writes into / reads from fine-grained memory
+__device__ __forceinline__ unsigned long long hs_ld_sys(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void hs_st_sys(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ unsigned hs_tag(unsigned seq, int row) {
   return (seq << 8) | (unsigned)(row + 1);  // (never 0: a zeroed ring matches nothing)
@@ -148,7 +167,7 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
       R.dbg[((long long)blockIdx.x * 64 + it) * 8 + (k)] = (long long)wall_clock64();   \
   } while (0)
 
-template <bool SYN>
+template <bool SYN, bool MULTI>
 __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs_run R) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
@@ -162,6 +181,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
   const int GRn = 2 * (ndim + 1);  // granules of a record that carry data (<= 32)
   const bool lik_wave = wv == (nwv > 1 ? 1 : 0);
   const int npk8 = H.F.npk8;
+  constexpr bool multi = MULTI;  // the ensemble is shared with other GPUs (an instance of its
+                                 // own: the one-GPU kernel is the code it was)
 
   // =========================== once per launch ==============================================
   if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
@@ -233,7 +254,9 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       if (lane < GRn) {
         const int d = lane >> 1;
         const double v = d < ndim ? H.coords[(long long)w * ndim + d] : H.logp[w];
-        hs_st_sc1(R.ring + (long long)w * R.gr + lane, hs_granule(v, lane, tag0));
+        unsigned long long* dst = R.ring + (long long)w * R.gr + lane;
+        if (multi) hs_st_sys(dst, hs_granule(v, lane, tag0));  // (every rank: its own copy)
+        else hs_st_sc1(dst, hs_granule(v, lane, tag0));
       }
     }
   }
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         int spins = 0, bad = 0;
         for (;;) {
           if (!ok) {
-            v = hs_ld_sc1(src);
+            v = multi ? hs_ld_sys(src) : hs_ld_sc1(src);
             ok = (unsigned)(v >> 32) == want;
           }
           if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
@@ -789,8 +812,17 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         if (lane < GRn) {
           const int d = lane >> 1;
           val = d < ndim ? (ok ? qs[d] : olds[d]) : (ok ? acc : oldlp);
-          hs_st_sc1(R.ring + ((long long)(tl + 1) * N + me2) * R.gr + lane,
-                    hs_granule(val, lane, hs_tag(R.seq, tl + 1)));
+          const long long roff = ((long long)(tl + 1) * N + me2) * R.gr + lane;
+          const unsigned long long gv = hs_granule(val, lane, hs_tag(R.seq, tl + 1));
+          if (!multi) {
+            hs_st_sc1(R.ring + roff, gv);
+          } else {
+            // into every rank's ring, this one's included (constant indices: a dynamic one
+            // would make the compiler copy the argument block to scratch)
+#pragma unroll
+            for (int pr = 0; pr < HS_RUN_MAX_RANKS; ++pr)
+              if (pr < R.nrank) hs_st_sys(R.peer[pr] + roff, gv);
+          }
         }
         if (R.dbg && lane == 0 && blockIdx.x < 256 && it < 64)
           R.dbg[((long long)blockIdx.x * 64 + it) * 8 + 7] = (long long)wall_clock64();
@@ -803,6 +835,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         }
         if (lane == 0) {
           R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
+          if (multi && R.hacc && hist) R.hacc[hrow * N + me2] = ok ? 1 : 0;
           if (acc != acc) atomicAdd(H.done + 2, 1);  // (see nh_half_step_nan_count)
         }
         if (ok) {  // the accepted position's blobs
@@ -816,9 +849,13 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
               } else if (lane == 0) {
                 dst[0] = nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom]);
               }
-            } else {  // no history: the current-blob array itself.  Several workgroups write a
-              // walker's row in the course of a launch: write-through, so that the LAST
-              // write is the one memory keeps (dirty lines of different L2s have no order)
+            }
+            if (!hb || multi) {
+              // no history: the current-blob array itself (also in a shared ensemble, whose
+              // ranks each keep the blobs of the moves they accepted, stamped: merged by stamp
+              // when somebody asks).  Several workgroups write a walker's row in the course of
+              // a launch: write-through, so that the LAST write is the one memory keeps (dirty
+              // lines of different L2s have no order)
               unsigned long long* dst = reinterpret_cast<unsigned long long*>(bl.cur + (long long)me2 * bl.m);
               if (bl.kind == 0) {
                 for (int t = lane; t < bl.m; t += 64)
@@ -829,6 +866,9 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
               }
             }
           }
+          if (multi && R.curstamp && lane == 0 && D.nblob > 0)
+            __hip_atomic_store(R.curstamp + me2, R.stamp0 + tl, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
@@ -847,22 +887,43 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   for (long long e = gid; e < (long long)N * (ndim + 1); e += gsz) {
     const int w = (int)(e / (ndim + 1)), d = (int)(e % (ndim + 1));
     const unsigned long long* rec = R.ring + ((long long)nsteps * N + w) * R.gr + 2 * d;
-    const unsigned long long lo = rec[0], hiw = rec[1];
+    unsigned long long lo = rec[0], hiw = rec[1];
+    if (R.nrank > 1) {
+      // a shared ensemble: this rank's launch is over, another rank's last movers may not be --
+      // their records are recognised by their tags like any other (bounded wait)
+      const unsigned want = hs_tag(R.seq, nsteps);
+      int spins = 0;
+      for (;;) {
+        lo = hs_ld_sys(rec);
+        hiw = hs_ld_sys(rec + 1);
+        if ((unsigned)(lo >> 32) == want && (unsigned)(hiw >> 32) == want) break;
+        if (++spins > R.spin_limit ||
+            ((spins & 255) == 0 &&
+             __hip_atomic_load(R.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          __hip_atomic_store(R.status, HS_RUN_ERR_LAST_ROW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
     const double v = __hiloint2double((int)(unsigned)hiw, (int)(unsigned)lo);
     if (d < ndim) const_cast<double*>(H.coords)[(long long)w * ndim + d] = v;
     else const_cast<double*>(H.logp)[w] = v;
   }
-  if (D.naccepted)
+  int* const nacc = R.nrank > 1 ? R.nacc_own : D.naccepted;
+  if (nacc)
     for (long long w = gid; w < N; w += gsz) {
       int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = R.accw[(long long)(t < nsteps ? t : nsteps - 1) * N + w];
       int a = 0;
 #pragma unroll
-      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += t < nsteps ? f[t] : 0;
-      D.naccepted[w] += a;
+      for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += (t < nsteps && f[t] > 0) ? 1 : 0;
+      nacc[w] += a;  // (a shared ensemble: flags of walkers other ranks moved are -1)
     }
-  const bool hist = R.hcoords != nullptr;
+  // (a shared ensemble: the blobs of a walker's earlier steps may be on another rank -- the
+  // rows of rejected proposals are filled when the ranks' histories are merged)
+  const bool hist = R.hcoords != nullptr && R.nrank <= 1;
   for (int b = 0; b < D.nblob; ++b) {
     const nh_hs_blob& bl = D.blob[b];
     double* hb = hist ? R.hblob[b] : nullptr;
@@ -909,14 +970,30 @@ struct nh_halfstep_run {
   size_t lds_bytes;
   int grid, threads;
   unsigned seq;
+  // a shared ensemble (nh_half_step_run_create_shared): `base` is ONE fine-grained allocation
+  // { HS_RUN_HEAD granules of probe slots | ring of even launches | ring of odd launches }
+  // that the other ranks map (hipIpc), peer_base[p] is rank p's as mapped here
+  int nrank, rank;
+  unsigned long long* base;
+  unsigned long long* peer_base[HS_RUN_MAX_RANKS];
+  size_t ring_elems, base_bytes;
+  int* nacc_own;
+  int* curstamp;
+  int* hacc;          // where the NEXT launch keeps its history flags (nh_half_step_run_hist_flags)
+  int* probe_out;
+  long long steps_total;
 };
 
-extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run** out) {
+static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh_halfstep_run** out) {
   NH_REQUIRE(c && P && out, "bad argument");
   const hs_hot& H = P->hot;
-  NH_REQUIRE(H.C.do_accept, "the resident loop needs the in-launch accept");
+  const bool shared = nrank > 1;
+  NH_REQUIRE(shared || H.C.do_accept, "the resident loop needs the in-launch accept");
   NH_REQUIRE(H.ndim <= 15, "at most 15 fit parameters in a record (32 granules per wave half)");
-  NH_REQUIRE(H.lo == 0 && H.nloc == H.ns, "the resident loop moves whole half-ensembles");
+  NH_REQUIRE(shared || (H.lo == 0 && H.nloc == H.ns), "the resident loop moves whole half-ensembles");
+  NH_REQUIRE(!shared || (nrank <= HS_RUN_MAX_RANKS && rank >= 0 && rank < nrank && H.nloc >= 1 &&
+                         H.lo >= 0 && H.lo + H.nloc <= H.ns),
+             "a shared ensemble: at most 8 ranks, each with at least one walker of every half-step");
   NH_REQUIRE(H.C.lp == nullptr, "a prior evaluated by a launch of its own cannot ride in the resident loop");
   for (int q = 0; q < H.C.ncomp; ++q)
     NH_REQUIRE(H.C.comp[q].off >= 0, "every component of the model must be produced inside the launch");
@@ -950,7 +1027,9 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
-  const void* fn = H.syn_grid >= 0 ? (const void*)k_half_step_run<true> : (const void*)k_half_step_run<false>;
+  const void* fn = H.syn_grid >= 0
+                       ? (shared ? (const void*)k_half_step_run<true, true> : (const void*)k_half_step_run<true, false>)
+                       : (shared ? (const void*)k_half_step_run<false, true> : (const void*)k_half_step_run<false, false>);
   if (lds > 64 * 1024)
     NH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // every workgroup of the launch has to be resident (they wait for each other's records)
@@ -976,9 +1055,36 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   Q->seq = 1;
   Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
   Q->xspec = nullptr; Q->tick = nullptr; Q->split = P->split;
-  const size_t ring_bytes = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr * sizeof(unsigned long long);
-  hipError_t e = hipMalloc(&Q->ring, ring_bytes);
-  if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
+  Q->nrank = shared ? nrank : 1; Q->rank = shared ? rank : 0;
+  Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
+  Q->probe_out = nullptr; Q->steps_total = 0;
+  for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
+  Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
+  const size_t ring_bytes = Q->ring_elems * sizeof(unsigned long long);
+  hipError_t e = hipSuccess;
+  if (shared) {
+    // Fine-grained device memory: what another GPU stores into it over xGMI is visible to a
+    // kernel that is already running here, and system-scope loads are served from memory, not
+    // from an L2 that the incoming writes never pass (coarse-grained memory is coherent with
+    // other agents at kernel boundaries only).  NH_RUN_SHARED_ALLOC = 1 fine-grained (default) |
+    // 2 uncached | 0 plain hipMalloc (two processes on ONE GPU: same memory, same L2s).
+    Q->base_bytes = HS_RUN_HEAD * sizeof(unsigned long long) + 2 * ring_bytes;
+    const int how = nh_env_int("NH_RUN_SHARED_ALLOC", 1);
+    void* b = nullptr;
+    if (how == 0) e = hipMalloc(&b, Q->base_bytes);
+    else e = hipExtMallocWithFlags(&b, Q->base_bytes, how == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+    Q->base = static_cast<unsigned long long*>(b);
+    if (e == hipSuccess) e = hipMemset(Q->base, 0, Q->base_bytes);
+    Q->peer_base[Q->rank] = Q->base;
+    if (e == hipSuccess) e = hipMalloc(&Q->nacc_own, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(Q->nacc_own, 0, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&Q->curstamp, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(Q->curstamp, 0xFF, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&Q->probe_out, 4 * sizeof(int));
+  } else {
+    e = hipMalloc(&Q->ring, ring_bytes);
+    if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
+  }
   if (e == hipSuccess) e = hipMalloc(&Q->status, sizeof(int));
   if (e == hipSuccess) e = hipMemset(Q->status, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
@@ -995,6 +1101,10 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
       }
   if (e != hipSuccess) {
     if (Q->ring) (void)hipFree(Q->ring);
+    if (Q->base) (void)hipFree(Q->base);
+    if (Q->nacc_own) (void)hipFree(Q->nacc_own);
+    if (Q->curstamp) (void)hipFree(Q->curstamp);
+    if (Q->probe_out) (void)hipFree(Q->probe_out);
     if (Q->status) (void)hipFree(Q->status);
     if (Q->accw) (void)hipFree(Q->accw);
     if (Q->dbg) (void)hipFree(Q->dbg);
@@ -1006,8 +1116,154 @@ extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfst
   Q->R.ring = Q->ring; Q->R.status = Q->status; Q->R.accw = Q->accw; Q->R.dbg = Q->dbg;
   Q->R.xspec = Q->xspec; Q->R.tick = Q->tick;
   Q->R.spin_limit = 1 << 22;  // ~1 s of polling: a record that has not come by then never will
+  // (a shared ensemble: the ranks' hosts launch on their own clocks; a rank may have to wait for
+  // another one's launch to START -- ~16 s)
+  if (shared) Q->R.spin_limit = 1 << 26;
   if (const char* sl = getenv("NH_RUN_SPIN_LIMIT")) Q->R.spin_limit = atoi(sl) > 0 ? atoi(sl) : Q->R.spin_limit;
+  Q->R.nrank = Q->nrank; Q->R.rank = Q->rank;
+  Q->R.nacc_own = Q->nacc_own; Q->R.curstamp = Q->curstamp;
   *out = Q;
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_create(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run** out) {
+  return hs_run_create(c, P, 0, 1, out);
+}
+
+// ---- The ensemble across GPUs -----------------------------------------------------------------
+// Walkers shard over the ranks of a node as in the per-launch loop (rank r proposes positions
+// [lo, lo + nloc) of every half-step; the move stream is replicated), but the one exchange of a
+// half-step -- the new state of every moved walker -- is no longer a collective between launches:
+// a mover stores its walker's record (96 bytes for cfg3) into EVERY rank's ring, its own
+// included, with system-scope write-through stores (over xGMI for the others), and consumers
+// poll their LOCAL ring exactly as on one GPU.  Tags make a record that has not arrived yet
+// unmistakable; nothing else is exchanged and no rank waits for more than the two records a
+// proposal needs.  Rings alternate between two buffers by the launch number's parity: a rank
+// cannot finish launch L + 1 (its epilogue needs every rank's last records of L + 1) before
+// every rank has started L + 1, i.e. finished reading launch L's ring, so whoever writes launch
+// L + 2's records into that buffer finds no reader of launch L left.  Chain history, blobs and
+// acceptance counts stay where they were produced (each rank: the moves it made, flagged in
+// `hacc`, the blobs' current values stamped) and are merged when somebody reads them.
+extern "C" int nh_half_step_run_create_shared(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank,
+                                              nh_halfstep_run** out) {
+  NH_REQUIRE(nrank >= 2, "a shared ensemble has at least two ranks");
+  return hs_run_create(c, P, rank, nrank, out);
+}
+
+// the 64-byte handle other processes map this rank's rings with
+extern "C" int nh_half_step_run_export(nh_ctx* c, nh_halfstep_run* Q, void* handle64) {
+  NH_REQUIRE(c && Q && handle64 && Q->base, "not a shared-ensemble loop");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h;
+  NH_CHECK_HIP(hipIpcGetMemHandle(&h, Q->base));
+  memcpy(handle64, &h, 64);
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_attach(nh_ctx* c, nh_halfstep_run* Q, int peer, const void* handle64) {
+  NH_REQUIRE(c && Q && handle64 && Q->base, "not a shared-ensemble loop");
+  NH_REQUIRE(peer >= 0 && peer < Q->nrank && peer != Q->rank, "bad peer rank");
+  NH_REQUIRE(Q->peer_base[peer] == nullptr, "peer attached twice");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  NH_CHECK_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  Q->peer_base[peer] = static_cast<unsigned long long*>(p);
+  return NH_OK;
+}
+
+// `rounds` exchanges of a tagged granule with every peer inside ONE launch: round r is stored
+// into slot [my rank] of every peer's head, then slot [p] of the local head is polled for every
+// peer p.  It passes only if stores made by another GPU while this kernel runs become visible
+// to its polling loads -- the property the shared loop stands on.
+struct hs_probe_args {
+  unsigned long long* peer[HS_RUN_MAX_RANKS];
+  int nrank, rank, rounds, spin_limit;
+  unsigned seq;
+  int* out;  // status (0 ok) | rounds completed | 100 MHz ticks of all rounds | spins
+};
+__global__ void k_run_probe(const hs_probe_args A) {
+  const int lane = threadIdx.x;
+  const bool on = lane < A.nrank && lane != A.rank;
+  unsigned long long* mine = nullptr;
+  unsigned long long* theirs = nullptr;
+#pragma unroll
+  for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) {
+    if (p == A.rank) mine = A.peer[p];
+    if (p == lane) theirs = A.peer[p];
+  }
+  int bad = 0, r = 0, spins_total = 0;
+  const long long t0 = wall_clock64();
+  for (r = 1; r <= A.rounds && !bad; ++r) {
+    const unsigned tag = (A.seq << 12) | (unsigned)r;
+    if (on) hs_st_sys(theirs + A.rank, ((unsigned long long)tag << 32) | (unsigned)A.rank);
+    bool ok = !on;
+    int spins = 0;
+    for (;;) {
+      if (!ok) {
+        const unsigned long long v = hs_ld_sys(mine + lane);
+        ok = (unsigned)(v >> 32) == tag && (unsigned)v == (unsigned)lane;
+      }
+      if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+      if (++spins > A.spin_limit) { bad = HS_RUN_ERR_TIMEOUT; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    spins_total += spins;
+  }
+  if (lane == 0) {
+    A.out[0] = bad;
+    A.out[1] = r - 1;
+    A.out[2] = (int)(wall_clock64() - t0);
+    A.out[3] = spins_total;
+  }
+}
+
+extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds, int* status,
+                                      double* us_per_round) {
+  NH_REQUIRE(c && Q && Q->base && status, "not a shared-ensemble loop");
+  NH_REQUIRE(rounds >= 1 && rounds < 4096, "1 .. 4095 rounds");
+  hs_probe_args A;
+  memset(&A, 0, sizeof(A));
+  for (int p = 0; p < Q->nrank; ++p) {
+    NH_REQUIRE(Q->peer_base[p] != nullptr, "a peer's rings are not attached");
+    A.peer[p] = Q->peer_base[p];
+  }
+  A.nrank = Q->nrank; A.rank = Q->rank; A.rounds = rounds;
+  A.spin_limit = Q->R.spin_limit;
+  A.seq = Q->seq++ & 0xFFFFFu;
+  A.out = Q->probe_out;
+  hipLaunchKernelGGL(k_run_probe, dim3(1), dim3(64), 0, c->stream, A);
+  NH_CHECK_HIP(hipGetLastError());
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  int o[4];
+  NH_CHECK_HIP(hipMemcpy(o, Q->probe_out, sizeof(o), hipMemcpyDeviceToHost));
+  *status = o[0];
+  if (us_per_round) *us_per_round = o[1] > 0 ? (double)o[2] * 0.01 / o[1] : 0.0;
+  return NH_OK;
+}
+
+// where the next launches of a shared ensemble keep their history flags ([hist_cap][N] ints,
+// pre-set to -1 by the caller; NULL: nowhere)
+extern "C" int nh_half_step_run_hist_flags(nh_halfstep_run* Q, int* hacc) {
+  NH_REQUIRE(Q && Q->base, "not a shared-ensemble loop");
+  Q->hacc = hacc;
+  return NH_OK;
+}
+
+// the shared loop's own bookkeeping: nacc_own[N] (moves this rank accepted since the last reset)
+// and curstamp[N] (-1, or the stamp of the last move this rank accepted for the walker) to the
+// host; reset != 0 zeroes / clears them afterwards.  Synchronises the stream.
+extern "C" int nh_half_step_run_counters(nh_ctx* c, nh_halfstep_run* Q, int* nacc_own, int* curstamp,
+                                         int reset) {
+  NH_REQUIRE(c && Q && Q->base, "not a shared-ensemble loop");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  const size_t nb = (size_t)Q->R.N * sizeof(int);
+  if (nacc_own) NH_CHECK_HIP(hipMemcpy(nacc_own, Q->nacc_own, nb, hipMemcpyDeviceToHost));
+  if (curstamp) NH_CHECK_HIP(hipMemcpy(curstamp, Q->curstamp, nb, hipMemcpyDeviceToHost));
+  if (reset & 1) NH_CHECK_HIP(hipMemset(Q->nacc_own, 0, nb));
+  if (reset & 2) NH_CHECK_HIP(hipMemset(Q->curstamp, 0xFF, nb));
   return NH_OK;
 }
 
@@ -1026,6 +1282,19 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.nslices = nslices;
   R.seq = Q->seq++ & 0xFFFFFFu;
   if (R.seq == 0) R.seq = Q->seq++ & 0xFFFFFFu;
+  if (Q->base) {  // a shared ensemble: this launch's ring, here and on every other rank
+    const size_t off = HS_RUN_HEAD + (size_t)(R.seq & 1u) * Q->ring_elems;
+    for (int p = 0; p < Q->nrank; ++p) {
+      NH_REQUIRE(Q->peer_base[p] != nullptr, "a peer's rings are not attached");
+      R.peer[p] = Q->peer_base[p] + off;
+    }
+    R.ring = R.peer[Q->rank];
+    R.hacc = hist_coords ? Q->hacc : nullptr;
+    R.stamp0 = (int)(Q->steps_total & 0x3FFFFFFF);
+    Q->steps_total += nslices / 2;
+    // (flags of walkers other ranks move stay -1)
+    NH_CHECK_HIP(hipMemsetAsync(Q->accw, 0xFF, (size_t)(nslices / 2) * R.N * sizeof(int), c->stream));
+  }
   R.hcoords = hist_coords;
   R.hlogp = hist_logp;
   R.hrow0 = hist_row0;
@@ -1037,12 +1306,15 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   {
     nh_prof_scope ps(c, NH_K_HALFSTEP);
     const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
-    if (H.syn_grid >= 0)
-      hipLaunchKernelGGL(k_half_step_run<true>, grid, dim3(Q->threads), Q->lds_bytes,
-                         c->stream, H, R);
+    const dim3 thr(Q->threads);
+    if (H.syn_grid >= 0 && Q->base)
+      hipLaunchKernelGGL((k_half_step_run<true, true>), grid, thr, Q->lds_bytes, c->stream, H, R);
+    else if (H.syn_grid >= 0)
+      hipLaunchKernelGGL((k_half_step_run<true, false>), grid, thr, Q->lds_bytes, c->stream, H, R);
+    else if (Q->base)
+      hipLaunchKernelGGL((k_half_step_run<false, true>), grid, thr, Q->lds_bytes, c->stream, H, R);
     else
-      hipLaunchKernelGGL(k_half_step_run<false>, grid, dim3(Q->threads), Q->lds_bytes,
-                         c->stream, H, R);
+      hipLaunchKernelGGL((k_half_step_run<false, false>), grid, thr, Q->lds_bytes, c->stream, H, R);
     NH_CHECK_HIP(hipGetLastError());
   }
   {
@@ -1092,7 +1364,13 @@ extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
   NH_REQUIRE(c, "ctx is NULL");
   if (!Q) return NH_OK;
   int rc = nh_sync(c);
-  if (Q->ring) (void)hipFree(Q->ring);
+  for (int p = 0; p < HS_RUN_MAX_RANKS; ++p)
+    if (Q->base && p != Q->rank && Q->peer_base[p]) (void)hipIpcCloseMemHandle(Q->peer_base[p]);
+  if (Q->base) (void)hipFree(Q->base);
+  else if (Q->ring) (void)hipFree(Q->ring);
+  if (Q->nacc_own) (void)hipFree(Q->nacc_own);
+  if (Q->curstamp) (void)hipFree(Q->curstamp);
+  if (Q->probe_out) (void)hipFree(Q->probe_out);
   if (Q->status) (void)hipFree(Q->status);
   if (Q->accw) (void)hipFree(Q->accw);
   if (Q->dbg) (void)hipFree(Q->dbg);

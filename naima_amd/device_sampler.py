@@ -194,12 +194,29 @@ class DeviceLoop:
         # plan / configuration cannot (or NAIMA_AMD_RESIDENT=0), else the handle
         self._run = None if os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0" else False
         self.resident_launches = 0
+        # ... and over an ensemble shared by several GPUs (nh_half_step_run_create_shared: movers
+        # store their walkers' records into every rank's ring; no collective per half-step).
+        # What a rank's launches leave on ITS device only -- the history rows and blobs of the
+        # moves it made, their acceptance counts, the blobs' current values (stamped) -- is
+        # merged over the control plane when somebody reads it
+        self.shared = False
+        self.shared_info = None
+        self._cur_dirty = False   # current blobs differ between ranks (merge by stamp pending)
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
     def reset(self):
-        self.flush()
+        """forget the chain and the acceptance counts (the sampler clears its host copies): the
+        history still on the device is dropped, not downloaded"""
+        self._flush_pending()
+        self.check_resident()
+        self.check_nan()
+        self.ctx.check_general()
+        self._sync_cur_blobs()
+        self.hist = []
         self.ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
+        if self.shared:
+            _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, None, None, 1))
 
     def _eval(self, qT_buf, n):
         """run the user's model on device parameters: (total DVec, blob list)"""
@@ -500,6 +517,7 @@ class DeviceLoop:
     def host_blobs(self):
         if not self.cur_blobs:
             return None
+        self._sync_cur_blobs()  # (a shared ensemble: collective -- every rank asks, or none)
         out = [cur.get().reshape((self.N,) + trail) for cur, m, _, trail in self.cur_blobs]
         for j, v in self.const_blobs:
             out.insert(j, np.full((self.N,), v))
@@ -524,7 +542,21 @@ class DeviceLoop:
                          logp=ctx.empty((iterations, N)),
                          blobs=[ctx.empty((iterations, N * m)) for _, m, _, _ in
                                 (self.cur_blobs or [])] if s.store_blobs else [])
+            if self.sharded and self.s.comm.size > 1:
+                # a shared ensemble's launches: who moved (and accepted) what, per row; the
+                # blobs as they stood before the first row (rows of rejected moves are filled
+                # from the row before when the ranks' histories are merged)
+                self._sync_cur_blobs()
+                block["own"] = ctx.empty((iterations, N), dtype=np.int32)
+                ctx.call("nh_memset", block["own"], 0xFF, block["own"].nbytes)
+                block["cur0"] = []
+                for cur, m, _, _ in (self.cur_blobs or []) if block["blobs"] else []:
+                    c0 = ctx.empty((N, m))
+                    ctx.call("nh_copy", c0, cur, 8 * N * m)
+                    block["cur0"].append(c0)
             self.hist.append(block)
+        if not (isinstance(initial_state, DeviceState) and initial_state._loop is self):
+            self._sync_cur_blobs()
         # chain history: appended on the device by nh_move_cycle when it is active for
         # the whole call, else one pair of copies per step
         dev_hist = self.fused and block is not None and not (
@@ -581,6 +613,7 @@ class DeviceLoop:
             mv["prev"] = mv["last"] = None  # (the per-launch loop takes over: see _moves_append)
         while it < iterations:
             self._flush_pending()  # (merged sharded mode) the block's last accept
+            self._sync_cur_blobs()  # (launches per half-step keep every rank's blobs whole)
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the
             # generator's page-locked ring (filled ahead by its worker thread) ----------
             # nh_moves_take's contract: only the copy of the MOST RECENT take may still be
@@ -633,6 +666,7 @@ class DeviceLoop:
                         if blob_dev_hist:
                             ctx.call("nh_half_step_append_blobs", self._plan["hs"]["plan"],
                                      block["n"] - 1)
+                    self._flush_pending()
                     self._run_resident(2 * k, 2 * g, block if dev_hist else None)
                     resident = True
                 elif (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and
@@ -746,13 +780,20 @@ class DeviceLoop:
         """can the rest of a block of moves run as ONE launch (nh_half_step_run)?  Needs the
         one-launch plan, a single rank, blobs (if kept) kept by the launch; the library has
         the last word (LDS, occupancy, the plan's shape)"""
-        if self._run is False or not self.mega or self.sharded or not self.s.use_graph:
+        if self._run is False or not self.mega or not self.s.use_graph:
+            return False
+        if self.sharded and (self.s.comm.size < 2 or getattr(self.s.comm, "group", None) is None
+                             or os.environ.get("NAIMA_AMD_SHARED", "1") == "0"):
             return False
         hs = self._plan["hs"] if self._plan else None
         if hs is None:
             return False
         if self.s.store_blobs and self.cur_blobs and not self.blobs_in_kernel:
             return False
+        if self._run is None and self.sharded:
+            self._run = self._create_shared_run(hs) or False
+            self.shared = bool(self._run)
+            return self.shared
         if self._run is None:
             h = _lib._dp()
             if _lib._lib.nh_half_step_run_create(self.ctx.h, hs["plan"], C.byref(h)) != 0:
@@ -766,8 +807,135 @@ class DeviceLoop:
             self.resident_info = dict(grid=g.value, threads=t.value, lds_bytes=l.value)
         return True
 
+    def _create_shared_run(self, hs):
+        """the resident loop over an ensemble shared with the other ranks' GPUs: rings in
+        fine-grained memory, mapped by every other rank (hipIpc handles carried by the control
+        plane), and a probe launch that exchanges tagged granules with every peer -- every step
+        agreed by all ranks, so that all take the shared loop or none does"""
+        lib, ctx, comm = _lib._lib, self.ctx, self.s.comm
+        g = comm.group
+        h = _lib._dp()
+        why = ""
+
+        def agreed(ok):
+            return g.reduce_scalar(1.0 if ok else 0.0, "min") == 1.0
+
+        def give_up(msg):
+            if h.value:
+                lib.nh_half_step_run_destroy(ctx.h, h)
+            self.resident_reason = msg
+            if comm.rank == 0:
+                import warnings
+                warnings.warn("the resident loop over a shared ensemble is not available (%s): "
+                              "one launch and one all-gather per half-step instead" % msg)
+            return None
+
+        ok = lib.nh_half_step_run_create_shared(ctx.h, hs["plan"], comm.rank, comm.size,
+                                                C.byref(h)) == 0
+        if not ok:
+            why = lib.nh_last_error().decode()
+        if not agreed(ok):
+            return give_up("create: " + why)
+        handle = C.create_string_buffer(64)
+        ok = lib.nh_half_step_run_export(ctx.h, h, handle) == 0
+        parts = g.allgather_bytes(handle.raw if ok else b"")
+        ok = all(len(p_) == 64 for p_ in parts)
+        for r, p_ in enumerate(parts):
+            if ok and r != comm.rank:
+                ok = lib.nh_half_step_run_attach(ctx.h, h, r, p_) == 0
+        if not ok:
+            why = lib.nh_last_error().decode()
+        if not agreed(ok):
+            return give_up("hipIpc: " + why)
+        ctx.sync()
+        g.barrier()
+        st, us = _lib._i(), C.c_double()
+        ok = lib.nh_half_step_run_probe(ctx.h, h, 64, C.byref(st), C.byref(us)) == 0 and \
+            st.value == 0
+        if not agreed(ok):
+            return give_up("a record stored by another GPU did not reach a running kernel")
+        self._res["runs"].append(h)
+        gr, t, l = _lib._i(), _lib._i(), _lib._ll()
+        _lib._chk(lib.nh_half_step_run_info(h, C.byref(gr), C.byref(t), C.byref(l)))
+        self.resident_info = dict(grid=gr.value, threads=t.value, lds_bytes=l.value)
+        self.shared_info = dict(ranks=comm.size, probe_us_per_exchange=us.value)
+        return h
+
+    def _sync_cur_blobs(self):
+        """a shared ensemble: every rank's current-blob arrays := the blobs of where each walker
+        IS -- held by the rank that accepted its last move (largest stamp).  Collective."""
+        if not self._cur_dirty:
+            return
+        self._cur_dirty = False
+        ctx, comm = self.ctx, self.s.comm
+        g, N = comm.group, self.N
+        stamps = np.empty(N, dtype=np.int32)
+        _lib._chk(_lib._lib.nh_half_step_run_counters(ctx.h, self._run, None,
+                                                      stamps.ctypes.data, 2))
+        allst = np.array([np.frombuffer(p_, dtype=np.int32) for p_ in
+                          g.allgather_bytes(stamps.tobytes())])
+        owner, has = allst.argmax(axis=0), allst.max(axis=0) >= 0
+        mine = has & (owner == comm.rank)
+        for cur, m, _, _ in self.cur_blobs or []:
+            host = cur.get().reshape(N, m)
+            parts = g.allgather_bytes(np.ascontiguousarray(host[mine]).tobytes())
+            for r, p_ in enumerate(parts):
+                if r != comm.rank:
+                    host[has & (owner == r)] = np.frombuffer(p_, dtype=float).reshape(-1, m)
+            cur.set(host.ravel())
+
+    def _merge_shared_block(self, block, n, c, l, per):
+        """the rows a shared ensemble's launches wrote, gathered from the ranks that moved each
+        walker (c [n][N][ndim], l [n][N], per[b] [n][N][m_b]: this rank's copies, completed in
+        place), blob rows of rejected moves filled from the row before.  Collective."""
+        comm = self.s.comm
+        g, N, ndim = comm.group, self.N, self.ndim
+        own = block["own"].get()[:n].reshape(n, N)
+        ms = [p_.shape[2] for p_ in per]
+        moved, acc = own >= 0, own > 0
+        rows_per = max(1, (16 << 20) // (N * (8 * (ndim + 1 + sum(ms)) + 1)))
+        for t0 in range(0, n, rows_per):
+            t1 = min(n, t0 + rows_per)
+            mv, ac = moved[t0:t1], acc[t0:t1]
+            flags = own[t0:t1].astype(np.int8).tobytes()
+            flags += b"\0" * (-len(flags) % 8)
+            payload = flags + c[t0:t1][mv].tobytes() + l[t0:t1][mv].tobytes() + \
+                b"".join(p_[t0:t1][ac].tobytes() for p_ in per)
+            for r, blob in enumerate(g.allgather_bytes(payload)):
+                if r == comm.rank:
+                    continue
+                nel = (t1 - t0) * N
+                o = np.frombuffer(blob, dtype=np.int8, count=nel).reshape(t1 - t0, N)
+                off = nel + (-nel % 8)
+                mv_r, ac_r = o >= 0, o > 0
+                cnt, cnta = int(mv_r.sum()), int(ac_r.sum())
+                c[t0:t1][mv_r] = np.frombuffer(blob, dtype=float, count=cnt * ndim,
+                                               offset=off).reshape(cnt, ndim)
+                off += 8 * cnt * ndim
+                l[t0:t1][mv_r] = np.frombuffer(blob, dtype=float, count=cnt, offset=off)
+                off += 8 * cnt
+                for p_, m in zip(per, ms):
+                    p_[t0:t1][ac_r] = np.frombuffer(blob, dtype=float, count=cnta * m,
+                                                    offset=off).reshape(cnta, m)
+                    off += 8 * cnta * m
+                moved[t0:t1] |= mv_r
+                acc[t0:t1] |= ac_r
+        if per:
+            cur0 = [b_.get().reshape(N, m) for b_, m in zip(block["cur0"], ms)]
+            for t in range(n):
+                rej = moved[t] & ~acc[t]
+                if rej.any():
+                    for p_, c0 in zip(per, cur0):
+                        p_[t][rej] = (p_[t - 1] if t > 0 else c0)[rej]
+
     def _run_resident(self, slice0, nslices, block):
         ctx, hs = self.ctx, self._plan["hs"]
+        if self.shared:
+            own = block.get("own") if block is not None else None
+            _lib._chk(_lib._lib.nh_half_step_run_hist_flags(self._run, own.ptr if own is not None
+                                                            else None))
+            if self.s.store_blobs and self.cur_blobs:
+                self._cur_dirty = True
         hc = hl = None
         hb, row0, cap = None, 0, 0
         if block is not None:
@@ -947,18 +1115,23 @@ class DeviceLoop:
         self.check_resident()
         self.check_nan()
         self.ctx.check_general()  # (a per-walker grid longer than the general kernel's LDS)
+        self._sync_cur_blobs()
         s = self.s
         for block in self.hist:
             n = block["n"]
             if n == 0:
                 continue
             c = block["coords"].get()[:n].reshape(n, self.N, self.ndim)
-            l = block["logp"].get()[:n]
+            l = block["logp"].get()[:n].reshape(n, self.N)
+            per = [hb.get()[:n].reshape(n, self.N, m)
+                   for hb, (cur, m, _, trail) in zip(block["blobs"], self.cur_blobs or [])]
+            if self.shared and block.get("own") is not None:
+                self._merge_shared_block(block, n, c, l, per)
             s._chain.extend(list(c))
             s._logp.extend(list(l))
             if block["blobs"]:
-                per = [hb.get()[:n].reshape((n, self.N) + trail)
-                       for hb, (cur, m, _, trail) in zip(block["blobs"], self.cur_blobs)]
+                per = [a.reshape((n, self.N) + trail)
+                       for a, (cur, m, _, trail) in zip(per, self.cur_blobs)]
                 for j, v in self.const_blobs:
                     per.insert(j, np.full((n, self.N), v))
                 if s._blobs is None:
@@ -967,3 +1140,9 @@ class DeviceLoop:
                     s._blobs[j].extend(list(a))
         self.hist = []
         s.naccepted = self.nacc.get().astype(float)
+        if self.shared:  # + the moves each rank's shared launches accepted
+            own = np.empty(self.N, dtype=np.int32)
+            _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, own.ctypes.data,
+                                                          None, 0))
+            for p_ in s.comm.group.allgather_bytes(own.tobytes()):
+                s.naccepted += np.frombuffer(p_, dtype=np.int32)

@@ -616,3 +616,46 @@ def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
     assert out["0"][2] == 0 and out["1"][2] >= 13
     assert np.array_equal(out["1"][0], out["0"][0])
     assert np.array_equal(out["1"][1], out["0"][1])
+
+
+@pytest.mark.parametrize("name,nw", [("cfg3", 32), ("cfg5", 64), ("cfg2", 48)],
+                         ids=["cfg3-32", "cfg5-64", "cfg2-48"])
+def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw):
+    """the resident loop over an ensemble SHARED by two ranks (nh_half_step_run_create_shared):
+    two processes, here on the one GPU of the box, each mapping the other's rings through hipIpc;
+    a mover stores its walker's record into both rings, nobody launches or gathers per
+    half-step.  Every rank ends with the same ensemble, chain, log-probabilities, blobs (history
+    rows gathered from whoever moved the walker, rows of rejected moves filled from the row
+    before; current blobs merged by stamp after a call without history) and acceptance counts
+    as one process on one GPU -- bit for bit: the walkers' arithmetic is the same code."""
+    import os
+    import subprocess
+    import sys
+    from naima_amd.sampler import EnsembleSampler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29800 + (os.getpid() % 1000)
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.join(root, "tests", "gpu_shared_ranks_worker.py"), str(tmp_path), name, str(nw)],
+        cwd=root, timeout=600,
+        env=dict(os.environ, MASTER_ADDR="127.0.0.1", NH_RUN_SPIN_LIMIT=str(1 << 24)))
+    model, p0, raw, data, prior = _problem(na, name, {})
+    nd = p0.size
+    s = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                        store_blobs=True, device=True, nan_policy="reject")
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
+    st = s.run_mcmc(pos, 5)
+    st = s.run_mcmc(st, 70)
+    st = s.run_mcmc(st, 9, store=False)
+    st = s.run_mcmc(st, 4)
+    want = dict(coords=st.coords, logp=st.log_prob, curblob0=np.asarray(st.blobs[0]),
+                curblob1=np.asarray(st.blobs[1]), chain=s.get_chain(), lnp=s.get_log_prob(),
+                blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
+                acc=s.acceptance_fraction)
+    assert want["chain"].shape[0] == 79
+    for r in (0, 1):
+        for key, w in want.items():
+            have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
+            assert have.shape == w.shape, (key, r)
+            assert_allclose(have, w, rtol=1e-10, atol=1e-300, err_msg="%s of rank %d" % (key, r))
