@@ -274,6 +274,22 @@ def main():
     pos = p0 + args.ball * p0 * sampler._rng.normal(size=(nwalkers, p0.size))
     state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
     ctx.sync()
+    if device and comm.size > 1:
+        # several GPUs share the ensemble through records stored into each other's memory
+        # (device_sampler._create_shared_run probes that before taking the path); should a
+        # launch still have given up waiting for a record, every rank drops to one launch and
+        # one all-gather per half-step -- agreed here, before anything is timed
+        state = sampler.run_mcmc(state, 40, store=False)
+        bad = 0.0
+        try:
+            sampler._dev.check_resident()
+        except _lib.NaimaHipError:
+            bad = 1.0
+        if comm.max(bad) > 0:
+            os.environ["NAIMA_AMD_SHARED"] = "0"
+            sampler = make_sampler(device, not args.no_graph, blobs=keep_blobs)
+            state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
+            ctx.sync()
     # Spin-up, untimed and reported as config.untimed_spinup_steps: the first ~20 ms after
     # an idle period run measurably slower (device clocks ramp, first replays of the
     # multi-step graph).  A short --warmup is topped up to 160 steps (at most 0.5 s of them,
@@ -292,14 +308,22 @@ def main():
     # ---- the timed region: EXACTLY K ensemble steps, barrier + device sync on both sides.
     # Repeated (every rank the same number of times) until --min-time seconds have been
     # timed: a 20-step region of cfg3 lasts 2 ms, which is noise.
+    # (several ranks: the control plane's barrier is a star of Python sockets -- its ranks leave it
+    # up to ~0.1 ms apart -- so ranks that share an ensemble through each other's memory line
+    # up once more on the device, DeviceLoop.device_barrier; a rank's time runs from there to
+    # its own device sync after step K, the closing barrier follows, and the MAX over ranks is
+    # the region's time)
     def timed_region(smp, st):
         comm.barrier()
+        if device:
+            smp._dev.device_barrier()
         ctx.sync()
         t0 = time.perf_counter()
         st = smp.run_mcmc(st, args.steps, store=not args.no_chain)
         ctx.sync()
+        dt_mine = time.perf_counter() - t0
         comm.barrier()
-        return comm.max(time.perf_counter() - t0), st
+        return comm.max(dt_mine), st
 
     # (rehearsals of the region, untimed: the graphs a K-step call replays -- the tail of a
     # block of moves is a graph of its own -- are captured here, not inside a timed region)
@@ -418,6 +442,9 @@ def main():
             "initial_ball": args.ball,
             "device": info["name"], "untimed_spinup_steps": spinup + rehearsed,
             "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
+                           "none: a mover stores its walker's record into every rank's ring "
+                           "(system-scope stores over xGMI, rings mapped through hipIpc); %r"
+                           % (sampler._dev.shared_info,) if getattr(sampler._dev, "shared", False) else
                            "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
                            else "all-gather between two graphs per half-step")
             if device else "host loop",

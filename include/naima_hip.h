@@ -583,9 +583,10 @@ int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
  *                  stores another GPU makes while the kernel runs reach its polling loads (call on
  *                  every rank at the same time; bounded like every wait of the loop);
  *   hist_flags:    where nh_half_step_run keeps who-moved-what of the following launches,
- *                  [hist_cap][N] ints preset to -1 by the caller: 0 / 1 = this rank moved the
- *                  walker in that step and rejected / accepted (history rows and blobs are written
- *                  by the mover only, on its own GPU; blob rows of rejected moves are NOT filled);
+ *                  [hist_cap][N] ints, rows hist_row0 ... of every launch: -1 = another rank
+ *                  moved the walker in that step, 0 / 1 = this rank did and rejected / accepted
+ *                  (history rows and blobs are written by the mover only, on its own GPU; blob
+ *                  rows of rejected moves are NOT filled);
  *   counters:      nacc_own[N] (moves this rank accepted; the plan's naccepted is not touched) and
  *                  curstamp[N] (-1, or the step count at which this rank last accepted a move of
  *                  the walker: whoever holds the largest stamp holds the walker's current blobs in

@@ -834,8 +834,9 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           if (lane == 0) R.hlogp[hrow * N + me2] = ok ? acc : oldlp;
         }
         if (lane == 0) {
-          R.accw[(long long)tl * N + me2] = ok ? 1 : 0;
-          if (multi && R.hacc && hist) R.hacc[hrow * N + me2] = ok ? 1 : 0;
+          // (a shared ensemble: the flag says which launch it belongs to -- entries of walkers
+          // other ranks move keep an older launch's number and are recognised by it, no memset)
+          R.accw[(long long)tl * N + me2] = multi ? (int)((R.seq << 2) | (ok ? 2u : 1u)) : (ok ? 1 : 0);
           if (acc != acc) atomicAdd(H.done + 2, 1);  // (see nh_half_step_nan_count)
         }
         if (ok) {  // the accepted position's blobs
@@ -916,10 +917,20 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
       int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = R.accw[(long long)(t < nsteps ? t : nsteps - 1) * N + w];
+      if (R.nrank > 1) {
+        // a shared ensemble: { launch number | 1 rejected, 2 accepted } -> -1 not moved by this
+        // rank | 0 | 1, also into the history's flags (what the merge of the ranks' rows reads)
+#pragma unroll
+        for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) {
+          const bool mine = (unsigned)f[t] >> 2 == R.seq;
+          f[t] = mine ? ((f[t] & 3) == 2 ? 1 : 0) : -1;
+          if (R.hacc && t < nsteps) R.hacc[(R.hrow0 + t) * N + w] = f[t];
+        }
+      }
       int a = 0;
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += (t < nsteps && f[t] > 0) ? 1 : 0;
-      nacc[w] += a;  // (a shared ensemble: flags of walkers other ranks moved are -1)
+      nacc[w] += a;
     }
   // (a shared ensemble: the blobs of a walker's earlier steps may be on another rank -- the
   // rows of rejected proposals are filled when the ranks' histories are merged)
@@ -981,6 +992,7 @@ struct nh_halfstep_run {
   int* curstamp;
   int* hacc;          // where the NEXT launch keeps its history flags (nh_half_step_run_hist_flags)
   int* probe_out;
+  unsigned probe_seq;
   long long steps_total;
 };
 
@@ -1043,21 +1055,27 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   // so registers or LDS bind first and the query is exact.  The bounded waits are the net.)
   long long cap = (long long)per_cu * ncu;
   if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
-  // More walkers per half-step than resident workgroups: a workgroup would take several walkers
-  // per slice, one after the other (cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s
-  // that way, two 256-thread workgroups per CU, against 24.2 M launched per half-step, four).
-  NH_REQUIRE((long long)H.nloc * P->split <= cap, "more walkers per half-step than resident workgroups");
+  // More walkers per half-step than resident workgroups: a workgroup takes several of a slice,
+  // one after the other (dependencies still point backwards in (slice, walker) order).  Pays for
+  // workgroups that own their CU -- cfg3 at 1024 / 2048 walkers: 7.8 / 8.1 M walker-steps/s
+  // launched per half-step, 10.9 / 11.2 M resident -- not for the small workgroups of a
+  // table-only model (cfg5 at 1024 walkers per half-step ran 19.6 M walker-steps/s with two
+  // walkers per workgroup and slice, two 256-thread workgroups per CU, against 24.2 M launched
+  // per half-step, four).  NH_RUN_MAX_PER_WG overrides (1: never).
+  const long long per_wg = nh_env_int("NH_RUN_MAX_PER_WG", P->threads >= 1024 ? 8 : 1);
+  NH_REQUIRE((long long)H.nloc * P->split <= cap * (per_wg > 1 ? per_wg : 1),
+             "more walkers per half-step than resident workgroups");
   nh_halfstep_run* Q = new nh_halfstep_run();
   Q->R = R;
   Q->lds_bytes = lds;
   Q->threads = P->threads;
-  Q->grid = (int)(H.nloc < cap ? H.nloc : cap);
+  Q->grid = (int)(H.nloc < cap / P->split ? H.nloc : cap / P->split);
   Q->seq = 1;
   Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
   Q->xspec = nullptr; Q->tick = nullptr; Q->split = P->split;
   Q->nrank = shared ? nrank : 1; Q->rank = shared ? rank : 0;
   Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
-  Q->probe_out = nullptr; Q->steps_total = 0;
+  Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1;
   for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
   Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
   const size_t ring_bytes = Q->ring_elems * sizeof(unsigned long long);
@@ -1230,7 +1248,7 @@ extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds,
   }
   A.nrank = Q->nrank; A.rank = Q->rank; A.rounds = rounds;
   A.spin_limit = Q->R.spin_limit;
-  A.seq = Q->seq++ & 0xFFFFFu;
+  A.seq = Q->probe_seq++ & 0xFFFFFu;  // (its own count: the launches' decides the ring's parity)
   A.out = Q->probe_out;
   hipLaunchKernelGGL(k_run_probe, dim3(1), dim3(64), 0, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
@@ -1244,7 +1262,7 @@ extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds,
 }
 
 // where the next launches of a shared ensemble keep their history flags ([hist_cap][N] ints,
-// pre-set to -1 by the caller; NULL: nowhere)
+// every row of a launch written by its epilogue; NULL: nowhere)
 extern "C" int nh_half_step_run_hist_flags(nh_halfstep_run* Q, int* hacc) {
   NH_REQUIRE(Q && Q->base, "not a shared-ensemble loop");
   Q->hacc = hacc;
@@ -1292,8 +1310,6 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     R.hacc = hist_coords ? Q->hacc : nullptr;
     R.stamp0 = (int)(Q->steps_total & 0x3FFFFFFF);
     Q->steps_total += nslices / 2;
-    // (flags of walkers other ranks move stay -1)
-    NH_CHECK_HIP(hipMemsetAsync(Q->accw, 0xFF, (size_t)(nslices / 2) * R.N * sizeof(int), c->stream));
   }
   R.hcoords = hist_coords;
   R.hlogp = hist_logp;

@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from . import units as u
 from .darray import DMat, DPars, DVec
-from .dist import shard_bounds
+from .dist import shard_bounds, shard_counts
 
 
 class DeviceState:
@@ -97,10 +97,13 @@ class DeviceLoop:
         self.N, self.ndim = sampler.nwalkers, sampler.ndim
         self.ns = self.N // 2
         comm = sampler.comm
-        if self.ns % comm.size:
-            raise ValueError("device=True needs the half-ensemble (%d) to divide evenly over %d "
-                             "ranks" % (self.ns, comm.size))
+        if self.ns < comm.size:
+            raise ValueError("device=True needs at least one walker of every half-ensemble (%d) "
+                             "per rank (%d)" % (self.ns, comm.size))
+        # (a half-ensemble that does not divide evenly: the first ranks take one walker more,
+        # as dist.shard_bounds says; all-gathers then travel padded to the largest block)
         self.lo, self.hi = shard_bounds(self.ns, comm.rank, comm.size)
+        self._pads = {}
         # the sharded code path (split graphs around the all-gather) even for ONE rank:
         # lets a 1-GPU box run everything but the multi-process part (tests)
         self.sharded = comm.size > 1 or os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") == "1"
@@ -202,6 +205,7 @@ class DeviceLoop:
         self.shared = False
         self.shared_info = None
         self._cur_dirty = False   # current blobs differ between ranks (merge by stamp pending)
+        self._cur_host = None     # host copies of the current blobs while nothing has changed them
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
@@ -461,18 +465,39 @@ class DeviceLoop:
         lds += min(items, 96) * 64 + nspec
         return 8 * lds <= 140 * 1024
 
+    def _gather_rows(self, send_ptr, recv, n, width):
+        """all-gather of rows of `width` doubles, rank r contributing its block of the n rows
+        (dist.shard_counts); blocks of unequal length travel padded to the longest and are put
+        side by side on arrival (one small copy per rank, in stream order)"""
+        ctx, comm = self.ctx, self.s.comm
+        counts = shard_counts(n, comm.size)
+        if len(set(counts)) == 1:
+            comm.allgather_device(ctx, send_ptr, recv, counts[0] * width)
+            return
+        m = max(counts)
+        key = (m * width, comm.size)
+        if key not in self._pads:
+            self._pads[key] = (ctx.empty((m * width,)), ctx.empty((comm.size * m * width,)))
+        ps, pr = self._pads[key]
+        ctx.call("nh_copy", ps, send_ptr, 8 * counts[comm.rank] * width)
+        comm.allgather_device(ctx, ps.ptr, pr, m * width)
+        off = 0
+        for r, cnt in enumerate(counts):
+            ctx.call("nh_copy", recv.ptr + 8 * off * width, pr.ptr + 8 * r * m * width,
+                     8 * cnt * width)
+            off += cnt
+
     def _exchange(self):
         """the one collective of the path: every rank's new log-probabilities"""
         if self.sharded and self.blobs_in_kernel and self.send_width:
-            self.s.comm.allgather_device(self.ctx, self.send_rows.ptr, self.recv_rows,
-                                         self.nloc * self.send_width)
+            self._gather_rows(self.send_rows.ptr, self.recv_rows, self.ns, self.send_width)
         elif self.sharded:
-            self.s.comm.allgather_device(self.ctx, self.mylp.ptr, self.newlp, self.nloc)
+            self._gather_rows(self.mylp.ptr, self.newlp, self.ns, 1)
             if self.s.store_blobs and self.cur_blobs:
                 # blobs of the proposals follow their log-probabilities: the walker a rank
                 # evaluates changes every step, so every rank keeps all of them
                 for nb, ab, (cur, m, _, _) in zip(self.new_blobs, self.all_blobs, self.cur_blobs):
-                    self.s.comm.allgather_device(self.ctx, nb.ptr, ab, self.nloc * m)
+                    self._gather_rows(nb.ptr, ab, self.ns, m)
 
     def _half_step_body(self):
         self._part_evaluate()
@@ -491,7 +516,7 @@ class DeviceLoop:
         qT = ctx.array(np.ascontiguousarray(coords_host[lo:hi].T))
         total, blobs = self._eval(qT, hi - lo)
         if self.sharded:
-            s.comm.allgather_device(ctx, total.ptr, self.logp, hi - lo)
+            self._gather_rows(total.ptr, self.logp, self.N, 1)
         else:
             ctx.call("nh_copy", self.logp, total.ptr, 8 * self.N)
         if s.store_blobs and blobs:
@@ -501,7 +526,7 @@ class DeviceLoop:
                 own, ptr, m, unit, trail = self._blob_dense(b)
                 cur = ctx.empty((self.N, m))
                 if self.sharded:
-                    s.comm.allgather_device(ctx, ptr, cur, (hi - lo) * m)
+                    self._gather_rows(ptr, cur, self.N, m)
                 else:
                     ctx.call("nh_scatter_rows", cur, m, ptr, m, ident, None, 0, hi - lo, m)
                 self.cur_blobs.append((cur, m, unit, trail))
@@ -513,6 +538,7 @@ class DeviceLoop:
         if np.any(np.isnan(lp)):
             raise ValueError("Probability function returned NaN")
         self._have_state = True
+        self._cur_host = None
 
     def host_blobs(self):
         if not self.cur_blobs:
@@ -548,12 +574,15 @@ class DeviceLoop:
                 # from the row before when the ranks' histories are merged)
                 self._sync_cur_blobs()
                 block["own"] = ctx.empty((iterations, N), dtype=np.int32)
-                ctx.call("nh_memset", block["own"], 0xFF, block["own"].nbytes)
+                block["shared_rows"] = []  # [row0, row1) of every shared launch
                 block["cur0"] = []
-                for cur, m, _, _ in (self.cur_blobs or []) if block["blobs"] else []:
-                    c0 = ctx.empty((N, m))
-                    ctx.call("nh_copy", c0, cur, 8 * N * m)
-                    block["cur0"].append(c0)
+                if block["blobs"] and self._cur_host is not None:
+                    block["cur0"] = self._cur_host  # (host copies the last merge left: no launch)
+                elif block["blobs"]:
+                    for cur, m, _, _ in self.cur_blobs or []:
+                        c0 = ctx.empty((N, m))
+                        ctx.call("nh_copy", c0, cur, 8 * N * m)
+                        block["cur0"].append(c0)
             self.hist.append(block)
         if not (isinstance(initial_state, DeviceState) and initial_state._loop is self):
             self._sync_cur_blobs()
@@ -614,6 +643,7 @@ class DeviceLoop:
         while it < iterations:
             self._flush_pending()  # (merged sharded mode) the block's last accept
             self._sync_cur_blobs()  # (launches per half-step keep every rank's blobs whole)
+            self._cur_host = None
             # ---- ship the moves of the next K steps: ONE asynchronous upload from the
             # generator's page-locked ring (filled ahead by its worker thread) ----------
             # nh_moves_take's contract: only the copy of the MOST RECENT take may still be
@@ -861,6 +891,16 @@ class DeviceLoop:
         self.shared_info = dict(ranks=comm.size, probe_us_per_exchange=us.value)
         return h
 
+    def device_barrier(self):
+        """ranks that share an ensemble meet on the device: one exchange of tagged granules
+        with every peer (the probe launch), a few microseconds apart instead of the control
+        plane's ~0.1 ms.  Synchronises the stream; a no-op for any other loop."""
+        if self.shared:
+            st = _lib._i()
+            _lib._chk(_lib._lib.nh_half_step_run_probe(self.ctx.h, self._run, 1, C.byref(st), None))
+            if st.value != 0:
+                raise _lib.NaimaHipError("device barrier of the shared ensemble timed out")
+
     def _sync_cur_blobs(self):
         """a shared ensemble: every rank's current-blob arrays := the blobs of where each walker
         IS -- held by the rank that accepted its last move (largest stamp).  Collective."""
@@ -876,6 +916,7 @@ class DeviceLoop:
                           g.allgather_bytes(stamps.tobytes())])
         owner, has = allst.argmax(axis=0), allst.max(axis=0) >= 0
         mine = has & (owner == comm.rank)
+        stash = []
         for cur, m, _, _ in self.cur_blobs or []:
             host = cur.get().reshape(N, m)
             parts = g.allgather_bytes(np.ascontiguousarray(host[mine]).tobytes())
@@ -883,6 +924,8 @@ class DeviceLoop:
                 if r != comm.rank:
                     host[has & (owner == r)] = np.frombuffer(p_, dtype=float).reshape(-1, m)
             cur.set(host.ravel())
+            stash.append(host)
+        self._cur_host = stash  # (valid until a launch changes the blobs again)
 
     def _merge_shared_block(self, block, n, c, l, per):
         """the rows a shared ensemble's launches wrote, gathered from the ranks that moved each
@@ -891,6 +934,10 @@ class DeviceLoop:
         comm = self.s.comm
         g, N, ndim = comm.group, self.N, self.ndim
         own = block["own"].get()[:n].reshape(n, N)
+        valid = np.zeros(n, dtype=bool)  # (rows of launches per half-step are whole on every rank)
+        for r0, r1 in block["shared_rows"]:
+            valid[r0:r1] = True
+        own[~valid] = -1
         ms = [p_.shape[2] for p_ in per]
         moved, acc = own >= 0, own > 0
         rows_per = max(1, (16 << 20) // (N * (8 * (ndim + 1 + sum(ms)) + 1)))
@@ -921,7 +968,8 @@ class DeviceLoop:
                 moved[t0:t1] |= mv_r
                 acc[t0:t1] |= ac_r
         if per:
-            cur0 = [b_.get().reshape(N, m) for b_, m in zip(block["cur0"], ms)]
+            cur0 = [(b_ if isinstance(b_, np.ndarray) else b_.get()).reshape(N, m)
+                    for b_, m in zip(block["cur0"], ms)]
             for t in range(n):
                 rej = moved[t] & ~acc[t]
                 if rej.any():
@@ -936,6 +984,9 @@ class DeviceLoop:
                                                             else None))
             if self.s.store_blobs and self.cur_blobs:
                 self._cur_dirty = True
+                self._cur_host = None
+            if own is not None:
+                block["shared_rows"].append((block["n"], block["n"] + nslices // 2))
         hc = hl = None
         hb, row0, cap = None, 0, 0
         if block is not None:
@@ -973,8 +1024,9 @@ class DeviceLoop:
             if st.value != 0:
                 raise _lib.NaimaHipError(
                     "the resident half-step loop timed out waiting for a walker's record (status "
-                    "%d): its workgroups were not all resident.  Run with NAIMA_AMD_RESIDENT=0"
-                    % st.value)
+                    "%d): its workgroups were not all resident%s.  Run with NAIMA_AMD_%s=0"
+                    % (st.value, ", or a rank of the shared ensemble fell behind or failed"
+                       if self.shared else "", "SHARED" if self.shared else "RESIDENT"))
 
     def _run_half_step_merged(self):
         ctx = self.ctx

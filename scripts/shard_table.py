@@ -1,11 +1,14 @@
 """Single-GPU projection of the multi-GPU targets (BASELINE: cfg5 2048 walkers over 8 GPUs,
-cfg4 1024 over 4; cfg3 for the headline): ms per ensemble step of the SHARDED device loop
-(NAIMA_AMD_FORCE_SHARDED=1, a one-rank RCCL communicator: split graphs or in-graph
-all-gather, exactly the code a rank of an R-GPU job runs) for local shards of
-1024 / 512 / 256 / 128 walkers per half-step, next to the fused single-GPU loop on the same
-ensemble.  Implied upper bound on the R-GPU speed-up of a W-walker ensemble:
-t_fused(W) / t_sharded(W / R) -- an upper bound because a one-rank all-gather costs less
-than one over xGMI.  Writes one JSON document to stdout."""
+cfg4 1024 over 4; cfg3 for the headline): ms per ensemble step of the one-GPU device loop (the
+resident loop wherever it applies) on ensembles of 2048 ... 128 walkers, next to the SHARDED
+per-launch loop (NAIMA_AMD_FORCE_SHARDED=1, a one-rank RCCL communicator: the fallback a rank
+runs when the shared resident loop is not available) on the same ensemble.
+A rank of an R-GPU run over W walkers that share one ensemble (nh_half_step_run_create_shared)
+runs the workgroups of a one-GPU resident loop over W / R walkers -- same geometry, same
+dependency chain per half-step, records stored into R rings instead of one -- so
+t_one(W) / t_one(W / R) bounds the R-GPU speed-up of the shared loop from above (xGMI latency
+on the hand-off and the 6 % measured for two ranks sharing ONE GPU come off it), and
+t_one(W) / t_sharded(W / R) that of the per-launch fallback.  """
 import json
 import os
 import sys
@@ -44,19 +47,20 @@ def measure(name, nwalkers, comm, steps, sharded):
         st = s.run_mcmc(st, steps, store=False)
         ctx.sync()
         ts.append(time.perf_counter() - t0)
-    mode = "fused" if not s._dev.sharded else ("in-graph" if s._dev.coll_in_graph else "split")
+    mode = ("resident" if s._dev.resident_launches else "fused") if not s._dev.sharded else \
+        ("in-graph" if s._dev.coll_in_graph else "split")
     del s
     return float(np.median(ts)) / steps * 1e3, mode
 
 
-out = {"note": __doc__.split("Writes")[0].strip(), "device": ctx.info()["name"], "rows": []}
+out = {"note": __doc__.strip(), "device": ctx.info()["name"], "rows": []}
 for name, steps in (("cfg5", 400), ("cfg3", 400), ("cfg1", 400), ("cfg2", 200)):
     for half in (1024, 512, 256, 128, 64):
         nw = 2 * half
-        ms_f, _ = measure(name, nw, local, steps, False)
+        ms_f, mode_f = measure(name, nw, local, steps, False)
         ms_s, mode = measure(name, nw, rccl, steps, True)
         out["rows"].append({"workload": name, "walkers_per_half_step": half, "ensemble": nw,
-                            "ms_per_step_fused_single_gpu": round(ms_f, 5),
+                            "ms_per_step_fused_single_gpu": round(ms_f, 5), "one_gpu_mode": mode_f,
                             "ms_per_step_sharded_one_rank": round(ms_s, 5),
                             "sharded_mode": mode,
                             "us_per_half_step_sharded": round(ms_s * 500, 2)})
@@ -72,7 +76,9 @@ for name, total in (("cfg5", 2048), ("cfg3", 2048), ("cfg3", 512), ("cfg2", 2048
         if sh is None:
             continue
         proj.append({"workload": name, "walkers_total": total, "gpus": R,
-                     "speedup_upper_bound": round(one["ms_per_step_fused_single_gpu"]
-                                                  / sh["ms_per_step_sharded_one_rank"], 2)})
+                     "speedup_upper_bound_shared_resident_loop":
+                         round(one["ms_per_step_fused_single_gpu"] / sh["ms_per_step_fused_single_gpu"], 2),
+                     "speedup_upper_bound_per_launch_fallback":
+                         round(one["ms_per_step_fused_single_gpu"] / sh["ms_per_step_sharded_one_rank"], 2)})
 out["projection"] = proj
 print(json.dumps(out, indent=1))

@@ -7,6 +7,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["NAIMA_AMD_DEVICE"] = "0"  # both ranks share the one GPU of the test box
+# (the per-launch sharded loop is what this worker covers: launches around an all-gather per
+# half-step, the fallback of the shared resident loop -- tests/gpu_shared_ranks_worker.py)
+os.environ["NAIMA_AMD_SHARED"] = "0"
 import naima_amd as na  # noqa: E402
 from bench import build_problem  # noqa: E402
 from naima_amd.dist import HostComm  # noqa: E402

@@ -472,9 +472,10 @@ def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkey
 
 @pytest.mark.parametrize("name,nw,mkw", [("cfg3", 512, {}), ("cfg5", 256, {}), ("cfg1", 32, {}),
                                          ("cfg5", 256, {"useLUT": False}), ("cfg2", 256, {}),
-                                         ("cfg3", 256, {}), ("cfg3", 48, {})],
+                                         ("cfg3", 256, {}), ("cfg3", 48, {}), ("cfg3", 1280, {})],
                          ids=["cfg3-512", "cfg5-256", "cfg1-32", "cfg5-analytic-256", "cfg2-256-two-per-walker",
-                              "cfg3-256-two-per-walker", "cfg3-48-eight-per-walker"])
+                              "cfg3-256-two-per-walker", "cfg3-48-eight-per-walker",
+                              "cfg3-1280-three-walkers-per-workgroup"])
 def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
     """nh_half_step_run -- a whole block of moves in ONE launch, walkers handed from half-step
     to half-step through per-walker records (write-through granules with tags) instead of
@@ -618,8 +619,8 @@ def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
     assert np.array_equal(out["1"][1], out["0"][1])
 
 
-@pytest.mark.parametrize("name,nw", [("cfg3", 32), ("cfg5", 64), ("cfg2", 48)],
-                         ids=["cfg3-32", "cfg5-64", "cfg2-48"])
+@pytest.mark.parametrize("name,nw", [("cfg3", 32), ("cfg5", 64), ("cfg2", 48), ("cfg3", 30)],
+                         ids=["cfg3-32", "cfg5-64", "cfg2-48", "cfg3-30-uneven-blocks"])
 def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw):
     """the resident loop over an ensemble SHARED by two ranks (nh_half_step_run_create_shared):
     two processes, here on the one GPU of the box, each mapping the other's rings through hipIpc;

@@ -355,8 +355,10 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
     import re
     import subprocess
     src = os.path.join(ROOT, "naima_amd", "csrc")
-    want = {"nh_halfstep.hip": ("k_half_step", 0), "nh_persist.hip": ("k_half_step_run", 256)}
-    for f, (sym, limit) in want.items():
+    # (file: kernel, instances, bytes of scratch per lane allowed; the resident kernel has a second
+    # pair of instances for an ensemble shared by several GPUs)
+    want = {"nh_halfstep.hip": ("k_half_step", 2, 0), "nh_persist.hip": ("k_half_step_run", 4, 256)}
+    for f, (sym, ninst, limit) in want.items():
         out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
                               "-mllvm", "-amdgpu-kernarg-preload-count=16",
                               "-Rpass-analysis=kernel-resource-usage", os.path.join(src, f),
@@ -365,6 +367,6 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
         sizes = {b.split()[0]: int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
                  for b in blocks}
         mine = {k: v for k, v in sizes.items() if sym + "IL" in k}
-        assert len(mine) == 2, sizes
+        assert len(mine) == ninst, sizes
         for k, v in mine.items():
             assert v <= limit, "%s uses %d bytes of scratch per lane" % (k, v)
