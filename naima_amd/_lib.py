@@ -162,6 +162,11 @@ def _profiler_workaround():
     and only when a profiler is attached; an explicit setting of the user wins."""
     if under_rocprofiler():
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    # device memory shared between processes (RCCL's buffers; the rings of an ensemble shared by
+    # several GPUs, hipIpcGetMemHandle): this driver stack supports dmabuf handles only -- the
+    # legacy mode fails with "hipIpcGetMemHandle: invalid argument".  Read when the HSA runtime
+    # starts, i.e. before the library's first HIP call; an explicit setting of the user wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def load():

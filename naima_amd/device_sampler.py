@@ -112,9 +112,15 @@ class DeviceLoop:
         # survive that in a throw-away probe process (RcclComm.graph_capture_ok); else the
         # collective sits between two graphs.  NAIMA_AMD_RCCL_IN_GRAPH = auto | 0 | 1
         mode = os.environ.get("NAIMA_AMD_RCCL_IN_GRAPH", "auto")
+        # (several ranks normally take the resident loop over the shared ensemble after a few
+        # steps, and these launches around an all-gather are only its run-in and its fallback:
+        # "auto" then does not spend a probe process per rank on them)
+        shared_expected = (comm.size > 1 and getattr(comm, "group", None) is not None and
+                           os.environ.get("NAIMA_AMD_SHARED", "1") != "0" and
+                           os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0" and sampler.use_graph)
         self.coll_in_graph = self.sharded and getattr(comm, "in_stream", False) and (
-            mode == "1" or (mode == "auto" and hasattr(comm, "graph_capture_ok")
-                            and comm.graph_capture_ok()))
+            mode == "1" or (mode == "auto" and not shared_expected and
+                            hasattr(comm, "graph_capture_ok") and comm.graph_capture_ok()))
         self.split = self.sharded and not self.coll_in_graph  # collective between two graphs
         self.nloc = self.hi - self.lo
         ctx = self.ctx

@@ -21,6 +21,11 @@ COPY = {"bench_n1_default.json": "bench_n1_default.json",
         "stamps_cfg5.txt": "cfg5_resident_loop_phase_stamps.txt",
         "bench_cfg3_w256.json": "bench_cfg3_w256.json",
         "bench_cfg5_strong2048_n1.json": "bench_cfg5_strong2048_n1.json"}
+for f in ("bench_cfg3_w1024.json", "bench_cfg3_w2048.json", "bench_cfg3_w1024_per_launch_kernel.json",
+          "bench_cfg3_w2048_per_launch_kernel.json", "bench_cfg3_shared_two_ranks_one_gpu.json",
+          "bench_cfg3_shared_two_ranks_one_gpu_steps100.json", "bench_cfg3_one_process_steps100.json",
+          "shard_table.json"):
+    COPY[f] = f
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
     COPY["%s_stats_kernel_stats.csv" % w] = "%s_kernel_stats.csv" % w
     COPY["%s_stats_bench.json" % w] = "%s_bench_under_rocprof.json" % w

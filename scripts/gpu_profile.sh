@@ -72,3 +72,22 @@ PY
 NH_HS_DEBUG=1 timeout 300 python scripts/run_stamps.py cfg3 512 > $O/stamps_cfg3.txt 2>&1
 NH_HS_DEBUG=1 timeout 300 python scripts/run_stamps.py cfg5 256 > $O/stamps_cfg5.txt 2>&1
 tail -3 $O/err_bench.log
+# 5. ensembles of more walkers than CUs (resident workgroups take several walkers of a half-step in turn)
+for n in 1024 2048; do
+  timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w$n.json 2>> $O/err_bench.log
+  NH_RUN_MAX_PER_WG=1 timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w${n}_per_launch_kernel.json 2>> $O/err_bench.log
+done
+# 6. the resident loop over an ensemble SHARED by two ranks -- two processes on this ONE GPU, 256 workgroups between them
+(
+export NAIMA_AMD_DEVICE=0 NAIMA_AMD_COMM=host NH_HS_SPLIT=1 NH_RUN_SPIN_LIMIT=$((1<<24))
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29655 \
+  bench.py --gpus 2 --walkers 256 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg3_shared_two_ranks_one_gpu.json 2>> $O/err_bench.log
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29656 \
+  bench.py --gpus 2 --walkers 256 --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_shared_two_ranks_one_gpu_steps100.json 2>> $O/err_bench.log
+)
+timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_one_process_steps100.json 2>> $O/err_bench.log
+# 7. one-GPU projection of the multi-GPU configurations
+timeout 1500 python scripts/shard_table.py > $O/shard_table.json 2> $O/shard_table.err
+for f in bench_cfg3_w1024 bench_cfg3_w2048 bench_cfg3_shared_two_ranks_one_gpu bench_cfg3_shared_two_ranks_one_gpu_steps100 bench_cfg3_one_process_steps100; do
+  python -c "import json; d=json.load(open('$O/$f.json')); print('$f', round(d['value']), d['ms_per_step'])"
+done

@@ -317,3 +317,80 @@ def test_save_run_layout_is_the_reference_hdf5_layout(tmp_path):
     assert r.blob_units[1] == na.u.erg and r.labels == m.labels
     assert_allclose(r.data["flux"].value, m.data["flux"].value)
     assert r.data["flux"].unit == m.data["flux"].unit and r.run_info["n_run"] == 3
+
+
+def test_shared_ensemble_history_merge_on_two_ranks():
+    """DeviceLoop._merge_shared_block (host arithmetic only; the launches that produce its input
+    are covered on the GPU by test_gpu_loops.py::test_shared_ensemble_two_ranks_one_gpu): rows a
+    shared ensemble's launches wrote hold, on each rank, only the walkers that rank moved (flags
+    -1 | 0 | 1); rows of launches per half-step are whole everywhere.  Two ranks (threads, an
+    in-memory control plane) each end with the full chain, blob rows of rejected moves filled
+    from the row before (the blobs of where the walker IS, as emcee keeps them)."""
+    import threading
+    import types
+
+    from naima_amd.device_sampler import DeviceLoop
+
+    n, N, ndim, ms = 7, 10, 3, (4, 1)
+    rng = np.random.default_rng(5)
+    shared_rows = [(2, 5), (5, 7)]
+    owner = rng.integers(0, 2, size=(n, N))
+    accepted = rng.random((n, N)) < 0.5
+    truth_c, truth_l = rng.normal(size=(n, N, ndim)), rng.normal(size=(n, N))
+    cur0 = [rng.normal(size=(N, m)) for m in ms]
+    prop = [rng.normal(size=(n, N, m)) for m in ms]  # the blobs of every step's proposal
+    truth_b = []
+    for b, c0 in zip(prop, cur0):
+        full = np.empty_like(b)
+        for t in range(n):
+            prev = full[t - 1] if t else c0
+            full[t] = np.where(accepted[t][:, None], b[t], prev)
+        truth_b.append(full)
+    shared = np.zeros(n, dtype=bool)
+    for a, b in shared_rows:
+        shared[a:b] = True
+
+    class Group:
+        def __init__(self):
+            self.bar, self.slots = threading.Barrier(2), [None, None]
+
+        def allgather_bytes(self, rank, payload):
+            self.slots[rank] = bytes(payload)
+            self.bar.wait()
+            out = list(self.slots)
+            self.bar.wait()
+            return out
+
+    group, results, errors = Group(), {}, []
+
+    def run(rank):
+        try:
+            mine = shared[:, None] & (owner == rank)
+            whole = ~shared[:, None] & np.ones((n, N), dtype=bool)
+            c = np.where((mine | whole)[:, :, None], truth_c, np.nan)
+            l = np.where(mine | whole, truth_l, np.nan)
+            per = [np.where(whole[:, :, None], tb, np.where((mine & accepted)[:, :, None], b, np.nan))
+                   for tb, b in zip(truth_b, prop)]
+            own = np.where(mine, accepted.astype(np.int32), -1).astype(np.int32)
+            own[~shared] = rng.integers(-1, 2, size=(int((~shared).sum()), N))  # (never written: anything)
+            g = types.SimpleNamespace(allgather_bytes=lambda p, r=rank: group.allgather_bytes(r, p))
+            fake = types.SimpleNamespace(
+                s=types.SimpleNamespace(comm=types.SimpleNamespace(group=g, rank=rank, size=2)),
+                N=N, ndim=ndim)
+            block = dict(own=types.SimpleNamespace(get=lambda: own.copy()), shared_rows=shared_rows,
+                         cur0=[x.copy() for x in cur0])
+            DeviceLoop._merge_shared_block(fake, block, n, c, l, per)
+            results[rank] = (c, l, per)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            group.bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert not errors, errors
+    for rank in (0, 1):
+        c, l, per = results[rank]
+        assert np.array_equal(c, truth_c) and np.array_equal(l, truth_l)
+        for have, want in zip(per, truth_b):
+            assert np.array_equal(have, want)
