@@ -412,6 +412,9 @@ int nh_stream_join(nh_ctx* ctx);
  *             walker with T <= 0 gets the NaN the reference's arithmetic gives)
  *   what = 2: We = trapz_loglog(gamma nelec, gamma mec2) over the walker's grid, erg
  *             (radiative.py:162-195: We, compute_We with per-walker limits); out[w*ldo]
+ *   what = 3: Bremsstrahlung (radiative.py:838-989): out[w*ldo + k] = trapz_loglog(nelec
+ *             sigma_ee, gamma), out[w*ldo + nE + k] the same with sigma_1 (electron-ion), per
+ *             eV; the caller applies n0 c and the abundance weights (radiative.py:949-987)
  * The limits arrive in the unit the caller's Quantity carries, with that unit's value in erg
  * beside them: the kernel forms gamma_min = (Eemin / mec2[erg]) * unit_erg exactly as the host
  * path does (what astropy reduces Eemin / mec2 to), so both paths take log10 of the same double.

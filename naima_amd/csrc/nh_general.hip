@@ -8,11 +8,13 @@
 // photon energy) of every walker.  One workgroup per (walker, component): it builds the
 // walker's grid and weights in LDS (models.py eval + radiative.py:156-160), then integrates
 //     Synchrotron._spectrum                       (radiative.py:282-342), or
-//     InverseCompton on one thermal seed field    (radiative.py:547-607, 657-687)
+//     InverseCompton on one thermal seed field    (radiative.py:547-607, 657-687), or
+//     Bremsstrahlung's e-e / e-ion emissivities   (radiative.py:838-989)
 // with trapz_loglog (utils.py:285-355).  The same holds when a seed field's temperature or
 // angle is a fit parameter (the Khangulyan kernel then differs per walker even on a shared
 // grid): T and theta are lazy per-walker scalars too.  The parameters stay in HBM, so the
 // device-resident step loop no longer falls back to the host for such models.
+#include "nh_brems.h"
 #include "nh_ic.h"
 #include "nh_pdist.h"
 #include "nh_pion.h"
@@ -160,6 +162,33 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
       }
       __syncthreads();
     }
+  } else if (A.what == 3) {
+    // ---- Bremsstrahlung: comp 0 = int(n sigma_ee), comp 1 = int(n sigma_1), per eV (the caller
+    // applies n0 c and the abundance weights, radiative.py:949-987; the Baring+99 fits go
+    // negative near their edges: the signed segment term) ----------------------------------
+    for (int k0 = 0; k0 < A.nE; k0 += 64) {
+      const int k = k0 + lane;
+      double acc = 0.0;
+      if (k < A.nE && s0 < s1) {
+        const double eps = A.E_eV[k] / NH_MEC2_EV;
+        auto Kb = [&](double g) {
+          double see, sep;
+          br_sigma(g, eps, see, sep);
+          return (comp == 0 ? see : sep) / NH_MEC2_EV;
+        };
+        double K1 = Kb(gam[s0]);
+        for (int s = s0; s < s1; ++s) {
+          const double K2 = Kb(gam[s + 1]);
+          acc += gen_term(wv[s], wv[s + 1], dw[s], K1, K2, lxs[s]);
+          K1 = K2;
+        }
+      }
+      part[wvi * 64 + lane] = acc;
+      __syncthreads();
+      if (wvi == 0 && k < A.nE)
+        orow[k] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+      __syncthreads();
+    }
   } else {
     // ---- InverseCompton on thermal seed `comp` (the caller applies uf * Eph / E) --------
     const double Tp = nh_lazy_eval(A.T[comp], wi) * NH_K_TO_MEC2;
@@ -198,10 +227,11 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
   NH_REQUIRE(what == 2 || (E_eV && nE >= 1), "photon energies missing");
   NH_REQUIRE(nEed->base || nEed->a > 0.0, "nEed must be positive");
   NH_REQUIRE(what == 0 ? (B_G != nullptr)
-                       : (what == 2 || (what == 1 && seed_T && seed_theta && nseed >= 1 &&
-                                        nseed <= NH_MAX_COMP)), "bad component");
+                       : (what == 2 || what == 3 ||
+                          (what == 1 && seed_T && seed_theta && nseed >= 1 && nseed <= NH_MAX_COMP)),
+             "bad component");
   if (what == 2) nE = 1;
-  const int ncomp = what == 1 ? nseed : 1;
+  const int ncomp = what == 1 ? nseed : (what == 3 ? 2 : 1);
   NH_REQUIRE(ldo >= ncomp * nE, "ldo too small");
   if (N == 0) return NH_OK;
   gen_args A;

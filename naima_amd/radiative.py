@@ -466,7 +466,7 @@ class BaseElectron(BaseRadiative):
             ned, k4 = lazy_const(float(nv)), None
         rows = pd.device_rows(ctx, N, amplitude_to=_PER_EV)
         nE = 1 if what == 2 else E_eV.size
-        ncomp = len(seeds) if what == 1 else 1
+        ncomp = len(seeds) if what == 1 else (2 if what == 3 else 1)
         out = ctx.empty((N, ncomp * nE))
         status = ctx.general_status()
         Bl, k3 = (lazy_of(B, "G") if what == 0 else (None, None))
@@ -1024,6 +1024,9 @@ class Bremsstrahlung(BaseElectron):
     _structural = BaseElectron._structural + ("weight_ee", "weight_ep")
     _walker_scalars = ("n0",)
 
+    def _general_supported(self):
+        return True
+
     def __init__(self, particle_distribution, n0=1 / u.cm ** 3, **kwargs):
         super().__init__(particle_distribution)
         self.n0 = n0
@@ -1042,6 +1045,28 @@ class Bremsstrahlung(BaseElectron):
         E = _validate_ene(photon_energy)
         E_eV = np.atleast_1d(E.to("eV").value).astype(float)
         nE = E_eV.size
+        rows = None
+        if _per_walker(self.n0):  # the target density is a fit parameter: one factor per walker
+            validate_physical_type("n0", self.n0, "number density")
+            rows, n0 = self.n0.to("1/cm3").value, 1.0
+        else:
+            n0 = validate_scalar("n0", self.n0, physical_type="number density").to("1/cm3").value
+        if self._general_limits():
+            # Eemin / Eemax / nEed per walker: every walker's own grid, the cross sections
+            # evaluated at its nodes (nh_general_electron, what = 3: e-e | e-ion side by side)
+            ctx, N, out = self._general_launch(3, E_eV)
+            fee, fep = n0 * self.weight_ee * C_CGS, n0 * self.weight_ep * C_CGS
+            if self.on_device:
+                tot = DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, scale=fee) + \
+                    DMat.from_buffer(ctx, out, N, nE, ld=2 * nE, col0=nE, scale=fep)
+                if rows is not None:
+                    tot = tot * _as_dvec(ctx, rows, N)
+                return u.Quantity(tot, _SPEC_UNIT)
+            host = out.get()
+            host = fee * host[:, :nE] + fep * host[:, nE:]
+            if rows is not None:
+                host = host * np.broadcast_to(np.asarray(rows, dtype=float), (N,))[:, None]
+            return u.Quantity(self._finish(host, E), _SPEC_UNIT)
         ctx, N, w, lw, gd, lx, gam = self._electron_weights()
         nG = gam.size
         Ed = ctx.const(E_eV)
@@ -1054,12 +1079,6 @@ class Bremsstrahlung(BaseElectron):
             return Kt, dKt
 
         Kt, dKt = ctx.table(("brems", gd.ptr, Ed.ptr), build)
-        rows = None
-        if _per_walker(self.n0):  # the target density is a fit parameter: one factor per walker
-            validate_physical_type("n0", self.n0, "number density")
-            rows, n0 = self.n0.to("1/cm3").value, 1.0
-        else:
-            n0 = validate_scalar("n0", self.n0, physical_type="number density").to("1/cm3").value
         # spec = n0 (w_ee c int(n sigma_ee) + w_ep c int(n sigma_1)), radiative.py:949-987
         scale = np.concatenate([np.full(nE, n0 * self.weight_ee * C_CGS),
                                 np.full(nE, n0 * self.weight_ep * C_CGS)])

@@ -636,3 +636,50 @@ def test_general_proton_kernel_against_oracle(na):
         l0, l1 = np.log10(wlo[i]), np.log10(epmax[i])
         Ep2 = np.logspace(l0, l1, max(10, int(ned[i] * (l1 - l0))))
         assert_allclose(Wp2[i], O.proton_energy_content(opd, Ep2), rtol=1e-9)
+
+
+def test_general_bremsstrahlung_against_oracle(na):
+    """Bremsstrahlung with Eemin / Eemax (and the target density) per walker: the general kernel
+    builds every walker's own grid (radiative.py:147-154) and evaluates the Baring+99 cross
+    sections (radiative.py:838-928) at its nodes -- e-e and e-ion emissivities, negative lobes of
+    the fits and the 2 MeV switch included -- against the oracle on that grid; host vectors and
+    device-resident parameters agree; nothing goes one walker at a time any more"""
+    from naima_amd._lib import get_context
+    from naima_amd.darray import DPars
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(9)
+    N = 29
+    amp = 10 ** rng.normal(36, 0.2, N)
+    alpha = rng.uniform(1.8, 2.9, N)
+    ecut = rng.uniform(5, 200, N)
+    emin = 10 ** rng.uniform(-3.2, -0.5, N)     # GeV: grids that start below and above 2 MeV
+    emax = 10 ** rng.uniform(3.0, 5.5, N)       # GeV
+    n0 = rng.uniform(0.5, 30, N)
+    Eg = np.geomspace(1e4, 1e13, 75)            # (10 keV ... 10 TeV; two tiles of 64 energies)
+    pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 1 * u.TeV, alpha, ecut * u.TeV)
+    br = na.Bremsstrahlung(pd, n0=n0 / u.cm ** 3, Eemin=emin * u.GeV, Eemax=emax * u.GeV, nEed=41)
+    assert not br._needs_walker_loop()
+    f = br.flux(Eg * u.eV, 0).value
+    assert f.shape == (N, Eg.size)
+    nodes = set()
+    for i in range(N):
+        gam = O.electron_grid(emin[i] * 1e9, emax[i] * 1e9, 41)
+        nodes.add(gam.size)
+        opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e12, alpha=alpha[i],
+                             e_cutoff=ecut[i] * 1e12, beta=1.0)
+        ref = O.brems_spectrum(Eg, gam, O.nelec_on(opd, gam), n0=n0[i])
+        assert_allclose(f[i], ref, rtol=1e-9, atol=np.abs(ref).max() * 1e-13)
+    assert len(nodes) > 8
+    # the same with every parameter resident on the device (as the device loop hands them over)
+    ctx = get_context()
+    host = np.stack([np.log10(amp), alpha, np.log10(ecut), np.log10(emin), np.log10(n0)])
+    pars = DPars(ctx, ctx.array(host), 5, N)
+    pdd = na.ExponentialCutoffPowerLaw(10 ** pars[0] / u.eV, 1 * u.TeV, pars[1],
+                                       10 ** pars[2] * u.TeV)
+    brd = na.Bremsstrahlung(pdd, n0=10 ** pars[4] / u.cm ** 3, Eemin=10 ** pars[3] * u.GeV,
+                            Eemax=1e4 * u.GeV, nEed=41)
+    fd = np.asarray(brd.flux(Eg * u.eV, 0).value).reshape(N, Eg.size)
+    fh = na.Bremsstrahlung(pd, n0=n0 / u.cm ** 3, Eemin=emin * u.GeV, Eemax=1e4 * u.GeV,
+                           nEed=41).flux(Eg * u.eV, 0).value
+    assert_allclose(fd, fh, rtol=1e-10, atol=np.abs(fh).max() * 1e-13)
