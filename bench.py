@@ -269,6 +269,7 @@ def main():
 
     device = not args.host_loop
     keep_blobs = not args.no_blobs
+    shared_note = None
     sampler = make_sampler(device, not args.no_graph, blobs=keep_blobs)
     # naima's initial ensemble: a ball of 10 % of p0 around p0 (core.py:477-481)
     pos = p0 + args.ball * p0 * sampler._rng.normal(size=(nwalkers, p0.size))
@@ -285,7 +286,12 @@ def main():
             sampler._dev.check_resident()
         except _lib.NaimaHipError:
             bad = 1.0
+        shared_note = ("taken" if sampler._dev.shared else "not available: %s"
+                       % getattr(sampler._dev, "resident_reason", "the model's launches are not "
+                                 "ones the resident kernel absorbs"))
         if comm.max(bad) > 0:
+            shared_note = ("a launch of the rehearsal gave up waiting for a record (workgroups not "
+                           "all resident, or a rank fell behind): per-launch loop for this run")
             os.environ["NAIMA_AMD_SHARED"] = "0"
             sampler = make_sampler(device, not args.no_graph, blobs=keep_blobs)
             state = sampler.run_mcmc(pos, max(2, args.warmup), store=False)
@@ -448,6 +454,7 @@ def main():
                            "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
                            else "all-gather between two graphs per half-step")
             if device else "host loop",
+            "shared_resident_loop": shared_note,
             "chain": "discarded (store=False)" if args.no_chain else
             "kept: every step's coords, log-prob%s appended in HBM by the step kernels"
             % (" and blobs" if keep_blobs else "")},
