@@ -1098,7 +1098,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (e == hipSuccess) e = hipMemset(Q->nacc_own, 0, (size_t)R.N * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&Q->curstamp, (size_t)R.N * sizeof(int));
     if (e == hipSuccess) e = hipMemset(Q->curstamp, 0xFF, (size_t)R.N * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&Q->probe_out, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&Q->probe_out, (4 + HS_RUN_MAX_RANKS) * sizeof(int));
   } else {
     e = hipMalloc(&Q->ring, ring_bytes);
     if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
@@ -1192,13 +1192,14 @@ extern "C" int nh_half_step_run_attach(nh_ctx* c, nh_halfstep_run* Q, int peer, 
 
 // `rounds` exchanges of a tagged granule with every peer inside ONE launch: round r is stored
 // into slot [my rank] of every peer's head, then slot [p] of the local head is polled for every
-// peer p.  It passes only if stores made by another GPU while this kernel runs become visible
+// peer p until it shows round r or a later one (tags count up across rounds and probes).  It passes only if stores made by another GPU while this kernel runs become visible
 // to its polling loads -- the property the shared loop stands on.
 struct hs_probe_args {
   unsigned long long* peer[HS_RUN_MAX_RANKS];
   int nrank, rank, rounds, spin_limit;
   unsigned seq;
-  int* out;  // status (0 ok) | rounds completed | 100 MHz ticks of all rounds | spins
+  int* out;  // status (0 ok) | rounds completed | 100 MHz ticks of all rounds | spins | then
+             // per peer: the last round whose granule was seen (diagnostics of a failed probe)
 };
 __global__ void k_run_probe(const hs_probe_args A) {
   const int lane = threadIdx.x;
@@ -1210,7 +1211,7 @@ __global__ void k_run_probe(const hs_probe_args A) {
     if (p == A.rank) mine = A.peer[p];
     if (p == lane) theirs = A.peer[p];
   }
-  int bad = 0, r = 0, spins_total = 0;
+  int bad = 0, r = 0, spins_total = 0, seen = 0;
   const long long t0 = wall_clock64();
   for (r = 1; r <= A.rounds && !bad; ++r) {
     const unsigned tag = (A.seq << 12) | (unsigned)r;
@@ -1220,7 +1221,10 @@ __global__ void k_run_probe(const hs_probe_args A) {
     for (;;) {
       if (!ok) {
         const unsigned long long v = hs_ld_sys(mine + lane);
-        ok = (unsigned)(v >> 32) == tag && (unsigned)v == (unsigned)lane;
+        // (">=": a peer that has seen everybody's round r moves on and overwrites its slot with
+        // round r + 1, or with the next probe's first round, before a slower rank has looked)
+        ok = (int)((unsigned)(v >> 32) - tag) >= 0 && (unsigned)v == (unsigned)lane;
+        if (ok) seen = r;
       }
       if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
       if (++spins > A.spin_limit) { bad = HS_RUN_ERR_TIMEOUT; break; }
@@ -1230,10 +1234,11 @@ __global__ void k_run_probe(const hs_probe_args A) {
   }
   if (lane == 0) {
     A.out[0] = bad;
-    A.out[1] = r - 1;
+    A.out[1] = bad ? r - 2 : r - 1;
     A.out[2] = (int)(wall_clock64() - t0);
     A.out[3] = spins_total;
   }
+  if (lane < HS_RUN_MAX_RANKS) A.out[4 + lane] = on ? seen : -1;
 }
 
 extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds, int* status,
@@ -1254,10 +1259,18 @@ extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds,
   NH_CHECK_HIP(hipGetLastError());
   int rc = nh_sync(c);
   if (rc) return rc;
-  int o[4];
+  int o[4 + HS_RUN_MAX_RANKS];
   NH_CHECK_HIP(hipMemcpy(o, Q->probe_out, sizeof(o), hipMemcpyDeviceToHost));
   *status = o[0];
   if (us_per_round) *us_per_round = o[1] > 0 ? (double)o[2] * 0.01 / o[1] : 0.0;
+  if (o[0] != 0) {  // (what the caller's warning says: which peers' granules stopped coming)
+    char msg[160];
+    int n = snprintf(msg, sizeof(msg), "probe of rank %d: %d of %d rounds; last round seen per peer:",
+                     Q->rank, o[1], rounds);
+    for (int p = 0; p < Q->nrank && n < (int)sizeof(msg) - 8; ++p)
+      n += snprintf(msg + n, sizeof(msg) - n, " %d", o[4 + p]);
+    nh_set_error(NH_EHIP, "%s", msg);
+  }
   return NH_OK;
 }
 

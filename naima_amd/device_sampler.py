@@ -888,8 +888,9 @@ class DeviceLoop:
         st, us = _lib._i(), C.c_double()
         ok = lib.nh_half_step_run_probe(ctx.h, h, 64, C.byref(st), C.byref(us)) == 0 and \
             st.value == 0
+        why = "" if ok else lib.nh_last_error().decode()
         if not agreed(ok):
-            return give_up("a record stored by another GPU did not reach a running kernel")
+            return give_up("a record stored by another GPU did not reach a running kernel; %s" % why)
         self._res["runs"].append(h)
         gr, t, l = _lib._i(), _lib._i(), _lib._ll()
         _lib._chk(lib.nh_half_step_run_info(h, C.byref(gr), C.byref(t), C.byref(l)))

@@ -619,13 +619,15 @@ def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
     assert np.array_equal(out["1"][1], out["0"][1])
 
 
-@pytest.mark.parametrize("name,nw", [("cfg3", 32), ("cfg5", 64), ("cfg2", 48), ("cfg3", 30)],
-                         ids=["cfg3-32", "cfg5-64", "cfg2-48", "cfg3-30-uneven-blocks"])
-def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw):
-    """the resident loop over an ensemble SHARED by two ranks (nh_half_step_run_create_shared):
-    two processes, here on the one GPU of the box, each mapping the other's rings through hipIpc;
-    a mover stores its walker's record into both rings, nobody launches or gathers per
-    half-step.  Every rank ends with the same ensemble, chain, log-probabilities, blobs (history
+@pytest.mark.parametrize("name,nw,nranks", [("cfg3", 32, 2), ("cfg5", 64, 2), ("cfg2", 48, 2),
+                                            ("cfg3", 30, 2), ("cfg3", 40, 4), ("cfg1", 32, 3)],
+                         ids=["cfg3-32", "cfg5-64", "cfg2-48", "cfg3-30-uneven-blocks",
+                              "cfg3-40-four-ranks", "cfg1-32-three-ranks-uneven"])
+def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
+    """the resident loop over an ensemble SHARED by two (three, four) ranks
+    (nh_half_step_run_create_shared): one process per rank, here all on the one GPU of the box,
+    each mapping the others' rings through hipIpc; a mover stores its walker's record into every
+    ring, nobody launches or gathers per half-step.  Every rank ends with the same ensemble, chain, log-probabilities, blobs (history
     rows gathered from whoever moved the walker, rows of rejected moves filled from the row
     before; current blobs merged by stamp after a call without history) and acceptance counts
     as one process on one GPU -- bit for bit: the walkers' arithmetic is the same code."""
@@ -636,8 +638,8 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29800 + (os.getpid() % 1000)
     subprocess.check_call(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-         "--master-addr", "127.0.0.1", "--master-port", str(port),
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node=%d" % nranks, "--master-addr", "127.0.0.1", "--master-port", str(port),
          os.path.join(root, "tests", "gpu_shared_ranks_worker.py"), str(tmp_path), name, str(nw)],
         cwd=root, timeout=600,
         env=dict(os.environ, MASTER_ADDR="127.0.0.1", NH_RUN_SPIN_LIMIT=str(1 << 24)))
@@ -655,7 +657,7 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw):
                 blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
                 acc=s.acceptance_fraction)
     assert want["chain"].shape[0] == 79
-    for r in (0, 1):
+    for r in range(nranks):
         for key, w in want.items():
             have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
             assert have.shape == w.shape, (key, r)
