@@ -430,6 +430,19 @@ int nh_general_electron(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NP
                         const nh_lazy* seed_T_K /*host*/, const nh_lazy* seed_theta /*host*/,
                         int nseed, const double* E_eV, int nE, double* out, int ldo, int nmax,
                         int* status /*device, 2 ints*/);
+/* the same over every walker's own grid for ONE monochromatic (ns = 1: seed_dens its energy
+ * density, eV/cm3) or tabulated (seed_dens in 1/(eV cm3) at the ns energies seed_E, eV) isotropic
+ * seed field that all walkers share -- InverseCompton._calc_specic's inner trapz_loglog over the
+ * seed's energies (radiative.py:609-655) at every (node, photon energy):
+ * out[w*ldo + k] = trapz_loglog(nelec sigma_seed, gamma); the caller applies Eph / E
+ * (radiative.py:684-687) */
+int nh_general_electron_seed(nh_ctx* ctx, int kind, const double* rows /*[N][NH_PD_NPAR]*/, int N,
+                             const nh_lazy* Eemin /*host*/, double Eemin_unit_erg,
+                             const nh_lazy* Eemax /*host*/, double Eemax_unit_erg,
+                             const nh_lazy* nEed /*host*/, const double* seed_E /*device*/,
+                             const double* seed_dens /*device*/, int ns,
+                             const double* E_eV /*device*/, int nE, double* out, int ldo, int nmax,
+                             int* status);
 
 /* The same for protons: Epmin / Epmax / nEpd per walker (radiative.py:1002-1055, 1495-1536).
  * Walker w integrates over Ep = logspace(log10 Epmin_w, log10 Epmax_w, max(10, int(nEpd_w *

@@ -128,6 +128,8 @@ _SIGS = {
     "nh_half_step_run_destroy": [_dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _i, _dp, _dp, _dp, _i, _dp, _i,
                             _dp, _i, _i, _dp],
+    "nh_general_electron_seed": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _dp, _dp, _i, _dp, _i, _dp,
+                                 _i, _i, _dp],
     "nh_general_proton": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _i, _i, _i, _i, _dp, _i, _dp, _i,
                           _dp, _dp, _i, _dp, _i, _i, _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _dp, _i, _i, _dp],

@@ -31,6 +31,7 @@ struct gen_args {
   const double* E_eV; int nE;
   double* out; int ldo;  // out[w*ldo + c*nE + k]
   int nmax;              // LDS capacity in nodes
+  const double* seed_E; const double* seed_d; int ns;  // what = 4: a monochromatic / tabulated seed
   int* status;           // [0]: the largest node count asked for when it exceeds nmax;
                          // [1]: evaluations whose node count sat on an int() boundary
 };
@@ -162,6 +163,33 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
       }
       __syncthreads();
     }
+  } else if (A.what == 4) {
+    // ---- InverseCompton on a monochromatic (ns = 1: energy density, eV/cm3) or tabulated
+    // (1/(eV cm3) at ns energies) isotropic seed, the same for every walker: the inner
+    // trapz_loglog over the seed's energies at every (node, photon energy), radiative.py:609-655;
+    // the caller applies Eph / E (radiative.py:684-687) ----------------------------------------
+    for (int k0 = 0; k0 < A.nE; k0 += 64) {
+      const int k = k0 + lane;
+      double acc = 0.0;
+      if (k < A.nE && s0 < s1) {
+        const double eg = A.E_eV[k] / NH_MEC2_EV;
+        auto Ks = [&](double g) {
+          return ic_seed_inner(A.seed_E, A.seed_d, A.ns, g, eg) *
+                 ((3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g));  // radiative.py:650-653
+        };
+        double K1 = Ks(gam[s0]);
+        for (int s = s0; s < s1; ++s) {
+          const double K2 = Ks(gam[s + 1]);
+          acc += gen_term(wv[s], wv[s + 1], dw[s], K1, K2, lxs[s]);
+          K1 = K2;
+        }
+      }
+      part[wvi * 64 + lane] = acc;
+      __syncthreads();
+      if (wvi == 0 && k < A.nE)
+        orow[k] = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+      __syncthreads();
+    }
   } else if (A.what == 3) {
     // ---- Bremsstrahlung: comp 0 = int(n sigma_ee), comp 1 = int(n sigma_1), per eV (the caller
     // applies n0 c and the abundance weights, radiative.py:949-987; the Baring+99 fits go
@@ -214,20 +242,21 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
   }
 }
 
-extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int N,
-                                   const nh_lazy* Eemin, double Eemin_unit_erg,
-                                   const nh_lazy* Eemax, double Eemax_unit_erg,
-                                   const nh_lazy* nEed, int what, const nh_lazy* B_G,
-                                   const nh_lazy* seed_T, const nh_lazy* seed_theta, int nseed,
-                                   const double* E_eV, int nE, double* out, int ldo, int nmax,
-                                   int* status) {
+static int general_electron(nh_ctx* c, int kind, const double* rows, int N,
+                            const nh_lazy* Eemin, double Eemin_unit_erg,
+                            const nh_lazy* Eemax, double Eemax_unit_erg,
+                            const nh_lazy* nEed, int what, const nh_lazy* B_G,
+                            const nh_lazy* seed_T, const nh_lazy* seed_theta, int nseed,
+                            const double* seed_E, const double* seed_d, int ns,
+                            const double* E_eV, int nE, double* out, int ldo, int nmax,
+                            int* status) {
   NH_REQUIRE(c && rows && Eemin && Eemax && nEed && out && status, "NULL pointer");
   NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
   NH_REQUIRE(N >= 0 && nmax >= 10 && Eemin_unit_erg > 0 && Eemax_unit_erg > 0, "bad sizes");
   NH_REQUIRE(what == 2 || (E_eV && nE >= 1), "photon energies missing");
   NH_REQUIRE(nEed->base || nEed->a > 0.0, "nEed must be positive");
   NH_REQUIRE(what == 0 ? (B_G != nullptr)
-                       : (what == 2 || what == 3 ||
+                       : (what == 2 || what == 3 || (what == 4 && seed_E && seed_d && ns >= 1) ||
                           (what == 1 && seed_T && seed_theta && nseed >= 1 && nseed <= NH_MAX_COMP)),
              "bad component");
   if (what == 2) nE = 1;
@@ -246,6 +275,7 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
     A.theta[s] = seed_theta[s];
   }
   A.E_eV = E_eV; A.nE = nE; A.out = out; A.ldo = ldo; A.nmax = nmax; A.status = status;
+  A.seed_E = seed_E; A.seed_d = seed_d; A.ns = ns;
   const size_t lds = ((size_t)4 * nmax + 256) * sizeof(double);
   NH_REQUIRE(lds <= 150 * 1024, "nmax does not fit in LDS (at most ~4700 nodes)");
   if (lds > 64 * 1024)
@@ -257,6 +287,32 @@ extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int 
                      c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
+}
+
+extern "C" int nh_general_electron(nh_ctx* c, int kind, const double* rows, int N,
+                                   const nh_lazy* Eemin, double Eemin_unit_erg,
+                                   const nh_lazy* Eemax, double Eemax_unit_erg,
+                                   const nh_lazy* nEed, int what, const nh_lazy* B_G,
+                                   const nh_lazy* seed_T, const nh_lazy* seed_theta, int nseed,
+                                   const double* E_eV, int nE, double* out, int ldo, int nmax,
+                                   int* status) {
+  NH_REQUIRE(what >= 0 && what <= 3, "what = 0 .. 3");
+  return general_electron(c, kind, rows, N, Eemin, Eemin_unit_erg, Eemax, Eemax_unit_erg, nEed, what,
+                          B_G, seed_T, seed_theta, nseed, nullptr, nullptr, 0, E_eV, nE, out, ldo,
+                          nmax, status);
+}
+
+// InverseCompton on ONE monochromatic or tabulated isotropic seed field that is the same for
+// every walker, over every walker's own grid (k_general_electron, what = 4)
+extern "C" int nh_general_electron_seed(nh_ctx* c, int kind, const double* rows, int N,
+                                        const nh_lazy* Eemin, double Eemin_unit_erg,
+                                        const nh_lazy* Eemax, double Eemax_unit_erg,
+                                        const nh_lazy* nEed, const double* seed_E,
+                                        const double* seed_dens, int ns, const double* E_eV, int nE,
+                                        double* out, int ldo, int nmax, int* status) {
+  return general_electron(c, kind, rows, N, Eemin, Eemin_unit_erg, Eemax, Eemax_unit_erg, nEed, 4,
+                          nullptr, nullptr, nullptr, 0, seed_E, seed_dens, ns, E_eV, nE, out, ldo,
+                          nmax, status);
 }
 
 

@@ -66,42 +66,7 @@ extern "C" int nh_table_ic_planck(nh_ctx* c, const double* gam, int nG, const do
   return table_dlog(c, Kt, nG, nE, ld, lnKt);
 }
 
-// ---------------------------------------------------------------------------
-// row 8: Aharonian & Atoyan 81 Eq. 22 (radiative.py:609-655)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double ic_fic_windowed(double e0, double g, double eg) {
-  double b = 4.0 * e0 * g;
-  double wq = eg / g;
-  double q = wq / (b * (1.0 - wq));
-  double bq = b * q;
-  double fic = 2.0 * q * log(q) + (1.0 + 2.0 * q) * (1.0 - q) +
-               0.5 * (bq * bq) * (1.0 - q) / (1.0 + bq);
-  double gi = fic * nh_heaviside(1.0 - q) * nh_heaviside(q - 1.0 / (4.0 * (g * g)));
-  return (gi != gi) ? 0.0 : gi;  // gamint[isnan] = 0, radiative.py:636
-}
-
-// inner reduction over the seed spectrum for one (E_k, gamma_i): trapz_loglog of
-// fic*n_ph/eps0 over eps0 (radiative.py:638-640), in the u/l form of nh_seg_term
-__device__ __forceinline__ double ic_seed_inner(const double* __restrict__ se,
-                                                const double* __restrict__ sd, int ns, double g,
-                                                double eg) {
-  if (ns == 1) {
-    double e0 = se[0] / NH_MEC2_EV;
-    double dens = sd[0] / NH_MEC2_EV;  // eV/cm3 -> mec2/cm3, radiative.py:642
-    return ic_fic_windowed(e0, g, eg) * (dens / (e0 * e0));
-  }
-  double acc = 0.0;
-  double e1 = se[0] / NH_MEC2_EV;
-  double u1 = ic_fic_windowed(e1, g, eg) * (sd[0] * NH_MEC2_EV);  // y*x = fic*n_ph
-  for (int s = 1; s < ns; ++s) {
-    double e2 = se[s] / NH_MEC2_EV;
-    double u2 = ic_fic_windowed(e2, g, eg) * (sd[s] * NH_MEC2_EV);
-    acc += nh_seg_term(u1, u2, log(fabs(u2 / u1)), log(e2 / e1));
-    e1 = e2; u1 = u2;
-  }
-  return acc;
-}
-
+// row 8: Aharonian & Atoyan 81 Eq. 22 (radiative.py:609-655): ic_fic_windowed / ic_seed_inner in nh_ic.h
 __global__ __launch_bounds__(256) void k_table_ic_seed(const double* __restrict__ gam, int nG,
                                                         const double* __restrict__ E_eV, int nE,
                                                         const double* __restrict__ se,

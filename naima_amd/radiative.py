@@ -428,9 +428,11 @@ class BaseElectron(BaseRadiative):
             return False
         return super()._needs_walker_loop()
 
-    def _general_launch(self, what, E_eV, B=None, seeds=(), Eemin=None, Eemax=None):
+    def _general_launch(self, what, E_eV, B=None, seeds=(), Eemin=None, Eemax=None, seed_arrays=None):
         """spectra [N][ncomp * nE] of nh_general_electron (device buffer); what = 2: We over
-        each walker's grid between Eemin and Eemax (default: the object's own limits), [N][1]"""
+        each walker's grid between Eemin and Eemax (default: the object's own limits), [N][1];
+        what = 4: InverseCompton on the shared monochromatic / tabulated seed
+        ``seed_arrays = (energies [eV], densities)`` (nh_general_electron_seed)"""
         import ctypes as C
 
         from .darray import lazy_const
@@ -482,11 +484,18 @@ class BaseElectron(BaseRadiative):
             else:
                 th[j], k = lazy_of(thq, "rad")
                 keep.append(k)
-        ctx.call("nh_general_electron", PD_KIND[pd.kind], rows, N, C.addressof(emin),
-                 float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
-                 C.addressof(ned), what, C.addressof(Bl) if Bl is not None else None, T, th, ncomp,
-                 ctx.const(E_eV) if what != 2 else None, nE, out, ncomp * nE, ctx.general_nmax,
-                 status)
+        if what == 4:
+            se, sd = seed_arrays
+            ctx.call("nh_general_electron_seed", PD_KIND[pd.kind], rows, N, C.addressof(emin),
+                     float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
+                     C.addressof(ned), ctx.const(se), ctx.const(sd), int(se.size), ctx.const(E_eV),
+                     nE, out, nE, ctx.general_nmax, status)
+        else:
+            ctx.call("nh_general_electron", PD_KIND[pd.kind], rows, N, C.addressof(emin),
+                     float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
+                     C.addressof(ned), what, C.addressof(Bl) if Bl is not None else None, T, th,
+                     ncomp, ctx.const(E_eV) if what != 2 else None, nE, out, ncomp * nE,
+                     ctx.general_nmax, status)
         del k1, k2, k3, k4, rows, keep
         if not self.on_device:
             ctx.check_general()
@@ -677,9 +686,12 @@ class InverseCompton(BaseElectron):
         self.__dict__.update(**kwargs)
 
     def _general_supported(self):
-        """the general path on the device: thermal seed fields only (their temperature, angle
-        and energy density may all be per walker)"""
-        return all(seed["type"] == "thermal" for seed in self.seed_photon_fields.values())
+        """the general path on the device: thermal seed fields (their temperature, angle and
+        energy density may all be per walker) and monochromatic / tabulated seeds that every
+        walker shares (a photon density per walker -- SSC -- still goes one walker at a time
+        when the grids differ too)"""
+        return all(seed["type"] == "thermal" or not self._seed_per_walker(seed)
+                   for seed in self.seed_photon_fields.values())
 
     def _seed_shape_per_walker(self):
         """a thermal seed whose temperature or angle is given per walker: its Khangulyan kernel
@@ -700,15 +712,30 @@ class InverseCompton(BaseElectron):
         """radiative.py:657-710 with a particle grid per walker (nh_general_electron): the
         Khangulyan kernel at every (node, energy) of every walker, no shared table"""
         nE = E_eV.size
-        names = list(self.seed_photon_fields)
+        allnames = list(self.seed_photon_fields)
+        names = [n for n in allnames if self.seed_photon_fields[n]["type"] == "thermal"]
+        Eph = E_eV / MEC2_EV
+        dev = self.on_device
+        byname = {}
+        for n in allnames:  # monochromatic / tabulated seeds: one launch each (what = 4)
+            seed = self.seed_photon_fields[n]
+            if seed["type"] == "thermal":
+                continue
+            se = np.atleast_1d(seed["energy"].to("eV").value).astype(float)
+            if se.size == 1:
+                sdv = np.atleast_1d(seed["photon_density"].to("eV/cm3").value).astype(float)
+            else:
+                sdv = np.asarray(seed["photon_density"].to("1/(eV cm3)").value, dtype=float)
+            ctx, N, o1 = self._general_launch(4, E_eV, seed_arrays=(se, sdv))
+            colfac = Eph / E_eV  # radiative.py:684-687 (uf = 1)
+            byname[n] = (DMat.from_buffer(ctx, o1, N, nE) * colfac) if dev else o1.get() * colfac
         seeds = []
         for n in names:
             sd = self.seed_photon_fields[n]
             seeds.append((sd["T"], None if sd["isotropic"] else sd["theta"]))
-        ctx, N, out = self._general_launch(1, E_eV, seeds=seeds)
-        Eph = E_eV / MEC2_EV
-        dev = self.on_device
-        host = None if dev else out.get()
+        if names:
+            ctx, N, out = self._general_launch(1, E_eV, seeds=seeds)
+        host = None if (dev or not names) else out.get()
         specs = []
         for j, n in enumerate(names):
             sd = self.seed_photon_fields[n]
@@ -723,6 +750,8 @@ class InverseCompton(BaseElectron):
             else:
                 v = host[:, j * nE:(j + 1) * nE] * colfac
                 specs.append(v * np.broadcast_to(np.asarray(uf, dtype=float), (N,))[:, None])
+        byname.update(zip(names, specs))
+        specs = [byname[n] for n in allnames]  # (in the order the seeds were given: specic)
         if dev:
             self.specic = [u.Quantity(m, _SPEC_UNIT) for m in specs]
             total = specs[0]

@@ -157,11 +157,20 @@ def test_general_path_device_values(na):
         pk = na.ExponentialCutoffPowerLaw(10 ** host[0, k] / u.eV, 10 * u.TeV, 2.4, 50 * u.TeV)
         one = seeded(pk, host[:, k]).flux(E, 1 * u.kpc)  # (scalars: the cached tables)
         assert_allclose(fh[k].value, one.value, rtol=1e-10)
-    # what still has no device form: a non-thermal seed beside a per-walker temperature
-    with pytest.raises(NotImplementedError):
-        na.InverseCompton(pdd, seed_photon_fields=[
-            ["FIR", P[1] * u.K, 0.5 * u.eV / u.cm ** 3],
-            ["mono", 1 * u.eV, 1 * u.eV / u.cm ** 3]]).flux(E, 1 * u.kpc)
+    # a non-thermal seed (shared by the walkers) beside a per-walker temperature: the general
+    # kernel as well (what = 4), device values == host vectors
+    def mixed(pd_, p):
+        return na.InverseCompton(pd_, seed_photon_fields=[
+            ["FIR", 6 * p[1] * u.K, 0.5 * u.eV / u.cm ** 3],
+            ["mono", 1 * u.eV, 1 * u.eV / u.cm ** 3]])
+
+    md, mh = mixed(pdd, P), mixed(pdh, host)
+    assert not md._needs_walker_loop() and not mh._needs_walker_loop()
+    assert_allclose(np.asarray(md.flux(E, 1 * u.kpc).value), mh.flux(E, 1 * u.kpc).value, rtol=1e-13)
+    for k in range(3):
+        pk = na.ExponentialCutoffPowerLaw(10 ** host[0, k] / u.eV, 10 * u.TeV, 2.4, 50 * u.TeV)
+        one = mixed(pk, host[:, k]).flux(E, 1 * u.kpc)  # (scalars: the cached tables)
+        assert_allclose(mh.flux(E, 1 * u.kpc)[k].value, one.value, rtol=1e-10)
 
 
 def test_general_kernel_against_oracle(na):
@@ -683,3 +692,45 @@ def test_general_bremsstrahlung_against_oracle(na):
     fh = na.Bremsstrahlung(pd, n0=n0 / u.cm ** 3, Eemin=emin * u.GeV, Eemax=1e4 * u.GeV,
                            nEed=41).flux(Eg * u.eV, 0).value
     assert_allclose(fd, fh, rtol=1e-10, atol=np.abs(fh).max() * 1e-13)
+
+
+def test_general_inverse_compton_on_shared_non_thermal_seeds(na):
+    """InverseCompton with Eemin / Eemax per walker AND monochromatic / tabulated seed fields
+    (the same for every walker) beside thermal ones: every seed through the general kernel on
+    each walker's own grid -- the inner trapz_loglog over a tabulated seed's energies
+    (radiative.py:609-655) at every (node, photon energy) -- against the oracle, total and per
+    seed; nothing goes one walker at a time"""
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(21)
+    N = 19
+    amp = 10 ** rng.normal(34, 0.2, N)
+    alpha = rng.uniform(1.9, 2.8, N)
+    ecut = rng.uniform(10, 150, N)
+    emin = 10 ** rng.uniform(-1, 2, N)       # GeV
+    emax = 10 ** rng.uniform(4.2, 5.8, N)    # GeV
+    mono_E, mono_u = 0.7, 1.3                # eV, eV/cm3
+    arr_E = np.geomspace(1e-3, 30.0, 23)     # eV
+    arr_n = 5e2 * arr_E ** -1.4 * np.exp(-arr_E / 8.0)  # 1/(eV cm3)
+    pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, ecut * u.TeV)
+    seeds_na = ["CMB", ["mono", mono_E * u.eV, mono_u * u.eV / u.cm ** 3],
+                ["star", 6000 * u.K, 3 * u.eV / u.cm ** 3, 100 * u.deg],
+                ["tab", arr_E * u.eV, arr_n / (u.eV * u.cm ** 3)]]
+    ic = na.InverseCompton(pd, seed_photon_fields=seeds_na, Eemin=emin * u.GeV, Eemax=emax * u.GeV,
+                           nEed=33)
+    assert not ic._needs_walker_loop()
+    Eg = np.geomspace(1e7, 1e14, 31)
+    f = ic.flux(Eg * u.eV, 0).value
+    per = [ic.flux(Eg * u.eV, 0, seed=n).value for n in ("CMB", "mono", "star", "tab")]
+    seeds_o = [O.thermal_seed("CMB"),
+               dict(type="array", energy=np.array([mono_E]), density=np.array([mono_u])),
+               dict(type="thermal", T=6000.0, u=3 * O.ERG_PER_EV, theta=np.deg2rad(100.0)),
+               dict(type="array", energy=arr_E, density=arr_n)]
+    for i in range(N):
+        gam = O.electron_grid(emin[i] * 1e9, emax[i] * 1e9, 33)
+        opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13, alpha=alpha[i],
+                             e_cutoff=ecut[i] * 1e12, beta=1.0)
+        tot, each = O.ic_spectrum(Eg, gam, O.nelec_on(opd, gam), seeds_o)
+        assert_allclose(f[i], tot, rtol=1e-9, atol=tot.max() * 1e-200)
+        for j in range(4):
+            assert_allclose(per[j][i], each[j], rtol=1e-9, atol=tot.max() * 1e-200)
