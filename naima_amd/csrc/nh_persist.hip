@@ -885,7 +885,11 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   const int N = R.N, ndim = H.ndim;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gsz = (long long)gridDim.x * blockDim.x;
-  for (long long e = gid; e < (long long)N * (ndim + 1); e += gsz) {
+  // the three jobs -- ensemble, counters, one per blob -- side by side (blockIdx.y): each is a
+  // chain of dependent round trips, one after the other they added up to 15 us of a 20-step
+  // region
+  const int job = blockIdx.y;
+  for (long long e = job == 0 ? gid : (long long)N * (ndim + 1); e < (long long)N * (ndim + 1); e += gsz) {
     const int w = (int)(e / (ndim + 1)), d = (int)(e % (ndim + 1));
     const unsigned long long* rec = R.ring + ((long long)nsteps * N + w) * R.gr + 2 * d;
     unsigned long long lo = rec[0], hiw = rec[1];
@@ -912,7 +916,7 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
     else const_cast<double*>(H.logp)[w] = v;
   }
   int* const nacc = R.nrank > 1 ? R.nacc_own : D.naccepted;
-  if (nacc)
+  if (nacc && job == 1)
     for (long long w = gid; w < N; w += gsz) {
       int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
 #pragma unroll
@@ -938,7 +942,7 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   for (int b = 0; b < D.nblob; ++b) {
     const nh_hs_blob& bl = D.blob[b];
     double* hb = hist ? R.hblob[b] : nullptr;
-    if (!hb) continue;
+    if (!hb || job != 2 + b) continue;
     for (long long e = gid; e < (long long)N * bl.m; e += gsz) {
       const int w = (int)(e / bl.m);
       // (every load of the column is issued before the first is used: walked one step at a time
@@ -1348,9 +1352,10 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   }
   {
     nh_prof_scope ps(c, NH_K_GLUE);
-    const long long work = (long long)R.N * (H.nE + H.ndim + 2);
-    const int blocks = (int)((work + 255) / 256 < 1024 ? (work + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_run_epilogue, dim3(blocks), dim3(256), 0, c->stream, H, R, nslices / 2);
+    const long long work = (long long)R.N * (H.nE > H.ndim + 1 ? H.nE : H.ndim + 1);
+    const int blocks = (int)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512);
+    const int jobs = 2 + ((hist_coords && !Q->base) ? H.C.nblob : 0);
+    hipLaunchKernelGGL(k_run_epilogue, dim3(blocks, jobs), dim3(256), 0, c->stream, H, R, nslices / 2);
     NH_CHECK_HIP(hipGetLastError());
   }
   return NH_OK;
