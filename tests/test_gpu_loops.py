@@ -652,11 +652,14 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
     st = s.run_mcmc(st, 70)
     st = s.run_mcmc(st, 9, store=False)
     st = s.run_mcmc(st, 4)
+    for st in s.sample(st, iterations=3):
+        pass
+    st = s.run_mcmc(st, 5)
     want = dict(coords=st.coords, logp=st.log_prob, curblob0=np.asarray(st.blobs[0]),
                 curblob1=np.asarray(st.blobs[1]), chain=s.get_chain(), lnp=s.get_log_prob(),
                 blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
                 acc=s.acceptance_fraction)
-    assert want["chain"].shape[0] == 79
+    assert want["chain"].shape[0] == 87
     for r in range(nranks):
         for key, w in want.items():
             have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
