@@ -585,6 +585,15 @@ int nh_half_step_run(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run* run, 
                      double* const* hist_blobs /*host array of device pointers, or NULL*/,
                      long long hist_row0, long long hist_cap);
 int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
+/* The resident loop's own copies of the plan's emission tables with their columns SORTED by the
+ * first grid row in which they are non-zero (an inverse-Compton or pi0 table is zero below the
+ * kinematic threshold gamma = E / mec2, Ep = E ...: rows that contribute exact zeros to
+ * trapz_loglog, utils.py:347-348).  kds[t] (device): the interleaved table [nG][nK][2] of plan
+ * table t with permuted columns (nh_table_interleave of the permuted Kt / dlnKt), followed by a
+ * trailer of ints { row0[8] | perm[nK] }: row0[tile] = first row in which any of the tile's 64
+ * columns is non-zero (segments below it are not walked), perm[p] = the column of the spectrum
+ * that position p holds.  NULL keeps the plan's table.  The caller keeps the buffers alive. */
+int nh_half_step_run_tables(nh_halfstep_run* run, const double* const* kds /*host*/, int ntab);
 /* ---- the resident loop over an ensemble SHARED by the GPUs of a node (2 .. 8 ranks, one process
  * per GPU).  Replaces, for walkers sharded as in the per-launch loop (rank r proposes positions
  * [lo, lo + nloc) of every half-step; the reference's analogue is Pool(threads) over a fixed

@@ -117,6 +117,7 @@ _SIGS = {
     "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],
     "nh_half_step_run_status": [_dp, _dp, C.POINTER(_i)],
+    "nh_half_step_run_tables": [_dp, _dp, _i],
     "nh_half_step_run_create_shared": [_dp, _dp, _i, _i, C.POINTER(_dp)],
     "nh_half_step_run_export": [_dp, _dp, _dp],
     "nh_half_step_run_attach": [_dp, _dp, _i, _dp],
@@ -604,6 +605,7 @@ class Context:
         d.nmoms = nmm
         d.syn.grid = -1
         nt = 0
+        tabs = []  # (what the resident loop sorts the columns of: sorted_tables)
         for ent in plan["emit"]:
             k = ent["key"]
             if ent["kind"] == "tab":
@@ -619,6 +621,7 @@ class Context:
                 self._pinned.add(("kd", Kt, dKt, nG * nK, bool(nonneg)))  # the plan points into it
                 d.tab[nt] = D.nh_hs_table(wgrid[w], nK, nK, nonneg, kd.ptr, None, sc or None,
                                           ent["out"].ptr)
+                tabs.append((Kt, dKt, nG, nK, lx, bool(nonneg)))
                 nt += 1
             else:
                 _, w, lw, Bp, ldB, N, gdp, lx, nG, Ed, nEs = k
@@ -672,10 +675,52 @@ class Context:
         spl = _i()
         _chk(_lib.nh_half_step_split(h, C.byref(spl)))
         plan["hs"] = dict(key=key, plan=h, keep=(conv, lpd, total, dd), threads=thr.value,
-                          blocks=blk.value, lds_bytes=lds.value, split=spl.value)
+                          blocks=blk.value, lds_bytes=lds.value, split=spl.value, tabs=tabs)
         # where the step loop stands in the current block of moves
         self.call("nh_half_step_begin_block", h, f["pos"]["slice"], f["pos"]["steps"])
         self.call("nh_half_step_launch", h, -1)
+
+    def sorted_tables(self, hs, run):
+        """the resident loop's own copies of the plan's tables, columns sorted by the first grid
+        row in which they are non-zero (nh_half_step_run_tables): below the kinematic threshold
+        an emission table is exactly zero -- half the grid for cfg3's TeV energies -- and once
+        the highest-energy columns share a tile, the kernel does not walk those rows.  Built on
+        the host from one download of each table (once per plan); a table without leading zero
+        rows keeps the plan's copy."""
+        import ctypes as C
+        if os.environ.get("NAIMA_AMD_SORTED_TABLES", "1") == "0":
+            return
+        ptrs, keep = (C.c_void_p * 4)(), []
+        for t, (Kt, dKt, nG, nK, lx, nonneg) in enumerate(hs.get("tabs", [])[:4]):
+            tiles = (nK + 63) // 64
+            if tiles > 8 or nG < 2:
+                continue
+            Kh, dKh = np.empty((nG, nK)), np.empty((nG, nK))
+            self.join()
+            _chk(_lib.nh_download(self.h, Kh.ctypes.data, Kt, Kh.nbytes))
+            _chk(_lib.nh_download(self.h, dKh.ctypes.data, dKt, dKh.nbytes))
+            live = Kh != 0.0
+            first = np.where(live.any(axis=0), live.argmax(axis=0), nG)
+            perm = np.argsort(first, kind="stable")
+            row0 = [int(first[perm][q * 64:(q + 1) * 64].min()) for q in range(tiles)]
+            if max(row0) < 32:  # (less than one work item's worth of rows to skip anywhere)
+                continue
+            Kp = self.array(np.ascontiguousarray(Kh[:, perm]))
+            dKp = self.array(np.ascontiguousarray(dKh[:, perm]))
+            ntrail = 8 + nK
+            kd = self.empty((2 * nG * nK + (ntrail + 1) // 2,))
+            self.call("nh_table_interleave", Kp, dKp, lx if nonneg else None, nG, nK, kd)
+            trail = np.zeros(2 * ((ntrail + 1) // 2), dtype=np.int32)
+            trail[:tiles] = row0
+            trail[8:8 + nK] = perm
+            th = self.array(trail, dtype=np.int32)
+            self.call("nh_copy", kd.ptr + 16 * nG * nK, th, trail.nbytes)
+            self.sync()
+            ptrs[t] = kd.ptr
+            keep.append(kd)
+        if keep:
+            _chk(_lib.nh_half_step_run_tables(run, ptrs, 4))
+            hs.setdefault("sorted", []).append(keep)  # (alive as long as the plan)
 
     # -- side streams ---------------------------------------------------------
     def branch(self):

@@ -25,6 +25,19 @@ struct hs_tab {
   // struct made the compiler copy the whole by-value descriptor to scratch in k_half_step.)
 };
 #define HS_CHUNKS(pk) ((pk) & 0xff)
+// A table copy with SORTED columns (the resident loop's own, nh_half_step_run_tables): its
+// columns are ordered by the first row in which they are non-zero, and the [nG][nK][2] doubles
+// are followed by a trailer of ints { row0[HS_TRAIL_TILES] | perm[nK] }: row0[tile] = the first
+// row in which any column of the tile is non-zero -- segments below it contribute exact zeros
+// (utils.py:347-348) and are not walked -- and perm[p] = the column of the spectrum that
+// position p of the table holds.  (An inverse-Compton table is zero below gamma = E / mec2: for
+// cfg3's TeV energies that is half the grid; sorted, the 64 highest-energy columns of its three
+// seed fields share a tile.  k_half_step keeps the plain table: a read through one more pointer
+// of its by-value descriptor has the compiler copy all 3 KB of it to scratch.)
+#define HS_TRAIL_TILES 8
+__device__ __forceinline__ const int* hs_tab_trailer(const double* KD, int nG, int nK) {
+  return reinterpret_cast<const int*>(KD + 2 * (long long)nG * nK);
+}
 
 // segments [s0, s1) of chunk `chunk` of a table over a grid of nseg segments
 __device__ __forceinline__ void hs_chunk_range(int packed_chunks, int chunk, int seg, int nseg,
@@ -206,13 +219,14 @@ __device__ __forceinline__ double hs_seg_pre(double acc, double u1, double u2, d
 template <bool SIGNED>
 __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
                                                 const double* ws, const double* ds,
-                                                const double* lxs, int lane) {
+                                                const double* lxs, int lane,
+                                                const double* KD = nullptr) {
   // the table's address and width come out of the descriptor: the compiler cannot
   // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
   // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
   // the 25 the loop then costs) -- say so once per work item instead
   const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
-  const unsigned long long kd = (unsigned long long)t.KD;
+  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
   const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
   const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
   const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
@@ -276,11 +290,12 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
 template <bool SIGNED, int PK>
 __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
                                                        const double* ws, const double* ds,
-                                                       const double* lxs, int lane) {
+                                                       const double* lxs, int lane,
+                                                       const double* KD = nullptr) {
   const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
   const int nKp = __builtin_amdgcn_readfirstlane(t.nKp);
   const int sub = __builtin_amdgcn_readfirstlane(t.sub);
-  const unsigned long long kd = (unsigned long long)t.KD;
+  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
   const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
   const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
   const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);

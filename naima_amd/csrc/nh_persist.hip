@@ -50,6 +50,7 @@
 #define HS_RUN_ERR_LAST_ROW 3  // (epilogue of a shared ensemble: a rank's last records never came)
 #define HS_RUN_MAX_RANKS 8     // GPUs of one node that may share an ensemble
 #define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
+#define HS_RUN_TRAIL 16        // ints of first-row entries per table in LDS (>= tiles of any table)
 
 struct hs_run {
   unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
@@ -70,6 +71,10 @@ struct hs_run {
   int o_gx[NH_MAX_GRIDS], o_lne[NH_MAX_GRIDS], o_ge[NH_MAX_GRIDS];  // LDS: grid nodes, ln E, E
   int o_pk, o_small1, o_olds;  // LDS: pack descriptors, the second small block, old coordinates
   int o_lcl;                   // LDS: ln(1 - cl[n]), n <= nE
+  int o_trail;                 // LDS: the tables' trailers (ints)
+  // the loop's own copies of the plan's tables with their columns sorted (nh_hs.h; NULL: the
+  // plan's table as it is)
+  const double* kds[HS_MAX_TAB];
   // order: 2 = synchrotron items (twice as long as table items) first, then the tables -- the
   // items pulled last decide how far apart the waves reach the barrier (cfg3: 18.9 -> 18.6 us of
   // items + wait); 0 = the two kinds alternate as in k_half_step
@@ -231,6 +236,20 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         sm[ko + nG + i] = H.mdK[m][i];
       }
       ko += 2 * nG;
+    }
+    // the tables' trailers (nh_hs.h: first non-zero row per tile, column order): ints
+    // { row0[HS_MAX_TAB][HS_RUN_TRAIL] | perm[nspec] }, identity for a table without one
+    {
+      int* tr = reinterpret_cast<int*>(sm + R.o_trail);
+      for (int t = 0; t < H.ntab; ++t) {
+        const hs_tab& tb = D.tab[t];
+        const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
+        const bool has = kds != nullptr;
+        const int* src = hs_tab_trailer(has ? kds : tb.KD, H.nG[tb.grid], tb.nK);
+        for (int q = tid; q < HS_RUN_TRAIL; q += T) tr[t * HS_RUN_TRAIL + q] = has && q < HS_TRAIL_TILES ? src[q] : 0;
+        for (int k = tid; k < tb.nK; k += T)
+          tr[HS_RUN_TRAIL * HS_MAX_TAB + tb.spec_off + k] = has ? src[HS_TRAIL_TILES + k] : k;
+      }
     }
     // the parameter packs' columns, one per thread of wave 0: a | b | c | tf, ncols | ld | out
     if (tid < npk8) {
@@ -548,6 +567,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
               sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
             }
             if (wv_ != 0.0) nzmask |= 1 << g;
+            // (a weight that is not finite -- a far-off walker whose distribution overflows --
+            // makes 0 x inf = NaN of a zero table entry, as in the reference: no row of such a
+            // walker's tables is skipped)
+            if (!isfinite(wv_)) nzmask |= 256 << g;
           }
       }
       {
@@ -661,19 +684,25 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
             int s0, s1;
             hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
+            // (rows below the tile's first non-zero one contribute exact zeros: not walked; the
+            // tables' trailers -- identity for a table without one -- sit in LDS for the launch)
+            if (!(nz >> (8 + tg) & 1))
+              s0 = max(s0, __builtin_amdgcn_readfirstlane(
+                               reinterpret_cast<const int*>(sm + R.o_trail)[t * HS_RUN_TRAIL + tile]));
+            const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
             const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
             const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
             const double* ds = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_dp[tg] : H.o_d[tg]);
             const double* lxs = sm + __builtin_amdgcn_readfirstlane(pre ? H.o_th[tg] : H.o_lx[tg]);
             double acc;
-            if (!(nz >> tg & 1))
+            if (!(nz >> tg & 1) || s0 >= s1)
               acc = 0.0;
             else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
-              acc = tb.nonneg ? hs_table_item_packed<false, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane)
-                              : hs_table_item_packed<true, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane);
+              acc = pre ? hs_table_item_packed<false, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane, kds)
+                        : hs_table_item_packed<true, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane, kds);
             else
-              acc = tb.nonneg ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane)
-                              : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane);
+              acc = pre ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds)
+                        : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds);
             part_t[ix * 64 + lane] = acc;
           } else if (SYN) {
             if (!syn_ready) {  // (wave-uniform) the tile waves' constants must have landed
@@ -709,8 +738,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
             sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
           }
-          sum *= sm[H.o_scale + tb.spec_off + k];
-          spec[tb.spec_off + k] = sum;
+          const int ko = reinterpret_cast<const int*>(sm + R.o_trail)[HS_RUN_TRAIL * HS_MAX_TAB +
+                                                                        tb.spec_off + k];  // (sorted columns)
+          sum *= sm[H.o_scale + tb.spec_off + ko];
+          spec[tb.spec_off + ko] = sum;
         }
       }
       if (has_syn) {
@@ -1035,6 +1066,9 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   R.o_small1 = off; off += HS_O_T64;
   R.o_olds = off; off += 128;
   R.o_lcl = off; off += H.nE + 1;
+  R.o_trail = off; off += (HS_RUN_TRAIL * HS_MAX_TAB + H.C.nspec + 1) / 2;
+  for (int t = 0; t < H.ntab; ++t)
+    NH_REQUIRE(H.C.tab[t].tiles <= HS_RUN_TRAIL, "a table of more column tiles than the resident loop stages");
   R.order = nh_env_int("NH_RUN_ORDER", 2);
   R.syn_nodes = H.C.syn_nodes;
   if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = 32;
@@ -1275,6 +1309,15 @@ extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds,
       n += snprintf(msg + n, sizeof(msg) - n, " %d", o[4 + p]);
     nh_set_error(NH_EHIP, "%s", msg);
   }
+  return NH_OK;
+}
+
+// The loop's own copies of the plan's tables with SORTED columns (nh_hs.h): kds[t] = device
+// pointer to [nG][nK][2] doubles + the trailer of ints { row0[8] | perm[nK] }, or NULL to keep
+// the plan's table t.  The caller owns the buffers and keeps them alive with the loop.
+extern "C" int nh_half_step_run_tables(nh_halfstep_run* Q, const double* const* kds, int ntab) {
+  NH_REQUIRE(Q && kds && ntab >= 0 && ntab <= HS_MAX_TAB, "bad argument");
+  for (int t = 0; t < HS_MAX_TAB; ++t) Q->R.kds[t] = t < ntab ? kds[t] : nullptr;
   return NH_OK;
 }
 

@@ -838,6 +838,7 @@ class DeviceLoop:
                 return False
             self._run = h
             self._res["runs"].append(h)
+            self.ctx.sorted_tables(hs, h)
             g, t, l = _lib._i(), _lib._i(), _lib._ll()
             _lib._chk(_lib._lib.nh_half_step_run_info(h, C.byref(g), C.byref(t), C.byref(l)))
             self.resident_info = dict(grid=g.value, threads=t.value, lds_bytes=l.value)
@@ -892,6 +893,7 @@ class DeviceLoop:
         if not agreed(ok):
             return give_up("a record stored by another GPU did not reach a running kernel; %s" % why)
         self._res["runs"].append(h)
+        ctx.sorted_tables(hs, h)
         gr, t, l = _lib._i(), _lib._i(), _lib._ll()
         _lib._chk(lib.nh_half_step_run_info(h, C.byref(gr), C.byref(t), C.byref(l)))
         self.resident_info = dict(grid=gr.value, threads=t.value, lds_bytes=l.value)

@@ -500,6 +500,10 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
             st2 = d.run_mcmc(st, 7, store=False)  # (no history: blobs go to the current array)
         assert d._dev.mega and d._dev._plan["hs"] is not None
         assert (d._dev.resident_launches > 0) == (mode == "1"), getattr(d._dev, "resident_reason", "")
+        if mode == "1" and name in ("cfg3", "cfg1"):
+            # (the resident loop walks its own copies of the inverse-Compton tables, columns sorted
+            # by their first non-zero row, rows below a tile's first one skipped: same spectra)
+            assert d._dev._plan["hs"].get("sorted"), "sorted tables not installed"
         runs[mode] = (d.get_chain(), d.get_log_prob(), d.get_blobs(), d.acceptance_fraction,
                       np.array(st2.coords), np.array(st2.log_prob),
                       [np.array(b) for b in (st2.blobs or [])])
