@@ -133,6 +133,20 @@ def executed_flop_eq(name, raw, coords):
             prev = on
         out["ic_seed_walkers"] = live * SSC_SEG_EQ
         return out
+    E_all = np.asarray(raw["energy"], dtype=float) * {"eV": 1.0, "keV": 1e3, "MeV": 1e6, "GeV": 1e9,
+                                                      "TeV": 1e12}[raw["energy_unit"]]
+    if name in ("cfg1", "cfg3") and os.environ.get("NAIMA_AMD_SORTED_TABLES", "1") != "0" \
+            and os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0":
+        # the resident loop does not walk the rows of an inverse-Compton table below a column
+        # tile's first non-zero one (zero for gamma <= E / mec2, radiative.py:574; columns sorted
+        # by that row, 64 to a tile: Context.sorted_tables)
+        lo_ic, nseed = {"cfg1": (1e9, 1), "cfg3": (1e11, 3)}[name]
+        l0, l1 = np.log10(lo_ic / K.MEC2_EV), np.log10(1e9)
+        gic = np.logspace(l0, l1, max(10, int(100 * (l1 - l0))))
+        first = np.sort(np.repeat(np.searchsorted(gic, E_all / K.MEC2_EV, side="right"), nseed))
+        rows = sum((gic.size - first[q:q + 64].min()) * first[q:q + 64].size
+                   for q in range(0, first.size, 64))
+        out["integrate_tables"] = float(rows) * 30.0
     if "synchrotron" not in out:
         return out
     # (Eemin, Eemax, nEed) of the workload's Synchrotron grid and the index of B [uG]
