@@ -92,7 +92,10 @@ struct hs_run {
   int* nacc_own;   // acceptance counters of the moves THIS rank made (the plan's are replicated)
   int* hacc;       // with a history: [hcap][N] -1 | 0 | 1 = not moved by this rank | rejected | accepted
   int* curstamp;   // with blobs: [N] stamp of the last move this rank accepted for the walker
-  int stamp0, pad2_;  // stamp of the launch's first step (counts the steps of all launches)
+  int stamp0;         // stamp of the launch's first step (counts the steps of all launches)
+  // NH_RUN_PUBLISH_DELAY (100 MHz ticks; experiments): a mover waits this long before it stores a
+  // record -- every hand-off of the shared loop then pays what a slower link would add
+  int publish_delay;
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -848,6 +851,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           if (!multi) {
             hs_st_sc1(R.ring + roff, gv);
           } else {
+            if (R.publish_delay > 0) {
+              const long long t0 = (long long)wall_clock64();
+              while ((long long)wall_clock64() - t0 < R.publish_delay) __builtin_amdgcn_s_sleep(1);
+            }
             // into every rank's ring, this one's included (constant indices: a dynamic one
             // would make the compiler copy the argument block to scratch)
 #pragma unroll
@@ -1177,6 +1184,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (shared) Q->R.spin_limit = 1 << 26;
   if (const char* sl = getenv("NH_RUN_SPIN_LIMIT")) Q->R.spin_limit = atoi(sl) > 0 ? atoi(sl) : Q->R.spin_limit;
   Q->R.nrank = Q->nrank; Q->R.rank = Q->rank;
+  Q->R.publish_delay = shared ? nh_env_int("NH_RUN_PUBLISH_DELAY", 0) : 0;
   Q->R.nacc_own = Q->nacc_own; Q->R.curstamp = Q->curstamp;
   *out = Q;
   return NH_OK;
