@@ -3,6 +3,9 @@ the naima workflow (get_sampler -> run_sampler -> save_run) with the ensemble an
 loop on one MI355X.  The model function is what one would write for naima itself.
 
     python examples/rxj1713_synic.py [nwalkers] [nburn] [nrun]
+    python -m torch.distributed.run --nproc-per-node 8 examples/rxj1713_synic.py 4096
+        (one process per GPU: the ranks share the ensemble; reading the chain, the
+        blobs and the acceptance is then a collective call -- every rank makes it)
 
 Data: the synthetic X-ray + TeV table of BASELINE workload cfg3 (naima_amd/workloads.py)."""
 import os
@@ -45,15 +48,20 @@ if __name__ == "__main__":
 
     data = make_data(W.build_data("cfg3", flux_at_p0))
     labels = ["log10(norm)", "index", "log10(cutoff)", "B", "beta"]
+    from naima_amd import dist
+    comm = dist.from_env()  # LocalComm for one process; RCCL + the control plane for several
     t0 = time.time()
     sampler, pos = naima.run_sampler(data_table=data, p0=p0, labels=labels, model=ElectronSynIC,
                                      prior=lnprior, nwalkers=nwalkers, nburn=nburn, nrun=nrun,
-                                     prefit=True, seed=1, verbose=False)
+                                     prefit=True, seed=1, verbose=False, comm=comm)
     dt = time.time() - t0
-    chain = sampler.get_chain()
-    print("chain", chain.shape, "blobs", [np.shape(b) for b in sampler.get_blobs()])
-    print("%d walkers x (%d + %d) steps in %.2f s; acceptance %.2f" % (
-        nwalkers, nburn, nrun, dt, np.mean(sampler.acceptance_fraction)))
+    chain, blobs = sampler.get_chain(), sampler.get_blobs()  # (every rank: collective reads)
+    acc = np.mean(sampler.acceptance_fraction)
+    if comm.rank != 0:
+        sys.exit(0)
+    print("chain", chain.shape, "blobs", [np.shape(b) for b in blobs])
+    print("%d walkers x (%d + %d) steps in %.2f s on %d GPU(s); acceptance %.2f" % (
+        nwalkers, nburn, nrun, dt, comm.size, acc))
     flat = chain[nrun // 2:].reshape(-1, chain.shape[-1])
     for lab, med, lo, hi, t in zip(labels, np.median(flat, 0), *np.percentile(flat, [16, 84], 0), p0):
         print("  %-14s %8.3f  (+%.3f -%.3f)   generated with %.3f" % (lab, med, hi - med, med - lo, t))

@@ -212,6 +212,8 @@ class DeviceLoop:
         self.shared_info = None
         self._cur_dirty = False   # current blobs differ between ranks (merge by stamp pending)
         self._cur_host = None     # host copies of the current blobs while nothing has changed them
+        self._acc_dirty = False   # shared launches have accepted moves since the counts were summed
+        self._acc_shared = 0.0
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
@@ -227,6 +229,7 @@ class DeviceLoop:
         self.ctx.call("nh_memset", self.nacc, 0, self.nacc.nbytes)
         if self.shared:
             _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, None, None, 1))
+            self._acc_dirty, self._acc_shared = False, 0.0
 
     def _eval(self, qT_buf, n):
         """run the user's model on device parameters: (total DVec, blob list)"""
@@ -988,6 +991,7 @@ class DeviceLoop:
     def _run_resident(self, slice0, nslices, block):
         ctx, hs = self.ctx, self._plan["hs"]
         if self.shared:
+            self._acc_dirty = True
             own = block.get("own") if block is not None else None
             _lib._chk(_lib._lib.nh_half_step_run_hist_flags(self._run, own.ptr if own is not None
                                                             else None))
@@ -1202,8 +1206,12 @@ class DeviceLoop:
         self.hist = []
         s.naccepted = self.nacc.get().astype(float)
         if self.shared:  # + the moves each rank's shared launches accepted
-            own = np.empty(self.N, dtype=np.int32)
-            _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, own.ctypes.data,
-                                                          None, 0))
-            for p_ in s.comm.group.allgather_bytes(own.tobytes()):
-                s.naccepted += np.frombuffer(p_, dtype=np.int32)
+            if self._acc_dirty:  # (collective only when launches have run since the last look)
+                self._acc_dirty = False
+                own = np.empty(self.N, dtype=np.int32)
+                _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run,
+                                                              own.ctypes.data, None, 0))
+                self._acc_shared = np.zeros(self.N)
+                for p_ in s.comm.group.allgather_bytes(own.tobytes()):
+                    self._acc_shared += np.frombuffer(p_, dtype=np.int32)
+            s.naccepted += self._acc_shared
