@@ -18,7 +18,13 @@ per-GPU walker count bench.py uses, with blobs kept and not kept:
     weight underflows, and with a log-probability of -inf -- the walkers for which the kernel
     takes its exact short-cuts (a proposal the prior forbids is not integrated; a grid of zero
     weights contributes exact zeros).  The tests count such proposals on the host and fail
-    if none occurred.
+    if none occurred;
+  * the resident loop (one launch per block of moves, walkers handed over by tagged records;
+    its own copies of the emission tables with sorted columns and skipped zero rows) == the
+    per-launch kernel, bit for bit, up to ensembles of more walkers than CUs;
+  * the resident loop over an ensemble SHARED by two, three and four ranks (one process each,
+    all on the one GPU of the box, rings mapped through hipIpc) == one process: ensemble, chain,
+    log-probabilities, blob history, merged current blobs, acceptance.
 """
 import numpy as np
 import pytest
