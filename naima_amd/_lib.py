@@ -172,6 +172,21 @@ def _profiler_workaround():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def sorted_columns(K):
+    """column order and first rows for Context.sorted_tables: K [nG][nK] (host) -> (perm, row0)
+    with perm = the columns ordered by the first row in which they are non-zero (stable: equal
+    columns keep their order; a column of zeros counts as nG) and row0[t] = the smallest such
+    row among the 64 columns perm[64 t : 64 t + 64] -- the segments [0, row0[t]) of that tile
+    have a zero node at both ends or at one (trapz_loglog: exactly 0, utils.py:347-348)"""
+    K = np.asarray(K)
+    nG, nK = K.shape
+    live = K != 0.0
+    first = np.where(live.any(axis=0), live.argmax(axis=0), nG)
+    perm = np.argsort(first, kind="stable")
+    row0 = [int(first[perm][q:q + 64].min()) for q in range(0, nK, 64)]
+    return perm, row0
+
+
 def load():
     """dlopen libnaima_hip.so; raises (loudly) when it has not been built."""
     global _lib
@@ -699,10 +714,7 @@ class Context:
             self.join()
             _chk(_lib.nh_download(self.h, Kh.ctypes.data, Kt, Kh.nbytes))
             _chk(_lib.nh_download(self.h, dKh.ctypes.data, dKt, dKh.nbytes))
-            live = Kh != 0.0
-            first = np.where(live.any(axis=0), live.argmax(axis=0), nG)
-            perm = np.argsort(first, kind="stable")
-            row0 = [int(first[perm][q * 64:(q + 1) * 64].min()) for q in range(tiles)]
+            perm, row0 = sorted_columns(Kh)
             if max(row0) < 32:  # (less than one work item's worth of rows to skip anywhere)
                 continue
             Kp = self.array(np.ascontiguousarray(Kh[:, perm]))

@@ -370,3 +370,32 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
         assert len(mine) == ninst, sizes
         for k, v in mine.items():
             assert v <= limit, "%s uses %d bytes of scratch per lane" % (k, v)
+
+
+def test_sorted_columns_of_an_emission_table():
+    """_lib.sorted_columns (what the resident loop's table copies are built from): columns in the
+    order of their first non-zero row, first row per tile of 64; with the oracle's trapz_loglog
+    the skipped segments are seen to contribute exact zeros, whatever the weights"""
+    from naima_amd._lib import sorted_columns
+    from oracle import naima_np as O
+    rng = np.random.default_rng(3)
+    nG, nK = 90, 150
+    x = np.geomspace(1.0, 1e4, nG)
+    thr = rng.integers(0, 80, size=nK)          # first live row of every column
+    thr[:5] = 0
+    thr[7] = nG                                 # a column of zeros
+    K = rng.uniform(0.5, 2.0, size=(nG, nK)) * (np.arange(nG)[:, None] >= thr[None, :])
+    perm, row0 = sorted_columns(K)
+    first = np.where((K != 0).any(axis=0), (K != 0).argmax(axis=0), nG)
+    assert sorted(perm.tolist()) == list(range(nK))
+    assert np.all(np.diff(first[perm]) >= 0)
+    assert len(row0) == 3 and row0[0] == 0 and row0 == [int(first[perm][q:q + 64].min()) for q in (0, 64, 128)]
+    assert perm[-1] == 7 and row0[2] > 0
+    w = rng.uniform(0.1, 3.0, size=nG) * x ** -1.3
+    for t, r0 in enumerate(row0):
+        for p in range(64 * t, min(nK, 64 * t + 64), 17):
+            y = w * K[:, perm[p]]
+            full = O.trapz_loglog(y, x)
+            assert O.trapz_loglog(y[r0:], x[r0:]) == full or np.isclose(O.trapz_loglog(y[r0:], x[r0:]), full, rtol=1e-15)
+            if r0 > 1:
+                assert O.trapz_loglog(y[:r0 + 1], x[:r0 + 1]) == 0.0
