@@ -592,8 +592,10 @@ int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
  * table t with permuted columns (nh_table_interleave of the permuted Kt / dlnKt), followed by a
  * trailer of ints { row0[8] | perm[nK] }: row0[tile] = first row in which any of the tile's 64
  * columns is non-zero (segments below it are not walked), perm[p] = the column of the spectrum
- * that position p holds.  NULL keeps the plan's table.  The caller keeps the buffers alive. */
-int nh_half_step_run_tables(nh_halfstep_run* run, const double* const* kds /*host*/, int ntab);
+ * that position p holds.  NULL keeps the plan's table.  The caller keeps the buffers alive.  The
+ * trailers are read back and checked (rows in range, the column order a permutation). */
+int nh_half_step_run_tables(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run* run,
+                            const double* const* kds /*host*/, int ntab);
 /* ---- the resident loop over an ensemble SHARED by the GPUs of a node (2 .. 8 ranks, one process
  * per GPU).  Replaces, for walkers sharded as in the per-launch loop (rank r proposes positions
  * [lo, lo + nloc) of every half-step; the reference's analogue is Pool(threads) over a fixed

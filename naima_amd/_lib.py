@@ -117,7 +117,7 @@ _SIGS = {
     "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],
     "nh_half_step_run_status": [_dp, _dp, C.POINTER(_i)],
-    "nh_half_step_run_tables": [_dp, _dp, _i],
+    "nh_half_step_run_tables": [_dp, _dp, _dp, _dp, _i],
     "nh_half_step_run_create_shared": [_dp, _dp, _i, _i, C.POINTER(_dp)],
     "nh_half_step_run_export": [_dp, _dp, _dp],
     "nh_half_step_run_attach": [_dp, _dp, _i, _dp],
@@ -731,7 +731,7 @@ class Context:
             ptrs[t] = kd.ptr
             keep.append(kd)
         if keep:
-            _chk(_lib.nh_half_step_run_tables(run, ptrs, 4))
+            _chk(_lib.nh_half_step_run_tables(self.h, hs["plan"], run, ptrs, 4))
             hs.setdefault("sorted", []).append(keep)  # (alive as long as the plan)
 
     # -- side streams ---------------------------------------------------------

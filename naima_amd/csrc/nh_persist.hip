@@ -43,6 +43,7 @@
 // proposals forward from the previous step and adds the accept flags to the acceptance
 // counters.
 #include "nh_hs.h"
+#include <vector>
 
 #define HS_RUN_MAX_STEPS 32  // steps per launch (one block of moves); ring rows = this + 1
 #define HS_RUN_ERR_TIMEOUT 1
@@ -1323,9 +1324,31 @@ extern "C" int nh_half_step_run_probe(nh_ctx* c, nh_halfstep_run* Q, int rounds,
 // The loop's own copies of the plan's tables with SORTED columns (nh_hs.h): kds[t] = device
 // pointer to [nG][nK][2] doubles + the trailer of ints { row0[8] | perm[nK] }, or NULL to keep
 // the plan's table t.  The caller owns the buffers and keeps them alive with the loop.
-extern "C" int nh_half_step_run_tables(nh_halfstep_run* Q, const double* const* kds, int ntab) {
-  NH_REQUIRE(Q && kds && ntab >= 0 && ntab <= HS_MAX_TAB, "bad argument");
-  for (int t = 0; t < HS_MAX_TAB; ++t) Q->R.kds[t] = t < ntab ? kds[t] : nullptr;
+extern "C" int nh_half_step_run_tables(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run* Q,
+                                       const double* const* kds, int ntab) {
+  NH_REQUIRE(c && P && Q && kds && ntab >= 0 && ntab <= HS_MAX_TAB, "bad argument");
+  const hs_hot& H = P->hot;
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  // the trailers decide where the kernel writes in LDS: checked here, once
+  for (int t = 0; t < ntab && t < H.ntab; ++t) {
+    if (!kds[t]) continue;
+    const hs_tab& tb = H.C.tab[t];
+    const int nG = H.nG[tb.grid], nK = tb.nK;
+    NH_REQUIRE(tb.tiles <= HS_TRAIL_TILES, "a sorted table has at most 8 column tiles");
+    std::vector<int> tr((size_t)HS_TRAIL_TILES + nK);
+    NH_CHECK_HIP(hipMemcpy(tr.data(), kds[t] + 2 * (size_t)nG * nK, tr.size() * sizeof(int),
+                           hipMemcpyDeviceToHost));
+    std::vector<char> seen((size_t)nK, 0);
+    for (int q = 0; q < HS_TRAIL_TILES; ++q)
+      NH_REQUIRE(tr[q] >= 0 && tr[q] <= nG, "sorted table: a tile's first row is out of range");
+    for (int k = 0; k < nK; ++k) {
+      const int p = tr[HS_TRAIL_TILES + k];
+      NH_REQUIRE(p >= 0 && p < nK && !seen[p], "sorted table: the column order is not a permutation");
+      seen[p] = 1;
+    }
+  }
+  for (int t = 0; t < HS_MAX_TAB; ++t) Q->R.kds[t] = (t < ntab && t < H.ntab) ? kds[t] : nullptr;
   return NH_OK;
 }
 

@@ -675,3 +675,40 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
             have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
             assert have.shape == w.shape, (key, r)
             assert_allclose(have, w, rtol=1e-10, atol=1e-300, err_msg="%s of rank %d" % (key, r))
+
+
+def test_sorted_table_trailers_are_checked_at_the_abi(na):
+    """nh_half_step_run_tables reads the trailers of the table copies back and refuses a first
+    row out of range or a column order that is not a permutation (they decide where the kernel
+    writes in LDS); the loop keeps the tables it had"""
+    import ctypes as C
+    from naima_amd import _lib
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg1", {})
+    nd = p0.size
+    d = EnsembleSampler(32, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
+                        store_blobs=True, device=True)
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((32, nd)))
+    st = d.run_mcmc(pos, 8)
+    st = d.run_mcmc(st, 8)
+    dev = d._dev
+    hs = dev._plan["hs"]
+    assert dev.resident_launches > 0 and hs.get("sorted")
+    ctx = dev.ctx
+    (Kt, dKt, nG, nK, lx, nonneg), good = hs["tabs"][0], hs["sorted"][0][0]
+    host = good.get()
+    trail = host[2 * nG * nK:].view(np.int32).copy()
+    for what, (idx, val) in {"permutation": (8 + 3, nK), "first row": (0, nG + 1)}.items():
+        bad_t = trail.copy()
+        bad_t[idx] = val
+        bad = host.copy()
+        bad[2 * nG * nK:] = bad_t.view(np.float64)
+        buf = ctx.array(bad)
+        ptrs = (C.c_void_p * 4)(buf.ptr, None, None, None)
+        rc = _lib._lib.nh_half_step_run_tables(ctx.h, hs["plan"], dev._run, ptrs, 4)
+        assert rc != 0 and what in _lib._lib.nh_last_error().decode(), what
+    ref = EnsembleSampler(32, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
+                          store_blobs=True, device=True)
+    st2 = ref.run_mcmc(ref.run_mcmc(pos, 8), 8)
+    st, st2 = d.run_mcmc(st, 40), ref.run_mcmc(st2, 40)
+    assert np.array_equal(st.coords, st2.coords)
