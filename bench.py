@@ -58,7 +58,8 @@ KERNEL_FLOP_EQ = {
     "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * SSC_SEG_EQ},
 }
 # profiler category -> kernel symbol in the rocprofv3 kernel trace
-KERNEL_SYMBOL = {"half_step": "k_half_step",  # (k_half_step_run when the loop is resident) "integrate_tables": "k_integrate_tables",
+# ("half_step" is k_half_step_run when the loop is resident)
+KERNEL_SYMBOL = {"half_step": "k_half_step", "integrate_tables": "k_integrate_tables",
                  "synchrotron": "k_synchrotron",
                  "particle_weights": "k_step_front (proposal+packs+weights+We)", "lnprob": "k_lnprobmodel",
                  "integrate_rows": "k_integrate_rows", "ic_seed_walkers": "k_ic_seed_walkers",

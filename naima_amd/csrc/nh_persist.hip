@@ -52,6 +52,9 @@
 #define HS_RUN_MAX_RANKS 8     // GPUs of one node that may share an ensemble
 #define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
 #define HS_RUN_TRAIL 16        // ints of first-row entries per table in LDS (>= tiles of any table)
+#ifndef HS_RUN_PK
+#define HS_RUN_PK 5      // nodes per trip of a narrow table's items in the table-only instances (nh_hs.h): 6 spilled 8 VGPRs (cfg5 9.12 M walker-steps/s, 9.77 M at 5; cfg1 1.49 -> 1.46 M)
+#endif
 
 struct hs_run {
   unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
@@ -406,21 +409,15 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         const double qv = __shfl(q, pkd < 0 ? 0 : pkd, 64);
         if (lane < npk8) {
           const double* o = sm + R.o_pk + lane * 6;
-          nh_lazy z;
-          z.base = nullptr;
-          z.stride = 1;
-          z.a = o[0];
-          z.b = o[1];
-          z.c = o[2];
-          z.tf = reinterpret_cast<const int*>(o + 3)[0];
-          z.pad = 0;
+          const double za = o[0], zb = o[1], zc = o[2];
+          const int ztf = reinterpret_cast<const int*>(o + 3)[0];
           const int nc = reinterpret_cast<const int*>(o + 3)[1];
           const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
           double* out = reinterpret_cast<double* const*>(o + 5)[0];
           const int col = lane % NH_MAX_LAZY;
           if (col < nc) {
-            double val = z.a;
-            if (pkd >= 0) val = hsr_lazy_apply(z.a, z.b, z.c, z.tf, qv);
+            double val = za;
+            if (pkd >= 0) val = hsr_lazy_apply(za, zb, zc, ztf, qv);
             out[(long long)j * ld + col] = val;
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
@@ -448,14 +445,16 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         double term = 0.0;
         if (lane < npri) {
           const nh_prior& pt = PR.t[lane];
-          const nh_lazy z = pt.x;
-          double v = z.a;
-          if (z.base) {
-            const long long d = z.base - H.qT;
+          // (field by field: a 48-byte copy of the term is a stack object)
+          const double* zbase = pt.x.base;
+          const long long zstride = pt.x.stride;
+          double v = pt.x.a;
+          if (zbase) {
+            const long long d = zbase - H.qT;
             // a term on one of this walker's proposed coordinates: taken from LDS
-            const bool mine = d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && z.stride == 1;
-            const double raw = mine ? qs[d / H.nloc] : z.base[(long long)j * z.stride];
-            v = hsr_lazy_apply(z.a, z.b, z.c, z.tf, raw);
+            const bool mine = d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && zstride == 1;
+            const double raw = mine ? qs[d / H.nloc] : zbase[(long long)j * zstride];
+            v = hsr_lazy_apply(pt.x.a, pt.x.b, pt.x.c, pt.x.tf, raw);
           }
           const double p0 = pt.p0, p1 = pt.p1;
           switch (pt.kind) {
@@ -523,10 +522,14 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int uu = u + q * nwork;
-          int g = 0;
-          while (uu < nunits && uu >= ub[g + 1]) ++g;
+          // (constant indices only: a dynamically indexed ub[] is an array in scratch, and the
+          // search a chain of dependent scratch loads at the head of every slice's weights)
+          int g = 0, u0 = 0;
+#pragma unroll
+          for (int gg = 1; gg < NH_MAX_GRIDS; ++gg)
+            if (uu < nunits && uu >= ub[gg]) { g = gg; u0 = ub[gg]; }
           gq[q] = g;
-          const int nG = H.nG[g], i = (uu - ub[g]) * 64 + lane;
+          const int nG = H.nG[g], i = (uu - u0) * 64 + lane;
           iq[q] = i;
           onq[q] = uu < nunits && i < nG;
           if (onq[q]) {
@@ -702,8 +705,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             if (!(nz >> tg & 1) || s0 >= s1)
               acc = 0.0;
             else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
-              acc = pre ? hs_table_item_packed<false, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane, kds)
-                        : hs_table_item_packed<true, SYN ? 4 : 6>(tb, nG, s0, s1, ws, ds, lxs, lane, kds);
+              acc = pre ? hs_table_item_packed<false, SYN ? 4 : HS_RUN_PK>(tb, nG, s0, s1, ws, ds, lxs, lane, kds)
+                        : hs_table_item_packed<true, SYN ? 4 : HS_RUN_PK>(tb, nG, s0, s1, ws, ds, lxs, lane, kds);
             else
               acc = pre ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds)
                         : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds);
@@ -882,12 +885,18 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           for (int b = 0; b < D.nblob; ++b) {
             const nh_hs_blob& bl = D.blob[b];
             double* hb = hist ? R.hblob[b] : nullptr;
+            // (a scalar blob -- We, Wp -- is a lazy transform of a moment: ONE out-of-line call;
+            // inlined at both of its uses the library's exp10 / log were 400 instructions of this
+            // tail and the only scratch loads of the kernel)
+            double sval = 0.0;
+            if (bl.kind != 0 && lane == 0)
+              sval = hsr_lazy_apply(bl.lazy.a, bl.lazy.b, bl.lazy.c, bl.lazy.tf, sm[D.o_mrow + H.nE + bl.mom]);
             if (hb) {  // (its row of the history; k_run_epilogue fills the rejected ones)
               double* dst = hb + (hrow * N + me2) * bl.m;
               if (bl.kind == 0) {
                 for (int t = lane; t < bl.m; t += 64) dst[t] = sm[D.o_mrow + t];
               } else if (lane == 0) {
-                dst[0] = nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom]);
+                dst[0] = sval;
               }
             }
             if (!hb || multi) {
@@ -901,8 +910,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
                 for (int t = lane; t < bl.m; t += 64)
                   hs_st_sc1(dst + t, (unsigned long long)__double_as_longlong(sm[D.o_mrow + t]));
               } else if (lane == 0) {
-                hs_st_sc1(dst, (unsigned long long)__double_as_longlong(
-                                   nh_lazy_apply(bl.lazy, sm[D.o_mrow + H.nE + bl.mom])));
+                hs_st_sc1(dst, (unsigned long long)__double_as_longlong(sval));
               }
             }
           }

@@ -351,25 +351,36 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
     """k_half_step takes its 3 KB descriptor by value; small edits (one more dynamic field read,
     an atomic in the wrong block) have twice made the compiler copy all of it to scratch memory
     -- 6x slower launches, and nothing but ScratchSize in the resource report shows it.  The
-    resident kernel's only scratch is the frames of its out-of-line math calls."""
+    resident kernel (every bench number comes from it) spills no vector register in any of its
+    four instances and its bodies hold no scratch instruction at all: the 48 bytes its resource
+    report shows are the frame the compiler reserves around its out-of-line math calls."""
     import re
     import subprocess
     src = os.path.join(ROOT, "naima_amd", "csrc")
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+            "-mllvm", "-amdgpu-kernarg-preload-count=16"]
     # (file: kernel, instances, bytes of scratch per lane allowed; the resident kernel has a second
     # pair of instances for an ensemble shared by several GPUs)
-    want = {"nh_halfstep.hip": ("k_half_step", 2, 0), "nh_persist.hip": ("k_half_step_run", 4, 256)}
+    want = {"nh_halfstep.hip": ("k_half_step", 2, 0), "nh_persist.hip": ("k_half_step_run", 4, 48)}
     for f, (sym, ninst, limit) in want.items():
-        out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
-                              "-mllvm", "-amdgpu-kernarg-preload-count=16",
-                              "-Rpass-analysis=kernel-resource-usage", os.path.join(src, f),
-                              "-o", os.devnull], capture_output=True, text=True).stderr
+        out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", os.path.join(src, f),
+                                     "-o", os.devnull], capture_output=True, text=True).stderr
         blocks = re.split(r"remark: Function Name: ", out)[1:]
-        sizes = {b.split()[0]: int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        sizes = {b.split()[0]: (int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)),
+                                int(re.search(r"VGPRs Spill: (\d+)", b).group(1)))
                  for b in blocks}
         mine = {k: v for k, v in sizes.items() if sym + "IL" in k}
         assert len(mine) == ninst, sizes
-        for k, v in mine.items():
-            assert v <= limit, "%s uses %d bytes of scratch per lane" % (k, v)
+        for k, (scratch, vspill) in mine.items():
+            assert scratch <= limit, "%s uses %d bytes of scratch per lane" % (k, scratch)
+            assert vspill == 0, "%s spills %d vector registers" % (k, vspill)
+    asm = subprocess.run(base + ["--cuda-device-only", "-S", os.path.join(src, "nh_persist.hip"), "-o", "-"],
+                         capture_output=True, text=True).stdout
+    bodies = re.findall(r"^(_Z15k_half_step_runILb[01]ELb[01]EEv6hs_hot6hs_run):[^\n]*\n(.*?)^\.Lfunc_end", asm,
+                        flags=re.S | re.M)
+    assert len(bodies) == 4
+    for name, body in bodies:
+        assert "scratch_" not in body, "%s touches scratch memory" % name
 
 
 def test_sorted_columns_of_an_emission_table():
