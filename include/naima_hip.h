@@ -630,6 +630,12 @@ int nh_half_step_run_counters(nh_ctx* ctx, nh_halfstep_run* run, int* nacc_own, 
                               int reset);
 int nh_half_step_run_info(const nh_halfstep_run* run, int* grid, int* threads,
                           long long* lds_bytes);
+/* How the loop evaluates Synchrotron._spectrum's integrand (radiative.py:300-340): mode 1 = in
+ * the log domain on the grid's comb (csrc/nh_syn2.h: one exponent per node, ln Gtilde from a
+ * table of `pieces` degree-5 pieces of `nodes_per_piece` grid steps; taken when the particle
+ * grid is log-uniform, as radiative.py:147-154 makes it), 0 = the direct form (any grid; no
+ * synchrotron component). */
+int nh_half_step_run_syn_info(const nh_halfstep_run* run, int* mode, int* nodes_per_piece, int* pieces);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
  * (workgroup, slice handled): start | records in | packs done | weights done | own items
  * done | all items done | spectra summed | record published; then [64][4][16]: for workgroup

@@ -78,22 +78,24 @@ __device__ __forceinline__ double pd_exp_tab(double x, const double* __restrict_
 // T64 != nullptr: exponentials through pd_exp_tab
 __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, double lxc,
                                         double lkb, bool b1, bool b2, double lr, double& n,
-                                        double& dsh, const double* __restrict__ T64 = nullptr) {
+                                        double& dsh, const double* __restrict__ T64 = nullptr,
+                                        double* __restrict__ lnn = nullptr) {
   auto pd_exp = [T64](double v) { return T64 ? pd_exp_tab(v, T64) : ::pd_exp(v); };
+  double ex;  // ln(n / A): what the log-domain consumers (nh_syn2.h) take instead of n
   switch (kind) {
     case NH_PD_POWERLAW:
-      n = p.A * pd_exp(-p.al * lxx);
+      ex = -p.al * lxx;
       dsh = -p.al * lr;
       break;
     case NH_PD_ECPL: {
       const double t = pd_exp(p.be * lxc);
-      n = p.A * pd_exp(-p.al * lxx - t);
+      ex = -p.al * lxx - t;
       dsh = -p.al * lr - t * pd_expm1_small(p.be * lr);
     } break;
     case NH_PD_BROKENPL:
     case NH_PD_ECBPL: {
       const double lK = (p.a2 - p.al) * lkb;
-      double ex = (b1 ? 0.0 : lK) - (b1 ? p.al : p.a2) * lxx;
+      ex = (b1 ? 0.0 : lK) - (b1 ? p.al : p.a2) * lxx;
       if (b1 == b2) {
         dsh = -(b1 ? p.al : p.a2) * lr;
       } else {  // the one segment that straddles the break
@@ -105,13 +107,14 @@ __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, d
         ex -= t;
         dsh -= t * pd_expm1_small(p.be * lr);
       }
-      n = p.A * pd_exp(ex);
     } break;
     default: {  // NH_PD_LOGPARABOLA
-      n = p.A * pd_exp((-p.al - p.be * lxx) * lxx);
+      ex = (-p.al - p.be * lxx) * lxx;
       dsh = -p.al * lr - p.be * lr * (lxx + (lxx + lr));
     } break;
   }
+  n = p.A * pd_exp(ex);
+  if (lnn) *lnn = ex;
   // a cutoff energy so far below the grid that (E/e_c)^beta overflows makes the log-ratio
   // -inf (the node itself is an exact 0): kept finite, because the reductions form 1/dl
   // before they look at the nodes (0 x 1/inf must stay 0, not become NaN)

@@ -43,6 +43,7 @@
 // proposals forward from the previous step and adds the accept flags to the acceptance
 // counters.
 #include "nh_hs.h"
+#include "nh_syn2.h"
 #include <vector>
 
 #define HS_RUN_MAX_STEPS 32  // steps per launch (one block of moves); ring rows = this + 1
@@ -51,6 +52,7 @@
 #define HS_RUN_ERR_LAST_ROW 3  // (epilogue of a shared ensemble: a rank's last records never came)
 #define HS_RUN_MAX_RANKS 8     // GPUs of one node that may share an ensemble
 #define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
+#define HS_O_LNA 48          // in the small per-walker block (proposal coordinates: <= 15 of its first 64 doubles)
 #define HS_RUN_TRAIL 16        // ints of first-row entries per table in LDS (>= tiles of any table)
 #ifndef HS_RUN_PK
 #define HS_RUN_PK 5      // nodes per trip of a narrow table's items in the table-only instances (nh_hs.h): 6 spilled 8 VGPRs (cfg5 9.12 M walker-steps/s, 9.77 M at 5; cfg1 1.49 -> 1.46 M)
@@ -100,6 +102,14 @@ struct hs_run {
   // NH_RUN_PUBLISH_DELAY (100 MHz ticks; experiments): a mover waits this long before it stores a
   // record -- every hand-off of the shared loop then pays what a slower link would add
   int publish_delay;
+  // ---- the synchrotron items in the log domain, on the grid's comb (nh_syn2.h; syn2 != 0) ----
+  int syn2, s2_own;  // s2_own: nobody else reads the synchrotron grid's w / dlw (its LDS is reused)
+  int o_s2tab, o_s2lw, o_s2ig, o_s2lg, o_s2q, o_s2z, o_s2t;  // LDS: table | Lambda ln w (guards either side) |
+                                                      // cbrt(1/gamma^2) (guards) | Lambda (ln gamma / 3 +
+                                                      // ln scale) | per live energy 4 doubles | comb index | 2^(j/128)
+  const double* s2_dev;  // device: the table's (P + 1) x 6 doubles, then the grid's nG values of the above
+  hs_syn2_par s2;
+  double s2_z0, s2_invd;  // z = s2_z0 - ln(q) s2_invd: where node 0 sits on the comb below T_top
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -139,8 +149,8 @@ __device__ __attribute__((noinline)) double hsr_lazy_apply(double a, double b, d
 }
 __device__ __attribute__((noinline)) double hsr_log(double x) { return log(x); }
 __device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x); }
-struct hsr_node { double n, dsh; };
-struct hsr_node2 { double n0, dsh0, n1, dsh1; };
+struct hsr_node { double n, dsh, ex; };  // ex = ln(n / A)
+struct hsr_node2 { double n0, dsh0, n1, dsh1, ex0, ex1; };
 __device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, double al, double be,
                                                           double a2, double lxx, double lxc,
                                                           double lkb, int b12, double lr,
@@ -148,7 +158,7 @@ __device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, do
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node r;
-  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64);
+  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64, &r.ex);
   return r;
 }
 
@@ -162,8 +172,8 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node2 r;
-  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64);
-  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64);
+  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64, &r.ex0);
+  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64, &r.ex1);
   return r;
 }
 
@@ -179,7 +189,9 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
       R.dbg[((long long)blockIdx.x * 64 + it) * 8 + (k)] = (long long)wall_clock64();   \
   } while (0)
 
-template <bool SYN, bool MULTI>
+// S2: the synchrotron items in the log domain (nh_syn2.h) -- an instance of its own, so that
+// neither form carries the other's registers and code
+template <bool SYN, bool MULTI, bool S2>
 __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs_run R) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
     for (int i = tid; i < nG; i += T) {
       sm[H.o_lx[g] + i] = i + 1 < nG ? H.lx[g][i] : 0.0;
       if (R.o_gx[0] >= 0) {  // (small workgroups leave the nodes in L2: LDS decides how many fit a CU)
-        sm[R.o_gx[g] + i] = H.xg[g][i];
+        if (!(SYN && S2 && R.s2_own && g == H.syn_grid)) sm[R.o_gx[g] + i] = H.xg[g][i];
         sm[R.o_lne[g] + i] = H.lne[g][i];
         if (broken) sm[R.o_ge[g] + i] = H.e[g][i];
       }
@@ -218,8 +230,22 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       const int nGs = H.F.syn_nG;
       for (int i = tid; i < nGs; i += T) {
         sm[H.o_ig2 + i] = H.F.syn_c[i];
-        sm[H.o_ig23 + i] = H.F.syn_c[nGs + i];
-        sm[H.o_dig2 + i] = H.F.syn_c[2 * nGs + i];
+        if (!(S2 && R.s2_own)) {  // (the log-domain items keep their own arrays there)
+          sm[H.o_ig23 + i] = H.F.syn_c[nGs + i];
+          sm[H.o_dig2 + i] = H.F.syn_c[2 * nGs + i];
+        }
+      }
+    }
+    if (SYN && S2) {
+      const int nGs = H.F.syn_nG, ntb = (R.s2.P + 1) * HS_S2_STRIDE;
+      for (int i = tid; i < ntb; i += T) sm[R.o_s2tab + i] = R.s2_dev[i];
+      if (tid < 128) sm[R.o_s2t + tid] = exp2((double)tid * 0.0078125);
+      for (int i = tid; i < nGs; i += T) sm[R.o_s2lg + i] = R.s2_dev[ntb + i];
+      for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
+        const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
+        sm[R.o_s2ig + i] = H.F.syn_c[nGs + ii];
+        // ln w of the guard nodes: zeros of their own (the walker's nodes are written every slice)
+        if (i < HS_S2_GUARD || i >= nGs + HS_S2_GUARD) sm[R.o_s2lw + i] = HS_S2_FLOOR;
       }
     }
     for (int t = 0; t < H.ntab; ++t)
@@ -421,7 +447,17 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             out[(long long)j * ld + col] = val;
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
-              if (col == 1 || col == 3 || col == 5) lg[col >> 1] = val > 0.0 ? hsr_log(val) : 0.0;
+              // (ln of e_0, e_cutoff, e_break for the weights; ln |amplitude| and its sign for the
+              // log-domain synchrotron items: one call, the lanes side by side)
+              if (col == 0 || col == 1 || col == 3 || col == 5) {
+                const double lv = hsr_log(fabs(val));
+                if (col == 0) {
+                  qs[HS_O_LNA] = lv;
+                  qs[HS_O_LNA + 1] = val < 0.0 ? -1.0 : 1.0;
+                } else {
+                  lg[col >> 1] = val > 0.0 ? lv : 0.0;
+                }
+              }
             }
           }
         }
@@ -470,7 +506,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         if (lane == 0) {
           accs[3] = prior;
           hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
-          lg[3] = (ndim - 1.0) * hsr_log(accs[0]);  // (the accept's z term: off the slice's tail)
+          // (the accept's z term: off the slice's tail.  ndim - 1 through the slice's opaque thread
+          // index: as a loop invariant the converted double was hoisted out of the slice loop and
+          // spilled -- the kernel's only scratch access)
+          lg[3] = (double)(ndim - 1 + (tid - tid0)) * hsr_log(accs[0]);
         }
       }
       // ---- particle weights on every grid (-> LDS); the synchrotron liveness search ----------
@@ -546,18 +585,20 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           }
         }
         const bool two = u + nwork < nunits;  // (wave-uniform)
-        double nnq[2], dshq[2];
+        double nnq[2], dshq[2], exq[2];
         if (two) {
           const hsr_node2 nd = hsr_pd_core2(D.kind, p.A, p.al, p.be, p.a2, lg[2] - lg[0],
                                             lneq[0] - lg[0], lneq[0] - lg[1], bq[0], lrq[0],
                                             lneq[1] - lg[0], lneq[1] - lg[1], bq[1], lrq[1],
                                             sm + HS_O_T64);
           nnq[0] = nd.n0; dshq[0] = nd.dsh0; nnq[1] = nd.n1; dshq[1] = nd.dsh1;
+          exq[0] = nd.ex0; exq[1] = nd.ex1;
         } else {
           const hsr_node nd = hsr_pd_core(D.kind, p.A, p.al, p.be, p.a2, lneq[0] - lg[0],
                                           lneq[0] - lg[1], lg[2] - lg[0], bq[0], lrq[0],
                                           sm + HS_O_T64);
           nnq[0] = nd.n; dshq[0] = nd.dsh; nnq[1] = 0.0; dshq[1] = 0.0;
+          exq[0] = nd.ex; exq[1] = 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -565,13 +606,27 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             const int g = gq[q], i = iq[q];
             const bool last = i + 1 >= H.nG[g];
             const double nn = nnq[q] * H.scale[g];
-            const double wv_ = gxq[q] * nn, dv = last ? 0.0 : lrq[q] + dshq[q];
-            sm[H.o_w[g] + i] = wv_;
-            sm[H.o_d[g] + i] = dv;
-            if (H.o_dp[g] >= 0) {  // what the non-negative table items read
-              const double il = last ? 0.0 : nh_rcp(lrq[q]);
-              sm[H.o_dp[g] + i] = dv * il;
-              sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+            double wv_ = gxq[q] * nn;
+            const double dv = last ? 0.0 : lrq[q] + dshq[q];
+            bool plain = true;  // (wave-uniform: a unit is 64 nodes of one grid)
+            if (SYN && S2 && g == H.syn_grid) {
+              // the log-domain items' Lambda ln|w| + Lambda ln cbrt(1/gamma^2) (nh_syn2.h); a zero
+              // weight (or amplitude) is the floor: an exact 0, and exact zeros for its segments
+              const double lw = fma(HS_S2_LAMBDA, qs[HS_O_LNA] + exq[q], sm[R.o_s2lg + i]);
+              sm[R.o_s2lw + HS_S2_GUARD + i] = lw > -1.0e290 ? lw : HS_S2_FLOOR;
+              if (R.s2_own) {  // (nobody reads this grid's w / dlw, and gx holds another array)
+                plain = false;
+                wv_ = nn;
+              }
+            }
+            if (plain) {
+              sm[H.o_w[g] + i] = wv_;
+              sm[H.o_d[g] + i] = dv;
+              if (H.o_dp[g] >= 0) {  // what the non-negative table items read
+                const double il = last ? 0.0 : nh_rcp(lrq[q]);
+                sm[H.o_dp[g] + i] = dv * il;
+                sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+              }
             }
             if (wv_ != 0.0) nzmask |= 1 << g;
             // (a weight that is not finite -- a far-off walker whose distribution overflows --
@@ -594,14 +649,19 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
       if (has_syn) {
         const int nEs = H.syn_nE;
         for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
-        const bool syn_zero = !(nz >> H.syn_grid & 1);
+        // (the log-domain items take ln q and ln w: a magnetic field that is not positive, or a
+        // weight that is not finite, makes the reference's spectrum NaN -- x < 0 overflows
+        // exp(-x), inf x 0 -- and this one with it)
+        const bool syn_nan = S2 && !hi[HI_DEAD] &&
+                             (!(Bw > 0.0) || !(Bw < INFINITY) || (nz >> (8 + H.syn_grid) & 1) != 0);
+        const bool syn_zero = !(nz >> H.syn_grid & 1) || syn_nan;
         if (nA > 0 && !syn_zero) {
           Cd = (hi[HI_LIVE] / nA + R.syn_nodes - 1) / R.syn_nodes;
           Cd = min(max(Cd, 1), D.syn_cdmax);
           nS = (nA * Cd + 63) >> 6;
         }
         if (syn_zero) {
-          for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = 0.0;
+          for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = syn_nan ? NAN : 0.0;
           nA = 0;
         }
         if (lv_k >= 0 && !syn_zero) {
@@ -616,12 +676,27 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             amap[pos] = lv_k;
             ai0[pos] = lv_i0;
-            sq[pos] = lv_q;
-            sq[nEs + pos] = hsr_cbrt(lv_q);
+            const double cbq = hsr_cbrt(lv_q);
             // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
-            sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                                (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
-                                 (lv_E * NH_ERG_PER_EV));
+            const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                               (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
+                                (lv_E * NH_ERG_PER_EV));
+            sq[pos] = lv_q;
+            sq[nEs + pos] = cbq;
+            sq[2 * nEs + pos] = cs1;
+            if (S2) {
+              // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
+              // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy
+              const double lnq = hsr_log(lv_q);
+              const double z = fma(-lnq, R.s2_invd, R.s2_z0);
+              const double Zf = floor(z);
+              double* s2q = sm + R.o_s2q;
+              s2q[pos] = cbq;
+              s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
+              s2q[2 * nEs + pos] = (z - Zf) * R.s2.im;
+              s2q[3 * nEs + pos] = cs1 * qs[HS_O_LNA + 1];
+              reinterpret_cast<int*>(sm + R.o_s2z)[pos] = (int)Zf;
+            }
           } else if (lv_k < nEs) {
             spec[H.syn_spec_off + lv_k] = 0.0;
           }
@@ -719,10 +794,17 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
               syn_ready = true;
             }
             const int g = H.syn_grid, nEs = H.syn_nE;
-            const hs_syn_lds L = {reinterpret_cast<const int*>(sm + H.o_amap), sm + H.o_ig2,
-                                  sm + H.o_dig2, sm + H.o_ig23, sm + H.o_w[g], sm + H.o_d[g],
-                                  sm + H.o_lx[g], sm + H.o_sq, sm + HS_O_T64};
-            hs_syn_item(ix, lane, nA, Cd, H.nG[g], nEs, L, part_s);
+            if (S2) {
+              hs_syn2_item(ix, lane, nA, Cd, nEs, R.s2, reinterpret_cast<const int*>(sm + H.o_amap) + nEs,
+                           reinterpret_cast<const int*>(sm + R.o_s2z), sm + R.o_s2q,
+                           hs_lds_addr(sm + R.o_s2lw + HS_S2_GUARD), hs_lds_addr(sm + R.o_s2ig + HS_S2_GUARD),
+                           hs_lds_addr(sm + R.o_s2tab), hs_lds_addr(sm + R.o_s2t), part_s);
+            } else {
+              const hs_syn_lds L = {reinterpret_cast<const int*>(sm + H.o_amap), sm + H.o_ig2,
+                                    sm + H.o_dig2, sm + H.o_ig23, sm + H.o_w[g], sm + H.o_d[g],
+                                    sm + H.o_lx[g], sm + H.o_sq, sm + HS_O_T64};
+              hs_syn_item(ix, lane, nA, Cd, H.nG[g], nEs, L, part_s);
+            }
           }
         }
       }
@@ -1045,7 +1127,51 @@ struct nh_halfstep_run {
   int* probe_out;
   unsigned probe_seq;
   long long steps_total;
+  double* s2_dev;     // the log-domain synchrotron items' table and grid constants (nh_syn2.h), or NULL
 };
+
+// ---- the table of nh_syn2.h, built on the host when the loop is created -------------------------
+// rho(t) = ln(Gtilde(x) e^x) - t / 3 - ln 1.808,  x = e^t   (radiative.py:300-311); the table holds
+// Lambda (rho + ln 1.808)
+static long double hs_s2_rho(long double t) {
+  const long double s = expl(2.0L * t / 3.0L);
+  return logl((1.0L + 2.210L * s + 0.347L * s * s) /
+              ((1.0L + 1.353L * s + 0.217L * s * s) * sqrtl(1.0L + 3.4L * s)));
+}
+// piece p covers t in (T_top - (p + 1) h, T_top - p h]; its polynomial in lambda = (T_top - t) / h - p
+// interpolates Lambda rho at the six Chebyshev nodes of [0, 1] (<= 1.2e-12 absolute for h <= 0.226)
+static void hs_s2_piece(int p, long double h, double* c /*[HS_S2_STRIDE]*/) {
+  const int n = HS_S2_DEG + 1;
+  long double A[HS_S2_DEG + 1][HS_S2_DEG + 2];
+  for (int r = 0; r < n; ++r) {
+    const long double lam = 0.5L * (1.0L + cosl((2 * r + 1) * 3.14159265358979323846264L / (2 * n)));
+    long double pw = 1.0L;
+    for (int k = 0; k < n; ++k) { A[r][k] = pw; pw *= lam; }
+    A[r][n] = (long double)HS_S2_LAMBDA * (hs_s2_rho((long double)HS_S2_TTOP - (p + lam) * h) + logl(1.808L));
+  }
+  for (int k = 0; k < n; ++k) {  // Gaussian elimination, partial pivoting
+    int piv = k;
+    for (int r = k + 1; r < n; ++r) if (fabsl(A[r][k]) > fabsl(A[piv][k])) piv = r;
+    for (int q = 0; q <= n; ++q) { const long double t = A[k][q]; A[k][q] = A[piv][q]; A[piv][q] = t; }
+    for (int r = k + 1; r < n; ++r) {
+      const long double f = A[r][k] / A[k][k];
+      for (int q = k; q <= n; ++q) A[r][q] -= f * A[k][q];
+    }
+  }
+  long double sol[HS_S2_DEG + 1];
+  for (int k = n - 1; k >= 0; --k) {
+    long double v = A[k][n];
+    for (int q = k + 1; q < n; ++q) v -= A[k][q] * sol[q];
+    sol[k] = v / A[k][k];
+    c[k] = (double)sol[k];
+  }
+}
+
+static const void* hs_run_kernel(bool syn, bool shared, bool s2) {
+  if (!syn) return shared ? (const void*)k_half_step_run<false, true, false> : (const void*)k_half_step_run<false, false, false>;
+  if (s2) return shared ? (const void*)k_half_step_run<true, true, true> : (const void*)k_half_step_run<true, false, true>;
+  return shared ? (const void*)k_half_step_run<true, true, false> : (const void*)k_half_step_run<true, false, false>;
+}
 
 static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh_halfstep_run** out) {
   NH_REQUIRE(c && P && out, "bad argument");
@@ -1085,6 +1211,86 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   R.o_trail = off; off += (HS_RUN_TRAIL * HS_MAX_TAB + H.C.nspec + 1) / 2;
   for (int t = 0; t < H.ntab; ++t)
     NH_REQUIRE(H.C.tab[t].tiles <= HS_RUN_TRAIL, "a table of more column tiles than the resident loop stages");
+  // ---- the synchrotron items in the log domain (nh_syn2.h): a log-uniform grid only -------------
+  std::vector<double> s2_host;
+  R.syn2 = 0;
+  R.s2_dev = nullptr;
+  if (H.syn_grid >= 0 && nh_env_int("NH_RUN_SYN2", 1) != 0) {
+    const int nG = H.nG[H.syn_grid];
+    std::vector<double> gam((size_t)nG);
+    int rc = nh_sync(c);
+    if (rc) return rc;
+    NH_CHECK_HIP(hipMemcpy(gam.data(), H.xg[H.syn_grid], (size_t)nG * sizeof(double), hipMemcpyDeviceToHost));
+    bool ok = nG >= 8 && gam[0] > 0.0 && H.scale[H.syn_grid] > 0.0;
+    long double lx = 0.0L, dev = 0.0L;
+    if (ok) {
+      const long double l0 = logl((long double)gam[0]);
+      lx = (logl((long double)gam[nG - 1]) - l0) / (nG - 1);
+      for (int i = 0; i < nG && ok; ++i) {
+        ok = gam[i] > 0.0;
+        if (ok) dev = fmaxl(dev, fabsl(logl((long double)gam[i]) - l0 - i * lx));
+      }
+      // (np.logspace, radiative.py:147-154: the nodes sit on i lx to a few 1e-15; 1e-12 in ln gamma
+      // is 7e-13 in ln Gtilde)
+      ok = ok && lx > 0.0L && dev <= 1e-12L;
+    }
+    int lm = 0;
+    if (ok) {
+      const double delta = (double)(2.0L * lx);
+      lm = (int)lrint(log2(0.16 / delta));
+      ok = lm >= 1 && lm <= 4;  // pieces of m = 2 .. 16 comb steps, h = m delta in [0.113, 0.226]
+    }
+    if (ok) {
+      const int m = 1 << lm;
+      const long double h = m * 2.0L * lx;
+      const int P = (int)ceill(((long double)HS_S2_TTOP - (long double)HS_S2_TBOT) / h);
+      s2_host.assign((size_t)(P + 1) * HS_S2_STRIDE + nG, 0.0);
+      for (int pc = 0; pc < P; ++pc) hs_s2_piece(pc, h, &s2_host[(size_t)pc * HS_S2_STRIDE]);
+      // (piece P, and every node below the table: rho = 0, i.e. Gtilde = 1.808 x^(1/3))
+      s2_host[(size_t)P * HS_S2_STRIDE] = (double)((long double)HS_S2_LAMBDA * logl(1.808L));
+      for (int i = 0; i < nG; ++i)
+        s2_host[(size_t)(P + 1) * HS_S2_STRIDE + i] =
+            (double)((long double)HS_S2_LAMBDA * (logl((long double)gam[i]) / 3.0L + logl((long double)H.scale[H.syn_grid])));
+      R.s2.lm = lm; R.s2.P = P; R.s2.nG = nG; R.s2.pad = 0;
+      R.s2.ilx = (double)(0.00541521234812457272982L / lx);  // (ln 2 / 128) / lx
+      R.s2.th = (double)((long double)NH_SEG_SMALL_POS / lx);
+      R.s2.im = 1.0 / m;
+      R.s2.lml = (double)(m - 1) / m;
+      R.s2_invd = (double)(1.0L / (2.0L * lx));
+      R.s2_z0 = (double)(((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
+      off += off & 1;  // (16-byte aligned: the pieces are read as ds_read_b128)
+      int o2 = off;
+      R.o_s2tab = o2; o2 += (P + 1) * HS_S2_STRIDE;
+      // the plan's LDS holds w | dlw of the synchrotron grid and 1/g^2 | its differences | its
+      // cube roots, none of which these items read: when no table and no single-row reduction
+      // shares the grid, the new arrays take their place (cfg3 with four workgroups per walker
+      // has 142 KB of partial sums and arrays before this table)
+      const int sg = H.syn_grid;
+      bool own = nG >= 2 * HS_S2_GUARD && H.o_d[sg] == H.o_w[sg] + nG && H.o_ig23 == H.o_dig2 + nG;
+      for (int t = 0; t < H.ntab; ++t) own = own && H.C.tab[t].grid != sg;
+      for (int q = 0; q < H.nmom; ++q) own = own && H.mgrid[q] != sg;
+      R.s2_own = own ? 1 : 0;
+      if (own) {
+        R.o_s2lw = H.o_w[sg];   // (w, dlw: 2 nG doubles in a row)
+        R.o_s2ig = H.o_dig2;    // (dig2, ig23: 2 nG doubles in a row)
+      } else {
+        R.o_s2lw = o2; o2 += nG + 2 * HS_S2_GUARD;
+        R.o_s2ig = o2; o2 += nG + 2 * HS_S2_GUARD;
+      }
+      if (own && grids_in_lds) {
+        R.o_s2lg = R.o_gx[sg];  // (gamma itself: only the weights w = gamma n read it)
+      } else {
+        R.o_s2lg = o2; o2 += nG;
+      }
+      R.o_s2q = o2; o2 += 4 * H.syn_nE;
+      R.o_s2z = o2; o2 += (H.syn_nE + 1) / 2;
+      R.o_s2t = o2; o2 += 128;
+      if ((size_t)o2 * sizeof(double) <= 160 * 1024) {
+        R.syn2 = 1;
+        off = o2;
+      }
+    }
+  }
   R.order = nh_env_int("NH_RUN_ORDER", 2);
   R.syn_nodes = H.C.syn_nodes;
   if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = 32;
@@ -1093,9 +1299,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
-  const void* fn = H.syn_grid >= 0
-                       ? (shared ? (const void*)k_half_step_run<true, true> : (const void*)k_half_step_run<true, false>)
-                       : (shared ? (const void*)k_half_step_run<false, true> : (const void*)k_half_step_run<false, false>);
+  const void* fn = hs_run_kernel(H.syn_grid >= 0, shared, R.syn2 != 0);
   if (lds > 64 * 1024)
     NH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // every workgroup of the launch has to be resident (they wait for each other's records)
@@ -1129,7 +1333,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->xspec = nullptr; Q->tick = nullptr; Q->split = P->split;
   Q->nrank = shared ? nrank : 1; Q->rank = shared ? rank : 0;
   Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
-  Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1;
+  Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1; Q->s2_dev = nullptr;
   for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
   Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
   const size_t ring_bytes = Q->ring_elems * sizeof(unsigned long long);
@@ -1157,6 +1361,11 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     e = hipMalloc(&Q->ring, ring_bytes);
     if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
   }
+  if (e == hipSuccess && R.syn2) {
+    e = hipMalloc(&Q->s2_dev, s2_host.size() * sizeof(double));
+    if (e == hipSuccess)
+      e = hipMemcpy(Q->s2_dev, s2_host.data(), s2_host.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc(&Q->status, sizeof(int));
   if (e == hipSuccess) e = hipMemset(Q->status, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
@@ -1182,11 +1391,12 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (Q->dbg) (void)hipFree(Q->dbg);
     if (Q->xspec) (void)hipFree(Q->xspec);
     if (Q->tick) (void)hipFree(Q->tick);
+    if (Q->s2_dev) (void)hipFree(Q->s2_dev);
     delete Q;
     return nh_set_error(NH_EHIP, "resident half-step loop: %s", hipGetErrorString(e));
   }
   Q->R.ring = Q->ring; Q->R.status = Q->status; Q->R.accw = Q->accw; Q->R.dbg = Q->dbg;
-  Q->R.xspec = Q->xspec; Q->R.tick = Q->tick;
+  Q->R.xspec = Q->xspec; Q->R.tick = Q->tick; Q->R.s2_dev = Q->s2_dev;
   Q->R.spin_limit = 1 << 22;  // ~1 s of polling: a record that has not come by then never will
   // (a shared ensemble: the ranks' hosts launch on their own clocks; a rank may have to wait for
   // another one's launch to START -- ~16 s)
@@ -1422,15 +1632,9 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     nh_prof_scope ps(c, NH_K_HALFSTEP);
     const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
     const dim3 thr(Q->threads);
-    if (H.syn_grid >= 0 && Q->base)
-      hipLaunchKernelGGL((k_half_step_run<true, true>), grid, thr, Q->lds_bytes, c->stream, H, R);
-    else if (H.syn_grid >= 0)
-      hipLaunchKernelGGL((k_half_step_run<true, false>), grid, thr, Q->lds_bytes, c->stream, H, R);
-    else if (Q->base)
-      hipLaunchKernelGGL((k_half_step_run<false, true>), grid, thr, Q->lds_bytes, c->stream, H, R);
-    else
-      hipLaunchKernelGGL((k_half_step_run<false, false>), grid, thr, Q->lds_bytes, c->stream, H, R);
-    NH_CHECK_HIP(hipGetLastError());
+    void* args[2] = {(void*)&H, (void*)&R};
+    NH_CHECK_HIP(hipLaunchKernel(hs_run_kernel(H.syn_grid >= 0, Q->base != nullptr, R.syn2 != 0), grid, thr,
+                                 args, Q->lds_bytes, c->stream));
   }
   {
     nh_prof_scope ps(c, NH_K_GLUE);
@@ -1459,6 +1663,15 @@ extern "C" int nh_half_step_run_info(const nh_halfstep_run* Q, int* grid, int* t
   if (grid) *grid = Q->grid;
   if (threads) *threads = Q->threads;
   if (lds_bytes) *lds_bytes = (long long)Q->lds_bytes;
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_syn_info(const nh_halfstep_run* Q, int* mode, int* nodes_per_piece,
+                                         int* pieces) {
+  NH_REQUIRE(Q, "bad argument");
+  if (mode) *mode = Q->R.syn2;
+  if (nodes_per_piece) *nodes_per_piece = Q->R.syn2 ? 1 << Q->R.s2.lm : 0;
+  if (pieces) *pieces = Q->R.syn2 ? Q->R.s2.P + 1 : 0;
   return NH_OK;
 }
 
@@ -1492,6 +1705,7 @@ extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
   if (Q->dbg) (void)hipFree(Q->dbg);
   if (Q->xspec) (void)hipFree(Q->xspec);
   if (Q->tick) (void)hipFree(Q->tick);
+  if (Q->s2_dev) (void)hipFree(Q->s2_dev);
   delete Q;
   return rc;
 }

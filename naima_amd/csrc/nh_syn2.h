@@ -1,0 +1,160 @@
+// nh_syn2.h -- Synchrotron._spectrum's integrand (radiative.py:300-340) in the log domain, on a
+// comb: the resident loop's synchrotron work item (k_half_step_run, nh_persist.hip).
+//
+// The direct form (nh_hs.h: hs_syn_item) costs ~69 vector instructions per grid node: the AKP10
+// function P(x) = Gtilde(x) e^x (one reciprocal square root, 19), exp(-x) (16), and -- because
+// trapz_loglog (utils.py:336-345) needs the LOG-ratio of neighbouring nodes to 1e-13 -- the
+// three-term atanh of (P2 - P1) / (P2 + P1) (14) before the segment itself (12).  The kernel is
+// bound by vector issue, so instructions per node are what its time is made of.
+//
+// Here every node is ONE exponent
+//     E_i = ln w_i + g(t_i) - x_i,     g(t) = ln(Gtilde(x) e^x),  t = ln x,
+// its integrand u_i = exp(E_i) and the segment's log-ratio ln(u2/u1) = E_2 - E_1 EXACTLY (one
+// subtraction of neighbouring exponents -- consistent with u_2 / u_1 to the last place of the
+// exponential, which is what the cancellation in (u2 - u1) / ln(u2/u1) needs; what an error of E
+// itself does is move u by that relative amount and no more).  g(t) is smooth and slowly varying
+// (t/3 + const for small x, a constant for large x), so it is tabulated; and because naima's
+// particle grid is np.logspace (radiative.py:147-154: ln gamma_i = ln gamma_0 + i lx), the nodes of
+// one (walker, photon energy) pair lie on a COMB in t,
+//     t_i = ln q - 2 ln gamma_i = T_top - (z + i) delta,   delta = 2 lx,
+// so with table pieces of m comb steps (h = m delta ~ 0.16; degree 5, <= 1.2e-12 absolute on g)
+// aligned to the same comb, node i sits in piece (Z + i) / m at the local coordinate
+// ((Z + i) mod m + f) / m with Z = floor(z), f = z - Z: no per-node index arithmetic, no
+// logarithm, the coefficients of a piece are read once per m nodes, and the lanes of a wave --
+// (energy, chunk) pairs whose chunks start on piece boundaries -- walk the pieces in step.
+// Everything is kept in units of ln2 / 128 (E' = E 128 / ln2), so that the exponential is
+// rint, a subtraction, a degree-4 polynomial and a 128-entry table 2^(j/128).
+//
+// ~37 vector instructions per node: x = cb^3 from the grid's cube roots (3), Horner (5), E' (2),
+// exponential (12), log-ratio (2), segment (hs_seg_pre: 10), bookkeeping (3).
+//
+// Taken when the plan's synchrotron grid is log-uniform to 1e-11 (checked on the host when the
+// loop is created; any other grid keeps hs_syn_item) -- then the segment width ln(g2/g1) is one
+// number too.  Exact zeros of the reference: a node with x > 746 has Gtilde = 0 there
+// (exp(-x) underflows) and is never the first node of a range, except for the <= m - 1 nodes a
+// range's start is aligned down by; those carry u ~ w e^-746 or less, 1e-324 of the integral.
+// A zero weight is ln w = -1e300: u = 0 exactly and the segment to either neighbour an exact 0,
+// as utils.py:347-348 has it (HS_S2_FLOOR below).  A negative
+// amplitude is a sign in front of the integral (the integrand is linear in it); a negative
+// magnetic field makes ln q a NaN and the spectrum with it, as it makes the reference's.
+#pragma once
+#include "nh_common.h"
+
+#define HS_S2_TTOP 7.0       // top of the table in t = ln x: above ln(746 e^h) for every h used
+#define HS_S2_TBOT (-46.0)   // below it g = ln 1.808 + t / 3 to 5e-14: the last piece, linear
+#define HS_S2_GUARD 16       // guard nodes either side of the walker's ln w and the grid's cube roots
+#define HS_S2_LAMBDA 184.6649652337873  // 128 / ln 2
+// ln w of a zero weight and of the guard nodes: hs_exp128 gives an exact 0 (the integer conversion
+// saturates), and the log-ratio to a finite neighbour is beyond the single-precision range, where
+// nh_rcp1f returns 0 -- the segment between a zero node and its neighbour is an exact 0, as
+// utils.py:347-348 has it (two zero nodes: the series branch, 0 x lx)
+#define HS_S2_FLOOR (-1.0e300)
+#define HS_S2_DEG 5
+#define HS_S2_STRIDE 6       // doubles per piece
+#ifndef HS_S2_INLINE
+#define HS_S2_INLINE __forceinline__
+#endif
+
+struct hs_syn2_par {  // wave-uniform
+  int lm, P, nG, pad;     // log2 of the nodes per piece | the last (linear) piece | grid nodes
+  double ilx, th, im, lml;  // (ln2/128) / lx | 2^-10 / lx | 1 / m | (m - 1) / m
+};
+
+typedef double hs_s2_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const hs_s2_d2 hs_s2_lds_d2;
+typedef __attribute__((address_space(3))) const double hs_s2_lds_d;
+
+__device__ __forceinline__ double hs_s2_ld(unsigned addr) {
+  return *(hs_s2_lds_d*)(unsigned long long)addr;
+}
+
+// 2^(v / 128) for finite v (NaN in, NaN out; gradual underflow, overflow and the saturating integer
+// conversion through ldexp).  t128: LDS byte address of 2^(j/128), j < 128.  The remainder's
+// polynomial is degree 4 on |r| ln2/128 <= 0.0027: 1.2e-15 relative -- it has to be that good,
+// because the truncation errors of two neighbouring nodes are NOT the same function of anything
+// and (u2 - u1) / ln(u2/u1) divides their difference by |dl| >= 2^-10 (with the 64-entry table
+// of nh_exp_tab and this degree: 4e-14 / 1e-3 = 4e-11 on the segments around the integrand's peak,
+// measured)
+__device__ __forceinline__ double hs_exp128(double v, unsigned t128) {
+  const double kf = rint(v);
+  const double r = v - kf;  // |r| <= 1/2 (exact)
+  double p = fma(r, 3.583032305400251e-11, 2.646642144433097e-08);  // c^4/24, c^3/6,  c = ln2/128
+  p = fma(p, r, 1.4662262387640425e-05);                           // c^2/2
+  p = fma(p, r, 5.4152123481245725e-03);                           // c
+  p = fma(p, r, 1.0);
+  const int k = (int)kf;
+  return ldexp(hs_s2_ld(t128 + 8u * (unsigned)(k & 127)) * p, k >> 7);
+}
+
+// One work item: 64 (live photon energy, chunk) pairs.  Per live energy a (compacted, as in
+// hs_syn_item): ai0[a] its first live node, Zs[a] the comb index of node 0, and in sq (nEs
+// apart) cbrt(q) | Lambda ln(q) / 3 | f / m | CS1 (signed by the amplitude).
+// a_lw / a_ig: LDS byte addresses of node 0 of the walker's Lambda ln(w) and of the grid's
+// cbrt(1/gamma^2) (HS_S2_GUARD entries either side); a_tab: the table, HS_S2_STRIDE doubles per
+// piece, 16-byte aligned; a_t128: 2^(j/128), j < 128.
+__device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int nEs,
+                                             const hs_syn2_par& S, const int* ai0, const int* Zs,
+                                             const double* sq, unsigned a_lw, unsigned a_ig,
+                                             unsigned a_tab, unsigned a_t128, double* part_s) {
+  const int vt = ix * 64 + lane;
+  const int a = vt % nA, ch = vt / nA;
+  if (ch >= Cd) return;
+  const int lm = S.lm, m = 1 << lm;
+  const int Z = Zs[a];
+  const int k0 = ((Z + ai0[a]) >> lm) << lm;  // the range starts on a piece boundary
+  const int kend = Z + S.nG - 1;              // the grid's last node
+  int per = (kend - k0 + Cd) / Cd;            // nodes k0 .. kend over Cd chunks ...
+  per = ((per + m - 1) >> lm) << lm;          // ... of whole pieces
+  const int kb = k0 + ch * per;
+  double acc = 0.0;
+  if (kb <= kend) {
+    const int n = min(per, kend - kb + 1);
+    const int groups = (n + m - 1) >> lm;     // (the last chunk's last piece runs on into the guards)
+    const double cbq = sq[a], Kc = sq[nEs + a], lam0 = sq[2 * nEs + a];
+    double c0, c1, c2, c3, c4, c5;
+    auto coefs = [&](int p, int kfirst, double& lam) {  // piece p, whose first node is kfirst
+      const int pe = min(p, S.P);
+      const unsigned at = a_tab + (unsigned)pe * (8u * HS_S2_STRIDE);
+      const hs_s2_d2 v01 = *(hs_s2_lds_d2*)(unsigned long long)at;
+      const hs_s2_d2 v23 = *(hs_s2_lds_d2*)(unsigned long long)(at + 16u);
+      const hs_s2_d2 v45 = *(hs_s2_lds_d2*)(unsigned long long)(at + 32u);
+      c0 = v01.x + Kc; c1 = v01.y; c2 = v23.x; c3 = v23.y; c4 = v45.x; c5 = v45.y;
+      lam = fma((double)(kfirst - (pe << lm)), S.im, lam0);  // (= f / m inside the table)
+    };
+    auto node = [&](unsigned pl, unsigned pg, double lam, double& E, double& u) {
+      const double cb = cbq * hs_s2_ld(pg);
+      const double s = cb * cb;
+      const double x = s * cb;
+      double g = fma(c5, lam, c4);
+      g = fma(g, lam, c3);
+      g = fma(g, lam, c2);
+      g = fma(g, lam, c1);
+      g = fma(g, lam, c0);
+      E = fma(x, -HS_S2_LAMBDA, g) + hs_s2_ld(pl);
+      u = hs_exp128(E, a_t128);
+    };
+    // the start node kb - 1: the last node of the piece before
+    double lam, E1, u1;
+    coefs((kb >> lm) - 1, kb - m, lam);
+    const int i0 = kb - 1 - Z;
+    unsigned pl = a_lw + 8u * (unsigned)i0, pg = a_ig + 8u * (unsigned)i0;
+    node(pl, pg, lam + S.lml, E1, u1);
+    int kf = kb;
+    for (int gi = 0; gi < groups; ++gi, kf += m) {
+      coefs(kf >> lm, kf, lam);
+      for (int j = 0; j < m; j += 2) {  // (m is even: two nodes per trip, two chains to interleave)
+        double EA, uA, EB, uB;
+        node(pl + 8u, pg + 8u, lam, EA, uA);
+        node(pl + 16u, pg + 16u, lam + S.im, EB, uB);
+        acc = hs_seg_pre(acc, u1, uA, (EA - E1) * S.ilx, S.th);
+        acc = hs_seg_pre(acc, uA, uB, (EB - EA) * S.ilx, S.th);
+        E1 = EB;
+        u1 = uB;
+        lam += 2.0 * S.im;
+        pl += 16u;
+        pg += 16u;
+      }
+    }
+  }
+  part_s[ch * nEs + a] = acc * sq[3 * nEs + a];  // linear in u: CS1 once per thread
+}

@@ -844,8 +844,15 @@ class DeviceLoop:
             self.ctx.sorted_tables(hs, h)
             g, t, l = _lib._i(), _lib._i(), _lib._ll()
             _lib._chk(_lib._lib.nh_half_step_run_info(h, C.byref(g), C.byref(t), C.byref(l)))
-            self.resident_info = dict(grid=g.value, threads=t.value, lds_bytes=l.value)
+            self.resident_info = dict(grid=g.value, threads=t.value, lds_bytes=l.value,
+                                      **self._syn_info(h))
         return True
+
+    @staticmethod
+    def _syn_info(h):
+        mode, m, pcs = _lib._i(), _lib._i(), _lib._i()
+        _lib._chk(_lib._lib.nh_half_step_run_syn_info(h, C.byref(mode), C.byref(m), C.byref(pcs)))
+        return dict(syn_log_domain=bool(mode.value), syn_nodes_per_piece=m.value, syn_pieces=pcs.value)
 
     def _create_shared_run(self, hs):
         """the resident loop over an ensemble shared with the other ranks' GPUs: rings in
@@ -899,7 +906,8 @@ class DeviceLoop:
         ctx.sorted_tables(hs, h)
         gr, t, l = _lib._i(), _lib._i(), _lib._ll()
         _lib._chk(lib.nh_half_step_run_info(h, C.byref(gr), C.byref(t), C.byref(l)))
-        self.resident_info = dict(grid=gr.value, threads=t.value, lds_bytes=l.value)
+        self.resident_info = dict(grid=gr.value, threads=t.value, lds_bytes=l.value,
+                                  **self._syn_info(h))
         self.shared_info = dict(ranks=comm.size, probe_us_per_exchange=us.value)
         return h
 

@@ -532,6 +532,55 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
     print("%s: resident == per-launch; bit-identical chain: %s" % (name, np.array_equal(a[0], b[0])))
 
 
+@pytest.mark.parametrize("name,nw", [("cfg3", 512), ("cfg2", 256), ("cfg3", 96)],
+                         ids=["cfg3-512", "cfg2-256-two-per-walker", "cfg3-96-four-per-walker"])
+def test_resident_synchrotron_items_in_the_log_domain(na, monkeypatch, name, nw):
+    """The resident loop evaluates Synchrotron._spectrum's integrand (radiative.py:300-340) as one
+    exponent per node, ln Gtilde from a table on the particle grid's comb (csrc/nh_syn2.h), not
+    with the arithmetic of the golden-pinned k_synchrotron.  Direct check: the model spectra
+    (blobs) of every walker and step of a resident run from the benchmark's ball against the
+    host-driven loop -- whose spectra are k_synchrotron's, held to the reference's at 1e-10 by
+    test_gpu_parity -- at 2e-11, and against the same resident loop with the direct form
+    (NH_RUN_SYN2=0)."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, name, {})
+    nd = p0.size
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True,
+              nan_policy="reject")
+    rng = np.random.default_rng(BENCH_SEED)
+    pos = p0 + 0.1 * p0 * rng.normal(size=(nw, nd))
+    steps = 12
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NH_RUN_SYN2", mode)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        with np.errstate(all="ignore"):
+            st = d.run_mcmc(pos, 4)
+            st = d.run_mcmc(st, steps)
+        assert d._dev.resident_launches > 0, getattr(d._dev, "resident_reason", "")
+        info = d._dev.resident_info
+        assert info["syn_log_domain"] == (mode == "1"), info
+        if mode == "1":
+            assert info["syn_nodes_per_piece"] in (2, 4) and 200 < info["syn_pieces"] < 480, info
+        out[mode] = (d.get_chain(), d.get_log_prob(), [np.asarray(b, dtype=float) for b in d.get_blobs()])
+    monkeypatch.delenv("NH_RUN_SYN2")
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    with np.errstate(all="ignore"):
+        sh = h.run_mcmc(pos, 4)
+        sh = h.run_mcmc(sh, steps)
+    ref = (h.get_chain(), h.get_log_prob(), [np.asarray(b, dtype=float) for b in h.get_blobs()])
+    for other in (out["0"], ref):
+        assert_allclose(out["1"][0], other[0], rtol=1e-10)
+        fin = np.isfinite(other[1])
+        assert np.array_equal(fin, np.isfinite(out["1"][1]))
+        assert_allclose(out["1"][1][fin], other[1][fin], rtol=1e-9)
+        for x, y in zip(out["1"][2], other[2]):
+            assert x.shape == y.shape
+            assert_allclose(x, y, rtol=2e-11, atol=1e-300, equal_nan=True)
+    spec = out["1"][2][0]
+    assert spec.shape[:2] == (4 + steps, nw) and np.isfinite(spec).mean() > 0.9
+
+
 def test_table_only_model_with_more_walkers_than_compute_units(na):
     """cfg5 at BASELINE's 2048 walkers on one GPU: 1024 walkers per half-step, four per compute
     unit -- the plan picks 256-thread workgroups (several walkers share a CU, one's prologue
