@@ -68,6 +68,41 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VEC_PEAK_TF = 78.6    # vendor figure quoted in SURVEY.md 8d (256 CU x 128 flop/clk x 2.4 GHz)
 
 
+def measured_utilisation(name, resident):
+    """What the vector pipe did, from the committed SQ counter passes of this workload's bench
+    command under rocprofv3 (profiles/r*_<name>_counters_per_launch.json, newest round): the
+    fraction of the dominant kernel's time its SIMDs spent issuing vector instructions
+    (SQ_ACTIVE_INST_VALU x 4 waves per SIMD / SQ_WAVE_CYCLES for the 1024-thread workgroups; this
+    is the utilisation figure of an issue-bound kernel -- `fp64_valu` beside it is SURVEY.md 8d's
+    op-count convention) and instructions per wave and launch.  None without a profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters_per_launch.json" % name)))
+    if not files:
+        return None
+    want = "half_step_run" if resident else ("ic_seed_walkers" if name == "cfg4" else "half_step")
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    best = None
+    for k, v in d.items():
+        if want in k and "SQ_ACTIVE_INST_VALU" in v and "SQ_WAVE_CYCLES" in v:
+            if best is None or v.get("SQ_WAVE_CYCLES", 0) > best[1].get("SQ_WAVE_CYCLES", 0):
+                best = (k, v)
+    if best is None:
+        return None
+    k, v = best
+    waves = max(v.get("SQ_WAVES", 1.0), 1.0)
+    out = {"kernel": k.split("(")[0].strip(), "source": os.path.basename(files[-1]),
+           "valu_busy": 4.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
+           "valu_insts_per_wave_and_launch": v.get("SQ_INSTS_VALU", 0.0) / waves,
+           "salu_insts_per_wave_and_launch": v.get("SQ_INSTS_SALU", 0.0) / waves,
+           "wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"],
+           "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_WAVE_CYCLES (four waves share a SIMD); "
+                   "a resident launch of the profiled command is 40 half-steps"}
+    return out
+
+
 def measured_traffic(name, symbol):
     """HBM-side bytes per launch of ``symbol`` from the committed TCC counter run
     (profiles/*_hbm_counters*.json: FETCH_SIZE and WRITE_SIZE collected in separate
@@ -245,6 +280,9 @@ def main():
     ap.add_argument("--no-blobs-run", action="store_true",
                     help="skip the extra measurement with the opposite blob setting")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--reject-nan", action="store_true",
+                    help="treat a NaN log-probability as a rejected proposal and count it; the "
+                         "default is emcee's: ValueError on the first one")
     ap.add_argument("--no-chain", action="store_true",
                     help="do not keep the chain (emcee's store=False); default keeps it in HBM")
     ap.add_argument("--host-loop", action="store_true",
@@ -280,7 +318,8 @@ def main():
     def make_sampler(device, graph, blobs=False):
         return EnsembleSampler(nwalkers, p0.size, na.lnprob, args=[data, model, prior],
                                seed=20260929, comm=comm, naima_style=True, store_blobs=blobs,
-                               device=device, use_graph=graph, nan_policy="reject")
+                               device=device, use_graph=graph,
+                               nan_policy="reject" if args.reject_nan else "raise")
 
     device = not args.host_loop
     keep_blobs = not args.no_blobs
@@ -510,9 +549,17 @@ def main():
         "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
         "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
         "acceptance_fraction": acc_frac,
-        # (emcee stops at the first NaN log-probability; far-off walkers of the 10 % ball of the
-        # weakly constrained workloads -- cfg2, cfg5 -- do produce them: rejected and counted)
+        # (emcee stops at the first NaN log-probability, and so does this run unless
+        # --reject-nan: the workloads' priors -- workloads.prior_for -- keep the walkers of the
+        # 10 % ball off the zero-flux plateau where 10 ** x of a wandered coordinate overflows)
+        "nan_policy": "reject" if args.reject_nan else "raise",
         "nan_proposals_rejected": int(sampler.nan_proposals),
+        # (a proposal the prior forbids is never accepted: the device loop evaluates none of its
+        # integrals, the reference evaluates the model and discards it, core.py:103-119 --
+        # identical results; such proposals are walker-steps of `value` like any other.  Counted
+        # by the kernels over every step the timed sampler made, warm-up included)
+        "proposals_forbidden_by_prior": int(sampler.prior_forbidden_proposals),
+        "proposals_total": int(sampler.n_walker_evals) * (comm.size if device else 1),
         "loop": ("host" if not device else
                  "device, resident workgroups: one launch of k_half_step_run per block of moves "
                  "(<= 32 steps), walkers handed over by tagged records" if resident else
@@ -544,6 +591,9 @@ def main():
                                           "kernel's windows, %g eq. each (the reciprocal's "
                                           "20 are five instructions on this chip: an op-count "
                                           "convention, not pipe utilisation)" % SSC_SEG_EQ}
+    util = measured_utilisation(name, resident)
+    if util:
+        out["valu_utilisation"] = util
     if not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
     print(json.dumps(out), flush=True)

@@ -554,6 +554,11 @@ int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
  * (EnsembleSampler.compute_log_prob; reference call site core.py:128), a launch rejects the
  * proposal and counts it here for the caller to act on.  Synchronises the stream. */
 int nh_half_step_nan_count(nh_ctx* ctx, nh_halfstep_plan* plan, int reset, int* count);
+/* The same with, beside it, the proposals the prior forbade (core.py:99-101, 115-119: the
+ * launch evaluates none of their integrals; the reference evaluates the model and discards the
+ * result).  A negative *nan / *forbidden on entry SETS that counter to -value - 1 first (a
+ * replayed block of moves must not count its proposals twice). */
+int nh_half_step_counts(nh_ctx* ctx, nh_halfstep_plan* plan, int reset, int* nan, int* forbidden);
 int nh_half_step_destroy(nh_ctx* ctx, nh_halfstep_plan* plan);
 
 /* ---- a whole block of moves in ONE launch: the half-step kernel with resident workgroups ----

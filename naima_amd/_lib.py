@@ -113,6 +113,7 @@ _SIGS = {
     "nh_half_step_split": [_dp, C.POINTER(_i)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_half_step_nan_count": [_dp, _dp, _i, C.POINTER(_i)],
+    "nh_half_step_counts": [_dp, _dp, _i, C.POINTER(_i), C.POINTER(_i)],
     "nh_half_step_stamps": [_dp, _dp, _dp],
     "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],

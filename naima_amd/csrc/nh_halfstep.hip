@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       atomicAdd(H.done, 1);
       // emcee raises "Probability function returned NaN" here; the launch cannot, it counts
       if (acc != acc) atomicAdd(H.done + 2, 1);
+      if (hi[HI_DEAD]) atomicAdd(H.done + 3, 1);  // (forbidden by the prior: nothing was integrated)
     }
     if (dbg_on && lane == 0 && j < 1024) D.dbg[256 + 1024 + j] = (long long)wall_clock64();
   }
@@ -1593,6 +1594,27 @@ extern "C" int nh_half_step_nan_count(nh_ctx* c, nh_halfstep_plan* P, int reset,
   if (rc) return rc;
   NH_CHECK_HIP(hipMemcpy(count, P->words + 2, sizeof(int), hipMemcpyDeviceToHost));
   if (reset && *count) NH_CHECK_HIP(hipMemset(P->words + 2, 0, sizeof(int)));
+  return NH_OK;
+}
+
+// the same, and beside it the proposals the prior forbade (core.py:99-101, 115-119: -inf; the
+// launch evaluates none of their integrals, the reference evaluates the model and discards it).
+// A negative *nan / *forbidden on entry SETS that counter to -value - 1 first (a replayed block of
+// moves must not count its proposals twice).
+extern "C" int nh_half_step_counts(nh_ctx* c, nh_halfstep_plan* P, int reset, int* nan, int* forbidden) {
+  NH_REQUIRE(c && P && nan && forbidden, "bad argument");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  int w[2];
+  NH_CHECK_HIP(hipMemcpy(w, P->words + 2, sizeof(w), hipMemcpyDeviceToHost));
+  if (*nan < 0 || *forbidden < 0) {
+    if (*nan < 0) w[0] = -*nan - 1;
+    if (*forbidden < 0) w[1] = -*forbidden - 1;
+    NH_CHECK_HIP(hipMemcpy(P->words + 2, w, sizeof(w), hipMemcpyHostToDevice));
+  }
+  *nan = w[0];
+  *forbidden = w[1];
+  if (reset && (w[0] || w[1])) NH_CHECK_HIP(hipMemset(P->words + 2, 0, sizeof(w)));
   return NH_OK;
 }
 

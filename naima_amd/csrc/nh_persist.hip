@@ -962,6 +962,7 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           // other ranks move keep an older launch's number and are recognised by it, no memset)
           R.accw[(long long)tl * N + me2] = multi ? (int)((R.seq << 2) | (ok ? 2u : 1u)) : (ok ? 1 : 0);
           if (acc != acc) atomicAdd(H.done + 2, 1);  // (see nh_half_step_nan_count)
+          if (hi[HI_DEAD]) atomicAdd(H.done + 3, 1);  // (forbidden by the prior: nothing was integrated)
         }
         if (ok) {  // the accepted position's blobs
           for (int b = 0; b < D.nblob; ++b) {
@@ -1018,6 +1019,10 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   // chain of dependent round trips, one after the other they added up to 15 us of a 20-step
   // region
   const int job = blockIdx.y;
+  // a launch that gave up (a record never came: nh_half_step_run_status) leaves the flat arrays,
+  // the counters and the blob rows as they were before it -- whoever finds the status can replay
+  // the block of moves from them
+  if (*R.status != 0) return;
   for (long long e = job == 0 ? gid : (long long)N * (ndim + 1); e < (long long)N * (ndim + 1); e += gsz) {
     const int w = (int)(e / (ndim + 1)), d = (int)(e % (ndim + 1));
     const unsigned long long* rec = R.ring + ((long long)nsteps * N + w) * R.gr + 2 * d;

@@ -202,6 +202,9 @@ class DeviceLoop:
         # from half-step to half-step by per-walker records): None = not tried yet, False = this
         # plan / configuration cannot (or NAIMA_AMD_RESIDENT=0), else the handle
         self._run = None if os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0" else False
+        self._resident_trust = 0          # launches of the resident loop that were checked as they were made
+        self.resident_failed_launches = 0
+        self._nan_pending = self._forbidden_pending = 0
         self.resident_launches = 0
         # ... and over an ensemble shared by several GPUs (nh_half_step_run_create_shared: movers
         # store their walkers' records into every rank's ring; no collective per half-step).
@@ -221,8 +224,8 @@ class DeviceLoop:
         """forget the chain and the acceptance counts (the sampler clears its host copies): the
         history still on the device is dropped, not downloaded"""
         self._flush_pending()
-        self.check_resident()
-        self.check_nan()
+        self.check_resident(collective=True)
+        self.check_nan(collective=True)
         self.ctx.check_general()
         self._sync_cur_blobs()
         self.hist = []
@@ -604,13 +607,17 @@ class DeviceLoop:
         # per-launch kernel's bookkeeping (history descriptor words, slice counter) is needed
         fast = (self._resident_ok() and yield_every >= iterations and (block is None or dev_hist)
                 and blob_hist_ok)
-        if self.fused and not fast:
+        def per_launch_history():
+            # (the per-launch kernel's history descriptor: where its launches append the chain)
             words = [block["coords"].ptr, block["logp"].ptr, 0, iterations] if dev_hist \
                 else [0, 0, 0, 0]
             if dev_hist and self.blobs_in_kernel:
                 words = words + [hb.ptr for hb in block["blobs"]]
             words = (words + [0, 0, 0, 0])[:8]
             ctx.call("nh_set_words", self.histd, (C.c_longlong * 8)(*words), 8)
+
+        if self.fused and not fast:
+            per_launch_history()
         blob_dev_hist = dev_hist and self.blobs_in_kernel  # the launches append the blobs too
         moves = s.moves(pinned=True)
         it = 0
@@ -629,7 +636,11 @@ class DeviceLoop:
             if mv["ahead"] is not None:  # the launch waits for the copy stream's last upload
                 ctx.call("nh_stream_wait_marker", mv["ahead"])
                 mv["ahead"] = None
-            self._run_resident(2 * mv["used"], 2 * want, block)
+            if not self._run_resident(2 * mv["used"], 2 * want, block):
+                fast = False  # (gave up: the per-launch loop below replays these steps)
+                if self.fused:
+                    per_launch_history()
+                break
             mv["used"] += want
             # a marker behind this launch: `blk` is a ring, and the host runs launches ahead of
             # the device -- an upload on the copy stream may overlap THIS launch (whose steps lie
@@ -706,7 +717,8 @@ class DeviceLoop:
                             ctx.call("nh_half_step_append_blobs", self._plan["hs"]["plan"],
                                      block["n"] - 1)
                     self._flush_pending()
-                    self._run_resident(2 * k, 2 * g, block if dev_hist else None)
+                    if not self._run_resident(2 * k, 2 * g, block if dev_hist else None):
+                        continue  # (gave up: _resident_ok() is false from now on)
                     resident = True
                 elif (self.step_graph is not None and self.fused and K - k >= gmax >= 2 and
                         yield_every >= gmax and (block is None or dev_hist) and
@@ -1015,39 +1027,99 @@ class DeviceLoop:
             row0, cap = block["n"], block["coords"].shape[0]
             if block["blobs"]:
                 hb = (C.c_void_p * 4)(*([b.ptr for b in block["blobs"]] + [None] * 4)[:4])
+        probation = not self.shared and self._resident_trust < 2
+        if probation:
+            # The first launches of a loop are checked before anything builds on them: a launch
+            # whose workgroups cannot all be resident (another process on the GPU, a profiler that
+            # serialises workgroups) gives up on its first wait -- it leaves the ensemble, the
+            # counters and the move stream as they were (k_run_epilogue does nothing then), so the
+            # same block of moves is replayed by the per-launch kernel and the run carries on
+            # with one launch per half-step.  (A shared ensemble: the ranks agree in
+            # _create_shared_run / bench.py's rehearsal; a time-out later in a run still raises.)
+            n0, f0 = self._read_counts(reset=False)
         ctx.call("nh_half_step_run", hs["plan"], self._run, slice0, nslices, hc, hl, hb, row0, cap)
+        if probation:
+            st = _lib._i()
+            _lib._chk(_lib._lib.nh_half_step_run_status(ctx.h, self._run, C.byref(st)))
+            if st.value != 0:
+                import warnings
+                self.resident_reason = ("a launch of the resident loop gave up waiting for a walker's "
+                                        "record (status %d): its workgroups were not all resident"
+                                        % st.value)
+                warnings.warn(self.resident_reason + "; the block of moves is replayed and the run "
+                              "continues with one launch per half-step")
+                self._run = False
+                self.resident_failed_launches += 1
+                self._read_counts(reset=False, set_to=(n0, f0))  # (the replay counts them again)
+                return False
+            self._resident_trust += 1
         self.resident_launches += 1
         self.s.n_lnprob_calls += nslices
         self.s.n_walker_evals += nslices * self.nloc
+        return True
 
-    def check_nan(self):
-        """NaN log-probabilities the launches met since the last look (one-launch plans count
-        them on the device): counted, or raised as emcee does, by the sampler's nan_policy"""
+    def _read_counts(self, reset, set_to=None):
+        """(NaN log-probabilities, proposals forbidden by the prior) the one-launch kernels have
+        counted on the device since the last reset"""
         hs = self._plan["hs"] if self._plan else None
         if hs is None or hs.get("plan") is None:
+            return 0, 0
+        n, f = _lib._i(0), _lib._i(0)
+        if set_to is not None:
+            n, f = _lib._i(-set_to[0] - 1), _lib._i(-set_to[1] - 1)
+        _lib._chk(_lib._lib.nh_half_step_counts(self.ctx.h, hs["plan"], 1 if reset else 0,
+                                                C.byref(n), C.byref(f)))
+        return n.value, f.value
+
+    def check_nan(self, collective=False):
+        """NaN log-probabilities the launches met since the last look (one-launch plans count
+        them on the device): counted, or raised as emcee does, by the sampler's nan_policy.
+        With several ranks the counts are per rank (a proposal is counted by the rank that moved
+        the walker): where every rank is known to be here (``collective``: flush, reset, the merge
+        of the current blobs) they are summed over the ranks first, so that every rank counts --
+        and raises -- the same; elsewhere a rank only accumulates what it has seen, because a
+        ValueError on one rank would leave the others waiting in their next collective."""
+        n, f = self._read_counts(reset=True)
+        self._nan_pending += n
+        self._forbidden_pending += f
+        multi = self.s.comm is not None and self.s.comm.size > 1
+        if multi and not collective:
             return
-        n = _lib._i()
-        _lib._chk(_lib._lib.nh_half_step_nan_count(self.ctx.h, hs["plan"], 1, C.byref(n)))
-        if n.value:
-            self.s.nan_proposals += n.value
+        n, f = self._nan_pending, self._forbidden_pending
+        self._nan_pending = self._forbidden_pending = 0
+        if multi:
+            import struct
+            parts = self.s.comm.group.allgather_bytes(struct.pack("<qq", n, f))
+            n = sum(struct.unpack("<qq", p_)[0] for p_ in parts)
+            f = sum(struct.unpack("<qq", p_)[1] for p_ in parts)
+        self.s.prior_forbidden_proposals += f
+        if n:
+            self.s.nan_proposals += n
             if self.s.nan_policy == "raise":
                 raise ValueError("Probability function returned NaN (%d proposals of the device "
                                  "loop; emcee stops at the first one -- pass nan_policy='reject' "
-                                 "to treat them as rejected proposals)" % n.value)
+                                 "to treat them as rejected proposals)" % n)
 
-    def check_resident(self):
+    def check_resident(self, collective=False):
         """raise if a launch of the resident loop gave up waiting for a walker's record (its
         workgroups were not all resident: another process on the GPU, a profiler that
-        serialises workgroups); the ensemble is undefined from that launch on"""
+        serialises workgroups); the ensemble is undefined from that launch on.  (The first
+        launches of a one-GPU loop are checked as they are made and replayed by the per-launch
+        kernel instead: _run_resident.)  ``collective``: every rank is here -- the worst status
+        of all ranks decides, and all of them raise."""
+        st = _lib._i(0)
         if self._run:
-            st = _lib._i()
             _lib._chk(_lib._lib.nh_half_step_run_status(self.ctx.h, self._run, C.byref(st)))
-            if st.value != 0:
-                raise _lib.NaimaHipError(
-                    "the resident half-step loop timed out waiting for a walker's record (status "
-                    "%d): its workgroups were not all resident%s.  Run with NAIMA_AMD_%s=0"
-                    % (st.value, ", or a rank of the shared ensemble fell behind or failed"
-                       if self.shared else "", "SHARED" if self.shared else "RESIDENT"))
+        bad = st.value
+        if collective and self.s.comm is not None and self.s.comm.size > 1:
+            bad = int(self.s.comm.group.reduce_scalar(float(bad), "max"))
+        if bad != 0:
+            raise _lib.NaimaHipError(
+                "the resident half-step loop timed out waiting for a walker's record (status "
+                "%d%s): its workgroups were not all resident%s.  Run with NAIMA_AMD_%s=0"
+                % (bad, "" if bad == st.value else ", on another rank",
+                   ", or a rank of the shared ensemble fell behind or failed"
+                   if self.shared else "", "SHARED" if self.shared else "RESIDENT"))
 
     def _run_half_step_merged(self):
         ctx = self.ctx
@@ -1185,8 +1257,8 @@ class DeviceLoop:
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""
         self._flush_pending()
-        self.check_resident()
-        self.check_nan()
+        self.check_resident(collective=True)
+        self.check_nan(collective=True)
         self.ctx.check_general()  # (a per-walker grid longer than the general kernel's LDS)
         self._sync_cur_blobs()
         s = self.s

@@ -80,6 +80,10 @@ class EnsembleSampler:
             raise ValueError("nan_policy must be 'raise' or 'reject'")
         self.nan_policy = nan_policy
         self.nan_proposals = 0
+        # proposals the prior forbade (-inf): the device loop evaluates none of their integrals
+        # (the reference evaluates the model and discards it, core.py:103-119); counted for the
+        # bench line, which credits them as walker-steps like every other proposal
+        self.prior_forbidden_proposals = 0
         # device=True: ensemble, proposals, log-probabilities and blobs live in HBM; the
         # launch sequence of one half-step (propose -> model -> likelihood -> accept)
         # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)

@@ -211,14 +211,27 @@ def test_vectors(name, n=8, spread=0.03):
 
 
 def prior_for(name, ns):
-    """Uniform priors in the spirit of examples/RXJ1713_SynIC.py:52-65."""
-    if name == "cfg3":
-        def lnprior(pars):
-            return (ns.uniform_prior(pars[0], 0.0, np.inf)
-                    + ns.uniform_prior(pars[1], -1, 5)
-                    + ns.uniform_prior(pars[3], 0, np.inf)
-                    + ns.uniform_prior(pars[4], 0.1, 5))
-        return lnprior
-    if name in ("cfg1", "cfg2"):
-        return lambda pars: ns.uniform_prior(pars[0], 0.0, np.inf)
+    """Uniform priors in the spirit of examples/RXJ1713_SynIC.py:52-65 (amplitude and B positive,
+    index within (-1, 5)), completed with physical bounds on the logarithmic parameters: the
+    likelihood has a plateau where the model flux is zero (a cut-off far below the grid), a
+    walker of naima's 10 % ball that lands there wanders, and ``10 ** pars[k]`` of a wandered
+    coordinate overflows -- a NaN log-probability, where emcee stops the run
+    (``ValueError: Probability function returned NaN``), or a zero cut-off energy, where the
+    reference's own validator does.  cfg1 keeps the prior of its reference script
+    (examples/RXJ1713_IC_minimal.py:28-31: its amplitude is linear)."""
+    U = ns.uniform_prior
+    if name == "cfg1":
+        return lambda pars: U(pars[0], 0.0, np.inf)
+    if name == "cfg2":   # log10(norm), index, log10(cutoff / TeV), B / uG
+        return lambda pars: (U(pars[0], 0.0, 100.0) + U(pars[1], -1, 5) + U(pars[2], -3, 5)
+                             + U(pars[3], 0, np.inf))
+    if name == "cfg3":   # ... + beta
+        return lambda pars: (U(pars[0], 0.0, 100.0) + U(pars[1], -1, 5) + U(pars[2], -3, 5)
+                             + U(pars[3], 0, np.inf) + U(pars[4], 0.1, 5))
+    if name == "cfg4":   # log10(norm), log10(break / TeV), index1, index2, log10(cutoff / TeV), B / uG
+        return lambda pars: (U(pars[0], 0.0, 100.0) + U(pars[1], -4, 4) + U(pars[2], -1, 6)
+                             + U(pars[3], -1, 6) + U(pars[4], -1, 6) + U(pars[5], 0, np.inf))
+    if name == "cfg5":   # log10(norm), log10(break / TeV), index1, index2, log10(cutoff / TeV)
+        return lambda pars: (U(pars[0], 0.0, 100.0) + U(pars[1], -3, 4) + U(pars[2], -1, 6)
+                             + U(pars[3], -1, 6) + U(pars[4], -2, 6))
     return None

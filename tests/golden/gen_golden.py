@@ -102,6 +102,13 @@ def gen_cfg(name, nvec, variant=None):
         lnprior.append(0.0 if prior is None else float(prior(p)))
     out = dict(pars=pars, flux=np.array(flux), blob=np.array(blob), lnprob=np.array(lnp),
                lnprior=np.array(lnprior))
+    # the prior alone (core.py:34-41 through the workload's lnprior), on vectors scattered far
+    # enough around p0 that most of them violate one bound or another
+    rng = np.random.default_rng(W.SEED + 500 + int(name[-1]))
+    wide = p0 * (1 + rng.standard_normal((48, p0.size)) * np.array([0.5, 1.0, 2.0])[rng.integers(3, size=48)][:, None])
+    wide[:3] = pars[:3]
+    out["prior_pars"] = wide
+    out["prior_lnprior"] = np.array([0.0 if prior is None else float(prior(p)) for p in wide])
     for k, v in raw.items():
         out["data_" + k] = np.asarray(v)
     return out, model, data, pars

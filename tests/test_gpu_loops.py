@@ -88,6 +88,35 @@ def test_device_loop_equals_host_loop(na, cfg, store_blobs):
         assert bd is None
 
 
+def test_cfg4_at_its_baseline_ensemble_size(na):
+    """BASELINE's CrabNebula Syn+SSC configuration at its full ensemble, 1024 walkers (512
+    proposals per half-step: the SSC seed kernel's walker groups, the table reductions and the
+    likelihood at four times the size the other loop tests use): device loop == host-driven
+    loop, chain, log-probability and acceptance.  From a 2 % ball: in naima's 10 % ball some
+    proposal has a negative magnetic field within a few steps -- the prior forbids it, but the
+    reference evaluates the model before it looks at the prior (core.py:103-119), the model
+    function's own validation refuses the NaN photon density ("SSC-density value is NaN or Inf",
+    extern/validator.py) and the host-driven run ends there, as the reference's would."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg4", {})
+    nw, nd = 1024, p0.size
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=False)
+    pos = p0 + 0.02 * p0 * np.random.default_rng(BENCH_SEED).normal(size=(nw, nd))
+    h = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    with np.errstate(all="ignore"):
+        sh, sd = h.run_mcmc(pos, 2), d.run_mcmc(pos, 2)
+        sh, sd = h.run_mcmc(sh, 6), d.run_mcmc(sd, 6)
+    assert d._dev is not None and d.device
+    assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
+    lh, ld = h.get_log_prob(), d.get_log_prob()
+    assert np.array_equal(np.isinf(ld), np.isinf(lh))
+    fin = np.isfinite(lh)
+    assert_allclose(ld[fin], lh[fin], rtol=1e-6)
+    assert_allclose(d.acceptance_fraction, h.acceptance_fraction)
+    assert d.nan_proposals == 0 and h.nan_proposals == 0
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_device_loop_equals_oracle_driven_sampler(na, cfg):
     """>= 4 ensemble steps of the device loop against oracle.stretch_move_reference fed with
@@ -253,24 +282,33 @@ def test_split_launch_of_the_table_only_instance(na, monkeypatch):
 BENCH_SEED = 20260929
 
 # hand-placed start positions, as factors on p0 (None: keep the ball's value)
-#   cfg3 priors (workloads.prior_for): p0 >= 0, -1 <= p1 <= 5, p3 = B >= 0, 0.1 <= p4 <= 5
+#   priors (workloads.prior_for): 0 <= log10 norm <= 100, -1 <= index <= 5, -3 <= log10 cut-off <= 5,
+#   B >= 0, 0.1 <= beta <= 5 (cfg3); cfg5: -3 <= log10 break <= 4, indices within (-1, 6) ...
 HAND = {
     "cfg3": [("norm below its prior", 0, -0.03), ("index above its prior", 1, 2.4),
              ("index below its prior", 1, -0.8), ("negative B (below its prior)", 3, -0.4),
              ("beta below its prior", 4, 0.05), ("beta above its prior", 4, 6.0),
-             ("cut-off 10 keV: every weight underflows", 2, -8.0 / np.log10(48.0))],
-    #   cfg2 prior: p0 >= 0 only; cfg5: none.  No zero-weight walker for these two: a walker on
-    #   the zero-flux plateau has the same likelihood wherever it goes, nothing but a prior holds
-    #   it, and within ~15 steps the stretch move walks it to |log10(cut-off)| > 308 -- 10**x is
-    #   then inf, which the reference refuses ("e_cutoff value is NaN or Inf",
-    #   extern/validator.py) and emcee passes on: the reference's run dies there, the host-driven
-    #   loop here raises the same error.  cfg3's priors keep its plateau walker in range.
-    "cfg2": [("norm below its prior", 0, -0.03)],
-    "cfg5": [],
+             ("cut-off 10 keV: every weight underflows (below the bench prior)", 2, -8.0 / np.log10(48.0))],
+    "cfg2": [("norm below its prior", 0, -0.03), ("negative B (below its prior)", 3, -0.4),
+             ("cut-off below its prior", 2, -8.0 / np.log10(48.0)), ("index above its prior", 1, 2.4)],
+    "cfg5": [("first index above its prior", 2, 4.0), ("break below its prior", 1, -20.0),
+             ("cut-off above its prior", 4, 3.5)],
 }
 # (The cut-off sits five decades below the particle grids -- exp(-(E/E_c)^beta) underflows at
 # every node -- but not absurdly far: a stretch move that uses such a walker as the partner
 # lands at 10^(+11) TeV, still a number.)
+
+
+def _loose_prior(na, name):
+    """round 3's priors (cfg3: examples/RXJ1713_SynIC.py:52-65 + beta; cfg2: the amplitude only):
+    without a bound on log10(cut-off) a walker can sit on the zero-flux plateau -- every particle
+    weight an exact zero, the kernel's skipped-items short-cut -- and, for cfg2, propose a
+    negative magnetic field (a NaN log-probability).  The benchmark's priors forbid both."""
+    U = na.uniform_prior
+    if name == "cfg3":
+        return lambda pars: (U(pars[0], 0.0, np.inf) + U(pars[1], -1, 5) + U(pars[3], 0, np.inf)
+                             + U(pars[4], 0.1, 5))
+    return lambda pars: U(pars[0], 0.0, np.inf)
 
 
 def _bench_ball(name, p0, nw):
@@ -330,21 +368,24 @@ def _count_shortcuts(na, model, prior, data, props):
     return int(dead.sum()), int((zero & ~dead).sum())
 
 
-@pytest.mark.parametrize("name,nw", [("cfg3", 512), ("cfg2", 256), ("cfg5", 256)],
-                         ids=["cfg3-512", "cfg2-256", "cfg5-256"])
-def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw):
+@pytest.mark.parametrize("name,nw,loose", [("cfg3", 512, False), ("cfg3", 512, True), ("cfg2", 256, False),
+                                           ("cfg5", 256, False)],
+                         ids=["cfg3-512", "cfg3-512-round-3-prior", "cfg2-256", "cfg5-256"])
+def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw, loose):
     """>= 64 steps with the blobs kept, from bench.py's initial ensemble and the hand-placed
     degenerate walkers: chain, log-probability, blobs and acceptance of the device loop are
     the host-driven loop's (which evaluates every proposal in full with the separate,
     golden-pinned kernels and discards what the prior forbids, as core.py:103-119 does)"""
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior = _problem(na, name, {})
+    if loose:
+        prior = _loose_prior(na, name)
     nd = p0.size
-    # (cfg2 and cfg5 have next to no prior: walkers the ball throws far off wander on, and within
-    # ~30 steps one of them proposes parameters for which the reference's own arithmetic gives a
-    # NaN log-probability -- the oracle agrees -- where emcee raises ValueError and the run is
-    # over, here as there (test_nan_log_probability_is_emcees_error).  To compare all 70 steps
-    # both loops run with nan_policy="reject": such a proposal is never accepted, and counted.)
+    # (under round 3's priors walkers the ball throws far off wander on, and within ~30 steps one
+    # of them proposes parameters for which the reference's own arithmetic gives a NaN
+    # log-probability -- the oracle agrees -- where emcee raises ValueError and the run is over,
+    # here as there (test_nan_log_probability_is_emcees_error).  To compare all 70 steps both
+    # loops run with nan_policy="reject": such a proposal is never accepted, and counted.)
     kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True,
               nan_policy="reject")
     pos = _bench_ball(name, p0, nw)
@@ -402,31 +443,50 @@ def test_device_loop_equals_host_loop_from_the_benchmarks_ball(na, name, nw):
              int(np.isinf(lh[-1]).sum()), h.nan_proposals, d.nan_proposals))
     if died is None:
         assert d.nan_proposals == h.nan_proposals
-    if prior is not None:
-        assert ndead > 0, "no proposal was forbidden by the prior: HI_DEAD not exercised"
-    if name == "cfg3":
+    assert ndead > 0, "no proposal was forbidden by the prior: HI_DEAD not exercised"
+    # (the kernels' own count of them: the run's first two half-steps go piece by piece, uncounted)
+    assert 0.9 * ndead <= d.prior_forbidden_proposals <= ndead
+    if loose:
         assert nzero > 0, "no proposal had a grid of zero weights: that short-cut not exercised"
+    else:
+        # the benchmark's priors keep every walker off the plateau and out of the NaN region
+        assert d.nan_proposals == 0 and died is None
 
 
-def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na):
-    """cfg3 at 512 walkers -- 256 per launch: the ONE-workgroup-per-walker instance that
-    produces the headline figure -- from bench.py's ball plus the degenerate walkers, two
-    ensemble steps against oracle.stretch_move_reference with the NumPy oracle's lnprob"""
+@pytest.mark.parametrize("name,nw,mkw", [("cfg3", 512, {}), ("cfg1", 32, {}), ("cfg5", 256, {}),
+                                         ("cfg2", 256, {})],
+                         ids=["cfg3-512", "cfg1-32", "cfg5-256", "cfg2-256-two-per-walker"])
+def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na, name, nw, mkw):
+    """The kernels that produce the bench numbers, DIRECTLY against the oracle: every BASELINE
+    workload the resident loop runs, at bench.py's walker count -- cfg3 at 512 walkers is 256
+    per launch, the one-workgroup-per-walker instance of the headline, on its own sorted copies
+    of the inverse-Compton tables and with the synchrotron integrand in the log domain -- from
+    bench.py's ball plus the degenerate walkers, against oracle.stretch_move_reference with the
+    NumPy oracle's lnprob.  The second call runs as a launch of the resident loop (asserted)."""
     import warnings
     from naima_amd.sampler import EnsembleSampler
     from oracle import naima_np as O
     from oracle import workloads_np as WN
-    name, nw, nsteps = "cfg3", 512, 2
-    model, p0, raw, data, prior = _problem(na, name, {})
+    nsteps = 2
+    model, p0, raw, data, prior = _problem(na, name, mkw)
     nd = p0.size
     s = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=BENCH_SEED,
                         naima_style=True, store_blobs=True, device=True)
-    start = _bench_ball(name, p0, nw)
+    start = _bench_ball(name, p0, nw) if name in HAND else \
+        p0 + 0.1 * p0 * np.random.default_rng(BENCH_SEED).normal(size=(nw, nd))
     with np.errstate(all="ignore"):
         st = s.run_mcmc(start, nsteps)
         st = s.run_mcmc(st, nsteps)  # (the first call's half-steps settle and record the plan)
     dev = s._dev
-    assert dev is not None and dev.mega and dev._plan["hs"]["split"] == 1
+    assert dev is not None and dev.mega
+    assert dev.resident_launches > 0, getattr(dev, "resident_reason", "")
+    if name == "cfg3":
+        assert dev._plan["hs"]["split"] == 1 and dev._plan["hs"].get("sorted")
+        assert dev.resident_info["syn_log_domain"]
+    if name == "cfg1":
+        assert dev._plan["hs"].get("sorted")
+    if name == "cfg2":
+        assert dev._plan["hs"]["split"] == 2 and dev.resident_info["syn_log_domain"]
 
     def oprior(q):
         return float(np.asarray(prior(q)))
@@ -434,11 +494,12 @@ def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na):
     def lnp(x):
         with warnings.catch_warnings(), np.errstate(all="ignore"):
             warnings.simplefilter("ignore")
-            return np.array([WN.lnprob(name, p, raw, prior=oprior)[0] for p in np.atleast_2d(x)])
+            return np.array([WN.lnprob(name, p, raw, prior=oprior, **mkw)[0] for p in np.atleast_2d(x)])
 
     S, P, Z, L = _move_stream(BENCH_SEED, nw, (nsteps, nsteps))
     c, l = start.copy(), lnp(start)
-    assert np.isinf(l).sum() >= 6 and np.isfinite(l).sum() >= nw - 8
+    if name in HAND:
+        assert np.isinf(l).sum() >= len(HAND[name]) - 1 and np.isfinite(l).sum() >= nw - 8
     chain = []
     for k in range(2 * nsteps):
         c, l, _ = O.stretch_move_reference(c, l, lnp, S[k], P[k], Z[k], L[k])
@@ -610,12 +671,16 @@ def test_nan_log_probability_is_emcees_error(na):
     function returned NaN") (EnsembleSampler.compute_log_prob; the reference just lets it
     through, core.py:128): the host-driven loop raises on the spot, the device loop -- whose
     launches cannot -- when the run's results next reach the host.  cfg2 from the benchmark's
-    ball meets its first such proposal (a negative magnetic field the prior does not forbid)
-    within ~30 steps."""
+    ball under round 3's prior (the amplitude only) meets its first such proposal -- a negative
+    magnetic field -- within ~30 steps."""
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior = _problem(na, "cfg2", {})
+    prior = _loose_prior(na, "cfg2")  # (the benchmark's prior forbids B < 0)
     nw, nd = 256, p0.size
-    pos = _bench_ball("cfg2", p0, nw)
+    rng = np.random.default_rng(BENCH_SEED)
+    pos = p0 + 0.1 * p0 * rng.normal(size=(nw, nd))
+    pos[0] = p0
+    pos[0, 0] = -0.03 * p0[0]
     kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=False)
     h = EnsembleSampler(nw, nd, na.lnprob, **kw)
     with pytest.raises(ValueError, match="returned NaN"), np.errstate(all="ignore"):
@@ -630,28 +695,43 @@ def test_nan_log_probability_is_emcees_error(na):
 def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
     """every wait of the resident loop is bounded: with a poll limit of ONE (NH_RUN_SPIN_LIMIT=1)
     the first walker whose record is not there yet makes its workgroup latch an error and leave,
-    every other workgroup follows, the launch ends, and the sampler raises when the results
-    reach the host -- the device is not left spinning"""
-    from naima_amd._lib import NaimaHipError
+    every other workgroup follows, the launch ends -- the device is not left spinning -- and its
+    epilogue leaves the ensemble, the counters and the move stream as they were.  The loop's
+    first launches are checked as they are made: the sampler warns once, replays the block of
+    moves with the per-launch kernel and stays with it -- the chain is the per-launch loop's."""
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior = _problem(na, "cfg3", {})
     nw, nd = 512, p0.size
     pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
+    kw = dict(args=[data, model, prior], seed=5, naima_style=True, store_blobs=True, device=True)
+    monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0")
+    ref = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    st = ref.run_mcmc(pos, 4)
+    st = ref.run_mcmc(st, 40)
+    assert ref._dev.resident_launches == 0
+    monkeypatch.delenv("NAIMA_AMD_RESIDENT")
     monkeypatch.setenv("NH_RUN_SPIN_LIMIT", "1")
-    d = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
-                        store_blobs=False, device=True)
+    d = EnsembleSampler(nw, nd, na.lnprob, **kw)
     st = d.run_mcmc(pos, 4)
-    with pytest.raises(NaimaHipError, match="timed out"):
+    with pytest.warns(UserWarning, match="gave up waiting"):
         st = d.run_mcmc(st, 40)
-        st.coords
-    assert d._dev.resident_launches > 0
-    # the context is still usable: a fresh sampler with the default limit runs
+    assert d._dev.resident_failed_launches == 1 and d._dev.resident_launches == 0
+    assert np.array_equal(d.get_chain(), ref.get_chain())
+    assert np.array_equal(d.get_log_prob(), ref.get_log_prob())
+    for x, y in zip(d.get_blobs(), ref.get_blobs()):
+        assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
+    assert_allclose(d.acceptance_fraction, ref.acceptance_fraction)
+    assert d.nan_proposals == ref.nan_proposals
+    assert d.prior_forbidden_proposals == ref.prior_forbidden_proposals
+    st = d.run_mcmc(st, 10, store=False)  # (and it carries on)
+    # the context is still usable: a fresh sampler with the default limit runs resident
     monkeypatch.delenv("NH_RUN_SPIN_LIMIT")
     d2 = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=5, naima_style=True,
                          store_blobs=False, device=True)
     st = d2.run_mcmc(pos, 4)
     st = d2.run_mcmc(st, 40)
     assert np.all(np.isfinite(st.coords)) and d2._dev.resident_launches > 0
+    assert np.array_equal(d2.get_chain(), ref.get_chain())
 
 
 def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):

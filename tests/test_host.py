@@ -92,6 +92,30 @@ def test_priors_vectorised():
                     [0.5, -np.inf, -np.inf])
 
 
+def test_workload_priors_against_the_reference(golden):
+    """workloads.prior_for -- uniform priors in the spirit of examples/RXJ1713_SynIC.py:52-65 with
+    physical bounds on the logarithmic parameters -- evaluated through this package's
+    uniform_prior, one walker at a time and vectorised, against the same function evaluated
+    through the reference's (core.py:34-41) on 48 scattered vectors per workload (gen_golden.py);
+    and p0 with naima's 10 % ball around it lies inside every bound"""
+    import naima_amd as na
+    from naima_amd import workloads as W
+    for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+        z = golden(name)
+        prior = W.prior_for(name, na)
+        assert prior is not None
+        pars, want = z["prior_pars"], z["prior_lnprior"]
+        assert np.isinf(want).sum() >= 8 and (want == 0).sum() >= 3
+        got = np.array([float(prior(p)) for p in pars])
+        assert np.array_equal(got, want), name
+        assert np.array_equal(np.asarray(prior(pars.T), dtype=float), want), name
+        p0 = np.asarray(W.WORKLOADS[name]["p0"], dtype=float)
+        ball = p0 + 0.1 * p0 * np.random.default_rng(0).normal(size=(4096, p0.size))
+        inside = np.asarray(prior(ball.T), dtype=float) == 0
+        # (cfg1's amplitude is linear, cfg3's beta starts 2 sigma... every workload keeps > 95 %)
+        assert inside.mean() > 0.95, (name, inside.mean())
+
+
 def test_abi_exports_every_declared_symbol():
     """the library loads on a GPU-less box and exports include/naima_hip.h"""
     import __graft_entry__ as g
