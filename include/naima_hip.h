@@ -443,6 +443,16 @@ int nh_general_electron_seed(nh_ctx* ctx, int kind, const double* rows /*[N][NH_
                              const double* seed_dens /*device*/, int ns,
                              const double* E_eV /*device*/, int nE, double* out, int ldo, int nmax,
                              int* status);
+/* The same with a photon density PER WALKER, seed_dens[w * seed_ld + s] (seed_ld >= ns): a
+ * synchrotron-self-Compton seed -- each walker's own synchrotron photons,
+ * examples/CrabNebula_SynSSC.py:29-45 -- combined with Eemin / Eemax / nEed per walker
+ * (InverseCompton takes any keyword per call, radiative.py:430; inner integral :609-655). */
+int nh_general_electron_seed_rows(nh_ctx* ctx, int kind, const double* rows, int N,
+                                  const nh_lazy* Eemin, double Eemin_unit_erg, const nh_lazy* Eemax,
+                                  double Eemax_unit_erg, const nh_lazy* nEed, const double* seed_E,
+                                  const double* seed_dens, long long seed_ld, int ns,
+                                  const double* E_eV, int nE, double* out, int ldo, int nmax,
+                                  int* status);
 
 /* The same for protons: Epmin / Epmax / nEpd per walker (radiative.py:1002-1055, 1495-1536).
  * Walker w integrates over Ep = logspace(log10 Epmin_w, log10 Epmax_w, max(10, int(nEpd_w *

@@ -133,6 +133,8 @@ _SIGS = {
                             _dp, _i, _i, _dp],
     "nh_general_electron_seed": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _dp, _dp, _i, _dp, _i, _dp,
                                  _i, _i, _dp],
+    "nh_general_electron_seed_rows": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _dp, _dp, _ll, _i, _dp,
+                                      _i, _dp, _i, _i, _dp],
     "nh_general_proton": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _i, _i, _i, _i, _dp, _i, _dp, _i,
                           _dp, _dp, _i, _dp, _i, _i, _dp],
     "nh_table_interleave": [_dp, _dp, _dp, _dp, _i, _i, _dp],

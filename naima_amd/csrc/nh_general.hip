@@ -32,6 +32,7 @@ struct gen_args {
   double* out; int ldo;  // out[w*ldo + c*nE + k]
   int nmax;              // LDS capacity in nodes
   const double* seed_E; const double* seed_d; int ns;  // what = 4: a monochromatic / tabulated seed
+  long long seed_ld;     // 0: every walker has the same densities; else walker w's are seed_d + w seed_ld (SSC)
   int* status;           // [0]: the largest node count asked for when it exceeds nmax;
                          // [1]: evaluations whose node count sat on an int() boundary
 };
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void k_general_electron(gen_args A) {
       if (k < A.nE && s0 < s1) {
         const double eg = A.E_eV[k] / NH_MEC2_EV;
         auto Ks = [&](double g) {
-          return ic_seed_inner(A.seed_E, A.seed_d, A.ns, g, eg) *
+          return ic_seed_inner(A.seed_E, A.seed_d + (long long)wi * A.seed_ld, A.ns, g, eg) *
                  ((3.0 / 4.0) * NH_SIGT_LIT * NH_C_CGS / (g * g));  // radiative.py:650-653
         };
         double K1 = Ks(gam[s0]);
@@ -249,7 +250,7 @@ static int general_electron(nh_ctx* c, int kind, const double* rows, int N,
                             const nh_lazy* seed_T, const nh_lazy* seed_theta, int nseed,
                             const double* seed_E, const double* seed_d, int ns,
                             const double* E_eV, int nE, double* out, int ldo, int nmax,
-                            int* status) {
+                            int* status, long long seed_ld = 0) {
   NH_REQUIRE(c && rows && Eemin && Eemax && nEed && out && status, "NULL pointer");
   NH_REQUIRE(kind >= NH_PD_POWERLAW && kind <= NH_PD_LOGPARABOLA, "unknown particle distribution kind");
   NH_REQUIRE(N >= 0 && nmax >= 10 && Eemin_unit_erg > 0 && Eemax_unit_erg > 0, "bad sizes");
@@ -275,7 +276,7 @@ static int general_electron(nh_ctx* c, int kind, const double* rows, int N,
     A.theta[s] = seed_theta[s];
   }
   A.E_eV = E_eV; A.nE = nE; A.out = out; A.ldo = ldo; A.nmax = nmax; A.status = status;
-  A.seed_E = seed_E; A.seed_d = seed_d; A.ns = ns;
+  A.seed_E = seed_E; A.seed_d = seed_d; A.ns = ns; A.seed_ld = seed_ld;
   const size_t lds = ((size_t)4 * nmax + 256) * sizeof(double);
   NH_REQUIRE(lds <= 150 * 1024, "nmax does not fit in LDS (at most ~4700 nodes)");
   if (lds > 64 * 1024)
@@ -313,6 +314,23 @@ extern "C" int nh_general_electron_seed(nh_ctx* c, int kind, const double* rows,
   return general_electron(c, kind, rows, N, Eemin, Eemin_unit_erg, Eemax, Eemax_unit_erg, nEed, 4,
                           nullptr, nullptr, nullptr, 0, seed_E, seed_dens, ns, E_eV, nE, out, ldo,
                           nmax, status);
+}
+
+// ... and the same with a photon density PER WALKER (seed_dens[w * seed_ld + s], seed_ld >= ns):
+// the synchrotron-self-Compton seed of examples/CrabNebula_SynSSC.py:29-45 -- each walker's own
+// synchrotron photons -- over each walker's own grid (InverseCompton takes any keyword per call,
+// radiative.py:430; the inner integral is radiative.py:609-655)
+extern "C" int nh_general_electron_seed_rows(nh_ctx* c, int kind, const double* rows, int N,
+                                             const nh_lazy* Eemin, double Eemin_unit_erg,
+                                             const nh_lazy* Eemax, double Eemax_unit_erg,
+                                             const nh_lazy* nEed, const double* seed_E,
+                                             const double* seed_dens, long long seed_ld, int ns,
+                                             const double* E_eV, int nE, double* out, int ldo,
+                                             int nmax, int* status) {
+  NH_REQUIRE(seed_ld >= ns && ns >= 1, "seed_ld must be at least the number of seed energies");
+  return general_electron(c, kind, rows, N, Eemin, Eemin_unit_erg, Eemax, Eemax_unit_erg, nEed, 4,
+                          nullptr, nullptr, nullptr, 0, seed_E, seed_dens, ns, E_eV, nE, out, ldo,
+                          nmax, status, seed_ld);
 }
 
 

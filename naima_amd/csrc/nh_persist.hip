@@ -89,7 +89,8 @@ struct hs_run {
   // workgroups that share a walker; one resident workgroup per walker runs fastest on items
   // three times that long (cfg3, us per 40 half-steps: 1 015 at 10, 981 at 16, 975 at 24, 959
   // at 30 and at 40; two workgroups per walker -- cfg2 -- 901 at 5, 885 at 10, 914 at 16)
-  int syn_nodes, pad_;
+  int syn_nodes;
+  int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
   // (peer[rank] == ring); a mover stores its walker's record into every one of them
@@ -756,6 +757,10 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             is_tab = nT - F0 > nS;
             ix = is_tab ? item - nS : item - nT;
           }
+          if (R.dbg_skip && (is_tab ? (R.dbg_skip & 2) : (R.dbg_skip & 1))) {
+            if (is_tab) part_t[ix * 64 + lane] = 0.0;
+            continue;
+          }
           if (is_tab) {
             int t = 0;
             while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
@@ -1301,6 +1306,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = 32;
   if (P->split == 2 && R.syn_nodes < 10) R.syn_nodes = 10;  // (cfg2: 901 -> 885 us; 914 at 16)
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
+  R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");

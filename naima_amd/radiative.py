@@ -428,7 +428,8 @@ class BaseElectron(BaseRadiative):
             return False
         return super()._needs_walker_loop()
 
-    def _general_launch(self, what, E_eV, B=None, seeds=(), Eemin=None, Eemax=None, seed_arrays=None):
+    def _general_launch(self, what, E_eV, B=None, seeds=(), Eemin=None, Eemax=None, seed_arrays=None,
+                        seed_rows=False):
         """spectra [N][ncomp * nE] of nh_general_electron (device buffer); what = 2: We over
         each walker's grid between Eemin and Eemax (default: the object's own limits), [N][1];
         what = 4: InverseCompton on the shared monochromatic / tabulated seed
@@ -484,7 +485,20 @@ class BaseElectron(BaseRadiative):
             else:
                 th[j], k = lazy_of(thq, "rad")
                 keep.append(k)
-        if what == 4:
+        if what == 4 and seed_rows:
+            se, sd = seed_arrays
+            if isinstance(sd, DMat):
+                sd_buf, sd_ptr = sd.buffer()
+            else:
+                sd_buf = ctx.array(np.ascontiguousarray(np.broadcast_to(np.asarray(sd, dtype=float),
+                                                                        (N, se.size))))
+                sd_ptr = sd_buf.ptr
+            ctx.call("nh_general_electron_seed_rows", PD_KIND[pd.kind], rows, N, C.addressof(emin),
+                     float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
+                     C.addressof(ned), ctx.const(se), sd_ptr, int(se.size), int(se.size),
+                     ctx.const(E_eV), nE, out, nE, ctx.general_nmax, status)
+            keep.append(sd_buf)
+        elif what == 4:
             se, sd = seed_arrays
             ctx.call("nh_general_electron_seed", PD_KIND[pd.kind], rows, N, C.addressof(emin),
                      float(_erg_factor(qmin)), C.addressof(emax), float(_erg_factor(qmax)),
@@ -687,11 +701,10 @@ class InverseCompton(BaseElectron):
 
     def _general_supported(self):
         """the general path on the device: thermal seed fields (their temperature, angle and
-        energy density may all be per walker) and monochromatic / tabulated seeds that every
-        walker shares (a photon density per walker -- SSC -- still goes one walker at a time
-        when the grids differ too)"""
-        return all(seed["type"] == "thermal" or not self._seed_per_walker(seed)
-                   for seed in self.seed_photon_fields.values())
+        energy density may all be per walker), monochromatic / tabulated seeds that every walker
+        shares, and tabulated seeds with a photon density per walker (SSC:
+        nh_general_electron_seed_rows)"""
+        return True
 
     def _seed_shape_per_walker(self):
         """a thermal seed whose temperature or angle is given per walker: its Khangulyan kernel
@@ -722,11 +735,19 @@ class InverseCompton(BaseElectron):
             if seed["type"] == "thermal":
                 continue
             se = np.atleast_1d(seed["energy"].to("eV").value).astype(float)
-            if se.size == 1:
-                sdv = np.atleast_1d(seed["photon_density"].to("eV/cm3").value).astype(float)
+            if self._seed_per_walker(seed):
+                # a photon density per walker (SSC: each walker's own synchrotron photons,
+                # examples/CrabNebula_SynSSC.py:29-45) over each walker's own grid: rows
+                # [N][ns] on the device, a host array or the lazy device expression the
+                # model function built from SYN.flux(...)
+                sdv = seed["photon_density"].to("1/(eV cm3)").value
+                ctx, N, o1 = self._general_launch(4, E_eV, seed_arrays=(se, sdv), seed_rows=True)
             else:
-                sdv = np.asarray(seed["photon_density"].to("1/(eV cm3)").value, dtype=float)
-            ctx, N, o1 = self._general_launch(4, E_eV, seed_arrays=(se, sdv))
+                if se.size == 1:
+                    sdv = np.atleast_1d(seed["photon_density"].to("eV/cm3").value).astype(float)
+                else:
+                    sdv = np.asarray(seed["photon_density"].to("1/(eV cm3)").value, dtype=float)
+                ctx, N, o1 = self._general_launch(4, E_eV, seed_arrays=(se, sdv))
             colfac = Eph / E_eV  # radiative.py:684-687 (uf = 1)
             byname[n] = (DMat.from_buffer(ctx, o1, N, nE) * colfac) if dev else o1.get() * colfac
         seeds = []

@@ -1,6 +1,6 @@
 """gpurun_out/<tag>prof (scripts/gpu_profile.sh on the GPU box) -> profiles/<tag>_* (tracked)
 
-    python scripts/collect_profiles.py [tag, default r03]
+    python scripts/collect_profiles.py [tag, default r04]
 """
 import glob
 import json
@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S, D = os.path.join(R, "gpurun_out", TAG + "prof"), os.path.join(R, "profiles")
 COPY = {"bench_n1_default.json": "bench_n1_default.json",
@@ -31,7 +31,7 @@ for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
     COPY["%s_stats_bench.json" % w] = "%s_bench_under_rocprof.json" % w
     if w != "cfg3":
         COPY["bench_%s.json" % w] = "bench_%s.json" % w
-for w in ("cfg3", "cfg5"):
+for w in ("cfg3", "cfg5", "cfg2", "cfg4"):
     COPY["%s_counters_per_launch.json" % w] = "%s_counters_per_launch.json" % w
 for a, b in COPY.items():
     src = os.path.join(S, a)

@@ -4,7 +4,7 @@
 #   bash scripts/gpu_profile.sh [round tag, default r03]   ->   gpurun_out/<tag>prof/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}prof
 rm -rf $O; mkdir -p $O
 DRV="bench.py --steps 20 --warmup 5"
@@ -28,10 +28,13 @@ for w in cfg3 cfg5; do
   prof ${w}_sqc --kernel-trace --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU
   prof ${w}_sqd --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
 done
+# (vector-pipe utilisation of the other two workloads' dominant kernels: one SQ pass each)
+CMD="$DRV --workload cfg2 --no-cpu --no-blobs-run --min-time 0.1"; prof cfg2_sqa --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
+CMD="bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run --min-time 0.1"; prof cfg4_sqa --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
 python - <<PY
 import csv, collections, glob, json, os
 O = "$O"
-for w in ("cfg3", "cfg5"):
+for w in ("cfg3", "cfg5", "cfg2", "cfg4"):
     res = {}
     for f in sorted(glob.glob(O + '/%s_*_counter_collection.csv' % w)):
         rows = list(csv.DictReader(open(f)))
@@ -45,7 +48,7 @@ for w in ("cfg3", "cfg5"):
                 res[k]["launches_" + c] = n[k][c]
     json.dump(res, open(O + '/%s_counters_per_launch.json' % w, 'w'), indent=1)
     for k, v in res.items():
-        if 'half_step' in k:
+        if 'half_step' in k or 'ic_seed' in k:
             print(w, k, json.dumps({c: round(x, 1) for c, x in v.items() if not c.startswith("launches")}))
 PY
 # 3. un-profiled bench lines

@@ -734,3 +734,71 @@ def test_general_inverse_compton_on_shared_non_thermal_seeds(na):
         assert_allclose(f[i], tot, rtol=1e-9, atol=tot.max() * 1e-200)
         for j in range(4):
             assert_allclose(per[j][i], each[j], rtol=1e-9, atol=tot.max() * 1e-200)
+
+
+def test_general_inverse_compton_with_a_seed_density_per_walker(na):
+    """InverseCompton with Eemin / Eemax per walker AND a tabulated seed whose photon density is
+    given per walker -- the synchrotron-self-Compton seed of examples/CrabNebula_SynSSC.py:29-45,
+    each walker's own synchrotron photons -- beside a thermal and a shared tabulated seed
+    (InverseCompton takes any keyword per call, radiative.py:430; inner integral :609-655): the
+    whole batch in launches of the general kernel (nh_general_electron_seed_rows), nothing one
+    walker at a time; against the oracle on each walker's grid and density, total and per seed.
+    The same through the model function of a device loop: Synchrotron.flux at Esy as a device
+    expression feeds the seed (host loop == device loop)."""
+    from oracle import naima_np as O
+    u = na.u
+    rng = np.random.default_rng(23)
+    N = 17
+    amp = 10 ** rng.normal(34, 0.2, N)
+    alpha = rng.uniform(1.9, 2.8, N)
+    ecut = rng.uniform(10, 150, N)
+    emin = 10 ** rng.uniform(-1, 2, N)       # GeV
+    emax = 10 ** rng.uniform(4.2, 5.8, N)    # GeV
+    arr_E = np.geomspace(1e-3, 30.0, 23)     # eV
+    arr_n = 5e2 * arr_E ** -1.4 * np.exp(-arr_E / 8.0)  # 1/(eV cm3)
+    ssc_E = np.geomspace(1e-6, 1e4, 40)      # eV
+    ssc_n = (10 ** rng.uniform(-2, 2, N))[:, None] * ssc_E[None, :] ** -rng.uniform(1.2, 1.9, N)[:, None] \
+        * np.exp(-ssc_E[None, :] / 10 ** rng.uniform(1, 3.5, N)[:, None])
+    ssc_n[3, :5] = 0.0                       # (zero-density seed nodes: utils.py:347-348)
+    pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, ecut * u.TeV)
+    seeds_na = ["CMB", ["tab", arr_E * u.eV, arr_n / (u.eV * u.cm ** 3)],
+                ["SSC", ssc_E * u.eV, ssc_n / (u.eV * u.cm ** 3)]]
+    ic = na.InverseCompton(pd, seed_photon_fields=seeds_na, Eemin=emin * u.GeV, Eemax=emax * u.GeV,
+                           nEed=33)
+    assert not ic._needs_walker_loop()
+    Eg = np.geomspace(1e7, 1e14, 29)
+    f = ic.flux(Eg * u.eV, 0).value
+    per = [ic.flux(Eg * u.eV, 0, seed=n).value for n in ("CMB", "tab", "SSC")]
+    for i in range(N):
+        seeds_o = [O.thermal_seed("CMB"), dict(type="array", energy=arr_E, density=arr_n),
+                   dict(type="array", energy=ssc_E, density=ssc_n[i])]
+        gam = O.electron_grid(emin[i] * 1e9, emax[i] * 1e9, 33)
+        opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13, alpha=alpha[i],
+                             e_cutoff=ecut[i] * 1e12, beta=1.0)
+        tot, each = O.ic_spectrum(Eg, gam, O.nelec_on(opd, gam), seeds_o)
+        assert_allclose(f[i], tot, rtol=1e-9, atol=tot.max() * 1e-200)
+        for j in range(3):
+            assert_allclose(per[j][i], each[j], rtol=1e-9, atol=tot.max() * 1e-200)
+    # the walker loop it replaces gives the same numbers (the table kernels, one walker at a time)
+    one = ic._loop_walkers("flux", Eg * u.eV, distance=0).value
+    assert_allclose(f, one, rtol=1e-9, atol=f.max() * 1e-200)
+    # ... and as a device loop's model function sees it: parameters resident in HBM, the seed a
+    # device expression of the walker's own synchrotron luminosity, Eemin a fit parameter
+    from naima_amd._lib import get_context
+    from naima_amd.darray import DPars
+    ctx = get_context()
+    host = np.array([np.log10(amp[:6]), emin[:6], rng.uniform(5, 50, 6)])
+    Esy = np.geomspace(1e-5, 1e5, 30) * u.eV
+
+    def crab_like(p):
+        pd6 = na.ExponentialCutoffPowerLaw(10 ** p[0] / u.eV, 10 * u.TeV, 2.3, 40 * u.TeV)
+        syn = na.Synchrotron(pd6, B=p[2] * u.uG, Eemin=p[1] * u.GeV)
+        phn = syn.flux(Esy, distance=0 * u.cm) / (4 * np.pi * (2.1 * u.pc) ** 2 * (29979245800.0 * u.cm / u.s)) * 2.24
+        icm = na.InverseCompton(pd6, seed_photon_fields=["CMB", ["SSC", Esy, phn]], Eemin=p[1] * u.GeV)
+        assert not icm._needs_walker_loop()
+        return icm.flux(Eg * u.eV, 2 * u.kpc)
+
+    fd = crab_like(DPars(ctx, ctx.array(host), 3, 6))
+    fh = crab_like(host)
+    assert_allclose(np.asarray(fd.value), fh.value, rtol=1e-12, atol=fh.value.max() * 1e-200)
+
