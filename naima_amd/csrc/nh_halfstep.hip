@@ -1305,7 +1305,12 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   // segments keep the waves evenly loaded; without one, ONE round of equal items over the
   // waves that are free from the start (not on a single-row reduction) ends soonest.
   C.ntab = d->ntab;
-  int seg = split >= 4 ? 8 : (split == 2 ? 16 : 32);
+  // (48 segments per item where a walker has one workgroup: with the synchrotron items in the log
+  // domain -- half the instructions they were -- the table items are the larger share of the
+  // resident loop's work, and a third fewer of them means a third less set-up: cfg3 10.6 -> 11.0 M
+  // walker-steps/s together with 48-node synchrotron items; 64: 10.9, 96: 10.7, 128: 10.3.  The
+  // per-launch kernel loses 2 % to it.)
+  int seg = split >= 4 ? 8 : (split == 2 ? 16 : (d->syn.grid >= 0 ? 48 : 32));
   if (split > 1) seg *= segscale;  // (coarser items: fewer partial sums in LDS)
   C.syn_nodes = HS_SYN_NODES / split > 3 ? HS_SYN_NODES / split : 3;
   if (const char* e = getenv("NH_HS_SEG")) seg = atoi(e) >= 4 ? atoi(e) : seg;  // (tuning experiments)

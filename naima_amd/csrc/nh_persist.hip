@@ -90,6 +90,7 @@ struct hs_run {
   // three times that long (cfg3, us per 40 half-steps: 1 015 at 10, 981 at 16, 975 at 24, 959
   // at 30 and at 40; two workgroups per walker -- cfg2 -- 901 at 5, 885 at 10, 914 at 16)
   int syn_nodes;
+  int rebalance;  // a tile's chunks divide the rows above its first non-zero one (table-only models)
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
@@ -773,9 +774,22 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
             // (rows below the tile's first non-zero one contribute exact zeros: not walked; the
             // tables' trailers -- identity for a table without one -- sit in LDS for the launch)
-            if (!(nz >> (8 + tg) & 1))
-              s0 = max(s0, __builtin_amdgcn_readfirstlane(
-                               reinterpret_cast<const int*>(sm + R.o_trail)[t * HS_RUN_TRAIL + tile]));
+            if (!(nz >> (8 + tg) & 1)) {
+              const int r0 = __builtin_amdgcn_readfirstlane(
+                  reinterpret_cast<const int*>(sm + R.o_trail)[t * HS_RUN_TRAIL + tile]);
+              if (R.rebalance) {
+                // the tile's chunks share the rows that are WALKED: cut into equal row ranges of
+                // the whole grid, the chunks below a pi0 / inverse-Compton threshold are empty and
+                // the waves that drew them idle while the others finish (cfg5: the sixteen waves
+                // reached the barrier 8.9 ... 11.9 us into the slice)
+                const int nch = HS_CHUNKS(tb.chunks);
+                const int per = (max(nG - 1 - r0, 0) + nch - 1) / nch;
+                s0 = r0 + chunk * per;
+                s1 = min(nG - 1, s0 + per);
+              } else {
+                s0 = max(s0, r0);
+              }
+            }
             const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
             const double* ws = sm + __builtin_amdgcn_readfirstlane(H.o_w[tg]);
             const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
@@ -1303,10 +1317,11 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   }
   R.order = nh_env_int("NH_RUN_ORDER", 2);
   R.syn_nodes = H.C.syn_nodes;
-  if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = 32;
+  if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = R.syn2 ? 48 : 32;
   if (P->split == 2 && R.syn_nodes < 10) R.syn_nodes = 10;  // (cfg2: 901 -> 885 us; 914 at 16)
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
   R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
+  R.rebalance = nh_env_int("NH_RUN_REBALANCE", H.syn_grid < 0 ? 1 : 0);
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");

@@ -754,8 +754,11 @@ def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
         st = d.run_mcmc(st, 50)
         out[mode] = (d.get_chain(), d.get_log_prob(), d._dev.resident_launches)
     assert out["0"][2] == 0 and out["1"][2] >= 13
+    # (the same accept decisions, hence the same positions to the last bit; the log-probabilities
+    # to rounding -- the resident loop cuts a table's rows into its work items differently, see
+    # hs_run.rebalance)
     assert np.array_equal(out["1"][0], out["0"][0])
-    assert np.array_equal(out["1"][1], out["0"][1])
+    assert_allclose(out["1"][1], out["0"][1], rtol=1e-12)
 
 
 @pytest.mark.parametrize("name,nw,nranks", [("cfg3", 32, 2), ("cfg5", 64, 2), ("cfg2", 48, 2),
