@@ -559,6 +559,12 @@ int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
  * arrive sums the partial spectra in index order and evaluates the likelihood: the results do
  * not depend on arrival order).  NH_HS_SPLIT=<K> in the environment caps K (1: never split). */
 int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
+/* NaN log-probabilities the accepts of the separate kernels (nh_lnprob / ..._lnprob with a move,
+ * nh_move_accept, nh_move_accept_rows) have met since the last reset: emcee raises
+ * ValueError("Probability function returned NaN") at the first one (EnsembleSampler.
+ * compute_log_prob; reference call site core.py:128); a launch rejects the proposal -- NaN
+ * compares false -- and counts.  The one-launch kernels count per plan (below). */
+int nh_nan_count(nh_ctx* ctx, int reset, int* count);
 /* proposals whose log-probability was NaN since the plan was created (or the last reset):
  * emcee raises ValueError("Probability function returned NaN") on the first one
  * (EnsembleSampler.compute_log_prob; reference call site core.py:128), a launch rejects the

@@ -56,6 +56,7 @@ struct nh_ctx {
   void* scratch;   // library-owned device scratch (grown outside graph capture)
   size_t scratch_bytes;
   hipStream_t copy_stream;  // uploads that run AHEAD of the main stream (nh_upload_ahead), or NULL
+  int* nan_word;  // device: NaN log-probabilities met by the accepts of the separate kernels (nh_nan_count)
 };
 
 // device scratch of at least `bytes`; contents are only valid within one entry point

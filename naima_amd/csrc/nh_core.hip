@@ -45,6 +45,7 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   c->scratch = nullptr;
   c->scratch_bytes = 0;
   c->copy_stream = nullptr;
+  c->nan_word = nullptr;
   memset(c->acc_ms, 0, sizeof(c->acc_ms));
   memset(c->acc_n, 0, sizeof(c->acc_n));
   NH_CHECK_HIP(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
@@ -57,7 +58,23 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   NH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   NH_CHECK_HIP(hipEventCreate(&c->t0));
   NH_CHECK_HIP(hipEventCreate(&c->t1));
+  NH_CHECK_HIP(hipMalloc(&c->nan_word, sizeof(int)));
+  NH_CHECK_HIP(hipMemset(c->nan_word, 0, sizeof(int)));
   *out = c;
+  return NH_OK;
+}
+
+// NaN log-probabilities the accepts of the SEPARATE kernels have met since the last reset
+// (nh_lnprob / nh_integrate_tables_lnprob / nh_synchrotron_lnprob with a move, nh_move_accept,
+// nh_move_accept_rows; the one-launch kernels count per plan: nh_half_step_counts).  emcee raises
+// ValueError("Probability function returned NaN") at the first one; a launch rejects the
+// proposal (NaN compares false) and counts.  Synchronises the stream.
+extern "C" int nh_nan_count(nh_ctx* c, int reset, int* count) {
+  NH_REQUIRE(c && count, "bad argument");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  NH_CHECK_HIP(hipMemcpy(count, c->nan_word, sizeof(int), hipMemcpyDeviceToHost));
+  if (reset && *count) NH_CHECK_HIP(hipMemset(c->nan_word, 0, sizeof(int)));
   return NH_OK;
 }
 
@@ -65,6 +82,7 @@ extern "C" int nh_destroy(nh_ctx* c) {
   if (!c) return NH_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->main_stream);
+  if (c->nan_word) (void)hipFree(c->nan_word);
   nh_comm_destroy(c);
   for (int i = 0; i < NH_NSIDE; ++i) {
     (void)hipStreamSynchronize(c->side[i]);
@@ -1071,6 +1089,7 @@ static int launch_lnprob(nh_ctx* c, const nh_comps& cs, int N, int nE, const dou
   nh_lnprob_args A;
   nh_lnprob_fill(A, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, model_out,
                  lnl, mv);
+  A.nan_count = c->nan_word;
   nh_prof_scope ps(c, NH_K_LNPROB);
   hipLaunchKernelGGL(k_lnprobmodel, dim3((N + 3) / 4), dim3(256), 0, c->stream, A);
   NH_CHECK_HIP(hipGetLastError());
@@ -1163,6 +1182,7 @@ extern "C" int nh_integrate_tables_lnprob(
   nh_lnprob_args A;
   nh_lnprob_fill(A, cs, N, nK, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, nullptr,
                  total, mv);
+  A.nan_count = c->nan_word;
   bool fused = false;
   int rc = integrate_impl(c, w, dlw, N, nG, lx, Kt, dlnKt, nK, scale, out, ldo, nonnegative, 1,
                           nK <= 64 ? &A : nullptr, loc_comp, &fused);

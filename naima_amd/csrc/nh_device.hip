@@ -172,7 +172,7 @@ __global__ void k_move_accept(double* __restrict__ coords, double* __restrict__ 
                               const double* __restrict__ blk, int* __restrict__ cursor,
                               const double* __restrict__ newlp, int ns, int ndim,
                               int* __restrict__ accepted, int* __restrict__ naccepted,
-                              int* __restrict__ sel, int advance) {
+                              int* __restrict__ sel, int advance, int* __restrict__ nan_count) {
   // every rank holds the full ensemble and all ns new log-probabilities: the
   // proposal is recomputed here from (coords, z, partner) so that no coordinates
   // ever have to be exchanged between ranks.  Single block (ns <= 1024 per pass).
@@ -193,6 +193,7 @@ __global__ void k_move_accept(double* __restrict__ coords, double* __restrict__ 
     }
     accepted[j] = acc ? 1 : 0;
     if (sel) sel[j] = me;  // the slice's active walkers, for the blob scatter that follows
+    if (newlp[j] != newlp[j]) atomicAdd(nan_count, 1);  // (emcee raises here: nh_nan_count)
   }
   __syncthreads();
   if (advance && threadIdx.x == 0) cursor[0] += 1;
@@ -208,7 +209,7 @@ extern "C" int nh_move_accept(nh_ctx* c, double* coords, double* logp, const dou
   // complementary half), so no ordering between threads is needed; the cursor is
   // advanced after the barrier
   hipLaunchKernelGGL(k_move_accept, dim3(1), dim3(1024), 0, c->stream, coords, logp, blk, cursor,
-                     newlp, ns, ndim, accepted, naccepted, sel, advance);
+                     newlp, ns, ndim, accepted, naccepted, sel, advance, c->nan_word);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -220,7 +221,7 @@ __global__ void k_move_accept_rows(double* __restrict__ coords, double* __restri
                                    const double* __restrict__ blk, int* __restrict__ cursor,
                                    const double* __restrict__ rows, int width, int ns, int ndim,
                                    int* __restrict__ accepted, int* __restrict__ naccepted,
-                                   int* __restrict__ sel, accept_blobs B) {
+                                   int* __restrict__ sel, accept_blobs B, int* __restrict__ nan_count) {
   const move_slice m = move_get(blk, cursor, ns);
   const int j = blockIdx.x;
   const int me = m.idx[j], pa = m.idx[ns + j];
@@ -249,6 +250,7 @@ __global__ void k_move_accept_rows(double* __restrict__ coords, double* __restri
     }
     accepted[j] = acc ? 1 : 0;
     if (sel) sel[j] = me;
+    if (r[0] != r[0]) atomicAdd(nan_count, 1);  // (emcee raises here: nh_nan_count)
   }
 }
 
@@ -289,7 +291,7 @@ extern "C" int nh_move_accept_rows(nh_ctx* c, double* coords, double* logp, cons
   NH_REQUIRE(width >= wsum, "rows narrower than 1 + the blobs' lengths");
   nh_prof_scope ps(c, NH_K_GLUE);
   hipLaunchKernelGGL(k_move_accept_rows, dim3((unsigned)ns), dim3(64), 0, c->stream, coords, logp,
-                     blk, cursor, rows, width, ns, ndim, accepted, naccepted, sel, B);
+                     blk, cursor, rows, width, ns, ndim, accepted, naccepted, sel, B, c->nan_word);
   if (advance) hipLaunchKernelGGL(k_cursor_advance, dim3(1), dim3(1), 0, c->stream, cursor);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;

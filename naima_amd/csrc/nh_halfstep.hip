@@ -1297,7 +1297,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     // (worth it where the work items are most of a launch: measured on cfg2 / cfg3 at 128
     // walkers per launch 42.3 -> 32.7 us and 33.8 -> 28.0 us; the hand-off costs ~3.5 us, which
     // the table-only models cfg1 / cfg5 -- 7 us of items in a 17 us launch -- do not get back)
-    if (work >= (1 << 20))
+    if (work >= nh_env_int("NH_HS_SPLIT_MIN_WORK", 1 << 20))
       while (split * 2 <= kmax && (long long)d->nloc * split * 2 <= ncu) split *= 2;
   }
   // ---- table reductions: work items of `seg` segments x 64 columns ----

@@ -18,6 +18,7 @@ struct nh_lnprob_args {
   nh_prior_pack pri;
   double* model_out; double* lnl;
   nh_accept mv;
+  int* nan_count;  // the context's counter of NaN log-probabilities met by an accept (or NULL)
 };
 
 __device__ __forceinline__ double nh_wave_sum(double v) {
@@ -109,6 +110,8 @@ __device__ __forceinline__ void nh_lnprob_wave(const nh_lnprob_args& A, int wi, 
       }
       mv.accepted[g] = ok ? 1 : 0;
       if (mv.sel) mv.sel[g] = me;
+      // emcee raises "Probability function returned NaN" here; a launch cannot, it counts
+      if (acc != acc && A.nan_count) atomicAdd(A.nan_count, 1);
     }
   }
 }
@@ -218,6 +221,7 @@ __device__ __forceinline__ void nh_lnprob64_finish(const nh_lnprob_args& A, cons
       }
       mv.accepted[g] = ok ? 1 : 0;
       if (mv.sel) mv.sel[g] = P.me;
+      if (acc != acc && A.nan_count) atomicAdd(A.nan_count, 1);
     }
   }
 }
@@ -234,4 +238,5 @@ static inline void nh_lnprob_fill(nh_lnprob_args& A, const nh_comps& cs, int N, 
   for (int j = 0; j < nterms; ++j) A.pri.t[j] = terms[j];
   nh_accept z = {};
   A.mv = mv ? *mv : z;
+  A.nan_count = nullptr;  // (the caller's context sets it where an accept rides in the launch)
 }

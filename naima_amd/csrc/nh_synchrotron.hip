@@ -289,5 +289,6 @@ extern "C" int nh_synchrotron_lnprob(nh_ctx* c, const double* w, const double* d
   nh_lnprob_args A;
   nh_lnprob_fill(A, cs, N, nE, conv, flux, err_lo, err_hi, ul, cl, lp, terms, nterms, nullptr,
                  total, mv);
+  A.nan_count = c->nan_word;
   return launch_synchrotron(c, w, dlw, B_G, ldB, N, gam, lx, nG, E_eV, nE, out, ldo, &A, syn_comp);
 }

@@ -205,6 +205,8 @@ class DeviceLoop:
         self._resident_trust = 0          # launches of the resident loop that were checked as they were made
         self.resident_failed_launches = 0
         self._nan_pending = self._forbidden_pending = 0
+        _n = _lib._i(0)  # (the context's word may hold what an earlier sampler left uncounted)
+        _lib._chk(_lib._lib.nh_nan_count(self.ctx.h, 1, C.byref(_n)))
         self.resident_launches = 0
         # ... and over an ensemble shared by several GPUs (nh_half_step_run_create_shared: movers
         # store their walkers' records into every rank's ring; no collective per half-step).
@@ -951,10 +953,16 @@ class DeviceLoop:
         stash = []
         for cur, m, _, _ in self.cur_blobs or []:
             host = cur.get().reshape(N, m)
-            parts = g.allgather_bytes(np.ascontiguousarray(host[mine]).tobytes())
-            for r, p_ in enumerate(parts):
-                if r != comm.rank:
-                    host[has & (owner == r)] = np.frombuffer(p_, dtype=float).reshape(-1, m)
+            # (in slabs of walkers: a gathered message is every rank's rows together, and the
+            # control plane refuses messages beyond 64 MiB)
+            step = max(1, (16 << 20) // (8 * m))
+            idx = np.arange(N)
+            for lo in range(0, N, step):
+                slab = (idx >= lo) & (idx < lo + step)
+                parts = g.allgather_bytes(np.ascontiguousarray(host[mine & slab]).tobytes())
+                for r, p_ in enumerate(parts):
+                    if r != comm.rank:
+                        host[has & (owner == r) & slab] = np.frombuffer(p_, dtype=float).reshape(-1, m)
             cur.set(host.ravel())
             stash.append(host)
         self._cur_host = stash  # (valid until a launch changes the blobs again)
@@ -1062,14 +1070,21 @@ class DeviceLoop:
         """(NaN log-probabilities, proposals forbidden by the prior) the one-launch kernels have
         counted on the device since the last reset"""
         hs = self._plan["hs"] if self._plan else None
+        extra = 0
+        if set_to is None:
+            # launches of the separate kernels (cfg4; the first half-steps of any run): their
+            # accepts count into the context's word
+            n = _lib._i(0)
+            _lib._chk(_lib._lib.nh_nan_count(self.ctx.h, 1 if reset else 0, C.byref(n)))
+            extra = n.value
         if hs is None or hs.get("plan") is None:
-            return 0, 0
+            return extra, 0
         n, f = _lib._i(0), _lib._i(0)
         if set_to is not None:
             n, f = _lib._i(-set_to[0] - 1), _lib._i(-set_to[1] - 1)
         _lib._chk(_lib._lib.nh_half_step_counts(self.ctx.h, hs["plan"], 1 if reset else 0,
                                                 C.byref(n), C.byref(f)))
-        return n.value, f.value
+        return n.value + (extra if reset else 0), f.value
 
     def check_nan(self, collective=False):
         """NaN log-probabilities the launches met since the last look (one-launch plans count

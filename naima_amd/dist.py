@@ -88,7 +88,8 @@ _MAX_MSG = 64 << 20  # nothing on the control plane comes near this (ids, scalar
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
     if n > _MAX_MSG:
-        raise ConnectionError("control-plane message of %d bytes refused (cap %d)" % (n, _MAX_MSG))
+        raise ConnectionError("control-plane message of %d bytes refused (cap %d; a gathered message "
+                              "is every rank's payload together)" % (n, _MAX_MSG))
     return _recv_exact(sock, n)
 
 
@@ -135,7 +136,12 @@ class SocketGroup:
             probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             try:
                 probe.bind((cand, 0))
-                bind_addr = cand
+                # (a node's own NAME may resolve to a loopback address on the node itself --
+                # Debian's 127.0.1.1 -- while the other nodes resolve it to the real one: only a
+                # literal loopback address, or "localhost", is taken as "this host only")
+                literal = addr == "localhost" or addr.startswith("127.")
+                if not cand.startswith("127.") or literal:
+                    bind_addr = cand
             finally:
                 probe.close()
         except OSError:

@@ -666,7 +666,8 @@ def test_table_only_model_with_more_walkers_than_compute_units(na):
                         atol=1e-300)
 
 
-def test_nan_log_probability_is_emcees_error(na):
+@pytest.mark.parametrize("mega", ["1", "0"], ids=["one-launch", "separate-kernels"])
+def test_nan_log_probability_is_emcees_error(na, monkeypatch, mega):
     """a proposal whose log-probability is NaN ends an emcee run with ValueError("Probability
     function returned NaN") (EnsembleSampler.compute_log_prob; the reference just lets it
     through, core.py:128): the host-driven loop raises on the spot, the device loop -- whose
@@ -674,6 +675,7 @@ def test_nan_log_probability_is_emcees_error(na):
     ball under round 3's prior (the amplitude only) meets its first such proposal -- a negative
     magnetic field -- within ~30 steps."""
     from naima_amd.sampler import EnsembleSampler
+    monkeypatch.setenv("NAIMA_AMD_MEGA", mega)  # ("0": the accept rides in k_lnprobmodel / k_synchrotron)
     model, p0, raw, data, prior = _problem(na, "cfg2", {})
     prior = _loose_prior(na, "cfg2")  # (the benchmark's prior forbids B < 0)
     nw, nd = 256, p0.size
@@ -690,6 +692,17 @@ def test_nan_log_probability_is_emcees_error(na):
         st = d.run_mcmc(pos, 2)
         st = d.run_mcmc(st, 68)
         st.coords
+    assert d._dev.mega == (mega == "1")
+    # ... and counted instead, with nan_policy="reject": the same number in either loop
+    kw["nan_policy"] = "reject"
+    h2 = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    d2 = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+    with np.errstate(all="ignore"):
+        h2.run_mcmc(pos, 40)
+        st = d2.run_mcmc(pos, 2)
+        st = d2.run_mcmc(st, 38)
+        st.coords
+    assert h2.nan_proposals > 0 and d2.nan_proposals == h2.nan_proposals
 
 
 def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
