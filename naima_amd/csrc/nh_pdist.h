@@ -79,7 +79,7 @@ __device__ __forceinline__ double pd_exp_tab(double x, const double* __restrict_
 __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, double lxc,
                                         double lkb, bool b1, bool b2, double lr, double& n,
                                         double& dsh, const double* __restrict__ T64 = nullptr,
-                                        double* __restrict__ lnn = nullptr) {
+                                        double* __restrict__ lnn = nullptr, bool full = true) {
   auto pd_exp = [T64](double v) { return T64 ? pd_exp_tab(v, T64) : ::pd_exp(v); };
   double ex;  // ln(n / A): what the log-domain consumers (nh_syn2.h) take instead of n
   switch (kind) {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, d
     case NH_PD_ECPL: {
       const double t = pd_exp(p.be * lxc);
       ex = -p.al * lxx - t;
-      dsh = -p.al * lr - t * pd_expm1_small(p.be * lr);
+      dsh = full ? -p.al * lr - t * pd_expm1_small(p.be * lr) : 0.0;
     } break;
     case NH_PD_BROKENPL:
     case NH_PD_ECBPL: {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, d
       if (kind == NH_PD_ECBPL) {
         const double t = pd_exp(p.be * lxc);
         ex -= t;
-        dsh -= t * pd_expm1_small(p.be * lr);
+        if (full) dsh -= t * pd_expm1_small(p.be * lr);
       }
     } break;
     default: {  // NH_PD_LOGPARABOLA
@@ -113,7 +113,9 @@ __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, d
       dsh = -p.al * lr - p.be * lr * (lxx + (lxx + lr));
     } break;
   }
-  n = p.A * pd_exp(ex);
+  // (full == false, wave-uniform: the caller wants ln(n / A) only -- the log-domain synchrotron
+  // items of nh_syn2.h -- and is spared the exponential and the cut-off's expm1)
+  n = full ? p.A * pd_exp(ex) : 0.0;
   if (lnn) *lnn = ex;
   // a cutoff energy so far below the grid that (E/e_c)^beta overflows makes the log-ratio
   // -inf (the node itself is an exact 0): kept finite, because the reductions form 1/dl

@@ -112,6 +112,7 @@ struct hs_run {
   const double* s2_dev;  // device: the table's (P + 1) x 6 doubles, then the grid's nG values of the above
   hs_syn2_par s2;
   double s2_z0, s2_invd;  // z = s2_z0 - ln(q) s2_invd: where node 0 sits on the comb below T_top
+  double s2_lnw0;         // ln |n| + ln(E / eV) above this: the weight gamma n scale is not 0 in double
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -153,6 +154,7 @@ __device__ __attribute__((noinline)) double hsr_log(double x) { return log(x); }
 __device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x); }
 struct hsr_node { double n, dsh, ex; };  // ex = ln(n / A)
 struct hsr_node2 { double n0, dsh0, n1, dsh1, ex0, ex1; };
+// b12 / b0 / b1: bit 0, 1 = this node / the next lie below the break; bit 2 = ln(n / A) only
 __device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, double al, double be,
                                                           double a2, double lxx, double lxc,
                                                           double lkb, int b12, double lr,
@@ -160,7 +162,7 @@ __device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, do
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node r;
-  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64, &r.ex);
+  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64, &r.ex, (b12 & 4) == 0);
   return r;
 }
 
@@ -174,8 +176,8 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node2 r;
-  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64, &r.ex0);
-  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64, &r.ex1);
+  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64, &r.ex0, (b0 & 4) == 0);
+  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64, &r.ex1, (b1 & 4) == 0);
   return r;
 }
 
@@ -565,6 +567,8 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
           const int uu = u + q * nwork;
           // (constant indices only: a dynamically indexed ub[] is an array in scratch, and the
           // search a chain of dependent scratch loads at the head of every slice's weights)
+          // (tried: the grid whose nodes are cheap -- ln w only -- LAST in the order of units, so that
+          // no wave computes two full units in a row: the weights phase 3.12 -> 3.36 us)
           int g = 0, u0 = 0;
 #pragma unroll
           for (int gg = 1; gg < NH_MAX_GRIDS; ++gg)
@@ -585,6 +589,9 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
               bq[q] = (E < p.eb ? 1 : 0) | (E2 < p.eb ? 2 : 0);
             }
           }
+          // (the log-domain synchrotron items read ln w and nothing else of this grid: no
+          // exponential, no expm1 for its nodes -- wave-uniform, a unit is one grid's)
+          if (SYN && S2 && R.s2_own && g == H.syn_grid) bq[q] |= 4;
         }
         const bool two = u + nwork < nunits;  // (wave-uniform)
         double nnq[2], dshq[2], exq[2];
@@ -614,11 +621,15 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             if (SYN && S2 && g == H.syn_grid) {
               // the log-domain items' Lambda ln|w| + Lambda ln cbrt(1/gamma^2) (nh_syn2.h); a zero
               // weight (or amplitude) is the floor: an exact 0, and exact zeros for its segments
-              const double lw = fma(HS_S2_LAMBDA, qs[HS_O_LNA] + exq[q], sm[R.o_s2lg + i]);
-              sm[R.o_s2lw + HS_S2_GUARD + i] = lw > -1.0e290 ? lw : HS_S2_FLOOR;
+              const double lna = qs[HS_O_LNA] + exq[q];  // ln |n|
+              const double lw = fma(HS_S2_LAMBDA, lna, sm[R.o_s2lg + i]);
+              // (w = gamma n scale underflows to an exact 0 in the reference below ln w = -744.44:
+              // the floor -- an exact zero node -- from there on)
+              const bool nonzero = lna + lneq[q] > R.s2_lnw0;
+              sm[R.o_s2lw + HS_S2_GUARD + i] = nonzero ? lw : HS_S2_FLOOR;
               if (R.s2_own) {  // (nobody reads this grid's w / dlw, and gx holds another array)
                 plain = false;
-                wv_ = nn;
+                wv_ = !(lw < INFINITY) ? lw : (nonzero ? 1.0 : 0.0);  // (what the flags below look at)
               }
             }
             if (plain) {
@@ -1281,6 +1292,8 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
       R.s2.im = 1.0 / m;
       R.s2.lml = (double)(m - 1) / m;
       R.s2_invd = (double)(1.0L / (2.0L * lx));
+      // w = gamma n scale = (E / mec2[eV]) n scale != 0  <=>  ln n + ln E > ln(2^-1075) + ln(mec2 / scale)
+      R.s2_lnw0 = (double)(-1075.0L * logl(2.0L) + logl((long double)NH_MEC2_EV / (long double)H.scale[H.syn_grid]));
       R.s2_z0 = (double)(((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
       off += off & 1;  // (16-byte aligned: the pieces are read as ds_read_b128)
       int o2 = off;
