@@ -1332,6 +1332,11 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   R.syn_nodes = H.C.syn_nodes;
   if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = R.syn2 ? 48 : 32;
   if (P->split == 2 && R.syn_nodes < 10) R.syn_nodes = 10;  // (cfg2: 901 -> 885 us; 914 at 16)
+  // (the log-domain items start on a piece boundary with a node and six coefficients of their
+  // own: short items pay for that -- cfg3 / 128, four workgroups per walker, us per half-step:
+  // 18.4 at the plan's 4 nodes, 16.9 at 16, 17.7 at 24, direct form 17.2; cfg3 / 256, two per
+  // walker: 20.8 at 10, 20.8 at 16, 20.0 at 24; cfg2 / 256: 17.7 at 10 and at 16, 18.3 at 24)
+  if (R.syn2 && P->split >= 2 && R.syn_nodes < 16) R.syn_nodes = 16;
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
   R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
   R.rebalance = nh_env_int("NH_RUN_REBALANCE", H.syn_grid < 0 ? 1 : 0);
