@@ -505,9 +505,12 @@ int nh_table_interleave(nh_ctx* ctx, const double* Kt, const double* dlnKt,
                         const double* lx /*[nG-1] device, or NULL*/, int nG, int nK,
                         double* KD);
 typedef struct { int grid /* -1: no synchrotron component */; int nE; int ldo;
-                 int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB; int pad;
+                 int bcol /* column of the particle rows that carries B [G], or -1 */; int ldB;
+                 int n1 /* 0, or: energies [n1, nE) go to out2 -- two Synchrotron.flux calls of one
+                           model evaluation (CrabNebula_SynSSC.py:29, 45) as ONE component */;
                  const double* E_eV; const double* B /* [nloc*ldB] when bcol < 0 */;
-                 double* out /*[nloc][ldo]*/; } nh_hs_syn;
+                 double* out /*[nloc][ldo]*/; double* out2 /*[nloc][ldo2] == out + nloc * ldo, or NULL*/; int ldo2; int pad2;
+               } nh_hs_syn;
 #define NH_HS_MAX_TAB 4
 /* a blob the model function returns besides its flux (core.py:103-113; emcee keeps the blobs
  * of the ACCEPTED position of every walker): kind 0 = the model spectrum itself (the sum of

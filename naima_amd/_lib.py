@@ -221,6 +221,9 @@ def _chk(rc):
         raise NaimaHipError("libnaima_hip error %d: %s" % (rc, _lib.nh_last_error().decode()))
 
 
+_POISON = int(os.environ.get("NAIMA_AMD_POISON", "0"), 0)
+
+
 class Moves:
     """the stretch-move random stream (nh_moves_*): a C++ worker thread draws ahead.
     ``take(k)`` -> (address, got, S, P, Z, L views for `got` consecutive steps)"""
@@ -378,6 +381,10 @@ class Context:
             p = _dp()
             _chk(_lib.nh_alloc(self.h, cap, C.byref(p)))
             ptr = p.value
+        if _POISON and not self.capturing:
+            # NAIMA_AMD_POISON=<byte>: every buffer handed out is filled with that byte first (a
+            # debugging aid: a launch that reads what nobody wrote shows up as a changed result)
+            _chk(_lib.nh_memset(self.h, ptr, _POISON & 0xFF, cap))
         return DeviceArray(self, ptr, shape, dtype, cap, nbytes)
 
     def _release(self, ptr, cap, graph_owned=False):
@@ -418,8 +425,8 @@ class Context:
     # REPLAY mode a request only checks that it is the recorded one and returns its
     # buffers.
     def plan_begin(self):
-        self._plan = dict(mode="record", packs=[], weights=[], moments=[], i=[0, 0, 0, 0],
-                          emit=[], calls=[], mega=False, hs=None)
+        self._plan = dict(mode="record", packs=[], weights=[], moments=[], i=[0, 0, 0, 0, 0],
+                          emit=[], calls=[], mega=False, hs=None, bufs=[])
         return self._plan
 
     def _replayed(self, kind, slot, key):
@@ -437,6 +444,25 @@ class Context:
         if self._plan is not None and self._plan["mode"] == "record":
             self._plan[kind].append((key, value))
         return value
+
+    def plan_buffer(self, key, shape):
+        """an output buffer of a launch that is NOT one of the step loop's recorded kinds (the SSC
+        seed integral) but whose result the likelihood reads: the same buffer at every
+        evaluation of a recorded plan, so that the plan's component pointers stay what they
+        were; a fresh one outside a plan"""
+        plan = self._plan
+        if plan is None:
+            return self.empty(shape)
+        if plan["mode"] == "record":
+            buf = self.empty(shape)
+            plan["bufs"].append((key, buf))
+            return buf
+        i = plan["i"][4]
+        if i >= len(plan["bufs"]) or plan["bufs"][i][0] != key:
+            raise NaimaHipError("the model's launch sequence changed between evaluations (%s); "
+                                "run the sampler with use_graph=False" % (key[0],))
+        plan["i"][4] = i + 1
+        return plan["bufs"][i][1]
 
     def pack_rows(self, cols, ncols, N):
         """out[N][ncols] from lazy columns (one nh_pack_rows launch unless replayed)"""
@@ -564,16 +590,19 @@ class Context:
             self.call("nh_integrate_tables", *args)
         return out, ns
 
-    def emit_synchrotron(self, w, lw, Bp, ldB, N, gd, lx, nG, Ed, nE, keep=()):
+    def emit_synchrotron(self, w, lw, Bp, ldB, N, gd, lx, nG, Ed, nE, keep=(), E_host=None):
         """out[N][nE] = Synchrotron._spectrum of every walker (nh_synchrotron)"""
         plan = self._plan
         key = ("syn", w.ptr, lw.ptr, int(Bp), int(ldB), N, gd.ptr, lx.ptr, nG, Ed.ptr, nE)
         if plan is not None and plan["mega"] and plan["mode"] == "replay":
+            if plan.get("staged"):
+                return self._stage_a(plan, key, N, nE)
             return self._emit_replayed("synchrotron", key, (N, nE))
         out = self.empty((N, nE))
         args = (w, lw, Bp, ldB, N, gd, lx, nG, Ed, nE, out, nE)
         if plan is not None and plan["mode"] == "record":
-            plan["emit"].append(dict(kind="syn", key=key, out=None, N=N, keep=(w, lw, gd, lx, Ed) + tuple(keep)))
+            plan["emit"].append(dict(kind="syn", key=key, out=None, N=N, keep=(w, lw, gd, lx, Ed) + tuple(keep),
+                                     E_host=None if E_host is None else np.array(E_host, dtype=float)))
         hook = self._accept_hook
         if hook is not None and not hook["used"] and hook["N"] == N and nE <= 64 \
                 and not self._deferred:
@@ -581,6 +610,84 @@ class Context:
         else:
             self.call("nh_synchrotron", *args)
         return out
+
+    def _hs_front(self, d, f):
+        """the part of an nh_hs_desc every plan of a device loop shares: the ensemble, the block of
+        moves, the parameter packs, the grids (returns {weights pointer: grid index})"""
+        for name in ("coords", "logp", "blk", "cursor", "qT", "factors"):
+            setattr(d, name, f[name])
+        d.ns, d.ndim, d.lo, d.nloc = f["ns"], f["ndim"], f["lo"], f["nloc"]
+        pk, npk, kind, rows_ptr, gd, ngr, mm, nmm = f["front_args"]
+        for q in range(npk):
+            d.packs[q] = pk[q]
+        d.npacks, d.kind, d.params = npk, kind, rows_ptr
+        wgrid = {}
+        for g in range(ngr):
+            d.grids[g] = gd[g]
+            wgrid[gd[g].w] = g
+        d.ngrids = ngr
+        return wgrid
+
+    def _stage_a(self, plan, key, N, nE):
+        """A model that asks for its synchrotron spectrum TWICE -- at the energies of a seed photon
+        field it then builds from it, and at the data's (examples/CrabNebula_SynSSC.py:29-45) --
+        with launches of other kernels in between (the SSC seed integral batches sixteen WALKERS
+        per wave: nothing a one-workgroup-per-walker launch can absorb): the half-step is two
+        nh_half_step launches around them.  Stage A, launched where the model asks for the first
+        spectrum: proposal -> packs -> weights (written to HBM for the kernels in between) ->
+        ONE synchrotron component over both sets of energies, no accept.  Stage C is the plan's
+        own launch (Context.half_step): proposal, packs and weights again (a few microseconds),
+        the table reductions, the spectra of the launches in between and stage A's from HBM,
+        likelihood, accept."""
+        import ctypes as C
+
+        from . import darray as D
+        i = plan["i"][3]
+        ent = plan["emit"][i] if i < len(plan["emit"]) else None
+        if ent is None or ent["key"] != key:
+            raise NaimaHipError("the model's launch sequence changed between evaluations "
+                                "(synchrotron); run the sampler with use_graph=False")
+        plan["i"][3] = i + 1
+        syn = [e for e in plan["emit"] if e["kind"] == "syn"]
+        st = plan.get("stage")
+        if st is None:
+            e1, e2 = syn
+            n1, n2 = e1["key"][10], e2["key"][10]
+            base = self.empty((N * (n1 + n2),))
+            e1["out"] = DeviceArray(self, base.ptr, (N, n1), np.float64, 0)
+            e2["out"] = DeviceArray(self, base.ptr + 8 * N * n1, (N, n2), np.float64, 0)
+            Ecat = self.array(np.concatenate([e1["E_host"], e2["E_host"]]))
+            f = plan["front"]
+            d = D.nh_hs_desc()
+            wgrid = self._hs_front(d, f)
+            rows_ptr = f["front_args"][3]
+            d.hist = None
+            d.do_accept, d.write_weights = 0, 1
+            d.nmoms, d.ntab = 0, 0
+            _, w, lw, Bp, ldB, _, gdp, lx, nG, _, _ = e1["key"]
+            in_rows = ldB == NH_PD_NPAR and 0 <= Bp - rows_ptr < 8 * NH_PD_NPAR
+            d.syn = D.nh_hs_syn(wgrid[w], n1 + n2, n1, (Bp - rows_ptr) // 8 if in_rows else -1, ldB,
+                                n1, Ecat.ptr, None if in_rows else Bp, base.ptr,
+                                base.ptr + 8 * N * n1, n2, 0)
+            # (a launch has a likelihood: this one's is of the first spectrum against columns of
+            # ones and zeros, into a buffer nobody reads)
+            ones, zeros = self.array(np.ones(n1)), self.array(np.zeros(n1))
+            izero = self.array(np.zeros(n1, dtype=np.int32), dtype=np.int32)
+            half = self.array(np.full(n1, 0.5))
+            dummy = self.empty((N,))
+            d.comps[0] = D.nh_comp(base.ptr, n1, 1.0)
+            d.ncomp, d.nE = 1, n1
+            d.conv, d.flux, d.err_lo, d.err_hi = ones.ptr, zeros.ptr, ones.ptr, ones.ptr
+            d.ul, d.cl, d.lp, d.nterms = izero.ptr, half.ptr, None, 0
+            d.model_out, d.total, d.nblobs, d.send_width = None, dummy.ptr, 0, 0
+            h = _dp()
+            _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))
+            st = plan["stage"] = dict(plan=h, keep=(base, Ecat, ones, zeros, izero, half, dummy))
+            self.call("nh_half_step_begin_block", h, f["pos"]["slice"], 0)
+        if ent is syn[0]:
+            pos = plan["front"]["pos"]
+            self.call("nh_half_step_launch", st["plan"], pos["slice"] if pos["bake"] else -1)
+        return ent["out"]
 
     def half_step(self, hook, comps, ncomp, nE, conv, dd, lpd, terms, nterms, total, blobs=()):
         """the plan's nh_half_step launch: everything the recorded model evaluation asked
@@ -643,11 +750,13 @@ class Context:
                                           ent["out"].ptr)
                 tabs.append((Kt, dKt, nG, nK, lx, bool(nonneg)))
                 nt += 1
+            elif plan.get("staged"):
+                pass  # (stage A's launch has produced it: the likelihood reads it from HBM)
             else:
                 _, w, lw, Bp, ldB, N, gdp, lx, nG, Ed, nEs = k
                 in_rows = ldB == NH_PD_NPAR and 0 <= Bp - rows_ptr < 8 * NH_PD_NPAR
                 d.syn = D.nh_hs_syn(wgrid[w], nEs, nEs, (Bp - rows_ptr) // 8 if in_rows else -1,
-                                    ldB, 0, Ed, None if in_rows else Bp, ent["out"].ptr)
+                                    ldB, 0, Ed, None if in_rows else Bp, ent["out"].ptr, None, 0, 0)
         d.ntab = nt
         for q in range(ncomp):
             d.comps[q] = comps[q]

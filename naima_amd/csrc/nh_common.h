@@ -59,6 +59,20 @@ struct nh_ctx {
   int* nan_word;  // device: NaN log-probabilities met by the accepts of the separate kernels (nh_nan_count)
 };
 
+// Fill / upload that has COMPLETED when it returns.  The context's streams are non-blocking
+// streams: the null stream's hipMemset orders nothing against them, and for device memory it
+// may return before the fill has happened -- a launch queued right behind it on c->stream can
+// then run first and have its words zeroed under it afterwards (seen with three and more
+// processes on one GPU: a plan's `done` counter reset in the middle of a block of moves).
+static inline hipError_t nh_fill_now(nh_ctx* c, void* p, int byte, size_t n) {
+  hipError_t e = hipMemsetAsync(p, byte, n, c->main_stream);
+  return e == hipSuccess ? hipStreamSynchronize(c->main_stream) : e;
+}
+static inline hipError_t nh_put_now(nh_ctx* c, void* dst, const void* src, size_t n) {
+  hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, c->main_stream);
+  return e == hipSuccess ? hipStreamSynchronize(c->main_stream) : e;
+}
+
 // device scratch of at least `bytes`; contents are only valid within one entry point
 int nh_scratch(nh_ctx* c, size_t bytes, void** out);
 

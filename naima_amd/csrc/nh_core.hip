@@ -59,7 +59,7 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   NH_CHECK_HIP(hipEventCreate(&c->t0));
   NH_CHECK_HIP(hipEventCreate(&c->t1));
   NH_CHECK_HIP(hipMalloc(&c->nan_word, sizeof(int)));
-  NH_CHECK_HIP(hipMemset(c->nan_word, 0, sizeof(int)));
+  NH_CHECK_HIP(nh_fill_now(c, c->nan_word, 0, sizeof(int)));
   *out = c;
   return NH_OK;
 }
@@ -74,7 +74,7 @@ extern "C" int nh_nan_count(nh_ctx* c, int reset, int* count) {
   int rc = nh_sync(c);
   if (rc) return rc;
   NH_CHECK_HIP(hipMemcpy(count, c->nan_word, sizeof(int), hipMemcpyDeviceToHost));
-  if (reset && *count) NH_CHECK_HIP(hipMemset(c->nan_word, 0, sizeof(int)));
+  if (reset && *count) NH_CHECK_HIP(nh_fill_now(c, c->nan_word, 0, sizeof(int)));
   return NH_OK;
 }
 

@@ -937,9 +937,18 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       for (int k = tid; k < tb.nK; k += T) tb.out[(long long)j * tb.ldo + k] = spec[tb.spec_off + k];
     }
   }
-  if (has_syn)
-    for (int k = tid; k < H.syn_nE; k += T)
-      D.syn_out[(long long)j * D.syn_ldo + k] = spec[H.syn_spec_off + k];
+  if (has_syn) {
+    // (energies [n1, nE) of a component that stands for two Synchrotron.flux calls go to a second
+    // array that follows the first: nh_hs.h, syn_ldo)
+    // (gridDim.x = the launch's walkers: H.nloc, read HERE, made the compiler copy the whole
+    // descriptor to scratch -- scripts/hs_usage.sh)
+    const int ldo = D.syn_ldo & 0xFFFFF, n1 = D.syn_ldo >> 20;
+    const long long second = (long long)gridDim.x * ldo + (long long)j * (H.syn_nE - n1) - n1;
+    for (int k = tid; k < H.syn_nE; k += T) {
+      const long long at = (n1 > 0 && k >= n1) ? second + k : (long long)j * ldo + k;
+      D.syn_out[at] = spec[H.syn_spec_off + k];
+    }
+  }
   // ---- 7. likelihood + priors (core.py:64-121) and the accept, one wave ---------------------
   if (lik_wave) {
     const int nE = H.nE;
@@ -1239,13 +1248,19 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   int syn_nE = 0;
   if (d->syn.grid >= 0) {
     const nh_hs_syn& s = d->syn;
-    NH_REQUIRE(s.grid < d->ngrids && s.E_eV && s.out && s.nE >= 1 && s.ldo >= s.nE &&
+    NH_REQUIRE(s.grid < d->ngrids && s.E_eV && s.out && s.nE >= 1 && s.ldo >= (s.out2 ? s.n1 : s.nE) &&
                    (s.bcol >= 0 ? s.bcol < NH_PD_NPAR : (s.B != nullptr && s.ldB >= 1)),
                "bad synchrotron component");
     const int nG = d->grids[s.grid].nG;
     NH_REQUIRE(s.nE <= 512, "at most 512 photon energies for the synchrotron component");
     H.syn_grid = s.grid; H.syn_E = s.E_eV; H.syn_nE = syn_nE = s.nE;
     C.synB = s.B; C.syn_out = s.out; C.syn_ldo = s.ldo; C.syn_bcol = s.bcol; C.syn_ldB = s.ldB;
+    NH_REQUIRE(s.out2 == nullptr || (s.n1 >= 1 && s.n1 < s.nE && s.ldo >= s.n1 && s.ldo2 >= s.nE - s.n1),
+               "bad split of the synchrotron component's output");
+    NH_REQUIRE(s.out2 == nullptr || (s.out2 == s.out + (long long)d->nloc * s.ldo && s.ldo2 == s.nE - s.n1 &&
+                                     s.ldo < (1 << 20) && s.n1 < (1 << 11)),
+               "the synchrotron component's second array must follow its first (out + nloc * ldo), rows of nE - n1");
+    if (s.out2) C.syn_ldo = s.ldo | (s.n1 << 20);
     H.o_ig2 = off; off += nG;
     H.o_dig2 = off; off += nG;
     H.o_ig23 = off; off += nG;
@@ -1434,7 +1449,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   if (const char* e = getenv("NH_HS_DEBUG"))
     if (atoi(e) != 0) {
       NH_CHECK_HIP(hipMalloc(&C.dbg, 67840 * sizeof(long long)));
-      NH_CHECK_HIP(hipMemset(C.dbg, 0, 67840 * sizeof(long long)));
+      NH_CHECK_HIP(nh_fill_now(c, C.dbg, 0, 67840 * sizeof(long long)));
     }
   nh_halfstep_plan* P = new nh_halfstep_plan();
   P->dbg = C.dbg;
@@ -1460,11 +1475,11 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   if (e == hipSuccess && split > 1) {
     e = hipMalloc(&P->xspec, (size_t)d->nloc * split * nspec * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&P->tick, (size_t)d->nloc * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(P->tick, 0, (size_t)d->nloc * sizeof(int));
+    if (e == hipSuccess) e = nh_fill_now(c, P->tick, 0, (size_t)d->nloc * sizeof(int));
   }
   if (e == hipSuccess) e = hipMalloc(&P->words, 4 * sizeof(int));  // done | hbase | NaN proposals | -
-  if (e == hipSuccess) e = hipMemcpy(P->dev, packs_host, sizeof(packs_host), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(P->words, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = nh_put_now(c, P->dev, packs_host, sizeof(packs_host));
+  if (e == hipSuccess) e = nh_fill_now(c, P->words, 0, 4 * sizeof(int));
   if (e == hipSuccess && lds > 64 * 1024)
     e = H.syn_grid >= 0
             ? hipFuncSetAttribute((const void*)k_half_step<true>,
@@ -1598,7 +1613,7 @@ extern "C" int nh_half_step_nan_count(nh_ctx* c, nh_halfstep_plan* P, int reset,
   int rc = nh_sync(c);
   if (rc) return rc;
   NH_CHECK_HIP(hipMemcpy(count, P->words + 2, sizeof(int), hipMemcpyDeviceToHost));
-  if (reset && *count) NH_CHECK_HIP(hipMemset(P->words + 2, 0, sizeof(int)));
+  if (reset && *count) NH_CHECK_HIP(nh_fill_now(c, P->words + 2, 0, sizeof(int)));
   return NH_OK;
 }
 
@@ -1615,11 +1630,11 @@ extern "C" int nh_half_step_counts(nh_ctx* c, nh_halfstep_plan* P, int reset, in
   if (*nan < 0 || *forbidden < 0) {
     if (*nan < 0) w[0] = -*nan - 1;
     if (*forbidden < 0) w[1] = -*forbidden - 1;
-    NH_CHECK_HIP(hipMemcpy(P->words + 2, w, sizeof(w), hipMemcpyHostToDevice));
+    NH_CHECK_HIP(nh_put_now(c, P->words + 2, w, sizeof(w)));
   }
   *nan = w[0];
   *forbidden = w[1];
-  if (reset && (w[0] || w[1])) NH_CHECK_HIP(hipMemset(P->words + 2, 0, sizeof(w)));
+  if (reset && (w[0] || w[1])) NH_CHECK_HIP(nh_fill_now(c, P->words + 2, 0, sizeof(w)));
   return NH_OK;
 }
 

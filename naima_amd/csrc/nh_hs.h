@@ -66,6 +66,10 @@ struct hs_dev {
   hs_tab tab[HS_MAX_TAB];
   int ntab, nT, seg;  // table items in total; segments per item
   const double* synB; double* syn_out;
+  // syn_ldo packs two numbers: ldo | n1 << 20.  n1 > 0: the energies [n1, nE) go to a second array
+  // [nloc][nE - n1] that FOLLOWS the first (nh_hs_syn.n1 / out2: two Synchrotron.flux calls of one
+  // model evaluation as one component).  (Packed: reading one more field of this block in
+  // k_half_step makes the compiler copy all 3 KB of it to scratch -- scripts/hs_usage.sh.)
   int syn_ldo, syn_bcol, syn_ldB, syn_cdmax;
   hs_comp comp[NH_MAX_COMP];
   int ncomp, pad0;

@@ -1394,26 +1394,26 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (how == 0) e = hipMalloc(&b, Q->base_bytes);
     else e = hipExtMallocWithFlags(&b, Q->base_bytes, how == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
     Q->base = static_cast<unsigned long long*>(b);
-    if (e == hipSuccess) e = hipMemset(Q->base, 0, Q->base_bytes);
+    if (e == hipSuccess) e = nh_fill_now(c, Q->base, 0, Q->base_bytes);
     Q->peer_base[Q->rank] = Q->base;
     if (e == hipSuccess) e = hipMalloc(&Q->nacc_own, (size_t)R.N * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(Q->nacc_own, 0, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = nh_fill_now(c, Q->nacc_own, 0, (size_t)R.N * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&Q->curstamp, (size_t)R.N * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(Q->curstamp, 0xFF, (size_t)R.N * sizeof(int));
+    if (e == hipSuccess) e = nh_fill_now(c, Q->curstamp, 0xFF, (size_t)R.N * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&Q->probe_out, (4 + HS_RUN_MAX_RANKS) * sizeof(int));
   } else {
     e = hipMalloc(&Q->ring, ring_bytes);
-    if (e == hipSuccess) e = hipMemset(Q->ring, 0, ring_bytes);
+    if (e == hipSuccess) e = nh_fill_now(c, Q->ring, 0, ring_bytes);
   }
   if (e == hipSuccess && R.syn2) {
     e = hipMalloc(&Q->s2_dev, s2_host.size() * sizeof(double));
     if (e == hipSuccess)
-      e = hipMemcpy(Q->s2_dev, s2_host.data(), s2_host.size() * sizeof(double), hipMemcpyHostToDevice);
+      e = nh_put_now(c, Q->s2_dev, s2_host.data(), s2_host.size() * sizeof(double));
   }
   if (e == hipSuccess) e = hipMalloc(&Q->status, sizeof(int));
-  if (e == hipSuccess) e = hipMemset(Q->status, 0, sizeof(int));
+  if (e == hipSuccess) e = nh_fill_now(c, Q->status, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(Q->accw, 0, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
+  if (e == hipSuccess) e = nh_fill_now(c, Q->accw, 0, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
   if (e == hipSuccess && P->split > 1) {
     e = hipMalloc(&Q->xspec, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * P->split * H.C.nspec * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&Q->tick, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * sizeof(int));
@@ -1422,7 +1422,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (const char* dv = getenv("NH_HS_DEBUG"))
       if (atoi(dv) != 0) {
         e = hipMalloc(&Q->dbg, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
-        if (e == hipSuccess) e = hipMemset(Q->dbg, 0, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
+        if (e == hipSuccess) e = nh_fill_now(c, Q->dbg, 0, (256 * 64 * 8 + 64 * 4 * 16) * sizeof(long long));
       }
   if (e != hipSuccess) {
     if (Q->ring) (void)hipFree(Q->ring);
@@ -1633,8 +1633,8 @@ extern "C" int nh_half_step_run_counters(nh_ctx* c, nh_halfstep_run* Q, int* nac
   const size_t nb = (size_t)Q->R.N * sizeof(int);
   if (nacc_own) NH_CHECK_HIP(hipMemcpy(nacc_own, Q->nacc_own, nb, hipMemcpyDeviceToHost));
   if (curstamp) NH_CHECK_HIP(hipMemcpy(curstamp, Q->curstamp, nb, hipMemcpyDeviceToHost));
-  if (reset & 1) NH_CHECK_HIP(hipMemset(Q->nacc_own, 0, nb));
-  if (reset & 2) NH_CHECK_HIP(hipMemset(Q->curstamp, 0xFF, nb));
+  if (reset & 1) NH_CHECK_HIP(nh_fill_now(c, Q->nacc_own, 0, nb));
+  if (reset & 2) NH_CHECK_HIP(nh_fill_now(c, Q->curstamp, 0xFF, nb));
   return NH_OK;
 }
 

@@ -68,8 +68,8 @@ class nh_hs_table(C.Structure):
 
 class nh_hs_syn(C.Structure):
     _fields_ = [("grid", C.c_int), ("nE", C.c_int), ("ldo", C.c_int), ("bcol", C.c_int),
-                ("ldB", C.c_int), ("pad", C.c_int), ("E_eV", C.c_void_p), ("B", C.c_void_p),
-                ("out", C.c_void_p)]
+                ("ldB", C.c_int), ("n1", C.c_int), ("E_eV", C.c_void_p), ("B", C.c_void_p),
+                ("out", C.c_void_p), ("out2", C.c_void_p), ("ldo2", C.c_int), ("pad2", C.c_int)]
 
 
 class nh_hs_blob(C.Structure):

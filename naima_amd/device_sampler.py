@@ -83,6 +83,11 @@ def _release_loop(ctx, res):
                 _lib._lib.nh_half_step_destroy(ctx.h, hs["plan"])
                 hs["plan"] = None
                 plan["hs"] = None
+            st = plan.get("stage") if plan else None
+            if st is not None and st.get("plan") is not None:
+                _lib._lib.nh_half_step_destroy(ctx.h, st["plan"])
+                st["plan"] = None
+                plan["stage"] = None
     except Exception:
         pass
     res["graphs"], res["plans"] = [], []
@@ -275,7 +280,7 @@ class DeviceLoop:
         ctx = self.ctx
         if self.fused:
             # proposal, parameter rows, weights, We: written by the preceding nh_step_front
-            self._plan["i"] = [0, 0, 0, 0]
+            self._plan["i"] = [0, 0, 0, 0, 0]
             ctx._plan = self._plan
             self._hook["used"] = False
             ctx._accept_hook = self._hook
@@ -454,13 +459,28 @@ class DeviceLoop:
         emit = plan["emit"]
         ntab = sum(1 for e in emit if e["kind"] == "tab")
         nsyn = len(emit) - ntab
+        # A model that takes its synchrotron spectrum twice with launches of other kernels in
+        # between -- the SSC seed of examples/CrabNebula_SynSSC.py:29-45: Synchrotron.flux at the
+        # seed's energies, a linear combination, the seed integral (sixteen walkers per wave: not
+        # a one-workgroup-per-walker job), Synchrotron.flux at the data's -- runs as TWO launches
+        # of the half-step kernel around those (Context._stage_a): plan["staged"]
+        between = {"nh_lincomb", "nh_ic_seed_walkers_tab", "nh_ic_seed_walkers"}
+        staged = nsyn == 2 and bool(set(plan["calls"]) & between)
+        if staged:
+            syn = [e for e in emit if e["kind"] == "syn"]
+            if os.environ.get("NAIMA_AMD_STAGED", "1") == "0" or emit[0]["kind"] != "syn" or \
+                    syn[0]["key"][1:9] != syn[1]["key"][1:9] or \
+                    any(e.get("E_host") is None for e in syn) or moments:
+                return False
+            allowed = allowed | between
+            nsyn = 1
         if not set(plan["calls"]) <= allowed or not emit or ntab > 4 or nsyn > 1:
             return False
         if plan["calls"].count("nh_lnprob") != 1:
             return False
         # every integrate call is either a recorded single-row reduction or an emission table
         if plan["calls"].count("nh_integrate_tables") != ntab + len(moments) or \
-                plan["calls"].count("nh_synchrotron") != nsyn:
+                plan["calls"].count("nh_synchrotron") != (2 if staged else nsyn):
             return False
         lds = 88 + 3 * sum(g[5] for g in grids) + sum(2 * grids[wptr[m[0][0]]][5] for m in moments)
         items = nspec = 0
@@ -472,12 +492,21 @@ class DeviceLoop:
                 nG, nK = k[4], k[8]
                 items += ((nK + 63) // 64) * ((nG - 1 + 31) // 32)
                 nspec += nK
-            else:
+            elif not staged:
                 nG, nE = k[8], k[10]
                 lds += 3 * nG + 4 * nE + 1 + 32 * nE
                 nspec += nE
         lds += min(items, 96) * 64 + nspec
-        return 8 * lds <= 140 * 1024
+        if staged:  # its other launch: one synchrotron component over both sets of energies
+            nG, nEa = syn[0]["key"][8], syn[0]["key"][10] + syn[1]["key"][10]
+            cd = 32
+            while cd > 1 and cd * nEa * 8 > 40 * 1024:
+                cd //= 2
+            lds = max(lds, 88 + 6 * nG + (5 + cd) * nEa + 8 * syn[0]["key"][10])
+        if 8 * lds > 140 * 1024:
+            return False
+        plan["staged"] = staged
+        return True
 
     def _gather_rows(self, send_ptr, recv, n, width):
         """all-gather of rows of `width` doubles, rank r contributing its block of the n rows
@@ -688,6 +717,8 @@ class DeviceLoop:
                     # (the one-launch kernel writes the cursor itself, every launch)
                     ctx.call("nh_half_step_begin_block", self._plan["hs"]["plan"], 0,
                              block["n"] if dev_hist else 0)
+                    if self._plan.get("stage") is not None:  # (its other launch: Context._stage_a)
+                        ctx.call("nh_half_step_begin_block", self._plan["stage"]["plan"], 0, 0)
                 else:
                     ctx.call("nh_memset", self.cursor, 0xFF, 4)  # -1: nothing accepted yet
                     if not self.mega:
@@ -833,7 +864,7 @@ class DeviceLoop:
         """can the rest of a block of moves run as ONE launch (nh_half_step_run)?  Needs the
         one-launch plan, a single rank, blobs (if kept) kept by the launch; the library has
         the last word (LDS, occupancy, the plan's shape)"""
-        if self._run is False or not self.mega or not self.s.use_graph:
+        if self._run is False or not self.mega or not self.s.use_graph or self._plan.get("staged"):
             return False
         if self.sharded and (self.s.comm.size < 2 or getattr(self.s.comm, "group", None) is None
                              or os.environ.get("NAIMA_AMD_SHARED", "1") == "0"):
@@ -1228,6 +1259,7 @@ class DeviceLoop:
                           % _lib._lib.nh_last_error().decode())
             self.mega = False
             self._plan["mega"] = False
+            self._plan["staged"] = False
             self.blobs_in_kernel = False
             self._hook.pop("blobs", None)
             self._hook.pop("blobs_in_kernel", None)

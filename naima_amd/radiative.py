@@ -678,7 +678,7 @@ class Synchrotron(BaseElectron):
             Bd = ctx.array(np.broadcast_to(np.asarray(Bv, dtype=float), (N,)))
             Bp = Bd.ptr
         out = ctx.emit_synchrotron(w, lw, Bp, ldB, N, gd, lx, gam.size, ctx.const(E_eV),
-                                   E_eV.size, keep=(Bd,))
+                                   E_eV.size, keep=(Bd,), E_host=E_eV)
         del Bd
         return self._result(ctx, out, N, E_eV.size, E)
 
@@ -997,7 +997,7 @@ class InverseCompton(BaseElectron):
             else:
                 sd_buf = ctx.array(np.broadcast_to(sdv, (N, se.size)))
                 sd_ptr = sd_buf.ptr
-            out = ctx.empty((N, nE))
+            out = ctx.plan_buffer(("seed-integral", name, N, nE), (N, nE))
             sed, ns = ctx.const(se), int(se.size)
             # the Aharonian-Atoyan kernel on (seed energy, gamma, photon energy) does not depend
             # on the walker: tabulated once per set of grids when HBM has room for it

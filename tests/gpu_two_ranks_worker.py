@@ -34,9 +34,9 @@ for b, x in enumerate(blobs):
 assert s._dev.graph is not None and s._dev.graph2 is not None
 assert s.n_walker_evals < 32 * 7  # each rank evaluated only its shard
 if name == "cfg4":
-    # the Crab model (its SSC seed integral is a launch of its own) is not a one-launch
-    # half-step: separate kernels around the all-gather
-    assert not s._dev.mega
+    # the Crab model (its SSC seed integral is a launch of its own): two launches of the half-step
+    # kernel around it (Context._stage_a), each rank over its block, around the all-gather
+    assert s._dev.mega and s._dev._plan.get("staged") and s._dev._plan.get("stage") is not None
 
 # without blobs run_mcmc takes the merged form of the sharded loop (accept + next evaluation
 # as one graph between all-gathers)

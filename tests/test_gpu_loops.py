@@ -774,6 +774,26 @@ def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
     assert_allclose(out["1"][1], out["0"][1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("name,nw,nranks", [("cfg1", 32, 3), ("cfg3", 40, 4)], ids=["cfg1-3", "cfg3-4"])
+def test_sharded_loop_three_ranks_again_and_again(na, name, nw, nranks):
+    """three (four) processes on the one GPU, a fresh sampler a hundred times over: every
+    repetition's chain is the single process's.  (What this caught: a plan's counters zeroed by
+    the NULL stream's hipMemset, which orders nothing against the context's non-blocking streams
+    and for device memory returns before the fill -- with three processes on the GPU the fill
+    landed some launches later about once in thirty samplers and reset the slice counter in the
+    middle of a block of moves.  nh_fill_now.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() % 1000)
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nranks,
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.join(root, "tests", "gpu_repeat_ranks_worker.py"), name, str(nw), "100", "5"],
+        cwd=root, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+
+
 @pytest.mark.parametrize("name,nw,nranks", [("cfg3", 32, 2), ("cfg5", 64, 2), ("cfg2", 48, 2),
                                             ("cfg3", 30, 2), ("cfg3", 40, 4), ("cfg1", 32, 3)],
                          ids=["cfg3-32", "cfg5-64", "cfg2-48", "cfg3-30-uneven-blocks",
@@ -815,6 +835,12 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
                 blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
                 acc=s.acceptance_fraction)
     assert want["chain"].shape[0] == 87
+    # (first: every rank holds what rank 0 holds -- a failure here is the shared loop's, one below
+    # is a difference between the shared loop and one process)
+    for r in range(1, nranks):
+        for key in want:
+            assert np.array_equal(np.load(tmp_path / ("%s_%d.npy" % (key, r))),
+                                  np.load(tmp_path / ("%s_0.npy" % key)), equal_nan=True), (key, r)
     for r in range(nranks):
         for key, w in want.items():
             have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
