@@ -559,7 +559,7 @@ def main():
         # identical results; such proposals are walker-steps of `value` like any other.  Counted
         # by the kernels over every step the timed sampler made, warm-up included)
         "proposals_forbidden_by_prior": int(sampler.prior_forbidden_proposals),
-        "proposals_total": int(sampler.n_walker_evals) * (comm.size if device else 1),
+        "proposals_total": int(sampler.steps_total) * int(nwalkers),
         "loop": ("host" if not device else
                  "device, resident workgroups: one launch of k_half_step_run per block of moves "
                  "(<= 32 steps), walkers handed over by tagged records" if resident else

@@ -679,6 +679,15 @@ class Context:
             d.ncomp, d.nE = 1, n1
             d.conv, d.flux, d.err_lo, d.err_hi = ones.ptr, zeros.ptr, ones.ptr, ones.ptr
             d.ul, d.cl, d.lp, d.nterms = izero.ptr, half.ptr, None, 0
+            # the prior of the recorded evaluation: a proposal it forbids is integrated by nobody
+            # (its synchrotron spectrum is written as zeros, the seed field made of it is empty and
+            # the SSC kernel packs such walkers out of its groups: k_ssc_order) -- as the plan's
+            # own launch does for it
+            pt = plan.get("prior_terms")
+            if pt is not None:
+                for q in range(pt[1]):
+                    d.terms[q] = pt[0][q]
+                d.nterms = pt[1]
             d.model_out, d.total, d.nblobs, d.send_width = None, dummy.ptr, 0, 0
             h = _dp()
             _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))

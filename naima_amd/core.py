@@ -167,6 +167,10 @@ def lnprobmodel(model, data, lp=None, blobs=()):
             terms, nterms = lp.packed()  # evaluated inside the likelihood kernel
             if terms is None:
                 lpd = lp.evaluate()
+            elif ctx._plan is not None and ctx._plan["mode"] == "record":
+                # (a staged plan's first launch evaluates the prior too: a proposal it forbids
+                # gets no synchrotron spectrum, hence no seed photons -- Context._stage_a)
+                ctx._plan["prior_terms"] = (terms, nterms)
         elif lp is not None:
             lpd = lp.dense()
         args = (m.comps(), len(m.terms), N, nE, dd.conv(model.unit, m.colfac),

@@ -129,9 +129,72 @@ extern "C" int nh_table_ic_seed(nh_ctx* c, const double* gam, int nG, const doub
 //   [2W, 2W+4)  lx = ln(eps0_s/eps0_{s-1}), 1/lx, 2^-10/lx (series threshold in units of
 //               dl' = dl/lx), 0     -- record 0: 1/eps0_0, 2 ln eps0_0 in the first two
 //   [2W+4, 2W+6)  1/eps0_{s+1}, 2 ln eps0_{s+1} (in mec2): the NEXT node's fic operands
+// A walker whose seed density is zero at EVERY node has an SSC spectrum of exactly 0 (every
+// segment of the inner trapz_loglog has a zero node: utils.py:347-348) -- and that is what the
+// step loop hands over for every proposal its prior forbids (the half-step kernel integrates
+// nothing for those: a third of cfg4's proposals while its walkers sit against the prior's
+// bounds).  The walkers with something to integrate are packed into the first groups:
+//   ord[0] = their number, ord[1 + p] = the walker at position p (the others behind them, in
+//   order), ord[1 + N + w] = 1 where walker w is one of them.
+// One workgroup: N is an ensemble's half at most.
+__global__ __launch_bounds__(1024) void k_ssc_order(const double* __restrict__ sd, int N, int ns,
+                                                    int* __restrict__ ord) {
+  __shared__ int cnt[1024];
+  __shared__ int nlive_s;
+  const int t = threadIdx.x, T = blockDim.x, lane = t & 63;
+  int* live = ord + 1 + N;
+  // a wave per walker, its lanes across the seed nodes (one round trip per 64 nodes)
+  // (four walkers' loads in flight per wave: the kernel is round trips and nothing else)
+  const int nwv = T >> 6;
+  for (int w = t >> 6; w < N; w += 4 * nwv) {
+    bool any[4] = {false, false, false, false};
+    for (int s = lane; s < ns; s += 64) {
+      double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = sd[(long long)min(w + q * nwv, N - 1) * ns + s];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) any[q] = any[q] || v[q] != 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool some = __builtin_amdgcn_ballot_w64(any[q]) != 0ull;
+      if (lane == 0 && w + q * nwv < N) live[w + q * nwv] = some ? 1 : 0;
+    }
+  }
+  __syncthreads();  // (the flags are this workgroup's own stores)
+  const int per = (N + T - 1) / T;  // consecutive walkers per thread: the order is kept
+  const int w_lo = min(t * per, N), w_hi = min(w_lo + per, N);
+  int mine = 0;
+  for (int w = w_lo; w < w_hi; ++w) mine += live[w];
+  cnt[t] = mine;
+  __syncthreads();
+  // exclusive scan of the counts: one wave, 1024 / 64 = 16 counts per lane at most
+  if (t < 64) {
+    const int chunk = (T + 63) / 64;
+    int sum = 0;
+    for (int q = 0; q < chunk; ++q) sum += t * chunk + q < T ? cnt[t * chunk + q] : 0;
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (t >= off) incl += v;
+    }
+    int run = incl - sum;
+    for (int q = 0; q < chunk; ++q)
+      if (t * chunk + q < T) { const int c = cnt[t * chunk + q]; cnt[t * chunk + q] = run; run += c; }
+    if (t == 63) { nlive_s = incl; ord[0] = incl; }
+  }
+  __syncthreads();
+  int pl = cnt[t];                       // walkers with a density before mine
+  int pd = nlive_s + (w_lo - cnt[t]);    // ... and where my first one without goes
+  for (int w = w_lo; w < w_hi; ++w) {
+    if (live[w]) ord[1 + pl++] = w;
+    else ord[1 + pd++] = w;
+  }
+}
+
 template <int SSC_W>
 __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restrict__ sd, int N,
-                           int ns, double* __restrict__ rec) {
+                           int ns, const int* __restrict__ ord, double* __restrict__ rec) {
   constexpr int REC = SSC_REC(SSC_W);
   static_assert((SSC_W & (SSC_W - 1)) == 0 && REC % 4 == 0, "record layout");
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,9 +203,10 @@ __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restri
   const int slot = (int)(idx % REC);
   const int s = (int)((idx / REC) % ns);
   const int grp = (int)(idx / ((long long)REC * ns));
+  if (grp * SSC_W >= ord[0]) return;  // (a group without a walker to integrate: never read)
   double v = 0.0;
   if (slot < 2 * SSC_W) {
-    const long long w = min(grp * SSC_W + (slot & (SSC_W - 1)), N - 1);
+    const long long w = ord[1 + min(grp * SSC_W + (slot & (SSC_W - 1)), N - 1)];
     const double b = sd[w * ns + s];
     if (slot < SSC_W) {
       v = b * NH_MEC2_EV;
@@ -246,13 +310,13 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
     const double* __restrict__ w, const double* __restrict__ dlw, int N,
     const double* __restrict__ gam, const double* __restrict__ lx, int nG,
     const double* __restrict__ E_eV, int nE, const double* __restrict__ rec, int ns, int ntile,
-    double* __restrict__ partial) {
+    const int* __restrict__ ord, double* __restrict__ partial) {
   constexpr int REC = SSC_REC(W);
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x % ntile, grp = blockIdx.x / ntile;
   const int k = blockIdx.y * C + ch;  // this wave's photon energy (wave-uniform)
-  if (k >= nE) return;
+  if (k >= nE || grp * W >= ord[0]) return;  // (ord: k_ssc_order)
   const double eg = E_eV[k] / NH_MEC2_EV;
   const int w0 = grp * W;
   const int i = tile * SSC_TILE + lane;  // this lane's node
@@ -334,14 +398,15 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers(
   const double lxi = lx[seg ? i : 0];
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    const size_t row = (size_t)min(w0 + j, N - 1) * (size_t)nG;
+    const int wj = ord[1 + min(w0 + j, N - 1)];  // the walker at this position of the packed order
+    const size_t row = (size_t)wj * (size_t)nG;
     const double Kv = in[j] * pref;
     const double Kn = __shfl_down(Kv, 1, 64);
     const double wi = w[row + ic], wn = w[row + (seg ? i + 1 : ic)];
     const double dl = dlw[row + (seg ? i : 0)] + SSC_LOG(fabs(Kn * nh_rcp(Kv)));
     double t = nh_seg_term(wi * Kv, wn * Kn, dl, lxi);
     t = nh_wave_sum(seg ? t : 0.0);
-    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + (w0 + j)) * nE + k] = t;
+    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + wj) * nE + k] = t;
   }
 #undef SSC_LOG
 }
@@ -422,14 +487,15 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
     const double* __restrict__ gam, const double* __restrict__ lx, int nG, int nE,
     const double* __restrict__ rec, int ns, int ntile, int groups, int ngchunk,
     const ssc_d2* __restrict__ F, const int2* __restrict__ win, const int* __restrict__ order,
-    double* __restrict__ partial) {
+    const int* __restrict__ ord, double* __restrict__ partial) {
   constexpr int REC = SSC_REC(W);
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
   const int slot = (by / ngchunk) * 8 + bx;
   const int grp = (by % ngchunk) * C + ch;
-  if (slot >= nE * ntile || grp >= groups) return;
+  // (ord: k_ssc_order -- the groups behind the last walker with a seed density have nothing to do)
+  if (slot >= nE * ntile || grp >= groups || grp * W >= ord[0]) return;
   const int tk = __builtin_amdgcn_readfirstlane(order[slot]);
   const int k = tk / ntile, tile = tk - k * ntile;
   const int w0 = grp * W;
@@ -495,7 +561,8 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
   const double lxi = lx[seg ? i : 0];
 #pragma unroll
   for (int j = 0; j < W; ++j) {
-    const size_t row = (size_t)min(w0 + j, N - 1) * (size_t)nG;
+    const int wj = ord[1 + min(w0 + j, N - 1)];  // the walker at this position of the packed order
+    const size_t row = (size_t)wj * (size_t)nG;
     const double Kv = in[j] * pref;
     const double Kn = __shfl_down(Kv, 1, 64);
     const double wi = w[row + ic], wnx = w[row + (seg ? i + 1 : ic)];
@@ -503,17 +570,21 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
                       ssc_log(fabs(Kn * nh_rcp(Kv)), L0, L1, L2, L3, L4, L5, L6);
     double t = nh_seg_term(wi * Kv, wnx * Kn, dl, lxi);
     t = nh_wave_sum(seg ? t : 0.0);
-    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + (w0 + j)) * nE + k] = t;
+    if (lane == 0 && w0 + j < N) partial[((size_t)tile * N + wj) * nE + k] = t;
   }
 }
 
 __global__ void k_ssc_finish(const double* __restrict__ partial, int nsuper, int N, int nE,
-                             const double* __restrict__ E_eV, double* __restrict__ out, int ldo) {
+                             const double* __restrict__ E_eV, const int* __restrict__ ord,
+                             double* __restrict__ out, int ldo) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)N * nE) return;
   int wi = (int)(idx / nE), k = (int)(idx % nE);
   double s = 0.0;
-  for (int y = 0; y < nsuper; ++y) s += partial[((long long)y * N + wi) * nE + k];
+  // (a walker without a seed density: nobody wrote its partial sums -- an exact 0, see k_ssc_order.
+  // One that shares a group with walkers that have one was integrated to the same 0.)
+  if (ord[1 + N + wi])
+    for (int y = 0; y < nsuper; ++y) s += partial[((long long)y * N + wi) * nE + k];
   const double E = E_eV[k];
   // lum = uf*Eph*integral, spec = lum/E   (uf = 1), radiative.py:676-687
   out[(long long)wi * ldo + k] = s * (E / NH_MEC2_EV) / E;
@@ -535,26 +606,30 @@ extern "C" int nh_ic_seed_walkers(nh_ctx* c, const double* w, const double* dlw,
   const int groups = (N + W - 1) / W;
   const int nsuper = (nG - 1 + SSC_TILE - 1) / SSC_TILE;  // tiles of the gamma grid
   const size_t nd = (size_t)groups * ns * SSC_REC(W);
-  const size_t need = (nd + SSC_REC(W) + (size_t)nsuper * N * nE) * sizeof(double);
+  const size_t nord = ((size_t)(1 + 2 * (size_t)N) * sizeof(int) + 7) / 8;  // (in doubles)
+  const size_t need = (nd + SSC_REC(W) + (size_t)nsuper * N * nE + nord) * sizeof(double);
   void* sc = nullptr;
   int rc = nh_scratch(c, need, &sc);
   if (rc) return rc;
   double* rec = static_cast<double*>(sc);
   double* partial = rec + nd + SSC_REC(W);
+  int* ord = reinterpret_cast<int*>(partial + (size_t)nsuper * N * nE);
   nh_prof_scope ps(c, NH_K_SSC);
   const dim3 gp((unsigned)((nd + 255) / 256)), gk(groups * nsuper, (nE + C - 1) / C);
+  hipLaunchKernelGGL(k_ssc_order, dim3(1), dim3(1024), 0,
+                     c->stream, seed_dens, N, ns, ord);
   if (W == 16) {
-    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, ord, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers<C, 16>), gk, dim3(64 * C), 0, c->stream, w, dlw, N, gam,
-                       lx, nG, E_eV, nE, rec, ns, nsuper, partial);
+                       lx, nG, E_eV, nE, rec, ns, nsuper, ord, partial);
   } else {
-    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, ord, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers<C, 8>), gk, dim3(64 * C), 0, c->stream, w, dlw, N, gam,
-                       lx, nG, E_eV, nE, rec, ns, nsuper, partial);
+                       lx, nG, E_eV, nE, rec, ns, nsuper, ord, partial);
   }
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                     partial, nsuper, N, nE, E_eV, out, ldo);
+                     partial, nsuper, N, nE, E_eV, ord, out, ldo);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }
@@ -612,12 +687,14 @@ extern "C" int nh_ic_seed_walkers_tab(nh_ctx* c, const double* w, const double* 
   const int ntile = (nG - 1 + SSC_TILE - 1) / SSC_TILE;
   NH_REQUIRE((long long)nE * ntile < (1LL << 27), "too many (energy, tile) pairs");
   const size_t nd = (size_t)groups * ns * SSC_REC(W);
-  const size_t need = (nd + SSC_REC(W) + (size_t)ntile * N * nE) * sizeof(double);
+  const size_t nord = ((size_t)(1 + 2 * (size_t)N) * sizeof(int) + 7) / 8;  // (in doubles)
+  const size_t need = (nd + SSC_REC(W) + (size_t)ntile * N * nE + nord) * sizeof(double);
   void* sc = nullptr;
   int rc = nh_scratch(c, need, &sc);
   if (rc) return rc;
   double* rec = static_cast<double*>(sc);
   double* partial = rec + nd + SSC_REC(W);
+  int* ord = reinterpret_cast<int*>(partial + (size_t)ntile * N * nE);
   const int2* win = static_cast<const int2*>(table);
   const int* order = reinterpret_cast<const int*>(win + (size_t)nE * ntile);
   const ssc_d2* F = reinterpret_cast<const ssc_d2*>(static_cast<const char*>(table) +
@@ -626,18 +703,20 @@ extern "C" int nh_ic_seed_walkers_tab(nh_ctx* c, const double* w, const double* 
   const dim3 gp((unsigned)((nd + 255) / 256));
   const unsigned tk8 = (unsigned)((nE * ntile + 7) / 8);
   const dim3 gk(tk8 * ngchunk * 8);
+  hipLaunchKernelGGL(k_ssc_order, dim3(1), dim3(1024), 0,
+                     c->stream, seed_dens, N, ns, ord);
   if (W == 16) {
-    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL(k_ssc_prep<16>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, ord, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 16>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
-                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, partial);
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, ord, partial);
   } else {
-    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, rec);
+    hipLaunchKernelGGL(k_ssc_prep<8>, gp, dim3(256), 0, c->stream, seed_E, seed_dens, N, ns, ord, rec);
     hipLaunchKernelGGL((k_ic_seed_walkers_tab<C, 8>), gk, dim3(64 * C), 0, c->stream, w, dlw, N,
-                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, partial);
+                       gam, lx, nG, nE, rec, ns, ntile, groups, ngchunk, F, win, order, ord, partial);
   }
   long long tot = (long long)N * nE;
   hipLaunchKernelGGL(k_ssc_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                     partial, ntile, N, nE, E_eV, out, ldo);
+                     partial, ntile, N, nE, E_eV, ord, out, ldo);
   NH_CHECK_HIP(hipGetLastError());
   return NH_OK;
 }

@@ -686,6 +686,7 @@ class DeviceLoop:
                 self._moves_append(moves, self.KSTEPS, ahead=True)
             it += want
             s.iteration += want
+            s.steps_total += want
             if block is not None:
                 block["n"] += want
             yield DeviceState(self, rng)
@@ -783,6 +784,7 @@ class DeviceLoop:
                 k += g
                 it += g
                 s.iteration += g
+                s.steps_total += g
                 if block is not None:
                     kk = block["n"]
                     if not dev_hist:

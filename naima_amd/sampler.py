@@ -84,6 +84,7 @@ class EnsembleSampler:
         # (the reference evaluates the model and discards it, core.py:103-119); counted for the
         # bench line, which credits them as walker-steps like every other proposal
         self.prior_forbidden_proposals = 0
+        self.steps_total = 0  # ensemble steps since the sampler was made (reset() keeps it)
         # device=True: ensemble, proposals, log-probabilities and blobs live in HBM; the
         # launch sequence of one half-step (propose -> model -> likelihood -> accept)
         # is captured into a hipGraph and replayed (needs naima_style log_prob_fn)
@@ -258,6 +259,7 @@ class EnsembleSampler:
                     for cur, nb in zip(self._cur_blobs, new):
                         cur[acc_idx] = self._gather_rows(nb, len(S))[accepted]
             self.iteration += 1
+            self.steps_total += 1
             if store:
                 self._chain.append(coords.copy())
                 self._logp.append(logp.copy())

@@ -59,6 +59,24 @@ for w in worst[:2]:
     print("  workgroup %d:" % w, " ".join("%s=%.2f" % (n, v) for n, v in zip(names, (allst[w] - allst[w, 0]) / 100.0)))
     print("     per wave (end us, tab, syn):", [(round((pw[w, q, 0] - allst[w, 0]) / 100.0, 1), int(pw[w, q, 1]), int(pw[w, q, 2] & 255)) for q in range(16)],
           "nA", int(pw[w, 0, 2] >> 8 & 4095), "Cd", int(pw[w, 0, 2] >> 20))
+stage = s._dev._plan.get("stage")
+if stage is not None:
+    # the staged plan's other launch (Context._stage_a): its phases the same way
+    import ctypes as C
+    th, bl, ld = C.c_int(), C.c_int(), C.c_longlong()
+    _lib._chk(_lib._lib.nh_half_step_info(stage["plan"], C.byref(th), C.byref(bl), C.byref(ld)))
+    out = np.zeros(67840, dtype=np.int64)
+    _lib._chk(_lib._lib.nh_half_step_stamps(ctx.h, stage["plan"], out.ctypes.data))
+    print("stage A: threads", th.value, "blocks", bl.value, "lds", ld.value)
+    a1 = out[:128].reshape(8, 16)[:, :12].astype(float)
+    for b in (0, 3, 7):
+        print("  block", b, " ".join("%s=%.2f" % (n, v) for n, v in zip(names, (a1[b] - a1[b, 0]) / 100.0)))
+    nb1 = bl.value
+    st1, en1 = out[256:256 + nb1].astype(float), out[1280:1280 + nb1].astype(float)
+    print("  all %d workgroups: duration median %.2f max %.2f us; first start -> last end %.2f us"
+          % (nb1, np.median(en1 - st1) / 100.0, (en1 - st1).max() / 100.0, (en1.max() - st1.min()) / 100.0))
+    print("  block 0 per wave: item-phase start / end, table items, syn items:",
+          [(round((out[176 + w] - out[0]) / 100.0, 1), round((out[128 + w] - out[0]) / 100.0, 1), int(out[144 + w]), int(out[160 + w])) for w in range(th.value // 64)])
 if name == "cfg3":
     from naima_amd import constants as K
     l0, l1 = np.log10(1e9 / K.MEC2_EV), 9.0

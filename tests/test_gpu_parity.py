@@ -861,7 +861,7 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
     orig = ctx.call
     monkeypatch.setattr(ctx, "call", lambda name, *a: (seen.append(name), orig(name, *a))[1])
 
-    def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=()):
+    def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=(), empty=()):
         E = np.geomspace(1e3, 3e13, nE) if nE > 1 else np.array([2e9])
         se = np.geomspace(1e-6, 1e4, ns)
         base = 1e3 * (se / 1e-2) ** -1.4 * np.exp(-se / 2e3)
@@ -870,6 +870,8 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
             sd[:, z] = 0.0
         if zeros and N > 2:
             sd[1, ns // 3] = 0.0  # ... and a zero that only one walker has
+        for wz in empty:  # walkers WITHOUT a seed field: packed out of the groups (k_ssc_order)
+            sd[wz, :] = 0.0
         amp = 10 ** (33 + 0.05 * rng.standard_normal(N))
         alpha = 2.3 + 0.1 * rng.standard_normal(N)
         pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, 30 * u.TeV)
@@ -884,6 +886,15 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
             ne = O.nelec_on(opd, gam)
             ref = O.ic_seed_spectrum(E, gam, ne, dict(type="array", energy=se, density=sd[i]))
             assert_allclose(got[i], ref, rtol=RT, atol=np.abs(ref).max() * 1e-200)
+        for wz in empty:
+            assert np.all(got[wz] == 0.0)
+        if empty:  # ... and their neighbours in the packed order are the walkers they were
+            for i in sorted(set(range(N)) - set(empty))[::7]:
+                opd = O.ParticleDist("ExponentialCutoffPowerLaw", amplitude=amp[i], e_0=1e13,
+                                     alpha=alpha[i], e_cutoff=30e12, beta=1.0)
+                ref = O.ic_seed_spectrum(E, gam, O.nelec_on(opd, gam),
+                                         dict(type="array", energy=se, density=sd[i]))
+                assert_allclose(got[i], ref, rtol=RT, atol=np.abs(ref).max() * 1e-200)
 
     check(N=1, ns=12, nE=9, Eemin_eV=1e9, Eemax_eV=1e14, nEed=20)
     check(N=9, ns=2, nE=5, Eemin_eV=1e9, Eemax_eV=1e13, nEed=10)        # two seed nodes, 40 nodes
@@ -891,6 +902,12 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
     check(N=33, ns=25, nE=1, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, zeros=(5,))  # 17 -> 10 nodes
     check(N=8, ns=40, nE=66, Eemin_eV=1e10, Eemax_eV=1e13, nEed=100)      # 300 nodes, 5 tiles
     check(N=150, ns=33, nE=19, Eemin_eV=1e9, Eemax_eV=1e14, nEed=30, zeros=(2,))  # 10 groups: two chunks
+    # walkers without a seed density (what a proposal the prior forbids hands over): some, scattered
+    # -- the last group of the packed order is mixed --, all but one, and every one
+    check(N=40, ns=20, nE=7, Eemin_eV=1e9, Eemax_eV=1e13, nEed=30, empty=(0, 3, 4, 17, 38, 39))
+    check(N=40, ns=20, nE=7, Eemin_eV=1e9, Eemax_eV=1e13, nEed=30, empty=tuple(set(range(40)) - {21}))
+    check(N=9, ns=20, nE=7, Eemin_eV=1e9, Eemax_eV=1e13, nEed=30, empty=tuple(range(9)))
+    check(N=1100, ns=8, nE=3, Eemin_eV=1e9, Eemax_eV=1e11, nEed=20, empty=tuple(range(5, 1100, 3)))
     assert ("nh_ic_seed_walkers_tab" in seen) == (tabulated == "1")
     assert ("nh_ic_seed_walkers" in seen) == (tabulated == "0")
 
