@@ -1266,8 +1266,8 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     H.o_ig23 = off; off += nG;
     H.o_sq = off; off += 3 * s.nE;
     H.o_amap = off; off += s.nE + 1;  // 2 nE ints
-    int cdmax = 32;
-    while (cdmax > 1 && (size_t)cdmax * s.nE * 8 > 40 * 1024) cdmax >>= 1;
+    int cdmax = (int)(((size_t)nh_env_int("NH_HS_PART_KB", 40) * 1024) / ((size_t)s.nE * 8));  // (partial sums: 40 KB of LDS at most)
+    cdmax = cdmax > 32 ? 32 : (cdmax < 1 ? 1 : cdmax);
     C.syn_cdmax = cdmax;
     H.o_part_s = off; off += cdmax * s.nE;
     H.syn_spec_off = nspec;
@@ -1338,7 +1338,8 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
       maxseg = nseg > maxseg ? nseg : maxseg;
     }
     const int free_waves = (threads / 64 - d->nmoms) * split;
-    const int per_tile = free_waves / tiles > 1 ? free_waves / tiles : 1;
+    int per_tile = free_waves / tiles > 1 ? free_waves / tiles : 1;
+    per_tile *= nh_env_int("NH_HS_TAB_ROUNDS", 1);  // (tuning experiments: that many rounds of shorter items)
     seg = (maxseg + per_tile - 1) / per_tile;
     if (seg < 8) seg = 8;
   }

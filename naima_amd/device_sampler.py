@@ -499,9 +499,7 @@ class DeviceLoop:
         lds += min(items, 96) * 64 + nspec
         if staged:  # its other launch: one synchrotron component over both sets of energies
             nG, nEa = syn[0]["key"][8], syn[0]["key"][10] + syn[1]["key"][10]
-            cd = 32
-            while cd > 1 and cd * nEa * 8 > 40 * 1024:
-                cd //= 2
+            cd = max(1, min(32, (40 * 1024) // (8 * nEa)))
             lds = max(lds, 88 + 6 * nG + (5 + cd) * nEa + 8 * syn[0]["key"][10])
         if 8 * lds > 140 * 1024:
             return False
