@@ -660,6 +660,12 @@ int nh_half_step_run_info(const nh_halfstep_run* run, int* grid, int* threads,
  * grid is log-uniform, as radiative.py:147-154 makes it), 0 = the direct form (any grid; no
  * synchrotron component). */
 int nh_half_step_run_syn_info(const nh_halfstep_run* run, int* mode, int* nodes_per_piece, int* pieces);
+/* Where the loop's table work items (the trapz_loglog over the particle grid of radiative.py:684,
+ * 1534-1536) read their rows: in_registers = 1 when the loop runs the instance of a table-only
+ * model whose items keep their rows of {K, dlnK} in vector registers for the whole launch
+ * (workgroups of 512 threads; an emission table does not depend on the walker), `nodes_max` the
+ * rows per lane that instance can hold; 0 = streamed from the L2s every half-step. */
+int nh_half_step_run_table_info(const nh_halfstep_run* run, int* in_registers, int* nodes_max);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
  * (workgroup, slice handled): start | records in | packs done | weights done | own items
  * done | all items done | spectra summed | record published; then [64][4][16]: for workgroup

@@ -128,6 +128,7 @@ _SIGS = {
     "nh_half_step_run_counters": [_dp, _dp, _dp, _dp, _i],
     "nh_half_step_run_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_run_syn_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "nh_half_step_run_table_info": [_dp, C.POINTER(_i), C.POINTER(_i)],
     "nh_half_step_run_stamps": [_dp, _dp, _dp],
     "nh_half_step_run_destroy": [_dp, _dp],
     "nh_general_electron": [_dp, _i, _dp, _i, _dp, _d, _dp, _d, _dp, _i, _dp, _dp, _dp, _i, _dp, _i,

@@ -1315,6 +1315,50 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     if (work >= nh_env_int("NH_HS_SPLIT_MIN_WORK", 1 << 20))
       while (split * 2 <= kmax && (long long)d->nloc * split * 2 <= ncu) split *= 2;
   }
+  // ---- a table-only model whose items' rows fit a lane's registers: workgroups of 512 threads
+  // (256 vector registers per lane), for the resident loop's register-resident items (nh_hs.h:
+  // hs_rt_item; k_half_step_run<false, ., false, RT>).  The rows an item walks start at the first
+  // one in which a column is non-zero (the resident loop's sorted copies: at least that far up).
+  bool rt_plan = false;
+  // (launches of at most one workgroup per CU: a workgroup of this instance has a CU to itself)
+  if (d->syn.grid < 0 && d->ntab > 0 && threads >= 256 && (long long)d->nloc * split <= ncu &&
+      nh_env_int("NH_HS_RT", 1) != 0) {
+    bool fits = true;
+    int tiles = 0;
+    for (int t = 0; t < d->ntab; ++t) {
+      tiles += (d->tab[t].nK + 63) / 64;
+    }
+    const int t_rt = threads > 512 ? 512 : threads;
+    const int free_waves = (t_rt / 64 - d->nmoms) * split;
+    fits = fits && free_waves >= 1 && tiles <= free_waves;
+    const int per_tile = fits ? free_waves / tiles : 1;
+    if (fits && nh_sync(c) != NH_OK) fits = false;
+    for (int t = 0; t < d->ntab && fits; ++t) {
+      const nh_hs_table& tb = d->tab[t];
+      const int nG = d->grids[tb.grid].nG, nK = tb.nK;
+      std::vector<double> kd((size_t)nG * nK * 2);
+      if (hipMemcpy(kd.data(), tb.KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        fits = false;
+        break;
+      }
+      int r0 = nG - 1;
+      for (int i = 0; i < nG - 1 && r0 == nG - 1; ++i)
+        for (int k = 0; k < nK; ++k)
+          if (kd[((size_t)i * nK + k) * 2] != 0.0) { r0 = i; break; }
+      const int sub = nK <= 32 ? (nK <= 16 ? (nK <= 8 ? (nK <= 4 ? (nK <= 2 ? (nK <= 1 ? 64 : 32) : 16) : 8) : 4) : 2) : 1;
+      const int per = (nG - 1 - r0 + per_tile - 1) / per_tile;
+      fits = (per + sub - 1) / sub + 1 <= HS_RT_NODES;
+      if (getenv("NH_HS_RT_DEBUG"))
+        fprintf(stderr, "RT: table %d nG %d nK %d r0 %d per_tile %d per %d sub %d nodes %d fits %d\n", t, nG, nK, r0,
+                per_tile, per, sub, (per + sub - 1) / sub + 1, (int)fits);
+    }
+    if (getenv("NH_HS_RT_DEBUG")) fprintf(stderr, "RT: fits %d threads %d nmoms %d split %d\n", (int)fits, threads, d->nmoms, split);
+    if (fits) {
+      threads = t_rt;
+      rt_plan = true;
+    }
+  }
   // ---- table reductions: work items of `seg` segments x 64 columns ----
   // With a synchrotron component the items interleave with its (issue-bound) items and 32
   // segments keep the waves evenly loaded; without one, ONE round of equal items over the
@@ -1458,6 +1502,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   P->threads = threads;
   P->blocks = d->nloc;
   P->split = split;
+  P->rt = rt_plan ? 1 : 0;
   P->dev = nullptr;
   P->words = nullptr;
   P->syn_c = nullptr;

@@ -143,6 +143,7 @@ struct nh_halfstep_plan {
   int* tick;         // device: arrival counters of a split launch, or NULL
   size_t lds_bytes;
   int threads, blocks, split;  // split = K workgroups per walker (gridDim.y)
+  int rt;  // the workgroup size was chosen for register-resident table items (hs_rt_item)
   long long* dbg;
 };
 
@@ -366,6 +367,97 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   return acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// A table item whose rows stay in REGISTERS for the whole launch (the resident loop of a
+// table-only model, k_half_step_run<false, ., false, RT>): an emission table does not depend on
+// the walker, a resident workgroup's waves take the same items slice after slice, and an item of
+// such a model is one round trip to the L2 and a dozen segments of arithmetic -- three to six
+// microseconds of a twelve-microsecond slice spent waiting for bytes that were the same bytes
+// the slice before (cfg5: 134 KB of walked rows per walker and half-step).  Workgroups of 512
+// threads own 256 vector registers per lane; RT nodes of {K, dlnK} take 4 RT of them.
+// The arithmetic is hs_table_item_packed's / hs_table_item's, operand for operand.
+#define HS_RT_NODES 28  // nodes per lane a register-resident item may hold (112 registers)
+template <int RT>
+struct hs_rt_item {
+  double K[RT], d[RT];   // node q of this lane's sub-range: K and the log-ratio of the segment that starts there
+  int ix;                // the item (index into the partial sums), or -1: this wave has none / not cached
+  int t, tile, len, owed, nKp, sub, pre;
+  unsigned aw, ad, al;   // LDS byte addresses of w | dlw / lx | 2^-10 / lx at the lane's first segment
+};
+
+template <int RT>
+__device__ __forceinline__ bool hs_rt_load(hs_rt_item<RT>& c, const hs_tab& t, const double* KD,
+                                           int nG, int tile, int s0, int s1, int lane,
+                                           const double* ws, const double* ds, const double* lxs) {
+  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
+  const int sub = __builtin_amdgcn_readfirstlane(t.sub);
+  const int nKp = sub > 1 ? __builtin_amdgcn_readfirstlane(t.nKp) : 64;
+  const int len = (s1 - s0 + sub - 1) / sub;  // segments per lane (wave-uniform)
+  if (len + 1 > RT || len < 1) return false;
+  const int k = sub > 1 ? (lane & (nKp - 1)) : tile * 64 + lane, h = sub > 1 ? lane / nKp : 0;
+  const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
+  const unsigned long long kd = (unsigned long long)KD;
+  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
+  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+  const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
+  const __amdgpu_buffer_rsrc_t rKD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)((unsigned)nG * nK * 16u), 0x00020000);
+  const unsigned rowb = nK * 16u;
+  const int sl = s0 + h * len, se = min(s1, sl + len);
+  const unsigned ob = ((unsigned)sl * nK + kk) * 16u;  // (rows past the table read 0)
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    c.K[q] = 0.0;
+    c.d[q] = 0.0;
+    if (q <= len) hs_buf_kd(rKD, ob + (unsigned)q * rowb, c.K[q], c.d[q]);
+  }
+  c.len = len;
+  c.owed = se - sl;
+  c.nKp = nKp;
+  c.sub = sub;
+  c.aw = hs_lds_addr(ws + sl);
+  c.ad = hs_lds_addr(ds + sl);
+  c.al = hs_lds_addr(lxs + sl);
+  return true;
+}
+
+// SIGNED = false: a non-negative table on pre-divided log-ratios (ds = dlw / lx, lxs = 2^-10 / lx);
+// true: any table (ds = dlw, lxs = lx; a sign change is a NaN log-ratio: nh_seg_signed)
+template <int RT, bool SIGNED>
+__device__ __forceinline__ double hs_rt_compute(const hs_rt_item<RT>& c) {
+  double acc = 0.0;
+  double u1 = hs_lds_at(c.aw, 0) * c.K[0], d1 = c.d[0];
+  const int len = __builtin_amdgcn_readfirstlane(c.len);  // (scalar branches below, no exec masks)
+  const int sub = __builtin_amdgcn_readfirstlane(c.sub);
+  if (sub > 1) {  // hs_table_item_packed: terms added, lanes past their sub-range masked
+#pragma unroll
+    for (int q = 0; q < RT - 1; ++q)
+      if (q < len) {
+        const double u2 = hs_lds_at(c.aw, q + 1) * c.K[q + 1];
+        const double dl = hs_lds_at(c.ad, q) + d1;
+        const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(c.al, q))
+                                   : hs_seg_pre(0.0, u1, u2, dl, hs_lds_at(c.al, q));
+        acc += q < c.owed ? term : 0.0;
+        u1 = u2;
+        d1 = c.d[q + 1];
+      }
+    const int nKp = __builtin_amdgcn_readfirstlane(c.nKp);
+    for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
+  } else {  // hs_table_item: the term joins the sum in the reciprocal's last FMA
+#pragma unroll
+    for (int q = 0; q < RT - 1; ++q)
+      if (q < len) {
+        const double u2 = hs_lds_at(c.aw, q + 1) * c.K[q + 1];
+        const double dl = hs_lds_at(c.ad, q) + d1;
+        if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(c.al, q));
+        else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(c.al, q));
+        u1 = u2;
+        d1 = c.d[q + 1];
+      }
+  }
+  return acc;
+}
 
 // One synchrotron work item: 64 (live photon energy, chunk of the gamma grid) pairs of
 // Synchrotron._spectrum's integrand (radiative.py:282-342) for the walker whose weights and

@@ -195,8 +195,10 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
 
 // S2: the synchrotron items in the log domain (nh_syn2.h) -- an instance of its own, so that
 // neither form carries the other's registers and code
-template <bool SYN, bool MULTI, bool S2>
-__global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs_run R) {
+// RT > 0: a table-only model in workgroups of at most 512 threads whose table items stay in
+// registers for the launch, RT nodes per lane at most (nh_hs.h: hs_rt_item)
+template <bool SYN, bool MULTI, bool S2, int RT = 0>
+__global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_hot H, const hs_run R) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
   const int T = blockDim.x, tid0 = threadIdx.x;
@@ -336,6 +338,55 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
     nwork = nwv;
     rank = wv;
     worker = true;
+  }
+
+  // ---- RT: this wave's table item, once: its rows into registers ----------------------------
+  // (the item a wave takes is a function of its index -- item = wave, rotated over the K
+  // workgroups of a walker as the pulls are -- and its rows of the walker, through the tile's
+  // first non-zero row alone: the same every slice)
+  hs_rt_item<(RT > 0 ? RT : 1)> rt;
+  rt.ix = -1;
+  if constexpr (RT > 0) {
+    const int total = D.nT;
+    int item = wv;
+    bool have = item < total;
+    if (K > 1) {
+      have = item * K < total;
+      item = item * K + ((part + item) & (K - 1));
+      have = have && item < total;
+    }
+    if (have) {
+      int t = 0;
+      while (t + 1 < D.ntab && item >= D.tab[t + 1].item0) ++t;
+      const hs_tab& tb = D.tab[t];
+      const int loc = item - tb.item0;
+      const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
+      const int tg = __builtin_amdgcn_readfirstlane(tb.grid);
+      const int nG = __builtin_amdgcn_readfirstlane(H.nG[tg]);
+      const int r0 = __builtin_amdgcn_readfirstlane(
+          reinterpret_cast<const int*>(sm + R.o_trail)[t * HS_RUN_TRAIL + tile]);
+      int s0, s1;
+      hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
+      if (R.rebalance) {
+        const int nch = HS_CHUNKS(tb.chunks);
+        const int per = (max(nG - 1 - r0, 0) + nch - 1) / nch;
+        s0 = r0 + chunk * per;
+        s1 = min(nG - 1, s0 + per);
+      } else {
+        s0 = max(s0, r0);
+      }
+      const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
+      const bool pre = __builtin_amdgcn_readfirstlane(tb.nonneg) != 0;
+      if (s0 < s1 && (!pre || H.o_dp[tg] >= 0) &&
+          hs_rt_load<(RT > 0 ? RT : 1)>(rt, tb, kds ? kds : tb.KD, nG, tile, s0, s1, tid0 & 63, sm + H.o_w[tg],
+                                        sm + (pre ? H.o_dp[tg] : H.o_d[tg]),
+                                        sm + (pre ? H.o_th[tg] : H.o_lx[tg]))) {
+        rt.ix = item;
+        rt.t = t;
+        rt.tile = tg;  // (the grid: what the slice's non-zero mask is indexed by)
+        rt.pre = pre ? 1 : 0;
+      }
+    }
   }
 
   // =========================== the slices ====================================================
@@ -744,10 +795,17 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
         bool syn_ready = !has_syn;
         double* part_t = sm + H.o_part_t;
         double* part_s = sm + H.o_part_s;
+        bool rt_first = true;
         for (;;) {
           int item = 0;
-          if (lane == 0) item = atomicAdd(&hi[HI_CNT], 1);
-          item = __builtin_amdgcn_readfirstlane(item);
+          if constexpr (RT > 0) {  // ONE item, the wave's own (its rows may sit in registers)
+            if (!rt_first) break;
+            rt_first = false;
+            item = wv;
+          } else {
+            if (lane == 0) item = atomicAdd(&hi[HI_CNT], 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+          }
           if (K > 1) {  // this workgroup's share: one of every K items, rotating
             if (item * K >= total) break;
             item = item * K + ((part + item) & (K - 1));
@@ -809,6 +867,9 @@ __global__ __launch_bounds__(1024) void k_half_step_run(const hs_hot H, const hs
             double acc;
             if (!(nz >> tg & 1) || s0 >= s1)
               acc = 0.0;
+            else if (RT > 0 && rt.ix == ix && !(nz >> (8 + tg) & 1))
+              acc = pre ? hs_rt_compute<(RT > 0 ? RT : 1), false>(rt)  // (the rows are in registers)
+                        : hs_rt_compute<(RT > 0 ? RT : 1), true>(rt);
             else if (__builtin_amdgcn_readfirstlane(tb.sub) > 1)
               acc = pre ? hs_table_item_packed<false, SYN ? 4 : HS_RUN_PK>(tb, nG, s0, s1, ws, ds, lxs, lane, kds)
                         : hs_table_item_packed<true, SYN ? 4 : HS_RUN_PK>(tb, nG, s0, s1, ws, ds, lxs, lane, kds);
@@ -1148,6 +1209,7 @@ struct nh_halfstep_run {
   int split;
   size_t lds_bytes;
   int grid, threads;
+  int rt;  // the instance whose table items stay in registers (hs_rt_item)
   unsigned seq;
   // a shared ensemble (nh_half_step_run_create_shared): `base` is ONE fine-grained allocation
   // { HS_RUN_HEAD granules of probe slots | ring of even launches | ring of odd launches }
@@ -1202,7 +1264,11 @@ static void hs_s2_piece(int p, long double h, double* c /*[HS_S2_STRIDE]*/) {
   }
 }
 
-static const void* hs_run_kernel(bool syn, bool shared, bool s2) {
+#define HS_RUN_RT HS_RT_NODES
+static const void* hs_run_kernel(bool syn, bool shared, bool s2, bool rt = false) {
+  if (!syn && rt)
+    return shared ? (const void*)k_half_step_run<false, true, false, HS_RUN_RT>
+                  : (const void*)k_half_step_run<false, false, false, HS_RUN_RT>;
   if (!syn) return shared ? (const void*)k_half_step_run<false, true, false> : (const void*)k_half_step_run<false, false, false>;
   if (s2) return shared ? (const void*)k_half_step_run<true, true, true> : (const void*)k_half_step_run<true, false, true>;
   return shared ? (const void*)k_half_step_run<true, true, false> : (const void*)k_half_step_run<true, false, false>;
@@ -1231,7 +1297,11 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   // distribution has a break) stay in LDS for the whole launch.  Smaller workgroups (a half-step
   // of more walkers than CUs, k_half_step item 14) share a CU, and LDS decides how many fit:
   // they read the nodes from L2 every slice, as k_half_step does, while a neighbour computes.
-  const bool grids_in_lds = P->threads >= 1024 && nh_env_int("NH_RUN_GRIDS_IN_LDS", 1) != 0;
+  // RT: a table-only model in workgroups of <= 512 threads (256 vector registers per lane) keeps
+  // its table items' rows in registers (nh_hs.h: hs_rt_item); a workgroup owns its CU then, too
+  bool rt = P->rt != 0 && H.syn_grid < 0 && H.ntab > 0 && P->threads <= 512 && nh_env_int("NH_RUN_RT", 1) != 0;
+  rt = rt && H.C.nT <= (P->threads / 64) * P->split;  // (one item per wave)
+  const bool grids_in_lds = (P->threads >= 1024 || rt) && nh_env_int("NH_RUN_GRIDS_IN_LDS", 1) != 0;
   for (int g = 0; g < NH_MAX_GRIDS; ++g) R.o_gx[g] = R.o_lne[g] = R.o_ge[g] = -1;
   for (int g = 0; g < H.ngrids && grids_in_lds; ++g) {
     R.o_gx[g] = off; off += H.nG[g];
@@ -1343,7 +1413,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
-  const void* fn = hs_run_kernel(H.syn_grid >= 0, shared, R.syn2 != 0);
+  const void* fn = hs_run_kernel(H.syn_grid >= 0, shared, R.syn2 != 0, rt);
   if (lds > 64 * 1024)
     NH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // every workgroup of the launch has to be resident (they wait for each other's records)
@@ -1371,6 +1441,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->R = R;
   Q->lds_bytes = lds;
   Q->threads = P->threads;
+  Q->rt = rt ? 1 : 0;
   Q->grid = (int)(H.nloc < cap / P->split ? H.nloc : cap / P->split);
   Q->seq = 1;
   Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
@@ -1677,7 +1748,7 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
     const dim3 thr(Q->threads);
     void* args[2] = {(void*)&H, (void*)&R};
-    NH_CHECK_HIP(hipLaunchKernel(hs_run_kernel(H.syn_grid >= 0, Q->base != nullptr, R.syn2 != 0), grid, thr,
+    NH_CHECK_HIP(hipLaunchKernel(hs_run_kernel(H.syn_grid >= 0, Q->base != nullptr, R.syn2 != 0, Q->rt != 0), grid, thr,
                                  args, Q->lds_bytes, c->stream));
   }
   {
@@ -1716,6 +1787,13 @@ extern "C" int nh_half_step_run_syn_info(const nh_halfstep_run* Q, int* mode, in
   if (mode) *mode = Q->R.syn2;
   if (nodes_per_piece) *nodes_per_piece = Q->R.syn2 ? 1 << Q->R.s2.lm : 0;
   if (pieces) *pieces = Q->R.syn2 ? Q->R.s2.P + 1 : 0;
+  return NH_OK;
+}
+
+extern "C" int nh_half_step_run_table_info(const nh_halfstep_run* Q, int* in_registers, int* nodes_max) {
+  NH_REQUIRE(Q, "bad argument");
+  if (in_registers) *in_registers = Q->rt ? 1 : 0;
+  if (nodes_max) *nodes_max = Q->rt ? HS_RUN_RT : 0;
   return NH_OK;
 }
 

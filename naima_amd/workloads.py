@@ -93,7 +93,7 @@ def cfg4_model(ns):
     return CrabSynSSC
 
 
-def cfg5_model(ns, useLUT=True):
+def cfg5_model(ns, useLUT=True, nEpd=100):
     u = ns.u
     Epmin = (0.9382720881604903 + 0.27966184 + 1e-4) * u.GeV
     Epmax = Epmin * 10 ** 6.005
@@ -102,7 +102,7 @@ def cfg5_model(ns, useLUT=True):
         ECBPL = ns.ExponentialCutoffBrokenPowerLaw(
             10 ** pars[0] / u.TeV, 1 * u.TeV, 10 ** pars[1] * u.TeV,
             pars[2], pars[3], 10 ** pars[4] * u.TeV)
-        PP = ns.PionDecay(ECBPL, nh=1.0 / u.cm ** 3, useLUT=useLUT, Epmax=Epmax)
+        PP = ns.PionDecay(ECBPL, nh=1.0 / u.cm ** 3, useLUT=useLUT, Epmax=Epmax, nEpd=nEpd)
         return PP.flux(data, distance=1.0 * u.kpc), PP.compute_Wp(Epmin=1 * u.TeV)
 
     return ProtonPP

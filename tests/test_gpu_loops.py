@@ -539,10 +539,12 @@ def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkey
 
 @pytest.mark.parametrize("name,nw,mkw", [("cfg3", 512, {}), ("cfg5", 256, {}), ("cfg1", 32, {}),
                                          ("cfg5", 256, {"useLUT": False}), ("cfg2", 256, {}),
-                                         ("cfg3", 256, {}), ("cfg3", 48, {}), ("cfg3", 1280, {})],
+                                         ("cfg3", 256, {}), ("cfg3", 48, {}), ("cfg3", 1280, {}),
+                                         ("cfg5", 256, {"nEpd": 50}), ("cfg5", 500, {"nEpd": 40, "useLUT": False})],
                          ids=["cfg3-512", "cfg5-256", "cfg1-32", "cfg5-analytic-256", "cfg2-256-two-per-walker",
                               "cfg3-256-two-per-walker", "cfg3-48-eight-per-walker",
-                              "cfg3-1280-three-walkers-per-workgroup"])
+                              "cfg3-1280-three-walkers-per-workgroup", "cfg5-lut-300-nodes-rows-in-registers",
+                              "cfg5-analytic-240-nodes-rows-in-registers"])
 def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
     """nh_half_step_run -- a whole block of moves in ONE launch, walkers handed from half-step
     to half-step through per-walker records (write-through granules with tags) instead of
@@ -567,6 +569,14 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
             st2 = d.run_mcmc(st, 7, store=False)  # (no history: blobs go to the current array)
         assert d._dev.mega and d._dev._plan["hs"] is not None
         assert (d._dev.resident_launches > 0) == (mode == "1"), getattr(d._dev, "resident_reason", "")
+        if mode == "1" and (name == "cfg1" or "nEpd" in mkw):
+            # (a table-only model whose items' rows fit a lane's registers: workgroups of 512
+            # threads, the rows loaded once per launch -- hs_rt_item; signed tables (the LUT's) and
+            # non-negative ones)
+            assert d._dev.resident_info["tables_in_registers"] and d._dev.resident_info["threads"] <= 512, \
+                d._dev.resident_info
+        if mode == "1" and name == "cfg5" and not mkw:
+            assert not d._dev.resident_info["tables_in_registers"]  # (600 nodes, no zero rows: streamed)
         if mode == "1" and name in ("cfg3", "cfg1"):
             # (the resident loop walks its own copies of the inverse-Compton tables, columns sorted
             # by their first non-zero row, rows below a tile's first one skipped: same spectra)
