@@ -580,6 +580,13 @@ def main():
                                       "flop_eq_per_walker_all_nodes": KERNEL_FLOP_EQ[name][cat]}
     if fp:
         out["fp64_valu"] = {"peak": FP64_VEC_PEAK_TF, "unit": "TFLOP-eq/s", "kernels": fp,
+                            # (the vendor peak is one FP64 vector instruction per 4 cycles and SIMD at
+                            # 2.4 GHz; scripts/ubench measures 5.2-5.6 cycles of the nominal clock for
+                            # v_add / v_mul / v_fma_f64 on this chip under load, profiles/README.md)
+                            "sustained_issue_note": "scripts/ubench: v_fma_f64 5.6, v_mul_f64 5.4, "
+                                                    "v_add_f64 5.2 cycles per wave at the nominal 2.4 GHz "
+                                                    "-- 0.71-0.77 of the quoted peak is what the pipe "
+                                                    "sustains",
                             "convention": "SURVEY.md 8d: transcendental = 20 flop-eq; "
                                           "Synchrotron node 50, table-reduction segment 30.  "
                                           "EXECUTED nodes only: the synchrotron kernel skips "
