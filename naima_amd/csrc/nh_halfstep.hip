@@ -29,6 +29,7 @@
 // index (nobody writes those rows).  The kernel boundary is the ensemble-wide barrier
 // between half-steps.
 #include "nh_hs.h"
+#include "nh_syn2.h"
 
 // The first arguments are what the proposal's chain of dependent reads starts from: scalar
 // kernel arguments can be preloaded into SGPRs at dispatch (-amdgpu-kernarg-preload-count),
@@ -66,7 +67,15 @@ static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
                   offsetof(hs_first, pkd) == 192, "hs_first: the layout the first trip reads");
 // SYN = false: the instance for models without a synchrotron component (table-only: cfg1,
 // cfg5) -- the synchrotron items' registers are not there to be allocated around
-template <bool SYN>
+// S2: the synchrotron items in the log domain on the grid's comb (nh_syn2.h), as the resident loop
+// runs them -- a log-uniform particle grid; its block in LDS behind H.o_s2 (doubles):
+//   16 header { ilx, th, im, lml, 1/(2 lx), z0, {lm, P}, {nG, -} } | (P + 1) x 6 table | 128 2^(j/128) |
+//   nG Lambda (ln gamma / 3 + ln scale) | nG + 2 GUARD cbrt(1/gamma^2) | nG + 2 GUARD Lambda ln w |
+//   4 nE per-energy constants | nE comb indices (ints)
+// the header, the table and the node constants behind the grid's three arrays in F.syn_c.
+#define HS_S2_HDR 16
+__device__ __attribute__((noinline)) double hs_log_ool(double x) { return log(x); }
+template <bool SYN, bool S2 = false>
 __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done_,
                                                     const double* __restrict__ blk_,
                                                     const double* coords_, int slice, int ns_,
@@ -473,6 +482,32 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     sm[H.o_ig23 + i] = F.syn_c[F.syn_nG + i];
     sm[H.o_dig2 + i] = F.syn_c[2 * F.syn_nG + i];
   }
+  // (S2) the log-domain items' table and node constants: one more batch of loads, used after the
+  // weights' barrier
+  int s2P = 0, s2lm = 0, o_s2t = 0, o_s2lg = 0, o_s2ig = 0, o_s2lw = 0, o_s2q = 0, o_s2z = 0;
+  if (SYN && S2) {
+    const int nGs = F.syn_nG, o = H.o_s2;
+    const auto* src = F.syn_c + 3 * nGs;  // (an address_space(1) pointer: see hs_gptr)
+    const double lmPd = src[6];
+    const hs_i2 lmP = {__double2loint(lmPd), __double2hiint(lmPd)};
+    s2lm = __builtin_amdgcn_readfirstlane(lmP.x);
+    s2P = __builtin_amdgcn_readfirstlane(lmP.y);
+    const int ntb = HS_S2_HDR + (s2P + 1) * HS_S2_STRIDE;
+    o_s2t = o + ntb;
+    o_s2lg = o_s2t + 128;
+    o_s2ig = o_s2lg + nGs;
+    o_s2lw = o_s2ig + nGs + 2 * HS_S2_GUARD;
+    o_s2q = o_s2lw + nGs + 2 * HS_S2_GUARD;
+    o_s2z = o_s2q + 4 * H.syn_nE;
+    for (int i = tid; i < ntb; i += T) sm[o + i] = src[i];
+    if (tid < 128) sm[o_s2t + tid] = exp2((double)tid * 0.0078125);
+    for (int i = tid; i < nGs; i += T) sm[o_s2lg + i] = src[ntb + i];
+    for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
+      const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
+      sm[o_s2ig + i] = F.syn_c[nGs + ii];
+      if (i < HS_S2_GUARD || i >= nGs + HS_S2_GUARD) sm[o_s2lw + i] = HS_S2_FLOOR;
+    }
+  }
   // ---- chain history rows (the step closed by the previous launch; hist->n is not used:
   // the row is the number of closed steps of this run - 1, what nh_hist_append is told too).
   // One wave's work, and not one of the proposal's chain.
@@ -626,16 +661,20 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         double nn, dsh;
         pd_core(D.kind, p, nln_[sl] - lg[0], nln_[sl] - lg[1], lg[2] - lg[0], nE_[sl] < p.eb,
                 nE2_[sl] < p.eb, nlr_[sl], nn, dsh, sm + HS_O_T64);
+        const double nraw = nn;
         nn *= H.scale[g];
         const double wv_ = ngx_[sl] * nn, dv = last ? 0.0 : nlr_[sl] + dsh;
         sm[H.o_w[g] + i] = wv_;
         sm[H.o_d[g] + i] = dv;
+        if (SYN && S2 && g == H.syn_grid)  // Lambda ln|w| + the node's share of ln Gtilde (nh_syn2.h); a zero weight: the floor
+          sm[o_s2lw + HS_S2_GUARD + i] = wv_ != 0.0 ? fma(HS_S2_LAMBDA, hs_log_ool(fabs(nraw)), sm[o_s2lg + i]) : HS_S2_FLOOR;
         if (H.o_dp[g] >= 0) {  // (wave-uniform) what the non-negative table items read
           const double il = last ? 0.0 : nh_rcp(nlr_[sl]);
           sm[H.o_dp[g] + i] = dv * il;
           sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
         }
         if (wv_ != 0.0) nzmask |= 1 << g;
+        if (SYN && S2 && !isfinite(wv_)) nzmask |= 256 << g;  // (the log-domain items: see syn_nan)
         if (D.write_weights) {
           D.w[g][(long long)j * nG + i] = wv_;
           D.dlw[g][(long long)j * nG + i] = dv;
@@ -657,16 +696,20 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       double nn, dsh;
       pd_core(D.kind, p, lnE - lg[0], lnE - lg[1], lg[2] - lg[0], E < p.eb, E2 < p.eb, lr, nn,
               dsh, sm + HS_O_T64);
+      const double nraw = nn;
       nn *= H.scale[g];
       const double wv_ = gx * nn, dv = last ? 0.0 : lr + dsh;
       sm[H.o_w[g] + i] = wv_;
       sm[H.o_d[g] + i] = dv;
+      if (SYN && S2 && g == H.syn_grid)
+        sm[o_s2lw + HS_S2_GUARD + i] = wv_ != 0.0 ? fma(HS_S2_LAMBDA, hs_log_ool(fabs(nraw)), sm[o_s2lg + i]) : HS_S2_FLOOR;
       if (H.o_dp[g] >= 0) {
         const double il = last ? 0.0 : nh_rcp(lr);
         sm[H.o_dp[g] + i] = dv * il;
         sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
       }
       if (wv_ != 0.0) nzmask |= 1 << g;
+      if (SYN && S2 && !isfinite(wv_)) nzmask |= 256 << g;
       if (D.write_weights) {
         D.w[g][(long long)j * nG + i] = wv_;
         D.dlw[g][(long long)j * nG + i] = dv;
@@ -691,14 +734,19 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   if (has_syn) {
     const int nG = H.nG[H.syn_grid], nEs = H.syn_nE;
     for (int q = 0; q < syn_tiles; ++q) nA += tcnt[q];
-    const bool syn_zero = !(nz >> H.syn_grid & 1);  // nothing to integrate: every spectrum value is 0
+    // (the log-domain items take ln q and ln w: a magnetic field that is not positive, or a weight
+    // that is not finite, makes the reference's spectrum NaN -- x < 0 overflows exp(-x), inf x 0 --
+    // and this one with it; k_half_step_run the same)
+    const bool syn_nan = S2 && !hi[HI_DEAD] &&
+                         (!(Bw > 0.0) || !(Bw < INFINITY) || (nz >> (8 + H.syn_grid) & 1) != 0);
+    const bool syn_zero = !(nz >> H.syn_grid & 1) || syn_nan;  // nothing to integrate
     if (nA > 0 && !syn_zero) {
       Cd = (hi[HI_LIVE] / nA + D.syn_nodes - 1) / D.syn_nodes;
       Cd = min(max(Cd, 1), D.syn_cdmax);
       nS = (nA * Cd + 63) >> 6;
     }
     if (syn_zero) {
-      for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = 0.0;
+      for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = syn_nan ? NAN : 0.0;
       nA = 0;
     }
     if (lv_k >= 0 && !syn_zero) {
@@ -718,9 +766,25 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
         sq[pos] = lv_q;
         sq[nEs + pos] = cbrt(lv_q);
         // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
-        sq[2 * nEs + pos] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                            (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
-                             (lv_E * NH_ERG_PER_EV));
+        const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                           (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
+                            (lv_E * NH_ERG_PER_EV));
+        sq[2 * nEs + pos] = cs1;
+        if (S2) {
+          // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
+          // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy; the sign of the
+          // amplitude in front of the integral
+          const double* hdr = sm + H.o_s2;
+          const double lnq = hs_log_ool(lv_q);
+          const double z = fma(-lnq, hdr[4], hdr[5]);
+          const double Zf = floor(z);
+          double* s2q = sm + o_s2q;
+          s2q[pos] = sq[nEs + pos];
+          s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
+          s2q[2 * nEs + pos] = (z - Zf) * hdr[2];
+          s2q[3 * nEs + pos] = p.A < 0.0 ? -cs1 : cs1;
+          reinterpret_cast<int*>(sm + o_s2z)[pos] = (int)Zf;
+        }
       } else if (lv_k < nEs) {
         spec[H.syn_spec_off + lv_k] = 0.0;
       }
@@ -839,7 +903,17 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           syn_ready = true;
         }
-        {
+        if (S2) {
+          const int nEs = H.syn_nE;
+          const double* hdr = sm + H.o_s2;
+          hs_syn2_par S;
+          S.lm = s2lm; S.P = s2P; S.nG = H.nG[H.syn_grid]; S.pad = 0;
+          S.ilx = hdr[0]; S.th = hdr[1]; S.im = hdr[2]; S.lml = hdr[3];
+          hs_syn2_item(ix, lane, nA, Cd, nEs, S, reinterpret_cast<const int*>(sm + H.o_amap) + nEs,
+                       reinterpret_cast<const int*>(sm + o_s2z), sm + o_s2q,
+                       hs_lds_addr(sm + o_s2lw + HS_S2_GUARD), hs_lds_addr(sm + o_s2ig + HS_S2_GUARD),
+                       hs_lds_addr(sm + H.o_s2 + HS_S2_HDR), hs_lds_addr(sm + o_s2t), part_s);
+        } else {
           const int g = H.syn_grid, nEs = H.syn_nE;
           const hs_syn_lds L = {reinterpret_cast<const int*>(sm + H.o_amap), sm + H.o_ig2,
                                 sm + H.o_dig2, sm + H.o_ig23, sm + H.o_w[g], sm + H.o_d[g],
@@ -1487,9 +1561,42 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   C.lp = d->lp; C.model_out = d->model_out; C.total = d->total;
   C.pri.n = d->nterms;
   for (int t = 0; t < d->nterms; ++t) C.pri.t[t] = d->terms[t];
+  // ---- the synchrotron items in the log domain (nh_syn2.h), as the resident loop runs them: a
+  // log-uniform grid (np.logspace, radiative.py:147-154), its table and node constants behind the
+  // grid's three arrays in syn_c, their block in LDS behind o_s2 (k_half_step<true, true>)
+  hs_s2_host s2h;
+  H.o_s2 = 0;
+  const size_t lds_core = (size_t)off * sizeof(double);  // (what the resident loop builds on: it has a block of its own)
+  if (d->syn.grid >= 0 && nh_env_int("NH_HS_SYN2", 1) != 0) {
+    const int sg = d->syn.grid, nGs = d->grids[sg].nG;
+    std::vector<double> gam((size_t)nGs);
+    bool ok = nh_sync(c) == NH_OK;
+    if (ok && hipMemcpy(gam.data(), d->grids[sg].xg, (size_t)nGs * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = false;
+    }
+    ok = ok && hs_s2_prepare(gam.data(), nGs, d->grids[sg].unit_scale, s2h);
+    if (getenv("NH_HS_RT_DEBUG"))
+      fprintf(stderr, "S2: grid %d nG %d nE %d log-uniform %d off %d (%.1f KB) split %d\n", sg, nGs, d->syn.nE, (int)ok, off,
+              off * 8.0 / 1024, split);
+    if (ok) {
+      const int o = off + (off & 1);  // (the pieces are read as ds_read_b128)
+      const int need = HS_S2_HDR + (s2h.par.P + 1) * HS_S2_STRIDE + 128 + nGs + 2 * (nGs + 2 * HS_S2_GUARD) +
+                       4 * d->syn.nE + (d->syn.nE + 1) / 2 + 1;
+      if ((size_t)(o + need) * sizeof(double) <= 160 * 1024) {  // (a CU's LDS; the plan's own layout keeps to 150 KB)
+        H.o_s2 = o;
+        off = o + need;
+        // (items that start on a piece boundary with a node and six coefficients of their own:
+        // short ones pay for that -- the resident loop's lengths)
+        // (cfg3 / 512, one launch per half-step: 30.6 us at 16 or 24 nodes per item, 31.1 at 32,
+        // 33.9 at 48, 32.7 in the direct form)
+        if (!getenv("NH_HS_SYN_NODES")) C.syn_nodes = split == 1 ? 24 : (C.syn_nodes < 16 ? 16 : C.syn_nodes);
+      }
+    }
+  }
   const size_t lds = (size_t)off * sizeof(double);
-  if (lds > 150 * 1024) *lds_overflow = true;
-  NH_REQUIRE(lds <= 150 * 1024, "the model's grids and tables do not fit in LDS");
+  if (lds_core > 150 * 1024) *lds_overflow = true;
+  NH_REQUIRE(lds_core <= 150 * 1024, "the model's grids and tables do not fit in LDS");
   C.dbg = nullptr;
   if (const char* e = getenv("NH_HS_DEBUG"))
     if (atoi(e) != 0) {
@@ -1499,6 +1606,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   nh_halfstep_plan* P = new nh_halfstep_plan();
   P->dbg = C.dbg;
   P->lds_bytes = lds;
+  P->lds_core = lds_core;
   P->threads = threads;
   P->blocks = d->nloc;
   P->split = split;
@@ -1511,11 +1619,21 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   hipError_t e = hipMalloc(&P->dev, sizeof(packs_host));
   if (e == hipSuccess && H.syn_grid >= 0) {
     const int nGs = H.nG[H.syn_grid];
-    e = hipMalloc(&P->syn_c, 3 * (size_t)nGs * sizeof(double));
+    const size_t ns2 = H.o_s2 ? HS_S2_HDR + s2h.data.size() : 0;
+    e = hipMalloc(&P->syn_c, (3 * (size_t)nGs + ns2) * sizeof(double));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_syn_consts, dim3((unsigned)((nGs + 255) / 256)), dim3(256), 0, c->stream,
                          H.xg[H.syn_grid], H.lx[H.syn_grid], nGs, P->syn_c);
       e = hipGetLastError();
+    }
+    if (e == hipSuccess && ns2) {
+      std::vector<double> up(ns2, 0.0);
+      up[0] = s2h.par.ilx; up[1] = s2h.par.th; up[2] = s2h.par.im; up[3] = s2h.par.lml;
+      up[4] = s2h.invd; up[5] = s2h.z0;
+      int* iv = reinterpret_cast<int*>(&up[6]);
+      iv[0] = s2h.par.lm; iv[1] = s2h.par.P; iv[2] = s2h.par.nG; iv[3] = 0;
+      for (size_t q = 0; q < s2h.data.size(); ++q) up[HS_S2_HDR + q] = s2h.data[q];
+      e = nh_put_now(c, P->syn_c + 3 * (size_t)nGs, up.data(), ns2 * sizeof(double));
     }
   }
   if (e == hipSuccess && split > 1) {
@@ -1528,8 +1646,10 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   if (e == hipSuccess) e = nh_fill_now(c, P->words, 0, 4 * sizeof(int));
   if (e == hipSuccess && lds > 64 * 1024)
     e = H.syn_grid >= 0
-            ? hipFuncSetAttribute((const void*)k_half_step<true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            ? (H.o_s2 ? hipFuncSetAttribute((const void*)k_half_step<true, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_half_step<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
             : hipFuncSetAttribute((const void*)k_half_step<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) {
@@ -1610,7 +1730,11 @@ extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   nh_prof_scope ps(c, NH_K_HALFSTEP);
   const hs_hot& H = P->hot;
   const dim3 grid((unsigned)P->blocks, (unsigned)P->split);
-  if (H.syn_grid >= 0)
+  if (H.syn_grid >= 0 && H.o_s2)
+    hipLaunchKernelGGL((k_half_step<true, true>), grid, dim3(P->threads), P->lds_bytes, c->stream,
+                       (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
+                       P->dbg ? 1 : 0, H);
+  else if (H.syn_grid >= 0)
     hipLaunchKernelGGL(k_half_step<true>, grid, dim3(P->threads), P->lds_bytes, c->stream,
                        (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
                        P->dbg ? 1 : 0, H);

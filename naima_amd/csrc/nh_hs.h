@@ -123,7 +123,8 @@ struct hs_hot {
   const double* mKt[NH_MAX_MOMENT]; const double* mdK[NH_MAX_MOMENT];
   int mgrid[NH_MAX_MOMENT];
   int o_mkt, o_part_t, o_spec, o_lik;
-  int syn_grid, syn_nE, syn_spec_off, o_ig2, o_dig2, o_ig23, o_sq, o_amap, o_part_s, pad1;
+  int syn_grid, syn_nE, syn_spec_off, o_ig2, o_dig2, o_ig23, o_sq, o_amap, o_part_s;
+  int o_s2;  // the log-domain synchrotron items' block in LDS (k_half_step<true, true>; nh_syn2.h), or 0
   const double* syn_E;
   const double* conv; const double* flux; const double* elo; const double* ehi;
   const int* ul; const double* cl;
@@ -142,6 +143,7 @@ struct nh_halfstep_plan {
   double* xspec;     // device: the partial spectra of a split launch, or NULL
   int* tick;         // device: arrival counters of a split launch, or NULL
   size_t lds_bytes;
+  size_t lds_core;  // ... without k_half_step's own log-domain synchrotron block (the last thing in it)
   int threads, blocks, split;  // split = K workgroups per walker (gridDim.y)
   int rt;  // the workgroup size was chosen for register-resident table items (hs_rt_item)
   long long* dbg;

@@ -1227,43 +1227,6 @@ struct nh_halfstep_run {
   double* s2_dev;     // the log-domain synchrotron items' table and grid constants (nh_syn2.h), or NULL
 };
 
-// ---- the table of nh_syn2.h, built on the host when the loop is created -------------------------
-// rho(t) = ln(Gtilde(x) e^x) - t / 3 - ln 1.808,  x = e^t   (radiative.py:300-311); the table holds
-// Lambda (rho + ln 1.808)
-static long double hs_s2_rho(long double t) {
-  const long double s = expl(2.0L * t / 3.0L);
-  return logl((1.0L + 2.210L * s + 0.347L * s * s) /
-              ((1.0L + 1.353L * s + 0.217L * s * s) * sqrtl(1.0L + 3.4L * s)));
-}
-// piece p covers t in (T_top - (p + 1) h, T_top - p h]; its polynomial in lambda = (T_top - t) / h - p
-// interpolates Lambda rho at the six Chebyshev nodes of [0, 1] (<= 1.2e-12 absolute for h <= 0.226)
-static void hs_s2_piece(int p, long double h, double* c /*[HS_S2_STRIDE]*/) {
-  const int n = HS_S2_DEG + 1;
-  long double A[HS_S2_DEG + 1][HS_S2_DEG + 2];
-  for (int r = 0; r < n; ++r) {
-    const long double lam = 0.5L * (1.0L + cosl((2 * r + 1) * 3.14159265358979323846264L / (2 * n)));
-    long double pw = 1.0L;
-    for (int k = 0; k < n; ++k) { A[r][k] = pw; pw *= lam; }
-    A[r][n] = (long double)HS_S2_LAMBDA * (hs_s2_rho((long double)HS_S2_TTOP - (p + lam) * h) + logl(1.808L));
-  }
-  for (int k = 0; k < n; ++k) {  // Gaussian elimination, partial pivoting
-    int piv = k;
-    for (int r = k + 1; r < n; ++r) if (fabsl(A[r][k]) > fabsl(A[piv][k])) piv = r;
-    for (int q = 0; q <= n; ++q) { const long double t = A[k][q]; A[k][q] = A[piv][q]; A[piv][q] = t; }
-    for (int r = k + 1; r < n; ++r) {
-      const long double f = A[r][k] / A[k][k];
-      for (int q = k; q <= n; ++q) A[r][q] -= f * A[k][q];
-    }
-  }
-  long double sol[HS_S2_DEG + 1];
-  for (int k = n - 1; k >= 0; --k) {
-    long double v = A[k][n];
-    for (int q = k + 1; q < n; ++q) v -= A[k][q] * sol[q];
-    sol[k] = v / A[k][k];
-    c[k] = (double)sol[k];
-  }
-}
-
 #define HS_RUN_RT HS_RT_NODES
 static const void* hs_run_kernel(bool syn, bool shared, bool s2, bool rt = false) {
   if (!syn && rt)
@@ -1292,7 +1255,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   R.N = 2 * H.ns;
   R.gr = ((2 * (H.ndim + 1) + 15) / 16) * 16;
   // LDS: the plan's layout, then what stays resident on top of it
-  int off = (int)(P->lds_bytes / sizeof(double));
+  int off = (int)(P->lds_core / sizeof(double));
   // Workgroups of 1024 threads own their CU: the grids' nodes, ln E (and E where the particle
   // distribution has a break) stay in LDS for the whole launch.  Smaller workgroups (a half-step
   // of more walkers than CUs, k_half_step item 14) share a CU, and LDS decides how many fit:

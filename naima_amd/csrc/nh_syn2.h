@@ -158,3 +158,87 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
   }
   part_s[ch * nEs + a] = acc * sq[3 * nEs + a];  // linear in u: CS1 once per thread
 }
+
+// ---- the table of nh_syn2.h, built on the host when the loop is created -------------------------
+// rho(t) = ln(Gtilde(x) e^x) - t / 3 - ln 1.808,  x = e^t   (radiative.py:300-311); the table holds
+// Lambda (rho + ln 1.808)
+static inline long double hs_s2_rho(long double t) {
+  const long double s = expl(2.0L * t / 3.0L);
+  return logl((1.0L + 2.210L * s + 0.347L * s * s) /
+              ((1.0L + 1.353L * s + 0.217L * s * s) * sqrtl(1.0L + 3.4L * s)));
+}
+// piece p covers t in (T_top - (p + 1) h, T_top - p h]; its polynomial in lambda = (T_top - t) / h - p
+// interpolates Lambda rho at the six Chebyshev nodes of [0, 1] (<= 1.2e-12 absolute for h <= 0.226)
+static inline void hs_s2_piece(int p, long double h, double* c /*[HS_S2_STRIDE]*/) {
+  const int n = HS_S2_DEG + 1;
+  long double A[HS_S2_DEG + 1][HS_S2_DEG + 2];
+  for (int r = 0; r < n; ++r) {
+    const long double lam = 0.5L * (1.0L + cosl((2 * r + 1) * 3.14159265358979323846264L / (2 * n)));
+    long double pw = 1.0L;
+    for (int k = 0; k < n; ++k) { A[r][k] = pw; pw *= lam; }
+    A[r][n] = (long double)HS_S2_LAMBDA * (hs_s2_rho((long double)HS_S2_TTOP - (p + lam) * h) + logl(1.808L));
+  }
+  for (int k = 0; k < n; ++k) {  // Gaussian elimination, partial pivoting
+    int piv = k;
+    for (int r = k + 1; r < n; ++r) if (fabsl(A[r][k]) > fabsl(A[piv][k])) piv = r;
+    for (int q = 0; q <= n; ++q) { const long double t = A[k][q]; A[k][q] = A[piv][q]; A[piv][q] = t; }
+    for (int r = k + 1; r < n; ++r) {
+      const long double f = A[r][k] / A[k][k];
+      for (int q = k; q <= n; ++q) A[r][q] -= f * A[k][q];
+    }
+  }
+  long double sol[HS_S2_DEG + 1];
+  for (int k = n - 1; k >= 0; --k) {
+    long double v = A[k][n];
+    for (int q = k + 1; q < n; ++q) v -= A[k][q] * sol[q];
+    sol[k] = v / A[k][k];
+    c[k] = (double)sol[k];
+  }
+}
+
+// What a kernel needs to run hs_syn2_item on a log-uniform grid (radiative.py:147-154 makes it
+// one): the table's pieces followed by Lambda (ln gamma_i / 3 + ln scale) per node, and the comb's
+// constants.  false: the grid is not log-uniform to 1e-12 (or too coarse / too fine for pieces of
+// 2 .. 16 steps): the direct form stays.  (k_half_step's plan; the resident loop's creation holds
+// the same steps.)
+struct hs_s2_host {
+  hs_syn2_par par;
+  double invd, z0;           // 1 / (2 lx);  (T_top + 2 ln gamma_0) / (2 lx)
+  std::vector<double> data;  // (P + 1) HS_S2_STRIDE table entries | nG node constants
+};
+static inline bool hs_s2_prepare(const double* gam, int nG, double scale, hs_s2_host& o) {
+  bool ok = nG >= 2 * HS_S2_GUARD && gam[0] > 0.0 && scale > 0.0;
+  long double lx = 0.0L, dev = 0.0L;
+  if (ok) {
+    const long double l0 = logl((long double)gam[0]);
+    lx = (logl((long double)gam[nG - 1]) - l0) / (nG - 1);
+    for (int i = 0; i < nG && ok; ++i) {
+      ok = gam[i] > 0.0;
+      if (ok) dev = fmaxl(dev, fabsl(logl((long double)gam[i]) - l0 - i * lx));
+    }
+    ok = ok && lx > 0.0L && dev <= 1e-12L;
+  }
+  int lm = 0;
+  if (ok) {
+    lm = (int)lrint(log2(0.16 / (double)(2.0L * lx)));
+    ok = lm >= 1 && lm <= 4;
+  }
+  if (!ok) return false;
+  const int m = 1 << lm;
+  const long double h = m * 2.0L * lx;
+  const int P = (int)ceill(((long double)HS_S2_TTOP - (long double)HS_S2_TBOT) / h);
+  o.data.assign((size_t)(P + 1) * HS_S2_STRIDE + nG, 0.0);
+  for (int pc = 0; pc < P; ++pc) hs_s2_piece(pc, h, &o.data[(size_t)pc * HS_S2_STRIDE]);
+  o.data[(size_t)P * HS_S2_STRIDE] = (double)((long double)HS_S2_LAMBDA * logl(1.808L));
+  for (int i = 0; i < nG; ++i)
+    o.data[(size_t)(P + 1) * HS_S2_STRIDE + i] =
+        (double)((long double)HS_S2_LAMBDA * (logl((long double)gam[i]) / 3.0L + logl((long double)scale)));
+  o.par.lm = lm; o.par.P = P; o.par.nG = nG; o.par.pad = 0;
+  o.par.ilx = (double)(0.00541521234812457272982L / lx);  // (ln 2 / 128) / lx
+  o.par.th = (double)((long double)NH_SEG_SMALL_POS / lx);
+  o.par.im = 1.0 / m;
+  o.par.lml = (double)(m - 1) / m;
+  o.invd = (double)(1.0L / (2.0L * lx));
+  o.z0 = (double)(((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
+  return true;
+}

@@ -385,7 +385,7 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
             "-mllvm", "-amdgpu-kernarg-preload-count=16"]
     # (file: kernel, instances, bytes of scratch per lane allowed; the resident kernel has a second
     # pair of instances for an ensemble shared by several GPUs)
-    want = {"nh_halfstep.hip": ("k_half_step", 2, 0), "nh_persist.hip": ("k_half_step_run", 8, 96)}
+    want = {"nh_halfstep.hip": ("k_half_step", 3, 0), "nh_persist.hip": ("k_half_step_run", 8, 96)}
     for f, (sym, ninst, limit) in want.items():
         out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", os.path.join(src, f),
                                      "-o", os.devnull], capture_output=True, text=True).stderr
