@@ -676,7 +676,8 @@ def test_table_only_model_with_more_walkers_than_compute_units(na):
                         atol=1e-300)
 
 
-@pytest.mark.parametrize("mega", ["1", "0"], ids=["one-launch", "separate-kernels"])
+@pytest.mark.parametrize("mega", ["1", "0", "per-launch"],
+                         ids=["one-launch", "separate-kernels", "one-launch-per-half-step"])
 def test_nan_log_probability_is_emcees_error(na, monkeypatch, mega):
     """a proposal whose log-probability is NaN ends an emcee run with ValueError("Probability
     function returned NaN") (EnsembleSampler.compute_log_prob; the reference just lets it
@@ -685,6 +686,11 @@ def test_nan_log_probability_is_emcees_error(na, monkeypatch, mega):
     ball under round 3's prior (the amplitude only) meets its first such proposal -- a negative
     magnetic field -- within ~30 steps."""
     from naima_amd.sampler import EnsembleSampler
+    if mega == "per-launch":
+        # (k_half_step<true, true> instead of the resident loop: its log-domain synchrotron items
+        # take ln B -- the NaN is made by its own test of the field, as in k_half_step_run)
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0")
+        mega = "1"
     monkeypatch.setenv("NAIMA_AMD_MEGA", mega)  # ("0": the accept rides in k_lnprobmodel / k_synchrotron)
     model, p0, raw, data, prior = _problem(na, "cfg2", {})
     prior = _loose_prior(na, "cfg2")  # (the benchmark's prior forbids B < 0)
