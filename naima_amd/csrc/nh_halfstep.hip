@@ -1410,6 +1410,10 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     for (int t = 0; t < d->ntab && fits; ++t) {
       const nh_hs_table& tb = d->tab[t];
       const int nG = d->grids[tb.grid].nG, nK = tb.nK;
+      if ((size_t)nG * nK * 16 > ((size_t)64 << 20)) {  // (nothing of that size fits a lane's registers)
+        fits = false;
+        break;
+      }
       std::vector<double> kd((size_t)nG * nK * 2);
       if (hipMemcpy(kd.data(), tb.KD, kd.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
