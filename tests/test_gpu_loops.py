@@ -117,6 +117,46 @@ def test_cfg4_at_its_baseline_ensemble_size(na):
     assert d.nan_proposals == 0 and h.nan_proposals == 0
 
 
+def test_register_resident_table_items_of_a_three_seed_model(na, monkeypatch):
+    """InverseCompton on CMB + FIR + NIR at cfg1's 28 TeV energies over a 700-node grid: ONE table
+    of 84 columns, two column tiles with lane = column (the form of hs_rt_item that cfg1's own
+    narrow table does not take), sixteen proposals per half-step, eight workgroups per walker:
+    each keeps THEIR items' rows in registers -- the rotation of the items over a walker's
+    workgroups is the same at load time and in every slice.  The resident loop with the rows in
+    registers == with the rows streamed == one launch per half-step == the host-driven loop."""
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    _, p0, raw, data, prior = _problem(na, "cfg1", {})
+
+    def ElectronIC(pars, data):
+        ECPL = na.ExponentialCutoffPowerLaw(pars[0] / u.eV, 10.0 * u.TeV, pars[1], 10 ** pars[2] * u.TeV)
+        IC = na.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"], Eemin=0.05 * u.GeV)
+        return IC.flux(data, distance=1.0 * u.kpc)
+
+    nw, nd = 32, p0.size
+    kw = dict(args=[data, ElectronIC, prior], seed=11, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.01 * np.random.default_rng(2).standard_normal((nw, nd)))
+    runs = {}
+    for mode in ("registers", "streamed", "per-launch", "host"):
+        monkeypatch.setenv("NH_RUN_RT", "0" if mode == "streamed" else "1")
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0" if mode == "per-launch" else "1")
+        d = EnsembleSampler(nw, nd, na.lnprob, device=mode != "host", **kw)
+        st = d.run_mcmc(pos, 3)
+        st = d.run_mcmc(st, 45)
+        if mode in ("registers", "streamed"):
+            info = d._dev.resident_info
+            assert d._dev.resident_launches > 0 and info["tables_in_registers"] == (mode == "registers"), info
+            assert info["grid"] == nw // 2 and d._dev._plan["hs"]["split"] > 1, (info, d._dev._plan["hs"]["split"])
+        runs[mode] = (d.get_chain(), d.get_log_prob(), np.asarray(d.get_blobs()[0], dtype=float))
+    a = runs["streamed"]
+    for mode in ("registers", "per-launch"):
+        assert np.array_equal(runs[mode][0], a[0]), mode  # (the same accept decisions)
+        assert_allclose(runs[mode][1], a[1], rtol=1e-11)
+        assert_allclose(runs[mode][2], a[2], rtol=1e-11, atol=1e-300)
+    assert_allclose(runs["host"][0], a[0], rtol=1e-8)
+    assert_allclose(runs["host"][1], a[1], rtol=1e-6)
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_device_loop_equals_oracle_driven_sampler(na, cfg):
     """>= 4 ensemble steps of the device loop against oracle.stretch_move_reference fed with
