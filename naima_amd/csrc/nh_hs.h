@@ -373,12 +373,12 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
 // ---------------------------------------------------------------------------------------------
 // A table item whose rows stay in REGISTERS for the whole launch (the resident loop of a
 // table-only model, k_half_step_run<false, ., false, RT>): an emission table does not depend on
-// the walker, a resident workgroup's waves take the same items slice after slice, and an item of
-// such a model is one round trip to the L2 and a dozen segments of arithmetic -- three to six
-// microseconds of a twelve-microsecond slice spent waiting for bytes that were the same bytes
-// the slice before (cfg5: 134 KB of walked rows per walker and half-step).  Workgroups of 512
-// threads own 256 vector registers per lane; RT nodes of {K, dlnK} take 4 RT of them.
-// The arithmetic is hs_table_item_packed's / hs_table_item's, operand for operand.
+// the walker and a resident workgroup's waves take the same items slice after slice, so the
+// round trip to the L2s at the head of every item -- for bytes that were the same bytes the
+// slice before -- is paid once per launch (cfg1: 9.6 -> 9.0 us per half-step; what is left of an
+// item is its arithmetic).  Workgroups of 512 threads own 256 vector registers per lane; RT
+// nodes of {K, dlnK} take 4 RT of them.  The arithmetic is hs_table_item_packed's /
+// hs_table_item's, operand for operand.
 #define HS_RT_NODES 28  // nodes per lane a register-resident item may hold (112 registers)
 template <int RT>
 struct hs_rt_item {
