@@ -802,3 +802,19 @@ def test_general_inverse_compton_with_a_seed_density_per_walker(na):
     fh = crab_like(host)
     assert_allclose(np.asarray(fd.value), fh.value, rtol=1e-12, atol=fh.value.max() * 1e-200)
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("rxj1713_synic.py", ["64", "6", "12"]),
+                                         ("crab_synssc.py", ["32", "3", "6"])])
+def test_examples_run(tmp_path, script, args):
+    """examples/: naima's workflow (run_sampler with burn-in, save_run, read_run) on the device
+    loop, at toy sizes -- the RXJ1713 Syn+IC fit and the Crab Syn+SSC fit"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "saved and read back" in out.stdout
