@@ -117,21 +117,29 @@ def test_cfg4_at_its_baseline_ensemble_size(na):
     assert d.nan_proposals == 0 and h.nan_proposals == 0
 
 
-def test_register_resident_table_items_of_a_three_seed_model(na, monkeypatch):
-    """InverseCompton on CMB + FIR + NIR at cfg1's 28 TeV energies over a 700-node grid: ONE table
+@pytest.mark.parametrize("kind", ["three-seeds", "ic+bremsstrahlung"])
+def test_register_resident_table_items_of_a_three_seed_model(na, monkeypatch, kind):
+    """(three-seeds) InverseCompton on CMB + FIR + NIR at cfg1's 28 TeV energies over a 700-node grid: ONE table
     of 84 columns, two column tiles with lane = column (the form of hs_rt_item that cfg1's own
     narrow table does not take), sixteen proposals per half-step, eight workgroups per walker:
     each keeps THEIR items' rows in registers -- the rotation of the items over a walker's
     workgroups is the same at load time and in every slice.  The resident loop with the rows in
-    registers == with the rows streamed == one launch per half-step == the host-driven loop."""
+    registers == with the rows streamed == one launch per half-step == the host-driven loop.
+    (ic+bremsstrahlung) InverseCompton(CMB) + Bremsstrahlung: TWO tables over two particle grids
+    (570 and 1340 nodes; the bremsstrahlung one of 56 columns, electron-electron and
+    electron-proton side by side), their items spread over the same waves."""
     from naima_amd.sampler import EnsembleSampler
     u = na.u
     _, p0, raw, data, prior = _problem(na, "cfg1", {})
 
     def ElectronIC(pars, data):
         ECPL = na.ExponentialCutoffPowerLaw(pars[0] / u.eV, 10.0 * u.TeV, pars[1], 10 ** pars[2] * u.TeV)
-        IC = na.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"], Eemin=0.05 * u.GeV)
-        return IC.flux(data, distance=1.0 * u.kpc)
+        if kind == "three-seeds":
+            IC = na.InverseCompton(ECPL, seed_photon_fields=["CMB", "FIR", "NIR"], Eemin=0.05 * u.GeV)
+            return IC.flux(data, distance=1.0 * u.kpc)
+        IC = na.InverseCompton(ECPL, seed_photon_fields=["CMB"])
+        BR = na.Bremsstrahlung(ECPL, n0=1.0 / u.cm ** 3, nEed=200)
+        return IC.flux(data, distance=1.0 * u.kpc) + BR.flux(data, distance=1.0 * u.kpc)
 
     nw, nd = 32, p0.size
     kw = dict(args=[data, ElectronIC, prior], seed=11, naima_style=True, store_blobs=True)
