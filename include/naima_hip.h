@@ -609,6 +609,16 @@ int nh_half_step_run(nh_ctx* ctx, nh_halfstep_plan* plan, nh_halfstep_run* run, 
                      double* const* hist_blobs /*host array of device pointers, or NULL*/,
                      long long hist_row0, long long hist_cap);
 int nh_half_step_run_status(nh_ctx* ctx, nh_halfstep_run* run, int* status);
+/* What launch number `launch` of the loop (1, 2, ...) left behind, read from page-locked host
+ * memory its epilogue wrote -- no stream operation, no synchronisation: *done = 0 while it has not
+ * ended (wait != 0: sleeps until it has), else its status (0 = it found every record; -1 = the
+ * report has been overwritten: only the last two launches have one) and the plan's counters of
+ * NaN log-probabilities and of proposals the prior forbids (core.py:99-119) as they stood behind
+ * it.  The sampler queues launch n + 1 only once launch n - 1 is known to have ended well, so a
+ * launch that gave up costs the replay of two blocks of moves at most.  One-GPU loops only. */
+int nh_half_step_run_report(nh_ctx* ctx, nh_halfstep_run* run, int launch, int wait, int* done,
+                            int* status, int* nan_count, int* forbidden,
+                            int* before /*[2]: the two counters as the launch found them, or NULL*/);
 /* The resident loop's own copies of the plan's emission tables with their columns SORTED by the
  * first grid row in which they are non-zero (an inverse-Compton or pi0 table is zero below the
  * kinematic threshold gamma = E / mec2, Ep = E ...: rows that contribute exact zeros to

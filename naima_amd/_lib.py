@@ -119,6 +119,8 @@ _SIGS = {
     "nh_half_step_run_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_run": [_dp, _dp, _dp, _i, _i, _dp, _dp, _dp, _ll, _ll],
     "nh_half_step_run_status": [_dp, _dp, C.POINTER(_i)],
+    "nh_half_step_run_report": [_dp, _dp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                C.POINTER(_i)],
     "nh_half_step_run_tables": [_dp, _dp, _dp, _dp, _i],
     "nh_half_step_run_create_shared": [_dp, _dp, _i, _i, C.POINTER(_dp)],
     "nh_half_step_run_export": [_dp, _dp, _dp],

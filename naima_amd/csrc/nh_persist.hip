@@ -45,6 +45,8 @@
 #include "nh_hs.h"
 #include "nh_syn2.h"
 #include <vector>
+#include <chrono>
+#include <unistd.h>
 
 #define HS_RUN_MAX_STEPS 32  // steps per launch (one block of moves); ring rows = this + 1
 #define HS_RUN_ERR_TIMEOUT 1
@@ -91,6 +93,11 @@ struct hs_run {
   // at 30 and at 40; two workgroups per walker -- cfg2 -- 901 at 5, 885 at 10, 914 at 16)
   int syn_nodes;
   int rebalance;  // a tile's chunks divide the rows above its first non-zero one (table-only models)
+  // what the host learns about a launch without a round trip of its own: k_run_epilogue stores
+  // { status, NaN proposals, forbidden proposals, launch number } (the number last) into one of
+  // two slots of page-locked host memory (nh_half_step_run_report)
+  int* report;
+  int report_launch;
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
@@ -303,6 +310,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       reinterpret_cast<long long*>(o + 4)[0] = (long long)P.ld;
       reinterpret_cast<double**>(o + 5)[0] = P.out;
     }
+  }
+  // (the plan's NaN / forbidden-proposal counters as this launch found them: what a replay of
+  // its block of moves starts from again -- nh_half_step_run_report)
+  if (R.report && blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0) {
+    volatile int* rp = R.report + 8 * (R.report_launch & 1);
+    rp[4] = H.done[2];
+    rp[5] = H.done[3];
   }
   // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or
   // by the host: the kernel boundary has made it visible).  Walker w by workgroup w mod grid.
@@ -1110,6 +1124,14 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   // chain of dependent round trips, one after the other they added up to 15 us of a 20-step
   // region
   const int job = blockIdx.y;
+  if (R.report && blockIdx.x == 0 && job == 0 && threadIdx.x == 0) {
+    volatile int* rp = R.report + 8 * (R.report_launch & 1);
+    rp[0] = *R.status;
+    rp[1] = H.done[2];
+    rp[2] = H.done[3];
+    __threadfence_system();
+    rp[3] = R.report_launch;  // (last: whoever sees the number sees the rest)
+  }
   // a launch that gave up (a record never came: nh_half_step_run_status) leaves the flat arrays,
   // the counters and the blob rows as they were before it -- whoever finds the status can replay
   // the block of moves from them
@@ -1210,6 +1232,8 @@ struct nh_halfstep_run {
   size_t lds_bytes;
   int grid, threads;
   int rt;  // the instance whose table items stay in registers (hs_rt_item)
+  int* report;        // page-locked host memory, two slots of four ints (hs_run.report)
+  int nlaunch, fail_at;  // launches so far; NH_RUN_FAIL_AT = the launch whose first wait times out (tests)
   unsigned seq;
   // a shared ensemble (nh_half_step_run_create_shared): `base` is ONE fine-grained allocation
   // { HS_RUN_HEAD granules of probe slots | ring of even launches | ring of odd launches }
@@ -1412,6 +1436,17 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->nrank = shared ? nrank : 1; Q->rank = shared ? rank : 0;
   Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
   Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1; Q->s2_dev = nullptr;
+  Q->report = nullptr; Q->nlaunch = 0; Q->fail_at = nh_env_int("NH_RUN_FAIL_AT", 0);
+  if (!shared) {  // (a shared ensemble's ranks agree on a launch's fate by other means)
+    void* rp = nullptr;
+    if (hipHostMalloc(&rp, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+      Q->report = static_cast<int*>(rp);
+      memset(Q->report, 0, 16 * sizeof(int));
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  Q->R.report = Q->report;
   for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
   Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
   const size_t ring_bytes = Q->ring_elems * sizeof(unsigned long long);
@@ -1687,6 +1722,8 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.nslices = nslices;
   R.seq = Q->seq++ & 0xFFFFFFu;
   if (R.seq == 0) R.seq = Q->seq++ & 0xFFFFFFu;
+  R.report_launch = ++Q->nlaunch;
+  if (Q->fail_at > 0 && Q->nlaunch == Q->fail_at) R.spin_limit = 0;  // (tests: this launch's first wait gives up)
   if (Q->base) {  // a shared ensemble: this launch's ring, here and on every other rank
     const size_t off = HS_RUN_HEAD + (size_t)(R.seq & 1u) * Q->ring_elems;
     for (int p = 0; p < Q->nrank; ++p) {
@@ -1732,6 +1769,42 @@ extern "C" int nh_half_step_run_status(nh_ctx* c, nh_halfstep_run* Q, int* statu
   int rc = nh_sync(c);
   if (rc) return rc;
   NH_CHECK_HIP(hipMemcpy(status, Q->status, sizeof(int), hipMemcpyDeviceToHost));
+  return NH_OK;
+}
+
+// What k_run_epilogue reported about launch number `launch` (1, 2, ...: nh_half_step_run counts
+// them) -- without touching the stream: *done = 0 while the launch has not ended (wait != 0:
+// sleeps until it has, at most ~60 s), else its status (0: every record came), the plan's
+// NaN / forbidden-proposal counters as they stood behind it and (before[2]) as it found them.  Only the last two launches have a
+// slot; an older one reads as done with status -1.
+extern "C" int nh_half_step_run_report(nh_ctx* c, nh_halfstep_run* Q, int launch, int wait, int* done,
+                                       int* status, int* nan_count, int* forbidden, int* before) {
+  NH_REQUIRE(c && Q && done && status && launch >= 1 && launch <= Q->nlaunch, "bad argument");
+  NH_REQUIRE(Q->report != nullptr, "this loop keeps no launch reports");
+  volatile int* rp = Q->report + 8 * (launch & 1);
+  *done = 0;
+  // (a launch is a millisecond: the wait spins on the word for the first 20 ms -- a sleep's
+  // granularity is tens of microseconds, 5 % of a 20-step region of cfg3 -- and sleeps from there)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const int seen = rp[3];
+    if (seen == launch) break;
+    if (seen > launch) {  // (its slot belongs to a later launch by now)
+      *done = 1;
+      *status = -1;
+      return NH_OK;
+    }
+    if (!wait) return NH_OK;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms > 60e3) return nh_set_error(NH_EHIP, "launch %d of the resident loop never reported", launch);
+    if (ms > 20.0) usleep(100);
+  }
+  __sync_synchronize();
+  *done = 1;
+  *status = rp[0];
+  if (nan_count) *nan_count = rp[1];
+  if (forbidden) *forbidden = rp[2];
+  if (before) { before[0] = rp[4]; before[1] = rp[5]; }
   return NH_OK;
 }
 
@@ -1791,6 +1864,7 @@ extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
   if (Q->xspec) (void)hipFree(Q->xspec);
   if (Q->tick) (void)hipFree(Q->tick);
   if (Q->s2_dev) (void)hipFree(Q->s2_dev);
+  if (Q->report) (void)hipHostFree(Q->report);
   delete Q;
   return rc;
 }

@@ -209,6 +209,14 @@ class DeviceLoop:
         self._run = None if os.environ.get("NAIMA_AMD_RESIDENT", "1") != "0" else False
         self._resident_trust = 0          # launches of the resident loop that were checked as they were made
         self.resident_failed_launches = 0
+        # launches of a one-GPU resident loop that are not yet known to have ended well: the
+        # sampler queues launch n + 1 only once launch n - 1 is (nh_half_step_run_report: page-
+        # locked memory the launch's epilogue writes, no stream operation), and settles all of
+        # them before a call returns -- a launch that gave up later in a run costs the replay of
+        # two blocks of moves at most, by the per-launch kernel (sample)
+        self._rl_count = 0     # launches queued so far (the library counts them the same way)
+        self._rl_pending = []
+        self._verify = os.environ.get("NAIMA_AMD_VERIFY_LAUNCHES", "1") != "0"
         self._nan_pending = self._forbidden_pending = 0
         _n = _lib._i(0)  # (the context's word may hold what an earlier sampler left uncounted)
         _lib._chk(_lib._lib.nh_nan_count(self.ctx.h, 1, C.byref(_n)))
@@ -651,6 +659,48 @@ class DeviceLoop:
         moves = s.moves(pinned=True)
         it = 0
         mv = self._mv
+
+        def rollback(rec):
+            """a launch of the resident loop gave up waiting for a walker's record (its workgroups
+            were not all resident: another process on the GPU, a profiler) -- `rec` is the first
+            such launch, everything queued behind it found the same status and changed nothing
+            either (k_run_epilogue leaves the ensemble, the counters and the blobs as a launch
+            that gave up found them).  The books go back to where `rec` was queued, the move
+            stream is made again up to that step (a function of the seed), and the per-launch
+            loop takes over for good: -> (it, the new move stream)"""
+            import warnings
+            from ._lib import Moves
+            void = [r for r in self._rl_pending if r["launch"] >= rec["launch"]]
+            self._rl_pending = []
+            ctx.sync()  # (the void launches behind it: nothing of theirs may still be running)
+            self.resident_reason = ("a launch of the resident loop gave up waiting for a walker's "
+                                    "record (status %d): its workgroups were not all resident"
+                                    % rec["status"])
+            warnings.warn(self.resident_reason + "; %d block(s) of moves are replayed and the run "
+                          "continues with one launch per half-step" % len(void))
+            self._run = False
+            self.resident_failed_launches += len(void)
+            self._read_counts(reset=False, set_to=rec["counts"])  # (the replay counts them again)
+            s.iteration, s.steps_total = rec["iteration"], rec["steps_total"]
+            s.n_lnprob_calls, s.n_walker_evals = rec["nlc"], rec["nwe"]
+            self.resident_launches = rec["rl"]
+            if block is not None:
+                block["n"] = rec["block_n"]
+            while self._inflight:
+                ctx.call("nh_marker_wait", self._inflight.pop(0))
+            mv["have"] = mv["used"] = 0
+            mv["ahead"] = mv["prev"] = mv["last"] = None
+            old = s._moves
+            s._moves = Moves(s.seed, s.nwalkers, s.a, ksteps=32, depth=4, pinned=True)
+            if old is not None:
+                old.close()
+            left = rec["steps_total"]
+            while left > 0:  # (the steps every loop of this sampler has made so far)
+                _, got = s._moves.take(min(32, left))
+                left -= got
+            if self.fused:
+                per_launch_history()
+            return rec["it"], s._moves
         while fast and it < iterations:
             # up to KSTEPS steps per launch.  The moves are a function of the seed only, so the
             # stream's next steps are already on the device (uploaded ahead, below) unless this
@@ -665,11 +715,25 @@ class DeviceLoop:
             if mv["ahead"] is not None:  # the launch waits for the copy stream's last upload
                 ctx.call("nh_stream_wait_marker", mv["ahead"])
                 mv["ahead"] = None
+            verify = self._verify and not self.shared
+            if verify and len(self._rl_pending) >= 2:
+                # launch n + 1 is queued only once launch n - 1 is known to have ended well (launch
+                # n is running meanwhile: the device does not wait for this)
+                gave_up = self._rl_settle(keep=1)
+                if gave_up is not None:
+                    it, moves = rollback(gave_up)
+                    fast = False
+                    break
+            rec = dict(launch=self._rl_count + 1, it=it, iteration=s.iteration, steps_total=s.steps_total,
+                       block_n=block["n"] if block is not None else None, nlc=s.n_lnprob_calls,
+                       nwe=s.n_walker_evals, rl=self.resident_launches)
             if not self._run_resident(2 * mv["used"], 2 * want, block):
                 fast = False  # (gave up: the per-launch loop below replays these steps)
                 if self.fused:
                     per_launch_history()
                 break
+            if verify:
+                self._rl_pending.append(rec)
             mv["used"] += want
             # a marker behind this launch: `blk` is a ring, and the host runs launches ahead of
             # the device -- an upload on the copy stream may overlap THIS launch (whose steps lie
@@ -687,6 +751,13 @@ class DeviceLoop:
             s.steps_total += want
             if block is not None:
                 block["n"] += want
+            if it >= iterations and self._rl_pending:
+                # the call's last launches: known to have ended well before the state is handed out
+                gave_up = self._rl_settle(keep=0)
+                if gave_up is not None:
+                    it, moves = rollback(gave_up)
+                    fast = False
+                    break
             yield DeviceState(self, rng)
         if it < iterations:
             mv["prev"] = mv["last"] = None  # (the per-launch loop takes over: see _moves_append)
@@ -885,6 +956,7 @@ class DeviceLoop:
                 self.resident_reason = _lib._lib.nh_last_error().decode()
                 return False
             self._run = h
+            self._rl_count, self._rl_pending = 0, []  # (the library numbers a loop's launches from 1)
             self._res["runs"].append(h)
             self.ctx.sorted_tables(hs, h)
             g, t, l = _lib._i(), _lib._i(), _lib._ll()
@@ -1080,6 +1152,7 @@ class DeviceLoop:
             # _create_shared_run / bench.py's rehearsal; a time-out later in a run still raises.)
             n0, f0 = self._read_counts(reset=False)
         ctx.call("nh_half_step_run", hs["plan"], self._run, slice0, nslices, hc, hl, hb, row0, cap)
+        self._rl_count += 1
         if probation:
             st = _lib._i()
             _lib._chk(_lib._lib.nh_half_step_run_status(ctx.h, self._run, C.byref(st)))
@@ -1099,6 +1172,20 @@ class DeviceLoop:
         self.s.n_lnprob_calls += nslices
         self.s.n_walker_evals += nslices * self.nloc
         return True
+
+    def _rl_settle(self, keep):
+        """wait until all but the last `keep` queued launches are known to have ended; None, or
+        the record of the first one that gave up (it and everything queued behind it are void)"""
+        while len(self._rl_pending) > keep:
+            rec = self._rl_pending[0]
+            done, st, before = _lib._i(0), _lib._i(0), (C.c_int * 2)()
+            _lib._chk(_lib._lib.nh_half_step_run_report(self.ctx.h, self._run, rec["launch"], 1,
+                                                        C.byref(done), C.byref(st), None, None, before))
+            if st.value != 0:
+                rec["status"], rec["counts"] = st.value, (before[0], before[1])
+                return rec
+            self._rl_pending.pop(0)
+        return None
 
     def _read_counts(self, reset, set_to=None):
         """(NaN log-probabilities, proposals forbidden by the prior) the one-launch kernels have

@@ -811,6 +811,55 @@ def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
     assert np.array_equal(d2.get_chain(), ref.get_chain())
 
 
+@pytest.mark.parametrize("fail_at,blobs", [(4, True), (7, False), (11, True)],
+                         ids=["fourth-launch", "seventh-no-blobs", "a-call's-last-launch"])
+def test_a_later_launch_that_gives_up_is_replayed(na, monkeypatch, fail_at, blobs):
+    """a launch of the resident loop that gives up LATER in a run (NH_RUN_FAIL_AT: that launch's
+    first wait times out; what another process taking the GPU's CUs would do): the sampler learns
+    of it one launch later from the page-locked report its epilogue wrote (nothing synchronises
+    per launch), the launch queued behind it found the same status and changed nothing, the books
+    go back two blocks of moves, the move stream is made again up to that step and the per-launch
+    kernel carries the run on -- chain, log-probabilities, blobs, acceptance and counters are the
+    per-launch loop's, bit for bit."""
+    from naima_amd.sampler import EnsembleSampler
+    model, p0, raw, data, prior = _problem(na, "cfg3", {})
+    nw, nd = 512, p0.size
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
+    kw = dict(args=[data, model, prior], seed=5, naima_style=True, store_blobs=blobs, device=True)
+
+    def run(d):
+        st = d.run_mcmc(pos, 4)
+        st = d.run_mcmc(st, 200)   # (seven launches of 32 steps at most)
+        st = d.run_mcmc(st, 70, store=False)
+        st = d.run_mcmc(st, 50)    # (launch 11 is the last of the third call when nothing failed)
+        return st
+
+    monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0")
+    ref = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    sr = run(ref)
+    monkeypatch.delenv("NAIMA_AMD_RESIDENT")
+    monkeypatch.setenv("NH_RUN_FAIL_AT", str(fail_at))
+    d = EnsembleSampler(nw, nd, na.lnprob, **kw)
+    with pytest.warns(UserWarning, match="gave up waiting"):
+        sd = run(d)
+    assert d._dev.resident_failed_launches >= 1 and d._dev.resident_launches == fail_at - 1, \
+        (d._dev.resident_failed_launches, d._dev.resident_launches)
+    # (the same accept decisions, hence the same positions to the last bit; the launches that ran
+    # resident before the one that gave up cut the tables' rows into work items differently: their
+    # log-probabilities and spectra agree to rounding, see test_resident_loop_equals_per_launch_loop)
+    assert np.array_equal(d.get_chain(), ref.get_chain())
+    assert_allclose(d.get_log_prob(), ref.get_log_prob(), rtol=1e-11)
+    assert np.array_equal(np.asarray(sd.coords), np.asarray(sr.coords))
+    if blobs:
+        for x, y in zip(d.get_blobs(), ref.get_blobs()):
+            assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10, atol=1e-300,
+                            equal_nan=True)
+    assert_allclose(d.acceptance_fraction, ref.acceptance_fraction)
+    assert d.nan_proposals == ref.nan_proposals
+    assert d.prior_forbidden_proposals == ref.prior_forbidden_proposals
+    assert d.iteration == ref.iteration and d.steps_total == ref.steps_total
+
+
 def test_resident_loop_through_many_blocks_of_moves(na, monkeypatch):
     """one run_mcmc call of 330 steps: eleven launches queued back to back, the device block of
     moves (a ring of 128 steps, refilled on a copy stream while launches run) wraps twice --
