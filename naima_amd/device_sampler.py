@@ -1149,7 +1149,8 @@ class DeviceLoop:
             # counters and the move stream as they were (k_run_epilogue does nothing then), so the
             # same block of moves is replayed by the per-launch kernel and the run carries on
             # with one launch per half-step.  (A shared ensemble: the ranks agree in
-            # _create_shared_run / bench.py's rehearsal; a time-out later in a run still raises.)
+            # _create_shared_run / bench.py's rehearsal and raise together on a later time-out; a
+            # one-GPU loop's later launches are checked a launch behind: sample, _rl_settle.)
             n0, f0 = self._read_counts(reset=False)
         ctx.call("nh_half_step_run", hs["plan"], self._run, slice0, nslices, hc, hl, hb, row0, cap)
         self._rl_count += 1
@@ -1239,9 +1240,10 @@ class DeviceLoop:
     def check_resident(self, collective=False):
         """raise if a launch of the resident loop gave up waiting for a walker's record (its
         workgroups were not all resident: another process on the GPU, a profiler that
-        serialises workgroups); the ensemble is undefined from that launch on.  (The first
-        launches of a one-GPU loop are checked as they are made and replayed by the per-launch
-        kernel instead: _run_resident.)  ``collective``: every rank is here -- the worst status
+        serialises workgroups); the ensemble is undefined from that launch on.  (A one-GPU
+        loop's launches are checked as they are made, or a launch behind, and replayed by the
+        per-launch kernel instead: _run_resident, sample -- what is left to find here is a
+        shared ensemble's, or a loop run with NAIMA_AMD_VERIFY_LAUNCHES=0.)  ``collective``: every rank is here -- the worst status
         of all ranks decides, and all of them raise."""
         st = _lib._i(0)
         if self._run:
