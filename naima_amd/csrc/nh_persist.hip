@@ -1437,20 +1437,20 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
   Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1; Q->s2_dev = nullptr;
   Q->report = nullptr; Q->nlaunch = 0; Q->fail_at = nh_env_int("NH_RUN_FAIL_AT", 0);
-  if (!shared) {  // (a shared ensemble's ranks agree on a launch's fate by other means)
-    void* rp = nullptr;
-    if (hipHostMalloc(&rp, 16 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
-      Q->report = static_cast<int*>(rp);
-      memset(Q->report, 0, 16 * sizeof(int));
-    } else {
-      (void)hipGetLastError();
-    }
-  }
-  Q->R.report = Q->report;
+  Q->R.report = nullptr;
   for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
   Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
   const size_t ring_bytes = Q->ring_elems * sizeof(unsigned long long);
   hipError_t e = hipSuccess;
+  if (!shared) {  // (a shared ensemble's ranks agree on a launch's fate by other means)
+    void* rp = nullptr;
+    e = hipHostMalloc(&rp, 16 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) {
+      Q->report = static_cast<int*>(rp);
+      memset(Q->report, 0, 16 * sizeof(int));
+      Q->R.report = Q->report;
+    }
+  }
   if (shared) {
     // Fine-grained device memory: what another GPU stores into it over xGMI is visible to a
     // kernel that is already running here, and system-scope loads are served from memory, not
@@ -1471,7 +1471,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (e == hipSuccess) e = nh_fill_now(c, Q->curstamp, 0xFF, (size_t)R.N * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&Q->probe_out, (4 + HS_RUN_MAX_RANKS) * sizeof(int));
   } else {
-    e = hipMalloc(&Q->ring, ring_bytes);
+    if (e == hipSuccess) e = hipMalloc(&Q->ring, ring_bytes);
     if (e == hipSuccess) e = nh_fill_now(c, Q->ring, 0, ring_bytes);
   }
   if (e == hipSuccess && R.syn2) {
@@ -1505,6 +1505,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (Q->xspec) (void)hipFree(Q->xspec);
     if (Q->tick) (void)hipFree(Q->tick);
     if (Q->s2_dev) (void)hipFree(Q->s2_dev);
+    if (Q->report) (void)hipHostFree(Q->report);
     delete Q;
     return nh_set_error(NH_EHIP, "resident half-step loop: %s", hipGetErrorString(e));
   }
