@@ -532,11 +532,16 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
       const double f2 = cur.x, dlf = cur.y;
 #pragma unroll
       for (int j = 0; j < W; ++j) {
-        const double uo = u1[j], io = in[j];
+        const double uo = u1[j];
         const double u2 = f2 * sd8[j];
         const double dl = dlf + dl8[j];
-        double t = fma(u2 - uo, nh_rcp1f(dl), io);
-        // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos
+        const double diff = u2 - uo, r = nh_rcp1f(dl);
+        // (accumulated IN PLACE: with the sum's old value kept for the rare branch below, the
+        // compiler computed into a temporary and paid a 64-bit move per walker and node to put
+        // the result back where the loop carries it -- one instruction of eleven)
+        in[j] = fma(diff, r, in[j]);
+        // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos instead of
+        // the term just added (taken off again: the sum moves by an ulp there)
         const bool small = fabs(dl) < thr;
         if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
           asm volatile("" ::: "memory");  // keep this a branch
@@ -545,9 +550,8 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
           f = fma(f, d, 1.666666666666667e-01);
           f = fma(f, d, 0.5);
           f = fma(f, d, 1.0);
-          t = small ? fma(uo * lxv, f, io) : t;
+          in[j] = small ? fma(uo * lxv, f, fma(-diff, r, in[j])) : in[j];
         }
-        in[j] = t;
         u1[j] = u2;
       }
     }
