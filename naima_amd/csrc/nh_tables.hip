@@ -213,6 +213,9 @@ __global__ void k_ssc_prep(const double* __restrict__ se, const double* __restri
     } else if (s > 0) {  // a zero node ends the power-law segment: marked as in the tables
       const double a = sd[w * ns + s - 1];
       v = (a == 0.0 || b == 0.0) ? NH_DL_ZERO : log(fabs(b / a)) / log(se[s] / se[s - 1]);
+      // (last mantissa bit SET, k_ssc_table's log-ratios have it CLEAR: the sum of the two that
+      // k_ic_seed_walkers_tab divides by is then never exactly 0 -- see there)
+      if (v != 0.0 && fabs(v) < INFINITY) v = __longlong_as_double(__double_as_longlong(v) | 1ll);
     }
   } else if (slot < 2 * SSC_W + 4) {
     const int q = slot - 2 * SSC_W;
@@ -467,7 +470,14 @@ __global__ __launch_bounds__(512) void k_ssc_table(const double* __restrict__ ga
     const double f2 = ssc_fic(gk, 1.0 / e, 2.0 * log(e));
     const double lf2 = ssc_log(fabs(f2), L0, L1, L2, L3, L4, L5, L6) + (f2 == 0.0 ? -INFINITY : 0.0);
     const double ilx = 1.0 / log(se[s] / se[s - 1]);
-    ssc_d2 v = {f2, fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx};
+    // The log-ratio with its last mantissa bit CLEAR, and 2^-60 for an exact 0 (two equal
+    // entries: the difference of the integrand's nodes is then 0 as well): with the walkers'
+    // log-ratios' last bit SET (k_ssc_prep) the sum of the two cannot cancel to exactly 0, and
+    // k_ic_seed_walkers_tab, which adds (u2 - u1) / dl to its sum BEFORE it looks at dl, never
+    // adds a NaN.
+    double dq = fmin(fmax(lf2 - lf1, -NH_DL_ZERO), NH_DL_ZERO) * ilx;
+    dq = dq == 0.0 ? 0x1p-60 : __longlong_as_double(__double_as_longlong(dq) & ~1ll);
+    ssc_d2 v = {f2, dq};
     Fp[(size_t)s * 64] = v;
     if (__builtin_amdgcn_ballot_w64(f1 != 0.0 || f2 != 0.0) != 0ull) {
       s_lo = min(s_lo, s);
@@ -541,7 +551,8 @@ __global__ __launch_bounds__(64 * C) void k_ic_seed_walkers_tab(
         // the result back where the loop carries it -- one instruction of eleven)
         in[j] = fma(diff, r, in[j]);
         // |dl| < 2^-10 (rare: the segment at the peak of u): the series of nh_seg_pos instead of
-        // the term just added (taken off again: the sum moves by an ulp there)
+        // the term just added (taken off again: the sum moves by an ulp there; dl is never an
+        // exact 0, whose reciprocal would have made the sum a NaN: k_ssc_table)
         const bool small = fabs(dl) < thr;
         if (__builtin_amdgcn_ballot_w64(small) != 0ull) {
           asm volatile("" ::: "memory");  // keep this a branch

@@ -850,7 +850,7 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
     density per walker, radiative.py:609-655 + 684 -- at the shapes
     their mapping cares about: 1 / 9 / 17 / 33 walkers (groups of 8 and of 16, padded groups), a
     seed spectrum of two nodes, seed nodes with ZERO density (the trapz_loglog zero rule,
-    utils.py:347-348) at the ends and in the middle, a particle grid shorter than a wave's 64
+    utils.py:347-348) at the ends and in the middle, a density that is the same at every node, a particle grid shorter than a wave's 64
     nodes and one that needs several gamma tiles, one photon energy"""
     from oracle import naima_np as O
     from naima_amd._lib import get_context
@@ -861,7 +861,7 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
     orig = ctx.call
     monkeypatch.setattr(ctx, "call", lambda name, *a: (seen.append(name), orig(name, *a))[1])
 
-    def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=(), empty=()):
+    def check(N, ns, nE, Eemin_eV, Eemax_eV, nEed, zeros=(), empty=(), flat=()):
         E = np.geomspace(1e3, 3e13, nE) if nE > 1 else np.array([2e9])
         se = np.geomspace(1e-6, 1e4, ns)
         base = 1e3 * (se / 1e-2) ** -1.4 * np.exp(-se / 2e3)
@@ -872,6 +872,8 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
             sd[1, ns // 3] = 0.0  # ... and a zero that only one walker has
         for wz in empty:  # walkers WITHOUT a seed field: packed out of the groups (k_ssc_order)
             sd[wz, :] = 0.0
+        for wf in flat:  # the SAME density at every node: the walker's log-ratios are exact zeros
+            sd[wf, :] = 7.0
         amp = 10 ** (33 + 0.05 * rng.standard_normal(N))
         alpha = 2.3 + 0.1 * rng.standard_normal(N)
         pd = na.ExponentialCutoffPowerLaw(amp / u.eV, 10 * u.TeV, alpha, 30 * u.TeV)
@@ -901,6 +903,7 @@ def test_ssc_seed_edge_shapes_against_oracle(na, tabulated, monkeypatch):
     check(N=17, ns=30, nE=70, Eemin_eV=1e8, Eemax_eV=1e15, nEed=40, zeros=(0, 29, 11))  # 280 nodes
     check(N=33, ns=25, nE=1, Eemin_eV=1e9, Eemax_eV=1.5e9, nEed=100, zeros=(5,))  # 17 -> 10 nodes
     check(N=8, ns=40, nE=66, Eemin_eV=1e10, Eemax_eV=1e13, nEed=100)      # 300 nodes, 5 tiles
+    check(N=20, ns=40, nE=30, Eemin_eV=1e9, Eemax_eV=1e14, nEed=40, flat=(0, 19))
     check(N=150, ns=33, nE=19, Eemin_eV=1e9, Eemax_eV=1e14, nEed=30, zeros=(2,))  # 10 groups: two chunks
     # walkers without a seed density (what a proposal the prior forbids hands over): some, scattered
     # -- the last group of the packed order is mixed --, all but one, and every one
