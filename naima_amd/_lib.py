@@ -360,10 +360,8 @@ class Context:
     # -- memory -------------------------------------------------------------
     @staticmethod
     def _bucket(nbytes):
-        b = 256
-        while b < nbytes:
-            b <<= 1
-        return b
+        # (the next power of two, 256 at least; on the sampler's per-call path)
+        return 256 if nbytes <= 256 else 1 << (int(nbytes) - 1).bit_length()
 
     def empty(self, shape, dtype=np.float64):
         # (on the sampler's per-call path: no numpy reductions for the product of three ints)
