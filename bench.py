@@ -68,6 +68,30 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VEC_PEAK_TF = 78.6    # vendor figure quoted in SURVEY.md 8d (256 CU x 128 flop/clk x 2.4 GHz)
 
 
+def _profiles_by_round(pattern):
+    """committed profiles matching ``pattern``, oldest round first (r10 after r9: by the parsed
+    round number, not by the name's spelling)"""
+    import glob
+    import re
+
+    def key(f):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        return (int(m.group(1)) if m else -1, os.path.basename(f))
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=key)
+
+
+def _last_commit_of(path):
+    """short hash of the commit that last touched ``path`` (None outside a git checkout: the GPU
+    box runs a snapshot without .git)"""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", path],
+                             capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
+
+
 def measured_utilisation(name, resident):
     """What the vector pipe did, from the committed SQ counter passes of this workload's bench
     command under rocprofv3 (profiles/r*_<name>_counters_per_launch.json, newest round): the
@@ -75,8 +99,7 @@ def measured_utilisation(name, resident):
     (SQ_ACTIVE_INST_VALU x 4 waves per SIMD / SQ_WAVE_CYCLES for the 1024-thread workgroups; this
     is the utilisation figure of an issue-bound kernel -- `fp64_valu` beside it is SURVEY.md 8d's
     op-count convention) and instructions per wave and launch.  None without a profile."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters_per_launch.json" % name)))
+    files = _profiles_by_round("r*_%s_counters_per_launch.json" % name)
     if not files:
         return None
     want = "half_step_run" if resident else ("ic_seed_walkers" if name == "cfg4" else "half_step")
@@ -94,6 +117,8 @@ def measured_utilisation(name, resident):
     k, v = best
     waves = max(v.get("SQ_WAVES", 1.0), 1.0)
     out = {"kernel": k.split("(")[0].strip(), "source": os.path.basename(files[-1]),
+           "from_committed_profile": True, "source_commit": _last_commit_of(files[-1]),
+           "measured_in_this_run": False,
            "valu_busy": 4.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
            "valu_insts_per_wave_and_launch": v.get("SQ_INSTS_VALU", 0.0) / waves,
            "salu_insts_per_wave_and_launch": v.get("SQ_INSTS_SALU", 0.0) / waves,
@@ -110,8 +135,7 @@ def measured_traffic(name, symbol):
     correction of MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced
     reads (16 B per lane: the kernel's table stream) and is doubled; WRITE_SIZE is
     uncalibrated and taken as reported.  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_hbm_counters*.json" % name)))
+    files = _profiles_by_round("r*_%s_hbm_counters*.json" % name)
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -258,61 +282,107 @@ def cpu_baseline(name, raw, p0, seconds=8.0):
                       "%.1f s (+%d on one core in %.1f s)" % (total, name, cores, wall, n1, t1)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --walkers per GPU (default); strong: --walkers-total split over the GPUs")
-    ap.add_argument("--walkers-total", type=int, default=None,
-                    help="strong scaling: size of the whole ensemble (default: the workload's "
-                         "BASELINE figure -- cfg5 2048, cfg4 1024, cfg3 512)")
-    ap.add_argument("--ball", type=float, default=0.1,
-                    help="relative spread of the initial ensemble around p0 (naima: 10 %%, core.py:477-481)")
-    ap.add_argument("--min-time", type=float, default=0.5,
-                    help="repeat the K-step timed region until this many seconds have been timed")
-    ap.add_argument("--no-blobs", action="store_true",
-                    help="the timed loop does not keep the blobs (emcee and the reference always do: "
-                         "(flux, We) per walker and step, core.py:450-457)")
-    ap.add_argument("--no-blobs-run", action="store_true",
-                    help="skip the extra measurement with the opposite blob setting")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--reject-nan", action="store_true",
-                    help="treat a NaN log-probability as a rejected proposal and count it; the "
-                         "default is emcee's: ValueError on the first one")
-    ap.add_argument("--no-chain", action="store_true",
-                    help="do not keep the chain (emcee's store=False); default keeps it in HBM")
-    ap.add_argument("--host-loop", action="store_true",
-                    help="drive the step loop from the host (no device-resident ensemble)")
-    ap.add_argument("--no-graph", action="store_true", help="device loop without hipGraph replay")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    args = ap.parse_args()
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves -- one
+    process per GPU, the reference's ``Pool(threads)`` of core.py:446-457 with GPUs for
+    workers -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    ``torch.distributed.run`` sets them (naima_amd.dist.SocketGroup is the control plane: no
+    torch).  Rank 0's stdout (the ONE JSON line) is passed through, every rank's stderr too.
+    Fewer than N visible devices is an error unless NAIMA_AMD_DEVICE pins every rank to one
+    (the rehearsal of the N-rank path on a one-GPU box: RCCL refuses two ranks of one device,
+    so the control plane is the host-staged one, NAIMA_AMD_COMM=host)."""
+    import signal
+    import subprocess
+    from naima_amd import _lib
+    ndev = _lib.device_count()
+    pinned = os.environ.get("NAIMA_AMD_DEVICE") or None
+    if ndev < n and pinned is None:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible.  One rank per GPU needs "
+                         "%d; set NAIMA_AMD_DEVICE=<k> to rehearse all ranks on ONE device."
+                         % (n, ndev, n))
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NAIMA_AMD_SELF_SPAWNED="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if pinned is not None:
+            env.setdefault("NAIMA_AMD_COMM", "host")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, cwd=ROOT, start_new_session=True,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for pr in list(alive):
+                c = pr.poll()
+                if c is None:
+                    continue
+                alive.remove(pr)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for other in alive:  # (exactly the process groups started above)
+                        try:
+                            os.killpg(other.pid, signal.SIGTERM)
+                        except OSError:
+                            pass
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+    raise SystemExit(rc)
+
+
+def exchange_info(sampler, comm, shared_note):
+    """which exchange path the ranks took for the one exchange of a half-step, and why"""
+    dev = getattr(sampler, "_dev", None)
+    if dev is None or comm.size == 1:
+        return {"path": "none (one rank)", "ranks": comm.size}
+    kind = type(comm).__name__
+    out = {"ranks": comm.size, "communicator": kind,
+           "rccl_nranks": comm.size if kind == "RcclComm" else None}
+    if getattr(dev, "shared", False):
+        out.update(path="shared_resident_loop", why=shared_note,
+                   probe_us_per_exchange=(dev.shared_info or {}).get("probe_us_per_exchange"))
+    else:
+        out.update(path=("RCCL all-gather" if kind == "RcclComm" else "host-staged all-gather"),
+                   in_graph=bool(getattr(dev, "coll_in_graph", False)), why=shared_note)
+    return out
+
+
+def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
+    """one workload on the ranks of ``comm``: the timed K-step regions (``full``: plus the other
+    blob setting, per-kernel HIP events, roofline, CPU baseline) -> the line's dict on rank 0,
+    None elsewhere"""
+    import math
 
     import naima_amd as na
-    from naima_amd import _lib, dist
+    from naima_amd import _lib
     from naima_amd import workloads as W
     from naima_amd.sampler import EnsembleSampler
-
-    ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
-    comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # host: test hook
-    name = args.workload
+    rank = comm.rank
     model, p0, raw, data, prior, labels = build_problem(name, na)
-    if args.scaling == "strong":
-        nwalkers = args.walkers_total or W.WORKLOADS[name]["nwalkers"]
+    if scaling == "strong":
+        nwalkers = walkers_total or W.WORKLOADS[name]["nwalkers"]
         if nwalkers % (2 * comm.size):
             raise SystemExit("--walkers-total %d does not split into two halves over %d GPUs"
                              % (nwalkers, comm.size))
         per_gpu = nwalkers // comm.size
     else:
-        per_gpu = args.walkers or (256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"])
+        per_gpu = walkers or (256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"])
         nwalkers = per_gpu * comm.size
 
     def make_sampler(device, graph, blobs=False):
@@ -362,6 +432,7 @@ def main():
         ctx.sync()
         per_step = comm.max((time.perf_counter() - tw) / 8)
         spinup = 8 + int(min(max(0, 152 - args.warmup), 0.5 / max(per_step, 1e-6)))
+        spinup = int(comm.max(spinup))
         if spinup > 8:
             state = sampler.run_mcmc(state, spinup - 8, store=False)
 
@@ -389,7 +460,6 @@ def main():
     # block of moves is a graph of its own -- are captured here, not inside a timed region)
     # (a K-step call takes its moves from 32-step blocks: where a call starts within a block
     # repeats after 32 / gcd(32, K) calls, and with it the set of graphs)
-    import math
     rehearsed = 0
     for _ in range(min(16, 32 // math.gcd(32, max(1, args.steps)))):
         _, state = timed_region(sampler, state)
@@ -399,8 +469,9 @@ def main():
     acc_frac = float(np.mean(sampler.acceptance_fraction))
     sampler.reset()  # (the chain of a region is dropped before the next one)
     times = [first]
+    min_time = args.min_time if full else min(args.min_time, 0.25)
     # every region's time is already the max over ranks: all ranks take the same decisions
-    while sum(times) < args.min_time and len(times) < 1000:
+    while sum(times) < min_time and len(times) < 1000:
         dt_i, state = timed_region(sampler, state)
         times.append(dt_i)
         sampler.reset()
@@ -411,7 +482,7 @@ def main():
     # per walker and step, core.py:450-457, and so does the timed loop above unless
     # --no-blobs): reported in an extra key
     blobs_value = None
-    if device and not args.no_blobs_run:
+    if device and full and not args.no_blobs_run:
         bs = make_sampler(device, not args.no_graph, blobs=not keep_blobs)
         bst = bs.run_mcmc(final_coords, 6, store=False)
         bt = []
@@ -430,32 +501,105 @@ def main():
     # the same K steps as the timed ones
     resident = device and getattr(sampler._dev, "resident_launches", 0) > 0
     prof_steps = max(args.steps, 50)
-    if resident:
-        ctx.sync()
-        ctx.profile(True)
-        ctx.profile_read(reset=True)
-        pstate, prof_steps = state, 0
-        while prof_steps < 50:
-            pstate = sampler.run_mcmc(pstate, args.steps, store=not args.no_chain)
-            sampler.reset()
-            prof_steps += args.steps
-        prof = ctx.profile_read(reset=True)
-        ctx.profile(False)
-    else:
-        prof_sampler = make_sampler(device, False, blobs=keep_blobs)
-        pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
-        ctx.sync()
-        ctx.profile(True)
-        ctx.profile_read(reset=True)
-        prof_sampler.run_mcmc(pstate, prof_steps, store=False)
-        prof = ctx.profile_read(reset=True)
-        ctx.profile(False)
-    ev_us = ctx.profile_overhead_us()  # what an event pair adds to every launch
+    prof, ev_us = {}, 0.0
+    if full or comm.size == 1:
+        if resident:
+            ctx.sync()
+            ctx.profile(True)
+            ctx.profile_read(reset=True)
+            pstate, prof_steps = state, 0
+            while prof_steps < 50:
+                pstate = sampler.run_mcmc(pstate, args.steps, store=not args.no_chain)
+                sampler.reset()
+                prof_steps += args.steps
+            prof = ctx.profile_read(reset=True)
+            ctx.profile(False)
+        else:
+            prof_sampler = make_sampler(device, False, blobs=keep_blobs)
+            pstate = prof_sampler.run_mcmc(final_coords, 2, store=False)
+            ctx.sync()
+            ctx.profile(True)
+            ctx.profile_read(reset=True)
+            prof_sampler.run_mcmc(pstate, prof_steps, store=False)
+            prof = ctx.profile_read(reset=True)
+            ctx.profile(False)
+        ev_us = ctx.profile_overhead_us()  # what an event pair adds to every launch
+    # (collective: every rank's counts meet here)
+    forbidden, nan_rej = int(sampler.prior_forbidden_proposals), int(sampler.nan_proposals)
+    proposals_total = int(sampler.steps_total) * int(nwalkers)
+    xinfo = exchange_info(sampler, comm, shared_note)
 
     if rank != 0:
-        return
+        return None
     value = nwalkers * args.steps / dt
     info = ctx.info()
+    frac_evaluated = 1.0 - forbidden / max(proposals_total, 1)
+    out = {
+        "metric": "walker-steps/sec (ensemble lnprob evals/s)",
+        "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        # walker-steps whose integrals RAN: a proposal the prior forbids is a walker-step of `value`
+        # (it is a proposal of the move, never accepted) but the device loop evaluates none of its
+        # integrals, where the reference evaluates the model and discards it (core.py:98-119) --
+        # the share is that of every step this sampler made, warm-up included
+        "value_evaluated": value * frac_evaluated,
+        "config": {"workload": "%s: %s" % (name, {
+            "cfg1": "ECPL -> IC(CMB), 28 energies",
+            "cfg2": "ECPL -> Synchrotron, 179 energies, 300-pt Ee grid",
+            "cfg3": "RXJ1713 Syn+IC joint fit (CMB+FIR+NIR), 5 parameters, 64 energies",
+            "cfg4": "Crab Syn+SSC, 261 energies, 869-pt Ee grid, 100 seed energies",
+            "cfg5": "PionDecay ECBPL, 28 energies, 600-pt Ep grid"}[name]),
+            "scaling": scaling,
+            "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
+            "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
+            "initial_ball": args.ball,
+            "device": info["name"], "untimed_spinup_steps": spinup + rehearsed,
+            "ranks": comm.size,
+            "ranks_started_by": ("bench.py itself (one process per GPU)"
+                                 if os.environ.get("NAIMA_AMD_SELF_SPAWNED") == "1" else
+                                 "the launcher (WORLD_SIZE)" if comm.size > 1 else "one process"),
+            "devices_pinned_to": os.environ.get("NAIMA_AMD_DEVICE"),
+            "exchange": xinfo,
+            "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
+                           "none: a mover stores its walker's record into every rank's ring "
+                           "(system-scope stores over xGMI, rings mapped through hipIpc); %r"
+                           % (sampler._dev.shared_info,) if getattr(sampler._dev, "shared", False) else
+                           "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
+                           else "all-gather between two graphs per half-step")
+            if device else "host loop",
+            "shared_resident_loop": shared_note,
+            "chain": "discarded (store=False)" if args.no_chain else
+            "kept: every step's coords, log-prob%s appended in HBM by the step kernels"
+            % (" and blobs" if keep_blobs else "")},
+        "timing": {"regions": len(times), "steps_per_region": args.steps,
+                   "statistic": "median region (every region: barrier + sync, K steps, sync + "
+                                "barrier, max over ranks)",
+                   "timed_s_total": float(np.sum(times)),
+                   "value_first_region": nwalkers * args.steps / times[0],
+                   "value_min": nwalkers * args.steps / max(times),
+                   "value_max": nwalkers * args.steps / min(times)},
+        "blobs": ("kept: the model spectrum and We/Wp of every walker and step, in HBM"
+                  if keep_blobs else "not kept (--no-blobs)"),
+        "acceptance_fraction": acc_frac,
+        # (emcee stops at the first NaN log-probability, and so does this run unless
+        # --reject-nan: the workloads' priors -- workloads.prior_for -- keep the walkers of the
+        # 10 % ball off the zero-flux plateau where 10 ** x of a wandered coordinate overflows)
+        "nan_policy": "reject" if args.reject_nan else "raise",
+        "nan_proposals_rejected": nan_rej,
+        # (counted by the kernels over every step the timed sampler made, warm-up included)
+        "proposals_forbidden_by_prior": forbidden,
+        "proposals_total": proposals_total,
+        "loop": ("host" if not device else
+                 "device, resident workgroups: one launch of k_half_step_run per block of moves "
+                 "(<= 32 steps), walkers handed over by tagged records" if resident else
+                 ("device+hipGraph" if sampler._dev.graph is not None else "device")),
+    }
+    if blobs_value is not None or full:
+        out["value_without_blobs" if keep_blobs else "value_store_blobs"] = blobs_value
+    if not prof:
+        return out
     # dominant kernel by accumulated HIP-event time (one category = one kernel symbol;
     # "glue"/"tables" aggregate several small kernels and are not candidates).  The fixed
     # cost of the event pair (an empty kernel bracketed the same way, minus its ~1 us of
@@ -484,92 +628,52 @@ def main():
     dom_symbol = ("k_half_step_run" if resident and dom == "half_step"
                   else KERNEL_SYMBOL.get(dom, dom).split("/")[0].split(" ")[0])
     traffic, traffic_src = measured_traffic(name, dom_symbol)
-    out = {
-        "metric": "walker-steps/sec (ensemble lnprob evals/s)",
-        "value": value, "unit": "walker-steps/s", "n_gpus": comm.size, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "%s: %s" % (name, {
-            "cfg1": "ECPL -> IC(CMB), 28 energies",
-            "cfg2": "ECPL -> Synchrotron, 179 energies, 300-pt Ee grid",
-            "cfg3": "RXJ1713 Syn+IC joint fit (CMB+FIR+NIR), 5 parameters, 64 energies",
-            "cfg4": "Crab Syn+SSC, 261 energies, 869-pt Ee grid, 100 seed energies",
-            "cfg5": "PionDecay ECBPL, 28 energies, 600-pt Ep grid"}[name]),
-            "scaling": args.scaling,
-            "walkers_per_gpu": per_gpu, "walkers_total": nwalkers, "ndim": int(p0.size),
-            "n_energies": int(len(raw["energy"])), "sharding": "walkers/%d" % comm.size,
-            "initial_ball": args.ball,
-            "device": info["name"], "untimed_spinup_steps": spinup + rehearsed,
-            "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
-                           "none: a mover stores its walker's record into every rank's ring "
-                           "(system-scope stores over xGMI, rings mapped through hipIpc); %r"
-                           % (sampler._dev.shared_info,) if getattr(sampler._dev, "shared", False) else
-                           "RCCL all-gather inside the step graphs" if sampler._dev.coll_in_graph
-                           else "all-gather between two graphs per half-step")
-            if device else "host loop",
-            "shared_resident_loop": shared_note,
-            "chain": "discarded (store=False)" if args.no_chain else
-            "kept: every step's coords, log-prob%s appended in HBM by the step kernels"
-            % (" and blobs" if keep_blobs else "")},
-        "timing": {"regions": len(times), "steps_per_region": args.steps,
-                   "statistic": "median region (every region: barrier + sync, K steps, sync + "
-                                "barrier, max over ranks)",
-                   "timed_s_total": float(np.sum(times)),
-                   "value_first_region": nwalkers * args.steps / times[0],
-                   "value_min": nwalkers * args.steps / max(times),
-                   "value_max": nwalkers * args.steps / min(times)},
-        "blobs": ("kept: the model spectrum and We/Wp of every walker and step, in HBM"
-                  if keep_blobs else "not kept (--no-blobs)"),
-        ("value_without_blobs" if keep_blobs else "value_store_blobs"): blobs_value,
-        "roofline": {"bound": "hbm",
-                     "kernel": ("k_half_step_run (nh_half_step_run: one launch per block of moves)"
-                                if resident and dom == "half_step"
-                                else KERNEL_SYMBOL.get(dom, dom)), "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_us": avg_s * 1e6,
-                     "avg_launch_us_raw_events": prof[dom]["ms"] * 1e3 / prof[dom]["launches"],
-                     "event_pair_overhead_us": ev_us, "event_correction": ev_note,
-                     "algorithmic_bytes_per_launch": abytes,
-                     "walkers_per_launch": walkers_per_launch,
-                     "us_per_half_step": (avg_s * 1e6 / (walkers_per_launch / (per_gpu / 2.0))),
-                     "note": "FP64-issue-bound path: the HBM fraction is << 1 % by "
-                             "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
-                             "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE) per launch "
-                             "of the profiled driver command (a resident launch = every half-step "
-                             "of a 20-step region: the tables stay in the L2s, what is left is the "
-                             "chain history, the kept blobs and the write-through records)"
-                             if resident else
-                             "FP64-issue-bound path: the HBM fraction is << 1 % by "
-                             "construction (SURVEY.md 8d); fp64_valu is the bound that applies. "
-                             "traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE): every "
-                             "launch starts with cold L2s, so each of the 8 XCDs pulls its own "
-                             "copy of the emission table (Infinity-Cache hits)"},
-        "kernels_us_per_launch": {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof},
-        "kernel_launches": {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()},
-        "acceptance_fraction": acc_frac,
-        # (emcee stops at the first NaN log-probability, and so does this run unless
-        # --reject-nan: the workloads' priors -- workloads.prior_for -- keep the walkers of the
-        # 10 % ball off the zero-flux plateau where 10 ** x of a wandered coordinate overflows)
-        "nan_policy": "reject" if args.reject_nan else "raise",
-        "nan_proposals_rejected": int(sampler.nan_proposals),
-        # (a proposal the prior forbids is never accepted: the device loop evaluates none of its
-        # integrals, the reference evaluates the model and discards it, core.py:103-119 --
-        # identical results; such proposals are walker-steps of `value` like any other.  Counted
-        # by the kernels over every step the timed sampler made, warm-up included)
-        "proposals_forbidden_by_prior": int(sampler.prior_forbidden_proposals),
-        "proposals_total": int(sampler.steps_total) * int(nwalkers),
-        "loop": ("host" if not device else
-                 "device, resident workgroups: one launch of k_half_step_run per block of moves "
-                 "(<= 32 steps), walkers handed over by tagged records" if resident else
-                 ("device+hipGraph" if sampler._dev.graph is not None else "device")),
-    }
+    base_note = ("FP64-issue-bound path: the HBM fraction is << 1 % by construction (SURVEY.md 8d); "
+                 "fp64_valu / valu_utilisation are the figures that apply.")
+    if traffic is None:
+        note = base_note + " traffic: no committed TCC counter pass for this kernel."
+    elif resident:
+        note = base_note + (" traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE) per launch "
+                            "of the profiled driver command (a resident launch = every half-step "
+                            "of a 20-step region: the tables stay in the L2s, what is left is the "
+                            "chain history, the kept blobs and the write-through records)")
+    else:
+        note = base_note + (" traffic = L2 memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE): every "
+                            "launch starts with cold L2s, so each of the 8 XCDs pulls its own "
+                            "copy of the emission table (Infinity-Cache hits)")
+    out["roofline"] = {"bound": "hbm",
+                       "kernel": ("k_half_step_run (nh_half_step_run: one launch per block of moves)"
+                                  if resident and dom == "half_step"
+                                  else KERNEL_SYMBOL.get(dom, dom)), "achieved": achieved,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": traffic, "traffic_source": traffic_src,
+                       "traffic_from_committed_profile": traffic is not None,
+                       "avg_launch_us": avg_s * 1e6,
+                       "avg_launch_us_raw_events": prof[dom]["ms"] * 1e3 / prof[dom]["launches"],
+                       "event_pair_overhead_us": ev_us, "event_correction": ev_note,
+                       "algorithmic_bytes_per_launch": abytes,
+                       "walkers_per_launch": walkers_per_launch,
+                       "us_per_half_step": (avg_s * 1e6 / (walkers_per_launch / (per_gpu / 2.0))),
+                       "note": note}
+    out["kernels_us_per_launch"] = {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof}
+    out["kernel_launches"] = {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()}
+    # what a timed region spends OUTSIDE its kernels (launch latency, Python, the synchronisation
+    # behind the last launch): the median region minus the kernels' event time per K steps
+    kern_us = sum(launch_us(k) * prof[k]["launches"] for k in prof) * args.steps / float(prof_steps)
+    out["region_overhead_us"] = dt * 1e6 - kern_us
+    out["region_us"] = dt * 1e6
     fp = {}
     executed = executed_flop_eq(name, raw, final_coords)
-    if "half_step" in prof:  # one launch does the table reductions AND the synchrotron nodes
-        executed = {"half_step": sum(executed.values())}
-        KERNEL_FLOP_EQ[name]["half_step"] = sum(KERNEL_FLOP_EQ[name].values())
+    flop_all = dict(KERNEL_FLOP_EQ.get(name, {}))
+    # a category the profiler saw under its own name is credited to its own kernel (cfg4's SSC
+    # seed integral next to the staged plan's two k_half_step launches); what runs INSIDE the
+    # one-launch kernel -- table reductions, synchrotron nodes -- is credited to it, together
+    if "half_step" in prof:
+        inside = {c: v for c, v in executed.items() if c not in prof}
+        if inside:
+            executed = {c: v for c, v in executed.items() if c in prof}
+            executed["half_step"] = sum(inside.values())
+            flop_all["half_step"] = sum(flop_all[c] for c in inside)
     for cat, kflop in executed.items():
         if cat in prof:
             t = launch_us(cat) * 1e-6
@@ -577,7 +681,7 @@ def main():
             fp[KERNEL_SYMBOL[cat]] = {"achieved": tf, "frac": tf / FP64_VEC_PEAK_TF,
                                       "avg_launch_us": t * 1e6,
                                       "flop_eq_per_walker": kflop,
-                                      "flop_eq_per_walker_all_nodes": KERNEL_FLOP_EQ[name][cat]}
+                                      "flop_eq_per_walker_all_nodes": flop_all[cat]}
     if fp:
         out["fp64_valu"] = {"peak": FP64_VEC_PEAK_TF, "unit": "TFLOP-eq/s", "kernels": fp,
                             # (the vendor peak is one FP64 vector instruction per 4 cycles and SIMD at
@@ -598,12 +702,87 @@ def main():
                                           "kernel's windows, %g eq. each (the reciprocal's "
                                           "20 are five instructions on this chip: an op-count "
                                           "convention, not pipe utilisation)" % SSC_SEG_EQ}
-    util = measured_utilisation(name, resident)
-    if util:
-        out["valu_utilisation"] = util
-    if not args.no_cpu and comm.size == 1:
+    default_walkers = 256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"]
+    if per_gpu == default_walkers and comm.size == 1:  # (the configuration the profiles were taken on)
+        util = measured_utilisation(name, resident)
+        if util:
+            out["valu_utilisation"] = util
+    if full and not args.no_cpu and comm.size == 1:
         out["cpu_baseline"] = cpu_baseline(name, raw, p0, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    return out
+
+
+# BASELINE.json's multi-GPU configurations: a fixed ensemble split over the GPUs
+BASELINE_SPLIT = {4: ("cfg4", 1024), 8: ("cfg5", 2048)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --walkers per GPU (default); strong: --walkers-total split over the GPUs")
+    ap.add_argument("--walkers-total", type=int, default=None,
+                    help="strong scaling: size of the whole ensemble (default: the workload's "
+                         "BASELINE figure -- cfg5 2048, cfg4 1024, cfg3 512)")
+    ap.add_argument("--baseline-split", choices=["auto", "on", "off"], default="auto",
+                    help="after the main line, BASELINE.json's fixed-ensemble configuration for this "
+                         "number of GPUs (4: cfg4 / 1024 walkers, 8: cfg5 / 2048; strong scaling) as "
+                         "the key `baseline_split` of the same JSON line.  auto: when --gpus is 4 or 8 "
+                         "and the main line is the default weak cfg3")
+    ap.add_argument("--ball", type=float, default=0.1,
+                    help="relative spread of the initial ensemble around p0 (naima: 10 %%, core.py:477-481)")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="repeat the K-step timed region until this many seconds have been timed")
+    ap.add_argument("--no-blobs", action="store_true",
+                    help="the timed loop does not keep the blobs (emcee and the reference always do: "
+                         "(flux, We) per walker and step, core.py:450-457)")
+    ap.add_argument("--no-blobs-run", action="store_true",
+                    help="skip the extra measurement with the opposite blob setting")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--reject-nan", action="store_true",
+                    help="treat a NaN log-probability as a rejected proposal and count it; the "
+                         "default is emcee's: ValueError on the first one")
+    ap.add_argument("--no-chain", action="store_true",
+                    help="do not keep the chain (emcee's store=False); default keeps it in HBM")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="drive the step loop from the host (no device-resident ensemble)")
+    ap.add_argument("--no-graph", action="store_true", help="device loop without hipGraph replay")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        # no launcher: this process becomes one (`python bench.py --gpus N` is a complete run)
+        launch_ranks(args.gpus)
+
+    from naima_amd import _lib, dist
+
+    ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
+    comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # host: test hook / one-GPU rehearsal
+    if comm.size != args.gpus:
+        raise SystemExit("--gpus %d but the communicator has %d rank(s)" % (args.gpus, comm.size))
+    out = measure(args, ctx, comm, args.workload, args.scaling, args.walkers, args.walkers_total,
+                  full=True)
+    split = BASELINE_SPLIT.get(comm.size)
+    want_split = split is not None and (
+        args.baseline_split == "on" or
+        (args.baseline_split == "auto" and args.workload == "cfg3" and args.scaling == "weak"))
+    if want_split:
+        # BASELINE.json's configuration for this many GPUs, strong scaling, in the same processes
+        try:
+            sub = measure(args, ctx, comm, split[0], "strong", None, split[1], full=False)
+        except Exception as e:  # (the main line stands on its own)
+            sub = {"error": "%s: %s" % (type(e).__name__, e)} if comm.rank == 0 else None
+        if out is not None:
+            out["baseline_split"] = sub
+    if comm.rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

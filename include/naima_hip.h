@@ -69,6 +69,10 @@ const char* nh_last_error(void);
 int nh_version(void);
 int nh_create(int device, nh_ctx** out);
 int nh_destroy(nh_ctx* ctx);
+/* HIP devices visible to this process (no context needed).  The reference's parallel mode asks
+ * for `threads` worker processes and takes what the host gives (core.py:446-448: Pool(threads));
+ * a launcher of one rank per GPU checks this first and refuses a run the node cannot hold. */
+int nh_device_count(int* count);
 int nh_device_info(nh_ctx* ctx, char* name, int name_len, int* compute_units,
                    double* hbm_bytes, int* clock_khz);
 int nh_alloc(nh_ctx* ctx, long long bytes, void** dev_out);

@@ -30,6 +30,7 @@ _ll = C.c_longlong
 _SIGS = {
     "nh_create": [_i, C.POINTER(_dp)],
     "nh_destroy": [_dp],
+    "nh_device_count": [C.POINTER(_i)],
     "nh_device_info": [_dp, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_i)],
     "nh_alloc": [_dp, _ll, C.POINTER(_dp)],
     "nh_free": [_dp, _dp],
@@ -1134,10 +1135,18 @@ class _Branch:
 _default = {}
 
 
+def device_count():
+    """HIP devices this process sees (raises when the library or the HIP runtime is missing)"""
+    load()
+    n = _i(0)
+    _chk(_lib.nh_device_count(C.byref(n)))
+    return n.value
+
+
 def get_context(device=None):
     """process-wide default context (device from NAIMA_AMD_DEVICE / LOCAL_RANK, else 0)"""
     if device is None:
-        device = int(os.environ.get("NAIMA_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        device = int(os.environ.get("NAIMA_AMD_DEVICE") or os.environ.get("LOCAL_RANK") or "0")
     ctx = _default.get(device)
     if ctx is None:
         ctx = Context(device)

@@ -125,6 +125,16 @@ int nh_scratch(nh_ctx* c, size_t bytes, void** out) {
   return NH_OK;
 }
 
+// HIP devices this process sees (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES applied): what a
+// launcher checks before it starts one rank per GPU.  No context needed.
+extern "C" int nh_device_count(int* count) {
+  NH_REQUIRE(count != nullptr, "count is NULL");
+  int ndev = 0;
+  NH_CHECK_HIP(hipGetDeviceCount(&ndev));
+  *count = ndev;
+  return NH_OK;
+}
+
 extern "C" int nh_device_info(nh_ctx* c, char* name, int name_len, int* cus, double* hbm,
                               int* clock_khz) {
   NH_REQUIRE(c, "ctx is NULL");

@@ -98,6 +98,11 @@ struct hs_run {
   // two slots of page-locked host memory (nh_half_step_run_report)
   int* report;
   int report_launch;
+  // NaN / forbidden proposals THIS launch has met (two device ints, a pair per launch parity):
+  // k_run_epilogue adds them to the plan's counters only when the launch ended well, so that a
+  // launch that gave up part of the way leaves the counters as it found them whoever of its
+  // workgroups had already counted (what a replay of its block of moves starts from)
+  int* lcnt;
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
@@ -310,13 +315,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       reinterpret_cast<long long*>(o + 4)[0] = (long long)P.ld;
       reinterpret_cast<double**>(o + 5)[0] = P.out;
     }
-  }
-  // (the plan's NaN / forbidden-proposal counters as this launch found them: what a replay of
-  // its block of moves starts from again -- nh_half_step_run_report)
-  if (R.report && blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0) {
-    volatile int* rp = R.report + 8 * (R.report_launch & 1);
-    rp[4] = H.done[2];
-    rp[5] = H.done[3];
   }
   // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or
   // by the host: the kernel boundary has made it visible).  Walker w by workgroup w mod grid.
@@ -1066,8 +1064,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           // (a shared ensemble: the flag says which launch it belongs to -- entries of walkers
           // other ranks move keep an older launch's number and are recognised by it, no memset)
           R.accw[(long long)tl * N + me2] = multi ? (int)((R.seq << 2) | (ok ? 2u : 1u)) : (ok ? 1 : 0);
-          if (acc != acc) atomicAdd(H.done + 2, 1);  // (see nh_half_step_nan_count)
-          if (hi[HI_DEAD]) atomicAdd(H.done + 3, 1);  // (forbidden by the prior: nothing was integrated)
+          if (acc != acc) atomicAdd(R.lcnt, 1);  // (see nh_half_step_nan_count; committed by the epilogue)
+          if (hi[HI_DEAD]) atomicAdd(R.lcnt + 1, 1);  // (forbidden by the prior: nothing was integrated)
         }
         if (ok) {  // the accepted position's blobs
           for (int b = 0; b < D.nblob; ++b) {
@@ -1124,13 +1122,27 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   // chain of dependent round trips, one after the other they added up to 15 us of a 20-step
   // region
   const int job = blockIdx.y;
-  if (R.report && blockIdx.x == 0 && job == 0 && threadIdx.x == 0) {
-    volatile int* rp = R.report + 8 * (R.report_launch & 1);
-    rp[0] = *R.status;
-    rp[1] = H.done[2];
-    rp[2] = H.done[3];
-    __threadfence_system();
-    rp[3] = R.report_launch;  // (last: whoever sees the number sees the rest)
+  if (blockIdx.x == 0 && job == 0 && threadIdx.x == 0) {
+    // this launch's NaN / forbidden-proposal counts join the plan's counters if -- and only if --
+    // it ended well; the report says how the counters stood before (a replay starts from there)
+    const int st = *R.status;
+    const int n0 = H.done[2], f0 = H.done[3];
+    if (st == 0) {
+      H.done[2] = n0 + R.lcnt[0];
+      H.done[3] = f0 + R.lcnt[1];
+    }
+    R.lcnt[0] = 0;  // (the pair's next user is the launch after next: behind this kernel in the stream)
+    R.lcnt[1] = 0;
+    if (R.report) {
+      volatile int* rp = R.report + 8 * (R.report_launch & 1);
+      rp[0] = st;
+      rp[1] = H.done[2];
+      rp[2] = H.done[3];
+      rp[4] = n0;
+      rp[5] = f0;
+      __threadfence_system();
+      rp[3] = R.report_launch;  // (last: whoever sees the number sees the rest)
+    }
   }
   // a launch that gave up (a record never came: nh_half_step_run_status) leaves the flat arrays,
   // the counters and the blob rows as they were before it -- whoever finds the status can replay
@@ -1232,7 +1244,8 @@ struct nh_halfstep_run {
   size_t lds_bytes;
   int grid, threads;
   int rt;  // the instance whose table items stay in registers (hs_rt_item)
-  int* report;        // page-locked host memory, two slots of four ints (hs_run.report)
+  int* report;        // page-locked host memory, two slots of eight ints (hs_run.report)
+  int* lcnt;          // device: two pairs of launch-local counters (hs_run.lcnt)
   int nlaunch, fail_at;  // launches so far; NH_RUN_FAIL_AT = the launch whose first wait times out (tests)
   unsigned seq;
   // a shared ensemble (nh_half_step_run_create_shared): `base` is ONE fine-grained allocation
@@ -1396,6 +1409,12 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (R.syn2 && P->split >= 2 && R.syn_nodes < 16) R.syn_nodes = 16;
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
   R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
+  if (R.dbg_skip != 0)
+    fprintf(stderr, "libnaima_hip: NH_RUN_DEBUG_SKIP=%d -- work items are DROPPED from the likelihood "
+                    "(instruction-count experiments): every result of this loop is wrong\n", R.dbg_skip);
+  if (nh_env_int("NH_RUN_FAIL_AT", 0) > 0)
+    fprintf(stderr, "libnaima_hip: NH_RUN_FAIL_AT=%d -- that launch of the resident loop is made to time "
+                    "out (fault injection of the tests)\n", nh_env_int("NH_RUN_FAIL_AT", 0));
   R.rebalance = nh_env_int("NH_RUN_REBALANCE", H.syn_grid < 0 ? 1 : 0);
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
@@ -1436,7 +1455,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->nrank = shared ? nrank : 1; Q->rank = shared ? rank : 0;
   Q->base = nullptr; Q->nacc_own = nullptr; Q->curstamp = nullptr; Q->hacc = nullptr;
   Q->probe_out = nullptr; Q->steps_total = 0; Q->probe_seq = 1; Q->s2_dev = nullptr;
-  Q->report = nullptr; Q->nlaunch = 0; Q->fail_at = nh_env_int("NH_RUN_FAIL_AT", 0);
+  Q->report = nullptr; Q->lcnt = nullptr; Q->nlaunch = 0; Q->fail_at = nh_env_int("NH_RUN_FAIL_AT", 0);
   Q->R.report = nullptr;
   for (int p = 0; p < HS_RUN_MAX_RANKS; ++p) Q->peer_base[p] = nullptr;
   Q->ring_elems = (size_t)(HS_RUN_MAX_STEPS + 1) * R.N * R.gr;
@@ -1479,6 +1498,8 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (e == hipSuccess)
       e = nh_put_now(c, Q->s2_dev, s2_host.data(), s2_host.size() * sizeof(double));
   }
+  if (e == hipSuccess) e = hipMalloc(&Q->lcnt, 4 * sizeof(int));
+  if (e == hipSuccess) e = nh_fill_now(c, Q->lcnt, 0, 4 * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->status, sizeof(int));
   if (e == hipSuccess) e = nh_fill_now(c, Q->status, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
@@ -1500,6 +1521,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     if (Q->curstamp) (void)hipFree(Q->curstamp);
     if (Q->probe_out) (void)hipFree(Q->probe_out);
     if (Q->status) (void)hipFree(Q->status);
+    if (Q->lcnt) (void)hipFree(Q->lcnt);
     if (Q->accw) (void)hipFree(Q->accw);
     if (Q->dbg) (void)hipFree(Q->dbg);
     if (Q->xspec) (void)hipFree(Q->xspec);
@@ -1724,6 +1746,7 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.seq = Q->seq++ & 0xFFFFFFu;
   if (R.seq == 0) R.seq = Q->seq++ & 0xFFFFFFu;
   R.report_launch = ++Q->nlaunch;
+  R.lcnt = Q->lcnt + 2 * (Q->nlaunch & 1);
   if (Q->fail_at > 0 && Q->nlaunch == Q->fail_at) R.spin_limit = 0;  // (tests: this launch's first wait gives up)
   if (Q->base) {  // a shared ensemble: this launch's ring, here and on every other rank
     const size_t off = HS_RUN_HEAD + (size_t)(R.seq & 1u) * Q->ring_elems;
@@ -1860,6 +1883,7 @@ extern "C" int nh_half_step_run_destroy(nh_ctx* c, nh_halfstep_run* Q) {
   if (Q->curstamp) (void)hipFree(Q->curstamp);
   if (Q->probe_out) (void)hipFree(Q->probe_out);
   if (Q->status) (void)hipFree(Q->status);
+  if (Q->lcnt) (void)hipFree(Q->lcnt);
   if (Q->accw) (void)hipFree(Q->accw);
   if (Q->dbg) (void)hipFree(Q->dbg);
   if (Q->xspec) (void)hipFree(Q->xspec);

@@ -217,6 +217,11 @@ class DeviceLoop:
         self._rl_count = 0     # launches queued so far (the library counts them the same way)
         self._rl_pending = []
         self._verify = os.environ.get("NAIMA_AMD_VERIFY_LAUNCHES", "1") != "0"
+        # copies of the current blobs as a launch WITHOUT a history found them (such a launch
+        # writes the blobs of accepted moves straight into the current-blob arrays): what a
+        # launch that gave up -- or ran void behind one that did -- is rolled back to
+        self._cur_snaps = [None] * 4
+        self._last_snap = None
         self._nan_pending = self._forbidden_pending = 0
         _n = _lib._i(0)  # (the context's word may hold what an earlier sampler left uncounted)
         _lib._chk(_lib._lib.nh_nan_count(self.ctx.h, 1, C.byref(_n)))
@@ -681,6 +686,7 @@ class DeviceLoop:
             self._run = False
             self.resident_failed_launches += len(void)
             self._read_counts(reset=False, set_to=rec["counts"])  # (the replay counts them again)
+            self._restore_cur_blobs(rec.get("snap"))  # (a void launch behind it may have written some)
             s.iteration, s.steps_total = rec["iteration"], rec["steps_total"]
             s.n_lnprob_calls, s.n_walker_evals = rec["nlc"], rec["nwe"]
             self.resident_launches = rec["rl"]
@@ -733,6 +739,7 @@ class DeviceLoop:
                     per_launch_history()
                 break
             if verify:
+                rec["snap"] = self._last_snap
                 self._rl_pending.append(rec)
             mv["used"] += want
             # a marker behind this launch: `blk` is a ring, and the host runs launches ahead of
@@ -1152,6 +1159,9 @@ class DeviceLoop:
             # _create_shared_run / bench.py's rehearsal and raise together on a later time-out; a
             # one-GPU loop's later launches are checked a launch behind: sample, _rl_settle.)
             n0, f0 = self._read_counts(reset=False)
+        self._last_snap = None
+        if block is None and not self.shared and self.s.store_blobs and self.cur_blobs:
+            self._last_snap = self._snapshot_cur_blobs()
         ctx.call("nh_half_step_run", hs["plan"], self._run, slice0, nslices, hc, hl, hb, row0, cap)
         self._rl_count += 1
         if probation:
@@ -1167,12 +1177,43 @@ class DeviceLoop:
                 self._run = False
                 self.resident_failed_launches += 1
                 self._read_counts(reset=False, set_to=(n0, f0))  # (the replay counts them again)
+                self._restore_cur_blobs(self._last_snap)  # (slices that finished before it gave up)
                 return False
             self._resident_trust += 1
         self.resident_launches += 1
         self.s.n_lnprob_calls += nslices
         self.s.n_walker_evals += nslices * self.nloc
         return True
+
+    def _snapshot_cur_blobs(self):
+        """device copies of the current blobs, in stream order ahead of the launch about to be
+        queued (one of four sets: at most three launches are ever unsettled) -> the set's index"""
+        k = self._rl_count % len(self._cur_snaps)
+        if self._cur_snaps[k] is None:
+            self._cur_snaps[k] = [self.ctx.empty((self.N, m)) for _, m, _, _ in self.cur_blobs]
+        for dst, (cur, m, _, _) in zip(self._cur_snaps[k], self.cur_blobs):
+            self.ctx.call("nh_copy", dst, cur, 8 * self.N * m)
+        return k
+
+    def _restore_cur_blobs(self, k):
+        if k is None or self._cur_snaps[k] is None:
+            return
+        for src, (cur, m, _, _) in zip(self._cur_snaps[k], self.cur_blobs):
+            self.ctx.call("nh_copy", cur, src, 8 * self.N * m)
+        self._cur_host = None
+
+    def _settle_before_read(self):
+        """somebody reads the state (or drains the counters) while launches of the resident loop
+        are still unsettled -- a caller iterating sample() launch by launch: wait for them; one that
+        gave up is replayed when the iteration goes on, and until then the state on the device is
+        the one BEFORE it"""
+        if self._rl_pending and self._run:
+            rec = self._rl_settle(keep=0)
+            if rec is not None:
+                raise _lib.NaimaHipError(
+                    "a launch of the resident loop gave up waiting for a walker's record (status %d); "
+                    "its block of moves is replayed when the iteration continues -- read the state "
+                    "after that" % rec["status"])
 
     def _rl_settle(self, keep):
         """wait until all but the last `keep` queued launches are known to have ended; None, or
@@ -1216,6 +1257,7 @@ class DeviceLoop:
         of the current blobs) they are summed over the ranks first, so that every rank counts --
         and raises -- the same; elsewhere a rank only accumulates what it has seen, because a
         ValueError on one rank would leave the others waiting in their next collective."""
+        self._settle_before_read()  # (the counters are not drained under an unsettled launch)
         n, f = self._read_counts(reset=True)
         self._nan_pending += n
         self._forbidden_pending += f

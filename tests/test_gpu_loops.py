@@ -176,6 +176,10 @@ def test_device_loop_equals_oracle_driven_sampler(na, cfg):
     _, name, mkw, _ = cfg
     model, p0, raw, data, prior = _problem(na, name, mkw)
     nd = p0.size
+    # (2 ndim + 2 walkers: cfg4 runs at 14 -- the NumPy oracle materialises the (100 x 261 x 869)
+    # seed tensor of radiative.py:609-655 and costs ~1 s per evaluation, 4 steps of 14 walkers are
+    # 70 of them; cfg4 at its BASELINE size, 1024 walkers, is held to the host-driven loop instead:
+    # test_cfg4_at_its_baseline_ensemble_size)
     nw, nsteps = 2 * nd + 2, 4
     s = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=17,
                         naima_style=True, store_blobs=False, device=True)
@@ -558,6 +562,28 @@ def test_device_loop_equals_oracle_driven_sampler_at_the_benchmarks_size(na, nam
     fin = np.isfinite(l)
     assert_allclose(got[fin], l[fin], rtol=1e-6)
     assert_allclose(st.coords, c, rtol=1e-8)
+    # ... and what a user READS of the run -- the blobs the resident kernel kept: every walker's
+    # model spectrum (and We / Wp) at the position it holds after the last step -- directly against
+    # the oracle's spectra there, not through the log-probability
+    blobs, units = s.get_blobs(), s.blob_units
+    assert blobs is not None and np.shape(blobs[0])[:2] == (2 * nsteps, nw)
+    flux_dev = np.asarray(blobs[0][-1], dtype=float)
+    if units and units[0] is not None:
+        flux_dev = na.u.Quantity(flux_dev, units[0]).to("1/(s cm2 eV)").value
+    checked = 0
+    for i in np.flatnonzero(fin)[::max(1, int(fin.sum()) // 64)]:
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            _, f_or, b_or = WN.lnprob(name, c[i], raw, prior=oprior, **mkw)
+        assert_allclose(flux_dev[i], f_or, rtol=1e-9 if name != "cfg5" else 1e-7, atol=1e-300,
+                        err_msg="model spectrum of walker %d" % i)
+        if len(blobs) > 1 and np.isfinite(np.asarray(b_or, dtype=float)).all():
+            b_dev = np.asarray(blobs[1][-1], dtype=float)[i]
+            if units[1] is not None:
+                b_dev = na.u.Quantity(b_dev, units[1]).to("erg").value
+            assert_allclose(b_dev, b_or, rtol=1e-9 if name != "cfg5" else 1e-7)
+        checked += 1
+    assert checked >= min(32, int(fin.sum()))
 
 
 def test_rejected_one_launch_plan_falls_back_to_the_three_launch_loop(na, monkeypatch):
@@ -811,8 +837,9 @@ def test_resident_loop_gives_up_instead_of_hanging(na, monkeypatch):
     assert np.array_equal(d2.get_chain(), ref.get_chain())
 
 
-@pytest.mark.parametrize("fail_at,blobs", [(4, True), (7, False), (11, True)],
-                         ids=["fourth-launch", "seventh-no-blobs", "a-call's-last-launch"])
+@pytest.mark.parametrize("fail_at,blobs", [(4, True), (7, False), (9, True), (10, True), (11, True)],
+                         ids=["fourth-launch", "seventh-no-blobs", "ninth-in-a-call-without-history",
+                              "tenth-the-last-of-a-call-without-history", "a-call's-last-launch"])
 def test_a_later_launch_that_gives_up_is_replayed(na, monkeypatch, fail_at, blobs):
     """a launch of the resident loop that gives up LATER in a run (NH_RUN_FAIL_AT: that launch's
     first wait times out; what another process taking the GPU's CUs would do): the sampler learns
@@ -820,7 +847,11 @@ def test_a_later_launch_that_gives_up_is_replayed(na, monkeypatch, fail_at, blob
     per launch), the launch queued behind it found the same status and changed nothing, the books
     go back two blocks of moves, the move stream is made again up to that step and the per-launch
     kernel carries the run on -- chain, log-probabilities, blobs, acceptance and counters are the
-    per-launch loop's, bit for bit."""
+    per-launch loop's, bit for bit.  Launches 8-10 are the call WITHOUT a history, whose launches
+    write accepted blobs straight into the current-blob arrays: the launch queued behind one that
+    gave up runs to its end as a void launch and writes blobs of proposals that are then
+    discarded -- the current blobs go back to the copy taken ahead of the first void launch, or
+    the blob rows of the next call's rejected steps would belong to positions never held."""
     from naima_amd.sampler import EnsembleSampler
     model, p0, raw, data, prior = _problem(na, "cfg3", {})
     nw, nd = 512, p0.size
@@ -851,6 +882,8 @@ def test_a_later_launch_that_gives_up_is_replayed(na, monkeypatch, fail_at, blob
     assert_allclose(d.get_log_prob(), ref.get_log_prob(), rtol=1e-11)
     assert np.array_equal(np.asarray(sd.coords), np.asarray(sr.coords))
     if blobs:
+        for x, y in zip(sd.blobs, sr.blobs):  # (the current blobs: where every walker IS)
+            assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10, atol=1e-300)
         for x, y in zip(d.get_blobs(), ref.get_blobs()):
             assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10, atol=1e-300,
                             equal_nan=True)

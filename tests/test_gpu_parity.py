@@ -37,6 +37,30 @@ def _pds(na):
     }
 
 
+def test_integration_md_stub_is_executable(na, golden):
+    """INTEGRATION.md section 1 -- the ctypes stub a naima maintainer would add as
+    src/naima/_hip.py to put Synchrotron._spectrum (radiative.py:282-342) behind the C ABI -- is
+    extracted from the document and EXECUTED as it stands (only the library's path is made
+    absolute), and its synchrotron_batch gives the reference's own numbers: units.npz
+    `syn_ecpl`, made by naima's Synchrotron(ECPL, B = 1 mG, 100 GeV .. 1 PeV).flux(E, 0)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(.*?)```", txt, re.S).group(1)
+    assert "def synchrotron_batch" in block and '"libnaima_hip.so"' in block
+    block = block.replace('"libnaima_hip.so"', repr(os.path.join(root, "naima_amd", "libnaima_hip.so")))
+    ns = {}
+    exec(compile(block, "INTEGRATION.md#1", "exec"), ns)
+    U = golden("units")
+    rows = np.array([[3e30, 2e12, 2.3, 30e12, 1.7, 0.0, 0.0, 0.0],
+                     [3e30, 2e12, 2.3, 30e12, 1.7, 0.0, 0.0, 0.0]])
+    spec = ns["synchrotron_batch"](rows, np.array([1e-3, 1e-3]), np.asarray(U["grid_2"]),
+                                   np.asarray(U["E"]))
+    assert spec.shape == (2, len(U["E"]))
+    for r in spec:
+        assert_allclose(r, U["syn_ecpl"], rtol=RT, atol=1e-300)
+
+
 def test_abi_trapz_loglog(na, golden):
     """row 1 straight through the C ABI, incl. zero nodes / sign changes / b=-1"""
     from naima_amd._lib import get_context
