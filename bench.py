@@ -315,6 +315,7 @@ def launch_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if pinned is not None:
             env.setdefault("NAIMA_AMD_COMM", "host")
+            env.setdefault("NAIMA_AMD_CU_SHARE", str(n))  # (every rank plans for its share of the CUs)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, cwd=ROOT, start_new_session=True,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -561,6 +562,7 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
                                  if os.environ.get("NAIMA_AMD_SELF_SPAWNED") == "1" else
                                  "the launcher (WORLD_SIZE)" if comm.size > 1 else "one process"),
             "devices_pinned_to": os.environ.get("NAIMA_AMD_DEVICE"),
+            "cu_share": int(os.environ.get("NAIMA_AMD_CU_SHARE", "1")),
             "exchange": xinfo,
             "collective": ("none (one rank)" if not getattr(sampler._dev, "sharded", False) else
                            "none: a mover stores its walker's record into every rank's ring "

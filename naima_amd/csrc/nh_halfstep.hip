@@ -1364,6 +1364,13 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
         prop.multiProcessorCount > 0)
       ncu = prop.multiProcessorCount;
   }
+  // (several ranks rehearsing a multi-GPU run on ONE device -- bench.py --gpus N under
+  // NAIMA_AMD_DEVICE -- each plan for their share of its CUs: resident workgroups of all ranks
+  // have to fit the chip together)
+  {
+    const int share = nh_env_int("NAIMA_AMD_CU_SHARE", 1);
+    if (share > 1) ncu = ncu / share > 1 ? ncu / share : 1;
+  }
   // A table-only model's launch is half prologue and tail (dependent round trips, single-wave
   // phases: 9 of cfg5's 16 us) with the CU's other waves idle.  When a launch holds more
   // walkers than the chip has CUs, smaller workgroups put several walkers on a CU at once and

@@ -56,6 +56,7 @@
 #define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
 #define HS_O_LNA 48          // in the small per-walker block (proposal coordinates: <= 15 of its first 64 doubles)
 #define HS_RUN_TRAIL 16        // ints of first-row entries per table in LDS (>= tiles of any table)
+#define HS_RUN_PKW 8           // doubles per parameter-pack column in LDS
 #ifndef HS_RUN_PK
 #define HS_RUN_PK 5      // nodes per trip of a narrow table's items in the table-only instances (nh_hs.h): 6 spilled 8 VGPRs (cfg5 9.12 M walker-steps/s, 9.77 M at 5; cfg1 1.49 -> 1.46 M)
 #endif
@@ -275,8 +276,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     for (int k = tid; k < H.nE; k += T) {
       lik[k] = H.conv[k];
       lik[H.nE + k] = H.flux[k];
-      lik[2 * H.nE + k] = H.elo[k];
-      lik[3 * H.nE + k] = H.ehi[k];
+      // (-1 / (2 sigma^2), core.py:79-87: the division once per launch, not on the tail of every
+      // slice -- the likelihood wave works alone there, and a double division is a chain of
+      // thirty dependent instructions)
+      lik[2 * H.nE + k] = -0.5 / (H.elo[k] * H.elo[k]);
+      lik[3 * H.nE + k] = -0.5 / (H.ehi[k] * H.ehi[k]);
       lik[4 * H.nE + k] = (double)H.ul[k];
     }
     int ko = H.o_mkt;
@@ -302,11 +306,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           tr[HS_RUN_TRAIL * HS_MAX_TAB + tb.spec_off + k] = has ? src[HS_TRAIL_TILES + k] : k;
       }
     }
-    // the parameter packs' columns, one per thread of wave 0: a | b | c | tf, ncols | ld | out
+    // the parameter packs' columns, one per thread of wave 0: a | b | c | tf, ncols | ld | out | ln|a|
     if (tid < npk8) {
       const nh_pack& P = D.pk[tid / NH_MAX_LAZY];
       const nh_lazy& z = P.cols[tid % NH_MAX_LAZY];
-      double* o = sm + R.o_pk + tid * 6;
+      double* o = sm + R.o_pk + tid * HS_RUN_PKW;
+      o[6] = log(fabs(z.a));
       o[0] = z.a;
       o[1] = z.b;
       o[2] = z.c;
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         }
         const double qv = __shfl(q, pkd < 0 ? 0 : pkd, 64);
         if (lane < npk8) {
-          const double* o = sm + R.o_pk + lane * 6;
+          const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
           const double za = o[0], zb = o[1], zc = o[2];
           const int ztf = reinterpret_cast<const int*>(o + 3)[0];
           const int nc = reinterpret_cast<const int*>(o + 3)[1];
@@ -515,9 +520,28 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
               // (ln of e_0, e_cutoff, e_break for the weights; ln |amplitude| and its sign for the
-              // log-domain synchrotron items: one call, the lanes side by side)
+              // log-domain synchrotron items.  A constant's logarithm was taken when the launch
+              // began; a power of ten -- naima's fits walk in log10 of the amplitude and of the
+              // energies -- has ln|a 10^y| = ln|a| + y ln 10 in two FMAs, as good as the logarithm of
+              // the rounded power (both are right to the last place of a number around 70); only
+              // another transform calls the library's log behind its own result -- the chain
+              // exp10 -> log on one lane was 0.4 us of every slice with every other wave waiting)
               if (col == 0 || col == 1 || col == 3 || col == 5) {
-                const double lv = hsr_log(fabs(val));
+                double lv;
+                const bool easy = pkd < 0 || ztf == NH_TF_POW10;
+                if (pkd < 0) {
+                  lv = o[6];
+                } else if (ztf == NH_TF_POW10) {
+                  const double y = fma(zb, qv, zc);
+                  lv = o[6] + fma(y, 2.302585092994046, y * -2.1707562233822494e-16);
+                } else {
+                  lv = 0.0;
+                }
+                if (__builtin_amdgcn_ballot_w64(!easy) != 0ull) {
+                  asm volatile("" ::: "memory");  // (keep the call behind the branch)
+                  const double lv2 = hsr_log(fabs(val));
+                  lv = easy ? lv : lv2;
+                }
                 if (col == 0) {
                   qs[HS_O_LNA] = lv;
                   qs[HS_O_LNA + 1] = val < 0.0 ? -1.0 : 1.0;
@@ -583,17 +607,17 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
       double* spec = sm + H.o_spec;
       double Bw = 0.0, qfac = 0.0;
-      if (has_syn) {
-        Bw = D.syn_bcol >= 0 ? row[D.syn_bcol] : D.synB[(long long)j * D.syn_ldB];
-        // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
-        qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
-      }
+      if (has_syn) Bw = D.syn_bcol >= 0 ? row[D.syn_bcol] : D.synB[(long long)j * D.syn_ldB];
       int lv_i0 = 0, lv_k = -1;
       double lv_q = 0.0, lv_E = 0.0;
       bool lv_live = false;
       int* tcnt = hi + 8;  // [<= 8] live energies per tile
       const int syn_tiles = tiles_;
       if (has_syn && nwv - 1 - wv < syn_tiles) {
+        // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
+        // (the division: on the tile waves only -- thirty dependent instructions at the head of
+        // every other wave's weights otherwise)
+        qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
         const int nG = H.nG[H.syn_grid];
         const double* ig2 = sm + H.o_ig2;
         const int t = nwv - 1 - wv;
@@ -617,6 +641,53 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         if (lane == 0) {
           tcnt[t] = __popcll(m);
           if (ln > 0) atomicAdd(&hi[HI_LIVE], ln);
+        }
+        // The live energies compacted in order, and what the items need per live energy -- here,
+        // ahead of the second barrier (the tile waves have no weights to form and used to reach it
+        // early, then did this BEHIND it while the waves that had pulled the first synchrotron
+        // items spun on HI_READY: the items phase began 1 us late for them, and this wave pulled
+        // its own first item last of all).  Where this tile's energies start in the compacted
+        // order needs the earlier tiles' live counts: an energy is live iff x <= 746 at the
+        // grid's LAST node (1/gamma^2 decreases along it) -- one comparison per lane and tile.
+        {
+          const int nEs = H.syn_nE;
+          int base = 0;
+          for (int q = 0; q < t; ++q) {
+            const int kq = q * 64 + lane;
+            const bool lq = kq < nEs && (sm[H.o_synE + min(kq, nEs - 1)] * qfac) * ig2[nG - 1] <= 746.0;
+            base += __popcll(__builtin_amdgcn_ballot_w64(lq));
+          }
+          int* amap = reinterpret_cast<int*>(sm + H.o_amap);
+          int* ai0 = amap + nEs;
+          double* sq = sm + H.o_sq;  // q | cbrt(q) | CS1 per live energy
+          if (lv_live) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            amap[pos] = lv_k;
+            ai0[pos] = lv_i0;
+            const double cbq = hsr_cbrt(lv_q);
+            // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
+            const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
+                               (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
+                                (lv_E * NH_ERG_PER_EV));
+            sq[pos] = lv_q;
+            sq[nEs + pos] = cbq;
+            sq[2 * nEs + pos] = cs1;
+            if (S2) {
+              // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
+              // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy
+              const double lnq = hsr_log(lv_q);
+              const double z = fma(-lnq, R.s2_invd, R.s2_z0);
+              const double Zf = floor(z);
+              double* s2q = sm + R.o_s2q;
+              s2q[pos] = cbq;
+              s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
+              s2q[2 * nEs + pos] = (z - Zf) * R.s2.im;
+              s2q[3 * nEs + pos] = cs1 * qs[HS_O_LNA + 1];
+              reinterpret_cast<int*>(sm + R.o_s2z)[pos] = (int)Zf;
+            }
+          } else if (lv_k < nEs) {
+            spec[H.syn_spec_off + lv_k] = 0.0;
+          }
         }
       }
       int nzmask = 0;
@@ -740,45 +811,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           for (int k = tid; k < nEs; k += T) spec[H.syn_spec_off + k] = syn_nan ? NAN : 0.0;
           nA = 0;
         }
-        if (lv_k >= 0 && !syn_zero) {
-          int* amap = reinterpret_cast<int*>(sm + H.o_amap);
-          int* ai0 = amap + nEs;
-          double* sq = sm + H.o_sq;  // q | cbrt(q) | CS1 per live energy
-          const int t = nwv - 1 - wv;
-          int base = 0;
-          for (int q = 0; q < t; ++q) base += tcnt[q];
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
-          if (lv_live) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            amap[pos] = lv_k;
-            ai0[pos] = lv_i0;
-            const double cbq = hsr_cbrt(lv_q);
-            // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
-            const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                               (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
-                                (lv_E * NH_ERG_PER_EV));
-            sq[pos] = lv_q;
-            sq[nEs + pos] = cbq;
-            sq[2 * nEs + pos] = cs1;
-            if (S2) {
-              // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
-              // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy
-              const double lnq = hsr_log(lv_q);
-              const double z = fma(-lnq, R.s2_invd, R.s2_z0);
-              const double Zf = floor(z);
-              double* s2q = sm + R.o_s2q;
-              s2q[pos] = cbq;
-              s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
-              s2q[2 * nEs + pos] = (z - Zf) * R.s2.im;
-              s2q[3 * nEs + pos] = cs1 * qs[HS_O_LNA + 1];
-              reinterpret_cast<int*>(sm + R.o_s2z)[pos] = (int)Zf;
-            }
-          } else if (lv_k < nEs) {
-            spec[H.syn_spec_off + lv_k] = 0.0;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) atomicAdd(&hi[HI_READY], 1);
-        }
       }
       // ---- single-row reductions (We, Wp), one wave each (from the back) ----------------------
       if (nwv - 1 - wv < H.nmom) {
@@ -804,7 +836,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const int nT = D.nT;
         const int F0 = min(nT, nwv);
         const int both = 2 * min(nT - F0, nS), total = nT + nS;
-        bool syn_ready = !has_syn;
         double* part_t = sm + H.o_part_t;
         double* part_s = sm + H.o_part_s;
         bool rt_first = true;
@@ -890,12 +921,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                         : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds);
             part_t[ix * 64 + lane] = acc;
           } else if (SYN) {
-            if (!syn_ready) {  // (wave-uniform) the tile waves' constants must have landed
-              while (__atomic_load_n(&hi[HI_READY], __ATOMIC_RELAXED) < syn_tiles)
-                __builtin_amdgcn_s_sleep(1);
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              syn_ready = true;
-            }
+            // (the tile waves' constants were written ahead of barrier 2)
             const int g = H.syn_grid, nEs = H.syn_nE;
             if (S2) {
               hs_syn2_item(ix, lane, nA, Cd, nEs, R.s2, reinterpret_cast<const int*>(sm + H.o_amap) + nEs,
@@ -1005,8 +1031,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             nviol += (mc > f) ? 1 : 0;
           } else {
             const double d = mc - f;
-            const double sg = (d > 0.0) ? lik[3 * nE + k] : lik[2 * nE + k];
-            acc += -(d * d) / (2.0 * (sg * sg));
+            const double sgw = (d > 0.0) ? lik[3 * nE + k] : lik[2 * nE + k];
+            acc = fma(d * d, sgw, acc);
           }
         }
         int cnt = nviol | (nul << 16);
@@ -1309,7 +1335,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     R.o_ge[g] = off;
     if (H.F.broken) off += H.nG[g];
   }
-  R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * 6;
+  R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * HS_RUN_PKW;
   R.o_small1 = off; off += HS_O_T64;
   R.o_olds = off; off += 128;
   R.o_lcl = off; off += H.nE + 1;
@@ -1431,6 +1457,10 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   // (MI355X_MICROARCH.md: the query can be one block per CU high where the SGPR file is what
   // limits residency -- 6 waves per SIMD at this kernel's ~110 SGPRs; its 128 VGPRs allow 4,
   // so registers or LDS bind first and the query is exact.  The bounded waits are the net.)
+  {  // (ranks that rehearse a multi-GPU run on one device: a share of its CUs each, nh_halfstep.hip)
+    const int share = nh_env_int("NAIMA_AMD_CU_SHARE", 1);
+    if (share > 1) ncu = ncu / share > 1 ? ncu / share : 1;
+  }
   long long cap = (long long)per_cu * ncu;
   if (const char* e = getenv("NH_RUN_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
   // More walkers per half-step than resident workgroups: a workgroup takes several of a slice,
