@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaima_hip.so")
+if os.environ.get("NAIMA_AMD_LIB"):  # (experiments: a variant of the library built with other flags)
+    LIB_PATH = os.path.abspath(os.environ["NAIMA_AMD_LIB"])
 
 NH_PD_NPAR = 8
 NH_K_NAMES = ("particle_weights", "integrate_tables", "synchrotron", "tables", "lnprob",

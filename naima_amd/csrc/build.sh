@@ -3,7 +3,7 @@
 # without a GPU.  Usage: naima_amd/csrc/build.sh [extra hipcc flags]
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/../libnaima_hip.so"
+out="${NH_OUT:-$here/../libnaima_hip.so}"
 tmp="$out.tmp.$$"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \

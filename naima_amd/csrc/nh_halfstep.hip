@@ -410,13 +410,19 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     const int col = tid % NH_MAX_LAZY;
     if (col < pk_nc) {
       double v = pkz.a;
-      if (pkd >= 0) v = nh_lazy_apply(pkz, kcj - (kcj - ksj) * mz);  // (the same q as qs[pkd])
+      const double qk = kcj - (kcj - ksj) * mz;  // (the same q as qs[pkd])
+      if (pkd >= 0) v = nh_lazy_apply(pkz, qk);
       int ld = pk_ld;
       asm volatile("" : "+v"(ld));  // (its sign extension would be hoisted to the load: a wait)
       pk_out[(long long)j * ld + col] = v;
       if (tid / NH_MAX_LAZY == F.ppk) {  // the particle rows: also into LDS
         row[col] = v;
-        if (col == 1 || col == 3 || col == 5) lg[col >> 1] = v > 0.0 ? log(v) : 0.0;
+        if (col == 1 || col == 3 || col == 5) {
+          // (a power of ten of a proposed coordinate: hs_ln_pow10, as the resident loop has it)
+          const bool p10 = pkd >= 0 && pkz.tf == NH_TF_POW10;
+          const double lv = log(fabs(p10 ? pkz.a : v));
+          lg[col >> 1] = v > 0.0 ? (p10 ? hs_ln_pow10(lv, pkz.b, pkz.c, qk) : lv) : 0.0;
+        }
       }
     }
   }

@@ -163,6 +163,40 @@ enum { HI_ME = 0, HI_PA, HI_READY, HI_TICK, HI_DEAD, HI_CNT, HI_LIVE, HI_NZ };
     if (dbg_on && tid == 0 && j < 1024) D.dbg[2304 + j * 16 + (k)] = (long long)wall_clock64(); \
   } while (0)
 
+// ln |a 10^(b x + c)| of a parameter-pack column that is a power of ten of a proposed coordinate
+// (naima's fits walk in log10 of amplitudes and energies): ln|a| + y ln 10 with ln 10 in two
+// pieces -- right to the last place of a number around 70, as the logarithm of the rounded power
+// is, and not a library call BEHIND the library's exp10 on the one lane every wave waits for.
+// Both half-step kernels take it, so that their weights are the same numbers.
+__device__ __forceinline__ double hs_ln_pow10(double lna, double zb, double zc, double x) {
+  const double y = fma(zb, x, zc);
+  return lna + fma(y, 2.302585092994046, y * -2.1707562233822494e-16);
+}
+
+// Wave-wide sums over DPP (row shifts inside the 16-lane rows, then the two row broadcasts): the
+// total lands in lane 63 -- a quarter of the latency of six ds_bpermute round trips, which on the
+// one wave that finishes a slice alone is time every other wave waits.  (The order of the
+// additions is fixed, like the shuffle tree's; it is a different order.)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int hs_dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double hs_dpp_f64(double v) {
+  const int lo = hs_dpp_i32<CTRL, ROW_MASK, BANK_MASK>(__double2loint(v));
+  const int hi = hs_dpp_i32<CTRL, ROW_MASK, BANK_MASK>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// (lanes a shift does not reach read 0: bound_ctrl off and old = 0 -- adding 0.0 / 0)
+__device__ __forceinline__ void hs_wave_sum_dpp(double& a, int& c) {
+  a += hs_dpp_f64<0x111, 0xf, 0xf>(a);  c += hs_dpp_i32<0x111, 0xf, 0xf>(c);   // row_shr:1
+  a += hs_dpp_f64<0x112, 0xf, 0xf>(a);  c += hs_dpp_i32<0x112, 0xf, 0xf>(c);   // row_shr:2
+  a += hs_dpp_f64<0x114, 0xf, 0xe>(a);  c += hs_dpp_i32<0x114, 0xf, 0xe>(c);   // row_shr:4
+  a += hs_dpp_f64<0x118, 0xf, 0xc>(a);  c += hs_dpp_i32<0x118, 0xf, 0xc>(c);   // row_shr:8
+  a += hs_dpp_f64<0x142, 0xa, 0xf>(a);  c += hs_dpp_i32<0x142, 0xa, 0xf>(c);   // row_bcast:15
+  a += hs_dpp_f64<0x143, 0xc, 0xf>(a);  c += hs_dpp_i32<0x143, 0xc, 0xf>(c);   // row_bcast:31
+}
+
 __device__ __forceinline__ double hs_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -223,19 +257,12 @@ __device__ __forceinline__ double hs_seg_pre(double acc, double u1, double u2, d
   return a2;
 }
 
+// (the loop itself: table address (wave-uniform halves) and width, node count, column tile, row
+// range, and the LDS byte addresses of w | dlw (/ lx) | lx (2^-10 / lx) AT row s0)
 template <bool SIGNED>
-__device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
-                                                const double* ws, const double* ds,
-                                                const double* lxs, int lane,
-                                                const double* KD = nullptr) {
-  // the table's address and width come out of the descriptor: the compiler cannot
-  // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
-  // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
-  // the 25 the loop then costs) -- say so once per work item instead
-  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
-  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
-  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
-  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+__device__ __forceinline__ double hs_table_item_v(unsigned kd_lo, unsigned kd_hi, unsigned nK, int nG,
+                                                  int tile, int s0, int s1, unsigned aw, unsigned ad,
+                                                  unsigned al, int lane) {
   const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
   const int k = tile * 64 + lane;
   const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
@@ -244,7 +271,6 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
       __builtin_amdgcn_make_buffer_rsrc((void*)KDu, 0, (int)tbytes, 0x00020000);
   const unsigned rowb = nK * 16u;
   unsigned ob = ((unsigned)s0 * nK + kk) * 16u;
-  unsigned aw = hs_lds_addr(ws + s0), ad = hs_lds_addr(ds + s0), al = hs_lds_addr(lxs + s0);
   double acc = 0.0;
   double K1, d1;  // node s: its K and the log-ratio of the segment that starts there
   hs_buf_kd(rKD, ob, K1, d1);
@@ -287,6 +313,23 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
   return acc;
 }
 
+template <bool SIGNED>
+__device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int tile, int s0, int s1,
+                                                const double* ws, const double* ds,
+                                                const double* lxs, int lane,
+                                                const double* KD = nullptr) {
+  // the table's address and width come out of the descriptor: the compiler cannot
+  // prove them wave-uniform and would wrap EVERY load in a waterfall loop (four
+  // v_readfirstlane + two v_cmp + exec juggling per load, 7 VALU instructions per segment of
+  // the 25 the loop then costs) -- say so once per work item instead
+  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
+  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
+  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
+  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+  return hs_table_item_v<SIGNED>(kd_lo, kd_hi, nK, nG, tile, s0, s1, hs_lds_addr(ws + s0),
+                                 hs_lds_addr(ds + s0), hs_lds_addr(lxs + s0), lane);
+}
+
 // The same for a table of at most 32 columns: a wave of 64 lanes would leave half of them (or
 // more) idle, and the loop is bound by instruction issue -- so `sub` = 64 / nKp sub-ranges of
 // the item's segments share the wave (lane = h nKp + k walks sub-range h of column k).  The
@@ -294,17 +337,12 @@ __device__ __forceinline__ double hs_table_item(const hs_tab& t, int nG, int til
 // PK nodes per trip: 4 in the general instance of the kernel (123 VGPRs), 6 where there is no
 // synchrotron component (99 VGPRs without them): a narrow table's items are bound by the round
 // trips of their loads, half as many rows again in flight per trip (8 spills)
+// (aw0 / ad0 / al0: LDS byte addresses of the arrays' row 0)
 template <bool SIGNED, int PK>
-__device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
-                                                       const double* ws, const double* ds,
-                                                       const double* lxs, int lane,
-                                                       const double* KD = nullptr) {
-  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
-  const int nKp = __builtin_amdgcn_readfirstlane(t.nKp);
-  const int sub = __builtin_amdgcn_readfirstlane(t.sub);
-  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
-  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
-  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+__device__ __forceinline__ double hs_table_item_packed_v(unsigned kd_lo, unsigned kd_hi, unsigned nK,
+                                                         int nKp, int sub, int nG, int s0, int s1,
+                                                         unsigned aw0, unsigned ad0, unsigned al0,
+                                                         int lane) {
   const void* KDu = (const void*)(((unsigned long long)kd_hi << 32) | kd_lo);
   const int k = lane & (nKp - 1), h = lane / nKp;
   const unsigned kk = (unsigned)k < nK ? (unsigned)k : nK - 1u;
@@ -319,7 +357,7 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   // per-lane LDS bases: the reads of a trip are immediate offsets from them.  Lanes whose
   // sub-range is shorter than `len` read on past its end (another array of the block, or
   // nothing: LDS reads out of range return 0) and discard the term.
-  unsigned aw = hs_lds_addr(ws + sl), ad = hs_lds_addr(ds + sl), al = hs_lds_addr(lxs + sl);
+  unsigned aw = aw0 + 8u * (unsigned)sl, ad = ad0 + 8u * (unsigned)sl, al = al0 + 8u * (unsigned)sl;
   double acc = 0.0;
   double K1, d1;
   hs_buf_kd(rKD, ob, K1, d1);
@@ -367,6 +405,21 @@ __device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, 
   // the sub-ranges of a column meet in its first lane group (fixed order: deterministic)
   for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
   return acc;
+}
+
+template <bool SIGNED, int PK>
+__device__ __forceinline__ double hs_table_item_packed(const hs_tab& t, int nG, int s0, int s1,
+                                                       const double* ws, const double* ds,
+                                                       const double* lxs, int lane,
+                                                       const double* KD = nullptr) {
+  const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(t.nK);
+  const int nKp = __builtin_amdgcn_readfirstlane(t.nKp);
+  const int sub = __builtin_amdgcn_readfirstlane(t.sub);
+  const unsigned long long kd = (unsigned long long)(KD ? KD : t.KD);
+  const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kd);
+  const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kd >> 32));
+  return hs_table_item_packed_v<SIGNED, PK>(kd_lo, kd_hi, nK, nKp, sub, nG, s0, s1, hs_lds_addr(ws),
+                                            hs_lds_addr(ds), hs_lds_addr(lxs), lane);
 }
 
 

@@ -68,6 +68,25 @@ __device__ __forceinline__ double pd_exp_tab(double x, const double* __restrict_
   return (x == x) ? ldexp(T64[k & 63] * p, k >> 6) : x;  // NaN in, NaN out
 }
 
+// the same with the table's LDS BYTE ADDRESS (a pointer into dynamic LDS handed to a function that
+// is not inlined is a flat pointer, and getting the local address back out of it costs a scalar
+// load from a per-kernel offset table at the head of every exponential)
+typedef __attribute__((address_space(3))) const double pd_lds_cd;
+__device__ __forceinline__ double pd_exp_tab_lds(double x, unsigned t64) {
+  const double xc = fmin(fmax(x, -1100.0), 1100.0);
+  const double kf = rint(xc * 92.33248261689366);   // 64 / ln 2
+  double r = fma(-kf, 0.010830424696223417, xc);    // ln2/64: 36 leading bits ...
+  r = fma(-kf, 2.572804622327669e-14, r);           // ... and the rest
+  double p = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const int k = (int)kf;
+  const double tj = *(pd_lds_cd*)(unsigned long long)(t64 + 8u * (unsigned)(k & 63));
+  return (x == x) ? ldexp(tj * p, k >> 6) : x;  // NaN in, NaN out
+}
+
 // One node of a walker's particle spectrum: n(E) as the reference evaluates it
 // (models.py:88-92, 157-161, 234-238, 330-335, 402-407; x**p as exp(p ln x), 1e-14)
 // and the log-ratio of the SHAPE to the next node, ln f(E2)/f(E1), assembled from
@@ -75,12 +94,15 @@ __device__ __forceinline__ double pd_exp_tab(double x, const double* __restrict_
 // -(t2 - t1) = -t1 expm1(beta lr);  log-parabola -> -alpha lr - beta lr (l1 + l2).
 // Inputs are logarithms: lxx = ln(E/e_0), lxc = ln(E/e_cutoff), lkb = ln(e_break/e_0);
 // b1, b2 say whether this node / the next one lie below the break.
-// T64 != nullptr: exponentials through pd_exp_tab
+// T64 != nullptr: exponentials through pd_exp_tab (t64_lds != 0: through pd_exp_tab_lds).
 __device__ __forceinline__ void pd_core(int kind, const pd_par& p, double lxx, double lxc,
                                         double lkb, bool b1, bool b2, double lr, double& n,
                                         double& dsh, const double* __restrict__ T64 = nullptr,
-                                        double* __restrict__ lnn = nullptr, bool full = true) {
-  auto pd_exp = [T64](double v) { return T64 ? pd_exp_tab(v, T64) : ::pd_exp(v); };
+                                        double* __restrict__ lnn = nullptr, bool full = true,
+                                        unsigned t64_lds = 0) {
+  auto pd_exp = [T64, t64_lds](double v) {
+    return t64_lds ? pd_exp_tab_lds(v, t64_lds) : (T64 ? pd_exp_tab(v, T64) : ::pd_exp(v));
+  };
   double ex;  // ln(n / A): what the log-domain consumers (nh_syn2.h) take instead of n
   switch (kind) {
     case NH_PD_POWERLAW:

@@ -61,6 +61,16 @@
 #define HS_RUN_PK 5      // nodes per trip of a narrow table's items in the table-only instances (nh_hs.h): 6 spilled 8 VGPRs (cfg5 9.12 M walker-steps/s, 9.77 M at 5; cfg1 1.49 -> 1.46 M)
 #endif
 
+// the weights' unit table (hs_run.o_ut): ints per unit
+enum { HSU_G = 0, HSU_I0, HSU_NG, HSU_W, HSU_D, HSU_DP, HSU_IL, HSU_TH, HSU_LX, HSU_LNE, HSU_GX, HSU_GE,
+       HSU_S2, HSU_S2LW, HSU_SC_LO, HSU_SC_HI, HSU_N };
+static_assert(HSU_N == 16, "a unit's descriptor is four 16-byte reads");
+
+// the table items' descriptors (hs_run.o_it): ints per item
+enum { HSI_KD_LO = 0, HSI_KD_HI, HSI_NK, HSI_NG, HSI_TILE, HSI_S0, HSI_S1, HSI_S0F, HSI_S1F, HSI_AW,
+       HSI_AD, HSI_AL, HSI_FLAGS, HSI_SUB, HSI_NKP, HSI_T, HSI_N };
+static_assert(HSI_N == 16, "an item's descriptor is four 16-byte reads");
+
 struct hs_run {
   unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
   int* status;               // device word: 0, or HS_RUN_ERR_* of the first workgroup that gave up
@@ -104,6 +114,24 @@ struct hs_run {
   // launch that gave up part of the way leaves the counters as it found them whoever of its
   // workgroups had already counted (what a replay of its block of moves starts from)
   int* lcnt;
+  int o_il[NH_MAX_GRIDS];  // LDS: 1 / lx per node of a grid a non-negative table is reduced over (-1: none)
+  // LDS: the weights' units -- 64 consecutive nodes of one grid each -- as 16 ints per unit
+  // (HSU_*: grid, first node, node count, where the node's inputs and outputs sit in LDS, the
+  // grid's scale), built once per launch; -1: the grids' nodes are not in LDS (small workgroups)
+  int o_ut;
+  // LDS: the table work items -- which table, column tile and rows, where the walker's arrays
+  // sit -- as 16 ints per item (HSI_*), built once per launch: a work item read its table's
+  // descriptor out of the kernel-argument segment field by field (dependent vector loads: the
+  // table index is not a constant) and re-derived its rows -- ~300 vector instructions before its
+  // first segment, as many as the segments of a 32-row item cost; -1: not used
+  int o_it;
+  // LDS: per column of the tables' (sorted) spectra 4 ints { first partial sum | stride | chunks |
+  // where it goes in spec } + its scale's index rides with `where`; and the model's components as
+  // NH_MAX_COMP x { offset in spec (int, as a double's low word) | scale }: the phases behind
+  // barrier 3 -- one or a few waves, everybody else waiting -- took these out of the
+  // kernel-argument segment one dependent scalar load at a time (four round trips per component)
+  int o_sum, o_cmp;
+  int sum_cols;  // columns of all the tables together (the sum phase's loop bound)
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
@@ -168,14 +196,16 @@ __device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x);
 struct hsr_node { double n, dsh, ex; };  // ex = ln(n / A)
 struct hsr_node2 { double n0, dsh0, n1, dsh1, ex0, ex1; };
 // b12 / b0 / b1: bit 0, 1 = this node / the next lie below the break; bit 2 = ln(n / A) only
+// t64: LDS byte address of 2^(j/64)
 __device__ __attribute__((noinline)) hsr_node hsr_pd_core(int kind, double A, double al, double be,
                                                           double a2, double lxx, double lxc,
                                                           double lkb, int b12, double lr,
-                                                          const double* T64) {
+                                                          unsigned t64) {
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node r;
-  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, T64, &r.ex, (b12 & 4) == 0);
+  pd_core(kind, p, lxx, lxc, lkb, (b12 & 1) != 0, (b12 & 2) != 0, lr, r.n, r.dsh, nullptr, &r.ex,
+          (b12 & 4) == 0, t64);
   return r;
 }
 
@@ -185,21 +215,49 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
                                                             double be, double a2, double lkb,
                                                             double lxx0, double lxc0, int b0,
                                                             double lr0, double lxx1, double lxc1,
-                                                            int b1, double lr1, const double* T64) {
+                                                            int b1, double lr1, unsigned t64) {
   pd_par p;
   p.A = A; p.e0 = 0.0; p.al = al; p.ec = 0.0; p.be = be; p.eb = 0.0; p.a2 = a2;
   hsr_node2 r;
-  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, T64, &r.ex0, (b0 & 4) == 0);
-  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, T64, &r.ex1, (b1 & 4) == 0);
+  pd_core(kind, p, lxx0, lxc0, lkb, (b0 & 1) != 0, (b0 & 2) != 0, lr0, r.n0, r.dsh0, nullptr, &r.ex0,
+          (b0 & 4) == 0, t64);
+  pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, nullptr, &r.ex1,
+          (b1 & 4) == 0, t64);
   return r;
 }
 
 // workgroup 0 only: when does each WAVE reach barrier 1 / 2 / 3 and finish its last item
+#ifdef HSR_FINE
+#define HSR_WSTAMP(k) do {} while (0)
+#else
 #define HSR_WSTAMP(k)                                                                  \
   do {                                                                                  \
     if (R.dbg && lane == 0 && blockIdx.x == 0 && it < 64)                               \
       R.dbg[256 * 64 * 8 + (it * 4 + (k)) * 16 + wv] = (long long)wall_clock64();       \
   } while (0)
+#endif
+// -DHSR_FINE (experiments: scripts/r5_fine.py): workgroup 0, iterations 32 .. 39, eight stamps per
+// wave inside a slice -- where does a phase's time go, wave by wave
+#ifdef HSR_FINE
+#define HSR_FSTAMP(k)                                                                   \
+  do {                                                                                   \
+    if (R.dbg && lane == 0 && blockIdx.x == 0 && it >= 32 && it < 40)                    \
+      R.dbg[256 * 64 * 8 + (((it & 7) * 8 + (k)) * 16) + wv] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define HSR_FSTAMP(k) do {} while (0)
+#endif
+#if defined(HSR_FINE) && HSR_FINE == 2  // (the same slots, for the tail of a slice instead)
+#undef HSR_FSTAMP
+#define HSR_FSTAMP(k) do {} while (0)
+#define HSR_GSTAMP(k)                                                                   \
+  do {                                                                                   \
+    if (R.dbg && lane == 0 && blockIdx.x == 0 && it >= 32 && it < 40)                    \
+      R.dbg[256 * 64 * 8 + (((it & 7) * 8 + (k)) * 16) + wv] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define HSR_GSTAMP(k) do {} while (0)
+#endif
 #define HSR_STAMP(k)                                                                   \
   do {                                                                                  \
     if (R.dbg && tid == 0 && blockIdx.x < 256 && it < 64)                               \
@@ -233,6 +291,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     const int nG = H.nG[g];
     for (int i = tid; i < nG; i += T) {
       sm[H.o_lx[g] + i] = i + 1 < nG ? H.lx[g][i] : 0.0;
+      if (R.o_il[g] >= 0) {
+        // 1 / lx and the series threshold 2^-10 / lx of a table grid's segments do not depend on
+        // the walker: once per launch (they were a reciprocal and two stores per node and slice)
+        const double il = i + 1 < nG ? nh_rcp(H.lx[g][i]) : 0.0;
+        sm[R.o_il[g] + i] = il;
+        sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+      }
       if (R.o_gx[0] >= 0) {  // (small workgroups leave the nodes in L2: LDS decides how many fit a CU)
         if (!(SYN && S2 && R.s2_own && g == H.syn_grid)) sm[R.o_gx[g] + i] = H.xg[g][i];
         sm[R.o_lne[g] + i] = H.lne[g][i];
@@ -319,6 +384,105 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       reinterpret_cast<int*>(o + 3)[1] = P.ncols;
       reinterpret_cast<long long*>(o + 4)[0] = (long long)P.ld;
       reinterpret_cast<double**>(o + 5)[0] = P.out;
+    }
+  }
+  // the weights' units: what the lanes of a unit read and write, resolved to LDS offsets ONCE --
+  // in the slice loop these came out of the kernel-argument segment one scalar load and one wait
+  // at a time (the fine stamps of round 5: 0.8 us of a unit before its first node's arithmetic,
+  // 0.65 us behind it)
+  if (R.o_ut >= 0) {
+    int* ut = reinterpret_cast<int*>(sm + R.o_ut);
+    int u0 = 0;
+    for (int g = 0; g < H.ngrids; ++g) {
+      const int nu = (H.nG[g] + 63) >> 6;
+      const bool s2g = SYN && S2 && g == H.syn_grid;
+      for (int q = tid; q < nu; q += T) {
+        int* d = ut + (u0 + q) * HSU_N;
+        const int i0 = q * 64;
+        d[HSU_G] = g;
+        d[HSU_I0] = i0;
+        d[HSU_NG] = H.nG[g];
+        d[HSU_W] = H.o_w[g] + i0;
+        d[HSU_D] = H.o_d[g] + i0;
+        d[HSU_DP] = H.o_dp[g] >= 0 ? H.o_dp[g] + i0 : -1;
+        d[HSU_IL] = R.o_il[g] >= 0 ? R.o_il[g] + i0 : -1;
+        d[HSU_TH] = H.o_th[g] >= 0 ? H.o_th[g] + i0 : -1;
+        d[HSU_LX] = H.o_lx[g] + i0;
+        d[HSU_LNE] = R.o_lne[g] + i0;
+        d[HSU_GX] = R.o_gx[g] + i0;
+        d[HSU_GE] = R.o_ge[g] + i0;
+        d[HSU_S2] = s2g ? (R.s2_own ? 2 : 1) : 0;
+        d[HSU_S2LW] = s2g ? R.o_s2lw + HS_S2_GUARD + i0 : 0;
+        d[HSU_SC_LO] = __double2loint(H.scale[g]);
+        d[HSU_SC_HI] = __double2hiint(H.scale[g]);
+      }
+      u0 += nu;
+    }
+  }
+  {
+    int* st = reinterpret_cast<int*>(sm + R.o_sum);
+    int c0 = 0;  // (the tables' columns one after the other)
+    for (int t = 0; t < D.ntab; ++t) {
+      const hs_tab& tb = D.tab[t];
+      const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
+      const int* perm = kds ? hs_tab_trailer(kds, H.nG[tb.grid], tb.nK) + HS_TRAIL_TILES : nullptr;
+      for (int k = tid; k < tb.nK; k += T) {
+        int* d = st + 4 * (c0 + k);
+        d[0] = H.o_part_t + (tb.item0 + (k >> 6)) * 64 + (k & 63);
+        d[1] = tb.tiles * 64;
+        d[2] = HS_CHUNKS(tb.chunks);
+        d[3] = tb.spec_off + (perm ? perm[k] : k);  // (sorted columns: back in the spectrum's order)
+      }
+      c0 += tb.nK;
+    }
+    double* cm = sm + R.o_cmp;
+    for (int q = tid; q < NH_MAX_COMP; q += T) {  // (LDS offsets of the components' spectra)
+      cm[2 * q] = q < D.ncomp ? (double)(H.o_spec + D.comp[q].off) : (double)(R.o_cmp + 2 * NH_MAX_COMP);
+      cm[2 * q + 1] = q < D.ncomp ? D.comp[q].scale : 0.0;
+    }
+    if (tid == 0) cm[2 * NH_MAX_COMP] = 0.0;  // (what a component the model does not have reads)
+  }
+  if (R.o_it >= 0) {
+    int* itab = reinterpret_cast<int*>(sm + R.o_it);
+    for (int ix = tid; ix < D.nT; ix += T) {
+      int t = 0;
+      while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
+      const hs_tab& tb = D.tab[t];
+      const int loc = ix - tb.item0;
+      const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
+      const int tg = tb.grid, nG = H.nG[tg];
+      const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
+      const double* kd = kds ? kds : tb.KD;
+      int s0f, s1f;
+      hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0f, s1f);
+      // (rows below the tile's first non-zero one contribute exact zeros: not walked -- unless the
+      // walker has a weight that is not finite, 0 x inf: the item then takes s0f, s1f)
+      const int r0 = kds ? hs_tab_trailer(kds, nG, tb.nK)[min(tile, HS_TRAIL_TILES - 1)] : 0;
+      int s0 = max(s0f, r0), s1 = s1f;
+      if (R.rebalance) {
+        const int nch = HS_CHUNKS(tb.chunks);
+        const int per = (max(nG - 1 - r0, 0) + nch - 1) / nch;
+        s0 = r0 + chunk * per;
+        s1 = min(nG - 1, s0 + per);
+      }
+      const bool pre = tb.nonneg != 0;
+      int* d = itab + ix * HSI_N;
+      d[HSI_KD_LO] = (int)(unsigned)(unsigned long long)kd;
+      d[HSI_KD_HI] = (int)(unsigned)((unsigned long long)kd >> 32);
+      d[HSI_NK] = tb.nK;
+      d[HSI_NG] = nG;
+      d[HSI_TILE] = tile;
+      d[HSI_S0] = s0;
+      d[HSI_S1] = s1;
+      d[HSI_S0F] = s0f;
+      d[HSI_S1F] = s1f;
+      d[HSI_AW] = (int)hs_lds_addr(sm + H.o_w[tg]);
+      d[HSI_AD] = (int)hs_lds_addr(sm + (pre ? H.o_dp[tg] : H.o_d[tg]));
+      d[HSI_AL] = (int)hs_lds_addr(sm + (pre ? H.o_th[tg] : H.o_lx[tg]));
+      d[HSI_FLAGS] = tg | (pre ? 16 : 0);
+      d[HSI_SUB] = tb.sub;
+      d[HSI_NKP] = tb.nKp;
+      d[HSI_T] = t;
     }
   }
   // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or
@@ -532,8 +696,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                 if (pkd < 0) {
                   lv = o[6];
                 } else if (ztf == NH_TF_POW10) {
-                  const double y = fma(zb, qv, zc);
-                  lv = o[6] + fma(y, 2.302585092994046, y * -2.1707562233822494e-16);
+                  lv = hs_ln_pow10(o[6], zb, zc, qv);
                 } else {
                   lv = 0.0;
                 }
@@ -557,6 +720,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       __syncthreads();  // ---------------------------------------------------------------- #1
       HSR_STAMP(2);
       if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
+      HSR_FSTAMP(0);
       if (K > 1) {  // the work items of the walker's other workgroups: their slots count as 0
         for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
         if (has_syn)
@@ -623,13 +787,37 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const int t = nwv - 1 - wv;
         lv_k = t * 64 + lane;
         lv_i0 = nG;
+        double lv_lnq = 0.0;
         if (lv_k < H.syn_nE) {
           lv_E = sm[H.o_synE + lv_k];
           lv_q = lv_E * qfac;
           int lo = 0, hi2 = nG;  // first i with q*ig2[i] <= 746 (ig2 decreases with i)
-          while (lo < hi2) {
-            const int mid = (lo + hi2) >> 1;
-            if (lv_q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
+          if (S2) {
+            // the grid is a comb in ln gamma (that is what S2 means): node i has ln x_i = ln q -
+            // 2 ln gamma_0 - 2 i lx, so the first live node is where the comb crosses ln 746 -- from
+            // the logarithm the items need anyway -- and the comparison itself, as the search made
+            // it, settles the last place (two or three reads instead of ten dependent ones)
+            lv_lnq = hsr_log(lv_q);
+            const double z = fma(-lv_lnq, R.s2_invd, R.s2_z0);  // node i at z + i steps below T_top
+            const double r = (HS_S2_TTOP - 6.61472560020376) * R.s2_invd - z;  // (ln 746)
+            if (r == r) {
+              int c = r > 0.0 ? (r < (double)nG ? (int)r : nG) : 0;
+              while (c > 0 && lv_q * ig2[c - 1] <= 746.0) --c;
+              while (c < nG && !(lv_q * ig2[c] <= 746.0)) ++c;
+              lo = c;
+            } else {
+              // (a field that is not positive: ln q is NaN -- the search itself, whose answer for a
+              // negative q is "every node", for a NaN "none")
+              while (lo < hi2) {
+                const int mid = (lo + hi2) >> 1;
+                if (lv_q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
+              }
+            }
+          } else {
+            while (lo < hi2) {
+              const int mid = (lo + hi2) >> 1;
+              if (lv_q * ig2[mid] <= 746.0) hi2 = mid; else lo = mid + 1;
+            }
           }
           lv_i0 = lo;
         }
@@ -675,7 +863,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             if (S2) {
               // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
               // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy
-              const double lnq = hsr_log(lv_q);
+              const double lnq = lv_lnq;
               const double z = fma(-lnq, R.s2_invd, R.s2_z0);
               const double Zf = floor(z);
               double* s2q = sm + R.o_s2q;
@@ -690,6 +878,117 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           }
         }
       }
+      HSR_FSTAMP(1);
+      if (R.o_ut >= 0) {
+        // ---- the grids' nodes are in LDS: units from the table built when the launch began ------
+        const int* ut = reinterpret_cast<const int*>(sm + R.o_ut);
+        const double lg0 = lg[0], lg1 = lg[1], lkb = lg[2] - lg[0];
+        const double lnA = (SYN && S2) ? qs[HS_O_LNA] : 0.0;
+        const unsigned t64 = hs_lds_addr(sm + HS_O_T64);
+        int fl = 0;  // (wave-uniform) grids with a non-zero weight | << 8: with one that is not finite
+        for (int u = worker ? rank : nunits; u < nunits; u += 2 * nwork) {
+          const bool two = u + nwork < nunits;  // (wave-uniform)
+          typedef int hsu_i4 __attribute__((ext_vector_type(4)));
+          int dq[2][HSU_N];
+          double lrq[2], lneq[2], gxq[2], ilq[2];
+          int bq[2], icq[2];
+          bool onq[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int uu = (q == 0 || two) ? u + q * nwork : u;  // (no second unit: the first one again, unused)
+            const hsu_i4* dp4 = reinterpret_cast<const hsu_i4*>(ut + uu * HSU_N);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const hsu_i4 v = dp4[k];
+              dq[q][4 * k] = v.x; dq[q][4 * k + 1] = v.y; dq[q][4 * k + 2] = v.z; dq[q][4 * k + 3] = v.w;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int* d = dq[q];
+            const int nl = d[HSU_NG] - d[HSU_I0];         // nodes of the grid from this unit's first on
+            onq[q] = (q == 0 || two) && lane < nl;
+            const int ic = min(lane, nl - 1);             // (lanes past the grid's end: its last node, discarded)
+            icq[q] = ic;
+            lrq[q] = sm[d[HSU_LX] + ic];                  // (0 at the last node)
+            lneq[q] = sm[d[HSU_LNE] + ic];
+            gxq[q] = sm[d[HSU_GX] + ic];
+            ilq[q] = d[HSU_IL] >= 0 ? sm[d[HSU_IL] + ic] : 0.0;
+            int b = 0;
+            if (broken) {
+              const double E = sm[d[HSU_GE] + ic];
+              const double E2 = sm[d[HSU_GE] + min(ic + 1, nl - 1)];
+              b = (E < p.eb ? 1 : 0) | (E2 < p.eb ? 2 : 0);
+            }
+            // (the log-domain synchrotron items read ln w and nothing else of this grid: no
+            // exponential, no expm1 for its nodes -- wave-uniform, a unit is one grid's)
+            if (d[HSU_S2] == 2) b |= 4;
+            bq[q] = b;
+          }
+          HSR_FSTAMP(2);
+          double nnq[2], dshq[2], exq[2];
+          if (two) {
+            const hsr_node2 nd = hsr_pd_core2(D.kind, p.A, p.al, p.be, p.a2, lkb, lneq[0] - lg0,
+                                              lneq[0] - lg1, bq[0], lrq[0], lneq[1] - lg0,
+                                              lneq[1] - lg1, bq[1], lrq[1], t64);
+            nnq[0] = nd.n0; dshq[0] = nd.dsh0; nnq[1] = nd.n1; dshq[1] = nd.dsh1;
+            exq[0] = nd.ex0; exq[1] = nd.ex1;
+          } else {
+            const hsr_node nd = hsr_pd_core(D.kind, p.A, p.al, p.be, p.a2, lneq[0] - lg0,
+                                            lneq[0] - lg1, lkb, bq[0], lrq[0], t64);
+            nnq[0] = nd.n; dshq[0] = nd.dsh; nnq[1] = 0.0; dshq[1] = 0.0;
+            exq[0] = nd.ex; exq[1] = 0.0;
+          }
+          HSR_FSTAMP(3);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !two) break;
+            const int* d = dq[q];
+            const int ic = icq[q];
+            const bool on = onq[q];
+            const bool last = ic + 1 >= d[HSU_NG] - d[HSU_I0];
+            const double nn = nnq[q] * __hiloint2double(d[HSU_SC_HI], d[HSU_SC_LO]);
+            double wv_ = gxq[q] * nn;
+            const double dv = last ? 0.0 : lrq[q] + dshq[q];
+            bool plain = true;  // (wave-uniform)
+            if (SYN && S2 && d[HSU_S2] != 0) {
+              // the log-domain items' Lambda ln|w| + Lambda ln cbrt(1/gamma^2) (nh_syn2.h); a zero
+              // weight (or amplitude) is the floor: an exact 0, and exact zeros for its segments
+              const double lna = lnA + exq[q];  // ln |n|
+              const double lw = fma(HS_S2_LAMBDA, lna, sm[R.o_s2lg + d[HSU_I0] + ic]);
+              // (w = gamma n scale underflows to an exact 0 in the reference below ln w = -744.44:
+              // the floor -- an exact zero node -- from there on)
+              const bool nonzero = lna + lneq[q] > R.s2_lnw0;
+              if (on) sm[d[HSU_S2LW] + ic] = nonzero ? lw : HS_S2_FLOOR;
+              if (d[HSU_S2] == 2) {  // (nobody reads this grid's w / dlw, and gx holds another array)
+                plain = false;
+                wv_ = !(lw < INFINITY) ? lw : (nonzero ? 1.0 : 0.0);  // (what the flags below look at)
+              }
+            }
+            if (plain && on) {
+              sm[d[HSU_W] + ic] = wv_;
+              sm[d[HSU_D] + ic] = dv;
+              if (d[HSU_DP] >= 0) {  // what the non-negative table items read
+                if (d[HSU_IL] >= 0) {  // (1 / lx and the threshold: in LDS since the launch began)
+                  sm[d[HSU_DP] + ic] = dv * ilq[q];
+                } else {
+                  const double il = last ? 0.0 : nh_rcp(lrq[q]);
+                  sm[d[HSU_DP] + ic] = dv * il;
+                  sm[d[HSU_TH] + ic] = NH_SEG_SMALL_POS * il;
+                }
+              }
+            }
+            // (a weight that is not finite -- a far-off walker whose distribution overflows --
+            // makes 0 x inf = NaN of a zero table entry, as in the reference: no row of such a
+            // walker's tables is skipped)
+            if (__builtin_amdgcn_ballot_w64(on && wv_ != 0.0) != 0ull) fl |= 1 << d[HSU_G];
+            if (__builtin_amdgcn_ballot_w64(on && !isfinite(wv_)) != 0ull) fl |= 256 << d[HSU_G];
+          }
+        }
+        HSR_FSTAMP(4);
+        fl = __builtin_amdgcn_readfirstlane(fl);
+        if (lane == 0 && fl) atomicOr(&hi[HI_NZ], fl);
+      } else {
       int nzmask = 0;
       for (int u = worker ? rank : nunits; u < nunits; u += 2 * nwork) {
         // this wave's units u and u + nwork (if any), node `lane` of each
@@ -729,20 +1028,23 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         }
         const bool two = u + nwork < nunits;  // (wave-uniform)
         double nnq[2], dshq[2], exq[2];
+        HSR_FSTAMP(2);
+        const unsigned t64 = hs_lds_addr(sm + HS_O_T64);
         if (two) {
           const hsr_node2 nd = hsr_pd_core2(D.kind, p.A, p.al, p.be, p.a2, lg[2] - lg[0],
                                             lneq[0] - lg[0], lneq[0] - lg[1], bq[0], lrq[0],
                                             lneq[1] - lg[0], lneq[1] - lg[1], bq[1], lrq[1],
-                                            sm + HS_O_T64);
+                                            t64);
           nnq[0] = nd.n0; dshq[0] = nd.dsh0; nnq[1] = nd.n1; dshq[1] = nd.dsh1;
           exq[0] = nd.ex0; exq[1] = nd.ex1;
         } else {
           const hsr_node nd = hsr_pd_core(D.kind, p.A, p.al, p.be, p.a2, lneq[0] - lg[0],
                                           lneq[0] - lg[1], lg[2] - lg[0], bq[0], lrq[0],
-                                          sm + HS_O_T64);
+                                          t64);
           nnq[0] = nd.n; dshq[0] = nd.dsh; nnq[1] = 0.0; dshq[1] = 0.0;
           exq[0] = nd.ex; exq[1] = 0.0;
         }
+        HSR_FSTAMP(3);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           if (onq[q]) {
@@ -770,9 +1072,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               sm[H.o_w[g] + i] = wv_;
               sm[H.o_d[g] + i] = dv;
               if (H.o_dp[g] >= 0) {  // what the non-negative table items read
-                const double il = last ? 0.0 : nh_rcp(lrq[q]);
-                sm[H.o_dp[g] + i] = dv * il;
-                sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+                if (R.o_il[g] >= 0) {  // (1 / lx and the threshold: in LDS since the launch began)
+                  sm[H.o_dp[g] + i] = dv * sm[R.o_il[g] + i];
+                } else {
+                  const double il = last ? 0.0 : nh_rcp(lrq[q]);
+                  sm[H.o_dp[g] + i] = dv * il;
+                  sm[H.o_th[g] + i] = NH_SEG_SMALL_POS * il;
+                }
               }
             }
             if (wv_ != 0.0) nzmask |= 1 << g;
@@ -782,15 +1088,19 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             if (!isfinite(wv_)) nzmask |= 256 << g;
           }
       }
+      HSR_FSTAMP(4);
       {
         int any = nzmask;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off, 64);
         if (lane == 0 && any) atomicOr(&hi[HI_NZ], any);
       }
+      }
+      HSR_FSTAMP(5);
       HSR_WSTAMP(1);
       __syncthreads();  // ---------------------------------------------------------------- #2
       HSR_STAMP(3);
+      HSR_FSTAMP(6);
       const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
       int nA = 0, Cd = 1, nS = 0;
       if (has_syn) {
@@ -874,7 +1184,40 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             if (is_tab) part_t[ix * 64 + lane] = 0.0;
             continue;
           }
-          if (is_tab) {
+          if (is_tab && RT == 0) {  // (the descriptor table is part of every such instance's layout)
+            typedef int hsi_i4 __attribute__((ext_vector_type(4)));
+            const hsi_i4* e4 = reinterpret_cast<const hsi_i4*>(reinterpret_cast<const int*>(sm + R.o_it) + ix * HSI_N);
+            const hsi_i4 e0 = e4[0], e1 = e4[1], e2 = e4[2], e3 = e4[3];
+            const int fl = __builtin_amdgcn_readfirstlane(e3.x);
+            const int tg = fl & 15;
+            const bool pre = (fl & 16) != 0;
+            const bool inf = (nz >> (8 + tg) & 1) != 0;  // (a weight that is not finite: every row)
+            const int s0 = __builtin_amdgcn_readfirstlane(inf ? e1.w : e1.y);
+            const int s1 = __builtin_amdgcn_readfirstlane(inf ? e2.x : e1.z);
+            const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane(e0.x);
+            const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane(e0.y);
+            const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(e0.z);
+            const int nG = __builtin_amdgcn_readfirstlane(e0.w);
+            const int sub = __builtin_amdgcn_readfirstlane(e3.y);
+            double acc;
+            if (!(nz >> tg & 1) || s0 >= s1) {
+              acc = 0.0;
+            } else if (sub > 1) {
+              const int nKp = __builtin_amdgcn_readfirstlane(e3.z);
+              acc = pre ? hs_table_item_packed_v<false, SYN ? 4 : HS_RUN_PK>(kd_lo, kd_hi, nK, nKp, sub, nG, s0, s1,
+                                                                            (unsigned)e2.y, (unsigned)e2.z, (unsigned)e2.w, lane)
+                        : hs_table_item_packed_v<true, SYN ? 4 : HS_RUN_PK>(kd_lo, kd_hi, nK, nKp, sub, nG, s0, s1,
+                                                                           (unsigned)e2.y, (unsigned)e2.z, (unsigned)e2.w, lane);
+            } else {
+              const int tile = __builtin_amdgcn_readfirstlane(e1.x);
+              const unsigned o8 = 8u * (unsigned)s0;
+              acc = pre ? hs_table_item_v<false>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e2.y + o8,
+                                                 (unsigned)e2.z + o8, (unsigned)e2.w + o8, lane)
+                        : hs_table_item_v<true>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e2.y + o8,
+                                                (unsigned)e2.z + o8, (unsigned)e2.w + o8, lane);
+            }
+            part_t[ix * 64 + lane] = acc;
+          } else if (RT > 0 && is_tab) {
             int t = 0;
             while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
             const hs_tab& tb = D.tab[t];
@@ -939,16 +1282,19 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       }
       HSR_STAMP(4);
       HSR_WSTAMP(2);
+      HSR_GSTAMP(0);
       __syncthreads();  // ---------------------------------------------------------------- #3
       HSR_STAMP(5);
+      HSR_GSTAMP(1);
       // ---- the walker's spectra meet in LDS (every thread its column: one wave alone took 1.9 us
       // over it, 16 waves and a barrier 0.9) ------------------------------------------------
-      for (int t = 0; t < D.ntab; ++t) {
-        const hs_tab& tb = D.tab[t];
-        for (int k = tid; k < tb.nK; k += T) {
-          const int tile = k >> 6, ln = k & 63;
-          const double* pp = sm + H.o_part_t + (tb.item0 + tile) * 64 + ln;
-          const int stride = tb.tiles * 64, chunks = HS_CHUNKS(tb.chunks);
+      {
+        typedef int hss_i4 __attribute__((ext_vector_type(4)));
+        const hss_i4* st = reinterpret_cast<const hss_i4*>(sm + R.o_sum);
+        for (int k = tid; k < R.sum_cols; k += T) {
+          const hss_i4 d = st[k];
+          const double* pp = sm + d.x;
+          const int stride = d.y, chunks = d.z;
           double sum = 0.0;
           for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
             double v[8];
@@ -956,10 +1302,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
             sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
           }
-          const int ko = reinterpret_cast<const int*>(sm + R.o_trail)[HS_RUN_TRAIL * HS_MAX_TAB +
-                                                                        tb.spec_off + k];  // (sorted columns)
-          sum *= sm[H.o_scale + tb.spec_off + ko];
-          spec[tb.spec_off + ko] = sum;
+          sum *= sm[H.o_scale + d.w];
+          spec[d.w] = sum;
         }
       }
       if (has_syn) {
@@ -978,7 +1322,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           spec[H.syn_spec_off + amap[a]] = sum;
         }
       }
+      HSR_GSTAMP(2);
       __syncthreads();  // ---------------------------------------------------------------- #4
+      HSR_GSTAMP(3);
       if (K > 1) {
         // the K workgroups of this walker meet: partial spectra out (write-through), one ticket
         // each; whoever draws the last one sums all K partials in the order of their index (the
@@ -1016,41 +1362,50 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         double acc = 0.0;
         int nviol = 0, nul = 0;
         const double* lik = sm + H.o_lik;
+        // (the components' places in spec and their factors: from LDS, all of them asked for at
+        // once -- every component is produced inside the launch, nh_half_step_run_create; a
+        // component the model does not have reads a word that is always 0.0, with the factor 0:
+        // eight reads in flight and one wait instead of a branch and a round trip per component)
+        int coff[NH_MAX_COMP];
+        double cscl[NH_MAX_COMP];
+#pragma unroll
+        for (int q = 0; q < NH_MAX_COMP; ++q) {
+          coff[q] = (int)sm[R.o_cmp + 2 * q];
+          cscl[q] = sm[R.o_cmp + 2 * q + 1];
+        }
         for (int k = lane; k < nE; k += 64) {
+          double sv[NH_MAX_COMP];
+#pragma unroll
+          for (int q = 0; q < NH_MAX_COMP; ++q) sv[q] = sm[coff[q] + (coff[q] == R.o_cmp + 2 * NH_MAX_COMP ? 0 : k)];
+          // (the data's columns: every one asked for before the first is used)
+          const double cv = lik[k], f = lik[nE + k], wlo = lik[2 * nE + k], whi = lik[3 * nE + k];
+          const bool isul = lik[4 * nE + k] != 0.0;
           double m = 0.0;
-          for (int q = 0; q < D.ncomp; ++q) {
-            const double v = D.comp[q].off >= 0 ? spec[D.comp[q].off + k]
-                                                : D.comp[q].ptr[(long long)j * D.comp[q].ld + k];
-            m += D.comp[q].scale * v;
-          }
+#pragma unroll
+          for (int q = 0; q < NH_MAX_COMP; ++q) m = fma(cscl[q], sv[q], m);
           if (D.nblob) sm[D.o_mrow + k] = m;
-          const double mc = m * lik[k];
-          const double f = lik[nE + k];
-          if (lik[4 * nE + k] != 0.0) {
-            nul += 1;
-            nviol += (mc > f) ? 1 : 0;
-          } else {
-            const double d = mc - f;
-            const double sgw = (d > 0.0) ? lik[3 * nE + k] : lik[2 * nE + k];
-            acc = fma(d * d, sgw, acc);
-          }
+          const double mc = m * cv;
+          const double d = mc - f;
+          const double term = (d * d) * ((d > 0.0) ? whi : wlo);
+          nul += isul ? 1 : 0;
+          nviol += (isul && mc > f) ? 1 : 0;
+          acc += isul ? 0.0 : term;
         }
         int cnt = nviol | (nul << 16);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const double a2 = __shfl_down(acc, off, 64);
-          const int c2 = __shfl_down(cnt, off, 64);
-          acc += a2;
-          cnt += c2;
-        }
-        if (lane == 0) {
+        hs_wave_sum_dpp(acc, cnt);  // (the totals: in lane 63)
+        // (... read out as scalars: every lane carries on with the same numbers, no second trip
+        // through the lanes to hand lane 0's result round)
+        acc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(acc), 63),
+                               __builtin_amdgcn_readlane(__double2loint(acc), 63));
+        cnt = __builtin_amdgcn_readlane(cnt, 63);
+        {
           nviol = cnt & 0xffff;
           nul = cnt >> 16;
           // quirk kept from core.py:89-92: cl is indexed by the violation count
           if (nul > 0) acc += (double)nviol * (nviol <= nE ? sm[R.o_lcl + nviol] : hsr_log(1.0 - H.cl[nviol]));
           if (has_prior) acc = isinf(prior) ? prior : acc + prior;  // core.py:115-119
         }
-        acc = __shfl(acc, 0, 64);
+        HSR_GSTAMP(5);
         // emcee RedBlueMove.propose for this walker
         const double oldlp = accs[2];
         const double dd = lg[3] + acc - oldlp;
@@ -1077,6 +1432,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               if (pr < R.nrank) hs_st_sys(R.peer[pr] + roff, gv);
           }
         }
+        HSR_GSTAMP(6);
         if (R.dbg && lane == 0 && blockIdx.x < 256 && it < 64)
           R.dbg[((long long)blockIdx.x * 64 + it) * 8 + 7] = (long long)wall_clock64();
         // chain history: this walker's entry of the step's row (nobody else writes it)
@@ -1335,6 +1691,33 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     R.o_ge[g] = off;
     if (H.F.broken) off += H.nG[g];
   }
+  // ---- the table grids' 1 / lx in LDS, and the weights' units (below)
+  for (int g = 0; g < NH_MAX_GRIDS; ++g) R.o_il[g] = -1;
+  R.o_ut = -1;
+  if (grids_in_lds && nh_env_int("NH_RUN_UT", 1) != 0) {
+    int nunits = 0;
+    for (int g = 0; g < H.ngrids; ++g) nunits += (H.nG[g] + 63) / 64;
+    off += off & 1;  // (16-byte aligned: a unit's descriptor is read as four ds_read_b128)
+    R.o_ut = off; off += nunits * (HSU_N / 2);
+  }
+  {
+    int ncols = 0;
+    for (int t = 0; t < H.ntab; ++t) ncols += H.C.tab[t].nK;
+    R.sum_cols = ncols;
+    off += off & 1;
+    R.o_sum = off; off += 2 * ncols;
+    R.o_cmp = off; off += 2 * NH_MAX_COMP + 2;
+  }
+  R.o_it = -1;
+  if (!rt && H.C.nT > 0) {  // (the register-resident instance keeps its rows per wave: no table)
+    off += off & 1;
+    R.o_it = off; off += H.C.nT * (HSI_N / 2);
+  }
+  if (nh_env_int("NH_RUN_IL", 1) != 0)
+    for (int g = 0; g < H.ngrids; ++g)
+      if (H.o_dp[g] >= 0 && (size_t)(off + H.nG[g]) * sizeof(double) <= 150 * 1024) {
+        R.o_il[g] = off; off += H.nG[g];
+      }
   R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * HS_RUN_PKW;
   R.o_small1 = off; off += HS_O_T64;
   R.o_olds = off; off += 128;
