@@ -131,6 +131,7 @@ struct hs_run {
   // barrier 3 -- one or a few waves, everybody else waiting -- took these out of the
   // kernel-argument segment one dependent scalar load at a time (four round trips per component)
   int o_sum, o_cmp;
+  int o_pci;  // LDS: per prior term the proposed coordinate it reads, or -1 (ints)
   int sum_cols;  // columns of all the tables together (the sum phase's loop bound)
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
@@ -153,6 +154,7 @@ struct hs_run {
   const double* s2_dev;  // device: the table's (P + 1) x 6 doubles, then the grid's nG values of the above
   hs_syn2_par s2;
   double s2_z0, s2_invd;  // z = s2_z0 - ln(q) s2_invd: where node 0 sits on the comb below T_top
+  double s2_r746;         // (T_top - ln 746) s2_invd - s2_z0: the first live node is ceil(ln(q) s2_invd + this)
   double s2_lnw0;         // ln |n| + ln(E / eV) above this: the weight gamma n scale is not 0 in double
 };
 
@@ -309,6 +311,17 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     const int npri = (int)(sizeof(nh_prior_pack) / sizeof(double));
     const double* psrc = reinterpret_cast<const double*>(&D.pri);
     for (int t = tid; t < npri; t += T) sm[H.o_pri + t] = psrc[t];
+    // which proposed coordinate a prior term reads (-1: none of this walker's -- a device array of
+    // its own): decided once per launch, it was two 64-bit divisions per term and slice
+    for (int t = tid; t < NH_MAX_PRIOR; t += T) {
+      int ci = -1;
+      if (t < D.pri.n && D.pri.t[t].x.base) {
+        const long long d = D.pri.t[t].x.base - H.qT;
+        if (d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && D.pri.t[t].x.stride == 1)
+          ci = (int)(d / H.nloc);
+      }
+      reinterpret_cast<int*>(sm + R.o_pci)[t] = ci;
+    }
     if (has_syn) {
       for (int k = tid; k < H.syn_nE; k += T) sm[H.o_synE + k] = H.syn_E[k];
       const int nGs = H.F.syn_nG;
@@ -377,6 +390,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       const nh_lazy& z = P.cols[tid % NH_MAX_LAZY];
       double* o = sm + R.o_pk + tid * HS_RUN_PKW;
       o[6] = log(fabs(z.a));
+      {  // (which proposed coordinate the column reads: -1 a constant)
+        const unsigned word = H.F.pkd[tid >> 2];
+        const int b = (int)((word >> (8 * (tid & 3))) & 0xFFu);
+        reinterpret_cast<int*>(o + 7)[0] = b != 0xFF ? b : -1;
+        reinterpret_cast<int*>(o + 7)[1] = P.ncols > (int)(tid % NH_MAX_LAZY) ? 1 : 0;
+      }
       o[0] = z.a;
       o[1] = z.b;
       o[2] = z.c;
@@ -591,6 +610,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       int* hi = reinterpret_cast<int*>(qs + HS_O_INT);
       double* olds = sm + R.o_olds + par * 64;
       HSR_STAMP(0);
+      double pval = 0.0;  // (wave 0) this lane's parameter-pack column, once evaluated ...
+      int pcol = -1;      // ... and which one it is (-1: none)
       // ---- A. wave 0: the two records, the proposal, the parameter packs ---------------------
       if (wv == 0) {
         const int g = H.lo + j;
@@ -606,6 +627,20 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         // lanes 0 .. GRn-1: my own record in row tl (the state after the previous step);
         // lanes 32 .. 32+GRn-1: the partner's -- row tl for the first half of a step, row
         // tl + 1 for the second (the partner has moved in the first half of THIS step)
+        // this lane's parameter-pack column (walker-independent: read BEFORE the wait for the
+        // records, so that what follows their arrival is shuffles and arithmetic only -- the byte
+        // of pkd was a vector load from the kernel-argument segment behind the records, the
+        // descriptor three dependent LDS trips)
+        double pk_a = 0.0, pk_b = 0.0, pk_c = 0.0, pk_lna = 0.0;
+        int pk_tf = 0, pk_nc = 0, pkd = -1;
+        if (lane < npk8) {
+          const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
+          pk_a = o[0]; pk_b = o[1]; pk_c = o[2];
+          pk_tf = reinterpret_cast<const int*>(o + 3)[0];
+          pk_nc = reinterpret_cast<const int*>(o + 3)[1];
+          pk_lna = o[6];
+          pkd = reinterpret_cast<const int*>(o + 7)[0];
+        }
         const bool mine = lane < GRn, theirs = lane >= 32 && lane - 32 < GRn;
         const int prow = tl + half;
         const unsigned long long* src =
@@ -662,25 +697,15 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         HSR_STAMP(1);
         // the packs: thread t < 8 npacks evaluates column t % 8 of pack t / 8 from ONE proposed
         // coordinate (which one is walker-independent: a byte of pkd), taken by a shuffle
-        int pkd = -1;
-        if (lane < npk8) {
-          const unsigned word = H.F.pkd[lane >> 2];
-          const int b = (int)((word >> (8 * (lane & 3))) & 0xFFu);
-          if (b != 0xFF) pkd = b;
-        }
         const double qv = __shfl(q, pkd < 0 ? 0 : pkd, 64);
         if (lane < npk8) {
-          const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
-          const double za = o[0], zb = o[1], zc = o[2];
-          const int ztf = reinterpret_cast<const int*>(o + 3)[0];
-          const int nc = reinterpret_cast<const int*>(o + 3)[1];
-          const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
-          double* out = reinterpret_cast<double* const*>(o + 5)[0];
+          const double za = pk_a, zb = pk_b, zc = pk_c;
+          const int ztf = pk_tf, nc = pk_nc;
           const int col = lane % NH_MAX_LAZY;
           if (col < nc) {
             double val = za;
             if (pkd >= 0) val = hsr_lazy_apply(za, zb, zc, ztf, qv);
-            out[(long long)j * ld + col] = val;
+
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
               // (ln of e_0, e_cutoff, e_break for the weights; ln |amplitude| and its sign for the
@@ -694,9 +719,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                 double lv;
                 const bool easy = pkd < 0 || ztf == NH_TF_POW10;
                 if (pkd < 0) {
-                  lv = o[6];
+                  lv = pk_lna;
                 } else if (ztf == NH_TF_POW10) {
-                  lv = hs_ln_pow10(o[6], zb, zc, qv);
+                  lv = hs_ln_pow10(pk_lna, zb, zc, qv);
                 } else {
                   lv = 0.0;
                 }
@@ -713,6 +738,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                 }
               }
             }
+            pval = val;
+            pcol = col;
           }
         }
       }
@@ -720,6 +747,14 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       __syncthreads();  // ---------------------------------------------------------------- #1
       HSR_STAMP(2);
       if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
+      if (wv == 0 && pcol >= 0) {
+        // the packs' rows in HBM, for whoever reads them outside this launch: behind the barrier
+        // everybody else was waiting at
+        const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
+        const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
+        double* out = reinterpret_cast<double* const*>(o + 5)[0];
+        out[(long long)j * ld + pcol] = pval;
+      }
       HSR_FSTAMP(0);
       if (K > 1) {  // the work items of the walker's other workgroups: their slots count as 0
         for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
@@ -741,10 +776,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           const long long zstride = pt.x.stride;
           double v = pt.x.a;
           if (zbase) {
-            const long long d = zbase - H.qT;
             // a term on one of this walker's proposed coordinates: taken from LDS
-            const bool mine = d >= 0 && d < (long long)H.ndim * H.nloc && d % H.nloc == 0 && zstride == 1;
-            const double raw = mine ? qs[d / H.nloc] : zbase[(long long)j * zstride];
+            const int ci = reinterpret_cast<const int*>(sm + R.o_pci)[lane];
+            const double raw = ci >= 0 ? qs[ci] : zbase[(long long)j * zstride];
             v = hsr_lazy_apply(pt.x.a, pt.x.b, pt.x.c, pt.x.tf, raw);
           }
           const double p0 = pt.p0, p1 = pt.p1;
@@ -764,7 +798,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           // (the accept's z term: off the slice's tail.  ndim - 1 through the slice's opaque thread
           // index: as a loop invariant the converted double was hoisted out of the slice loop and
           // spilled -- the kernel's only scratch access)
-          lg[3] = (double)(ndim - 1 + (tid - tid0)) * hsr_log(accs[0]);
+          int nd1 = ndim - 1;
+          asm volatile("" : "+s"(nd1));  // (opaque per slice: the conversion below stays here)
+          lg[3] = (double)nd1 * hsr_log(accs[0]);
         }
       }
       // ---- particle weights on every grid (-> LDS); the synchrotron liveness search ----------
@@ -798,8 +834,10 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             // the logarithm the items need anyway -- and the comparison itself, as the search made
             // it, settles the last place (two or three reads instead of ten dependent ones)
             lv_lnq = hsr_log(lv_q);
-            const double z = fma(-lv_lnq, R.s2_invd, R.s2_z0);  // node i at z + i steps below T_top
-            const double r = (HS_S2_TTOP - 6.61472560020376) * R.s2_invd - z;  // (ln 746)
+            // (node i sits z + i comb steps below T_top, z = s2_z0 - ln q / (2 lx); s2_r746 = (T_top - ln 746)
+            // / (2 lx) - s2_z0, formed on the host: as an expression here it is a loop invariant the
+            // compiler computes at the head of every slice and spills)
+            const double r = fma(lv_lnq, R.s2_invd, R.s2_r746);
             if (r == r) {
               int c = r > 0.0 ? (r < (double)nG ? (int)r : nG) : 0;
               while (c > 0 && lv_q * ig2[c - 1] <= 746.0) --c;
@@ -1707,6 +1745,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     off += off & 1;
     R.o_sum = off; off += 2 * ncols;
     R.o_cmp = off; off += 2 * NH_MAX_COMP + 2;
+    R.o_pci = off; off += (NH_MAX_PRIOR + 1) / 2;
   }
   R.o_it = -1;
   if (!rt && H.C.nT > 0) {  // (the register-resident instance keeps its rows per wave: no table)
@@ -1774,6 +1813,8 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
       // w = gamma n scale = (E / mec2[eV]) n scale != 0  <=>  ln n + ln E > ln(2^-1075) + ln(mec2 / scale)
       R.s2_lnw0 = (double)(-1075.0L * logl(2.0L) + logl((long double)NH_MEC2_EV / (long double)H.scale[H.syn_grid]));
       R.s2_z0 = (double)(((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
+      R.s2_r746 = (double)(((long double)HS_S2_TTOP - logl(746.0L)) / (2.0L * lx) -
+                           ((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
       off += off & 1;  // (16-byte aligned: the pieces are read as ds_read_b128)
       int o2 = off;
       R.o_s2tab = o2; o2 += (P + 1) * HS_S2_STRIDE;

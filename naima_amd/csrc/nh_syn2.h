@@ -86,6 +86,17 @@ __device__ __forceinline__ double hs_exp128(double v, unsigned t128) {
   return ldexp(hs_s2_ld(t128 + 8u * (unsigned)(k & 127)) * p, k >> 7);
 }
 
+// floor(x / d) for 0 <= x < 2^20, 1 <= d < 2^12 with d's reciprocal given in single precision: a
+// multiplication, a conversion and one correction either way instead of the ~25 instructions of
+// an integer division (a work item starts with two of them per lane)
+__device__ __forceinline__ int hs_div_small(int x, int d, float rd) {
+  int q = (int)((float)x * rd);
+  const int r = x - q * d;
+  q += r >= d ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+
 // One work item: 64 (live photon energy, chunk) pairs.  Per live energy a (compacted, as in
 // hs_syn_item): ai0[a] its first live node, Zs[a] the comb index of node 0, and in sq (nEs
 // apart) cbrt(q) | Lambda ln(q) / 3 | f / m | CS1 (signed by the amplitude).
@@ -97,13 +108,14 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
                                              const double* sq, unsigned a_lw, unsigned a_ig,
                                              unsigned a_tab, unsigned a_t128, double* part_s) {
   const int vt = ix * 64 + lane;
-  const int a = vt % nA, ch = vt / nA;
+  const int ch = hs_div_small(vt, nA, __builtin_amdgcn_rcpf((float)nA));  // (nA, Cd: wave-uniform)
+  const int a = vt - ch * nA;
   if (ch >= Cd) return;
   const int lm = S.lm, m = 1 << lm;
   const int Z = Zs[a];
   const int k0 = ((Z + ai0[a]) >> lm) << lm;  // the range starts on a piece boundary
   const int kend = Z + S.nG - 1;              // the grid's last node
-  int per = (kend - k0 + Cd) / Cd;            // nodes k0 .. kend over Cd chunks ...
+  int per = hs_div_small(kend - k0 + Cd, Cd, __builtin_amdgcn_rcpf((float)Cd));  // nodes k0 .. kend over Cd chunks ...
   per = ((per + m - 1) >> lm) << lm;          // ... of whole pieces
   const int kb = k0 + ch * per;
   double acc = 0.0;
