@@ -679,6 +679,10 @@ int nh_half_step_run_syn_info(const nh_halfstep_run* run, int* mode, int* nodes_
  * model whose items keep their rows of {K, dlnK} in vector registers for the whole launch
  * (workgroups of 512 threads; an emission table does not depend on the walker), `nodes_max` the
  * rows per lane that instance can hold; 0 = streamed from the L2s every half-step. */
+/* workgroups per walker of the resident loop's launches (the plan's split) and whether they
+ * divide the grid's ROWS between them (table-only models: core.py:450-457's one evaluation per
+ * walker on two compute units, each with half of radiative.py:1495-1536's proton grid) */
+int nh_half_step_run_split_info(const nh_halfstep_run* run, int* split, int* rows);
 int nh_half_step_run_table_info(const nh_halfstep_run* run, int* in_registers, int* nodes_max);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
  * (workgroup, slice handled): start | records in | packs done | weights done | own items

@@ -1402,6 +1402,18 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     if (work >= nh_env_int("NH_HS_SPLIT_MIN_WORK", 1 << 20))
       while (split * 2 <= kmax && (long long)d->nloc * split * 2 <= ncu) split *= 2;
   }
+  // ---- a table-only model with ONE table, at most half as many walkers per launch as
+  // CUs (BASELINE's PionDecay fit at one GPU's share of its 2048 walkers): two workgroups per
+  // walker that split the grid's ROWS -- each forms the weights of its half, reduces its half of
+  // the table (from registers: half the rows fit a lane's) and of the single-row reductions, and
+  // the second hands its partial spectrum to the first (the resident loop: hs_run.rowsplit; the
+  // per-launch kernel runs the same plan with its items interleaved, as any split launch)
+  bool rowsplit = false;
+  if (split == 1 && d->syn.grid < 0 && d->ntab == 1 && kmax >= 2 &&
+      (long long)d->nloc * 2 <= ncu && nh_env_int("NH_HS_ROWSPLIT", 1) != 0) {
+    split = 2;
+    rowsplit = true;
+  }
   // ---- a table-only model whose items' rows fit a lane's registers: workgroups of 512 threads
   // (256 vector registers per lane), for the resident loop's register-resident items (nh_hs.h:
   // hs_rt_item; k_half_step_run<false, ., false, RT>).  The rows an item walks start at the first
@@ -1627,6 +1639,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
   P->threads = threads;
   P->blocks = d->nloc;
   P->split = split;
+  P->rowsplit = rowsplit ? 1 : 0;
   P->rt = rt_plan ? 1 : 0;
   P->dev = nullptr;
   P->words = nullptr;

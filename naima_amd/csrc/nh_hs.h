@@ -146,6 +146,7 @@ struct nh_halfstep_plan {
   size_t lds_core;  // ... without k_half_step's own log-domain synchrotron block (the last thing in it)
   int threads, blocks, split;  // split = K workgroups per walker (gridDim.y)
   int rt;  // the workgroup size was chosen for register-resident table items (hs_rt_item)
+  int rowsplit;  // split == 2 was chosen for a table-only model whose two workgroups halve the ROWS
   long long* dbg;
 };
 

@@ -66,10 +66,12 @@ enum { HSU_G = 0, HSU_I0, HSU_NG, HSU_W, HSU_D, HSU_DP, HSU_IL, HSU_TH, HSU_LX, 
        HSU_S2, HSU_S2LW, HSU_SC_LO, HSU_SC_HI, HSU_N };
 static_assert(HSU_N == 16, "a unit's descriptor is four 16-byte reads");
 
-// the table items' descriptors (hs_run.o_it): ints per item
-enum { HSI_KD_LO = 0, HSI_KD_HI, HSI_NK, HSI_NG, HSI_TILE, HSI_S0, HSI_S1, HSI_S0F, HSI_S1F, HSI_AW,
-       HSI_AD, HSI_AL, HSI_FLAGS, HSI_SUB, HSI_NKP, HSI_T, HSI_N };
-static_assert(HSI_N == 16, "an item's descriptor is four 16-byte reads");
+// the table items' descriptors (hs_run.o_it): HS_MAX_TAB x 16 ints per TABLE (HST_*), then 4 ints
+// per ITEM { table | tile << 4, first row, end row, the same two ignoring the leading zero rows (16
+// bits each) }
+enum { HST_KD_LO = 0, HST_KD_HI, HST_NK, HST_NG, HST_AW, HST_AD, HST_AL, HST_FLAGS, HST_SUB, HST_NKP,
+       HST_N = 16 };
+#define HSI_N 4
 
 struct hs_run {
   unsigned long long* ring;  // [HS_RUN_MAX_STEPS + 1][N][gr] granules
@@ -132,6 +134,14 @@ struct hs_run {
   // kernel-argument segment one dependent scalar load at a time (four round trips per component)
   int o_sum, o_cmp;
   int o_pci;  // LDS: per prior term the proposed coordinate it reads, or -1 (ints)
+  // K workgroups of a table-only walker split the grid's ROWS (nh_halfstep.hip: the plan's
+  // rowsplit): workgroup `part` owns the nodes [b_part, b_part+1] -- the boundaries sit between
+  // two of the table's chunks -- forms the weights there, reduces its chunks and its part of the
+  // single-row reductions, and hands its partial sums to workgroup 0 of the walker
+  int rowsplit;
+  int tcompact;  // K > 1: a table item's partial sums in the slot of its group (hs_run_create)
+  int o_rs;   // LDS: this workgroup's nodes per grid and its units (rowsplit)
+  int nxmax;  // doubles a workgroup hands over at most (spectrum + single-row reductions)
   int sum_cols;  // columns of all the tables together (the sum phase's loop bound)
   int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
@@ -446,11 +456,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
       const int* perm = kds ? hs_tab_trailer(kds, H.nG[tb.grid], tb.nK) + HS_TRAIL_TILES : nullptr;
       for (int k = tid; k < tb.nK; k += T) {
-        int* d = st + 4 * (c0 + k);
-        d[0] = H.o_part_t + (tb.item0 + (k >> 6)) * 64 + (k & 63);
-        d[1] = tb.tiles * 64;
-        d[2] = HS_CHUNKS(tb.chunks);
-        d[3] = tb.spec_off + (perm ? perm[k] : k);  // (sorted columns: back in the spectrum's order)
+        int* d = st + 2 * (c0 + k);  // { first partial sum | stride << 16, chunks | where it goes << 8 }
+        d[0] = (H.o_part_t + (tb.item0 + (k >> 6)) * 64 + (k & 63)) | ((tb.tiles * 64) << 16);
+        // (K > 1, compact slots: { the column's first item | the tile's lane << 10 | items per chunk << 16 })
+        if (K > 1 && R.tcompact) d[0] = (tb.item0 + (k >> 6)) | ((k & 63) << 10) | (tb.tiles << 16);
+        d[1] = HS_CHUNKS(tb.chunks) | ((tb.spec_off + (perm ? perm[k] : k)) << 8);  // (sorted columns: back in order)
       }
       c0 += tb.nK;
     }
@@ -462,7 +472,26 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     if (tid == 0) cm[2 * NH_MAX_COMP] = 0.0;  // (what a component the model does not have reads)
   }
   if (R.o_it >= 0) {
-    int* itab = reinterpret_cast<int*>(sm + R.o_it);
+    int* ttab = reinterpret_cast<int*>(sm + R.o_it);
+    int* itab = ttab + HS_MAX_TAB * HST_N;
+    for (int t = tid; t < D.ntab; t += T) {
+      const hs_tab& tb = D.tab[t];
+      const int tg = tb.grid;
+      const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
+      const double* kd = kds ? kds : tb.KD;
+      const bool pre = tb.nonneg != 0;
+      int* d = ttab + t * HST_N;
+      d[HST_KD_LO] = (int)(unsigned)(unsigned long long)kd;
+      d[HST_KD_HI] = (int)(unsigned)((unsigned long long)kd >> 32);
+      d[HST_NK] = tb.nK;
+      d[HST_NG] = H.nG[tg];
+      d[HST_AW] = (int)hs_lds_addr(sm + H.o_w[tg]);
+      d[HST_AD] = (int)hs_lds_addr(sm + (pre ? H.o_dp[tg] : H.o_d[tg]));
+      d[HST_AL] = (int)hs_lds_addr(sm + (pre ? H.o_th[tg] : H.o_lx[tg]));
+      d[HST_FLAGS] = tg | (pre ? 16 : 0);
+      d[HST_SUB] = tb.sub;
+      d[HST_NKP] = tb.nKp;
+    }
     for (int ix = tid; ix < D.nT; ix += T) {
       int t = 0;
       while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
@@ -471,7 +500,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       const int tile = loc % tb.tiles, chunk = loc / tb.tiles;
       const int tg = tb.grid, nG = H.nG[tg];
       const double* kds = t == 0 ? R.kds[0] : t == 1 ? R.kds[1] : t == 2 ? R.kds[2] : R.kds[3];
-      const double* kd = kds ? kds : tb.KD;
       int s0f, s1f;
       hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0f, s1f);
       // (rows below the tile's first non-zero one contribute exact zeros: not walked -- unless the
@@ -484,24 +512,42 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         s0 = r0 + chunk * per;
         s1 = min(nG - 1, s0 + per);
       }
-      const bool pre = tb.nonneg != 0;
       int* d = itab + ix * HSI_N;
-      d[HSI_KD_LO] = (int)(unsigned)(unsigned long long)kd;
-      d[HSI_KD_HI] = (int)(unsigned)((unsigned long long)kd >> 32);
-      d[HSI_NK] = tb.nK;
-      d[HSI_NG] = nG;
-      d[HSI_TILE] = tile;
-      d[HSI_S0] = s0;
-      d[HSI_S1] = s1;
-      d[HSI_S0F] = s0f;
-      d[HSI_S1F] = s1f;
-      d[HSI_AW] = (int)hs_lds_addr(sm + H.o_w[tg]);
-      d[HSI_AD] = (int)hs_lds_addr(sm + (pre ? H.o_dp[tg] : H.o_d[tg]));
-      d[HSI_AL] = (int)hs_lds_addr(sm + (pre ? H.o_th[tg] : H.o_lx[tg]));
-      d[HSI_FLAGS] = tg | (pre ? 16 : 0);
-      d[HSI_SUB] = tb.sub;
-      d[HSI_NKP] = tb.nKp;
-      d[HSI_T] = t;
+      d[0] = t | (tile << 4);
+      d[1] = s0;
+      d[2] = s1;
+      d[3] = s0f | (s1f << 16);
+    }
+  }
+  if (R.rowsplit) {
+    // This workgroup's nodes of every grid, rs[2 g], rs[2 g + 1] = first and last, and the units
+    // that hold them: rs[8] of them, listed from rs[9] on.  The table's grid is cut where a group
+    // of its chunks ends (one table: its chunks divide the rows from the first non-zero one on,
+    // K equal groups); a grid that only a single-row reduction reads, in K runs of whole units.
+    if (tid == 0) {
+      const hs_tab& tb = D.tab[0];
+      int* rs = reinterpret_cast<int*>(sm + R.o_rs);
+      int nmy = 0, u0 = 0;
+      for (int g = 0; g < H.ngrids; ++g) {
+        const int nG = H.nG[g], nu = (nG + 63) >> 6;
+        int lo, hi2;
+        if (g == tb.grid) {
+          const int nch = HS_CHUNKS(tb.chunks);
+          const int r0 = R.kds[0] ? hs_tab_trailer(R.kds[0], nG, tb.nK)[0] : 0;
+          const int per = (max(nG - 1 - r0, 0) + nch - 1) / nch;
+          const int cpp = nch / K;  // chunks per workgroup
+          lo = part == 0 ? 0 : min(nG - 1, r0 + part * cpp * per);
+          hi2 = part == K - 1 ? nG - 1 : min(nG - 1, r0 + (part + 1) * cpp * per);
+        } else {
+          lo = min(nG - 1, ((nu * part) / K) * 64);
+          hi2 = part == K - 1 ? nG - 1 : min(nG - 1, ((nu * (part + 1)) / K) * 64);
+        }
+        rs[2 * g] = lo;
+        rs[2 * g + 1] = hi2;
+        for (int u = lo >> 6; u <= hi2 >> 6; ++u) rs[9 + nmy++] = u0 + u;
+        u0 += nu;
+      }
+      rs[8] = nmy;
     }
   }
   // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or
@@ -550,7 +596,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     const int total = D.nT;
     int item = wv;
     bool have = item < total;
-    if (K > 1) {
+    if (K > 1 && R.rowsplit) {  // (this part's chunks: one after the other; K is a power of two)
+      const int per_part = total >> __builtin_ctz(K);
+      have = item < per_part;
+      item += part * per_part;
+    } else if (K > 1) {
       have = item * K < total;
       item = item * K + ((part + item) & (K - 1));
       have = have && item < total;
@@ -757,7 +807,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       }
       HSR_FSTAMP(0);
       if (K > 1) {  // the work items of the walker's other workgroups: their slots count as 0
-        for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
+        if (!R.tcompact)  // (compact slots: a slot is read only where this workgroup wrote it)
+          for (int t = tid; t < D.nT * 64; t += T) sm[H.o_part_t + t] = 0.0;
         if (has_syn)
           for (int t = tid; t < D.syn_cdmax * H.syn_nE; t += T) sm[H.o_part_s + t] = 0.0;
       }
@@ -924,8 +975,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const double lnA = (SYN && S2) ? qs[HS_O_LNA] : 0.0;
         const unsigned t64 = hs_lds_addr(sm + HS_O_T64);
         int fl = 0;  // (wave-uniform) grids with a non-zero weight | << 8: with one that is not finite
-        for (int u = worker ? rank : nunits; u < nunits; u += 2 * nwork) {
-          const bool two = u + nwork < nunits;  // (wave-uniform)
+        // (rows split between the walker's workgroups: the units that hold this one's nodes, listed
+        // when the launch began)
+        const int* ul = reinterpret_cast<const int*>(sm + R.o_rs) + 9;
+        const int u_end = R.rowsplit ? __builtin_amdgcn_readfirstlane(ul[-1]) : nunits;
+        for (int u = worker ? rank : u_end; u < u_end; u += 2 * nwork) {
+          const bool two = u + nwork < u_end;  // (wave-uniform)
           typedef int hsu_i4 __attribute__((ext_vector_type(4)));
           int dq[2][HSU_N];
           double lrq[2], lneq[2], gxq[2], ilq[2];
@@ -933,7 +988,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           bool onq[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            const int uu = (q == 0 || two) ? u + q * nwork : u;  // (no second unit: the first one again, unused)
+            int uu = (q == 0 || two) ? u + q * nwork : u;  // (no second unit: the first one again, unused)
+            if (R.rowsplit) uu = __builtin_amdgcn_readfirstlane(ul[uu]);
             const hsu_i4* dp4 = reinterpret_cast<const hsu_i4*>(ut + uu * HSU_N);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1170,7 +1226,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const double* ds = sm + H.o_d[g];
         const double* lxs = sm + H.o_lx[g];
         double acc = 0.0;
-        for (int sgm = lane; sgm < nG - 1; sgm += 64) {
+        int sg0 = 0, sg1 = nG - 1;
+        if (R.rowsplit) {  // (this workgroup's rows: the walker's first workgroup adds the parts)
+          const int* rs = reinterpret_cast<const int*>(sm + R.o_rs);
+          sg0 = rs[2 * g];
+          sg1 = rs[2 * g + 1];
+        }
+        for (int sgm = sg0 + lane; sgm < sg1; sgm += 64) {
           const double u1 = ws[sgm] * sm[ko + sgm];
           const double u2 = ws[sgm + 1] * sm[ko + sgm + 1];
           const double dl = ds[sgm] + sm[ko + nG + sgm];
@@ -1188,7 +1250,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         double* part_s = sm + H.o_part_s;
         bool rt_first = true;
         for (;;) {
-          int item = 0;
+          int item = 0, pulled = 0;
           if constexpr (RT > 0) {  // ONE item, the wave's own (its rows may sit in registers)
             if (!rt_first) break;
             rt_first = false;
@@ -1197,7 +1259,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             if (lane == 0) item = atomicAdd(&hi[HI_CNT], 1);
             item = __builtin_amdgcn_readfirstlane(item);
           }
-          if (K > 1) {  // this workgroup's share: one of every K items, rotating
+          pulled = item;  // (K > 1: this workgroup's n-th item -- the slot of its partial sums)
+          if (K > 1 && R.rowsplit) {  // this workgroup's share: its part of the rows
+            const int per_part = total >> __builtin_ctz(K);  // (a shift: K is a power of two)
+            if (item >= per_part) break;
+            item += part * per_part;
+          } else if (K > 1) {  // ... one of every K items, rotating
             if (item * K >= total) break;
             item = item * K + ((part + item) & (K - 1));
             if (item >= total) continue;
@@ -1219,42 +1286,45 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             ix = is_tab ? item - nS : item - nT;
           }
           if (R.dbg_skip && (is_tab ? (R.dbg_skip & 2) : (R.dbg_skip & 1))) {
-            if (is_tab) part_t[ix * 64 + lane] = 0.0;
+            if (is_tab) part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = 0.0;
             continue;
           }
           if (is_tab && RT == 0) {  // (the descriptor table is part of every such instance's layout)
             typedef int hsi_i4 __attribute__((ext_vector_type(4)));
-            const hsi_i4* e4 = reinterpret_cast<const hsi_i4*>(reinterpret_cast<const int*>(sm + R.o_it) + ix * HSI_N);
-            const hsi_i4 e0 = e4[0], e1 = e4[1], e2 = e4[2], e3 = e4[3];
-            const int fl = __builtin_amdgcn_readfirstlane(e3.x);
+            const int* ttab = reinterpret_cast<const int*>(sm + R.o_it);
+            const hsi_i4 ei = reinterpret_cast<const hsi_i4*>(ttab + HS_MAX_TAB * HST_N)[ix];
+            const int tt = __builtin_amdgcn_readfirstlane(ei.x);
+            const hsi_i4* e4 = reinterpret_cast<const hsi_i4*>(ttab + (tt & 15) * HST_N);
+            const hsi_i4 e0 = e4[0], e1 = e4[1], e2 = e4[2];
+            const int fl = __builtin_amdgcn_readfirstlane(e1.w);
             const int tg = fl & 15;
             const bool pre = (fl & 16) != 0;
             const bool inf = (nz >> (8 + tg) & 1) != 0;  // (a weight that is not finite: every row)
-            const int s0 = __builtin_amdgcn_readfirstlane(inf ? e1.w : e1.y);
-            const int s1 = __builtin_amdgcn_readfirstlane(inf ? e2.x : e1.z);
+            const int s0 = __builtin_amdgcn_readfirstlane(inf ? (ei.w & 0xffff) : ei.y);
+            const int s1 = __builtin_amdgcn_readfirstlane(inf ? (int)((unsigned)ei.w >> 16) : ei.z);
             const unsigned kd_lo = (unsigned)__builtin_amdgcn_readfirstlane(e0.x);
             const unsigned kd_hi = (unsigned)__builtin_amdgcn_readfirstlane(e0.y);
             const unsigned nK = (unsigned)__builtin_amdgcn_readfirstlane(e0.z);
             const int nG = __builtin_amdgcn_readfirstlane(e0.w);
-            const int sub = __builtin_amdgcn_readfirstlane(e3.y);
+            const int sub = __builtin_amdgcn_readfirstlane(e2.x);
             double acc;
             if (!(nz >> tg & 1) || s0 >= s1) {
               acc = 0.0;
             } else if (sub > 1) {
-              const int nKp = __builtin_amdgcn_readfirstlane(e3.z);
+              const int nKp = __builtin_amdgcn_readfirstlane(e2.y);
               acc = pre ? hs_table_item_packed_v<false, SYN ? 4 : HS_RUN_PK>(kd_lo, kd_hi, nK, nKp, sub, nG, s0, s1,
-                                                                            (unsigned)e2.y, (unsigned)e2.z, (unsigned)e2.w, lane)
+                                                                            (unsigned)e1.x, (unsigned)e1.y, (unsigned)e1.z, lane)
                         : hs_table_item_packed_v<true, SYN ? 4 : HS_RUN_PK>(kd_lo, kd_hi, nK, nKp, sub, nG, s0, s1,
-                                                                           (unsigned)e2.y, (unsigned)e2.z, (unsigned)e2.w, lane);
+                                                                           (unsigned)e1.x, (unsigned)e1.y, (unsigned)e1.z, lane);
             } else {
-              const int tile = __builtin_amdgcn_readfirstlane(e1.x);
+              const int tile = tt >> 4;
               const unsigned o8 = 8u * (unsigned)s0;
-              acc = pre ? hs_table_item_v<false>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e2.y + o8,
-                                                 (unsigned)e2.z + o8, (unsigned)e2.w + o8, lane)
-                        : hs_table_item_v<true>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e2.y + o8,
-                                                (unsigned)e2.z + o8, (unsigned)e2.w + o8, lane);
+              acc = pre ? hs_table_item_v<false>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e1.x + o8,
+                                                 (unsigned)e1.y + o8, (unsigned)e1.z + o8, lane)
+                        : hs_table_item_v<true>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e1.x + o8,
+                                                (unsigned)e1.y + o8, (unsigned)e1.z + o8, lane);
             }
-            part_t[ix * 64 + lane] = acc;
+            part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
           } else if (RT > 0 && is_tab) {
             int t = 0;
             while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
@@ -1300,7 +1370,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             else
               acc = pre ? hs_table_item<false>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds)
                         : hs_table_item<true>(tb, nG, tile, s0, s1, ws, ds, lxs, lane, kds);
-            part_t[ix * 64 + lane] = acc;
+            part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
           } else if (SYN) {
             // (the tile waves' constants were written ahead of barrier 2)
             const int g = H.syn_grid, nEs = H.syn_nE;
@@ -1327,21 +1397,49 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       // ---- the walker's spectra meet in LDS (every thread its column: one wave alone took 1.9 us
       // over it, 16 waves and a barrier 0.9) ------------------------------------------------
       {
-        typedef int hss_i4 __attribute__((ext_vector_type(4)));
-        const hss_i4* st = reinterpret_cast<const hss_i4*>(sm + R.o_sum);
+        typedef int hss_i2 __attribute__((ext_vector_type(2)));
+        const hss_i2* st = reinterpret_cast<const hss_i2*>(sm + R.o_sum);
         for (int k = tid; k < R.sum_cols; k += T) {
-          const hss_i4 d = st[k];
-          const double* pp = sm + d.x;
-          const int stride = d.y, chunks = d.z;
+          const hss_i2 d = st[k];
+          const int chunks = d.y & 0xff, dst = (int)((unsigned)d.y >> 8);
           double sum = 0.0;
-          for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
-            double v[8];
+          if (K > 1 && R.tcompact) {
+            // this workgroup's items only, each in the slot of its group: chunk c of the column is
+            // item ix0 + c tiles -- the g-th of all items (the synchrotron items come first) --
+            // mine if it is my member of its group of K (or lies in my rows), slot = the group
+            const int ix0 = d.x & 0x3ff, ln = (d.x >> 10) & 63, tiles = (int)((unsigned)d.x >> 16);
+            const int lk = __builtin_ctz(K);
+            const int per_part = (D.nT + nS) >> lk;
+            for (int c0 = 0; c0 < chunks; c0 += 8) {
+              double v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
-            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+              for (int q = 0; q < 8; ++q) {
+                const int g = ix0 + (c0 + q) * tiles + nS;
+                int slot;
+                bool mine;
+                if (R.rowsplit) {
+                  slot = g - part * per_part;
+                  mine = slot >= 0 && slot < per_part;
+                } else {
+                  slot = g >> lk;
+                  mine = g == (slot << lk) + ((part + slot) & (K - 1));
+                }
+                v[q] = (c0 + q < chunks && mine) ? sm[H.o_part_t + slot * 64 + ln] : 0.0;
+              }
+              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+          } else {
+            const double* pp = sm + (d.x & 0xffff);
+            const int stride = (int)((unsigned)d.x >> 16);
+            for (int c0 = 0; c0 < chunks; c0 += 8) {  // eight partial sums in flight, fixed order
+              double v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = c0 + q < chunks ? pp[(c0 + q) * stride] : 0.0;
+              sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
           }
-          sum *= sm[H.o_scale + d.w];
-          spec[d.w] = sum;
+          sum *= sm[H.o_scale + dst];
+          spec[dst] = sum;
         }
       }
       if (has_syn) {
@@ -1364,31 +1462,62 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       __syncthreads();  // ---------------------------------------------------------------- #4
       HSR_GSTAMP(3);
       if (K > 1) {
-        // the K workgroups of this walker meet: partial spectra out (write-through), one ticket
-        // each; whoever draws the last one sums all K partials in the order of their index (the
-        // result does not depend on who arrived when) and carries on; the others go to their
-        // next slice.  (sc1 stores, drained, before the ticket; sc1 loads behind it.)
-        const long long cell = (long long)s * H.nloc + j;
-        unsigned long long* xs = reinterpret_cast<unsigned long long*>(R.xspec) +
-                                 (cell * K + part) * D.nspec;
-        for (int k = tid; k < D.nspec; k += T)
-          hs_st_sc1(xs + k, (unsigned long long)__double_as_longlong(spec[k]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-          hi[HI_LIVE] = __hip_atomic_fetch_add(R.tick + cell, 1, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (hi[HI_LIVE] != K - 1) continue;  // (the whole workgroup; HI_LIVE is free by now)
-        const unsigned long long* xa = reinterpret_cast<const unsigned long long*>(R.xspec) +
-                                       cell * K * D.nspec;
-        for (int k = tid; k < D.nspec; k += T) {
-          double sum = 0.0;
-          for (int q = 0; q < K; ++q)
-            sum += __longlong_as_double((long long)hs_ld_sc1(xa + (long long)q * D.nspec + k));
-          spec[k] = sum;
+        // The K workgroups of this walker meet: workgroups 1 .. K - 1 hand their partial spectra to
+        // workgroup 0 as tagged granules { 32 bits of payload | (launch, slice) } -- the records'
+        // own hand-off: no drain, no ticket, no barrier on the sending side; a granule that has
+        // not been written yet, or belongs to another launch, is recognised and never consumed --
+        // and go on to their next slice; workgroup 0 adds the parts in the order of their index
+        // (the result does not depend on who arrived when) and carries on to the likelihood.
+        // (Round 4's meeting -- stores drained, a ticket drawn by an atomic, the last to arrive
+        // reads everything back -- was 2.3 us of cfg2's 17; rows split between the workgroups
+        // hand over the single-row reductions' parts as well.)
+        int jx = j;  // (opaque: the cell's address is formed HERE, not carried -- spilled -- from
+        asm volatile("" : "+s"(jx));  // the head of the slice)
+        const long long cell = (long long)s * H.nloc + jx;
+        const int nsp = D.nspec;
+        const int nx = nsp + (R.rowsplit ? H.nmom : 0);
+        unsigned long long* xg = reinterpret_cast<unsigned long long*>(R.xspec) +
+                                 cell * (long long)(K - 1) * 2 * R.nxmax;
+        const unsigned xtag = (R.seq << 8) | (unsigned)(s + 1);
+        int tk = tid;  // (made opaque here: as the slice's `tid` its 64-bit multiples were formed at
+        asm volatile("" : "+v"(tk));  // the head of the slice and carried -- spilled -- to this point)
+        if (part != 0) {
+          int px = part;  // (opaque too: a launch-wide invariant the compiler parks in a vector register)
+          asm volatile("" : "+s"(px));
+          unsigned long long* dst = xg + (long long)(px - 1) * 2 * R.nxmax;
+          for (int k = tk; k < nx; k += T) {
+            const double v = k < nsp ? spec[k] : sm[D.o_mrow + H.nE + (k - nsp)];
+            hs_st_sc1(dst + 2 * k, hs_granule(v, 0, xtag));
+            hs_st_sc1(dst + 2 * k + 1, hs_granule(v, 1, xtag));
+          }
+          continue;  // (the whole workgroup: on to its next slice)
+        }
+        for (int k = tk; k < nx; k += T) {
+          double sum = k < nsp ? spec[k] : sm[D.o_mrow + H.nE + (k - nsp)];
+          for (int q = 1; q < K; ++q) {
+            const unsigned long long* src = xg + (long long)(q - 1) * 2 * R.nxmax + 2 * k;
+            unsigned long long lo = 0, hiw = 0;
+            int spins = 0;
+            for (;;) {
+              lo = hs_ld_sc1(src);
+              hiw = hs_ld_sc1(src + 1);
+              if ((unsigned)(lo >> 32) == xtag && (unsigned)(hiw >> 32) == xtag) break;
+              if (++spins > R.spin_limit ||
+                  ((spins & 255) == 0 &&
+                   __hip_atomic_load(R.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(R.status, HS_RUN_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[HI_TICK] = HS_RUN_ERR_TIMEOUT;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            sum += __hiloint2double((int)(unsigned)hiw, (int)(unsigned)lo);
+          }
+          if (k < nsp) spec[k] = sum;
+          else sm[D.o_mrow + H.nE + (k - nsp)] = sum;
         }
         __syncthreads();
+        if (hi[HI_TICK] != 0) return;  // (a part never came: the launch gives up, as for a record)
       }
       HSR_STAMP(6);
       // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
@@ -1731,37 +1860,78 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   }
   // ---- the table grids' 1 / lx in LDS, and the weights' units (below)
   for (int g = 0; g < NH_MAX_GRIDS; ++g) R.o_il[g] = -1;
+  R.order = nh_env_int("NH_RUN_ORDER", 2);
+  R.rebalance = nh_env_int("NH_RUN_REBALANCE", H.syn_grid < 0 ? 1 : 0);
+  const bool units_tab = grids_in_lds && nh_env_int("NH_RUN_UT", 1) != 0;
+  // (the plan chose two workgroups per walker for a table-only model with one table: they halve
+  // the grids' rows when the units' table is there -- the grids' nodes in LDS -- the chunks divide
+  // the walked rows and come in a whole number per workgroup; else they interleave the items)
+  R.rowsplit = (P->rowsplit && P->split >= 2 && units_tab && R.rebalance && H.ntab == 1 &&
+                HS_CHUNKS(H.C.tab[0].chunks) % P->split == 0 && H.C.nT % P->split == 0 &&
+                nh_env_int("NH_RUN_ROWSPLIT", 1) != 0) ? 1 : 0;
+  // K > 1 workgroups per walker: a workgroup computes one work item of every K, and keeps its
+  // table items' partial sums in the slot of the GROUP (its n-th item: slot n) -- a K-th of the
+  // plan's block of them, which k_half_step fills in full; what that frees (54 KB at four
+  // workgroups per walker) is the first place the loop's own arrays go
+  // (from four workgroups per walker on: with two, clearing the whole block every slice and
+  // summing it blindly measured faster than deciding per chunk whose it is -- cfg5 / 256 10.9
+  // against 10.3 M walker-steps/s, cfg3 / 256 7.12 against 6.94; cfg3 / 128, four per walker: 3.95
+  // against 4.07 the other way, and its log-domain synchrotron table fits LDS again)
+  R.tcompact = (P->split >= nh_env_int("NH_RUN_TCOMPACT_MIN", 4) && (R.rowsplit || R.order == 2)) ? 1 : 0;
+  int hole_lo = 0, hole_hi = 0;
+  if (R.tcompact) {
+    int nsmax = 0;  // synchrotron items of a slice at most
+    if (H.syn_grid >= 0) nsmax = (H.syn_nE * H.C.syn_cdmax + 63) / 64;
+    const int nslots = R.rowsplit ? H.C.nT / P->split : (H.C.nT + nsmax) / P->split + 2;
+    if (nslots < H.C.nT) {
+      hole_lo = H.o_part_t + nslots * 64;
+      hole_hi = H.o_part_t + H.C.nT * 64;
+    } else {
+      R.tcompact = 0;
+    }
+  }
+  auto take = [&](int n, bool align16) {
+    if (align16) hole_lo += hole_lo & 1;
+    if (hole_lo + n <= hole_hi) {
+      const int at = hole_lo;
+      hole_lo += n;
+      return at;
+    }
+    if (align16) off += off & 1;
+    const int at = off;
+    off += n;
+    return at;
+  };
   R.o_ut = -1;
-  if (grids_in_lds && nh_env_int("NH_RUN_UT", 1) != 0) {
+  if (units_tab) {
     int nunits = 0;
     for (int g = 0; g < H.ngrids; ++g) nunits += (H.nG[g] + 63) / 64;
-    off += off & 1;  // (16-byte aligned: a unit's descriptor is read as four ds_read_b128)
-    R.o_ut = off; off += nunits * (HSU_N / 2);
+    R.o_ut = take(nunits * (HSU_N / 2), true);  // (a unit's descriptor is read as four ds_read_b128)
   }
   {
     int ncols = 0;
     for (int t = 0; t < H.ntab; ++t) ncols += H.C.tab[t].nK;
     R.sum_cols = ncols;
-    off += off & 1;
-    R.o_sum = off; off += 2 * ncols;
-    R.o_cmp = off; off += 2 * NH_MAX_COMP + 2;
-    R.o_pci = off; off += (NH_MAX_PRIOR + 1) / 2;
+    R.o_sum = take(ncols, false);
+    R.o_cmp = take(2 * NH_MAX_COMP + 2, false);
+    R.o_pci = take((NH_MAX_PRIOR + 1) / 2, false);
+    {
+      int nun = 0;
+      for (int g = 0; g < H.ngrids; ++g) nun += (H.nG[g] + 63) / 64;
+      R.o_rs = take((9 + nun + 2 * NH_MAX_GRIDS + 1) / 2, false);
+    }
+    R.nxmax = H.C.nspec + NH_MAX_MOMENT;
   }
+  for (int t = 0; t < H.ntab; ++t)
+    NH_REQUIRE(H.nG[H.C.tab[t].grid] < 65536, "a table's grid has too many nodes for the items' descriptors");
   R.o_it = -1;
-  if (!rt && H.C.nT > 0) {  // (the register-resident instance keeps its rows per wave: no table)
-    off += off & 1;
-    R.o_it = off; off += H.C.nT * (HSI_N / 2);
-  }
-  if (nh_env_int("NH_RUN_IL", 1) != 0)
-    for (int g = 0; g < H.ngrids; ++g)
-      if (H.o_dp[g] >= 0 && (size_t)(off + H.nG[g]) * sizeof(double) <= 150 * 1024) {
-        R.o_il[g] = off; off += H.nG[g];
-      }
-  R.o_pk = off; off += NH_MAX_PACK * NH_MAX_LAZY * HS_RUN_PKW;
-  R.o_small1 = off; off += HS_O_T64;
-  R.o_olds = off; off += 128;
-  R.o_lcl = off; off += H.nE + 1;
-  R.o_trail = off; off += (HS_RUN_TRAIL * HS_MAX_TAB + H.C.nspec + 1) / 2;
+  if (!rt && H.C.nT > 0)  // (the register-resident instance keeps its rows per wave: no table)
+    R.o_it = take((HS_MAX_TAB * HST_N + H.C.nT * HSI_N + 1) / 2, true);
+  R.o_pk = take(NH_MAX_PACK * NH_MAX_LAZY * HS_RUN_PKW, false);
+  R.o_small1 = take(HS_O_T64, false);
+  R.o_olds = take(128, false);
+  R.o_lcl = take(H.nE + 1, false);
+  R.o_trail = take((HS_RUN_TRAIL * HS_MAX_TAB + H.C.nspec + 1) / 2, false);
   for (int t = 0; t < H.ntab; ++t)
     NH_REQUIRE(H.C.tab[t].tiles <= HS_RUN_TRAIL, "a table of more column tiles than the resident loop stages");
   // ---- the synchrotron items in the log domain (nh_syn2.h): a log-uniform grid only -------------
@@ -1815,9 +1985,8 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
       R.s2_z0 = (double)(((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
       R.s2_r746 = (double)(((long double)HS_S2_TTOP - logl(746.0L)) / (2.0L * lx) -
                            ((long double)HS_S2_TTOP + 2.0L * logl((long double)gam[0])) / (2.0L * lx));
-      off += off & 1;  // (16-byte aligned: the pieces are read as ds_read_b128)
-      int o2 = off;
-      R.o_s2tab = o2; o2 += (P + 1) * HS_S2_STRIDE;
+      const int off_was = off, hole_was = hole_lo;  // (tentative: undone if it does not fit)
+      R.o_s2tab = take((P + 1) * HS_S2_STRIDE, true);  // (16-byte aligned: the pieces are read as ds_read_b128)
       // the plan's LDS holds w | dlw of the synchrotron grid and 1/g^2 | its differences | its
       // cube roots, none of which these items read: when no table and no single-row reduction
       // shares the grid, the new arrays take their place (cfg3 with four workgroups per walker
@@ -1831,24 +2000,30 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
         R.o_s2lw = H.o_w[sg];   // (w, dlw: 2 nG doubles in a row)
         R.o_s2ig = H.o_dig2;    // (dig2, ig23: 2 nG doubles in a row)
       } else {
-        R.o_s2lw = o2; o2 += nG + 2 * HS_S2_GUARD;
-        R.o_s2ig = o2; o2 += nG + 2 * HS_S2_GUARD;
+        R.o_s2lw = take(nG + 2 * HS_S2_GUARD, false);
+        R.o_s2ig = take(nG + 2 * HS_S2_GUARD, false);
       }
       if (own && grids_in_lds) {
         R.o_s2lg = R.o_gx[sg];  // (gamma itself: only the weights w = gamma n read it)
       } else {
-        R.o_s2lg = o2; o2 += nG;
+        R.o_s2lg = take(nG, false);
       }
-      R.o_s2q = o2; o2 += 4 * H.syn_nE;
-      R.o_s2z = o2; o2 += (H.syn_nE + 1) / 2;
-      R.o_s2t = o2; o2 += 128;
-      if ((size_t)o2 * sizeof(double) <= 160 * 1024) {
+      R.o_s2q = take(4 * H.syn_nE, false);
+      R.o_s2z = take((H.syn_nE + 1) / 2, false);
+      R.o_s2t = take(128, false);
+      if ((size_t)off * sizeof(double) <= 160 * 1024) {
         R.syn2 = 1;
-        off = o2;
+      } else {
+        off = off_was;
+        hole_lo = hole_was;
       }
     }
   }
-  R.order = nh_env_int("NH_RUN_ORDER", 2);
+  // (1 / lx of the table grids: optional -- where LDS has room behind everything else)
+  if (nh_env_int("NH_RUN_IL", 1) != 0)
+    for (int g = 0; g < H.ngrids; ++g)
+      if (H.o_dp[g] >= 0 && (hole_lo + H.nG[g] <= hole_hi || (size_t)(off + H.nG[g]) * sizeof(double) <= 158 * 1024))
+        R.o_il[g] = take(H.nG[g], false);
   R.syn_nodes = H.C.syn_nodes;
   if (P->split == 1 && R.syn_nodes < 32) R.syn_nodes = R.syn2 ? 48 : 32;
   if (P->split == 2 && R.syn_nodes < 10) R.syn_nodes = 10;  // (cfg2: 901 -> 885 us; 914 at 16)
@@ -1865,7 +2040,6 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (nh_env_int("NH_RUN_FAIL_AT", 0) > 0)
     fprintf(stderr, "libnaima_hip: NH_RUN_FAIL_AT=%d -- that launch of the resident loop is made to time "
                     "out (fault injection of the tests)\n", nh_env_int("NH_RUN_FAIL_AT", 0));
-  R.rebalance = nh_env_int("NH_RUN_REBALANCE", H.syn_grid < 0 ? 1 : 0);
   NH_REQUIRE(R.syn_nodes >= 1, "NH_RUN_SYN_NODES must be positive");
   const size_t lds = (size_t)off * sizeof(double);
   NH_REQUIRE(lds <= 160 * 1024, "the resident loop's working set does not fit in LDS");
@@ -1959,8 +2133,12 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (e == hipSuccess) e = hipMalloc(&Q->accw, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
   if (e == hipSuccess) e = nh_fill_now(c, Q->accw, 0, (size_t)HS_RUN_MAX_STEPS * R.N * sizeof(int));
   if (e == hipSuccess && P->split > 1) {
-    e = hipMalloc(&Q->xspec, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * P->split * H.C.nspec * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&Q->tick, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * sizeof(int));
+    // per (slice, walker): what workgroups 1 .. K - 1 hand over, two tagged granules per double
+    // (no clearing between launches: the tags carry the launch's number)
+    const size_t cellw = (size_t)(P->split - 1) * 2 * Q->R.nxmax;
+    e = hipMalloc(&Q->xspec, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * cellw * sizeof(unsigned long long));
+    if (e == hipSuccess)
+      e = nh_fill_now(c, Q->xspec, 0, (size_t)2 * HS_RUN_MAX_STEPS * H.nloc * cellw * sizeof(unsigned long long));
   }
   if (e == hipSuccess)
     if (const char* dv = getenv("NH_HS_DEBUG"))
@@ -2219,8 +2397,6 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.hcap = hist_cap;
   for (int b = 0; b < NH_HS_MAX_BLOB; ++b)
     R.hblob[b] = (hist_coords && hist_blobs && b < H.C.nblob) ? hist_blobs[b] : nullptr;
-  if (Q->tick)  // (the arrival tickets of this launch's slices)
-    NH_CHECK_HIP(hipMemsetAsync(Q->tick, 0, (size_t)nslices * H.nloc * sizeof(int), c->stream));
   {
     nh_prof_scope ps(c, NH_K_HALFSTEP);
     const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
@@ -2301,6 +2477,16 @@ extern "C" int nh_half_step_run_syn_info(const nh_halfstep_run* Q, int* mode, in
   if (mode) *mode = Q->R.syn2;
   if (nodes_per_piece) *nodes_per_piece = Q->R.syn2 ? 1 << Q->R.s2.lm : 0;
   if (pieces) *pieces = Q->R.syn2 ? Q->R.s2.P + 1 : 0;
+  return NH_OK;
+}
+
+// workgroups per walker of the loop's launches, and whether they split the grid's ROWS between
+// them (a table-only model: each forms its part of the weights and reduces its part of the table)
+// rather than taking every K-th work item of a walker whose weights every one of them forms
+extern "C" int nh_half_step_run_split_info(const nh_halfstep_run* Q, int* split, int* rows) {
+  NH_REQUIRE(Q, "bad argument");
+  if (split) *split = Q->split;
+  if (rows) *rows = Q->R.rowsplit;
   return NH_OK;
 }
 

@@ -978,8 +978,11 @@ class DeviceLoop:
         _lib._chk(_lib._lib.nh_half_step_run_syn_info(h, C.byref(mode), C.byref(m), C.byref(pcs)))
         inreg, nmax = _lib._i(), _lib._i()
         _lib._chk(_lib._lib.nh_half_step_run_table_info(h, C.byref(inreg), C.byref(nmax)))
+        spl, rows = _lib._i(), _lib._i()
+        _lib._chk(_lib._lib.nh_half_step_run_split_info(h, C.byref(spl), C.byref(rows)))
         return dict(syn_log_domain=bool(mode.value), syn_nodes_per_piece=m.value, syn_pieces=pcs.value,
-                    tables_in_registers=bool(inreg.value))
+                    tables_in_registers=bool(inreg.value), workgroups_per_walker=spl.value,
+                    rows_split=bool(rows.value))
 
     def _create_shared_run(self, hs):
         """the resident loop over an ensemble shared with the other ranks' GPUs: rings in

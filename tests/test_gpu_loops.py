@@ -650,7 +650,12 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
             assert d._dev.resident_info["tables_in_registers"] and d._dev.resident_info["threads"] <= 512, \
                 d._dev.resident_info
         if mode == "1" and name == "cfg5" and not mkw:
-            assert not d._dev.resident_info["tables_in_registers"]  # (600 nodes, no zero rows: streamed)
+            # (600 nodes, no zero rows, 128 proposals per half-step on 256 CUs: two workgroups per
+            # walker that halve the grid's ROWS -- each forms its half of the weights, reduces its half
+            # of the table from registers, and the second hands its partial spectrum and its part of Wp
+            # to the first)
+            info = d._dev.resident_info
+            assert info["rows_split"] and info["workgroups_per_walker"] == 2 and info["tables_in_registers"], info
         if mode == "1" and name in ("cfg3", "cfg1"):
             # (the resident loop walks its own copies of the inverse-Compton tables, columns sorted
             # by their first non-zero row, rows below a tile's first one skipped: same spectra)
