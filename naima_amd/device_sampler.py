@@ -237,6 +237,18 @@ class DeviceLoop:
         self._cur_host = None     # host copies of the current blobs while nothing has changed them
         self._acc_dirty = False   # shared launches have accepted moves since the counts were summed
         self._acc_shared = 0.0
+        self._acc_base = 0.0      # moves accepted by the launches of a shared loop that was given up
+        # A shared ensemble's launches are not checked one by one (that would be a collective per
+        # launch): every rank keeps the ensemble as it stood at the last point where ALL ranks were
+        # known to be well (flush, reset: `verified`), and a journal of the sample() calls made
+        # since.  A launch that gave up on any rank is found at the next such point -- the status
+        # reduction every rank takes part in -- and the ranks TOGETHER go back to the kept ensemble
+        # and make the journal's steps again with one launch and one all-gather per half-step
+        # (the reference's Pool carries on when a worker is slow, core.py:523-536; this used to be
+        # an exception on every rank)
+        self._sh_snap = None
+        self._sh_journal = []
+        self._replaying = False
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
 
     # ------------------------------------------------------------------ pieces
@@ -253,6 +265,7 @@ class DeviceLoop:
         if self.shared:
             _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, None, None, 1))
             self._acc_dirty, self._acc_shared = False, 0.0
+        self._acc_base = 0.0
 
     def _eval(self, qT_buf, n):
         """run the user's model on device parameters: (total DVec, blob list)"""
@@ -616,6 +629,11 @@ class DeviceLoop:
             self._init_state(st.coords, st.log_prob)
         rng, N, ns = s._rng, self.N, self.ns
         iterations = int(iterations)
+        if self.sharded and s.comm.size > 1 and not self._replaying and self._run is not False:
+            fresh = not (isinstance(initial_state, DeviceState) and initial_state._loop is self)
+            if self._sh_snap is None or fresh:  # (normally kept at the verified point itself, below)
+                self._shared_snapshot()
+            self._sh_journal.append((iterations, bool(store), yield_every))
         block = None
         if store and iterations > 0:
             block = dict(n=0, coords=ctx.empty((iterations, N * self.ndim)),
@@ -1218,6 +1236,95 @@ class DeviceLoop:
                     "its block of moves is replayed when the iteration continues -- read the state "
                     "after that" % rec["status"])
 
+    # ------------------------------------------------ a shared ensemble: kept state and replay
+    def _shared_snapshot(self):
+        """device copies of the ensemble (positions, log-probabilities, acceptance counts, current
+        blobs) and the host's books, at a point where every rank is known to be well"""
+        ctx, s = self.ctx, self.s
+        self._flush_pending()
+        snap = dict(coords=ctx.empty((self.N * self.ndim,)), logp=ctx.empty((self.N,)),
+                    nacc=ctx.empty((self.N,), dtype=np.int32), blobs=[],
+                    iteration=s.iteration, steps_total=s.steps_total, nlc=s.n_lnprob_calls,
+                    nwe=s.n_walker_evals, rl=self.resident_launches,
+                    nan_pending=self._nan_pending, forbidden_pending=self._forbidden_pending)
+        ctx.call("nh_copy", snap["coords"], self.coords, 8 * self.N * self.ndim)
+        ctx.call("nh_copy", snap["logp"], self.logp, 8 * self.N)
+        ctx.call("nh_copy", snap["nacc"], self.nacc, 4 * self.N)
+        if self.s.store_blobs and self.cur_blobs:
+            self._sync_cur_blobs()  # (every rank's current blobs whole before they are kept)
+            for cur, m, _, _ in self.cur_blobs:
+                b = ctx.empty((self.N, m))
+                ctx.call("nh_copy", b, cur, 8 * self.N * m)
+                snap["blobs"].append(b)
+        self._sh_snap = snap
+        self._sh_journal = []
+
+    def _shared_verified(self):
+        """every rank's launches since the kept state ended well: the ensemble as it stands is the
+        one to go back to from now on (kept here, where every rank is anyway -- flush, reset -- and
+        not inside the next call: a 20-step call is a millisecond)"""
+        self._sh_snap = None
+        self._sh_journal = []
+        if self.shared and self._have_state:
+            self._shared_snapshot()
+
+    def _replay_shared(self, bad, mine):
+        """a launch of the shared loop gave up on some rank (status `bad`; this rank's own: `mine`).
+        Every rank is here (the status was reduced over all of them): back to the kept ensemble,
+        the move stream made again up to its step, and the journal's calls once more -- one launch
+        and one all-gather per half-step from here on."""
+        import warnings
+        from ._lib import Moves
+        ctx, s, snap = self.ctx, self.s, self._sh_snap
+        journal = list(self._sh_journal)
+        ctx.sync()
+        self.resident_reason = ("a launch of the resident loop over the shared ensemble gave up waiting "
+                                "for a record (status %d%s)" % (bad, "" if bad == mine else ", on another rank"))
+        if s.comm.rank == 0:
+            warnings.warn(self.resident_reason + "; every rank goes back %d step(s) to the last ensemble "
+                          "all of them held and carries on with one launch and one all-gather per "
+                          "half-step" % (s.steps_total - snap["steps_total"]))
+        self.resident_failed_launches += max(1, self.resident_launches - snap["rl"])
+        # what the shared launches accepted up to the kept state stays counted (flush folded it)
+        self._acc_base = self._acc_base + self._acc_shared
+        self._acc_shared, self._acc_dirty = 0.0, False
+        self._run, self.shared = False, False
+        self._cur_dirty, self._cur_host = False, None
+        self._sh_snap, self._sh_journal = None, []
+        ctx.call("nh_copy", self.coords, snap["coords"], 8 * self.N * self.ndim)
+        ctx.call("nh_copy", self.logp, snap["logp"], 8 * self.N)
+        ctx.call("nh_copy", self.nacc, snap["nacc"], 4 * self.N)
+        for b, (cur, m, _, _) in zip(snap["blobs"], self.cur_blobs or []):
+            ctx.call("nh_copy", cur, b, 8 * self.N * m)
+        self.hist = []
+        s.iteration, s.steps_total = snap["iteration"], snap["steps_total"]
+        s.n_lnprob_calls, s.n_walker_evals = snap["nlc"], snap["nwe"]
+        self.resident_launches = snap["rl"]
+        self._read_counts(reset=False, set_to=(0, 0))  # (drained at the kept state; the replay counts again)
+        self._nan_pending, self._forbidden_pending = snap["nan_pending"], snap["forbidden_pending"]
+        while self._inflight:
+            ctx.call("nh_marker_wait", self._inflight.pop(0))
+        mv = self._mv
+        mv["have"] = mv["used"] = 0
+        mv["ahead"] = mv["prev"] = mv["last"] = None
+        old = s._moves
+        s._moves = Moves(s.seed, s.nwalkers, s.a, ksteps=32, depth=4, pinned=True)
+        if old is not None:
+            old.close()
+        left = snap["steps_total"]
+        while left > 0:
+            _, got = s._moves.take(min(32, left))
+            left -= got
+        self._replaying = True
+        try:
+            for iterations, store, yield_every in journal:
+                for _ in self.sample(DeviceState(self, s._rng), iterations, store, yield_every=1 << 30):
+                    pass
+            self._flush_pending()
+            ctx.sync()
+        finally:
+            self._replaying = False
+
     def _rl_settle(self, keep):
         """wait until all but the last `keep` queued launches are known to have ended; None, or
         the record of the first one that gave up (it and everything queued behind it are void)"""
@@ -1296,6 +1403,11 @@ class DeviceLoop:
         bad = st.value
         if collective and self.s.comm is not None and self.s.comm.size > 1:
             bad = int(self.s.comm.group.reduce_scalar(float(bad), "max"))
+            if bad == 0:
+                self._shared_verified()
+            elif self.shared and self._sh_snap is not None and not self._replaying:
+                self._replay_shared(bad, st.value)
+                return
         if bad != 0:
             raise _lib.NaimaHipError(
                 "the resident half-step loop timed out waiting for a walker's record (status "
@@ -1468,7 +1580,7 @@ class DeviceLoop:
                 for j, a in enumerate(per):
                     s._blobs[j].extend(list(a))
         self.hist = []
-        s.naccepted = self.nacc.get().astype(float)
+        s.naccepted = self.nacc.get().astype(float) + self._acc_base
         if self.shared:  # + the moves each rank's shared launches accepted
             if self._acc_dirty:  # (collective only when launches have run since the last look)
                 self._acc_dirty = False

@@ -999,6 +999,53 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
             assert_allclose(have, w, rtol=1e-10, atol=1e-300, err_msg="%s of rank %d" % (key, r))
 
 
+@pytest.mark.parametrize("fail_at", [3, 4], ids=["third-launch", "fourth-launch"])
+def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_at):
+    """three ranks on the one GPU share cfg3's ensemble; one launch of ONE rank's resident loop is
+    made to time out (NH_RUN_FAIL_AT: what another process taking the GPU's CUs would do).  The
+    other ranks' launches starve of its records and give up too; nobody raises: at the next point
+    where every rank is (a flush) the status is reduced over the ranks, all of them go back to the
+    ensemble they kept at the previous such point, make the move stream again and repeat the steps
+    with one launch and one all-gather per half-step -- the final chain, log-probabilities, blobs
+    and acceptance equal one process's (the reference's Pool carries on likewise,
+    core.py:523-536)."""
+    import os
+    import subprocess
+    import sys
+    from naima_amd.sampler import EnsembleSampler
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + (os.getpid() % 1000)
+    nw, name = 30, "cfg3"
+    subprocess.check_call(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.join(root, "tests", "gpu_shared_fail_worker.py"), str(tmp_path), name, str(nw), str(fail_at)],
+        cwd=root, timeout=900,
+        env=dict(os.environ, MASTER_ADDR="127.0.0.1", NH_RUN_SPIN_LIMIT=str(1 << 22)))
+    model, p0, raw, data, prior = _problem(na, name, {})
+    nd = p0.size
+    s = EnsembleSampler(nw, nd, na.lnprob, args=[data, model, prior], seed=42, naima_style=True,
+                        store_blobs=True, device=True, nan_policy="reject")
+    pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
+    st = s.run_mcmc(pos, 5)
+    st = s.run_mcmc(st, 40)
+    st = s.run_mcmc(st, 50)
+    st = s.run_mcmc(st, 9, store=False)
+    st = s.run_mcmc(st, 12)
+    want = dict(coords=st.coords, logp=st.log_prob, chain=s.get_chain(), lnp=s.get_log_prob(),
+                blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
+                curblob0=np.asarray(st.blobs[0]), acc=s.acceptance_fraction)
+    assert want["chain"].shape[0] == 107
+    for r in range(3):
+        for key, w in want.items():
+            have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))
+            assert have.shape == w.shape, (key, r)
+            # (the steps made again ran one launch per half-step: the resident loop's arithmetic to
+            # rounding, test_resident_loop_equals_per_launch_loop)
+            assert_allclose(have, w, rtol=1e-9 if key in ("logp", "lnp") else 1e-10, atol=1e-300,
+                            err_msg="%s of rank %d" % (key, r))
+
+
 def test_sorted_table_trailers_are_checked_at_the_abi(na):
     """nh_half_step_run_tables reads the trailers of the table copies back and refuses a first
     row out of range or a column order that is not a permutation (they decide where the kernel
