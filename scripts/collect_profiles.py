@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S, D = os.path.join(R, "gpurun_out", TAG + "prof"), os.path.join(R, "profiles")
 COPY = {"bench_n1_default.json": "bench_n1_default.json",
@@ -24,7 +24,9 @@ COPY = {"bench_n1_default.json": "bench_n1_default.json",
 for f in ("bench_cfg3_w1024.json", "bench_cfg3_w2048.json", "bench_cfg3_w1024_per_launch_kernel.json",
           "bench_cfg3_w2048_per_launch_kernel.json", "bench_cfg3_shared_two_ranks_one_gpu.json",
           "bench_cfg3_shared_two_ranks_one_gpu_steps100.json", "bench_cfg3_one_process_steps100.json",
-          "shard_table.json"):
+          "shard_table.json", "bench_cfg3_weak_two_ranks_one_gpu.json",
+          "bench_cfg3_weak_four_ranks_one_gpu_baseline_split.json", "bench_cfg4_strong1024_n1.json",
+          "region_host_latency.txt"):
     COPY[f] = f
 for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
     COPY["%s_stats_kernel_stats.csv" % w] = "%s_kernel_stats.csv" % w

@@ -4,7 +4,7 @@
 #   bash scripts/gpu_profile.sh [round tag, default r03]   ->   gpurun_out/<tag>prof/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}prof
 rm -rf $O; mkdir -p $O
 DRV="bench.py --steps 20 --warmup 5"
@@ -80,17 +80,23 @@ for n in 1024 2048; do
   timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w$n.json 2>> $O/err_bench.log
   NH_RUN_MAX_PER_WG=1 timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w${n}_per_launch_kernel.json 2>> $O/err_bench.log
 done
-# 6. the resident loop over an ensemble SHARED by two ranks -- two processes on this ONE GPU, 256 workgroups between them
+# 6. bench.py starting its own ranks (round 5): two ranks on this ONE GPU (NAIMA_AMD_DEVICE pins them; each
+# plans for half the CUs) -- cfg3's 512 walkers SHARED by the two (strong), 512 each (weak), and the same
+# with 100-step regions
 (
-export NAIMA_AMD_DEVICE=0 NAIMA_AMD_COMM=host NH_HS_SPLIT=1 NH_RUN_SPIN_LIMIT=$((1<<24))
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29655 \
-  bench.py --gpus 2 --walkers 256 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg3_shared_two_ranks_one_gpu.json 2>> $O/err_bench.log
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29656 \
-  bench.py --gpus 2 --walkers 256 --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_shared_two_ranks_one_gpu_steps100.json 2>> $O/err_bench.log
+export NAIMA_AMD_DEVICE=0 NH_RUN_SPIN_LIMIT=$((1<<24))
+timeout 600 python bench.py --gpus 2 --scaling strong --walkers-total 512 --steps 20 --warmup 5 --no-cpu > $O/bench_cfg3_shared_two_ranks_one_gpu.json 2>> $O/err_bench.log
+timeout 600 python bench.py --gpus 2 --scaling strong --walkers-total 512 --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_shared_two_ranks_one_gpu_steps100.json 2>> $O/err_bench.log
+timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_weak_two_ranks_one_gpu.json 2>> $O/err_bench.log
+timeout 900 python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu --no-blobs-run --walkers 128 > $O/bench_cfg3_weak_four_ranks_one_gpu_baseline_split.json 2>> $O/err_bench.log
 )
+# 6b. BASELINE's cfg4 at its 1024 walkers on one GPU
+timeout 900 python bench.py --scaling strong --workload cfg4 --walkers-total 1024 --steps 10 --warmup 2 --no-cpu --no-blobs-run > $O/bench_cfg4_strong1024_n1.json 2>> $O/err_bench.log
+# 6c. where a 20-step region's time goes on the host
+timeout 300 python scripts/region_host_latency.py cfg3 20 > $O/region_host_latency.txt 2>&1
 timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_one_process_steps100.json 2>> $O/err_bench.log
 # 7. one-GPU projection of the multi-GPU configurations
-timeout 1500 python scripts/shard_table.py > $O/shard_table.json 2> $O/shard_table.err
-for f in bench_cfg3_w1024 bench_cfg3_w2048 bench_cfg3_shared_two_ranks_one_gpu bench_cfg3_shared_two_ranks_one_gpu_steps100 bench_cfg3_one_process_steps100; do
+timeout 2400 python scripts/shard_table.py > $O/shard_table.json 2> $O/shard_table.err
+for f in bench_cfg3_w1024 bench_cfg3_w2048 bench_cfg3_shared_two_ranks_one_gpu bench_cfg3_shared_two_ranks_one_gpu_steps100 bench_cfg3_weak_two_ranks_one_gpu bench_cfg3_weak_four_ranks_one_gpu_baseline_split bench_cfg4_strong1024_n1 bench_cfg3_one_process_steps100; do
   python -c "import json; d=json.load(open('$O/$f.json')); print('$f', round(d['value']), d['ms_per_step'])"
 done
