@@ -92,7 +92,7 @@ def _last_commit_of(path):
         return None
 
 
-def measured_utilisation(name, resident):
+def measured_utilisation(name, resident, waves_per_simd=4):
     """What the vector pipe did, from the committed SQ counter passes of this workload's bench
     command under rocprofv3 (profiles/r*_<name>_counters_per_launch.json, newest round): the
     fraction of the dominant kernel's time its SIMDs spent issuing vector instructions
@@ -119,12 +119,14 @@ def measured_utilisation(name, resident):
     out = {"kernel": k.split("(")[0].strip(), "source": os.path.basename(files[-1]),
            "from_committed_profile": True, "source_commit": _last_commit_of(files[-1]),
            "measured_in_this_run": False,
-           "valu_busy": 4.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
+           "valu_busy": float(waves_per_simd) * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
+           "waves_per_simd": waves_per_simd,
            "valu_insts_per_wave_and_launch": v.get("SQ_INSTS_VALU", 0.0) / waves,
            "salu_insts_per_wave_and_launch": v.get("SQ_INSTS_SALU", 0.0) / waves,
            "wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"],
-           "note": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_WAVE_CYCLES (four waves share a SIMD); "
-                   "a resident launch of the profiled command is 40 half-steps"}
+           "note": "valu_busy = SQ_ACTIVE_INST_VALU x W / SQ_WAVE_CYCLES, W = the workgroup's waves per "
+                   "SIMD (1024 threads: 4, 512: 2 -- one workgroup per CU); a resident launch of the "
+                   "profiled command is 40 half-steps"}
     return out
 
 
@@ -706,7 +708,8 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
                                           "convention, not pipe utilisation)" % SSC_SEG_EQ}
     default_walkers = 256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"]
     if per_gpu == default_walkers and comm.size == 1:  # (the configuration the profiles were taken on)
-        util = measured_utilisation(name, resident)
+        thr = (getattr(sampler._dev, "resident_info", None) or {}).get("threads", 1024) if resident else 1024
+        util = measured_utilisation(name, resident, max(1, int(thr) // 256))
         if util:
             out["valu_utilisation"] = util
     if full and not args.no_cpu and comm.size == 1:
