@@ -5,6 +5,18 @@
 
 struct pd_par { double A, e0, al, ec, be, eb, a2; };
 
+// fma(a, b, C) with the constant C in a SCALAR register pair.  Left to itself the compiler writes a
+// Horner step whose addend is a 64-bit literal as v_mov_b32 x 2 + v_fmac_f64 -- the addend of the
+// two-operand form is its destination, so the constant is built in vector registers first: three
+// vector instructions per coefficient where one does (the weights' two exponentials and the
+// cut-off's expm1 are 19 such steps per node).  s_mov_b32 x 2 go to the scalar unit, which the
+// waves of a SIMD that are bound by their vector instructions do not miss.
+__device__ __forceinline__ double pd_fma_sc(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+
 // exp(d) - 1 with d = beta * ln(E2/E1): a few per cent on naima's default grids (100 nodes
 // per decade: d = 0.023 beta) -- ten Taylor terms are exact to 3e-17 below |d| = 0.1; the
 // grid density is a user parameter (nEed = 10 gives d = 0.23), so a wave that sees a
@@ -14,14 +26,13 @@ __device__ __forceinline__ double pd_expm1_small(double d) {
     asm volatile("" ::: "memory");  // keep the library call in the branch
     return expm1(d);
   }
-  double p = 2.7557319223985893e-07;  // 1/10!
-  p = fma(p, d, 2.7557319223985888e-06);
-  p = fma(p, d, 2.4801587301587302e-05);
-  p = fma(p, d, 1.9841269841269841e-04);
-  p = fma(p, d, 1.3888888888888889e-03);
-  p = fma(p, d, 8.3333333333333332e-03);
-  p = fma(p, d, 4.1666666666666664e-02);
-  p = fma(p, d, 1.6666666666666666e-01);
+  double p = fma(d, 2.7557319223985893e-07 /* 1/10! */, 2.7557319223985888e-06);
+  p = pd_fma_sc(p, d, 2.4801587301587302e-05);
+  p = pd_fma_sc(p, d, 1.9841269841269841e-04);
+  p = pd_fma_sc(p, d, 1.3888888888888889e-03);
+  p = pd_fma_sc(p, d, 8.3333333333333332e-03);
+  p = pd_fma_sc(p, d, 4.1666666666666664e-02);
+  p = pd_fma_sc(p, d, 1.6666666666666666e-01);
   p = fma(p, d, 0.5);
   p = fma(p, d, 1.0);
   return p * d;
@@ -60,7 +71,7 @@ __device__ __forceinline__ double pd_exp_tab(double x, const double* __restrict_
   double r = fma(-kf, 0.010830424696223417, xc);    // ln2/64: 36 leading bits ...
   r = fma(-kf, 2.572804622327669e-14, r);           // ... and the rest
   double p = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
+  p = pd_fma_sc(p, r, 1.6666666666666666e-01);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
@@ -78,7 +89,7 @@ __device__ __forceinline__ double pd_exp_tab_lds(double x, unsigned t64) {
   double r = fma(-kf, 0.010830424696223417, xc);    // ln2/64: 36 leading bits ...
   r = fma(-kf, 2.572804622327669e-14, r);           // ... and the rest
   double p = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
-  p = fma(p, r, 1.6666666666666666e-01);
+  p = pd_fma_sc(p, r, 1.6666666666666666e-01);
   p = fma(p, r, 0.5);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);

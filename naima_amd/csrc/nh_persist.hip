@@ -62,8 +62,11 @@
 #endif
 
 // the weights' unit table (hs_run.o_ut): ints per unit
-enum { HSU_G = 0, HSU_I0, HSU_NG, HSU_W, HSU_D, HSU_DP, HSU_IL, HSU_TH, HSU_LX, HSU_LNE, HSU_GX, HSU_GE,
-       HSU_S2, HSU_S2LW, HSU_SC_LO, HSU_SC_HI, HSU_N };
+enum { HSU_FL = 0, HSU_NL, HSU_G, HSU_W, HSU_D, HSU_DP, HSU_IL, HSU_TH, HSU_LX, HSU_LNE, HSU_GX, HSU_GE,
+       HSU_S2LW, HSU_S2LG, HSU_SC_LO, HSU_SC_HI, HSU_N };
+// HSU_FL: bits 0-1 = 0 plain | 1 the log-domain synchrotron items read ln w of this grid too | 2 and
+// nothing else of it; bit 2: the non-negative table items' pre-divided log-ratios are kept; bit 3:
+// ... with 1 / lx and the thresholds in LDS since the launch began; bit 4: the unit is its grid's last
 static_assert(HSU_N == 16, "a unit's descriptor is four 16-byte reads");
 
 // the table items' descriptors (hs_run.o_it): HS_MAX_TAB x 16 ints per TABLE (HST_*), then 4 ints
@@ -236,6 +239,179 @@ __device__ __attribute__((noinline)) hsr_node2 hsr_pd_core2(int kind, double A, 
   pd_core(kind, p, lxx1, lxc1, lkb, (b1 & 1) != 0, (b1 & 2) != 0, lr1, r.n1, r.dsh1, nullptr, &r.ex1,
           (b1 & 4) == 0, t64);
   return r;
+}
+
+// ---- the particle weights of a slice: a wave's units, from LDS to LDS ---------------------------
+// One call per wave and slice, specialised by the kind of distribution.  What it replaced: the unit
+// loop inline in the kernel with hsr_pd_core / hsr_pd_core2 called per pair of units -- 350 vector
+// instructions for a wave with two units of which ~140 were the nodes' arithmetic: the callee took
+// the kind and the break flags in vector registers and branched on them lane by lane (every case of
+// the switch an exec-mask region), 25 moves marshalled each call, 16 v_readfirstlane per unit turned
+// the unit's descriptor into scalars.  Here the descriptor's addresses stay in vector registers
+// (uniform contents: an address is only ever added to the lane's offset), one flag word per unit is
+// made scalar, the kind is a template argument.
+// All arguments are wave-uniform; LDS byte addresses unless said otherwise.
+typedef __attribute__((address_space(3))) double hsr_ld;
+typedef __attribute__((address_space(3))) const int hsr_lci;
+typedef int hsr_i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const hsr_i4 hsr_lci4;
+__device__ __forceinline__ double hsr_rd(unsigned a) { return *(const hsr_ld*)(unsigned long long)a; }
+__device__ __forceinline__ void hsr_wr(unsigned a, double v) { *(hsr_ld*)(unsigned long long)a = v; }
+
+struct hsr_unit {  // a unit's descriptor as it is read (HSU_*), and this lane's inputs
+  unsigned a_w, a_d, a_dp, a_il, a_th, a_s2lw, a_s2lg;
+  int fl, nl, g, ic8;
+  bool on, last;
+  double sc, lr, lne, gx, il, s2lg;
+  int b;
+};
+
+template <bool BROKEN>
+__device__ __forceinline__ void hsr_unit_read(hsr_unit& U, unsigned a_ut, int uu, int lane, double eb) {
+  const unsigned a = a_ut + (unsigned)uu * (HSU_N * 4);
+  const hsr_i4 d0 = *(hsr_lci4*)(unsigned long long)a;
+  const hsr_i4 d1 = *(hsr_lci4*)(unsigned long long)(a + 16);
+  const hsr_i4 d2 = *(hsr_lci4*)(unsigned long long)(a + 32);
+  const hsr_i4 d3 = *(hsr_lci4*)(unsigned long long)(a + 48);
+  U.fl = __builtin_amdgcn_readfirstlane(d0.x);
+  U.nl = d0.y; U.g = d0.z; U.a_w = (unsigned)d0.w;
+  U.a_d = (unsigned)d1.x; U.a_dp = (unsigned)d1.y; U.a_il = (unsigned)d1.z; U.a_th = (unsigned)d1.w;
+  U.a_s2lw = (unsigned)d3.x; U.a_s2lg = (unsigned)d3.y;
+  U.sc = __hiloint2double(d3.w, d3.z);
+  U.on = lane < U.nl;
+  const int ic = min(lane, U.nl - 1);  // (lanes past the grid's end: its last node, discarded)
+  U.last = ic + 1 >= U.nl;
+  U.ic8 = ic << 3;
+  U.lr = hsr_rd((unsigned)d2.x + U.ic8);  // (0 at the last node)
+  U.lne = hsr_rd((unsigned)d2.y + U.ic8);
+  U.gx = hsr_rd((unsigned)d2.z + U.ic8);
+  U.il = (U.fl & 8) ? hsr_rd(U.a_il + U.ic8) : 0.0;
+  U.s2lg = (U.fl & 3) ? hsr_rd(U.a_s2lg + U.ic8) : 0.0;
+  U.b = 0;
+  if (BROKEN) {
+    const double E = hsr_rd((unsigned)d2.w + U.ic8);
+    const double E2 = hsr_rd((unsigned)d2.w + (U.last ? U.ic8 : U.ic8 + 8));
+    U.b = (E < eb ? 1 : 0) | (E2 < eb ? 2 : 0);
+  }
+}
+
+// (one node's results -> LDS and the flags: grids with a non-zero weight | << 8: with one that is
+// not finite)
+template <bool S2SYN>
+__device__ __forceinline__ int hsr_unit_write(const hsr_unit& U, double n, double dsh, double ex, double lnA,
+                                              double s2_lnw0) {
+  const double nn = n * U.sc;
+  double wv_ = U.gx * nn;
+  const double dv = U.last ? 0.0 : U.lr + dsh;
+  bool plain = true;  // (wave-uniform)
+  if (S2SYN && (U.fl & 3) != 0) {
+    // the log-domain items' Lambda ln|w| + Lambda ln cbrt(1/gamma^2) (nh_syn2.h); a zero weight (or
+    // amplitude) is the floor: an exact 0, and exact zeros for its segments
+    const double lna = lnA + ex;  // ln |n|
+    const double lw = fma(HS_S2_LAMBDA, lna, U.s2lg);
+    // (w = gamma n scale underflows to an exact 0 in the reference below ln w = -744.44: the floor
+    // -- an exact zero node -- from there on)
+    const bool nonzero = lna + U.lne > s2_lnw0;
+    if (U.on) hsr_wr(U.a_s2lw + U.ic8, nonzero ? lw : HS_S2_FLOOR);
+    if ((U.fl & 3) == 2) {  // (nobody reads this grid's w / dlw, and gx holds another array)
+      plain = false;
+      wv_ = !(lw < INFINITY) ? lw : (nonzero ? 1.0 : 0.0);  // (what the flags below look at)
+    }
+  }
+  if (plain && U.on) {
+    hsr_wr(U.a_w + U.ic8, wv_);
+    hsr_wr(U.a_d + U.ic8, dv);
+    if (U.fl & 4) {  // what the non-negative table items read
+      if (U.fl & 8) {  // (1 / lx and the threshold: in LDS since the launch began)
+        hsr_wr(U.a_dp + U.ic8, dv * U.il);
+      } else {
+        const double il = U.last ? 0.0 : nh_rcp(U.lr);
+        hsr_wr(U.a_dp + U.ic8, dv * il);
+        hsr_wr(U.a_th + U.ic8, NH_SEG_SMALL_POS * il);
+      }
+    }
+  }
+  // (a weight that is not finite -- a far-off walker whose distribution overflows -- makes
+  // 0 x inf = NaN of a zero table entry, as in the reference: no row of such a walker's tables is
+  // skipped)
+  int fl = 0;
+  if (__builtin_amdgcn_ballot_w64(U.on && wv_ != 0.0) != 0ull) fl |= 1 << U.g;
+  if (__builtin_amdgcn_ballot_w64(U.on && !isfinite(wv_)) != 0ull) fl |= 256 << U.g;
+  return fl;
+}
+
+// a_ul != 0: the units are taken from that list of unit numbers (rows split between a walker's
+// workgroups: the units that hold this one's nodes); units u0 and u0 + ustep (if < uend), their
+// chains of ~70 dependent instructions interleaved
+template <int KIND, bool S2SYN>
+__device__ __attribute__((noinline)) int hsr_weights(unsigned a_ut, unsigned a_ul, int u0, int ustep,
+                                                     int uend, unsigned a_row, unsigned a_lg,
+                                                     unsigned a_lna, unsigned t64, double s2_lnw0) {
+  a_ut = __builtin_amdgcn_readfirstlane(a_ut);
+  a_ul = __builtin_amdgcn_readfirstlane(a_ul);
+  u0 = __builtin_amdgcn_readfirstlane(u0);
+  ustep = __builtin_amdgcn_readfirstlane(ustep);
+  uend = __builtin_amdgcn_readfirstlane(uend);
+  t64 = __builtin_amdgcn_readfirstlane(t64);
+  __builtin_assume(t64 != 0u);  // (pd_core: the exponentials through the table in LDS, no other form compiled in)
+  const int lane = (int)__lane_id();
+  constexpr bool BROKEN = KIND == NH_PD_BROKENPL || KIND == NH_PD_ECBPL;
+  pd_par p;  // (the particle row of the slice: {A, e_0, alpha, e_cutoff, beta, e_break, alpha_2})
+  p.A = hsr_rd(a_row); p.e0 = 0.0; p.al = hsr_rd(a_row + 16); p.ec = 0.0; p.be = hsr_rd(a_row + 32);
+  p.eb = BROKEN ? hsr_rd(a_row + 40) : 0.0; p.a2 = BROKEN ? hsr_rd(a_row + 48) : 0.0;
+  const double lg0 = hsr_rd(a_lg), lg1 = hsr_rd(a_lg + 8);
+  const double lkb = BROKEN ? hsr_rd(a_lg + 16) - lg0 : 0.0;
+  const double lnA = S2SYN ? hsr_rd(a_lna) : 0.0;
+  int fl = 0;
+  // (ONE pair of units per call -- the caller loops, once for all but the largest grids: with the
+  // loop in here the compiler parks the exponentials' coefficients in ~60 vector registers across
+  // it, callee-saved ones that it then saves to scratch on the way in)
+  {
+    const int u = u0;
+    const bool two = u + ustep < uend;  // (wave-uniform)
+    int uu0 = u, uu1 = two ? u + ustep : u;
+    if (a_ul) {
+      uu0 = __builtin_amdgcn_readfirstlane(*(hsr_lci*)(unsigned long long)(a_ul + 4u * (unsigned)uu0));
+      uu1 = __builtin_amdgcn_readfirstlane(*(hsr_lci*)(unsigned long long)(a_ul + 4u * (unsigned)uu1));
+    }
+    hsr_unit U0, U1;
+    hsr_unit_read<BROKEN>(U0, a_ut, uu0, lane, p.eb);
+    if (two) hsr_unit_read<BROKEN>(U1, a_ut, uu1, lane, p.eb);
+    // (the log-domain synchrotron items read ln w and nothing else of a grid: no exponential, no
+    // expm1 for its nodes -- wave-uniform, a unit is one grid's)
+    double n0, d0, e0, n1 = 0.0, d1 = 0.0, e1 = 0.0;
+    if (two) {
+      pd_core(KIND, p, U0.lne - lg0, U0.lne - lg1, lkb, (U0.b & 1) != 0, (U0.b & 2) != 0, U0.lr, n0, d0,
+              nullptr, &e0, (U0.fl & 3) != 2, t64);
+      pd_core(KIND, p, U1.lne - lg0, U1.lne - lg1, lkb, (U1.b & 1) != 0, (U1.b & 2) != 0, U1.lr, n1, d1,
+              nullptr, &e1, (U1.fl & 3) != 2, t64);
+      fl |= hsr_unit_write<S2SYN>(U0, n0, d0, e0, lnA, s2_lnw0);
+      fl |= hsr_unit_write<S2SYN>(U1, n1, d1, e1, lnA, s2_lnw0);
+    } else {
+      pd_core(KIND, p, U0.lne - lg0, U0.lne - lg1, lkb, (U0.b & 1) != 0, (U0.b & 2) != 0, U0.lr, n0, d0,
+              nullptr, &e0, (U0.fl & 3) != 2, t64);
+      fl |= hsr_unit_write<S2SYN>(U0, n0, d0, e0, lnA, s2_lnw0);
+    }
+  }
+  return fl;
+}
+
+template <bool S2SYN>
+__device__ __forceinline__ int hsr_weights_kind(int kind, unsigned a_ut, unsigned a_ul, int u0, int ustep,
+                                                int uend, unsigned a_row, unsigned a_lg, unsigned a_lna,
+                                                unsigned t64, double s2_lnw0) {
+  switch (kind) {  // (a kernel argument: a scalar branch)
+    case NH_PD_POWERLAW:
+      return hsr_weights<NH_PD_POWERLAW, S2SYN>(a_ut, a_ul, u0, ustep, uend, a_row, a_lg, a_lna, t64, s2_lnw0);
+    case NH_PD_ECPL:
+      return hsr_weights<NH_PD_ECPL, S2SYN>(a_ut, a_ul, u0, ustep, uend, a_row, a_lg, a_lna, t64, s2_lnw0);
+    case NH_PD_BROKENPL:
+      return hsr_weights<NH_PD_BROKENPL, S2SYN>(a_ut, a_ul, u0, ustep, uend, a_row, a_lg, a_lna, t64, s2_lnw0);
+    case NH_PD_ECBPL:
+      return hsr_weights<NH_PD_ECBPL, S2SYN>(a_ut, a_ul, u0, ustep, uend, a_row, a_lg, a_lna, t64, s2_lnw0);
+    default:
+      return hsr_weights<NH_PD_LOGPARABOLA, S2SYN>(a_ut, a_ul, u0, ustep, uend, a_row, a_lg, a_lna, t64, s2_lnw0);
+  }
 }
 
 // workgroup 0 only: when does each WAVE reach barrier 1 / 2 / 3 and finish its last item
@@ -428,20 +604,22 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       for (int q = tid; q < nu; q += T) {
         int* d = ut + (u0 + q) * HSU_N;
         const int i0 = q * 64;
+        const bool dp = H.o_dp[g] >= 0, il = R.o_il[g] >= 0;
+        auto at = [&](int off) { return (int)hs_lds_addr(sm + off + i0); };
+        d[HSU_FL] = (s2g ? (R.s2_own ? 2 : 1) : 0) | (dp ? 4 : 0) | (dp && il ? 8 : 0);
+        d[HSU_NL] = H.nG[g] - i0;  // nodes of the grid from this unit's first on
         d[HSU_G] = g;
-        d[HSU_I0] = i0;
-        d[HSU_NG] = H.nG[g];
-        d[HSU_W] = H.o_w[g] + i0;
-        d[HSU_D] = H.o_d[g] + i0;
-        d[HSU_DP] = H.o_dp[g] >= 0 ? H.o_dp[g] + i0 : -1;
-        d[HSU_IL] = R.o_il[g] >= 0 ? R.o_il[g] + i0 : -1;
-        d[HSU_TH] = H.o_th[g] >= 0 ? H.o_th[g] + i0 : -1;
-        d[HSU_LX] = H.o_lx[g] + i0;
-        d[HSU_LNE] = R.o_lne[g] + i0;
-        d[HSU_GX] = R.o_gx[g] + i0;
-        d[HSU_GE] = R.o_ge[g] + i0;
-        d[HSU_S2] = s2g ? (R.s2_own ? 2 : 1) : 0;
-        d[HSU_S2LW] = s2g ? R.o_s2lw + HS_S2_GUARD + i0 : 0;
+        d[HSU_W] = at(H.o_w[g]);
+        d[HSU_D] = at(H.o_d[g]);
+        d[HSU_DP] = dp ? at(H.o_dp[g]) : 0;
+        d[HSU_IL] = il ? at(R.o_il[g]) : 0;
+        d[HSU_TH] = H.o_th[g] >= 0 ? at(H.o_th[g]) : 0;
+        d[HSU_LX] = at(H.o_lx[g]);
+        d[HSU_LNE] = at(R.o_lne[g]);
+        d[HSU_GX] = at(R.o_gx[g]);
+        d[HSU_GE] = at(R.o_ge[g]);
+        d[HSU_S2LW] = s2g ? at(R.o_s2lw + HS_S2_GUARD) : 0;
+        d[HSU_S2LG] = s2g ? at(R.o_s2lg) : 0;
         d[HSU_SC_LO] = __double2loint(H.scale[g]);
         d[HSU_SC_HI] = __double2hiint(H.scale[g]);
       }
@@ -970,115 +1148,16 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       HSR_FSTAMP(1);
       if (R.o_ut >= 0) {
         // ---- the grids' nodes are in LDS: units from the table built when the launch began ------
-        const int* ut = reinterpret_cast<const int*>(sm + R.o_ut);
-        const double lg0 = lg[0], lg1 = lg[1], lkb = lg[2] - lg[0];
-        const double lnA = (SYN && S2) ? qs[HS_O_LNA] : 0.0;
-        const unsigned t64 = hs_lds_addr(sm + HS_O_T64);
-        int fl = 0;  // (wave-uniform) grids with a non-zero weight | << 8: with one that is not finite
         // (rows split between the walker's workgroups: the units that hold this one's nodes, listed
         // when the launch began)
         const int* ul = reinterpret_cast<const int*>(sm + R.o_rs) + 9;
         const int u_end = R.rowsplit ? __builtin_amdgcn_readfirstlane(ul[-1]) : nunits;
-        for (int u = worker ? rank : u_end; u < u_end; u += 2 * nwork) {
-          const bool two = u + nwork < u_end;  // (wave-uniform)
-          typedef int hsu_i4 __attribute__((ext_vector_type(4)));
-          int dq[2][HSU_N];
-          double lrq[2], lneq[2], gxq[2], ilq[2];
-          int bq[2], icq[2];
-          bool onq[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            int uu = (q == 0 || two) ? u + q * nwork : u;  // (no second unit: the first one again, unused)
-            if (R.rowsplit) uu = __builtin_amdgcn_readfirstlane(ul[uu]);
-            const hsu_i4* dp4 = reinterpret_cast<const hsu_i4*>(ut + uu * HSU_N);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const hsu_i4 v = dp4[k];
-              dq[q][4 * k] = v.x; dq[q][4 * k + 1] = v.y; dq[q][4 * k + 2] = v.z; dq[q][4 * k + 3] = v.w;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int* d = dq[q];
-            const int nl = d[HSU_NG] - d[HSU_I0];         // nodes of the grid from this unit's first on
-            onq[q] = (q == 0 || two) && lane < nl;
-            const int ic = min(lane, nl - 1);             // (lanes past the grid's end: its last node, discarded)
-            icq[q] = ic;
-            lrq[q] = sm[d[HSU_LX] + ic];                  // (0 at the last node)
-            lneq[q] = sm[d[HSU_LNE] + ic];
-            gxq[q] = sm[d[HSU_GX] + ic];
-            ilq[q] = d[HSU_IL] >= 0 ? sm[d[HSU_IL] + ic] : 0.0;
-            int b = 0;
-            if (broken) {
-              const double E = sm[d[HSU_GE] + ic];
-              const double E2 = sm[d[HSU_GE] + min(ic + 1, nl - 1)];
-              b = (E < p.eb ? 1 : 0) | (E2 < p.eb ? 2 : 0);
-            }
-            // (the log-domain synchrotron items read ln w and nothing else of this grid: no
-            // exponential, no expm1 for its nodes -- wave-uniform, a unit is one grid's)
-            if (d[HSU_S2] == 2) b |= 4;
-            bq[q] = b;
-          }
-          HSR_FSTAMP(2);
-          double nnq[2], dshq[2], exq[2];
-          if (two) {
-            const hsr_node2 nd = hsr_pd_core2(D.kind, p.A, p.al, p.be, p.a2, lkb, lneq[0] - lg0,
-                                              lneq[0] - lg1, bq[0], lrq[0], lneq[1] - lg0,
-                                              lneq[1] - lg1, bq[1], lrq[1], t64);
-            nnq[0] = nd.n0; dshq[0] = nd.dsh0; nnq[1] = nd.n1; dshq[1] = nd.dsh1;
-            exq[0] = nd.ex0; exq[1] = nd.ex1;
-          } else {
-            const hsr_node nd = hsr_pd_core(D.kind, p.A, p.al, p.be, p.a2, lneq[0] - lg0,
-                                            lneq[0] - lg1, lkb, bq[0], lrq[0], t64);
-            nnq[0] = nd.n; dshq[0] = nd.dsh; nnq[1] = 0.0; dshq[1] = 0.0;
-            exq[0] = nd.ex; exq[1] = 0.0;
-          }
-          HSR_FSTAMP(3);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            if (q == 1 && !two) break;
-            const int* d = dq[q];
-            const int ic = icq[q];
-            const bool on = onq[q];
-            const bool last = ic + 1 >= d[HSU_NG] - d[HSU_I0];
-            const double nn = nnq[q] * __hiloint2double(d[HSU_SC_HI], d[HSU_SC_LO]);
-            double wv_ = gxq[q] * nn;
-            const double dv = last ? 0.0 : lrq[q] + dshq[q];
-            bool plain = true;  // (wave-uniform)
-            if (SYN && S2 && d[HSU_S2] != 0) {
-              // the log-domain items' Lambda ln|w| + Lambda ln cbrt(1/gamma^2) (nh_syn2.h); a zero
-              // weight (or amplitude) is the floor: an exact 0, and exact zeros for its segments
-              const double lna = lnA + exq[q];  // ln |n|
-              const double lw = fma(HS_S2_LAMBDA, lna, sm[R.o_s2lg + d[HSU_I0] + ic]);
-              // (w = gamma n scale underflows to an exact 0 in the reference below ln w = -744.44:
-              // the floor -- an exact zero node -- from there on)
-              const bool nonzero = lna + lneq[q] > R.s2_lnw0;
-              if (on) sm[d[HSU_S2LW] + ic] = nonzero ? lw : HS_S2_FLOOR;
-              if (d[HSU_S2] == 2) {  // (nobody reads this grid's w / dlw, and gx holds another array)
-                plain = false;
-                wv_ = !(lw < INFINITY) ? lw : (nonzero ? 1.0 : 0.0);  // (what the flags below look at)
-              }
-            }
-            if (plain && on) {
-              sm[d[HSU_W] + ic] = wv_;
-              sm[d[HSU_D] + ic] = dv;
-              if (d[HSU_DP] >= 0) {  // what the non-negative table items read
-                if (d[HSU_IL] >= 0) {  // (1 / lx and the threshold: in LDS since the launch began)
-                  sm[d[HSU_DP] + ic] = dv * ilq[q];
-                } else {
-                  const double il = last ? 0.0 : nh_rcp(lrq[q]);
-                  sm[d[HSU_DP] + ic] = dv * il;
-                  sm[d[HSU_TH] + ic] = NH_SEG_SMALL_POS * il;
-                }
-              }
-            }
-            // (a weight that is not finite -- a far-off walker whose distribution overflows --
-            // makes 0 x inf = NaN of a zero table entry, as in the reference: no row of such a
-            // walker's tables is skipped)
-            if (__builtin_amdgcn_ballot_w64(on && wv_ != 0.0) != 0ull) fl |= 1 << d[HSU_G];
-            if (__builtin_amdgcn_ballot_w64(on && !isfinite(wv_)) != 0ull) fl |= 256 << d[HSU_G];
-          }
-        }
+        int fl = 0;  // (wave-uniform) grids with a non-zero weight | << 8: with one that is not finite
+        for (int u = worker ? rank : u_end; u < u_end; u += 2 * nwork)
+          fl |= hsr_weights_kind<(SYN && S2)>(
+              D.kind, hs_lds_addr(sm + R.o_ut), R.rowsplit ? hs_lds_addr(reinterpret_cast<const double*>(ul)) : 0u,
+              u, nwork, u_end, hs_lds_addr(row), hs_lds_addr(lg), hs_lds_addr(qs + HS_O_LNA),
+              hs_lds_addr(sm + HS_O_T64), R.s2_lnw0);
         HSR_FSTAMP(4);
         fl = __builtin_amdgcn_readfirstlane(fl);
         if (lane == 0 && fl) atomicOr(&hi[HI_NZ], fl);
