@@ -1741,9 +1741,21 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
 // acceptance counters += the accept flags; blob history rows of rejected proposals := the
 // previous step's (emcee keeps the blobs of the position a walker is AT), the current blobs :=
 // the last row.  One thread per (walker, element).
-__global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
-  const hs_dev& D = H.C;
-  const int N = R.N, ndim = H.ndim;
+// (its own small argument block: handed hs_hot and hs_run by value -- 3 KB -- the kernel opened
+// with every field's scalar load and parked 650 of them in vector-register lanes: 12 us for a
+// kernel that moves 5 MB)
+struct hs_epi {
+  int N, ndim, gr, nrank, nblob, spin_limit, report_launch, pad;
+  unsigned seq;
+  int* status; int* done; int* lcnt; volatile int* report;
+  const unsigned long long* ring;
+  double* coords; double* logp;
+  int* nacc; const int* accw; int* hacc;
+  long long hrow0;
+  double* hblob[NH_HS_MAX_BLOB]; double* bcur[NH_HS_MAX_BLOB]; int bm[NH_HS_MAX_BLOB];
+};
+__global__ void k_run_epilogue(const hs_epi R, int nsteps) {
+  const int N = R.N, ndim = R.ndim;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gsz = (long long)gridDim.x * blockDim.x;
   // the three jobs -- ensemble, counters, one per blob -- side by side (blockIdx.y): each is a
@@ -1754,18 +1766,18 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
     // this launch's NaN / forbidden-proposal counts join the plan's counters if -- and only if --
     // it ended well; the report says how the counters stood before (a replay starts from there)
     const int st = *R.status;
-    const int n0 = H.done[2], f0 = H.done[3];
+    const int n0 = R.done[2], f0 = R.done[3];
     if (st == 0) {
-      H.done[2] = n0 + R.lcnt[0];
-      H.done[3] = f0 + R.lcnt[1];
+      R.done[2] = n0 + R.lcnt[0];
+      R.done[3] = f0 + R.lcnt[1];
     }
     R.lcnt[0] = 0;  // (the pair's next user is the launch after next: behind this kernel in the stream)
     R.lcnt[1] = 0;
     if (R.report) {
       volatile int* rp = R.report + 8 * (R.report_launch & 1);
       rp[0] = st;
-      rp[1] = H.done[2];
-      rp[2] = H.done[3];
+      rp[1] = R.done[2];
+      rp[2] = R.done[3];
       rp[4] = n0;
       rp[5] = f0;
       __threadfence_system();
@@ -1775,11 +1787,16 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
   // a launch that gave up (a record never came: nh_half_step_run_status) leaves the flat arrays,
   // the counters and the blob rows as they were before it -- whoever finds the status can replay
   // the block of moves from them
-  if (*R.status != 0) return;
-  for (long long e = job == 0 ? gid : (long long)N * (ndim + 1); e < (long long)N * (ndim + 1); e += gsz) {
-    const int w = (int)(e / (ndim + 1)), d = (int)(e % (ndim + 1));
+  // (the status is ASKED for here and looked at only where a job is about to store: its loads do
+  // not wait for it -- one dependent round trip of three or four less, ~1.5 us each)
+  const int st_now = __hip_atomic_load(R.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (R.nrank > 1 && st_now != 0) return;
+  const unsigned n_ens = (unsigned)N * (unsigned)(ndim + 1);  // (32-bit: nh_half_step_run_create checks)
+  for (unsigned e = job == 0 ? (unsigned)gid : n_ens; e < n_ens; e += (unsigned)gsz) {
+    const int w = (int)(e / (unsigned)(ndim + 1)), d = (int)(e % (unsigned)(ndim + 1));
     const unsigned long long* rec = R.ring + ((long long)nsteps * N + w) * R.gr + 2 * d;
     unsigned long long lo = rec[0], hiw = rec[1];
+    if (st_now != 0) return;
     if (R.nrank > 1) {
       // a shared ensemble: this rank's launch is over, another rank's last movers may not be --
       // their records are recognised by their tags like any other (bounded wait)
@@ -1799,16 +1816,16 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
       }
     }
     const double v = __hiloint2double((int)(unsigned)hiw, (int)(unsigned)lo);
-    if (d < ndim) const_cast<double*>(H.coords)[(long long)w * ndim + d] = v;
-    else const_cast<double*>(H.logp)[w] = v;
+    if (d < ndim) R.coords[(long long)w * ndim + d] = v;
+    else R.logp[w] = v;
   }
-  int* const nacc = R.nrank > 1 ? R.nacc_own : D.naccepted;
+  int* const nacc = R.nacc;
   if (nacc && job == 1)
     for (long long w = gid; w < N; w += gsz) {
       int f[HS_RUN_MAX_STEPS];  // (all the flags asked for at once: one round trip, not nsteps)
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) f[t] = R.accw[(long long)(t < nsteps ? t : nsteps - 1) * N + w];
-      if (R.nrank > 1) {
+      if (R.nrank > 1) {  // (st_now == 0 here)
         // a shared ensemble: { launch number | 1 rejected, 2 accepted } -> -1 not moved by this
         // rank | 0 | 1, also into the history's flags (what the merge of the ranks' rows reads)
 #pragma unroll
@@ -1821,17 +1838,20 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
       int a = 0;
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) a += (t < nsteps && f[t] > 0) ? 1 : 0;
-      nacc[w] += a;
+      const int before = nacc[w];
+      if (st_now != 0) return;
+      nacc[w] = before + a;
     }
   // (a shared ensemble: the blobs of a walker's earlier steps may be on another rank -- the
   // rows of rejected proposals are filled when the ranks' histories are merged)
-  const bool hist = R.hcoords != nullptr && R.nrank <= 1;
-  for (int b = 0; b < D.nblob; ++b) {
-    const nh_hs_blob& bl = D.blob[b];
-    double* hb = hist ? R.hblob[b] : nullptr;
+  for (int b = 0; b < R.nblob; ++b) {
+    double* hb = R.hblob[b];  // (null: no history, or a shared ensemble)
     if (!hb || job != 2 + b) continue;
-    for (long long e = gid; e < (long long)N * bl.m; e += gsz) {
-      const int w = (int)(e / bl.m);
+    const int bm = R.bm[b];
+    double* const bcur = R.bcur[b];
+    const unsigned n_bl = (unsigned)N * (unsigned)bm;
+    for (unsigned e = (unsigned)gid; e < n_bl; e += (unsigned)gsz) {
+      const int w = (int)(e / (unsigned)bm);
       // (every load of the column is issued before the first is used: walked one step at a time
       // the fill was a chain of 2 x nsteps dependent round trips, 24 us for 20 steps)
       double cell[HS_RUN_MAX_STEPS];
@@ -1841,10 +1861,11 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
         // (straight-line, every address valid: steps past the launch's re-read its last one.
         // Behind a condition per step the compiler waited for each load before the next.)
         const long long tt = t < nsteps ? t : nsteps - 1;
-        cell[t] = hb[(R.hrow0 + tt) * (long long)N * bl.m + e];
+        cell[t] = hb[(R.hrow0 + tt) * (long long)N * bm + e];
         fl[t] = R.accw[tt * N + w];
       }
-      double prev = bl.cur[e];
+      double prev = bcur[e];
+      if (st_now != 0) return;
       unsigned acc = 0;  // (first use of any load: after the last one has been issued)
 #pragma unroll
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t) acc |= (t < nsteps && fl[t]) ? 1u << t : 0u;
@@ -1852,9 +1873,9 @@ __global__ void k_run_epilogue(hs_hot H, hs_run R, int nsteps) {
       for (int t = 0; t < HS_RUN_MAX_STEPS; ++t)
         if (t < nsteps) {
           if (acc >> t & 1) prev = cell[t];
-          else hb[(R.hrow0 + t) * (long long)N * bl.m + e] = prev;
+          else hb[(R.hrow0 + t) * (long long)N * bm + e] = prev;
         }
-      bl.cur[e] = prev;
+      bcur[e] = prev;
     }
   }
 }
@@ -1913,6 +1934,8 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
                          H.lo >= 0 && H.lo + H.nloc <= H.ns),
              "a shared ensemble: at most 8 ranks, each with at least one walker of every half-step");
   NH_REQUIRE(H.C.lp == nullptr, "a prior evaluated by a launch of its own cannot ride in the resident loop");
+  for (int b = 0; b < H.C.nblob; ++b)
+    NH_REQUIRE(2LL * H.ns * H.C.blob[b].m < (1LL << 31), "a blob's rows of one step: too large for 32-bit element offsets");
   for (int q = 0; q < H.C.ncomp; ++q)
     NH_REQUIRE(H.C.comp[q].off >= 0, "every component of the model must be produced inside the launch");
   hs_run R;
@@ -2489,7 +2512,20 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     const long long work = (long long)R.N * (H.nE > H.ndim + 1 ? H.nE : H.ndim + 1);
     const int blocks = (int)((work + 255) / 256 < 512 ? (work + 255) / 256 : 512);
     const int jobs = 2 + ((hist_coords && !Q->base) ? H.C.nblob : 0);
-    hipLaunchKernelGGL(k_run_epilogue, dim3(blocks, jobs), dim3(256), 0, c->stream, H, R, nslices / 2);
+    hs_epi E;
+    memset(&E, 0, sizeof(E));
+    E.N = R.N; E.ndim = H.ndim; E.gr = R.gr; E.nrank = R.nrank; E.nblob = H.C.nblob;
+    E.spin_limit = R.spin_limit; E.report_launch = R.report_launch; E.seq = R.seq;
+    E.status = R.status; E.done = H.done; E.lcnt = R.lcnt; E.report = R.report;
+    E.ring = R.ring; E.coords = const_cast<double*>(H.coords); E.logp = const_cast<double*>(H.logp);
+    E.nacc = R.nrank > 1 ? R.nacc_own : H.C.naccepted; E.accw = R.accw; E.hacc = R.hacc;
+    E.hrow0 = R.hrow0;
+    for (int b = 0; b < NH_HS_MAX_BLOB && b < H.C.nblob; ++b) {
+      E.hblob[b] = (R.hcoords != nullptr && R.nrank <= 1) ? R.hblob[b] : nullptr;
+      E.bcur[b] = H.C.blob[b].cur;
+      E.bm[b] = H.C.blob[b].m;
+    }
+    hipLaunchKernelGGL(k_run_epilogue, dim3(blocks, jobs), dim3(256), 0, c->stream, E, nslices / 2);
     NH_CHECK_HIP(hipGetLastError());
   }
   return NH_OK;
