@@ -165,6 +165,78 @@ def test_register_resident_table_items_of_a_three_seed_model(na, monkeypatch, ki
     assert_allclose(runs["host"][1], a[1], rtol=1e-6)
 
 
+@pytest.mark.parametrize("shape", ["syn+ic", "ic"])
+@pytest.mark.parametrize("kind", ["PowerLaw", "ExponentialCutoffPowerLaw", "BrokenPowerLaw",
+                                  "ExponentialCutoffBrokenPowerLaw", "LogParabola"])
+def test_resident_loop_every_particle_distribution(na, monkeypatch, kind, shape):
+    """The resident loop forms a slice's particle weights in a function specialised by the KIND of
+    distribution (hsr_weights<KIND, ...>, round 5); the BASELINE workloads all use the cut-off
+    power law.  Every kind of models.py:49-407, a break inside the grid for the broken ones, in the
+    synchrotron + IC instance (log-domain items: ln w of one grid, w of the others, We as a blob)
+    and in the table-only one (rows in registers): resident loop == one launch per half-step ==
+    the host-driven loop (the class kernels of nh_core.hip: other code)."""
+    from naima_amd.sampler import EnsembleSampler
+    u = na.u
+    _, _, raw, data, _ = _problem(na, "cfg3" if shape == "syn+ic" else "cfg1", {})
+    # pars: log10 amplitude, alpha, log10(e_cutoff or e_break / TeV), B / uG, the second index
+    p0 = np.array([33.2 if shape == "syn+ic" else 33.0, 2.1, 1.2, 12.0, 2.9])
+
+    def pdist(pars):
+        amp, e0 = 10 ** pars[0] / u.eV, 10.0 * u.TeV
+        if kind == "PowerLaw":
+            return na.PowerLaw(amp, e0, pars[1] + 0.6)
+        if kind == "ExponentialCutoffPowerLaw":
+            return na.ExponentialCutoffPowerLaw(amp, e0, pars[1], 10 ** pars[2] * u.TeV)
+        if kind == "BrokenPowerLaw":
+            return na.BrokenPowerLaw(amp, e0, 10 ** pars[2] * u.TeV, pars[1], pars[4])
+        if kind == "ExponentialCutoffBrokenPowerLaw":
+            return na.ExponentialCutoffBrokenPowerLaw(amp, e0, 10 ** (pars[2] - 1.0) * u.TeV, pars[1], pars[4],
+                                                      10 ** (pars[2] + 0.8) * u.TeV)
+        return na.LogParabola(amp, e0, pars[1] + 0.3, 0.1 * pars[4])
+
+    def model(pars, data):
+        pd = pdist(pars)
+        if shape == "ic":
+            IC = na.InverseCompton(pd, seed_photon_fields=["CMB"])
+            return IC.flux(data, distance=1.0 * u.kpc)
+        IC = na.InverseCompton(pd, seed_photon_fields=["CMB", "FIR"], Eemin=100 * u.GeV)
+        SYN = na.Synchrotron(pd, B=pars[3] * u.uG)
+        return (IC.flux(data, distance=1.0 * u.kpc) + SYN.flux(data, distance=1.0 * u.kpc),
+                IC.compute_We(Eemin=1 * u.TeV))
+
+    def prior(pars):
+        return (na.uniform_prior(pars[1], 0.5, 4.0) + na.uniform_prior(pars[2], -1.0, 3.0) +
+                na.uniform_prior(pars[3], 0.1, 100.0) + na.uniform_prior(pars[4], 2.0, 5.0))
+
+    nw, nd = 48, p0.size
+    kw = dict(args=[data, model, prior], seed=5, naima_style=True, store_blobs=True)
+    pos = p0 * (1 + 0.005 * np.random.default_rng(3).standard_normal((nw, nd)))
+    runs = {}
+    for mode in ("resident", "per-launch", "host"):
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", "0" if mode == "per-launch" else "1")
+        d = EnsembleSampler(nw, nd, na.lnprob, device=mode != "host", **kw)
+        st = d.run_mcmc(pos, 3)
+        st = d.run_mcmc(st, 37)
+        if mode == "resident":
+            assert d._dev is not None and d._dev.resident_launches > 0, d._dev.resident_reason
+            info = d._dev.resident_info
+            assert info["syn_log_domain"] == (shape == "syn+ic"), info
+        if mode == "per-launch":
+            assert d._dev.resident_launches == 0 and d._dev.mega
+        runs[mode] = (d.get_chain(), d.get_log_prob(),
+                      [np.asarray(b, dtype=float) for b in d.get_blobs()], d.acceptance_fraction)
+    r = runs["resident"]
+    assert np.isfinite(r[1]).all() and 0.05 < r[3].mean() < 0.95, r[3].mean()
+    assert np.array_equal(runs["per-launch"][0], r[0])  # (the same accept decisions)
+    assert_allclose(runs["per-launch"][1], r[1], rtol=1e-10)
+    for x, y in zip(runs["per-launch"][2], r[2]):
+        assert_allclose(x, y, rtol=1e-10, atol=1e-300)
+    assert_allclose(runs["host"][0], r[0], rtol=1e-8)
+    assert_allclose(runs["host"][1], r[1], rtol=1e-6)
+    for x, y in zip(runs["host"][2], r[2]):
+        assert_allclose(x, y, rtol=1e-8, atol=1e-300)
+
+
 @pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_device_loop_equals_oracle_driven_sampler(na, cfg):
     """>= 4 ensemble steps of the device loop against oracle.stretch_move_reference fed with
