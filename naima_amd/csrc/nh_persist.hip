@@ -840,6 +840,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       HSR_STAMP(0);
       double pval = 0.0;  // (wave 0) this lane's parameter-pack column, once evaluated ...
       int pcol = -1;      // ... and which one it is (-1: none)
+      int slice_bad = 0;  // (wave 0) the records never came
       // ---- A. wave 0: the two records, the proposal, the parameter packs ---------------------
       if (wv == 0) {
         const int g = H.lo + j;
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           if (spins > R.spin_limit) { bad = HS_RUN_ERR_TIMEOUT; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+        slice_bad = bad;
         if (bad) {
           if (lane == 0) {
             hi[HI_TICK] = bad;
@@ -974,8 +976,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       HSR_WSTAMP(0);
       __syncthreads();  // ---------------------------------------------------------------- #1
       HSR_STAMP(2);
-      if (hi[HI_TICK] != 0) return;  // (the whole workgroup: a record never came)
-      if (wv == 0 && pcol >= 0) {
+      // (a record that never came -- hi[HI_TICK]: the whole workgroup leaves.  The table-only
+      // instances with their rows in registers look at it behind barrier 2, with the words every wave
+      // reads there anyway: here it is one more LDS round trip ahead of everybody's weights -- cfg5 /
+      // 256 11.57 -> 11.72 M, cfg1 1.73 -> 1.77 M; what a slice without its records computes until
+      // then is garbage nobody keeps.  The 1024-thread instances measured 0.2 % slower that way.)
+      if (RT == 0 && hi[HI_TICK] != 0) return;
+      if (wv == 0 && pcol >= 0 && !slice_bad) {
         // the packs' rows in HBM, for whoever reads them outside this launch: behind the barrier
         // everybody else was waiting at
         const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
@@ -1274,6 +1281,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       __syncthreads();  // ---------------------------------------------------------------- #2
       HSR_STAMP(3);
       HSR_FSTAMP(6);
+      if (RT > 0 && hi[HI_TICK] != 0) return;  // (a record never came: see behind barrier 1)
       const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
       int nA = 0, Cd = 1, nS = 0;
       if (has_syn) {
