@@ -70,7 +70,7 @@ static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
 // S2: the synchrotron items in the log domain on the grid's comb (nh_syn2.h), as the resident loop
 // runs them -- a log-uniform particle grid; its block in LDS behind H.o_s2 (doubles):
 //   16 header { ilx, th, im, lml, 1/(2 lx), z0, {lm, P}, {nG, -} } | (P + 1) x 6 table | 128 2^(j/128) |
-//   nG Lambda (ln gamma / 3 + ln scale) | nG + 2 GUARD cbrt(1/gamma^2) | nG + 2 GUARD Lambda ln w |
+//   nG Lambda (ln gamma / 3 + ln scale) | nG + 2 GUARD 1/gamma^2 | nG + 2 GUARD Lambda ln w |
 //   4 nE per-energy constants | nE comb indices (ints)
 // the header, the table and the node constants behind the grid's three arrays in F.syn_c.
 #define HS_S2_HDR 16
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     for (int i = tid; i < nGs; i += T) sm[o_s2lg + i] = src[ntb + i];
     for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
       const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
-      sm[o_s2ig + i] = F.syn_c[nGs + ii];
+      sm[o_s2ig + i] = F.syn_c[ii];  // (1 / gamma^2)
       if (i < HS_S2_GUARD || i >= nGs + HS_S2_GUARD) sm[o_s2lw + i] = HS_S2_FLOOR;
     }
   }
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
           const double z = fma(-lnq, hdr[4], hdr[5]);
           const double Zf = floor(z);
           double* s2q = sm + o_s2q;
-          s2q[pos] = sq[nEs + pos];
+          s2q[pos] = lv_q;
           s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
           s2q[2 * nEs + pos] = (z - Zf) * hdr[2];
           s2q[3 * nEs + pos] = p.A < 0.0 ? -cs1 : cs1;

@@ -162,7 +162,7 @@ struct hs_run {
   // ---- the synchrotron items in the log domain, on the grid's comb (nh_syn2.h; syn2 != 0) ----
   int syn2, s2_own;  // s2_own: nobody else reads the synchrotron grid's w / dlw (its LDS is reused)
   int o_s2tab, o_s2lw, o_s2ig, o_s2lg, o_s2q, o_s2z, o_s2t;  // LDS: table | Lambda ln w (guards either side) |
-                                                      // cbrt(1/gamma^2) (guards) | Lambda (ln gamma / 3 +
+                                                      // 1/gamma^2 (guards) | Lambda (ln gamma / 3 +
                                                       // ln scale) | per live energy 4 doubles | comb index | 2^(j/128)
   const double* s2_dev;  // device: the table's (P + 1) x 6 doubles, then the grid's nG values of the above
   hs_syn2_par s2;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       for (int i = tid; i < nGs; i += T) sm[R.o_s2lg + i] = R.s2_dev[ntb + i];
       for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
         const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
-        sm[R.o_s2ig + i] = H.F.syn_c[nGs + ii];
+        sm[R.o_s2ig + i] = H.F.syn_c[ii];  // (1 / gamma^2)
         // ln w of the guard nodes: zeros of their own (the walker's nodes are written every slice)
         if (i < HS_S2_GUARD || i >= nGs + HS_S2_GUARD) sm[R.o_s2lw + i] = HS_S2_FLOOR;
       }
@@ -1126,14 +1126,15 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             amap[pos] = lv_k;
             ai0[pos] = lv_i0;
-            const double cbq = hsr_cbrt(lv_q);
             // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
             const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
                                (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
                                 (lv_E * NH_ERG_PER_EV));
-            sq[pos] = lv_q;
-            sq[nEs + pos] = cbq;
-            sq[2 * nEs + pos] = cs1;
+            if (!S2) {  // (the direct form's operands; the log-domain items take q itself)
+              sq[pos] = lv_q;
+              sq[nEs + pos] = hsr_cbrt(lv_q);
+              sq[2 * nEs + pos] = cs1;
+            }
             if (S2) {
               // where this energy's nodes sit on the comb (nh_syn2.h): node i at z + i steps below
               // T_top, z = Z + f; ln Gtilde's t / 3 + ln 1.808 rides with the energy
@@ -1141,7 +1142,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               const double z = fma(-lnq, R.s2_invd, R.s2_z0);
               const double Zf = floor(z);
               double* s2q = sm + R.o_s2q;
-              s2q[pos] = cbq;
+              s2q[pos] = lv_q;
               s2q[nEs + pos] = (HS_S2_LAMBDA / 3.0) * lnq;  // (ln 1.808 rides in the table)
               s2q[2 * nEs + pos] = (z - Zf) * R.s2.im;
               s2q[3 * nEs + pos] = cs1 * qs[HS_O_LNA + 1];

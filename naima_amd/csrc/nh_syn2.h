@@ -99,9 +99,9 @@ __device__ __forceinline__ int hs_div_small(int x, int d, float rd) {
 
 // One work item: 64 (live photon energy, chunk) pairs.  Per live energy a (compacted, as in
 // hs_syn_item): ai0[a] its first live node, Zs[a] the comb index of node 0, and in sq (nEs
-// apart) cbrt(q) | Lambda ln(q) / 3 | f / m | CS1 (signed by the amplitude).
+// apart) q | Lambda ln(q) / 3 | f / m | CS1 (signed by the amplitude).
 // a_lw / a_ig: LDS byte addresses of node 0 of the walker's Lambda ln(w) and of the grid's
-// cbrt(1/gamma^2) (HS_S2_GUARD entries either side); a_tab: the table, HS_S2_STRIDE doubles per
+// 1/gamma^2 (HS_S2_GUARD entries either side); a_tab: the table, HS_S2_STRIDE doubles per
 // piece, 16-byte aligned; a_t128: 2^(j/128), j < 128.
 __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int nEs,
                                              const hs_syn2_par& S, const int* ai0, const int* Zs,
@@ -118,11 +118,17 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
   int per = hs_div_small(kend - k0 + Cd, Cd, __builtin_amdgcn_rcpf((float)Cd));  // nodes k0 .. kend over Cd chunks ...
   per = ((per + m - 1) >> lm) << lm;          // ... of whole pieces
   const int kb = k0 + ch * per;
+  // The segments' log-ratios stay in the exponents' own unit (1/128 octave): dl' = dE ilx has the
+  // same ilx for every segment of a log-uniform grid, so the sum is taken over (u2 - u1) / dE and
+  // multiplied by 1 / ilx once (one multiplication per node less); |dl'| < th = 2^-10 / lx  <=>
+  // |dE| < th / ilx = 2^-10 128 / ln 2, whatever the grid.
+  double thE = 0x1p-10 * HS_S2_LAMBDA;
+  asm volatile("" : "+s"(thE));  // (a scalar operand of the comparison, not a vector register kept across the loops)
   double acc = 0.0;
   if (kb <= kend) {
     const int n = min(per, kend - kb + 1);
     const int groups = (n + m - 1) >> lm;     // (the last chunk's last piece runs on into the guards)
-    const double cbq = sq[a], Kc = sq[nEs + a], lam0 = sq[2 * nEs + a];
+    const double qx = sq[a], Kc = sq[nEs + a], lam0 = sq[2 * nEs + a];
     double c0, c1, c2, c3, c4, c5;
     auto coefs = [&](int p, int kfirst, double& lam) {  // piece p, whose first node is kfirst
       const int pe = min(p, S.P);
@@ -134,9 +140,7 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
       lam = fma((double)(kfirst - (pe << lm)), S.im, lam0);  // (= f / m inside the table)
     };
     auto node = [&](unsigned pl, unsigned pg, double lam, double& E, double& u) {
-      const double cb = cbq * hs_s2_ld(pg);
-      const double s = cb * cb;
-      const double x = s * cb;
+      const double x = qx * hs_s2_ld(pg);  // (q / gamma^2: one product -- it was the cube of cbrt(q) cbrt(1/gamma^2), three)
       double g = fma(c5, lam, c4);
       g = fma(g, lam, c3);
       g = fma(g, lam, c2);
@@ -158,8 +162,8 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
         double EA, uA, EB, uB;
         node(pl + 8u, pg + 8u, lam, EA, uA);
         node(pl + 16u, pg + 16u, lam + S.im, EB, uB);
-        acc = hs_seg_pre(acc, u1, uA, (EA - E1) * S.ilx, S.th);
-        acc = hs_seg_pre(acc, uA, uB, (EB - EA) * S.ilx, S.th);
+        acc = hs_seg_pre(acc, u1, uA, EA - E1, thE);
+        acc = hs_seg_pre(acc, uA, uB, EB - EA, thE);
         E1 = EB;
         u1 = uB;
         lam += 2.0 * S.im;
@@ -168,7 +172,13 @@ __device__ HS_S2_INLINE void hs_syn2_item(int ix, int lane, int nA, int Cd, int 
       }
     }
   }
-  part_s[ch * nEs + a] = acc * sq[3 * nEs + a];  // linear in u: CS1 once per thread
+  // (linear in u: CS1 once per thread -- and the segments' common 1 / ilx, see thE)
+  // (ilx is a kernel argument: as a loop invariant its reciprocal is formed once per launch, kept in
+  // a vector register pair across every phase of every slice, and spilled -- opaque, it is six
+  // instructions per item)
+  double ilx_here = S.ilx;
+  asm volatile("" : "+v"(ilx_here));
+  part_s[ch * nEs + a] = acc * (sq[3 * nEs + a] * nh_rcp(ilx_here));
 }
 
 // ---- the table of nh_syn2.h, built on the host when the loop is created -------------------------
