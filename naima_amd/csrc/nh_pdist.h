@@ -94,7 +94,9 @@ __device__ __forceinline__ double pd_exp_tab_lds(double x, unsigned t64) {
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   const int k = (int)kf;
-  const double tj = *(pd_lds_cd*)(unsigned long long)(t64 + 8u * (unsigned)(k & 63));
+  unsigned j = (unsigned)(k & 63);
+  asm("" : "+v"(j));  // (v_and + v_lshl_add, not shift + mask + add)
+  const double tj = *(pd_lds_cd*)(unsigned long long)(t64 + (j << 3));
   return (x == x) ? ldexp(tj * p, k >> 6) : x;  // NaN in, NaN out
 }
 

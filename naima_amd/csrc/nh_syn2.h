@@ -75,15 +75,36 @@ __device__ __forceinline__ double hs_s2_ld(unsigned addr) {
 // and (u2 - u1) / ln(u2/u1) divides their difference by |dl| >= 2^-10 (with the 64-entry table
 // of nh_exp_tab and this degree: 4e-14 / 1e-3 = 4e-11 on the segments around the integrand's peak,
 // measured)
+// fma(a, b, c) as ONE three-operand v_fma_f64 whatever it would have written: in the items' inner loop, with the coefficients parked in
+// vector registers across it, every other Horner step came out as v_mov_b64 (a copy of the
+// coefficient) + v_fmac_f64 (which overwrites its addend)
+__device__ __forceinline__ double hs_fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ double hs_fma3c(double a, double b, double c_scalar) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+  return d;
+}
+__device__ __forceinline__ double hs_fma3s(double a, double b_scalar, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_scalar), "v"(c));
+  return d;
+}
 __device__ __forceinline__ double hs_exp128(double v, unsigned t128) {
   const double kf = rint(v);
   const double r = v - kf;  // |r| <= 1/2 (exact)
-  double p = fma(r, 3.583032305400251e-11, 2.646642144433097e-08);  // c^4/24, c^3/6,  c = ln2/128
-  p = fma(p, r, 1.4662262387640425e-05);                           // c^2/2
-  p = fma(p, r, 5.4152123481245725e-03);                           // c
+  double p = hs_fma3s(r, 3.583032305400251e-11, 2.646642144433097e-08);  // c^4/24, c^3/6,  c = ln2/128
+  p = hs_fma3c(p, r, 1.4662262387640425e-05);                          // c^2/2
+  p = hs_fma3c(p, r, 5.4152123481245725e-03);                          // c
   p = fma(p, r, 1.0);
   const int k = (int)kf;
-  return ldexp(hs_s2_ld(t128 + 8u * (unsigned)(k & 127)) * p, k >> 7);
+  // (v_and + v_lshl_add: left to itself the compiler shifts first, masks with 0x3f8 and adds -- three)
+  unsigned j = (unsigned)(k & 127);
+  asm("" : "+v"(j));
+  return ldexp(hs_s2_ld(t128 + (j << 3)) * p, k >> 7);
 }
 
 // floor(x / d) for 0 <= x < 2^20, 1 <= d < 2^12 with d's reciprocal given in single precision: a
