@@ -206,10 +206,13 @@ __device__ __forceinline__ double hs_wave_sum(double v) {
 
 typedef unsigned int hs_u32x4 __attribute__((ext_vector_type(4)));
 // one 16-byte element {K[i][k], dlnK[i][k]} of the interleaved table
+// (byte_off: the lane's; row_off: wave-uniform -- it rides in the instruction's scalar offset, where
+// the rows of a trip, a multiple of the table's row apart, used to cost a v_add_u32 each: one
+// vector instruction of a segment's eleven)
 __device__ __forceinline__ void hs_buf_kd(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double& K,
-                                          double& d) {
+                                          double& d, unsigned row_off = 0u) {
   typedef double hs_f64x2 __attribute__((ext_vector_type(2)));
-  const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  const hs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, row_off, 0);
   const hs_f64x2 kd = __builtin_bit_cast(hs_f64x2, v);  // (register pairs as loaded: no moves)
   K = kd.x;
   d = kd.y;
@@ -280,7 +283,7 @@ __device__ __forceinline__ double hs_table_item_v(unsigned kd_lo, unsigned kd_hi
   for (; s + 8 <= s1; s += 8) {
     double K2[8], dK[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
+    for (int q = 0; q < 8; ++q) hs_buf_kd(rKD, ob, K2[q], dK[q], (q + 1) * rowb);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const double u2 = hs_lds_at(aw, q + 1) * K2[q];
@@ -298,7 +301,7 @@ __device__ __forceinline__ double hs_table_item_v(unsigned kd_lo, unsigned kd_hi
   if (s < s1) {  // tail: the remaining (< 8) nodes in one trip; rows past the table read 0
     double K2[7], dK[7];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, K2[q], dK[q]);
+    for (int q = 0; q < 7; ++q) hs_buf_kd(rKD, ob, K2[q], dK[q], (q + 1) * rowb);
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
       if (s + q < s1) {
@@ -368,7 +371,7 @@ __device__ __forceinline__ double hs_table_item_packed_v(unsigned kd_lo, unsigne
   // name instead of being copied (eight 64-bit moves per trip otherwise).
   double KA[PK], dA[PK], KB[PK], dB[PK];
 #pragma unroll
-  for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+  for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob, KA[q], dA[q], (q + 1) * rowb);
   double u1 = hs_lds_at(aw, 0) * K1;
   const int owed = se - sl;  // segments of this lane's sub-range (<= 0: idle from the start)
   int done = 0;              // (wave-uniform: lives in an SGPR)
@@ -392,14 +395,14 @@ __device__ __forceinline__ double hs_table_item_packed_v(unsigned kd_lo, unsigne
     ob += PK * rowb;
     if (q0 + PK < len) {
 #pragma unroll
-      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KB[q], dB[q]);
+      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob, KB[q], dB[q], (q + 1) * rowb);
     }
     trip(KA, dA);
     if (q0 + PK >= len) break;
     ob += PK * rowb;
     if (q0 + 2 * PK < len) {
 #pragma unroll
-      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob + (q + 1) * rowb, KA[q], dA[q]);
+      for (int q = 0; q < PK; ++q) hs_buf_kd(rKD, ob, KA[q], dA[q], (q + 1) * rowb);
     }
     trip(KB, dB);
   }
