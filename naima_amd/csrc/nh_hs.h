@@ -189,6 +189,16 @@ __device__ __forceinline__ double hs_dpp_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 // (lanes a shift does not reach read 0: bound_ctrl off and old = 0 -- adding 0.0 / 0)
+// the sum of an int over the wave, in lane 63 (row shifts, two row broadcasts: no LDS round trip)
+__device__ __forceinline__ int hs_wave_sum_i32_dpp(int c) {
+  c += hs_dpp_i32<0x111, 0xf, 0xf>(c);   // row_shr:1
+  c += hs_dpp_i32<0x112, 0xf, 0xf>(c);   // row_shr:2
+  c += hs_dpp_i32<0x114, 0xf, 0xe>(c);   // row_shr:4
+  c += hs_dpp_i32<0x118, 0xf, 0xc>(c);   // row_shr:8
+  c += hs_dpp_i32<0x142, 0xa, 0xf>(c);   // row_bcast:15
+  c += hs_dpp_i32<0x143, 0xc, 0xf>(c);   // row_bcast:31
+  return c;
+}
 __device__ __forceinline__ void hs_wave_sum_dpp(double& a, int& c) {
   a += hs_dpp_f64<0x111, 0xf, 0xf>(a);  c += hs_dpp_i32<0x111, 0xf, 0xf>(c);   // row_shr:1
   a += hs_dpp_f64<0x112, 0xf, 0xf>(a);  c += hs_dpp_i32<0x112, 0xf, 0xf>(c);   // row_shr:2

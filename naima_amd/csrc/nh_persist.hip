@@ -137,6 +137,7 @@ struct hs_run {
   // kernel-argument segment one dependent scalar load at a time (four round trips per component)
   int o_sum, o_cmp;
   int o_pci;  // LDS: per prior term the proposed coordinate it reads, or -1 (ints)
+  int o_synce;  // LDS: CS1 / B per photon energy (walker-independent: a division per live energy and slice otherwise)
   // K workgroups of a table-only walker split the grid's ROWS (nh_halfstep.hip: the plan's
   // rowsplit): workgroup `part` owns the nodes [b_part, b_part+1] -- the boundaries sit between
   // two of the table's chunks -- forms the weights there, reduces its chunks and its part of the
@@ -509,7 +510,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       reinterpret_cast<int*>(sm + R.o_pci)[t] = ci;
     }
     if (has_syn) {
-      for (int k = tid; k < H.syn_nE; k += T) sm[H.o_synE + k] = H.syn_E[k];
+      for (int k = tid; k < H.syn_nE; k += T) {
+        const double E = H.syn_E[k];
+        sm[H.o_synE + k] = E;
+        // CS1 / B = sqrt(3) e^3 / (2 pi m_e c^2 hbar E)          radiative.py:319-328
+        sm[R.o_synce + k] = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS)) /
+                            (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS * (E * NH_ERG_PER_EV));
+      }
       const int nGs = H.F.syn_nG;
       for (int i = tid; i < nGs; i += T) {
         sm[H.o_ig2 + i] = H.F.syn_c[i];
@@ -1053,7 +1060,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         // x = E/Ec,  Ec = 3 e hbar B gamma^2 / (2 m_e c)         radiative.py:331-334
         // (the division: on the tile waves only -- thirty dependent instructions at the head of
         // every other wave's weights otherwise)
-        qfac = NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS * Bw);
+        // (1 / B by v_rcp_f64 and two Newton steps: a last-place difference in q, nothing a spectrum
+        // sees; a field that is not positive and finite makes the spectrum NaN whatever q is, below)
+        qfac = (NH_ERG_PER_EV * (2.0 * (NH_M_E_G * NH_C_CGS)) / (3.0 * NH_E_GAUSS * NH_HBAR_CGS)) * nh_rcp(Bw);
         const int nG = H.nG[H.syn_grid];
         const double* ig2 = sm + H.o_ig2;
         const int t = nwv - 1 - wv;
@@ -1076,8 +1085,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             const double r = fma(lv_lnq, R.s2_invd, R.s2_r746);
             if (r == r) {
               int c = r > 0.0 ? (r < (double)nG ? (int)r : nG) : 0;
-              while (c > 0 && lv_q * ig2[c - 1] <= 746.0) --c;
-              while (c < nG && !(lv_q * ig2[c] <= 746.0)) ++c;
+              // (both neighbours of the estimate asked for at once: it is right, or one off, and the
+              // two reads one after the other were two LDS round trips of this wave's chain)
+              const double xa = lv_q * ig2[max(c - 1, 0)], xb = lv_q * ig2[min(c, nG - 1)];
+              if (!(c > 0 && c < nG && !(xa <= 746.0) && xb <= 746.0)) {
+                while (c > 0 && lv_q * ig2[c - 1] <= 746.0) --c;
+                while (c < nG && !(lv_q * ig2[c] <= 746.0)) ++c;
+              }
               lo = c;
             } else {
               // (a field that is not positive: ln q is NaN -- the search itself, whose answer for a
@@ -1098,9 +1112,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         lv_live = lv_i0 < nG;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(lv_live);
         int ln = lv_live ? (nG - 1) - lv_i0 : 0;  // segments this energy walks
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ln += __shfl_down(ln, off, 64);
-        if (lane == 0) {
+        ln = hs_wave_sum_i32_dpp(ln);  // (the total: in lane 63)
+        if (lane == 63) {
           tcnt[t] = __popcll(m);
           if (ln > 0) atomicAdd(&hi[HI_LIVE], ln);
         }
@@ -1127,9 +1140,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             amap[pos] = lv_k;
             ai0[pos] = lv_i0;
             // CS1 = sqrt(3) e^3 B / (2 pi m_e c^2 hbar E)          radiative.py:319-328
-            const double cs1 = (1.7320508075688772 * (NH_E_GAUSS * NH_E_GAUSS * NH_E_GAUSS) * Bw) /
-                               (2.0 * NH_PI * NH_M_E_G * (NH_C_CGS * NH_C_CGS) * NH_HBAR_CGS *
-                                (lv_E * NH_ERG_PER_EV));
+            const double cs1 = Bw * sm[R.o_synce + lv_k];
             if (!S2) {  // (the direct form's operands; the log-domain items take q itself)
               sq[pos] = lv_q;
               sq[nEs + pos] = hsr_cbrt(lv_q);
@@ -2026,6 +2037,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     R.o_sum = take(ncols, false);
     R.o_cmp = take(2 * NH_MAX_COMP + 2, false);
     R.o_pci = take((NH_MAX_PRIOR + 1) / 2, false);
+    R.o_synce = H.syn_grid >= 0 ? take(H.syn_nE, false) : -1;
     {
       int nun = 0;
       for (int g = 0; g < H.ngrids; ++g) nun += (H.nG[g] + 63) / 64;
