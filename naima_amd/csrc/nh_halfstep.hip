@@ -500,13 +500,13 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     s2P = __builtin_amdgcn_readfirstlane(lmP.y);
     const int ntb = HS_S2_HDR + (s2P + 1) * HS_S2_STRIDE;
     o_s2t = o + ntb;
-    o_s2lg = o_s2t + 128;
+    o_s2lg = o_s2t + HS_S2_TN;
     o_s2ig = o_s2lg + nGs;
     o_s2lw = o_s2ig + nGs + 2 * HS_S2_GUARD;
     o_s2q = o_s2lw + nGs + 2 * HS_S2_GUARD;
     o_s2z = o_s2q + 4 * H.syn_nE;
     for (int i = tid; i < ntb; i += T) sm[o + i] = src[i];
-    if (tid < 128) sm[o_s2t + tid] = exp2((double)tid * 0.0078125);
+    for (int i = tid; i < HS_S2_TN; i += T) sm[o_s2t + i] = exp2((double)i * (1.0 / HS_S2_TN));
     for (int i = tid; i < nGs; i += T) sm[o_s2lg + i] = src[ntb + i];
     for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
       const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
@@ -1610,7 +1610,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
               off * 8.0 / 1024, split);
     if (ok) {
       const int o = off + (off & 1);  // (the pieces are read as ds_read_b128)
-      const int need = HS_S2_HDR + (s2h.par.P + 1) * HS_S2_STRIDE + 128 + nGs + 2 * (nGs + 2 * HS_S2_GUARD) +
+      const int need = HS_S2_HDR + (s2h.par.P + 1) * HS_S2_STRIDE + HS_S2_TN + nGs + 2 * (nGs + 2 * HS_S2_GUARD) +
                        4 * d->syn.nE + (d->syn.nE + 1) / 2 + 1;
       if ((size_t)(o + need) * sizeof(double) <= 160 * 1024) {  // (a CU's LDS; the plan's own layout keeps to 150 KB)
         H.o_s2 = o;

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     if (SYN && S2) {
       const int nGs = H.F.syn_nG, ntb = (R.s2.P + 1) * HS_S2_STRIDE;
       for (int i = tid; i < ntb; i += T) sm[R.o_s2tab + i] = R.s2_dev[i];
-      if (tid < 128) sm[R.o_s2t + tid] = exp2((double)tid * 0.0078125);
+      for (int i = tid; i < HS_S2_TN; i += T) sm[R.o_s2t + i] = exp2((double)i * (1.0 / HS_S2_TN));
       for (int i = tid; i < nGs; i += T) sm[R.o_s2lg + i] = R.s2_dev[ntb + i];
       for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
         const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
@@ -2098,7 +2098,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
         s2_host[(size_t)(P + 1) * HS_S2_STRIDE + i] =
             (double)((long double)HS_S2_LAMBDA * (logl((long double)gam[i]) / 3.0L + logl((long double)H.scale[H.syn_grid])));
       R.s2.lm = lm; R.s2.P = P; R.s2.nG = nG; R.s2.pad = 0;
-      R.s2.ilx = (double)(0.00541521234812457272982L / lx);  // (ln 2 / 128) / lx
+      R.s2.ilx = (double)(HS_S2_C / lx);  // (ln 2 / 1024) / lx
       R.s2.th = (double)((long double)NH_SEG_SMALL_POS / lx);
       R.s2.im = 1.0 / m;
       R.s2.lml = (double)(m - 1) / m;
@@ -2133,7 +2133,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
       }
       R.o_s2q = take(4 * H.syn_nE, false);
       R.o_s2z = take((H.syn_nE + 1) / 2, false);
-      R.o_s2t = take(128, false);
+      R.o_s2t = take(HS_S2_TN, false);
       if ((size_t)off * sizeof(double) <= 160 * 1024) {
         R.syn2 = 1;
       } else {

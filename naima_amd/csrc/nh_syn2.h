@@ -43,7 +43,10 @@
 #define HS_S2_TTOP 7.0       // top of the table in t = ln x: above ln(746 e^h) for every h used
 #define HS_S2_TBOT (-46.0)   // below it g = ln 1.808 + t / 3 to 5e-14: the last piece, linear
 #define HS_S2_GUARD 16       // guard nodes either side of the walker's ln w and the grid's cube roots
-#define HS_S2_LAMBDA 184.6649652337873  // 128 / ln 2
+#define HS_S2_TBITS 10       // the exponential's table: 2^(j / 1024), 8 KB of LDS -- a degree-3 remainder (128 entries: degree 4)
+#define HS_S2_TN (1 << HS_S2_TBITS)
+#define HS_S2_LAMBDA 1477.3197218702985  // 1024 / ln 2
+#define HS_S2_C 0.00067690154351557159L  // ln 2 / 1024
 // ln w of a zero weight and of the guard nodes: hs_exp128 gives an exact 0 (the integer conversion
 // saturates), and the log-ratio to a finite neighbour is beyond the single-precision range, where
 // nh_rcp1f returns 0 -- the segment between a zero node and its neighbour is an exact 0, as
@@ -96,15 +99,14 @@ __device__ __forceinline__ double hs_fma3s(double a, double b_scalar, double c) 
 __device__ __forceinline__ double hs_exp128(double v, unsigned t128) {
   const double kf = rint(v);
   const double r = v - kf;  // |r| <= 1/2 (exact)
-  double p = hs_fma3s(r, 3.583032305400251e-11, 2.646642144433097e-08);  // c^4/24, c^3/6,  c = ln2/128
-  p = hs_fma3c(p, r, 1.4662262387640425e-05);                          // c^2/2
-  p = hs_fma3c(p, r, 5.4152123481245725e-03);                          // c
+  double p = hs_fma3s(r, 5.169222938345892e-11, 2.2909784980688163e-07);  // c^3/6, c^2/2,  c = ln2/1024
+  p = hs_fma3c(p, r, 6.769015435155716e-04);                              // c
   p = fma(p, r, 1.0);
   const int k = (int)kf;
   // (v_and + v_lshl_add: left to itself the compiler shifts first, masks with 0x3f8 and adds -- three)
-  unsigned j = (unsigned)(k & 127);
+  unsigned j = (unsigned)(k & (HS_S2_TN - 1));
   asm("" : "+v"(j));
-  return ldexp(hs_s2_ld(t128 + (j << 3)) * p, k >> 7);
+  return ldexp(hs_s2_ld(t128 + (j << 3)) * p, k >> HS_S2_TBITS);
 }
 
 // floor(x / d) for 0 <= x < 2^20, 1 <= d < 2^12 with d's reciprocal given in single precision: a
@@ -277,7 +279,7 @@ static inline bool hs_s2_prepare(const double* gam, int nG, double scale, hs_s2_
     o.data[(size_t)(P + 1) * HS_S2_STRIDE + i] =
         (double)((long double)HS_S2_LAMBDA * (logl((long double)gam[i]) / 3.0L + logl((long double)scale)));
   o.par.lm = lm; o.par.P = P; o.par.nG = nG; o.par.pad = 0;
-  o.par.ilx = (double)(0.00541521234812457272982L / lx);  // (ln 2 / 128) / lx
+  o.par.ilx = (double)(HS_S2_C / lx);  // (ln 2 / 1024) / lx
   o.par.th = (double)((long double)NH_SEG_SMALL_POS / lx);
   o.par.im = 1.0 / m;
   o.par.lml = (double)(m - 1) / m;
