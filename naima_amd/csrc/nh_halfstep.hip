@@ -69,9 +69,9 @@ static_assert(sizeof(hs_first) == 256 && offsetof(hs_first, qT) == 224 &&
 // cfg5) -- the synchrotron items' registers are not there to be allocated around
 // S2: the synchrotron items in the log domain on the grid's comb (nh_syn2.h), as the resident loop
 // runs them -- a log-uniform particle grid; its block in LDS behind H.o_s2 (doubles):
-//   16 header { ilx, th, im, lml, 1/(2 lx), z0, {lm, P}, {nG, -} } | (P + 1) x 6 table | 128 2^(j/128) |
-//   nG Lambda (ln gamma / 3 + ln scale) | nG + 2 GUARD 1/gamma^2 | nG + 2 GUARD Lambda ln w |
-//   4 nE per-energy constants | nE comb indices (ints)
+//   16 header { ilx, th, im, lml, 1/(2 lx), z0, {lm, P}, {nG, -} } | (P + 1) x 6 table | 1024 2^(j/1024) |
+//   nG Lambda (ln gamma / 3 + ln scale) | nG + 2 GUARD Lambda ln w | 4 nE per-energy constants |
+//   nE comb indices (ints); 1 / gamma^2 with its guards: where the direct form keeps dig2 | ig23
 // the header, the table and the node constants behind the grid's three arrays in F.syn_c.
 #define HS_S2_HDR 16
 __device__ __attribute__((noinline)) double hs_log_ool(double x) { return log(x); }
@@ -478,15 +478,21 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       lik[4 * H.nE + k] = (double)H.ul[k];
     }
   }
+  // (the log-domain instance reads 1 / gamma^2 and nothing else of these: the two arrays of the
+  // direct form -- adjacent -- hold its guarded copy, o_s2ig below)
   if (tid < F.syn_nG) {
     sm[H.o_ig2 + tid] = sc0;
-    sm[H.o_ig23 + tid] = sc1;
-    sm[H.o_dig2 + tid] = sc2;
+    if (!(SYN && S2)) {
+      sm[H.o_ig23 + tid] = sc1;
+      sm[H.o_dig2 + tid] = sc2;
+    }
   }
   for (int i = tid + T; i < F.syn_nG; i += T) {  // a grid longer than the workgroup
     sm[H.o_ig2 + i] = F.syn_c[i];
-    sm[H.o_ig23 + i] = F.syn_c[F.syn_nG + i];
-    sm[H.o_dig2 + i] = F.syn_c[2 * F.syn_nG + i];
+    if (!(SYN && S2)) {
+      sm[H.o_ig23 + i] = F.syn_c[F.syn_nG + i];
+      sm[H.o_dig2 + i] = F.syn_c[2 * F.syn_nG + i];
+    }
   }
   // (S2) the log-domain items' table and node constants: one more batch of loads, used after the
   // weights' barrier
@@ -501,8 +507,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     const int ntb = HS_S2_HDR + (s2P + 1) * HS_S2_STRIDE;
     o_s2t = o + ntb;
     o_s2lg = o_s2t + HS_S2_TN;
-    o_s2ig = o_s2lg + nGs;
-    o_s2lw = o_s2ig + nGs + 2 * HS_S2_GUARD;
+    o_s2ig = H.o_dig2;  // (dig2, ig23: 2 nG >= nG + 2 guards doubles in a row, hs_s2_prepare's nG >= 2 guards)
+    o_s2lw = o_s2lg + nGs;
     o_s2q = o_s2lw + nGs + 2 * HS_S2_GUARD;
     o_s2z = o_s2q + 4 * H.syn_nE;
     for (int i = tid; i < ntb; i += T) sm[o + i] = src[i];
@@ -1610,7 +1616,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
               off * 8.0 / 1024, split);
     if (ok) {
       const int o = off + (off & 1);  // (the pieces are read as ds_read_b128)
-      const int need = HS_S2_HDR + (s2h.par.P + 1) * HS_S2_STRIDE + HS_S2_TN + nGs + 2 * (nGs + 2 * HS_S2_GUARD) +
+      const int need = HS_S2_HDR + (s2h.par.P + 1) * HS_S2_STRIDE + HS_S2_TN + nGs + (nGs + 2 * HS_S2_GUARD) +
                        4 * d->syn.nE + (d->syn.nE + 1) / 2 + 1;
       if ((size_t)(o + need) * sizeof(double) <= 160 * 1024) {  // (a CU's LDS; the plan's own layout keeps to 150 KB)
         H.o_s2 = o;
