@@ -566,6 +566,10 @@ int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
  * arrive sums the partial spectra in index order and evaluates the likelihood: the results do
  * not depend on arrival order).  NH_HS_SPLIT=<K> in the environment caps K (1: never split). */
 int nh_half_step_split(const nh_halfstep_plan* plan, int* split);
+/* How the plan's launches integrate the synchrotron component (radiative.py:282-342): *form = 0 no
+ * such component, 1 the direct form (nh_syn.h), 2 the log-domain form on the grid's comb
+ * (nh_syn2.h: a log-uniform particle grid whose table fits in LDS beside the model's). */
+int nh_half_step_syn_form(const nh_halfstep_plan* plan, int* form);
 /* NaN log-probabilities the accepts of the separate kernels (nh_lnprob / ..._lnprob with a move,
  * nh_move_accept, nh_move_accept_rows) have met since the last reset: emcee raises
  * ValueError("Probability function returned NaN") at the first one (EnsembleSampler.

@@ -114,6 +114,7 @@ _SIGS = {
     "nh_half_step_launch": [_dp, _dp, _i],
     "nh_half_step_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_split": [_dp, C.POINTER(_i)],
+    "nh_half_step_syn_form": [_dp, C.POINTER(_i)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_nan_count": [_dp, _i, C.POINTER(_i)],
     "nh_half_step_nan_count": [_dp, _dp, _i, C.POINTER(_i)],

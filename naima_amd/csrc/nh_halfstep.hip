@@ -1791,6 +1791,12 @@ extern "C" int nh_half_step_info(const nh_halfstep_plan* P, int* threads, int* b
   return NH_OK;
 }
 
+extern "C" int nh_half_step_syn_form(const nh_halfstep_plan* P, int* form) {
+  NH_REQUIRE(P && form, "bad argument");
+  *form = P->hot.syn_grid < 0 ? 0 : (P->hot.o_s2 ? 2 : 1);
+  return NH_OK;
+}
+
 extern "C" int nh_half_step_split(const nh_halfstep_plan* P, int* split) {
   NH_REQUIRE(P && split, "bad argument");
   *split = P->split;

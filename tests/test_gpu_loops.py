@@ -108,6 +108,13 @@ def test_cfg4_at_its_baseline_ensemble_size(na):
         sh, sd = h.run_mcmc(pos, 2), d.run_mcmc(pos, 2)
         sh, sd = h.run_mcmc(sh, 6), d.run_mcmc(sd, 6)
     assert d._dev is not None and d.device
+    # (the launch that integrates both synchrotron spectra -- 361 energies over 869 nodes: the
+    # log-domain form with its table in LDS, not the direct form it falls back to when LDS is short)
+    import ctypes as C
+    from naima_amd import _lib
+    form = C.c_int(0)
+    _lib._chk(_lib._lib.nh_half_step_syn_form(d._dev._plan["stage"]["plan"], C.byref(form)))
+    assert form.value == 2, form.value
     assert_allclose(d.get_chain(), h.get_chain(), rtol=1e-8)
     lh, ld = h.get_log_prob(), d.get_log_prob()
     assert np.array_equal(np.isinf(ld), np.isinf(lh))
