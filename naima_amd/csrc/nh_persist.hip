@@ -1424,6 +1424,20 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                                                 (unsigned)e1.y + o8, (unsigned)e1.z + o8, lane);
             }
             part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
+          } else if (RT > 0 && is_tab && __builtin_amdgcn_readfirstlane(rt.ix) == ix &&
+                     !(nz >> (8 + __builtin_amdgcn_readfirstlane(rt.tile)) & 1)) {
+            // The wave's own item, its rows in registers since the launch began (every slice but
+            // one whose weights are not finite): nothing of the item is looked up again -- the
+            // lookup below walks the by-value argument block (D.tab[t]: dependent loads from the
+            // kernel-argument segment, a division, the trailer), which at one item per wave and
+            // slice was most of these instances' items phase.
+            const int tg = __builtin_amdgcn_readfirstlane(rt.tile);
+            double acc = 0.0;
+            if (nz >> tg & 1)
+              acc = __builtin_amdgcn_readfirstlane(rt.pre) != 0
+                        ? hs_rt_compute<(RT > 0 ? RT : 1), false>(rt)  // (the rows are in registers)
+                        : hs_rt_compute<(RT > 0 ? RT : 1), true>(rt);
+            part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
           } else if (RT > 0 && is_tab) {
             int t = 0;
             while (t + 1 < D.ntab && ix >= D.tab[t + 1].item0) ++t;
