@@ -493,37 +493,77 @@ __device__ __forceinline__ bool hs_rt_load(hs_rt_item<RT>& c, const hs_tab& t, c
 
 // SIGNED = false: a non-negative table on pre-divided log-ratios (ds = dlw / lx, lxs = 2^-10 / lx);
 // true: any table (ds = dlw, lxs = lx; a sign change is a NaN log-ratio: nh_seg_signed)
+// A segment's term WITHOUT its rare branches (the series for |dl| < 2^-10, which the caller takes
+// for a whole group of segments at once): SIGNED as nh_seg_signed (ds = dlw, lx in `l`), else as
+// hs_seg_pre (pre-divided log-ratios, the threshold 2^-10 / lx in `l`)
+template <bool SIGNED>
+__device__ __forceinline__ double hs_seg_fast(double u1, double u2, double dl, double l, bool& small) {
+  if (SIGNED) {
+    const double t = ((u2 - u1) * l) * nh_rcp1f(dl);
+    small = fabs(dl) < NH_SEG_SMALL_POS;  // (false for NaN)
+    return (dl == dl) ? t : u1 * l;
+  }
+  small = fabs(dl) < l;
+  return (u2 - u1) * nh_rcp1f(dl);
+}
+template <bool SIGNED>
+__device__ __forceinline__ double hs_seg_exact(double u1, double u2, double dl, double l) {
+  return SIGNED ? nh_seg_signed(u1, u2, dl, l) : hs_seg_pre(0.0, u1, u2, dl, l);
+}
+
+// Segments in GROUPS of four: a segment's rare branch (behind a ballot) ends the scheduler's view,
+// so with one per segment the four dependent chains of a group -- log-ratio, reciprocal seed,
+// Newton step, term: ~60 cycles each -- ran one after the other; with two waves per SIMD (the
+// 512-thread instances that keep their rows in registers) nobody else filled the gaps.  One ballot
+// per group: the chains interleave.
 template <int RT, bool SIGNED>
 __device__ __forceinline__ double hs_rt_compute(const hs_rt_item<RT>& c) {
   double acc = 0.0;
   double u1 = hs_lds_at(c.aw, 0) * c.K[0], d1 = c.d[0];
   const int len = __builtin_amdgcn_readfirstlane(c.len);  // (scalar branches below, no exec masks)
   const int sub = __builtin_amdgcn_readfirstlane(c.sub);
-  if (sub > 1) {  // hs_table_item_packed: terms added, lanes past their sub-range masked
+  const bool packed = sub > 1;  // hs_table_item_packed: lanes past their sub-range masked
 #pragma unroll
-    for (int q = 0; q < RT - 1; ++q)
-      if (q < len) {
-        const double u2 = hs_lds_at(c.aw, q + 1) * c.K[q + 1];
-        const double dl = hs_lds_at(c.ad, q) + d1;
-        const double term = SIGNED ? nh_seg_signed(u1, u2, dl, hs_lds_at(c.al, q))
-                                   : hs_seg_pre(0.0, u1, u2, dl, hs_lds_at(c.al, q));
-        acc += q < c.owed ? term : 0.0;
-        u1 = u2;
-        d1 = c.d[q + 1];
+  for (int q0 = 0; q0 < RT - 1; q0 += 4) {
+    if (q0 + 4 <= len && q0 + 4 <= RT - 1) {
+      double uu[5], dd[4], ll[4], t[4];
+      bool sm[4];
+      uu[0] = u1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uu[g + 1] = hs_lds_at(c.aw, q0 + g + 1) * c.K[q0 + g + 1];
+        dd[g] = hs_lds_at(c.ad, q0 + g) + (g == 0 ? d1 : c.d[q0 + g]);
+        ll[g] = hs_lds_at(c.al, q0 + g);
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) t[g] = hs_seg_fast<SIGNED>(uu[g], uu[g + 1], dd[g], ll[g], sm[g]);
+      if (__builtin_amdgcn_ballot_w64(sm[0] || sm[1] || sm[2] || sm[3]) != 0ull) {
+        asm volatile("" ::: "memory");  // keep this a branch
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t[g] = hs_seg_exact<SIGNED>(uu[g], uu[g + 1], dd[g], ll[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc += (!packed || q0 + g < c.owed) ? t[g] : 0.0;
+      u1 = uu[4];
+      d1 = c.d[q0 + 4 < RT ? q0 + 4 : RT - 1];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q = q0 + g;
+        if (q < RT - 1 && q < len) {
+          const double u2 = hs_lds_at(c.aw, q + 1) * c.K[q + 1];
+          const double dl = hs_lds_at(c.ad, q) + d1;
+          const double term = hs_seg_exact<SIGNED>(u1, u2, dl, hs_lds_at(c.al, q));
+          acc += (!packed || q < c.owed) ? term : 0.0;
+          u1 = u2;
+          d1 = c.d[q + 1];
+        }
+      }
+    }
+  }
+  if (packed) {
     const int nKp = __builtin_amdgcn_readfirstlane(c.nKp);
     for (int off = 32; off >= nKp; off >>= 1) acc += __shfl_down(acc, off, 64);
-  } else {  // hs_table_item: the term joins the sum in the reciprocal's last FMA
-#pragma unroll
-    for (int q = 0; q < RT - 1; ++q)
-      if (q < len) {
-        const double u2 = hs_lds_at(c.aw, q + 1) * c.K[q + 1];
-        const double dl = hs_lds_at(c.ad, q) + d1;
-        if (SIGNED) acc += nh_seg_signed(u1, u2, dl, hs_lds_at(c.al, q));
-        else acc = hs_seg_pre(acc, u1, u2, dl, hs_lds_at(c.al, q));
-        u1 = u2;
-        d1 = c.d[q + 1];
-      }
   }
   return acc;
 }
