@@ -451,7 +451,7 @@ template <int RT>
 struct hs_rt_item {
   double K[RT], d[RT];   // node q of this lane's sub-range: K and the log-ratio of the segment that starts there
   int ix;                // the item (index into the partial sums), or -1: this wave has none / not cached
-  int t, tile, len, owed, nKp, sub, pre;
+  int t, tile, len, owed, nKp, sub, pre, slot;
   unsigned aw, ad, al;   // LDS byte addresses of w | dlw / lx | 2^-10 / lx at the lane's first segment
 };
 

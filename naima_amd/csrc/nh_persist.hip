@@ -817,6 +817,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                                         sm + (pre ? H.o_dp[tg] : H.o_d[tg]),
                                         sm + (pre ? H.o_th[tg] : H.o_lx[tg]))) {
         rt.ix = item;
+        rt.slot = (K > 1 && R.tcompact) ? wv : item;
         rt.t = t;
         rt.tile = tg;  // (the grid: what the slice's non-zero mask is indexed by)
         rt.pre = pre ? 1 : 0;
@@ -1348,6 +1349,27 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         double* part_t = sm + H.o_part_t;
         double* part_s = sm + H.o_part_s;
         bool rt_first = true;
+        if constexpr (RT > 0) {
+          // The wave's own item, its rows in registers since the launch began (every slice but one
+          // whose weights are not finite): NOTHING of the item is looked up again.  The loop below
+          // -- which item, which table, its rows -- walks the by-value argument block (D.nT,
+          // D.tab[t]: dependent loads from the kernel-argument segment, a division, the trailer):
+          // at one item per wave and slice that was most of these instances' items phase.
+          const int ixr = __builtin_amdgcn_readfirstlane(rt.ix);
+          if (ixr >= 0) {
+            const int tg = __builtin_amdgcn_readfirstlane(rt.tile);
+            if (!(nz >> (8 + tg) & 1)) {
+              double acc = 0.0;
+              if (nz >> tg & 1)
+                acc = __builtin_amdgcn_readfirstlane(rt.pre) != 0
+                          ? hs_rt_compute<(RT > 0 ? RT : 1), false>(rt)
+                          : hs_rt_compute<(RT > 0 ? RT : 1), true>(rt);
+              // (its slot: the item's, or -- compact slots, four workgroups per walker on -- the wave's)
+              sm[H.o_part_t + __builtin_amdgcn_readfirstlane(rt.slot) * 64 + lane] = acc;
+              rt_first = false;  // (done: the loop below has nothing to do)
+            }
+          }
+        }
         for (;;) {
           int item = 0, pulled = 0;
           if constexpr (RT > 0) {  // ONE item, the wave's own (its rows may sit in registers)
@@ -1423,20 +1445,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                         : hs_table_item_v<true>(kd_lo, kd_hi, nK, nG, tile, s0, s1, (unsigned)e1.x + o8,
                                                 (unsigned)e1.y + o8, (unsigned)e1.z + o8, lane);
             }
-            part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
-          } else if (RT > 0 && is_tab && __builtin_amdgcn_readfirstlane(rt.ix) == ix &&
-                     !(nz >> (8 + __builtin_amdgcn_readfirstlane(rt.tile)) & 1)) {
-            // The wave's own item, its rows in registers since the launch began (every slice but
-            // one whose weights are not finite): nothing of the item is looked up again -- the
-            // lookup below walks the by-value argument block (D.tab[t]: dependent loads from the
-            // kernel-argument segment, a division, the trailer), which at one item per wave and
-            // slice was most of these instances' items phase.
-            const int tg = __builtin_amdgcn_readfirstlane(rt.tile);
-            double acc = 0.0;
-            if (nz >> tg & 1)
-              acc = __builtin_amdgcn_readfirstlane(rt.pre) != 0
-                        ? hs_rt_compute<(RT > 0 ? RT : 1), false>(rt)  // (the rows are in registers)
-                        : hs_rt_compute<(RT > 0 ? RT : 1), true>(rt);
             part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = acc;
           } else if (RT > 0 && is_tab) {
             int t = 0;
