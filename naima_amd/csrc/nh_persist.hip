@@ -1647,6 +1647,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const int nE = H.nE;
         const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
         const double prior = accs[3];
+        // (what the accept and the record need besides the likelihood: asked for HERE, with the
+        // components' descriptors -- behind the sums they were one more LDS round trip on the one
+        // wave every other workgroup's next proposal may be waiting for)
+        const double oldlp = accs[2], mlnu_ = accs[1], lg3 = lg[3];
+        const int me2 = hi[HI_ME];
+        const double q_new = qs[min(lane >> 1, HS_O_LNA - 1)], q_old = olds[min(lane >> 1, 63)];
         double acc = 0.0;
         int nviol = 0, nul = 0;
         const double* lik = sm + H.o_lik;
@@ -1695,15 +1701,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         }
         HSR_GSTAMP(5);
         // emcee RedBlueMove.propose for this walker
-        const double oldlp = accs[2];
-        const double dd = lg[3] + acc - oldlp;
-        const bool ok = accs[1] < dd;  // NaN compares false, as numpy
-        const int me2 = hi[HI_ME];
+        const double dd = lg3 + acc - oldlp;
+        const bool ok = mlnu_ < dd;  // NaN compares false, as numpy
         // the record of the state after this step: row tl + 1
         double val = 0.0;
         if (lane < GRn) {
           const int d = lane >> 1;
-          val = d < ndim ? (ok ? qs[d] : olds[d]) : (ok ? acc : oldlp);
+          val = d < ndim ? (ok ? q_new : q_old) : (ok ? acc : oldlp);
           const long long roff = ((long long)(tl + 1) * N + me2) * R.gr + lane;
           const unsigned long long gv = hs_granule(val, lane, hs_tag(R.seq, tl + 1));
           if (!multi) {
