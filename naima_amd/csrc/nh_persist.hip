@@ -1307,7 +1307,16 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                              (!(Bw > 0.0) || !(Bw < INFINITY) || (nz >> (8 + H.syn_grid) & 1) != 0);
         const bool syn_zero = !(nz >> H.syn_grid & 1) || syn_nan;
         if (nA > 0 && !syn_zero) {
-          Cd = (hi[HI_LIVE] / nA + R.syn_nodes - 1) / R.syn_nodes;
+          // (every wave forms these two quotients in every slice, ahead of its first item: as
+          // 32-bit divisions they were ~60 vector instructions of the slice's serial part;
+          // hs_div_small's ranges -- x < 2^20, d < 2^12 -- hold for any grid that fits LDS)
+          const int live = hi[HI_LIVE];
+          if (live < (1 << 20) && nA < (1 << 12) && R.syn_nodes < (1 << 12)) {
+            const int per = hs_div_small(live, nA, __builtin_amdgcn_rcpf((float)nA));
+            Cd = hs_div_small(per + R.syn_nodes - 1, R.syn_nodes, __builtin_amdgcn_rcpf((float)R.syn_nodes));
+          } else {
+            Cd = (live / nA + R.syn_nodes - 1) / R.syn_nodes;
+          }
           Cd = min(max(Cd, 1), D.syn_cdmax);
           nS = (nA * Cd + 63) >> 6;
         }
