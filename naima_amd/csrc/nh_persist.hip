@@ -137,6 +137,7 @@ struct hs_run {
   // kernel-argument segment one dependent scalar load at a time (four round trips per component)
   int o_sum, o_cmp;
   int o_pci;  // LDS: per prior term the proposed coordinate it reads, or -1 (ints)
+  int o_mt;     // LDS: per single-row reduction { w, dlw, lx, K | dlnK (LDS byte addresses), nG, first row, last row } (ints)
   int o_synce;  // LDS: CS1 / B per photon energy (walker-independent: a division per live energy and slice otherwise)
   // K workgroups of a table-only walker split the grid's ROWS (nh_halfstep.hip: the plan's
   // rowsplit): workgroup `part` owns the nodes [b_part, b_part+1] -- the boundaries sit between
@@ -750,6 +751,30 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     }
   }
   __syncthreads();
+  // the single-row reductions (We, Wp): what their wave needs, resolved once -- in the slice loop
+  // it looked the grid up by a wave-dependent index in the by-value argument block (H.mgrid[m],
+  // H.nG[g], H.o_w[g]: dependent loads from the kernel-argument segment at the head of that wave's
+  // items phase, every slice)
+  if (RT > 0 && tid < H.nmom) {
+    const int m = tid, g = H.mgrid[m], nG = H.nG[g];
+    int ko = H.o_mkt;
+    for (int q = 0; q < m; ++q) ko += 2 * H.nG[H.mgrid[q]];
+    int sg0 = 0, sg1 = nG - 1;
+    if (R.rowsplit) {  // (this workgroup's rows: the walker's first workgroup adds the parts)
+      const int* rs = reinterpret_cast<const int*>(sm + R.o_rs);
+      sg0 = rs[2 * g];
+      sg1 = rs[2 * g + 1];
+    }
+    int* d = reinterpret_cast<int*>(sm + R.o_mt) + 8 * m;
+    d[0] = (int)hs_lds_addr(sm + H.o_w[g]);
+    d[1] = (int)hs_lds_addr(sm + H.o_d[g]);
+    d[2] = (int)hs_lds_addr(sm + H.o_lx[g]);
+    d[3] = (int)hs_lds_addr(sm + ko);
+    d[4] = nG;
+    d[5] = sg0;
+    d[6] = sg1;
+    d[7] = 0;
+  }
 
   // which grid does unit u (64 consecutive nodes of one grid) belong to
   int ub[NH_MAX_GRIDS + 1];
@@ -1326,7 +1351,10 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         }
       }
       // ---- single-row reductions (We, Wp), one wave each (from the back) ----------------------
-      if (nwv - 1 - wv < H.nmom) {
+      if (RT == 0 && nwv - 1 - wv < H.nmom) {
+        // (the 1024-thread instances: the wave that has a reduction pulls work items behind it like
+        // every other wave, and the look-up is hidden -- with the table below they measured 0.3 %
+        // slower, ten more scalars spilled)
         const int m = nwv - 1 - wv;
         const int g = H.mgrid[m], nG = H.nG[g];
         int ko = H.o_mkt;
@@ -1346,6 +1374,24 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           const double u2 = ws[sgm + 1] * sm[ko + sgm + 1];
           const double dl = ds[sgm] + sm[ko + nG + sgm];
           acc += nh_seg_term(u1, u2, dl, lxs[sgm]);
+        }
+        acc = hs_wave_sum(acc);
+        if (lane == 0) sm[D.o_mrow + H.nE + m] = acc;
+      }
+      if (RT > 0 && nwv - 1 - wv < H.nmom) {
+        const int m = nwv - 1 - wv;
+        typedef int hsm_i4 __attribute__((ext_vector_type(4)));
+        const hsm_i4* mt = reinterpret_cast<const hsm_i4*>(sm + R.o_mt) + 2 * m;  // (built when the launch began)
+        const hsm_i4 m0 = mt[0], m1 = mt[1];
+        const unsigned aw = (unsigned)m0.x, ad = (unsigned)m0.y, al = (unsigned)m0.z, ak = (unsigned)m0.w;
+        const int nG = __builtin_amdgcn_readfirstlane(m1.x);
+        const int sg0 = __builtin_amdgcn_readfirstlane(m1.y), sg1 = __builtin_amdgcn_readfirstlane(m1.z);
+        double acc = 0.0;
+        for (int sgm = sg0 + lane; sgm < sg1; sgm += 64) {
+          const double u1 = hs_lds_at(aw, sgm) * hs_lds_at(ak, sgm);
+          const double u2 = hs_lds_at(aw, sgm + 1) * hs_lds_at(ak, sgm + 1);
+          const double dl = hs_lds_at(ad, sgm) + hs_lds_at(ak, nG + sgm);
+          acc += nh_seg_term(u1, u2, dl, hs_lds_at(al, sgm));
         }
         acc = hs_wave_sum(acc);
         if (lane == 0) sm[D.o_mrow + H.nE + m] = acc;
@@ -2073,6 +2119,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     R.o_cmp = take(2 * NH_MAX_COMP + 2, false);
     R.o_pci = take((NH_MAX_PRIOR + 1) / 2, false);
     R.o_synce = H.syn_grid >= 0 ? take(H.syn_nE, false) : -1;
+    R.o_mt = take(4 * NH_MAX_MOMENT, true);
     {
       int nun = 0;
       for (int g = 0; g < H.ngrids; ++g) nun += (H.nG[g] + 63) / 64;
