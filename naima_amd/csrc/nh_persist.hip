@@ -978,7 +978,10 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               // the rounded power (both are right to the last place of a number around 70); only
               // another transform calls the library's log behind its own result -- the chain
               // exp10 -> log on one lane was 0.4 us of every slice with every other wave waiting)
-              if (col == 0 || col == 1 || col == 3 || col == 5) {
+              // (ln |amplitude|: only the log-domain synchrotron items read it -- for a table-only
+              // model whose amplitude is not a power of ten, cfg1's, it was a library log on the one
+              // wave everybody waits for)
+              if (((SYN && S2) && col == 0) || col == 1 || col == 3 || col == 5) {
                 double lv;
                 const bool easy = pkd < 0 || ztf == NH_TF_POW10;
                 if (pkd < 0) {
