@@ -138,6 +138,7 @@ struct hs_run {
   int o_sum, o_cmp;
   int o_pci;  // LDS: per prior term the proposed coordinate it reads, or -1 (ints)
   int o_mt;     // LDS: per single-row reduction { w, dlw, lx, K | dlnK (LDS byte addresses), nG, first row, last row } (ints)
+  int o_lnt;    // LDS: 128 x { 1 / c_j, ln c_j }, c_j the centres of [1/2, 1)'s 128 bins (hsr_ln_tab; log-domain instances)
   int o_synce;  // LDS: CS1 / B per photon energy (walker-independent: a division per live energy and slice otherwise)
   // K workgroups of a table-only walker split the grid's ROWS (nh_halfstep.hip: the plan's
   // rowsplit): workgroup `part` owns the nodes [b_part, b_part+1] -- the boundaries sit between
@@ -210,6 +211,35 @@ __device__ __attribute__((noinline)) double hsr_lazy_apply(double a, double b, d
 }
 __device__ __attribute__((noinline)) double hsr_log(double x) { return log(x); }
 __device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x); }
+// ln x by a 128-bin table of [1/2, 1) and a degree-6 series of the remainder (|r| <= 2^-8:
+// r^7 / 7 < 2e-18) -- 20 instructions where the library's is ~70 behind a call: the liveness waves
+// take the logarithm of q = E / E_c for every photon energy of every slice, and with three of them
+// (cfg2's 179 energies) they reached barrier 2 a microsecond behind the waves that form the weights.
+// About one unit in the last place of a result of order 10; anything that is not a positive normal
+// number goes to the library (wave-uniform branch).  a_t: LDS byte address of { 1 / c_j, ln c_j }.
+typedef double hsr_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const hsr_d2 hsr_lcd2;
+__device__ __attribute__((noinline)) double hsr_ln_tab(double x, unsigned a_t) {  // (a call: inlined, its coefficients are parked across the slice loop)
+  const bool plain = x >= 2.2250738585072014e-308 && x < INFINITY;
+  if (__builtin_amdgcn_ballot_w64(!plain) != 0ull) {
+    asm volatile("" ::: "memory");  // (keep the call behind the branch)
+    return hsr_log(x);
+  }
+  const double m = __builtin_amdgcn_frexp_mant(x);  // [1/2, 1)
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  unsigned j = ((unsigned)__double2hiint(m) >> 13) & 127u;  // the seven mantissa bits below the leading one
+  asm("" : "+v"(j));
+  const hsr_d2 t = *(hsr_lcd2*)(unsigned long long)(a_t + (j << 4));
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, -1.6666666666666666e-01, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 3.3333333333333331e-01);
+  p = fma(p, r, -0.5);
+  p = fma(p * r, r, r);  // r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
+  const double ed = (double)e;
+  // e ln 2 in two pieces (the first exact for |e| < 2^11), the small ones first
+  return fma(ed, 6.93147180369123816490e-01, t.y) + fma(ed, 1.90821492927058770002e-10, p);
+}
 struct hsr_node { double n, dsh, ex; };  // ex = ln(n / A)
 struct hsr_node2 { double n0, dsh0, n1, dsh1, ex0, ex1; };
 // b12 / b0 / b1: bit 0, 1 = this node / the next lie below the break; bit 2 = ln(n / A) only
@@ -531,6 +561,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       const int nGs = H.F.syn_nG, ntb = (R.s2.P + 1) * HS_S2_STRIDE;
       for (int i = tid; i < ntb; i += T) sm[R.o_s2tab + i] = R.s2_dev[i];
       for (int i = tid; i < HS_S2_TN; i += T) sm[R.o_s2t + i] = exp2((double)i * (1.0 / HS_S2_TN));
+      if (tid < 128) {  // hsr_ln_tab's table
+        const double c = 0.5 + ((double)tid + 0.5) * (1.0 / 256.0);
+        sm[R.o_lnt + 2 * tid] = 1.0 / c;
+        sm[R.o_lnt + 2 * tid + 1] = log(c);
+      }
       for (int i = tid; i < nGs; i += T) sm[R.o_s2lg + i] = R.s2_dev[ntb + i];
       for (int i = tid; i < nGs + 2 * HS_S2_GUARD; i += T) {  // (guards: the edge values, any finite number)
         const int ii = min(max(i - HS_S2_GUARD, 0), nGs - 1);
@@ -1107,7 +1142,10 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             // 2 ln gamma_0 - 2 i lx, so the first live node is where the comb crosses ln 746 -- from
             // the logarithm the items need anyway -- and the comparison itself, as the search made
             // it, settles the last place (two or three reads instead of ten dependent ones)
-            lv_lnq = hsr_log(lv_q);
+            // (several liveness waves -- more than 64 photon energies -- reach barrier 2 behind the
+            // weights' waves: the short logarithm; one of them does not, and cfg3 measured 1 % slower
+            // with it than with the library's)
+            lv_lnq = syn_tiles > 1 ? hsr_ln_tab(lv_q, hs_lds_addr(sm + R.o_lnt)) : hsr_log(lv_q);
             // (node i sits z + i comb steps below T_top, z = s2_z0 - ln q / (2 lx); s2_r746 = (T_top - ln 746)
             // / (2 lx) - s2_z0, formed on the host: as an expression here it is a loop invariant the
             // compiler computes at the head of every slice and spills)
@@ -2122,6 +2160,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
     R.o_cmp = take(2 * NH_MAX_COMP + 2, false);
     R.o_pci = take((NH_MAX_PRIOR + 1) / 2, false);
     R.o_synce = H.syn_grid >= 0 ? take(H.syn_nE, false) : -1;
+    R.o_lnt = -1;  // (allotted with the log-domain block, below)
     R.o_mt = take(4 * NH_MAX_MOMENT, true);
     {
       int nun = 0;
@@ -2219,6 +2258,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
       R.o_s2q = take(4 * H.syn_nE, false);
       R.o_s2z = take((H.syn_nE + 1) / 2, false);
       R.o_s2t = take(HS_S2_TN, false);
+      R.o_lnt = take(256, true);
       if ((size_t)off * sizeof(double) <= 160 * 1024) {
         R.syn2 = 1;
       } else {
