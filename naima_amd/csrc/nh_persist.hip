@@ -210,6 +210,7 @@ __device__ __attribute__((noinline)) double hsr_lazy_apply(double a, double b, d
   return nh_lazy_apply(z, raw);
 }
 __device__ __attribute__((noinline)) double hsr_log(double x) { return log(x); }
+__device__ __attribute__((noinline)) double hsr_exp10(double x) { return exp10(x); }
 __device__ __attribute__((noinline)) double hsr_cbrt(double x) { return cbrt(x); }
 // ln x by a 128-bin table of [1/2, 1) and a degree-6 series of the remainder (|r| <= 2^-8:
 // r^7 / 7 < 2e-18) -- 20 instructions where the library's is ~70 behind a call: the liveness waves
@@ -1002,7 +1003,19 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           const int col = lane % NH_MAX_LAZY;
           if (col < nc) {
             double val = za;
-            if (pkd >= 0) val = hsr_lazy_apply(za, zb, zc, ztf, qv);
+            // (the common fit -- every column the identity or a power of ten of its coordinate: one
+            // exp10 for the wave and a select.  hsr_lazy_apply takes the transform in a vector register
+            // and walks its switch as exec-mask regions, case by case: ~40 vector instructions of
+            // compares and masks around the 45 of the one transform that is there, on the wave
+            // everybody waits for.  The same operations on the same operands: the same bits.)
+            const bool odd = pkd >= 0 && ztf != NH_TF_ID && ztf != NH_TF_POW10;
+            if (__builtin_amdgcn_ballot_w64(odd) == 0ull) {
+              const double xl = zb * qv + zc;
+              const double xe = hsr_exp10(xl);
+              if (pkd >= 0) val = za * (ztf == NH_TF_POW10 ? xe : xl);
+            } else if (pkd >= 0) {
+              val = hsr_lazy_apply(za, zb, zc, ztf, qv);
+            }
 
             if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
               row[col] = val;
