@@ -886,6 +886,21 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     }
   }
 
+  // (the register-resident instances' likelihood wave: the components' places and factors -- the
+  // table above -- in registers for the launch: one LDS round trip less between the last barrier of
+  // a slice and the record's store)
+  int lk_coff[NH_MAX_COMP];
+  double lk_cscl[NH_MAX_COMP];
+#pragma unroll
+  for (int q = 0; q < NH_MAX_COMP; ++q) {
+    lk_coff[q] = 0;
+    lk_cscl[q] = 0.0;
+    if (RT > 0 && lik_wave) {
+      lk_coff[q] = (int)sm[R.o_cmp + 2 * q];
+      lk_cscl[q] = sm[R.o_cmp + 2 * q + 1];
+    }
+  }
+
   // =========================== the slices ====================================================
   int it = 0;
   for (int s = 0; s < R.nslices; ++s) {
@@ -1773,8 +1788,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         double cscl[NH_MAX_COMP];
 #pragma unroll
         for (int q = 0; q < NH_MAX_COMP; ++q) {
-          coff[q] = (int)sm[R.o_cmp + 2 * q];
-          cscl[q] = sm[R.o_cmp + 2 * q + 1];
+          if (RT > 0) {  // (kept in this wave's registers since the launch began: 256 of them per lane there)
+            coff[q] = lk_coff[q];
+            cscl[q] = lk_cscl[q];
+          } else {
+            coff[q] = (int)sm[R.o_cmp + 2 * q];
+            cscl[q] = sm[R.o_cmp + 2 * q + 1];
+          }
         }
         for (int k = lane; k < nE; k += 64) {
           double sv[NH_MAX_COMP];
