@@ -901,15 +901,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     }
   }
 
-  int sum_dx = 0, sum_dy = 0;  // (RT: this thread's first column of the sum phase)
-  double sum_sc = 0.0;
-  if (RT > 0 && tid0 < R.sum_cols) {
-    const int* st = reinterpret_cast<const int*>(sm + R.o_sum);
-    sum_dx = st[2 * tid0];
-    sum_dy = st[2 * tid0 + 1];
-    sum_sc = sm[H.o_scale + (int)((unsigned)sum_dy >> 8)];
-  }
-
   // =========================== the slices ====================================================
   int it = 0;
   for (int s = 0; s < R.nslices; ++s) {
@@ -1654,11 +1645,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         typedef int hss_i2 __attribute__((ext_vector_type(2)));
         const hss_i2* st = reinterpret_cast<const hss_i2*>(sm + R.o_sum);
         for (int k = tid; k < R.sum_cols; k += T) {
-          // (the register-resident instances: a thread's first column, its descriptor and scale kept
-          // since the launch began -- one LDS round trip of this phase's two)
-          const bool kept = RT > 0 && k == tid;
-          hss_i2 d;
-          if (kept) { d.x = sum_dx; d.y = sum_dy; } else { d = st[k]; }
+          const hss_i2 d = st[k];
           const int chunks = d.y & 0xff, dst = (int)((unsigned)d.y >> 8);
           double sum = 0.0;
           if (K > 1 && R.tcompact) {
@@ -1696,7 +1683,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
           }
-          sum *= kept ? sum_sc : sm[H.o_scale + dst];
+          sum *= sm[H.o_scale + dst];
           spec[dst] = sum;
         }
       }
