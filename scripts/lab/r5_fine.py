@@ -1,7 +1,7 @@
 """Eight stamps per wave inside a slice (library built with -DHSR_FINE; workgroup 0, iterations
 32 .. 39): median time of each stamp relative to the slice's start, per wave.
 
-    NAIMA_AMD_LIB=naima_amd/variants/fine.so NH_HS_DEBUG=1 python scripts/r5_fine.py cfg3 512
+    NAIMA_AMD_LIB=naima_amd/variants/fine.so NH_HS_DEBUG=1 python scripts/lab/r5_fine.py cfg3 512
 """
 import ctypes as C
 import os
