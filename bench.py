@@ -45,14 +45,17 @@ ALGO = {
 }
 # flop-equivalents per launch-walker of the two hot kernels (op-count convention of
 # a node of Synchrotron 50 eq., a segment of a table reduction 30 eq.)
-SSC_SEG_EQ = 34.0 if os.environ.get("NAIMA_AMD_SSC_TABLE", "1") == "0" else 30.0
+# (round 6: the SSC segment's reciprocal is credited with the FIVE instructions it is on this chip
+# -- v_rcp_f64 seed + Newton -- not with the convention's 20: at 30 eq. per segment the kernel's
+# `frac` came out at 1.006 of the FP64 peak, which is a statement about the convention; 5 + 10 = 15)
+SSC_SEG_EQ = 19.0 if os.environ.get("NAIMA_AMD_SSC_TABLE", "1") == "0" else 15.0
 KERNEL_FLOP_EQ = {
     "cfg3": {"synchrotron": 64 * 570 * 50.0, "integrate_tables": 64 * 3 * 370 * 30.0},
     "cfg2": {"synchrotron": 179 * 300 * 50.0},
     "cfg1": {"integrate_tables": 28 * 570 * 30.0},
     "cfg5": {"integrate_tables": 28 * 600 * 30.0},
-    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 30 eq. each: per
-    # walker a reciprocal (20) + mul, add, sub, cmp, three fma (10).  (The Aharonian-Atoyan
+    # (seed energy, photon energy, gamma) segments of the SSC seed integral, 15 eq. each: per
+    # walker a reciprocal (5: see SSC_SEG_EQ) + mul, add, sub, cmp, three fma (10).  (The Aharonian-Atoyan
     # kernel and its logarithm come from the table built once per sampler; evaluated per step
     # -- NAIMA_AMD_SSC_TABLE=0 -- a walker's 1/16 share of them is another 4.)
     "cfg4": {"ic_seed_walkers": 100 * 261 * 869 * SSC_SEG_EQ},
@@ -447,15 +450,27 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
     # up once more on the device, DeviceLoop.device_barrier; a rank's time runs from there to
     # its own device sync after step K, the closing barrier follows, and the MAX over ranks is
     # the region's time)
+    # What a region spends OUTSIDE its kernels (Python ahead of the launch calls, launch latency,
+    # the gaps between launches, the synchronisation behind the last one): this rank's host time
+    # minus the device span clock over the SAME launches (nh_clock_read: every span of the step
+    # loop -- a resident launch with its epilogue, or one half-step's launches -- is stamped on the
+    # device by its first workgroup in and its last workgroup out).  The spans lie inside the host
+    # interval and do not overlap, so the difference cannot be negative.  The clock is reset ahead
+    # of t0 and read behind the region's own sync: nothing is added to the timed launches.
+    overheads, spans_seen = [], []
+
     def timed_region(smp, st):
         comm.barrier()
         if device:
             smp._dev.device_barrier()
-        ctx.sync()
+        ctx.clock_read(reset=True)  # (synchronises)
         t0 = time.perf_counter()
         st = smp.run_mcmc(st, args.steps, store=not args.no_chain)
         ctx.sync()
         dt_mine = time.perf_counter() - t0
+        span_us, nspans = ctx.clock_read()
+        overheads.append(dt_mine * 1e6 - span_us)
+        spans_seen.append(nspans)
         comm.barrier()
         return comm.max(dt_mine), st
 
@@ -468,6 +483,7 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
         _, state = timed_region(sampler, state)
         sampler.reset()
         rehearsed += args.steps
+    del overheads[:], spans_seen[:]  # (the rehearsals' are not the timed regions')
     first, state = timed_region(sampler, state)
     acc_frac = float(np.mean(sampler.acceptance_fraction))
     sampler.reset()  # (the chain of a region is dropped before the next one)
@@ -479,6 +495,7 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
         times.append(dt_i)
         sampler.reset()
     dt = float(np.median(times))
+    region_overheads, region_spans = list(overheads), list(spans_seen)
     final_coords = np.asarray(state.coords)
 
     # ---- the same loop with the other blob setting (the reference always stores (flux, We)
@@ -602,6 +619,19 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
     }
     if blobs_value is not None or full:
         out["value_without_blobs" if keep_blobs else "value_store_blobs"] = blobs_value
+    out["region_us"] = dt * 1e6
+    if region_spans and min(region_spans) > 0:
+        # (rank 0's own regions: its host time around the K steps minus its device spans)
+        out["region_overhead_us"] = float(np.median(region_overheads))
+        out["region_overhead"] = {
+            "min_us": float(np.min(region_overheads)), "max_us": float(np.max(region_overheads)),
+            "device_spans_per_region": int(np.median(region_spans)),
+            "how": "host perf_counter around the K steps (launch calls + sync) minus the device "
+                   "span clock of the same launches (nh_clock_read: wall_clock64 stamps by the first "
+                   "workgroup in and the last workgroup out of every span) -- non-negative by "
+                   "construction"}
+    else:
+        out["region_overhead_us"] = None  # (a loop whose launches carry no span stamps: host loop)
     if not prof:
         return out
     # dominant kernel by accumulated HIP-event time (one category = one kernel symbol;
@@ -661,11 +691,6 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
                        "note": note}
     out["kernels_us_per_launch"] = {KERNEL_SYMBOL.get(k, k): round(launch_us(k), 2) for k in prof}
     out["kernel_launches"] = {KERNEL_SYMBOL.get(k, k): v["launches"] for k, v in prof.items()}
-    # what a timed region spends OUTSIDE its kernels (launch latency, Python, the synchronisation
-    # behind the last launch): the median region minus the kernels' event time per K steps
-    kern_us = sum(launch_us(k) * prof[k]["launches"] for k in prof) * args.steps / float(prof_steps)
-    out["region_overhead_us"] = dt * 1e6 - kern_us
-    out["region_us"] = dt * 1e6
     fp = {}
     executed = executed_flop_eq(name, raw, final_coords)
     flop_all = dict(KERNEL_FLOP_EQ.get(name, {}))
@@ -703,9 +728,10 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
                                           "from the final ensemble's B, mean over walkers; "
                                           "the SSC seed kernel (cfg4) is credited with the "
                                           "seed-axis segments inside the Aharonian-Atoyan "
-                                          "kernel's windows, %g eq. each (the reciprocal's "
-                                          "20 are five instructions on this chip: an op-count "
-                                          "convention, not pipe utilisation)" % SSC_SEG_EQ}
+                                          "kernel's windows, %g eq. each (the reciprocal "
+                                          "credited with its five instructions on this chip, not "
+                                          "the convention's 20: an op count, not pipe utilisation "
+                                          "-- valu_utilisation.valu_busy is that)" % SSC_SEG_EQ}
     default_walkers = 256 if name in ("cfg4", "cfg5") else W.WORKLOADS[name]["nwalkers"]
     if per_gpu == default_walkers and comm.size == 1:  # (the configuration the profiles were taken on)
         thr = (getattr(sampler._dev, "resident_info", None) or {}).get("threads", 1024) if resident else 1024

@@ -558,6 +558,12 @@ int nh_half_step_begin_block(nh_ctx* ctx, nh_halfstep_plan* plan, int first_slic
 /* slice >= 0: the launch works on that slice of the block of moves (a captured graph replays
  * it for the same slice); slice < 0: the slice the plan's own launch counter says is next */
 int nh_half_step_launch(nh_ctx* ctx, nh_halfstep_plan* plan, int slice);
+/* Which launches of a half-step open and close a span of the context's device clock
+ * (nh_clock_read).  Default: every launch of the plan is a span by itself.  A half-step of
+ * several launches -- a model that asks for its synchrotron spectrum twice with the SSC seed
+ * integral in between, examples/CrabNebula_SynSSC.py:29-45 -- opens with its first launch
+ * (1, 0) and closes with its last (0, 1). */
+int nh_half_step_span(nh_halfstep_plan* plan, int open, int close);
 int nh_half_step_info(const nh_halfstep_plan* plan, int* threads, int* blocks,
                       long long* lds_bytes);
 /* workgroups per walker of the plan's launches: 1, or K = 2, 4, 8 where a launch holds fewer
@@ -576,6 +582,17 @@ int nh_half_step_syn_form(const nh_halfstep_plan* plan, int* form);
  * compute_log_prob; reference call site core.py:128); a launch rejects the proposal -- NaN
  * compares false -- and counts.  The one-launch kernels count per plan (below). */
 int nh_nan_count(nh_ctx* ctx, int reset, int* count);
+/* The device span clock: what the step loop's launches -- the kernels that replace emcee's
+ * EnsembleSampler.sample loop around core.py:97-121 (reference call sites core.py:128, 450-457)
+ * -- have spent ON the device since the last reset, measured on those launches themselves: the
+ * first workgroup of a span's first kernel stamps the GPU's constant-rate wall clock, the last
+ * workgroup out of the span's last kernel adds the difference (a span = one launch of the
+ * resident loop with its epilogue, or the launches of one half-step of the per-launch loop).
+ * out[3] = { ticks inside closed spans, closed spans, ticks per millisecond }.  Spans lie inside
+ * the host interval around their launch calls and do not overlap, so (host time of a region) -
+ * (span time) >= 0 by construction: bench.py's region_overhead_us.  Synchronises the stream;
+ * reading adds nothing to any launch. */
+int nh_clock_read(nh_ctx* ctx, int reset, long long* out);
 /* proposals whose log-probability was NaN since the plan was created (or the last reset):
  * emcee raises ValueError("Probability function returned NaN") on the first one
  * (EnsembleSampler.compute_log_prob; reference call site core.py:128), a launch rejects the

@@ -117,6 +117,8 @@ _SIGS = {
     "nh_half_step_syn_form": [_dp, C.POINTER(_i)],
     "nh_half_step_destroy": [_dp, _dp],
     "nh_nan_count": [_dp, _i, C.POINTER(_i)],
+    "nh_clock_read": [_dp, _i, C.POINTER(C.c_longlong)],
+    "nh_half_step_span": [_dp, _i, _i],
     "nh_half_step_nan_count": [_dp, _dp, _i, C.POINTER(_i)],
     "nh_half_step_counts": [_dp, _dp, _i, C.POINTER(_i), C.POINTER(_i)],
     "nh_half_step_stamps": [_dp, _dp, _dp],
@@ -698,6 +700,8 @@ class Context:
             h = _dp()
             _chk(_lib.nh_half_step_create(self.h, C.addressof(d), C.byref(h)))
             st = plan["stage"] = dict(plan=h, keep=(base, Ecat, ones, zeros, izero, half, dummy))
+            # the span clock: this launch opens the half-step's span, the plan's own closes it
+            _chk(_lib.nh_half_step_span(h, 1, 0))
             self.call("nh_half_step_begin_block", h, f["pos"]["slice"], 0)
         if ent is syn[0]:
             pos = plan["front"]["pos"]
@@ -818,6 +822,8 @@ class Context:
         _chk(_lib.nh_half_step_info(h, C.byref(thr), C.byref(blk), C.byref(lds)))
         spl = _i()
         _chk(_lib.nh_half_step_split(h, C.byref(spl)))
+        if plan.get("staged"):  # (the span clock: stage A's launch has opened this half-step's span)
+            _chk(_lib.nh_half_step_span(h, 0, 1))
         plan["hs"] = dict(key=key, plan=h, keep=(conv, lpd, total, dd), threads=thr.value,
                           blocks=blk.value, lds_bytes=lds.value, split=spl.value, tabs=tabs)
         # where the step loop stands in the current block of moves
@@ -1078,6 +1084,13 @@ class Context:
         v = _d()
         _chk(_lib.nh_profile_calibrate(self.h, int(reps), C.byref(v)))
         return v.value
+
+    def clock_read(self, reset=False):
+        """the device span clock (nh_clock_read): (microseconds the step loop's launches have
+        spent on the device since the last reset, spans) -- measured on the launches themselves"""
+        out = (_ll * 3)()
+        _chk(_lib.nh_clock_read(self.h, int(reset), out))
+        return out[0] * 1e3 / float(out[2]), int(out[1])
 
     def profile_read(self, reset=True):
         nk = len(NH_K_NAMES)

@@ -57,6 +57,9 @@ struct nh_ctx {
   size_t scratch_bytes;
   hipStream_t copy_stream;  // uploads that run AHEAD of the main stream (nh_upload_ahead), or NULL
   int* nan_word;  // device: NaN log-probabilities met by the accepts of the separate kernels (nh_nan_count)
+  // device: the span clock (nh_clock_read) -- { wall_clock64 at the open span's start | ticks of
+  // all closed spans | closed spans | (int) blocks of a closing launch that are through }
+  long long* clk;
 };
 
 // Fill / upload that has COMPLETED when it returns.  The context's streams are non-blocking
@@ -141,6 +144,24 @@ struct nh_prof_scope {
 // ---------------------------------------------------------------------------
 // 1/x for a well-scaled x: v_rcp_f64 + two Newton steps, without the
 // v_div_scale/v_div_fixup dance of a generic IEEE division
+// ---- the device span clock (nh_clock_read, naima_hip.h) --------------------------------------
+// What the step loop's launches spend ON the device, measured on the launches themselves: the
+// first workgroup of a span's first kernel stamps clk[0]; whoever is the LAST workgroup out of the
+// span's last kernel adds (now - clk[0]) to clk[1].  A span lies inside the host interval around
+// its launch calls and the synchronisation behind them, and spans do not overlap (one stream), so
+// host time - span time >= 0 by construction: that is bench.py's `region_overhead_us`.
+// (agent-scope atomics: the opening and the closing workgroup may sit on different XCDs -- different
+// L2s -- of the SAME launch)
+__device__ __forceinline__ void nh_clk_open(long long* clk) {
+  __hip_atomic_store(clk, (long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nh_clk_close(long long* clk) {
+  const long long t1 = (long long)wall_clock64();
+  const long long t0 = __hip_atomic_load(clk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  clk[1] += t1 - t0;  // (one closer at a time: launches of a stream do not overlap)
+  clk[2] += 1;
+}
+
 __device__ __forceinline__ double nh_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = fma(-x, r, 1.0);

@@ -46,6 +46,7 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   c->scratch_bytes = 0;
   c->copy_stream = nullptr;
   c->nan_word = nullptr;
+  c->clk = nullptr;
   memset(c->acc_ms, 0, sizeof(c->acc_ms));
   memset(c->acc_n, 0, sizeof(c->acc_n));
   NH_CHECK_HIP(hipStreamCreateWithFlags(&c->main_stream, hipStreamNonBlocking));
@@ -60,7 +61,29 @@ extern "C" int nh_create(int device, nh_ctx** out) {
   NH_CHECK_HIP(hipEventCreate(&c->t1));
   NH_CHECK_HIP(hipMalloc(&c->nan_word, sizeof(int)));
   NH_CHECK_HIP(nh_fill_now(c, c->nan_word, 0, sizeof(int)));
+  NH_CHECK_HIP(hipMalloc(&c->clk, 8 * sizeof(long long)));
+  NH_CHECK_HIP(nh_fill_now(c, c->clk, 0, 8 * sizeof(long long)));
   *out = c;
+  return NH_OK;
+}
+
+// The device span clock: what the step loop's launches have spent on the device since the last
+// reset, measured on those launches themselves (nh_common.h: nh_clk_open / nh_clk_close; a span =
+// k_half_step_run + k_run_epilogue of one block of moves, or the launches of one half-step of the
+// per-launch loop).  out = { ticks inside closed spans, closed spans, ticks per millisecond }.
+// Synchronises the stream; nothing is added to any launch by reading.
+extern "C" int nh_clock_read(nh_ctx* c, int reset, long long* out) {
+  NH_REQUIRE(c && out, "bad argument");
+  int rc = nh_sync(c);
+  if (rc) return rc;
+  long long w[4];
+  NH_CHECK_HIP(hipMemcpy(w, c->clk, sizeof(w), hipMemcpyDeviceToHost));
+  int khz = 0;
+  NH_CHECK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+  out[0] = w[1];
+  out[1] = w[2];
+  out[2] = khz > 0 ? khz : 100000;  // (wall_clock64: 100 MHz on gfx942 / gfx950)
+  if (reset) NH_CHECK_HIP(nh_fill_now(c, c->clk, 0, 8 * sizeof(long long)));
   return NH_OK;
 }
 
@@ -83,6 +106,7 @@ extern "C" int nh_destroy(nh_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->main_stream);
   if (c->nan_word) (void)hipFree(c->nan_word);
+  if (c->clk) (void)hipFree(c->clk);
   nh_comm_destroy(c);
   for (int i = 0; i < NH_NSIDE; ++i) {
     (void)hipStreamSynchronize(c->side[i]);

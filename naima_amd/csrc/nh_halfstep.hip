@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
                                                     const double* __restrict__ blk_,
                                                     const double* coords_, int slice, int ns_,
                                                     int ndim_, int lo_, int flags_,
-                                                    const hs_hot H) {
+                                                    const hs_hot H, long long* clk_) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
   const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63;
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
   const bool dbg_on = (flags_ & 1) != 0;
   HS_STAMP(0);
   if (dbg_on && tid == 0 && j < 1024) D.dbg[256 + j] = (long long)wall_clock64();
+  // the span clock (nh_common.h; flags 2 / 4: this launch opens / closes a span -- a half-step of
+  // one launch does both, the staged plan's first launch opens and its second closes)
+  if ((flags_ & 2) && j == 0 && blockIdx.y == 0 && tid == 0) nh_clk_open(clk_);
 
   // ---- trip 1 ------------------------------------------------------------------------------
   // which slice?  `done` counts the workgroups that have finished since the current block of
@@ -1004,7 +1007,10 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
       hi[HI_TICK] = __hip_atomic_fetch_add(D.tick + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (hi[HI_TICK] != K - 1) {  // (the whole workgroup)
-      if (tid == 0) atomicAdd(H.done, 1);
+      if (tid == 0) {
+        const int through = atomicAdd(H.done, 1) + 1;
+        if ((flags_ & 4) && through % (int)(gridDim.x * gridDim.y) == 0) nh_clk_close(clk_);
+      }
       return;
     }
     if (tid == 0) D.tick[j] = 0;  // for the next launch
@@ -1125,7 +1131,8 @@ __global__ __launch_bounds__(1024) void k_half_step(const int* __restrict__ done
     }
     // ---- 8. one more workgroup is through (nobody waits for the answer) -------------------
     if (lane == 0) {
-      atomicAdd(H.done, 1);
+      const int through = atomicAdd(H.done, 1) + 1;
+      if ((flags_ & 4) && through % (int)(gridDim.x * gridDim.y) == 0) nh_clk_close(clk_);
       // emcee raises "Probability function returned NaN" here; the launch cannot, it counts
       if (acc != acc) atomicAdd(H.done + 2, 1);
       if (hi[HI_DEAD]) atomicAdd(H.done + 3, 1);  // (forbidden by the prior: nothing was integrated)
@@ -1640,6 +1647,7 @@ static int hs_create(nh_ctx* c, const nh_hs_desc* d, nh_halfstep_plan** out, int
     }
   nh_halfstep_plan* P = new nh_halfstep_plan();
   P->dbg = C.dbg;
+  P->span = 3;
   P->lds_bytes = lds;
   P->lds_core = lds_core;
   P->threads = threads;
@@ -1769,16 +1777,27 @@ extern "C" int nh_half_step_launch(nh_ctx* c, nh_halfstep_plan* P, int slice) {
   if (H.syn_grid >= 0 && H.o_s2)
     hipLaunchKernelGGL((k_half_step<true, true>), grid, dim3(P->threads), P->lds_bytes, c->stream,
                        (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
-                       P->dbg ? 1 : 0, H);
+                       (P->dbg ? 1 : 0) | (P->span << 1), H, c->clk);
   else if (H.syn_grid >= 0)
     hipLaunchKernelGGL(k_half_step<true>, grid, dim3(P->threads), P->lds_bytes, c->stream,
                        (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
-                       P->dbg ? 1 : 0, H);
+                       (P->dbg ? 1 : 0) | (P->span << 1), H, c->clk);
   else
     hipLaunchKernelGGL(k_half_step<false>, grid, dim3(P->threads), P->lds_bytes, c->stream,
                        (const int*)H.done, H.blk, H.coords, slice, H.ns, H.ndim, H.lo,
-                       P->dbg ? 1 : 0, H);
+                       (P->dbg ? 1 : 0) | (P->span << 1), H, c->clk);
   NH_CHECK_HIP(hipGetLastError());
+  return NH_OK;
+}
+
+// Which launches of a half-step open and close a span of the context's clock (nh_clock_read).
+// The default: a launch of the plan is a span by itself.  A half-step of several launches -- the
+// staged plan of a model that asks for its synchrotron spectrum twice, with the SSC seed
+// integral's kernels in between -- opens with its first launch (open = 1, close = 0) and closes
+// with its last (0, 1): the span then covers the kernels in between as well.
+extern "C" int nh_half_step_span(nh_halfstep_plan* P, int open, int close) {
+  NH_REQUIRE(P, "bad argument");
+  P->span = (open ? 1 : 0) | (close ? 2 : 0);
   return NH_OK;
 }
 

@@ -148,6 +148,7 @@ struct nh_halfstep_plan {
   int rt;  // the workgroup size was chosen for register-resident table items (hs_rt_item)
   int rowsplit;  // split == 2 was chosen for a table-only model whose two workgroups halve the ROWS
   long long* dbg;
+  int span;  // the span clock (nh_common.h): bit 0 a launch of this plan opens a span, bit 1 it closes one (nh_half_step_span)
 };
 
 // ints at the head of the LDS block (after qs/row/lg/acc)

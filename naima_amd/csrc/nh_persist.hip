@@ -172,6 +172,7 @@ struct hs_run {
   double s2_z0, s2_invd;  // z = s2_z0 - ln(q) s2_invd: where node 0 sits on the comb below T_top
   double s2_r746;         // (T_top - ln 746) s2_invd - s2_z0: the first live node is ceil(ln(q) s2_invd + this)
   double s2_lnw0;         // ln |n| + ln(E / eV) above this: the weight gamma n scale is not 0 in double
+  long long* clk;         // the context's span clock (nh_common.h): this launch opens a span, k_run_epilogue closes it
 };
 
 static_assert(sizeof(hs_hot) + sizeof(hs_run) <= 4000, "both argument blocks fit the kernarg segment");
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                                  // own: the one-GPU kernel is the code it was)
 
   // =========================== once per launch ==============================================
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0) nh_clk_open(R.clk);
   if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
   for (int g = 0; g < H.ngrids; ++g) {
     const int nG = H.nG[g];
@@ -1923,13 +1925,14 @@ struct hs_epi {
   int N, ndim, gr, nrank, nblob, spin_limit, report_launch, pad;
   unsigned seq;
   int* status; int* done; int* lcnt; volatile int* report;
+  long long* clk;  // the span clock: the last workgroup out closes the span k_half_step_run opened
   const unsigned long long* ring;
   double* coords; double* logp;
   int* nacc; const int* accw; int* hacc;
   long long hrow0;
   double* hblob[NH_HS_MAX_BLOB]; double* bcur[NH_HS_MAX_BLOB]; int bm[NH_HS_MAX_BLOB];
 };
-__global__ void k_run_epilogue(const hs_epi R, int nsteps) {
+__device__ __forceinline__ void run_epilogue_jobs(const hs_epi& R, int nsteps) {
   const int N = R.N, ndim = R.ndim;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gsz = (long long)gridDim.x * blockDim.x;
@@ -2051,6 +2054,19 @@ __global__ void k_run_epilogue(const hs_epi R, int nsteps) {
           else hb[(R.hrow0 + t) * (long long)N * bm + e] = prev;
         }
       bcur[e] = prev;
+    }
+  }
+}
+__global__ void k_run_epilogue(const hs_epi R, int nsteps) {
+  run_epilogue_jobs(R, nsteps);
+  // the span clock: whoever is the last workgroup out closes the span the launch opened
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int* through = reinterpret_cast<int*>(R.clk + 3);
+    const int total = (int)(gridDim.x * gridDim.y);
+    if (__hip_atomic_fetch_add(through, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+      __hip_atomic_store(through, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nh_clk_close(R.clk);
     }
   }
 }
@@ -2446,6 +2462,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   }
   Q->R.ring = Q->ring; Q->R.status = Q->status; Q->R.accw = Q->accw; Q->R.dbg = Q->dbg;
   Q->R.xspec = Q->xspec; Q->R.tick = Q->tick; Q->R.s2_dev = Q->s2_dev;
+  Q->R.clk = c->clk;
   Q->R.spin_limit = 1 << 22;  // ~1 s of polling: a record that has not come by then never will
   // (a shared ensemble: the ranks' hosts launch on their own clocks; a rank may have to wait for
   // another one's launch to START -- ~16 s)
@@ -2659,6 +2676,7 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
   R.seq = Q->seq++ & 0xFFFFFFu;
   if (R.seq == 0) R.seq = Q->seq++ & 0xFFFFFFu;
   R.report_launch = ++Q->nlaunch;
+  R.clk = c->clk;
   R.lcnt = Q->lcnt + 2 * (Q->nlaunch & 1);
   if (Q->fail_at > 0 && Q->nlaunch == Q->fail_at) R.spin_limit = 0;  // (tests: this launch's first wait gives up)
   if (Q->base) {  // a shared ensemble: this launch's ring, here and on every other rank
@@ -2696,6 +2714,7 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     E.N = R.N; E.ndim = H.ndim; E.gr = R.gr; E.nrank = R.nrank; E.nblob = H.C.nblob;
     E.spin_limit = R.spin_limit; E.report_launch = R.report_launch; E.seq = R.seq;
     E.status = R.status; E.done = H.done; E.lcnt = R.lcnt; E.report = R.report;
+    E.clk = c->clk;
     E.ring = R.ring; E.coords = const_cast<double*>(H.coords); E.logp = const_cast<double*>(H.logp);
     E.nacc = R.nrank > 1 ? R.nacc_own : H.C.naccepted; E.accw = R.accw; E.hacc = R.hacc;
     E.hrow0 = R.hrow0;

@@ -247,6 +247,7 @@ class DeviceLoop:
         # (the reference's Pool carries on when a worker is slow, core.py:523-536; this used to be
         # an exception on every rank)
         self._sh_snap = None
+        self._sh_want = False
         self._sh_journal = []
         self._replaying = False
         self._finalizer = weakref.finalize(self, _release_loop, self.ctx, self._res)
@@ -1261,12 +1262,23 @@ class DeviceLoop:
 
     def _shared_verified(self):
         """every rank's launches since the kept state ended well: the ensemble as it stands is the
-        one to go back to from now on (kept here, where every rank is anyway -- flush, reset -- and
-        not inside the next call: a 20-step call is a millisecond)"""
+        one to go back to from now on.  It is KEPT at the end of the flush / reset this was found in
+        (keep_verified) -- after the NaN / forbidden counts have been drained, the acceptance
+        counters zeroed and the sampler's iteration reset -- so that a replay starts from the
+        books as they stand behind that point, not before it (kept here, a reset()'s
+        snapshot held the burn-in's acceptance counts and iteration)."""
         self._sh_snap = None
         self._sh_journal = []
-        if self.shared and self._have_state:
-            self._shared_snapshot()
+        self._sh_want = bool(self.shared and self._have_state)
+
+    def keep_verified(self):
+        """the last thing a flush does, and a reset (the sampler's, once ITS books are cleared):
+        keep the ensemble every rank was found well at (here, where every rank is anyway, and
+        not inside the next call: a 20-step call is a millisecond)"""
+        if getattr(self, "_sh_want", False):
+            self._sh_want = False
+            if self.shared and self._have_state:
+                self._shared_snapshot()
 
     def _replay_shared(self, bad, mine):
         """a launch of the shared loop gave up on some rank (status `bad`; this rank's own: `mine`).
@@ -1591,3 +1603,4 @@ class DeviceLoop:
                 for p_ in s.comm.group.allgather_bytes(own.tobytes()):
                     self._acc_shared += np.frombuffer(p_, dtype=np.int32)
             s.naccepted += self._acc_shared
+        self.keep_verified()

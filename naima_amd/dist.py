@@ -113,6 +113,13 @@ class SocketGroup:
                                        os.environ.get("TORCHELASTIC_RUN_ID", ""), salt,
                                        os.environ.get("NAIMA_AMD_GROUP_SECRET", ""))
         self.token = hashlib.sha256(ident.encode()).digest()[:16]
+        # the hub's answer is NOT the hello's prefix: a client that connects to a loopback port
+        # nobody listens on yet can be handed that very port as its own source port (TCP
+        # simultaneous open: the socket is connected to ITSELF), reads its own hello back and
+        # -- with a symmetric handshake -- takes itself for the hub; its first collective then
+        # reads the four bytes of its own rank and half of its own header as a length (round 6:
+        # "control-plane message of 17592186044417 bytes", one run in ~10 of two self-started ranks)
+        self.reply = hashlib.sha256(b"hub:" + self.token).digest()[:16]
         self.peers = {}     # rank 0: rank -> socket
         self.sock = None    # other ranks: the socket to rank 0
         self._srv = None
@@ -178,16 +185,23 @@ class SocketGroup:
                         not (0 < r < self.size) or r in self.peers:
                     c.close()
                     continue
-                c.sendall(_MAGIC + self.token)
+                c.sendall(_MAGIC + self.reply)
                 c.settimeout(self.timeout)
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 self.peers[r] = c
             except (OSError, ConnectionError, struct.error):
                 c.close()
 
+    def _client_handshake(self, s):
+        """True when the socket's other end is THIS job's hub"""
+        if s.getsockname() == s.getpeername():  # (connected to itself: see self.reply)
+            return False
+        s.settimeout(10.0)
+        s.sendall(_MAGIC + self.token + struct.pack("<i", self.rank))
+        return _recv_exact(s, len(_MAGIC) + 16) == _MAGIC + self.reply
+
     def _connect(self, addr, ports):
         deadline = time.time() + self.timeout
-        hello = _MAGIC + self.token + struct.pack("<i", self.rank)
         while True:
             for p in ports:
                 try:
@@ -195,9 +209,7 @@ class SocketGroup:
                 except OSError:
                     continue
                 try:
-                    s.settimeout(10.0)
-                    s.sendall(hello)
-                    if _recv_exact(s, len(_MAGIC) + 16) == _MAGIC + self.token:
+                    if self._client_handshake(s):
                         s.settimeout(self.timeout)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         self.sock = s

@@ -114,6 +114,12 @@ class EnsembleSampler:
         self._chain, self._logp, self._blobs = [], [], None
         self.blob_units = None
         self.naccepted = np.zeros(self.nwalkers)
+        if getattr(self, "_dev", None) is not None:
+            # several ranks: the ensemble all of them were found well at is kept NOW, behind the
+            # cleared books (a replay after the reference's burn-in -> reset -> run flow,
+            # core.py:483-487, 529-530, must not bring the burn-in's iteration count and
+            # acceptance counters back)
+            self._dev.keep_verified()
 
     @property
     def acceptance_fraction(self):

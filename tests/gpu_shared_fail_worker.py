@@ -18,6 +18,7 @@ from naima_amd.dist import HostComm  # noqa: E402
 from naima_amd.sampler import EnsembleSampler  # noqa: E402
 
 out, name, nw = sys.argv[1], sys.argv[2], int(sys.argv[3])
+flow = sys.argv[5] if len(sys.argv) > 5 else "plain"
 comm = HostComm()
 model, p0, raw, data, prior, labels = build_problem(name, na)
 nd = p0.size
@@ -29,6 +30,10 @@ with warnings.catch_warnings(record=True) as w:
     st = s.run_mcmc(pos, 5)
     st = s.run_mcmc(st, 40)            # launches 1 and 2 of the shared loop
     chain1 = s.get_chain()             # (flush: every rank verified, the ensemble kept)
+    if flow == "reset":
+        # the reference's burn-in -> reset -> run (core.py:483-487, 529-530): the ensemble is kept
+        # BEHIND the reset -- iteration 0, acceptance counters 0 -- and the replay starts there
+        s.reset()
     st = s.run_mcmc(st, 50)            # launch 3 gives up on rank 1 ...
     st = s.run_mcmc(st, 9, store=False)
     st = s.run_mcmc(st, 12)

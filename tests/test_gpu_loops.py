@@ -1078,8 +1078,9 @@ def test_shared_ensemble_two_ranks_one_gpu(na, tmp_path, name, nw, nranks):
             assert_allclose(have, w, rtol=1e-10, atol=1e-300, err_msg="%s of rank %d" % (key, r))
 
 
-@pytest.mark.parametrize("fail_at", [3, 4], ids=["third-launch", "fourth-launch"])
-def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_at):
+@pytest.mark.parametrize("fail_at,flow", [(3, "plain"), (4, "plain"), (3, "reset")],
+                         ids=["third-launch", "fourth-launch", "third-launch-after-reset"])
+def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_at, flow):
     """three ranks on the one GPU share cfg3's ensemble; one launch of ONE rank's resident loop is
     made to time out (NH_RUN_FAIL_AT: what another process taking the GPU's CUs would do).  The
     other ranks' launches starve of its records and give up too; nobody raises: at the next point
@@ -1087,7 +1088,10 @@ def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_a
     ensemble they kept at the previous such point, make the move stream again and repeat the steps
     with one launch and one all-gather per half-step -- the final chain, log-probabilities, blobs
     and acceptance equal one process's (the reference's Pool carries on likewise,
-    core.py:523-536)."""
+    core.py:523-536).  `reset`: the reference's burn-in -> reset -> run flow (core.py:483-487,
+    529-530) with the failure behind the reset -- the kept ensemble is the one BEHIND the reset
+    (iteration 0, acceptance counters 0), so the acceptance fraction of the replayed run is the
+    run's, not the burn-in's plus the run's."""
     import os
     import subprocess
     import sys
@@ -1098,7 +1102,8 @@ def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_a
     subprocess.check_call(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
          "--master-addr", "127.0.0.1", "--master-port", str(port),
-         os.path.join(root, "tests", "gpu_shared_fail_worker.py"), str(tmp_path), name, str(nw), str(fail_at)],
+         os.path.join(root, "tests", "gpu_shared_fail_worker.py"), str(tmp_path), name, str(nw), str(fail_at),
+         flow],
         cwd=root, timeout=900,
         env=dict(os.environ, MASTER_ADDR="127.0.0.1", NH_RUN_SPIN_LIMIT=str(1 << 22)))
     model, p0, raw, data, prior = _problem(na, name, {})
@@ -1108,13 +1113,15 @@ def test_shared_loop_that_gives_up_is_replayed_by_all_ranks(na, tmp_path, fail_a
     pos = p0 * (1 + 0.003 * np.random.default_rng(1).standard_normal((nw, nd)))
     st = s.run_mcmc(pos, 5)
     st = s.run_mcmc(st, 40)
+    if flow == "reset":
+        s.reset()
     st = s.run_mcmc(st, 50)
     st = s.run_mcmc(st, 9, store=False)
     st = s.run_mcmc(st, 12)
     want = dict(coords=st.coords, logp=st.log_prob, chain=s.get_chain(), lnp=s.get_log_prob(),
                 blob0=np.asarray(s.get_blobs()[0]), blob1=np.asarray(s.get_blobs()[1]),
                 curblob0=np.asarray(st.blobs[0]), acc=s.acceptance_fraction)
-    assert want["chain"].shape[0] == 107
+    assert want["chain"].shape[0] == (62 if flow == "reset" else 107)
     for r in range(3):
         for key, w in want.items():
             have = np.load(tmp_path / ("%s_%d.npy" % (key, r)))

@@ -394,3 +394,35 @@ def test_shared_ensemble_history_merge_on_two_ranks():
         assert np.array_equal(c, truth_c) and np.array_equal(l, truth_l)
         for have, want in zip(per, truth_b):
             assert np.array_equal(have, want)
+
+
+def test_control_plane_client_does_not_take_itself_for_the_hub():
+    """A rank that looks for the hub before the hub listens can be handed the very port it
+    connects to as its own source port on loopback (TCP simultaneous open): the socket is then
+    connected to ITSELF and echoes the hello.  Round 6 found one run in ~10 of two self-started
+    ranks dying of it ("control-plane message of 17592186044417 bytes": the rank's own four bytes
+    + half of its own header).  The handshake must refuse such a socket -- by the addresses, and
+    because the hub's answer is not a prefix of the hello."""
+    import socket
+    import struct
+
+    from naima_amd import dist
+    g = dist.SocketGroup(1, 1)  # (size 1: no connection is made; the handshake is driven by hand)
+    g.size = 2
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    try:
+        s.connect(s.getsockname())  # the self-connection, made deterministically
+    except OSError:
+        s.close()
+        pytest.skip("this kernel refuses a TCP self-connection")
+    try:
+        assert s.getsockname() == s.getpeername()
+        assert g._client_handshake(s) is False
+        # and without the address check: the echo of the hello is not the hub's answer
+        s.settimeout(5.0)
+        s.sendall(dist._MAGIC + g.token + struct.pack("<i", 1))
+        echo = dist._recv_exact(s, len(dist._MAGIC) + 16)
+        assert echo == dist._MAGIC + g.token and echo != dist._MAGIC + g.reply
+    finally:
+        s.close()
