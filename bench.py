@@ -312,11 +312,22 @@ def launch_ranks(n):
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible.  One rank per GPU needs "
                          "%d; set NAIMA_AMD_DEVICE=<k> to rehearse all ranks on ONE device."
                          % (n, ndev, n))
+    import tempfile
     port = _free_port()
     procs = []
+    # first-contact hardening: every rank reports how far it has come (one word in a file of its
+    # own: "ctx" = GPU context made, "comm" = communicator made, "done"); a rank that stays between
+    # "ctx" and "comm" for too long is stuck in communicator creation -- ncclCommInitRank waits
+    # for every rank and cannot be interrupted from inside -- and a run that exceeds its budget is
+    # stuck somewhere else: every process group started here is ended, the stuck ranks are named,
+    # the exit code is non-zero.  (The driver's limit for a line is 1 800 s.)
+    comm_limit = float(os.environ.get("NAIMA_AMD_LAUNCH_COMM_TIMEOUT", "300"))
+    budget = float(os.environ.get("NAIMA_AMD_BENCH_BUDGET", "1500"))
+    pdir = tempfile.mkdtemp(prefix="naima_amd_ranks_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NAIMA_AMD_SELF_SPAWNED="1",
+                   NAIMA_AMD_PROGRESS_FILE=os.path.join(pdir, "rank%d" % r),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if pinned is not None:
             env.setdefault("NAIMA_AMD_COMM", "host")
@@ -324,7 +335,33 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, cwd=ROOT, start_new_session=True,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def progress(r):
+        try:
+            return open(os.path.join(pdir, "rank%d" % r)).read().split()
+        except OSError:
+            return []
+
+    def end_all(which):
+        for pr in which:  # (exactly the process groups started above)
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 5.0
+        for pr in which:
+            while pr.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+
     rc = 0
+    t_start = time.time()
+    ctx_seen = {}
     try:
         alive = list(procs)
         while alive:
@@ -335,32 +372,81 @@ def launch_ranks(n):
                 alive.remove(pr)
                 if c != 0 and rc == 0:
                     rc = c
-                    for other in alive:  # (exactly the process groups started above)
-                        try:
-                            os.killpg(other.pid, signal.SIGTERM)
-                        except OSError:
-                            pass
+                    end_all(alive)
+            now = time.time()
+            stuck = []
+            for r, pr in enumerate(procs):
+                if pr.poll() is not None:
+                    continue
+                seen = progress(r)
+                if "ctx" in seen and r not in ctx_seen:
+                    ctx_seen[r] = now
+                if "comm" not in seen and r in ctx_seen and now - ctx_seen[r] > comm_limit:
+                    stuck.append(r)
+            if stuck and rc == 0:
+                sys.stderr.write("bench.py --gpus %d: rank(s) %s have not passed communicator creation "
+                                 "within %.0f s of having a GPU context (RCCL probe / ncclCommInitRank); "
+                                 "ending all ranks\n" % (n, stuck, comm_limit))
+                rc = 18
+                end_all(alive)
+            elif now - t_start > budget and rc == 0:
+                where = {r: (progress(r) or ["started"])[-1] for r, pr in enumerate(procs)
+                         if pr.poll() is None}
+                sys.stderr.write("bench.py --gpus %d: the run exceeded its budget of %.0f s; ranks still "
+                                 "running and the last stage each reported: %s; ending all ranks\n"
+                                 % (n, budget, where))
+                rc = 19
+                end_all(alive)
             time.sleep(0.05)
     except KeyboardInterrupt:
         rc = 130
-        for pr in procs:
-            if pr.poll() is None:
-                try:
-                    os.killpg(pr.pid, signal.SIGTERM)
-                except OSError:
-                    pass
+        end_all(procs)
+    finally:
+        import shutil
+        shutil.rmtree(pdir, ignore_errors=True)
     raise SystemExit(rc)
 
 
-def exchange_info(sampler, comm, shared_note):
-    """which exchange path the ranks took for the one exchange of a half-step, and why"""
+def report_progress(stage):
+    """one word per stage into the file the rank's launcher watches (launch_ranks)"""
+    f = os.environ.get("NAIMA_AMD_PROGRESS_FILE")
+    if f:
+        try:
+            with open(f, "a") as fh:
+                fh.write(stage + "\n")
+        except OSError:
+            pass
+
+
+def exchange_info(sampler, comm, shared_note, ctx=None):
+    """which exchange path the ranks took for the one exchange of a half-step, and why: the
+    ladder's rungs in the order they were tried -- records stored into each other's rings by the
+    resident loop | one launch + one RCCL all-gather per half-step | the same with the all-gather
+    staged through the host -- and who the ranks are (PCI bus id of each rank's GPU; the live
+    communicator's own count).  Collective: every rank calls it."""
     dev = getattr(sampler, "_dev", None)
     if dev is None or comm.size == 1:
         return {"path": "none (one rank)", "ranks": comm.size}
     kind = type(comm).__name__
-    out = {"ranks": comm.size, "communicator": kind,
-           "rccl_nranks": comm.size if kind == "RcclComm" else None}
-    if getattr(dev, "shared", False):
+    out = {"ranks": comm.size, "communicator": kind, "rccl_nranks": None}
+    if kind == "RcclComm":
+        # (what ncclCommCount says of the communicator that exists, not Python's idea of the world)
+        live = comm.live_info()
+        out["rccl_nranks"], out["rccl_device"] = live["nranks"], live["device"]
+    group = getattr(comm, "group", None)
+    if group is not None and ctx is not None:
+        ids = [p_.decode() for p_ in group.allgather_bytes(ctx.pci_bus_id().encode())]
+        out["devices"] = ids
+        out["devices_distinct"] = len(set(ids)) == len(ids)
+    shared = bool(getattr(dev, "shared", False))
+    ladder = [dict(rung="shared_resident_loop", taken=shared,
+                   why="" if shared else (getattr(dev, "resident_reason", None) or shared_note or ""))]
+    if not shared:
+        ladder += list(getattr(comm, "ladder", None) or
+                       [dict(rung="RCCL all-gather" if kind == "RcclComm" else "host-staged all-gather",
+                             taken=True, why="")])
+    out["ladder"] = ladder
+    if shared:
         out.update(path="shared_resident_loop", why=shared_note,
                    probe_us_per_exchange=(dev.shared_info or {}).get("probe_us_per_exchange"))
     else:
@@ -547,7 +633,7 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
     # (collective: every rank's counts meet here)
     forbidden, nan_rej = int(sampler.prior_forbidden_proposals), int(sampler.nan_proposals)
     proposals_total = int(sampler.steps_total) * int(nwalkers)
-    xinfo = exchange_info(sampler, comm, shared_note)
+    xinfo = exchange_info(sampler, comm, shared_note, ctx)
 
     if rank != 0:
         return None
@@ -794,10 +880,26 @@ def main():
 
     from naima_amd import _lib, dist
 
+    if world > 1:
+        # (a rank of several: whatever blocks for ever ends the rank, with a message, well inside
+        # the driver's 1 800 s -- its launcher then ends the others)
+        dist._Watchdog("the whole bench run", float(os.environ.get("NAIMA_AMD_BENCH_BUDGET", "1500"))).__enter__()
     ctx = _lib.get_context()  # raises when libnaima_hip.so or the GPU is missing
+    report_progress("ctx")
+    if os.environ.get("NAIMA_AMD_TEST_STALL_BEFORE_COMM") == os.environ.get("RANK", "0"):
+        time.sleep(3600)  # (tests: this rank never reaches communicator creation)
     comm = dist.from_env(os.environ.get("NAIMA_AMD_COMM", "rccl"))  # host: test hook / one-GPU rehearsal
+    report_progress("comm")
     if comm.size != args.gpus:
         raise SystemExit("--gpus %d but the communicator has %d rank(s)" % (args.gpus, comm.size))
+    if comm.size > 1:
+        # one rank per GPU: the ranks' PCI bus ids are distinct, unless NAIMA_AMD_DEVICE pinned
+        # them to one device on purpose (the one-GPU rehearsal)
+        ids = [p_.decode() for p_ in comm.group.allgather_bytes(ctx.pci_bus_id().encode())]
+        if len(set(ids)) != len(ids) and not os.environ.get("NAIMA_AMD_DEVICE"):
+            raise SystemExit("bench.py --gpus %d: ranks share a GPU (PCI bus ids %s) although "
+                             "NAIMA_AMD_DEVICE does not pin them; LOCAL_RANK / the visible devices "
+                             "are not what one rank per GPU needs" % (args.gpus, ids))
     out = measure(args, ctx, comm, args.workload, args.scaling, args.walkers, args.walkers_total,
                   full=True)
     split = BASELINE_SPLIT.get(comm.size)
@@ -812,6 +914,7 @@ def main():
             sub = {"error": "%s: %s" % (type(e).__name__, e)} if comm.rank == 0 else None
         if out is not None:
             out["baseline_split"] = sub
+    report_progress("done")
     if comm.rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -75,6 +75,10 @@ int nh_destroy(nh_ctx* ctx);
 int nh_device_count(int* count);
 int nh_device_info(nh_ctx* ctx, char* name, int name_len, int* compute_units,
                    double* hbm_bytes, int* clock_khz);
+/* PCI bus id of the context's GPU, e.g. "0000:c1:00.0" (len >= 16): one worker per GPU is the
+ * reference's Pool(threads) with GPUs for workers (core.py:446-457) -- a launcher checks that the
+ * ranks' ids are distinct */
+int nh_device_pci_bus_id(nh_ctx* ctx, char* out, int len);
 int nh_alloc(nh_ctx* ctx, long long bytes, void** dev_out);
 int nh_free(nh_ctx* ctx, void* dev);
 int nh_upload(nh_ctx* ctx, void* dev_dst, const void* host_src, long long bytes);
@@ -750,6 +754,9 @@ int nh_comm_available(void);
 int nh_comm_unique_id(char* id_out /*[NH_UNIQUE_ID_BYTES]*/);
 int nh_comm_init(nh_ctx* ctx, int rank, int nranks, const char* id);
 int nh_comm_destroy(nh_ctx* ctx);
+/* what the live communicator says of itself (ncclCommCount, ncclCommUserRank, ncclCommCuDevice):
+ * the workers the reference's Pool(threads) would report, core.py:446-457 */
+int nh_comm_info(nh_ctx* ctx, int* nranks, int* rank, int* device);
 /* recv[r*count .. (r+1)*count) = send of rank r (device buffers, float64 count) */
 int nh_comm_allgather(nh_ctx* ctx, const double* send, double* recv, long long count);
 

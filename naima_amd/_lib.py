@@ -34,6 +34,7 @@ _SIGS = {
     "nh_destroy": [_dp],
     "nh_device_count": [C.POINTER(_i)],
     "nh_device_info": [_dp, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_i)],
+    "nh_device_pci_bus_id": [_dp, C.c_char_p, _i],
     "nh_alloc": [_dp, _ll, C.POINTER(_dp)],
     "nh_free": [_dp, _dp],
     "nh_upload": [_dp, _dp, _dp, _ll],
@@ -108,6 +109,7 @@ _SIGS = {
     "nh_comm_unique_id": [C.c_char_p],
     "nh_comm_init": [_dp, _i, _i, C.c_char_p],
     "nh_comm_destroy": [_dp],
+    "nh_comm_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "nh_comm_allgather": [_dp, _dp, _dp, _ll],
     "nh_half_step_create": [_dp, _dp, C.POINTER(_dp)],
     "nh_half_step_begin_block": [_dp, _dp, _i, _i],
@@ -1068,6 +1070,11 @@ class Context:
         return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=hbm.value,
                     clock_khz=clk.value)
 
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        _chk(_lib.nh_device_pci_bus_id(self.h, buf, 64))
+        return buf.value.decode()
+
     # -- timing ---------------------------------------------------------------
     def timer_start(self):
         _chk(_lib.nh_timer_start(self.h))
@@ -1164,6 +1171,13 @@ def get_context(device=None):
     """process-wide default context (device from NAIMA_AMD_DEVICE / LOCAL_RANK, else 0)"""
     if device is None:
         device = int(os.environ.get("NAIMA_AMD_DEVICE") or os.environ.get("LOCAL_RANK") or "0")
+        if not os.environ.get("NAIMA_AMD_DEVICE") and device > 0:
+            # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES /
+            # ROCR_VISIBLE_DEVICES per rank) leaves LOCAL_RANK pointing past the one device the
+            # rank sees: take what is visible (bench.py checks that the ranks' PCI bus ids differ)
+            n = device_count()
+            if 0 < n <= device:
+                device = device % n
     ctx = _default.get(device)
     if ctx is None:
         ctx = Context(device)

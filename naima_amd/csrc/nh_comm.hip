@@ -21,6 +21,9 @@ struct rccl_api {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 static rccl_api g_rccl;
@@ -55,6 +58,9 @@ static int rccl_load() {
   NH_SYM(CommDestroy, "ncclCommDestroy")
   NH_SYM(AllGather, "ncclAllGather")
   NH_SYM(GetErrorString, "ncclGetErrorString")
+  NH_SYM(CommCount, "ncclCommCount")
+  NH_SYM(CommUserRank, "ncclCommUserRank")
+  NH_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef NH_SYM
   g_rccl.lib = h;
   return NH_OK;
@@ -93,6 +99,19 @@ extern "C" int nh_comm_init(nh_ctx* c, int rank, int nranks, const char* idbytes
   ncclComm_t comm;
   NH_CHECK_RCCL(g_rccl.CommInitRank(&comm, nranks, id, rank));
   c->comm = comm;
+  return NH_OK;
+}
+
+// What the LIVE communicator says of itself -- ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+// -- not what the caller believes it asked for: bench.py prints these (`rccl_nranks`), so that the
+// day RCCL sees fewer ranks than the launcher started the line shows it.
+extern "C" int nh_comm_info(nh_ctx* c, int* nranks, int* rank, int* device) {
+  NH_REQUIRE(c && nranks && rank && device, "bad argument");
+  NH_REQUIRE(c->comm != nullptr, "nh_comm_init has not been called");
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm);
+  NH_CHECK_RCCL(g_rccl.CommCount(comm, nranks));
+  NH_CHECK_RCCL(g_rccl.CommUserRank(comm, rank));
+  NH_CHECK_RCCL(g_rccl.CommCuDevice(comm, device));
   return NH_OK;
 }
 

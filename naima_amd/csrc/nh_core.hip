@@ -171,6 +171,15 @@ extern "C" int nh_device_info(nh_ctx* c, char* name, int name_len, int* cus, dou
   return NH_OK;
 }
 
+// The PCI bus id of the context's GPU ("0000:c1:00.0"): what tells two ranks apart that were
+// meant to sit on different GPUs (bench.py prints every rank's and refuses a run whose ranks
+// share a device unless NAIMA_AMD_DEVICE pinned them there on purpose).
+extern "C" int nh_device_pci_bus_id(nh_ctx* c, char* out, int len) {
+  NH_REQUIRE(c && out && len >= 16, "bad argument");
+  NH_CHECK_HIP(hipDeviceGetPCIBusId(out, len, c->device));
+  return NH_OK;
+}
+
 extern "C" int nh_alloc(nh_ctx* c, long long bytes, void** out) {
   NH_REQUIRE(c && out && bytes >= 0, "bad argument");
   NH_CHECK_HIP(hipSetDevice(c->device));

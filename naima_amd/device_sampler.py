@@ -1049,6 +1049,10 @@ class DeviceLoop:
         ok = lib.nh_half_step_run_probe(ctx.h, h, 64, C.byref(st), C.byref(us)) == 0 and \
             st.value == 0
         why = "" if ok else lib.nh_last_error().decode()
+        if "ring" in os.environ.get("NAIMA_AMD_LADDER_REFUSE", "").split(","):
+            # (tests: this rung of the exchange ladder refused although the probe went well -- the
+            # ranks then take the next one, as on a node whose GPUs cannot store into each other)
+            ok, why = False, "refused on request (NAIMA_AMD_LADDER_REFUSE=ring: fault injection of the tests)"
         if not agreed(ok):
             return give_up("a record stored by another GPU did not reach a running kernel; %s" % why)
         self._res["runs"].append(h)

@@ -385,33 +385,20 @@ class RcclComm:
         hipGraph capture and replay.  Probed once, in a throw-away process per rank with
         its own rendezvous (``python -m naima_amd._rccl_probe``): a collective that hangs
         under capture then costs the probe its timeout, not the run.  Every rank gets the
-        same answer (minimum over ranks)."""
+        same answer (minimum over ranks).  (from_env has normally run the probe already,
+        ahead of the communicator itself.)"""
         if self._graph_ok is None:
-            import subprocess
-            import sys
-            ok = False
-            proc = None
-            port = self.group.free_port()  # the probes' own rendezvous (agreed by all ranks)
-            try:
-                env = dict(os.environ)
-                env["MASTER_PORT"] = str(port)
-                env["NAIMA_AMD_DEVICE"] = str(self.ctx.device)
-                env["RANK"], env["WORLD_SIZE"] = str(self.rank), str(self.size)
-                env["NAIMA_AMD_GROUP_SALT"] = "rccl-probe"
-                env.pop("NAIMA_AMD_FORCE_SHARDED", None)
-                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-                proc = subprocess.Popen([sys.executable, "-m", "naima_amd._rccl_probe"], env=env,
-                                        cwd=root, stdout=subprocess.PIPE,
-                                        stderr=subprocess.DEVNULL)
-                out, _ = proc.communicate(timeout=timeout)
-                ok = proc.returncode == 0 and b"captured + replayed ok: True" in out
-            except Exception:
-                ok = False
-                if proc is not None and proc.poll() is None:
-                    proc.kill()  # this probe only: the PID we started
-                    proc.wait()
-            self._graph_ok = self.group.reduce_scalar(1.0 if ok else 0.0, "min") == 1.0
+            self._graph_ok = run_rccl_probe(self.group, self.ctx.device, timeout)["graph"]
         return self._graph_ok
+
+    def live_info(self):
+        """what the LIVE communicator says of itself: ncclCommCount / UserRank / CuDevice"""
+        import ctypes as C
+
+        from . import _lib
+        n, r, d = C.c_int(), C.c_int(), C.c_int()
+        _lib._chk(_lib.load().nh_comm_info(self.ctx.h, C.byref(n), C.byref(r), C.byref(d)))
+        return dict(nranks=n.value, rank=r.value, device=d.value)
 
     def allgather(self, x):
         """ranks contribute equal-sized blocks (the sampler pads to the largest shard)"""
@@ -441,18 +428,120 @@ class RcclUnavailable(RuntimeError):
     pass
 
 
+def run_rccl_probe(group, device, timeout=None):
+    """Collective over ``group``: every rank starts ``python -m naima_amd._rccl_probe`` -- a
+    throw-away process with its own rendezvous that builds an RCCL communicator of the same ranks
+    on the same devices, all-gathers eagerly, then under hipGraph capture and replay -- and the
+    ranks agree on what it saw: {"init": communicator + eager all-gather fine on EVERY rank,
+    "graph": ... and inside a graph, "why": the first complaint}.  ncclCommInitRank blocks until
+    every rank has called it and cannot be interrupted: a set of ranks on which it hangs (or
+    fails, or an all-gather hangs under capture) costs the probe its timeout, not the run."""
+    import subprocess
+    import sys
+    if timeout is None:
+        timeout = float(os.environ.get("NAIMA_AMD_RCCL_PROBE_TIMEOUT", "120"))
+    eager = graph = False
+    why, proc = "", None
+    port = group.free_port()  # the probes' own rendezvous (agreed by all ranks)
+    try:
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(port)
+        env["NAIMA_AMD_DEVICE"] = str(device)
+        env["RANK"], env["WORLD_SIZE"] = str(group.rank), str(group.size)
+        env["NAIMA_AMD_GROUP_SALT"] = "rccl-probe"
+        env.pop("NAIMA_AMD_FORCE_SHARDED", None)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        proc = subprocess.Popen([sys.executable, "-m", "naima_amd._rccl_probe"], env=env,
+                                cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        out, err = proc.communicate(timeout=timeout)
+        eager = b"eager ok: True" in out
+        graph = proc.returncode == 0 and b"captured + replayed ok: True" in out
+        if not eager:
+            tail = [ln for ln in err.decode(errors="replace").splitlines() if ln.strip()]
+            why = "rank %d's probe: %s" % (group.rank, tail[-1][:300] if tail else
+                                           "exit code %s" % proc.returncode)
+    except subprocess.TimeoutExpired:
+        why = "rank %d's probe did not finish within %.0f s (ncclCommInitRank or an all-gather hangs)" \
+              % (group.rank, timeout)
+    except Exception as e:
+        why = "rank %d's probe could not run: %r" % (group.rank, e)
+    finally:
+        if proc is not None and proc.poll() is None:
+            proc.kill()  # this probe only: the PID we started
+            proc.wait()
+    parts = group.allgather_bytes(struct.pack("<??", eager, graph) + why.encode())
+    flags = [struct.unpack("<??", p_[:2]) for p_ in parts]
+    whys = [p_[2:].decode(errors="replace") for p_ in parts if len(p_) > 2]
+    return dict(init=all(f[0] for f in flags), graph=all(f[1] for f in flags),
+                why=whys[0] if whys else "")
+
+
+class _Watchdog:
+    """``with _Watchdog(what, seconds):`` -- a step that can block for ever inside a library call
+    (ncclCommInitRank waits for every rank; a rank that never comes leaves the others inside it,
+    where no Python exception can reach them).  When the time is up the process says which rank
+    was stuck in what and exits with code 17: its launcher (bench.py's own, torch.distributed.run)
+    then ends the other ranks.  The driver's limit for a bench line is 1 800 s; this is 120."""
+
+    def __init__(self, what, seconds):
+        import threading
+        self.what, self.seconds = what, float(seconds)
+        self._done = threading.Event()
+        self._t = threading.Thread(target=self._watch, daemon=True)
+
+    def _watch(self):
+        if not self._done.wait(self.seconds):
+            import sys
+            sys.stderr.write("naima_amd: rank %s stuck in %s for %.0f s -- giving up (exit 17)\n"
+                             % (os.environ.get("RANK", "0"), self.what, self.seconds))
+            sys.stderr.flush()
+            os._exit(17)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
 def from_env(prefer="rccl"):
     """LocalComm for a single process, else RCCL (GPU) or the host-staged control plane
-    (``prefer="host"``: CPU tests)"""
+    (``prefer="host"``: CPU tests).  The returned communicator says how it came about:
+    ``comm.ladder`` = the rungs tried, in order, each {"rung", "taken", "why"}."""
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and \
             os.environ.get("NAIMA_AMD_FORCE_SHARDED", "0") != "1":
         return LocalComm()
     if prefer != "rccl":
-        return HostComm()
-    try:
-        return RcclComm()  # collective: succeeds or raises on every rank alike
-    except RcclUnavailable as e:
-        import warnings
-        warnings.warn("RCCL communicator unavailable (%s); all-gathers are staged through the "
-                      "host over the control plane: correct, slower" % (e,))
-        return HostComm()
+        c = HostComm()
+        c.ladder = [dict(rung="RCCL all-gather", taken=False,
+                         why="NAIMA_AMD_COMM=%s asks for the host-staged control plane" % prefer),
+                    dict(rung="host-staged all-gather", taken=True, why="")]
+        return c
+    import warnings
+    group = default_group()
+    limit = float(os.environ.get("NAIMA_AMD_COMM_TIMEOUT", "120"))
+    why, graph = None, None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("NAIMA_AMD_RCCL_PROBE", "1") != "0":
+        # the communicator is built in a throw-away process FIRST (collective: every rank the same)
+        from . import _lib
+        pr = run_rccl_probe(group, _lib.get_context().device)
+        graph = pr["graph"]
+        if not pr["init"]:
+            why = "the probe processes could not build an RCCL communicator of these ranks (%s)" % pr["why"]
+    if why is None:
+        try:
+            with _Watchdog("RCCL communicator creation (ncclCommInitRank)", limit):
+                c = RcclComm()  # collective: succeeds or raises on every rank alike
+            c._graph_ok = graph
+            c.ladder = [dict(rung="RCCL all-gather", taken=True, why="")]
+            return c
+        except RcclUnavailable as e:
+            why = str(e)
+    warnings.warn("RCCL communicator unavailable (%s); all-gathers are staged through the "
+                  "host over the control plane: correct, slower" % (why,))
+    c = HostComm()
+    c.ladder = [dict(rung="RCCL all-gather", taken=False, why=why),
+                dict(rung="host-staged all-gather", taken=True, why="")]
+    return c

@@ -105,3 +105,18 @@ def test_bench_refuses_more_ranks_than_devices():
     n = _lib.device_count()
     p = _bench(["--gpus", str(n + 1), "--steps", "2", "--warmup", "2", "--no-cpu"], timeout=120)
     assert p.returncode != 0 and "visible" in (p.stderr + p.stdout)
+
+
+def test_cfg4_line_never_claims_more_than_the_peak():
+    """cfg4 (the staged plan: two k_half_step launches around the SSC seed integral): every
+    `frac` of the line is a fraction -- round 5's line credited the SSC kernel with 1.006 of the
+    FP64 peak (an op-count convention that counted a five-instruction reciprocal as 20) -- and the
+    span clock covers the whole half-step (the first launch opens it, the last closes it)"""
+    d = _line(_bench(["--workload", "cfg4", "--walkers", "64", "--steps", "4", "--warmup", "2",
+                      "--no-cpu", "--min-time", "0.05", "--no-blobs-run"]))
+    assert d["config"]["workload"].startswith("cfg4")
+    assert 0.0 < d["roofline"]["frac"] < 1.0
+    for k, v in d["fp64_valu"]["kernels"].items():
+        assert 0.0 < v["frac"] <= 1.0, (k, v)
+    assert d["region_overhead_us"] >= 0.0
+    assert d["region_overhead"]["device_spans_per_region"] == 8  # (one per half-step)
