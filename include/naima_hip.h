@@ -708,6 +708,11 @@ int nh_half_step_run_syn_info(const nh_halfstep_run* run, int* mode, int* nodes_
  * divide the grid's ROWS between them (table-only models: core.py:450-457's one evaluation per
  * walker on two compute units, each with half of radiative.py:1495-1536's proton grid) */
 int nh_half_step_run_split_info(const nh_halfstep_run* run, int* split, int* rows);
+/* *deep = 1 when the loop's launches keep TWO walkers of a workgroup in flight (ensembles of more
+ * walkers per half-step than resident workgroups: a workgroup's next walker has its records,
+ * proposal and parameter packs made while the current one's work items run, and its weights
+ * start while the current one's likelihood -- core.py:64-121 -- is still being summed) */
+int nh_half_step_run_pipeline_info(const nh_halfstep_run* run, int* deep);
 int nh_half_step_run_table_info(const nh_halfstep_run* run, int* in_registers, int* nodes_max);
 /* NH_HS_DEBUG=1: out[256][64][8] wall-clock stamps (100 MHz) of the last launch, per
  * (workgroup, slice handled): start | records in | packs done | weights done | own items

@@ -139,6 +139,7 @@ _SIGS = {
     "nh_half_step_run_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)],
     "nh_half_step_run_syn_info": [_dp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "nh_half_step_run_split_info": [_dp, C.POINTER(_i), C.POINTER(_i)],
+    "nh_half_step_run_pipeline_info": [_dp, C.POINTER(_i)],
     "nh_half_step_run_table_info": [_dp, C.POINTER(_i), C.POINTER(_i)],
     "nh_half_step_run_stamps": [_dp, _dp, _dp],
     "nh_half_step_run_destroy": [_dp, _dp],

@@ -54,6 +54,8 @@
 #define HS_RUN_ERR_LAST_ROW 3  // (epilogue of a shared ensemble: a rank's last records never came)
 #define HS_RUN_MAX_RANKS 8     // GPUs of one node that may share an ensemble
 #define HS_RUN_HEAD 512        // granules ahead of the rings in a shared allocation (probe slots)
+#define HS_O_HX 56           // two ints of the small block: HX_PRE, HX_SPECRD (two walkers in flight)
+enum { HX_PRE = 0, HX_SPECRD = 1 };
 #define HS_O_LNA 48          // in the small per-walker block (proposal coordinates: <= 15 of its first 64 doubles)
 #define HS_RUN_TRAIL 16        // ints of first-row entries per table in LDS (>= tiles of any table)
 #define HS_RUN_PKW 8           // doubles per parameter-pack column in LDS
@@ -172,6 +174,7 @@ struct hs_run {
   double s2_z0, s2_invd;  // z = s2_z0 - ln(q) s2_invd: where node 0 sits on the comb below T_top
   double s2_r746;         // (T_top - ln 746) s2_invd - s2_z0: the first live node is ceil(ln(q) s2_invd + this)
   double s2_lnw0;         // ln |n| + ln(E / eV) above this: the weight gamma n scale is not 0 in double
+  int pipeline;           // two walkers in flight (a workgroup with several walkers of a slice): NH_RUN_PIPELINE
   long long* clk;         // the context's span clock (nh_common.h): this launch opens a span, k_run_epilogue closes it
 };
 
@@ -490,7 +493,10 @@ __device__ __forceinline__ int hsr_weights_kind(int kind, unsigned a_ut, unsigne
 // neither form carries the other's registers and code
 // RT > 0: a table-only model in workgroups of at most 512 threads whose table items stay in
 // registers for the launch, RT nodes per lane at most (nh_hs.h: hs_rt_item)
-template <bool SYN, bool MULTI, bool S2, int RT = 0>
+struct hsr_a_out { double pval; int pcol, bad, ok; };  // what phase A leaves in wave 0's registers
+// DEEP: two walkers in flight -- an instance of its own (launches whose workgroups have several
+// walkers of a slice to themselves): the other instances' code is the code it was, to the register
+template <bool SYN, bool MULTI, bool S2, int RT = 0, bool DEEP = false>
 __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_hot H, const hs_run R) {
   extern __shared__ double sm[];
   const hs_dev& D = H.C;
@@ -510,6 +516,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
   // =========================== once per launch ==============================================
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid0 == 0) nh_clk_open(R.clk);
   if (wv == nwv - 1) sm[HS_O_T64 + lane] = exp2((double)lane * 0.015625);
+  if (DEEP && tid0 < 2) {  // (two walkers in flight: nothing made ahead, nothing read yet)
+    int* hx0 = reinterpret_cast<int*>((tid0 ? sm + R.o_small1 : sm) + HS_O_HX);
+    hx0[HX_PRE] = 0;
+    hx0[HX_SPECRD] = 0;
+  }
   for (int g = 0; g < H.ngrids; ++g) {
     const int nG = H.nG[g];
     for (int i = tid; i < nG; i += T) {
@@ -903,6 +914,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
     }
   }
 
+  // (two walkers in flight: only where a workgroup has the walker to itself and more than one of
+  // a slice -- the 1024-thread instances on ensembles of more walkers than twice the CUs)
+  constexpr bool deep = DEEP;  // (hs_run_create: RT == 0, K == 1, more walkers of a slice than workgroups)
   // =========================== the slices ====================================================
   int it = 0;
   for (int s = 0; s < R.nslices; ++s) {
@@ -923,159 +937,67 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       double* accs = qs + HS_O_ACC;
       int* hi = reinterpret_cast<int*>(qs + HS_O_INT);
       double* olds = sm + R.o_olds + par * 64;
+      int* hx_cur = reinterpret_cast<int*>(qs + HS_O_HX);
       HSR_STAMP(0);
       double pval = 0.0;  // (wave 0) this lane's parameter-pack column, once evaluated ...
       int pcol = -1;      // ... and which one it is (-1: none)
       int slice_bad = 0;  // (wave 0) the records never came
       // ---- A. wave 0: the two records, the proposal, the parameter packs ---------------------
-      if (wv == 0) {
-        const int g = H.lo + j;
-        const int me = idx[g], pa = idx[ns + g];
-        const double mz = r[g], mlnu = r[ns + g];
-        if (lane == 0) {
-          hi[HI_CNT] = 0;
-          hi[HI_LIVE] = 0;
-          hi[HI_READY] = 0;
-          hi[HI_NZ] = 0;
-          hi[HI_TICK] = 0;  // (here: the abort flag of this slice)
+      // (a function of the walker it is made for: wave 0 makes the NEXT walker's, too, ahead of its
+      // own work items when this workgroup has more walkers to come -- `ahead`: one look at the
+      // records, no waiting; see "two walkers in flight" below)
+      auto phase_a = [&](int s_, int j_, int par_) -> hsr_a_out {
+        double pval = 0.0;
+        int pcol = -1, slice_bad = 0;
+        const int tl = s_ >> 1, half = s_ & 1;
+        const double* r = H.blk + (long long)(R.slice0 + s_) * 3 * ns;
+        const int* idx = reinterpret_cast<const int*>(r + 2 * ns);
+        const int j = j_;
+        double* qs = par_ ? sm + R.o_small1 : sm;
+        double* row = qs + HS_O_ROW;
+        double* lg = qs + HS_O_LG;
+        double* accs = qs + HS_O_ACC;
+        int* hi = reinterpret_cast<int*>(qs + HS_O_INT);
+        int* hx = reinterpret_cast<int*>(qs + HS_O_HX);
+        double* olds = sm + R.o_olds + par_ * 64;
+        {
+#define HSR_A_AHEAD true
+#define HSR_A_NOT_YET return hsr_a_out{0.0, -1, 0, 0}
+#include "nh_persist_phase_a.inc"
+#undef HSR_A_AHEAD
+#undef HSR_A_NOT_YET
         }
-        // lanes 0 .. GRn-1: my own record in row tl (the state after the previous step);
-        // lanes 32 .. 32+GRn-1: the partner's -- row tl for the first half of a step, row
-        // tl + 1 for the second (the partner has moved in the first half of THIS step)
-        // this lane's parameter-pack column (walker-independent: read BEFORE the wait for the
-        // records, so that what follows their arrival is shuffles and arithmetic only -- the byte
-        // of pkd was a vector load from the kernel-argument segment behind the records, the
-        // descriptor three dependent LDS trips)
-        double pk_a = 0.0, pk_b = 0.0, pk_c = 0.0, pk_lna = 0.0;
-        int pk_tf = 0, pk_nc = 0, pkd = -1;
-        if (lane < npk8) {
-          const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
-          pk_a = o[0]; pk_b = o[1]; pk_c = o[2];
-          pk_tf = reinterpret_cast<const int*>(o + 3)[0];
-          pk_nc = reinterpret_cast<const int*>(o + 3)[1];
-          pk_lna = o[6];
-          pkd = reinterpret_cast<const int*>(o + 7)[0];
-        }
-        const bool mine = lane < GRn, theirs = lane >= 32 && lane - 32 < GRn;
-        const int prow = tl + half;
-        const unsigned long long* src =
-            R.ring + ((long long)(lane < 32 ? tl : prow) * N + (lane < 32 ? me : pa)) * R.gr +
-            (lane & 31);
-        const unsigned want = hs_tag(R.seq, lane < 32 ? tl : prow);
-        unsigned long long v = 0;
-        bool ok = !(mine || theirs);
-        int spins = 0, bad = 0;
-        for (;;) {
-          if (!ok) {
-            v = multi ? hs_ld_sys(src) : hs_ld_sc1(src);
-            ok = (unsigned)(v >> 32) == want;
-          }
-          if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
-          ++spins;
-          if ((spins & 255) == 0) {  // somebody else has given up: so do we
-            int st = 0;
-            if (lane == 0)
-              st = (int)__hip_atomic_load(R.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            st = __builtin_amdgcn_readfirstlane(st);
-            if (st != 0) { bad = HS_RUN_ERR_PEER; break; }
-          }
-          if (spins > R.spin_limit) { bad = HS_RUN_ERR_TIMEOUT; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        slice_bad = bad;
-        if (bad) {
-          if (lane == 0) {
-            hi[HI_TICK] = bad;
-            if (bad == HS_RUN_ERR_TIMEOUT)
-              __hip_atomic_store(R.status, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        const unsigned pl = (unsigned)v;
-        const int d2 = (2 * lane) & 31;
-        const unsigned mlo = (unsigned)__shfl((int)pl, d2, 64);
-        const unsigned mhi = (unsigned)__shfl((int)pl, d2 + 1, 64);
-        const unsigned plo = (unsigned)__shfl((int)pl, 32 + d2, 64);
-        const unsigned phi = (unsigned)__shfl((int)pl, 33 + d2, 64);
-        const double sme = __hiloint2double((int)mhi, (int)mlo);
-        const double spa = __hiloint2double((int)phi, (int)plo);
-        const double q = spa - (spa - sme) * mz;  // emcee StretchMove.get_proposal
-        if (lane < ndim) {
-          qs[lane] = q;
-          olds[lane] = sme;
-        }
-        if (lane == ndim) accs[2] = sme;  // the old log-probability rides behind the coordinates
-        if (lane == 0) {
-          accs[0] = mz;
-          accs[1] = mlnu;
-          hi[HI_ME] = me;
-          hi[HI_PA] = pa;
-        }
-        HSR_STAMP(1);
-        // the packs: thread t < 8 npacks evaluates column t % 8 of pack t / 8 from ONE proposed
-        // coordinate (which one is walker-independent: a byte of pkd), taken by a shuffle
-        const double qv = __shfl(q, pkd < 0 ? 0 : pkd, 64);
-        if (lane < npk8) {
-          const double za = pk_a, zb = pk_b, zc = pk_c;
-          const int ztf = pk_tf, nc = pk_nc;
-          const int col = lane % NH_MAX_LAZY;
-          if (col < nc) {
-            double val = za;
-            // (the common fit -- every column the identity or a power of ten of its coordinate: one
-            // exp10 for the wave and a select.  hsr_lazy_apply takes the transform in a vector register
-            // and walks its switch as exec-mask regions, case by case: ~40 vector instructions of
-            // compares and masks around the 45 of the one transform that is there, on the wave
-            // everybody waits for.  The same operations on the same operands: the same bits.)
-            const bool odd = pkd >= 0 && ztf != NH_TF_ID && ztf != NH_TF_POW10;
-            if (__builtin_amdgcn_ballot_w64(odd) == 0ull) {
-              const double xl = zb * qv + zc;
-              const double xe = hsr_exp10(xl);
-              if (pkd >= 0) val = za * (ztf == NH_TF_POW10 ? xe : xl);
-            } else if (pkd >= 0) {
-              val = hsr_lazy_apply(za, zb, zc, ztf, qv);
-            }
-
-            if (lane / NH_MAX_LAZY == H.F.ppk) {  // the particle rows: also into LDS
-              row[col] = val;
-              // (ln of e_0, e_cutoff, e_break for the weights; ln |amplitude| and its sign for the
-              // log-domain synchrotron items.  A constant's logarithm was taken when the launch
-              // began; a power of ten -- naima's fits walk in log10 of the amplitude and of the
-              // energies -- has ln|a 10^y| = ln|a| + y ln 10 in two FMAs, as good as the logarithm of
-              // the rounded power (both are right to the last place of a number around 70); only
-              // another transform calls the library's log behind its own result -- the chain
-              // exp10 -> log on one lane was 0.4 us of every slice with every other wave waiting)
-              // (ln |amplitude|: only the log-domain synchrotron items read it -- for a table-only
-              // model whose amplitude is not a power of ten, cfg1's, it was a library log on the one
-              // wave everybody waits for)
-              if (((SYN && S2) && col == 0) || col == 1 || col == 3 || col == 5) {
-                double lv;
-                const bool easy = pkd < 0 || ztf == NH_TF_POW10;
-                if (pkd < 0) {
-                  lv = pk_lna;
-                } else if (ztf == NH_TF_POW10) {
-                  lv = hs_ln_pow10(pk_lna, zb, zc, qv);
-                } else {
-                  lv = 0.0;
-                }
-                if (__builtin_amdgcn_ballot_w64(!easy) != 0ull) {
-                  asm volatile("" ::: "memory");  // (keep the call behind the branch)
-                  const double lv2 = hsr_log(fabs(val));
-                  lv = easy ? lv : lv2;
-                }
-                if (col == 0) {
-                  qs[HS_O_LNA] = lv;
-                  qs[HS_O_LNA + 1] = val < 0.0 ? -1.0 : 1.0;
-                } else {
-                  lg[col >> 1] = val > 0.0 ? lv : 0.0;
-                }
-              }
-            }
-            pval = val;
-            pcol = col;
-          }
-        }
+        return hsr_a_out{pval, pcol, slice_bad, 1};
+      };
+      // ---- two walkers in flight (round 6) ---------------------------------------------------
+      // A workgroup with several walkers of a slice took them strictly in turn: records, proposal,
+      // packs (wave 0 alone, the other fifteen at barrier 1) -> weights -> items -> sums -> likelihood,
+      // accept, record (one wave).  The next walker's phase A depends on nothing this walker
+      // computes -- its records belong to the slice before (the FIRST walker of the next slice may
+      // need this very walker's: `ahead` looks once and never waits) -- so wave 0 makes it at the
+      // head of this walker's items phase, into the other small block; the next turn then opens
+      // without phase A and WITHOUT barrier 1: the waves go straight from this walker's sums into
+      // the next one's weights while the likelihood wave is still in this walker's tail.  What that
+      // tail reads and the next walker's phases ahead of barrier 2 write is disjoint but for `spec`
+      // (a tile wave zeroes the dead energies' entries): the tile waves wait for HX_SPECRD of the
+      // previous turn's block, set by the likelihood wave once it holds its columns.
+      bool pre_a = false;
+      if constexpr (DEEP) pre_a = hx_cur[HX_PRE] != 0;  // (workgroup-uniform: written ahead of barrier 3 of the turn before)
+      // (tried: barrier 1 kept for a slice's FIRST walker, so that the record of the slice's last
+      // one -- what other workgroups' next turns wait for -- is made on a SIMD it has to itself:
+      // cfg3 / 2048 15.28 -> 15.07 M, cfg2 / 1024 13.72 -> 13.18 M)
+      const bool skip1 = pre_a;
+      if (wv == 0 && !pre_a) {
+        int* hx = hx_cur;
+        (void)hx;
+#define HSR_A_AHEAD false
+#define HSR_A_NOT_YET do {} while (0)
+#include "nh_persist_phase_a.inc"
+#undef HSR_A_AHEAD
+#undef HSR_A_NOT_YET
       }
       HSR_WSTAMP(0);
-      __syncthreads();  // ---------------------------------------------------------------- #1
+      if (!(DEEP && skip1)) __syncthreads();  // -------------------------------------------- #1
       HSR_STAMP(2);
       // (a record that never came -- hi[HI_TICK]: the whole workgroup leaves.  The table-only
       // instances with their rows in registers look at it behind barrier 2, with the words every wave
@@ -1085,7 +1007,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       if (RT == 0 && hi[HI_TICK] != 0) return;
       if (wv == 0 && pcol >= 0 && !slice_bad) {
         // the packs' rows in HBM, for whoever reads them outside this launch: behind the barrier
-        // everybody else was waiting at
+        // everybody else was waiting at (made ahead: pcol stayed -1 here, stored where it was made)
         const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
         const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
         double* out = reinterpret_cast<double* const*>(o + 5)[0];
@@ -1181,7 +1103,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             // compiler computes at the head of every slice and spills)
             const double r = fma(lv_lnq, R.s2_invd, R.s2_r746);
             if (r == r) {
-              int c = r > 0.0 ? (r < (double)nG ? (int)r : nG) : 0;
+              // (the first live node is ceil(r) -- ADVICE r5: the floor made the one-shot check below
+              // fail for almost every energy and the fix-up loops run every slice)
+              int c = r > 0.0 ? (r < (double)nG ? (int)__builtin_ceil(r) : nG) : 0;
               // (both neighbours of the estimate asked for at once: it is right, or one off, and the
               // two reads one after the other were two LDS round trips of this wave's chain)
               const double xa = lv_q * ig2[max(c - 1, 0)], xb = lv_q * ig2[min(c, nG - 1)];
@@ -1257,6 +1181,13 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
               reinterpret_cast<int*>(sm + R.o_s2z)[pos] = (int)Zf;
             }
           } else if (lv_k < nEs) {
+            if (DEEP && skip1) {
+              // (barrier 1 was not taken: the walker before may still be in its likelihood -- its
+              // columns of `spec` must have been read)
+              const int* hxp = reinterpret_cast<const int*>((par ? sm : sm + R.o_small1) + HS_O_HX);
+              while (__atomic_load_n(&hxp[HX_SPECRD], __ATOMIC_RELAXED) == 0) __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             spec[H.syn_spec_off + lv_k] = 0.0;
           }
         }
@@ -1391,6 +1322,31 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       HSR_STAMP(3);
       HSR_FSTAMP(6);
       if (RT > 0 && hi[HI_TICK] != 0) return;  // (a record never came: see behind barrier 1)
+      // ---- the next walker's phase A, ahead of this wave's items -- here, where little is live (two walkers in flight) ---------
+      if constexpr (DEEP) if (wv == 0) {
+        int made = 0;
+        const int jn = j + (int)gridDim.x;
+        const int s_n = jn < H.nloc ? s : s + 1, j_n = jn < H.nloc ? jn : (int)blockIdx.x;
+        if (s_n < R.nslices) {
+          const hsr_a_out a = phase_a(s_n, j_n, par ^ 1);
+          const double pv = a.pval;
+          const int pc = a.pcol;
+          if (a.ok) {
+            made = 1;
+            if (pc >= 0) {  // (the packs' rows in HBM: see behind barrier 1)
+              const double* o = sm + R.o_pk + lane * HS_RUN_PKW;
+              const long long ld = reinterpret_cast<const long long*>(o + 4)[0];
+              double* out = reinterpret_cast<double* const*>(o + 5)[0];
+              out[(long long)j_n * ld + pc] = pv;
+            }
+          }
+        }
+        if (lane == 0) reinterpret_cast<int*>((par ? sm : sm + R.o_small1) + HS_O_HX)[HX_PRE] = made;
+        if (R.dbg && lane == 0 && blockIdx.x == 0) {  // (NH_HS_DEBUG: looks ahead | made ahead)
+          R.dbg[256 * 64 * 8 + 3 * 16 + 0] += 1;
+          R.dbg[256 * 64 * 8 + 3 * 16 + 1] += made;
+        }
+      }
       const int nz = hi[HI_DEAD] ? 0 : hi[HI_NZ];  // (forbidden by the prior: nothing is integrated)
       int nA = 0, Cd = 1, nS = 0;
       if (has_syn) {
@@ -1816,6 +1772,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
           nviol += (isul && mc > f) ? 1 : 0;
           acc += isul ? 0.0 : term;
         }
+        if constexpr (DEEP) {
+          // (two walkers in flight: this walker's columns of `spec` are in registers -- the next
+          // walker's tile waves may zero theirs)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __atomic_store_n(&hx_cur[HX_SPECRD], 1, __ATOMIC_RELAXED);
+        }
         int cnt = nviol | (nul << 16);
         hs_wave_sum_dpp(acc, cnt);  // (the totals: in lane 63)
         // (... read out as scalars: every lane carries on with the same numbers, no second trip
@@ -2084,6 +2046,7 @@ struct nh_halfstep_run {
   size_t lds_bytes;
   int grid, threads;
   int rt;  // the instance whose table items stay in registers (hs_rt_item)
+  int deep;  // the instance with two walkers in flight (DEEP)
   int* report;        // page-locked host memory, two slots of eight ints (hs_run.report)
   int* lcnt;          // device: two pairs of launch-local counters (hs_run.lcnt)
   int nlaunch, fail_at;  // launches so far; NH_RUN_FAIL_AT = the launch whose first wait times out (tests)
@@ -2105,7 +2068,11 @@ struct nh_halfstep_run {
 };
 
 #define HS_RUN_RT HS_RT_NODES
-static const void* hs_run_kernel(bool syn, bool shared, bool s2, bool rt = false) {
+static const void* hs_run_kernel(bool syn, bool shared, bool s2, bool rt = false, bool deep = false) {
+  if (deep && !shared && !rt && syn) {
+    return s2 ? (const void*)k_half_step_run<true, false, true, 0, true>
+              : (const void*)k_half_step_run<true, false, false, 0, true>;
+  }
   if (!syn && rt)
     return shared ? (const void*)k_half_step_run<false, true, false, HS_RUN_RT>
                   : (const void*)k_half_step_run<false, false, false, HS_RUN_RT>;
@@ -2331,6 +2298,7 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   if (R.syn2 && P->split >= 2 && R.syn_nodes < 16) R.syn_nodes = 16;
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
   R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
+  R.pipeline = nh_env_int("NH_RUN_PIPELINE", 1);
   if (R.dbg_skip != 0)
     fprintf(stderr, "libnaima_hip: NH_RUN_DEBUG_SKIP=%d -- work items are DROPPED from the likelihood "
                     "(instruction-count experiments): every result of this loop is wrong\n", R.dbg_skip);
@@ -2374,6 +2342,23 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   Q->threads = P->threads;
   Q->rt = rt ? 1 : 0;
   Q->grid = (int)(H.nloc < cap / P->split ? H.nloc : cap / P->split);
+  // two walkers in flight (the DEEP instance): one GPU's loop whose workgroups own their CU, have
+  // the walker to themselves and take more than one of a slice -- a model with a synchrotron
+  // component (the 1024-thread instances; a table-only model's ensembles of that size run in small
+  // workgroups that share a CU, where the hardware overlaps them) and with table items
+  // (cfg2, synchrotron items only -- twenty of them for sixteen waves -- measured 1 % SLOWER with
+  // it at 1024 and 2048 walkers; NH_RUN_PIPELINE = 0 never | 1 | 2 also without tables)
+  Q->deep = 0;
+  if (!shared && !rt && H.syn_grid >= 0 && P->split == 1 && P->threads >= 1024 && H.nloc > Q->grid &&
+      R.pipeline != 0 && (H.C.nT > 0 || R.pipeline == 2)) {
+    const void* fd = hs_run_kernel(H.syn_grid >= 0, false, R.syn2 != 0, false, true);
+    int per_cu_d = 0;
+    hipError_t ed = lds > 64 * 1024 ? hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipSuccess;
+    if (ed == hipSuccess) ed = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, fd, P->threads, lds);
+    if (ed == hipSuccess && per_cu_d >= per_cu) Q->deep = 1;  // (as resident as the instance the grid was sized for)
+    else (void)hipGetLastError();
+  }
   Q->seq = 1;
   Q->ring = nullptr; Q->status = nullptr; Q->accw = nullptr; Q->dbg = nullptr;
   Q->xspec = nullptr; Q->tick = nullptr; Q->split = P->split;
@@ -2701,7 +2686,7 @@ extern "C" int nh_half_step_run(nh_ctx* c, nh_halfstep_plan* P, nh_halfstep_run*
     const dim3 grid((unsigned)Q->grid, (unsigned)Q->split);
     const dim3 thr(Q->threads);
     void* args[2] = {(void*)&H, (void*)&R};
-    NH_CHECK_HIP(hipLaunchKernel(hs_run_kernel(H.syn_grid >= 0, Q->base != nullptr, R.syn2 != 0, Q->rt != 0), grid, thr,
+    NH_CHECK_HIP(hipLaunchKernel(hs_run_kernel(H.syn_grid >= 0, Q->base != nullptr, R.syn2 != 0, Q->rt != 0, Q->deep != 0), grid, thr,
                                  args, Q->lds_bytes, c->stream));
   }
   {
@@ -2796,6 +2781,12 @@ extern "C" int nh_half_step_run_syn_info(const nh_halfstep_run* Q, int* mode, in
 // workgroups per walker of the loop's launches, and whether they split the grid's ROWS between
 // them (a table-only model: each forms its part of the weights and reduces its part of the table)
 // rather than taking every K-th work item of a walker whose weights every one of them forms
+extern "C" int nh_half_step_run_pipeline_info(const nh_halfstep_run* Q, int* deep) {
+  NH_REQUIRE(Q && deep, "bad argument");
+  *deep = Q->deep;
+  return NH_OK;
+}
+
 extern "C" int nh_half_step_run_split_info(const nh_halfstep_run* Q, int* split, int* rows) {
   NH_REQUIRE(Q, "bad argument");
   if (split) *split = Q->split;

@@ -999,9 +999,11 @@ class DeviceLoop:
         _lib._chk(_lib._lib.nh_half_step_run_table_info(h, C.byref(inreg), C.byref(nmax)))
         spl, rows = _lib._i(), _lib._i()
         _lib._chk(_lib._lib.nh_half_step_run_split_info(h, C.byref(spl), C.byref(rows)))
+        deep = _lib._i()
+        _lib._chk(_lib._lib.nh_half_step_run_pipeline_info(h, C.byref(deep)))
         return dict(syn_log_domain=bool(mode.value), syn_nodes_per_piece=m.value, syn_pieces=pcs.value,
                     tables_in_registers=bool(inreg.value), workgroups_per_walker=spl.value,
-                    rows_split=bool(rows.value))
+                    rows_split=bool(rows.value), two_walkers_in_flight=bool(deep.value))
 
     def _create_shared_run(self, hs):
         """the resident loop over an ensemble shared with the other ranks' GPUs: rings in

@@ -735,6 +735,10 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
             # to the first)
             info = d._dev.resident_info
             assert info["rows_split"] and info["workgroups_per_walker"] == 2 and info["tables_in_registers"], info
+        if mode == "1" and name == "cfg3":
+            # (more walkers of a half-step than resident workgroups: two walkers of a workgroup in
+            # flight -- the next one's records, proposal and packs made during this one's work items)
+            assert d._dev.resident_info["two_walkers_in_flight"] == (nw // 2 > d._dev.resident_info["grid"])
         if mode == "1" and name in ("cfg3", "cfg1"):
             # (the resident loop walks its own copies of the inverse-Compton tables, columns sorted
             # by their first non-zero row, rows below a tile's first one skipped: same spectra)
@@ -759,6 +763,48 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
         assert_allclose(np.asarray(x, dtype=float), np.asarray(y, dtype=float), rtol=1e-10,
                         atol=1e-300, equal_nan=True)
     print("%s: resident == per-launch; bit-identical chain: %s" % (name, np.array_equal(a[0], b[0])))
+
+
+@pytest.mark.parametrize("syn2", ["1", "0"], ids=["log-domain", "direct-form"])
+def test_two_walkers_in_flight_changes_no_bit(na, monkeypatch, syn2):
+    """cfg3 with 1280 walkers on 256 CUs: a workgroup takes two or three walkers of every half-step.
+    With two of them in flight (the DEEP instance: the next walker's phase A made ahead during this
+    one's work items, barrier 1 skipped, the tile waves gated on the previous likelihood having read
+    its columns) the arithmetic and its order are the ones of the strictly serial turns
+    (NH_RUN_PIPELINE=0): chain, log-probabilities, blobs and acceptance bit for bit -- for the
+    synchrotron items in the log domain and in the direct form, through a block boundary and a
+    tail, with and without a history"""
+    from naima_amd.sampler import EnsembleSampler
+    name, nw = "cfg3", 1280
+    model, p0, raw, data, prior = _problem(na, name, {})
+    nd = p0.size
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True,
+              nan_policy="reject")
+    pos = p0 + 0.1 * p0 * np.random.default_rng(BENCH_SEED).normal(size=(nw, nd))
+    monkeypatch.setenv("NH_RUN_SYN2", syn2)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NH_RUN_PIPELINE", mode)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        with np.errstate(all="ignore"):
+            st = d.run_mcmc(pos, 3)
+            st = d.run_mcmc(st, 45)
+            st2 = d.run_mcmc(st, 5, store=False)
+        info = d._dev.resident_info
+        assert d._dev.resident_launches > 0 and info["two_walkers_in_flight"] == (mode == "1"), info
+        assert info["syn_log_domain"] == (syn2 == "1")
+        runs[mode] = (d.get_chain(), d.get_log_prob(), d.get_blobs(), d.acceptance_fraction,
+                      np.array(st2.coords), np.array(st2.log_prob),
+                      [np.array(b) for b in (st2.blobs or [])])
+    a, b = runs["0"], runs["1"]
+    assert a[0].shape == (48, nw, nd)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(a[5], b[5], equal_nan=True)
+    for x, y in zip(a[6], b[6]):
+        assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
 
 
 @pytest.mark.parametrize("name,nw", [("cfg3", 512), ("cfg2", 256), ("cfg3", 96)],
