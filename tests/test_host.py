@@ -405,9 +405,9 @@ def test_half_step_kernel_keeps_its_descriptor_out_of_scratch():
             assert vspill <= (1 if shared else 0), "%s spills %d vector registers" % (k, vspill)
     asm = subprocess.run(base + ["--cuda-device-only", "-S", os.path.join(src, "nh_persist.hip"), "-o", "-"],
                          capture_output=True, text=True).stdout
-    bodies = re.findall(r"^(_Z15k_half_step_runILb[01]ELb[01]ELb[01]ELi\d+EEv6hs_hot6hs_run):[^\n]*\n(.*?)^\.Lfunc_end", asm,
+    bodies = re.findall(r"^(_Z15k_half_step_runILb[01]ELb[01]ELb[01]ELi\d+ELb[01]EEv6hs_hot6hs_run):[^\n]*\n(.*?)^\.Lfunc_end", asm,
                         flags=re.S | re.M)
-    assert len(bodies) == 8
+    assert len(bodies) == 10
     for name, body in bodies:
         shared = "ILb1ELb1E" in name or "ILb0ELb1E" in name
         assert body.count("scratch_") <= (2 if shared else 0), "%s touches scratch memory" % name
