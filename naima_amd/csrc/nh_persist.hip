@@ -151,7 +151,7 @@ struct hs_run {
   int o_rs;   // LDS: this workgroup's nodes per grid and its units (rowsplit)
   int nxmax;  // doubles a workgroup hands over at most (spectrum + single-row reductions)
   int sum_cols;  // columns of all the tables together (the sum phase's loop bound)
-  int dbg_skip;  // NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
+  int dbg_skip;  // -DNH_LAB builds only: NH_RUN_DEBUG_SKIP (experiments: instruction counts by kind): 1 no synchrotron items, 2 no table items
   // ---- an ensemble shared by several GPUs (nrank > 1; see "The ensemble across GPUs" below):
   // `ring` is this launch's ring in THIS rank's memory, peer[p] the same ring in rank p's
   // (peer[rank] == ring); a mover stores its walker's record into every one of them
@@ -452,6 +452,9 @@ __device__ __forceinline__ int hsr_weights_kind(int kind, unsigned a_ut, unsigne
 }
 
 // workgroup 0 only: when does each WAVE reach barrier 1 / 2 / 3 and finish its last item
+#ifndef HSR_FINE_PART
+#define HSR_FINE_PART 0  // (which of a walker's workgroups writes the fine stamps)
+#endif
 #ifdef HSR_FINE
 #define HSR_WSTAMP(k) do {} while (0)
 #else
@@ -466,7 +469,7 @@ __device__ __forceinline__ int hsr_weights_kind(int kind, unsigned a_ut, unsigne
 #ifdef HSR_FINE
 #define HSR_FSTAMP(k)                                                                   \
   do {                                                                                   \
-    if (R.dbg && lane == 0 && blockIdx.x == 0 && it >= 32 && it < 40)                    \
+    if (R.dbg && lane == 0 && blockIdx.x == 0 && blockIdx.y == HSR_FINE_PART && it >= 32 && it < 40) \
       R.dbg[256 * 64 * 8 + (((it & 7) * 8 + (k)) * 16) + wv] = (long long)wall_clock64(); \
   } while (0)
 #else
@@ -477,7 +480,7 @@ __device__ __forceinline__ int hsr_weights_kind(int kind, unsigned a_ut, unsigne
 #define HSR_FSTAMP(k) do {} while (0)
 #define HSR_GSTAMP(k)                                                                   \
   do {                                                                                   \
-    if (R.dbg && lane == 0 && blockIdx.x == 0 && it >= 32 && it < 40)                    \
+    if (R.dbg && lane == 0 && blockIdx.x == 0 && blockIdx.y == HSR_FINE_PART && it >= 32 && it < 40) \
       R.dbg[256 * 64 * 8 + (((it & 7) * 8 + (k)) * 16) + wv] = (long long)wall_clock64(); \
   } while (0)
 #else
@@ -916,7 +919,6 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
 
   // (two walkers in flight: only where a workgroup has the walker to itself and more than one of
   // a slice -- the 1024-thread instances on ensembles of more walkers than twice the CUs)
-  constexpr bool deep = DEEP;  // (hs_run_create: RT == 0, K == 1, more walkers of a slice than workgroups)
   // =========================== the slices ====================================================
   int it = 0;
   for (int s = 0; s < R.nslices; ++s) {
@@ -1488,10 +1490,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             is_tab = nT - F0 > nS;
             ix = is_tab ? item - nS : item - nT;
           }
+#ifdef NH_LAB  // (build.sh -DNH_LAB: instruction counts by kind of work item; every result is wrong)
           if (R.dbg_skip && (is_tab ? (R.dbg_skip & 2) : (R.dbg_skip & 1))) {
             if (is_tab) part_t[((K > 1 && R.tcompact) ? pulled : ix) * 64 + lane] = 0.0;
             continue;
           }
+#endif
           if (is_tab && RT == 0) {  // (the descriptor table is part of every such instance's layout)
             typedef int hsi_i4 __attribute__((ext_vector_type(4)));
             const int* ttab = reinterpret_cast<const int*>(sm + R.o_it);
@@ -1671,6 +1675,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         // not been written yet, or belongs to another launch, is recognised and never consumed --
         // and go on to their next slice; workgroup 0 adds the parts in the order of their index
         // (the result does not depend on who arrived when) and carries on to the likelihood.
+        // (Round 6 tried the meeting by the likelihood waves alone for the rows-split instance -- a
+        // lane per column sums its workgroup's chunks, hands over / takes in, no sum phase of all
+        // threads, no barrier 4, no barrier behind the meeting: cfg5 / 256 9.05 -> 8.87 us per
+        // half-step (+ 1.9 %), and 2 - 5 vector registers of the 256-register instance spilled;
+        // with the second workgroup's ITEM waves handing their chunks over themselves 9.14 -> 9.95.
+        // Not kept: profiles/NOTES_r06.md.)
         // (Round 4's meeting -- stores drained, a ticket drawn by an atomic, the last to arrive
         // reads everything back -- was 2.3 us of cfg2's 17; rows split between the workgroups
         // hand over the single-row reductions' parts as well.)
@@ -1723,6 +1733,7 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         if (hi[HI_TICK] != 0) return;  // (a part never came: the launch gives up, as for a record)
       }
       HSR_STAMP(6);
+      HSR_GSTAMP(4);
       // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
       // wave 0 is already polling for the next slice and the others wait at its first barrier ----
       if (lik_wave) {
@@ -2297,7 +2308,11 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   // walker: 20.8 at 10, 20.8 at 16, 20.0 at 24; cfg2 / 256: 17.7 at 10 and at 16, 18.3 at 24)
   if (R.syn2 && P->split >= 2 && R.syn_nodes < 16) R.syn_nodes = 16;
   R.syn_nodes = nh_env_int("NH_RUN_SYN_NODES", R.syn_nodes);
+#ifdef NH_LAB
   R.dbg_skip = nh_env_int("NH_RUN_DEBUG_SKIP", 0);
+#else
+  R.dbg_skip = 0;  // (the product build has no switch that drops work: -DNH_LAB, scripts/lab/r4_count.sh)
+#endif
   R.pipeline = nh_env_int("NH_RUN_PIPELINE", 1);
   if (R.dbg_skip != 0)
     fprintf(stderr, "libnaima_hip: NH_RUN_DEBUG_SKIP=%d -- work items are DROPPED from the likelihood "

@@ -1,4 +1,5 @@
 # instruction counts of the resident kernel by kind of work item (rocprofv3 --pmc, cfg3)
+# (needs a library built with: NH_OUT=naima_amd/variants/lab.so naima_amd/csrc/build.sh -DNH_LAB; NAIMA_AMD_LIB points at it)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r4count; rm -rf $O; mkdir -p $O
 run() { name=$1; shift
