@@ -111,6 +111,7 @@ def measured_utilisation(name, resident, waves_per_simd=4):
     except Exception:
         return None
     best = None
+    recorded = d.pop("_source_commit", None)  # (written by scripts/collect_profiles.py at collection)
     for k, v in d.items():
         if want in k and "SQ_ACTIVE_INST_VALU" in v and "SQ_WAVE_CYCLES" in v:
             if best is None or v.get("SQ_WAVE_CYCLES", 0) > best[1].get("SQ_WAVE_CYCLES", 0):
@@ -120,7 +121,10 @@ def measured_utilisation(name, resident, waves_per_simd=4):
     k, v = best
     waves = max(v.get("SQ_WAVES", 1.0), 1.0)
     out = {"kernel": k.split("(")[0].strip(), "source": os.path.basename(files[-1]),
-           "from_committed_profile": True, "source_commit": _last_commit_of(files[-1]),
+           "from_committed_profile": True,
+           # (the tree the counters were measured on: recorded in the file at collection; the commit
+           # that last touched the file where there is a .git and no record)
+           "source_commit": recorded or _last_commit_of(files[-1]),
            "measured_in_this_run": False,
            "valu_busy": float(waves_per_simd) * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"],
            "waves_per_simd": waves_per_simd,

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S, D = os.path.join(R, "gpurun_out", TAG + "prof"), os.path.join(R, "profiles")
 COPY = {"bench_n1_default.json": "bench_n1_default.json",
@@ -35,6 +35,21 @@ for w in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
         COPY["bench_%s.json" % w] = "bench_%s.json" % w
 for w in ("cfg3", "cfg5", "cfg2", "cfg4"):
     COPY["%s_counters_per_launch.json" % w] = "%s_counters_per_launch.json" % w
+COPY["cfg3w2048_counters_per_launch.json"] = "cfg3_w2048_counters_per_launch.json"
+def head_commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+HEAD = head_commit()  # (the tree the GPU box ran: the profile run is made on a committed tree)
+for f in ("bench_cfg3_w4096.json", "bench_cfg3_w1024_serial_turns.json", "bench_cfg3_w2048_serial_turns.json",
+          "bench_cfg3_w4096_serial_turns.json", "bench_ladder_rings_refused_rccl_unavailable_host_staged.json",
+          "stamps_cfg3_w2048.txt", "per_launch_kernel_phase_stamps_cfg3.txt"):
+    COPY[f] = f
 for a, b in COPY.items():
     src = os.path.join(S, a)
     if os.path.exists(src) and os.path.getsize(src) > 0:
@@ -59,3 +74,10 @@ for w in ("cfg3", "cfg5"):
                 out["launches"][k] = v.get("launches_" + src)
     json.dump(out, open(os.path.join(D, "%s_%s_hbm_counters.json" % (TAG, w)), "w"), indent=1)
     print(w, {k: v for k, v in out["fetch"].items() if "half_step" in k}, {k: v for k, v in out["write"].items() if "half_step" in k})
+
+# which tree the counter files were measured on (bench.py's valu_utilisation.source_commit: the GPU box
+# runs a snapshot without .git, so the commit is recorded here, at collection)
+for f in glob.glob(os.path.join(D, "%s_*_counters_per_launch.json" % TAG)):
+    d = json.load(open(f))
+    d["_source_commit"] = HEAD
+    json.dump(d, open(f, "w"), indent=1)

@@ -4,7 +4,7 @@
 #   bash scripts/gpu_profile.sh [round tag, default r03]   ->   gpurun_out/<tag>prof/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}prof
 rm -rf $O; mkdir -p $O
 DRV="bench.py --steps 20 --warmup 5"
@@ -31,10 +31,12 @@ done
 # (vector-pipe utilisation of the other two workloads' dominant kernels: one SQ pass each)
 CMD="$DRV --workload cfg2 --no-cpu --no-blobs-run --min-time 0.1"; prof cfg2_sqa --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
 CMD="bench.py --workload cfg4 --steps 10 --warmup 2 --no-cpu --no-blobs-run --min-time 0.1"; prof cfg4_sqa --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
+# (round 6: the instance with two walkers of a workgroup in flight -- cfg3 at 2048 walkers)
+CMD="$DRV --workload cfg3 --walkers 2048 --no-cpu --no-blobs-run --min-time 0.1"; prof cfg3w2048_sqa --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
 python - <<PY
 import csv, collections, glob, json, os
 O = "$O"
-for w in ("cfg3", "cfg5", "cfg2", "cfg4"):
+for w in ("cfg3", "cfg5", "cfg2", "cfg4", "cfg3w2048"):
     res = {}
     for f in sorted(glob.glob(O + '/%s_*_counter_collection.csv' % w)):
         rows = list(csv.DictReader(open(f)))
@@ -75,9 +77,15 @@ PY
 NH_HS_DEBUG=1 timeout 300 python scripts/run_stamps.py cfg3 512 > $O/stamps_cfg3.txt 2>&1
 NH_HS_DEBUG=1 timeout 300 python scripts/run_stamps.py cfg5 256 > $O/stamps_cfg5.txt 2>&1
 tail -3 $O/err_bench.log
-# 5. ensembles of more walkers than CUs (resident workgroups take several walkers of a half-step in turn)
-for n in 1024 2048; do
+NH_HS_DEBUG=1 timeout 300 python scripts/run_stamps.py cfg3 2048 > $O/stamps_cfg3_w2048.txt 2>&1
+NH_HS_DEBUG=1 NAIMA_AMD_RESIDENT=0 timeout 300 python scripts/hs_stamps.py cfg3 512 > $O/per_launch_kernel_phase_stamps_cfg3.txt 2>&1
+# 5. ensembles of more walkers than CUs (resident workgroups take several walkers of a half-step: two of
+# them in flight -- round 6; NH_RUN_PIPELINE=0: strictly in turn, as in round 5)
+for n in 1024 2048 4096; do
   timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w$n.json 2>> $O/err_bench.log
+  NH_RUN_PIPELINE=0 timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w${n}_serial_turns.json 2>> $O/err_bench.log
+done
+for n in 1024 2048; do
   NH_RUN_MAX_PER_WG=1 timeout 600 python bench.py --workload cfg3 --walkers $n --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_w${n}_per_launch_kernel.json 2>> $O/err_bench.log
 done
 # 6. bench.py starting its own ranks (round 5): two ranks on this ONE GPU (NAIMA_AMD_DEVICE pins them; each
@@ -89,6 +97,9 @@ timeout 600 python bench.py --gpus 2 --scaling strong --walkers-total 512 --step
 timeout 600 python bench.py --gpus 2 --scaling strong --walkers-total 512 --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_shared_two_ranks_one_gpu_steps100.json 2>> $O/err_bench.log
 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_weak_two_ranks_one_gpu.json 2>> $O/err_bench.log
 timeout 900 python bench.py --gpus 4 --steps 20 --warmup 5 --no-cpu --no-blobs-run --walkers 128 > $O/bench_cfg3_weak_four_ranks_one_gpu_baseline_split.json 2>> $O/err_bench.log
+# (round 6: every rung of the exchange ladder refused in turn -- rings by fault injection, RCCL by the probe
+# processes: two ranks of one device -- the host-staged all-gather taken; config.exchange.ladder says so)
+NAIMA_AMD_COMM=rccl NAIMA_AMD_LADDER_REFUSE=ring NAIMA_AMD_RCCL_PROBE_TIMEOUT=60 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu --no-blobs-run > $O/bench_ladder_rings_refused_rccl_unavailable_host_staged.json 2>> $O/err_bench.log
 )
 # 6b. BASELINE's cfg4 at its 1024 walkers on one GPU
 timeout 900 python bench.py --scaling strong --workload cfg4 --walkers-total 1024 --steps 10 --warmup 2 --no-cpu --no-blobs-run > $O/bench_cfg4_strong1024_n1.json 2>> $O/err_bench.log
@@ -97,6 +108,6 @@ timeout 300 python scripts/region_host_latency.py cfg3 20 > $O/region_host_laten
 timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu --no-blobs-run > $O/bench_cfg3_one_process_steps100.json 2>> $O/err_bench.log
 # 7. one-GPU projection of the multi-GPU configurations
 timeout 2400 python scripts/shard_table.py > $O/shard_table.json 2> $O/shard_table.err
-for f in bench_cfg3_w1024 bench_cfg3_w2048 bench_cfg3_shared_two_ranks_one_gpu bench_cfg3_shared_two_ranks_one_gpu_steps100 bench_cfg3_weak_two_ranks_one_gpu bench_cfg3_weak_four_ranks_one_gpu_baseline_split bench_cfg4_strong1024_n1 bench_cfg3_one_process_steps100; do
+for f in bench_cfg3_w1024 bench_cfg3_w2048 bench_cfg3_w4096 bench_cfg3_w2048_serial_turns bench_ladder_rings_refused_rccl_unavailable_host_staged bench_cfg3_shared_two_ranks_one_gpu bench_cfg3_shared_two_ranks_one_gpu_steps100 bench_cfg3_weak_two_ranks_one_gpu bench_cfg3_weak_four_ranks_one_gpu_baseline_split bench_cfg4_strong1024_n1 bench_cfg3_one_process_steps100; do
   python -c "import json; d=json.load(open('$O/$f.json')); print('$f', round(d['value']), d['ms_per_step'])"
 done
