@@ -501,11 +501,7 @@ def measure(args, ctx, comm, name, scaling, walkers, walkers_total, full):
         # launch still have given up waiting for a record, every rank drops to one launch and
         # one all-gather per half-step -- agreed here, before anything is timed
         state = sampler.run_mcmc(state, 40, store=False)
-        bad = 0.0
-        try:
-            sampler._dev.check_resident()
-        except _lib.NaimaHipError:
-            bad = 1.0
+        bad = 1.0 if sampler._dev.resident_status() != 0 else 0.0  # (reduced over the ranks below)
         shared_note = ("taken" if sampler._dev.shared else "not available: %s"
                        % getattr(sampler._dev, "resident_reason", "the model's launches are not "
                                  "ones the resident kernel absorbs"))

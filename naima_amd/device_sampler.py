@@ -38,6 +38,7 @@ class DeviceState:
     def coords(self):
         if self._c is None:
             self._loop._flush_pending()
+            self._loop._settle_before_read()  # (one GPU: the friendlier message, ahead of the status)
             self._loop.check_resident()
             self._loop.check_nan()
             self._c = self._loop.coords.get().reshape(self._loop.N, self._loop.ndim)
@@ -47,6 +48,7 @@ class DeviceState:
     def log_prob(self):
         if self._l is None:
             self._loop._flush_pending()
+            self._loop._settle_before_read()
             self._loop.check_resident()
             self._loop.check_nan()
             self._l = self._loop.logp.get()
@@ -630,11 +632,15 @@ class DeviceLoop:
             self._init_state(st.coords, st.log_prob)
         rng, N, ns = s._rng, self.N, self.ns
         iterations = int(iterations)
+        jentry = None
         if self.sharded and s.comm.size > 1 and not self._replaying and self._run is not False:
             fresh = not (isinstance(initial_state, DeviceState) and initial_state._loop is self)
             if self._sh_snap is None or fresh:  # (normally kept at the verified point itself, below)
                 self._shared_snapshot()
-            self._sh_journal.append((iterations, bool(store), yield_every))
+            # (the steps the call has MADE, kept up to date as it goes: a caller that breaks out of
+            # the generator early must not have the full count replayed -- ADVICE r5)
+            jentry = [0, bool(store), yield_every]
+            self._sh_journal.append(jentry)
         block = None
         if store and iterations > 0:
             block = dict(n=0, coords=ctx.empty((iterations, N * self.ndim)),
@@ -747,6 +753,8 @@ class DeviceLoop:
                 gave_up = self._rl_settle(keep=1)
                 if gave_up is not None:
                     it, moves = rollback(gave_up)
+                    if jentry is not None:
+                        jentry[0] = it
                     fast = False
                     break
             rec = dict(launch=self._rl_count + 1, it=it, iteration=s.iteration, steps_total=s.steps_total,
@@ -773,6 +781,8 @@ class DeviceLoop:
                     mv["have"] + self.KSTEPS <= self.MOVES_CAP:
                 self._moves_append(moves, self.KSTEPS, ahead=True)
             it += want
+            if jentry is not None:
+                jentry[0] = it
             s.iteration += want
             s.steps_total += want
             if block is not None:
@@ -782,6 +792,8 @@ class DeviceLoop:
                 gave_up = self._rl_settle(keep=0)
                 if gave_up is not None:
                     it, moves = rollback(gave_up)
+                    if jentry is not None:
+                        jentry[0] = it
                     fast = False
                     break
             yield DeviceState(self, rng)
@@ -878,6 +890,8 @@ class DeviceLoop:
                     mark_pending = False
                 k += g
                 it += g
+                if jentry is not None:
+                    jentry[0] = it
                 s.iteration += g
                 s.steps_total += g
                 if block is not None:
@@ -1253,7 +1267,9 @@ class DeviceLoop:
                     nacc=ctx.empty((self.N,), dtype=np.int32), blobs=[],
                     iteration=s.iteration, steps_total=s.steps_total, nlc=s.n_lnprob_calls,
                     nwe=s.n_walker_evals, rl=self.resident_launches,
-                    nan_pending=self._nan_pending, forbidden_pending=self._forbidden_pending)
+                    nan_pending=self._nan_pending, forbidden_pending=self._forbidden_pending,
+                    # (chain rows of earlier calls that nobody has asked for yet: they stay)
+                    hist_len=len(self.hist))
         ctx.call("nh_copy", snap["coords"], self.coords, 8 * self.N * self.ndim)
         ctx.call("nh_copy", snap["logp"], self.logp, 8 * self.N)
         ctx.call("nh_copy", snap["nacc"], self.nacc, 4 * self.N)
@@ -1314,7 +1330,7 @@ class DeviceLoop:
         ctx.call("nh_copy", self.nacc, snap["nacc"], 4 * self.N)
         for b, (cur, m, _, _) in zip(snap["blobs"], self.cur_blobs or []):
             ctx.call("nh_copy", cur, b, 8 * self.N * m)
-        self.hist = []
+        self.hist = self.hist[:snap.get("hist_len", 0)]  # (what predates the kept ensemble stays)
         s.iteration, s.steps_total = snap["iteration"], snap["steps_total"]
         s.n_lnprob_calls, s.n_walker_evals = snap["nlc"], snap["nwe"]
         self.resident_launches = snap["rl"]
@@ -1335,8 +1351,10 @@ class DeviceLoop:
             left -= got
         self._replaying = True
         try:
-            for iterations, store, yield_every in journal:
-                for _ in self.sample(DeviceState(self, s._rng), iterations, store, yield_every=1 << 30):
+            for made, store, yield_every in journal:
+                if made <= 0:
+                    continue
+                for _ in self.sample(DeviceState(self, s._rng), made, store, yield_every=1 << 30):
                     pass
             self._flush_pending()
             ctx.sync()
@@ -1407,6 +1425,15 @@ class DeviceLoop:
                                  "loop; emcee stops at the first one -- pass nan_policy='reject' "
                                  "to treat them as rejected proposals)" % n)
 
+    def resident_status(self):
+        """this rank's status word of the resident loop (0: every launch found its records);
+        synchronises the stream, raises nothing -- for callers that reduce it over the ranks
+        themselves (bench.py's rehearsal)"""
+        st = _lib._i(0)
+        if self._run:
+            _lib._chk(_lib._lib.nh_half_step_run_status(self.ctx.h, self._run, C.byref(st)))
+        return st.value
+
     def check_resident(self, collective=False):
         """raise if a launch of the resident loop gave up waiting for a walker's record (its
         workgroups were not all resident: another process on the GPU, a profiler that
@@ -1415,6 +1442,11 @@ class DeviceLoop:
         per-launch kernel instead: _run_resident, sample -- what is left to find here is a
         shared ensemble's, or a loop run with NAIMA_AMD_VERIFY_LAUNCHES=0.)  ``collective``: every rank is here -- the worst status
         of all ranks decides, and all of them raise."""
+        if self.shared and not collective and self.s.comm is not None and self.s.comm.size > 1:
+            # a shared loop's status is acted on where EVERY rank is (flush, reset): an exception on
+            # the one rank that reads its state here would leave the others waiting in their next
+            # collective -- the launch that gave up is found there and replayed by all (ADVICE r5)
+            return
         st = _lib._i(0)
         if self._run:
             _lib._chk(_lib._lib.nh_half_step_run_status(self.ctx.h, self._run, C.byref(st)))
