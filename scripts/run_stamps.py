@@ -37,6 +37,7 @@ wst = raw[256 * 64 * 8:].reshape(64, 4, 16).astype(float) / 100.0
 print(name, nw, "walkers;", dev.resident_info)
 G = min(256, dev.resident_info["grid"])
 t = buf[:G].astype(float) / 100.0  # us
+t[buf[:G] == 0] = np.nan  # (a stamp nobody wrote: phase A made AHEAD -- two walkers in flight -- leaves none)
 names = ["records in", "packs + barrier 1", "weights + barrier 2", "tid 0's items", "barrier 3",
          "spectra summed (barrier 4)", "record published"]
 it = np.arange(4, 60)  # (steady state)
@@ -44,7 +45,14 @@ d = np.diff(t[:, :, :], axis=2)[:, it, :]
 print("phase durations, us (median over %d workgroups x %d slices | 10 %% | 90 %%):" % (G, len(it)))
 for k, nm in enumerate(names):
     v = d[:, :, k].ravel()
-    print("  %-28s %6.2f  %6.2f  %6.2f" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90)))
+    n_all = v.size
+    v = v[np.isfinite(v)]
+    if v.size == 0:
+        print("  %-28s      -       -       -   (no turn wrote this stamp)" % nm)
+        continue
+    print("  %-28s %6.2f  %6.2f  %6.2f%s" % (nm, np.median(v), np.percentile(v, 10), np.percentile(v, 90),
+                                           "" if v.size == n_all else "   (%d %% of the turns: the others had phase A made ahead)"
+                                           % round(100.0 * v.size / n_all)))
 per = np.diff(t[:, :, 0], axis=1)[:, it[:-1]]
 print("slice period (start to start): median %.2f, 10 %% %.2f, 90 %% %.2f us"
       % (np.median(per), np.percentile(per, 10), np.percentile(per, 90)))
@@ -52,7 +60,9 @@ tot = t[:, 60, 0] - t[:, 4, 0]
 print("56 slices of a workgroup: median %.1f us = %.2f us per slice; launch start skew %.2f us"
       % (np.median(tot), np.median(tot) / 56, t[:, 0, 0].max() - t[:, 0, 0].min()))
 wait = d[:, :, 0]
-print("waiting for records: mean %.2f us, fraction of slices > 2 us: %.3f" % (wait.mean(), (wait > 2).mean()))
+wait = wait[np.isfinite(wait)]
+if wait.size:
+    print("waiting for records: mean %.2f us, fraction of slices > 2 us: %.3f" % (wait.mean(), (wait > 2).mean()))
 
 # workgroup 0: arrival of each wave at the barriers, relative to the slice's start (us), slices 8..40
 t0 = t[0, :, 0]
