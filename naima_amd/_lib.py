@@ -1168,17 +1168,27 @@ def device_count():
     return n.value
 
 
+def default_device():
+    """the device index a rank's default context takes: NAIMA_AMD_DEVICE, else LOCAL_RANK, else 0
+    (no context is made, no GPU needed to ask)"""
+    device = int(os.environ.get("NAIMA_AMD_DEVICE") or os.environ.get("LOCAL_RANK") or "0")
+    if not os.environ.get("NAIMA_AMD_DEVICE") and device > 0:
+        # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES /
+        # ROCR_VISIBLE_DEVICES per rank) leaves LOCAL_RANK pointing past the one device the
+        # rank sees: take what is visible (bench.py checks that the ranks' PCI bus ids differ)
+        try:
+            n = device_count()
+        except Exception:
+            n = 0
+        if 0 < n <= device:
+            device = device % n
+    return device
+
+
 def get_context(device=None):
     """process-wide default context (device from NAIMA_AMD_DEVICE / LOCAL_RANK, else 0)"""
     if device is None:
-        device = int(os.environ.get("NAIMA_AMD_DEVICE") or os.environ.get("LOCAL_RANK") or "0")
-        if not os.environ.get("NAIMA_AMD_DEVICE") and device > 0:
-            # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES /
-            # ROCR_VISIBLE_DEVICES per rank) leaves LOCAL_RANK pointing past the one device the
-            # rank sees: take what is visible (bench.py checks that the ranks' PCI bus ids differ)
-            n = device_count()
-            if 0 < n <= device:
-                device = device % n
+        device = default_device()
     ctx = _default.get(device)
     if ctx is None:
         ctx = Context(device)

@@ -786,6 +786,12 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         u0 += nu;
       }
       rs[8] = nmy;
+      if (R.dbg && blockIdx.x == 0 && part < 4) {  // (NH_HS_DEBUG: this part's units | its rows of every grid)
+        R.dbg[256 * 64 * 8 + 3 * 16 + 4 + part] = nmy;
+        for (int g = 0; g < H.ngrids && g < 2; ++g)
+          R.dbg[256 * 64 * 8 + 7 * 16 + part * 4 + 2 * g] = rs[2 * g] | ((long long)rs[2 * g + 1] << 32);
+        R.dbg[256 * 64 * 8 + 7 * 16 + part * 4 + 1] |= (long long)(R.kds[0] ? hs_tab_trailer(R.kds[0], H.nG[D.tab[0].grid], D.tab[0].nK)[0] : -1) << 48;
+      }
     }
   }
   // row 0 of the ring: the ensemble as the flat arrays hold it (written by earlier launches or

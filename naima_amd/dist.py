@@ -526,7 +526,7 @@ def from_env(prefer="rccl"):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("NAIMA_AMD_RCCL_PROBE", "1") != "0":
         # the communicator is built in a throw-away process FIRST (collective: every rank the same)
         from . import _lib
-        pr = run_rccl_probe(group, _lib.get_context().device)
+        pr = run_rccl_probe(group, _lib.default_device())
         graph = pr["graph"]
         if not pr["init"]:
             why = "the probe processes could not build an RCCL communicator of these ranks (%s)" % pr["why"]

@@ -426,3 +426,41 @@ def test_control_plane_client_does_not_take_itself_for_the_hub():
         assert echo == dist._MAGIC + g.token and echo != dist._MAGIC + g.reply
     finally:
         s.close()
+
+
+LADDER_WORKER = r'''
+import os, sys, warnings
+sys.path.insert(0, %(root)r)
+from naima_amd import dist
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    comm = dist.from_env("rccl")
+assert type(comm).__name__ == "HostComm", type(comm).__name__
+rungs = [(r["rung"], r["taken"]) for r in comm.ladder]
+assert rungs == [("RCCL all-gather", False), ("host-staged all-gather", True)], comm.ladder
+assert "probe" in comm.ladder[0]["why"], comm.ladder
+assert any("RCCL communicator unavailable" in str(x.message) for x in w)
+import numpy as np
+g = comm.allgather(np.full((1, 2), float(comm.rank)))
+assert g.shape == (2, 2) and g[1, 0] == 1.0
+open(os.path.join(%(out)r, "ok_%%d" %% comm.rank), "w").write(comm.ladder[0]["why"])
+'''
+
+
+def test_two_ranks_without_rccl_take_the_host_staged_rung_and_say_why(tmp_path):
+    """world_size 2 on a box where RCCL cannot work (here: no GPU at all): the throw-away probe
+    processes fail, EVERY rank learns it over the control plane, both take the host-staged
+    all-gather and the communicator says which rung was refused and why -- nobody enters
+    ncclCommInitRank, nobody hangs (the reference's Pool has no such failure mode: core.py:446-448)"""
+    script = tmp_path / "worker.py"
+    script.write_text(LADDER_WORKER % {"root": ROOT, "out": str(tmp_path)})
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
+                   LOCAL_RANK=str(r), WORLD_SIZE="2", NAIMA_AMD_RCCL_PROBE_TIMEOUT="120")
+        env.pop("NAIMA_AMD_COMM", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
