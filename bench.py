@@ -388,9 +388,14 @@ def launch_ranks(n):
                 if "comm" not in seen and r in ctx_seen and now - ctx_seen[r] > comm_limit:
                     stuck.append(r)
             if stuck and rc == 0:
+                # (communicator creation is a rendezvous: a rank waits in it for every other one, so
+                # the ranks named first are the ones whose time ran out first, not necessarily the
+                # one everybody is waiting for -- hence every rank's last reported stage)
+                where = {r: (progress(r) or ["started"])[-1] for r in range(n)}
                 sys.stderr.write("bench.py --gpus %d: rank(s) %s have not passed communicator creation "
                                  "within %.0f s of having a GPU context (RCCL probe / ncclCommInitRank); "
-                                 "ending all ranks\n" % (n, stuck, comm_limit))
+                                 "last stage reported by every rank: %s; ending all ranks\n"
+                                 % (n, stuck, comm_limit, where))
                 rc = 18
                 end_all(alive)
             elif now - t_start > budget and rc == 0:

@@ -1208,6 +1208,9 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
         const int* ul = reinterpret_cast<const int*>(sm + R.o_rs) + 9;
         const int u_end = R.rowsplit ? __builtin_amdgcn_readfirstlane(ul[-1]) : nunits;
         int fl = 0;  // (wave-uniform) grids with a non-zero weight | << 8: with one that is not finite
+        // (tried, round 6: s_setprio 3 for the waves that decide when barrier 2 opens -- a pair of
+        // units, the liveness search: cfg3 / 512 13.37 -> 13.37 M, cfg5 - 0.4 %, cfg2 + 1 %, cfg3 /
+        // 2048 - 0.5 %: the phase is latency, not issue slots)
         for (int u = worker ? rank : u_end; u < u_end; u += 2 * nwork)
           fl |= hsr_weights_kind<(SYN && S2)>(
               D.kind, hs_lds_addr(sm + R.o_ut), R.rowsplit ? hs_lds_addr(reinterpret_cast<const double*>(ul)) : 0u,

@@ -12,12 +12,11 @@ taken and why the ones before it were not (config.exchange.ladder).  And the lau
 a rank that never reaches communicator creation ends the run with the rank named, not with the
 driver's 1 800 s limit.  The reference's parallel entry: core.py:446-457, 533-536 (Pool(threads)).
 
-No assertion here depends on a clock except the watchdog's own bound, which is minutes wide."""
+No assertion here depends on a clock (a watchdog that does not fire runs into the subprocess timeout)."""
 import json
 import os
 import subprocess
 import sys
-import time
 
 import pytest
 
@@ -83,19 +82,24 @@ def test_rings_refused_host_staged_by_request():
 
 def test_a_rank_that_never_reaches_the_communicator_ends_the_run_by_name():
     """rank 1 stalls between its GPU context and communicator creation (what a rank stuck in
-    ncclCommInitRank looks like from outside): bench.py's launcher ends every rank, names rank 1
-    and exits non-zero -- in seconds, not at the driver's limit"""
-    t0 = time.time()
+    ncclCommInitRank looks like from outside): bench.py's launcher ends every rank, says which
+    ranks' time ran out and what stage every rank last reported, and exits non-zero -- in seconds,
+    not at the driver's limit (the subprocess timeout is the only clock here)"""
     p = _bench(ARGS, {"NAIMA_AMD_DEVICE": "0", "NAIMA_AMD_TEST_STALL_BEFORE_COMM": "1",
                       "NAIMA_AMD_LAUNCH_COMM_TIMEOUT": "8"}, timeout=300)
     assert p.returncode == 18, (p.returncode, p.stderr[-2000:])
-    # (rank 0 waits for rank 1 inside communicator creation: both are named, as all ranks of a
-    # hanging ncclCommInitRank would be)
+    # (communicator creation is a rendezvous: rank 0 waits in it for rank 1, and whose time runs out
+    # first depends on who had its GPU context first -- the message names those AND every rank's
+    # last reported stage; the stalled rank is the one that is not past "ctx")
+    import ast
     import re
     m = re.search(r"rank\(s\) \[([0-9, ]+)\] have not passed communicator creation", p.stderr)
-    assert m and 1 in [int(v) for v in m.group(1).split(",")], p.stderr[-2000:]
+    assert m and len(m.group(1).split(",")) >= 1, p.stderr[-2000:]
+    w = re.search(r"last stage reported by every rank: (\{[^}]*\})", p.stderr)
+    assert w, p.stderr[-2000:]
+    stages = ast.literal_eval(w.group(1))
+    assert set(stages) == {0, 1} and stages[1] in ("ctx", "started") and "comm" not in stages.values(), stages
     assert p.stdout.strip() == ""
-    assert time.time() - t0 < 240  # (the watchdog's own bound; the stall itself is an hour)
 
 
 def test_run_budget_ends_a_run_that_overstays():
