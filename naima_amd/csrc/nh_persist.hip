@@ -754,7 +754,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       d[0] = t | (tile << 4);
       d[1] = s0;
       d[2] = s1;
-      d[3] = s0f | (s1f << 16);
+      // (what the item walks when a weight is not finite -- 0 x inf = NaN for the zero rows, as the
+      // reference: every row.  Rebalanced chunks keep their ranges, the tile's first one reaching
+      // down to row 0: the unbalanced ranges would reach, for the second of two workgroups that
+      // split the rows, below the nodes it formed -- ADVICE r5)
+      d[3] = R.rebalance ? ((chunk == 0 ? 0 : s0) | (s1 << 16)) : (s0f | (s1f << 16));
     }
   }
   if (R.rowsplit) {
@@ -1553,7 +1557,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
             hs_chunk_range(tb.chunks, chunk, D.seg, nG - 1, s0, s1);
             // (rows below the tile's first non-zero one contribute exact zeros: not walked; the
             // tables' trailers -- identity for a table without one -- sit in LDS for the launch)
-            if (!(nz >> (8 + tg) & 1)) {
+            {
+              const bool inf = (nz >> (8 + tg) & 1) != 0;  // (a weight that is not finite: every row counts)
               const int r0 = __builtin_amdgcn_readfirstlane(
                   reinterpret_cast<const int*>(sm + R.o_trail)[t * HS_RUN_TRAIL + tile]);
               if (R.rebalance) {
@@ -1561,11 +1566,16 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
                 // the whole grid, the chunks below a pi0 / inverse-Compton threshold are empty and
                 // the waves that drew them idle while the others finish (cfg5: the sixteen waves
                 // reached the barrier 8.9 ... 11.9 us into the slice)
+                // (a weight that is not finite: the SAME ranges, the tile's first chunk reaching down to
+                // row 0 -- 0 x inf = NaN for the zero rows, as the reference -- and not the unbalanced
+                // chunk ranges: with the rows split between two workgroups those reach, for the second
+                // one, below the nodes it formed -- ADVICE r5)
                 const int nch = HS_CHUNKS(tb.chunks);
                 const int per = (max(nG - 1 - r0, 0) + nch - 1) / nch;
                 s0 = r0 + chunk * per;
                 s1 = min(nG - 1, s0 + per);
-              } else {
+                if (inf && chunk == 0) s0 = 0;
+              } else if (!inf) {
                 s0 = max(s0, r0);
               }
             }

@@ -765,6 +765,52 @@ def test_resident_loop_equals_per_launch_loop(na, monkeypatch, name, nw, mkw):
     print("%s: resident == per-launch; bit-identical chain: %s" % (name, np.array_equal(a[0], b[0])))
 
 
+@pytest.mark.parametrize("mkw", [{"useLUT": False}, {}], ids=["analytic-zero-rows", "lut"])
+def test_rows_split_with_weights_that_are_not_finite(na, monkeypatch, mkw):
+    """cfg5 at 256 walkers -- two workgroups per walker that split the grid's ROWS -- with walkers whose
+    amplitude overflows double precision at the grid's low energies and not at its high ones (a prior
+    wide enough to let them be evaluated): 0 x inf = NaN for the table's zero rows, as in the
+    reference (utils.py:336-348), so the items walk EVERY row -- each workgroup within the nodes it
+    formed (the unbalanced chunk ranges reached, for the second workgroup, below them).
+    The resident loop against the per-launch kernel (one workgroup per walker or interleaved items:
+    every node formed by whoever walks it): the same proposals are NaN, the same are accepted, the
+    chains agree"""
+    from naima_amd.sampler import EnsembleSampler
+    name, nw = "cfg5", 256
+    model, p0, raw, data, _ = _problem(na, name, mkw)
+    nd = p0.size
+    U = na.uniform_prior
+    prior = lambda pars: (U(pars[0], 0.0, 1000.0) + U(pars[1], -3, 4) + U(pars[2], -1, 6)  # noqa: E731
+                          + U(pars[3], -1, 6) + U(pars[4], -2, 6))
+    rng = np.random.default_rng(77)
+    pos = p0 + 0.05 * p0 * rng.normal(size=(nw, nd))
+    # a quarter of the ensemble far up in log10(amplitude): finite weights (a log-probability of -inf
+    # or hugely negative, not NaN), but a stretch towards them overflows at the low-energy rows first
+    far = rng.choice(nw, nw // 4, replace=False)
+    pos[far, 0] = rng.uniform(262.0, 296.0, size=far.size)
+    kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=False,
+              nan_policy="reject")
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NAIMA_AMD_RESIDENT", mode)
+        d = EnsembleSampler(nw, nd, na.lnprob, device=True, **kw)
+        with np.errstate(all="ignore"):
+            st = d.run_mcmc(pos, 4)
+            st = d.run_mcmc(st, 60)
+        if mode == "1":
+            info = d._dev.resident_info
+            assert d._dev.resident_launches > 0 and info["rows_split"] and info["workgroups_per_walker"] == 2, info
+        runs[mode] = (d.get_chain(), d.get_log_prob(), d.acceptance_fraction, int(d.nan_proposals))
+    a, b = runs["0"], runs["1"]
+    assert a[3] > 0, "no proposal of this ensemble had a NaN log-probability: the test tests nothing"
+    assert a[3] == b[3], (a[3], b[3])
+    assert np.array_equal(np.isnan(a[1]), np.isnan(b[1])) and np.array_equal(np.isinf(a[1]), np.isinf(b[1]))
+    fin = np.isfinite(a[1])
+    assert_allclose(b[1][fin], a[1][fin], rtol=1e-9)
+    assert_allclose(b[0], a[0], rtol=1e-10)
+    assert_allclose(b[2], a[2])
+
+
 @pytest.mark.parametrize("syn2", ["1", "0"], ids=["log-domain", "direct-form"])
 def test_two_walkers_in_flight_changes_no_bit(na, monkeypatch, syn2):
     """cfg3 with 1280 walkers on 256 CUs: a workgroup takes two or three walkers of every half-step.
