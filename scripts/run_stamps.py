@@ -38,6 +38,10 @@ print(name, nw, "walkers;", dev.resident_info)
 G = min(256, dev.resident_info["grid"])
 t = buf[:G].astype(float) / 100.0  # us
 t[buf[:G] == 0] = np.nan  # (a stamp nobody wrote: phase A made AHEAD -- two walkers in flight -- leaves none)
+with np.errstate(invalid="ignore"):
+    # (... or leaves an OLDER launch's in its slot: a stamp earlier than its turn's first one)
+    stale = t[:, :, 1:] < t[:, :, :1]
+t[:, :, 1:][stale] = np.nan
 names = ["records in", "packs + barrier 1", "weights + barrier 2", "tid 0's items", "barrier 3",
          "spectra summed (barrier 4)", "record published"]
 it = np.arange(4, 60)  # (steady state)
