@@ -979,6 +979,11 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
 #undef HSR_A_AHEAD
 #undef HSR_A_NOT_YET
         }
+        {
+          // (... and the turn's priors with it: the likelihood wave is still in the previous walker's
+          // tail when that turn opens, and was the last to reach its barrier 2 by a microsecond)
+#include "nh_persist_priors.inc"
+        }
         return hsr_a_out{pval, pcol, slice_bad, 1};
       };
       // ---- two walkers in flight (round 6) ---------------------------------------------------
@@ -1035,44 +1040,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       // ---- B. priors (core.py:34-58, 99-101): a proposal the prior forbids is never accepted,
       // so none of its integrals is evaluated (the reference evaluates and discards,
       // core.py:103-119)
-      if (lik_wave) {
-        const nh_prior_pack& PR = *reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri);
-        const int npri = PR.n;
-        const bool has_prior = D.lp || npri > 0;
-        double term = 0.0;
-        if (lane < npri) {
-          const nh_prior& pt = PR.t[lane];
-          // (field by field: a 48-byte copy of the term is a stack object)
-          const double* zbase = pt.x.base;
-          const long long zstride = pt.x.stride;
-          double v = pt.x.a;
-          if (zbase) {
-            // a term on one of this walker's proposed coordinates: taken from LDS
-            const int ci = reinterpret_cast<const int*>(sm + R.o_pci)[lane];
-            const double raw = ci >= 0 ? qs[ci] : zbase[(long long)j * zstride];
-            v = hsr_lazy_apply(pt.x.a, pt.x.b, pt.x.c, pt.x.tf, raw);
-          }
-          const double p0 = pt.p0, p1 = pt.p1;
-          switch (pt.kind) {
-            case NH_PRIOR_UNIFORM: term = (p0 <= v && v <= p1) ? 0.0 : -INFINITY; break;
-            case NH_PRIOR_NORMAL: term = -0.5 * (2.0 * NH_PI * p1) - (v - p0) * (v - p0) / (2.0 * p1); break;
-            case NH_PRIOR_LOGUNIFORM: term = (v > 0.0 && v >= p0 && v <= p1) ? 1.0 / v : -INFINITY; break;
-            default: term = v; break;
-          }
-        }
-        double prior = 0.0;
-        for (int t = 0; t < npri; ++t) prior += __shfl(term, t, 64);
-        if (D.lp) prior += D.lp[j];
-        if (lane == 0) {
-          accs[3] = prior;
-          hi[HI_DEAD] = (has_prior && isinf(prior)) ? 1 : 0;
-          // (the accept's z term: off the slice's tail.  ndim - 1 through the slice's opaque thread
-          // index: as a loop invariant the converted double was hoisted out of the slice loop and
-          // spilled -- the kernel's only scratch access)
-          int nd1 = ndim - 1;
-          asm volatile("" : "+s"(nd1));  // (opaque per slice: the conversion below stays here)
-          lg[3] = (double)nd1 * hsr_log(accs[0]);
-        }
+      if (lik_wave && !(DEEP && pre_a)) {
+#include "nh_persist_priors.inc"
       }
       // ---- particle weights on every grid (-> LDS); the synchrotron liveness search ----------
       const pd_par p = {row[0], row[1], row[2], row[3], row[4], row[5], row[6]};
@@ -1756,6 +1725,8 @@ __global__ __launch_bounds__(RT > 0 ? 512 : 1024) void k_half_step_run(const hs_
       // ---- D. likelihood + priors (core.py:64-121), the accept, the record: one wave, while
       // wave 0 is already polling for the next slice and the others wait at its first barrier ----
       if (lik_wave) {
+        // (two walkers in flight: this tail runs beside the next walker's weights, 2.0 us instead of
+        // 0.9; s_setprio 3 for it changed nothing -- cfg3 / 2048 15.75 -> 15.75 M)
         const int nE = H.nE;
         const bool has_prior = D.lp || reinterpret_cast<const nh_prior_pack*>(sm + H.o_pri)->n > 0;
         const double prior = accs[3];
