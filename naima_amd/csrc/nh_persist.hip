@@ -2350,12 +2350,13 @@ static int hs_run_create(nh_ctx* c, nh_halfstep_plan* P, int rank, int nrank, nh
   // two walkers in flight (the DEEP instance): one GPU's loop whose workgroups own their CU, have
   // the walker to themselves and take more than one of a slice -- a model with a synchrotron
   // component (the 1024-thread instances; a table-only model's ensembles of that size run in small
-  // workgroups that share a CU, where the hardware overlaps them) and with table items
-  // (cfg2, synchrotron items only -- twenty of them for sixteen waves -- measured 1 % SLOWER with
-  // it at 1024 and 2048 walkers; NH_RUN_PIPELINE = 0 never | 1 | 2 also without tables)
+  // workgroups that share a CU, where the hardware overlaps them).  NH_RUN_PIPELINE=0: never.
+  // (With phase A alone made ahead cfg2 -- synchrotron items only, twenty of them for sixteen waves --
+  // measured 1 % slower and models without table items were left out; with the priors made ahead as
+  // well it gains like cfg3: cfg2 / 1024 13.61 -> 14.01 M, / 2048 14.01 -> 14.73 M.)
   Q->deep = 0;
   if (!shared && !rt && H.syn_grid >= 0 && P->split == 1 && P->threads >= 1024 && H.nloc > Q->grid &&
-      R.pipeline != 0 && (H.C.nT > 0 || R.pipeline == 2)) {
+      R.pipeline != 0) {
     const void* fd = hs_run_kernel(H.syn_grid >= 0, false, R.syn2 != 0, false, true);
     int per_cu_d = 0;
     hipError_t ed = lds > 64 * 1024 ? hipFuncSetAttribute(fd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)

@@ -811,9 +811,11 @@ def test_rows_split_with_weights_that_are_not_finite(na, monkeypatch, mkw):
     assert_allclose(b[2], a[2])
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg2"], ids=["cfg3-syn+tables", "cfg2-syn-only"])
 @pytest.mark.parametrize("syn2", ["1", "0"], ids=["log-domain", "direct-form"])
-def test_two_walkers_in_flight_changes_no_bit(na, monkeypatch, syn2):
-    """cfg3 with 1280 walkers on 256 CUs: a workgroup takes two or three walkers of every half-step.
+def test_two_walkers_in_flight_changes_no_bit(na, monkeypatch, syn2, name):
+    """cfg3 (synchrotron + three inverse-Compton tables) and cfg2 (synchrotron alone: no table items)
+    with 1280 walkers on 256 CUs: a workgroup takes two or three walkers of every half-step.
     With two of them in flight (the DEEP instance: the next walker's phase A made ahead during this
     one's work items, barrier 1 skipped, the tile waves gated on the previous likelihood having read
     its columns) the arithmetic and its order are the ones of the strictly serial turns
@@ -821,7 +823,7 @@ def test_two_walkers_in_flight_changes_no_bit(na, monkeypatch, syn2):
     synchrotron items in the log domain and in the direct form, through a block boundary and a
     tail, with and without a history"""
     from naima_amd.sampler import EnsembleSampler
-    name, nw = "cfg3", 1280
+    nw = 1280
     model, p0, raw, data, prior = _problem(na, name, {})
     nd = p0.size
     kw = dict(args=[data, model, prior], seed=BENCH_SEED, naima_style=True, store_blobs=True,
