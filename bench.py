@@ -901,6 +901,13 @@ def main():
         # one rank per GPU: the ranks' PCI bus ids are distinct, unless NAIMA_AMD_DEVICE pinned
         # them to one device on purpose (the one-GPU rehearsal)
         ids = [p_.decode() for p_ in comm.group.allgather_bytes(ctx.pci_bus_id().encode())]
+        if len(set(ids)) != len(ids) and os.environ.get("NAIMA_AMD_DEVICE") and \
+                not os.environ.get("NAIMA_AMD_CU_SHARE"):
+            # the one-GPU rehearsal under a launcher that does not know about it (bench.py's own sets
+            # this): every rank plans for its share of the device's CUs, or the ranks' resident
+            # launches cannot all be resident together and the rehearsal falls back to the last rung
+            import collections
+            os.environ["NAIMA_AMD_CU_SHARE"] = str(max(collections.Counter(ids).values()))
         if len(set(ids)) != len(ids) and not os.environ.get("NAIMA_AMD_DEVICE"):
             raise SystemExit("bench.py --gpus %d: ranks share a GPU (PCI bus ids %s) although "
                              "NAIMA_AMD_DEVICE does not pin them; LOCAL_RANK / the visible devices "
