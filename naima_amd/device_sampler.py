@@ -110,6 +110,16 @@ class DeviceLoop:
         # (a half-ensemble that does not divide evenly: the first ranks take one walker more,
         # as dist.shard_bounds says; all-gathers then travel padded to the largest block)
         self.lo, self.hi = shard_bounds(self.ns, comm.rank, comm.size)
+        if comm.size > 1 and getattr(comm, "group", None) is not None:
+            # ranks that sit on ONE device (a multi-GPU run rehearsed on a one-GPU box) each plan
+            # for their share of its CUs -- or their resident launches cannot all be resident
+            # together and the first shared launch gives up.  Who shares a device is read off the
+            # ranks' PCI bus ids (collective: every rank, always); NAIMA_AMD_CU_SHARE overrides.
+            import collections
+            ids = [p_.decode() for p_ in comm.group.allgather_bytes(self.ctx.pci_bus_id().encode())]
+            share = max(collections.Counter(ids).values())
+            if share > 1 and not os.environ.get("NAIMA_AMD_CU_SHARE"):
+                os.environ["NAIMA_AMD_CU_SHARE"] = str(share)
         self._pads = {}
         # the sharded code path (split graphs around the all-gather) even for ONE rank:
         # lets a 1-GPU box run everything but the multi-process part (tests)
