@@ -258,6 +258,7 @@ class DeviceLoop:
         # and make the journal's steps again with one launch and one all-gather per half-step
         # (the reference's Pool carries on when a worker is slow, core.py:523-536; this used to be
         # an exception on every rank)
+        self._flushed = False  # (nothing has run since the last flush: see flush)
         self._sh_snap = None
         self._sh_want = False
         self._sh_journal = []
@@ -279,6 +280,7 @@ class DeviceLoop:
             _lib._chk(_lib._lib.nh_half_step_run_counters(self.ctx.h, self._run, None, None, 1))
             self._acc_dirty, self._acc_shared = False, 0.0
         self._acc_base = 0.0
+        self._flushed = False
 
     def _eval(self, qT_buf, n):
         """run the user's model on device parameters: (total DVec, blob list)"""
@@ -643,6 +645,7 @@ class DeviceLoop:
         rng, N, ns = s._rng, self.N, self.ns
         iterations = int(iterations)
         jentry = None
+        self._flushed = False
         if self.sharded and s.comm.size > 1 and not self._replaying and self._run is not False:
             fresh = not (isinstance(initial_state, DeviceState) and initial_state._loop is self)
             if self._sh_snap is None or fresh:  # (normally kept at the verified point itself, below)
@@ -1612,6 +1615,14 @@ class DeviceLoop:
 
     def flush(self):
         """bring the pending chain history and acceptance counters to the host"""
+        if self._flushed and not self.hist and not self._pending:
+            # nothing has run since the last flush: the books are on the host already.  (With
+            # several ranks a flush is collective; the ranks run the same program, so this early
+            # return is taken by all of them or none -- and a rank that reads its results AGAIN,
+            # alone, after the others have left -- rank 0 writing the run to disk, as the
+            # reference's save_run does in its one process, analysis.py:366-471 -- is not left
+            # waiting for peers that are gone.)
+            return
         self._flush_pending()
         self.check_resident(collective=True)
         self.check_nan(collective=True)
@@ -1652,3 +1663,4 @@ class DeviceLoop:
                     self._acc_shared += np.frombuffer(p_, dtype=np.int32)
             s.naccepted += self._acc_shared
         self.keep_verified()
+        self._flushed = True
